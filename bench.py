@@ -1,0 +1,233 @@
+#!/usr/bin/env python
+"""bench.py -- the driver's benchmark contract for the 4D render-and-denoise hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = one pass of the hot path over one batch of synthetic input: rendering ONE 4D sample
+(24 frames, 800x800, 262 144 Gaussians with per-frame deltas, SH degree 2 -- BASELINE.json
+configs[1]) through the fused batched rasteriser (gvf_rast_forward_batched).  Inputs are resident in
+HBM when the timed region starts.  With N > 1 each rank renders its own sample (batch sharded over
+the GPUs, weak scaling) and the ranks exchange the finished uint8 frames with ONE all-gather per
+step (RCCL), overlapped with the next step's rendering on a side stream.
+rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import ctypes
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
+STAGES = ["preprocess", "scan", "duplicate", "sort", "ranges", "blend"]
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--gaussians", type=int, default=262_144)
+    ap.add_argument("--res", type=int, default=800)
+    ap.add_argument("--frames", type=int, default=24)
+    ap.add_argument("--sh-degree", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dit", action="store_true")
+    return ap.parse_args()
+
+
+class RasterWorkload:
+    """One 4D sample resident on the device + a preallocated workspace; step() enqueues one
+    gvf_rast_forward_batched() on the current stream (no host sync)."""
+
+    def __init__(self, dev, P, S, F, deg, seed):
+        from gvfdiffusion_amd import synthetic, _lib, rasterizer as R
+        from rast_util import camera_block
+        self._lib, self.R, self.dev = _lib, R, dev
+        self.P, self.S, self.F, self.deg, self.M = P, S, F, deg, (deg + 1) ** 2
+        self.attrs = synthetic.random_gaussians(P, sh_degree=deg, seed=seed, scale_lo=0.002, scale_hi=0.01)
+        self.gm = synthetic.gaussian_model_from(self.attrs, deg, dev)
+        self.delta_cpu = synthetic.random_deltas(F, P, seed=seed + 1)
+        self.delta = self.delta_cpu.to(dev)
+        self.cams = [camera_block(azi=15.0 * f) for f in range(F)]
+        self.frames = (_lib.GvfRastFrame * F)(*[
+            R.make_frame(c["viewmatrix"], c["projmatrix"], c["campos"], c["tanfovx"], c["tanfovy"], f)
+            for f, c in enumerate(self.cams)])
+        self.st = R.make_settings(S, S, deg, _lib.RAST_MODE_MIP, synthetic.KERNEL_2D, 1.0, synthetic.BG)
+        self.act = self.gm.activation_struct()
+        g = self.gm
+        self.raw = [t.contiguous().float() for t in (g._xyz, g.get_features, g._scaling, g._rotation, g._opacity.reshape(-1))]
+        self.color = torch.empty((F, 3, S, S), dtype=torch.float32, device=dev)
+        self.nr = torch.zeros((F,), dtype=torch.int32, device=dev)
+        # size the workspace from one synchronised call
+        out = R.rasterize_batched(self.st, list(self.frames), self.act, *self.raw, delta=self.delta)
+        self.D_frames = out["num_rendered"].to(torch.int64).cpu()
+        self.D = int(self.D_frames.sum())
+        self.cap = int(self.D * 1.02) + 4096
+        self.ws_bytes = R.workspace_bytes(P, F, S, S, self.cap)
+        R._WORKSPACES.clear()
+        del out
+        torch.cuda.empty_cache()
+        self.ws = torch.empty(self.ws_bytes + 256, dtype=torch.uint8, device=dev)
+        self.ws_base = (self.ws.data_ptr() + 255) // 256 * 256
+
+    def step(self):
+        L, p = self._lib, self._lib.ptr
+        rc = L.lib().gvf_rast_forward_batched(
+            ctypes.byref(self.st), self.frames, self.F, ctypes.byref(self.act), self.P, self.M, p(self.raw[0]),
+            p(self.raw[1]), p(self.raw[2]), p(self.raw[3]), p(self.raw[4]), p(self.delta), self.F,
+            ctypes.c_void_p(self.ws_base), self.ws_bytes, self.cap, p(self.color), None, None, None, p(self.nr),
+            L.current_stream(self.dev))
+        L.check(rc, "gvf_rast_forward_batched")
+
+    # algorithmic HBM bytes, SURVEY.md section 8d: B_alg/frame = P*P_in + D*24 + D*36 + H*W*4*3
+    def alg_bytes_frame(self):
+        p_in = 12 + 12 + 16 + 4 + 12 * self.M + 56          # xyz+scale+rot+op+sh (+ the 14-float delta row)
+        d = self.D / self.F
+        return self.P * p_in + d * 24 + d * 36 + self.S * self.S * 4 * 3
+
+    def alg_bytes_blend_launch(self):
+        # the blend launch covers all F frames: per instance 36 B of splat record + its 4 B id, plus the image
+        return self.D * (36 + 4) + self.F * self.S * self.S * 4 * 3
+
+
+def cpu_baseline(work, budget_s=12.0):
+    """The CPU oracle (kind "port": the reference has no CPU Gaussian rasteriser)
+    timed on this box's host cores on the first frames of the same sample."""
+    import oracle
+    n = lambda t: t.detach().cpu().numpy()
+    g = work.gm
+    raw = [n(t) for t in (g._xyz, g.get_features, g._scaling, g._rotation, g._opacity)]
+    from rast_util import oracle_render
+    done, t0 = 0, time.time()
+    while done < work.F:
+        oa = oracle.gaussian_activate(*raw, n(work.delta_cpu[done]), aabb=[-0.5, -0.5, -0.5, 1, 1, 1],
+                                      scale_bias=float(g.scale_bias), opacity_bias=float(g.opacity_bias),
+                                      min_kernel_size=float(g.mininum_kernel_size), scaling_activation=1)
+        attrs = {k: torch.from_numpy(oa[k]) for k in ("means3D", "scales", "rotations", "shs")}
+        attrs["opacities"] = torch.from_numpy(oa["opacities"])
+        oracle_render(oracle, attrs, work.cams[done], work.S, work.S, work.deg, mode=0)
+        done += 1
+        if time.time() - t0 > budget_s:
+            break
+    dt = time.time() - t0
+    return {"value": round(done / dt, 4), "unit": "frames/s", "cores": oracle.num_threads(), "kind": "port",
+            "sample": f"first {done} of the {work.F} frames of the same sample (activations + full render) in {dt:.1f} s; "
+                      "reference has no CPU Gaussian path (renderers/pytorch_renderer is CUDA-only Strivec)"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from gvfdiffusion_amd import _lib
+    work = RasterWorkload(dev, a.gaussians, a.res, a.frames, a.sh_degree, seed=rank)
+    F, S = a.frames, a.res
+
+    # frame exchange (N > 1): uint8 frames, one all-gather per step on a side stream
+    side = torch.cuda.Stream(device=dev) if world > 1 else None
+    u8 = [torch.empty((F, 3, S, S), dtype=torch.uint8, device=dev) for _ in range(2)] if world > 1 else None
+    gathered = [torch.empty((world, F, 3, S, S), dtype=torch.uint8, device=dev) for _ in range(2)] if world > 1 else None
+    ready = [torch.cuda.Event() for _ in range(2)] if world > 1 else None
+    consumed = [torch.cuda.Event() for _ in range(2)] if world > 1 else None
+
+    def step(i):
+        work.step()
+        if world > 1:
+            b = i & 1
+            torch.cuda.current_stream().wait_event(consumed[b])           # buffer b free again
+            u8[b].copy_((work.color.clamp(0.0, 1.0) * 255.0).to(torch.uint8))
+            ready[b].record()
+            with torch.cuda.stream(side):
+                side.wait_event(ready[b])
+                dist.all_gather_into_tensor(gathered[b], u8[b])
+                consumed[b].record(side)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if world > 1:
+        for e in consumed:
+            e.record()
+    for i in range(a.warmup):
+        step(i)
+    barrier()
+    _lib.check(_lib.lib().gvf_rast_profile_enable(1), "profile_enable")
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    ms = (ctypes.c_float * len(STAGES))()
+    calls = ctypes.c_int(0)
+    _lib.check(_lib.lib().gvf_rast_profile_read(ms, ctypes.byref(calls)), "profile_read")
+    _lib.lib().gvf_rast_profile_enable(0)
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    # overflow check after the timed region (no sync inside it)
+    assert int(work.nr.to(torch.int64).sum()) <= work.cap, "workspace overflow during the timed region"
+
+    if rank == 0:
+        ncalls = max(1, calls.value)
+        stage_ms = {s: ms[k] / ncalls for k, s in enumerate(STAGES)}
+        blend_s = stage_ms["blend"] * 1e-3
+        achieved = work.alg_bytes_blend_launch() / blend_s / 1e9 if blend_s > 0 else 0.0
+        gpu_frame_s = sum(stage_ms.values()) * 1e-3 / F
+        out = {
+            "metric": "4D frames/sec (800x800x24f, 256k Gaussians) + DiT denoise steps/sec",
+            "value": round(world * F * a.steps / dt, 2),
+            "unit": "frames/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: single-GPU HIP rasteriser, one 4D sample per step = "
+                                   f"{F} frames x {S}x{S}, {a.gaussians} Gaussians + per-frame deltas (fused "
+                                   f"activations), SH degree {a.sh_degree}, mip 2D filter, white bg",
+                       "gaussians": a.gaussians, "resolution": S, "frames_per_step": F, "sh_degree": a.sh_degree,
+                       "instances_per_frame": round(work.D / F, 1), "parallelism": f"sample-sharded x{world}"},
+            "roofline": {"bound": "hbm", "kernel": "blend_kernel (R6, one launch = all frames of the step)",
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "alg_bytes_per_launch": int(work.alg_bytes_blend_launch()),
+                         "avg_launch_ms": round(stage_ms["blend"], 4)},
+            "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
+            "pipeline_roofline": {"alg_bytes_per_frame": int(work.alg_bytes_frame()),
+                                  "achieved_GBs": round(work.alg_bytes_frame() / gpu_frame_s / 1e9, 2) if gpu_frame_s else 0,
+                                  "frac": round(work.alg_bytes_frame() / gpu_frame_s / 1e9 / HBM_PEAK_GBS, 5) if gpu_frame_s else 0},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(work)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

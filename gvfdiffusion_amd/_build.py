@@ -1,0 +1,69 @@
+"""In-tree build of the gfx950 HIP library (libgvf_hip.so).
+
+hipcc cross-compiles gfx950 code objects without a GPU, so this runs in the CPU-only build
+container; the resulting .so sits next to this file (git-ignored, but shipped to the GPU box).
+"""
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+OBJ_DIR = os.path.join(CSRC, "build")
+LIB_PATH = os.path.join(_HERE, "libgvf_hip.so")
+
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# per-source extra flags.  rast.hip: the floating-point contract shared with oracle/rast_oracle.c
+# (no implicit fma contraction; fmaf only where written).
+SOURCES = {
+    "sort.hip": [],
+    "rast.hip": ["-ffp-contract=off"],
+    "vox2seq.hip": [],
+    "attn.hip": [],
+    "gemm.hip": [],
+    "elem.hip": [],
+}
+
+
+def _hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the gfx950 HIP library cannot be built")
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hipcc = _hipcc()
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    inc = os.path.join(os.path.dirname(_HERE), "include")
+    headers += [os.path.join(inc, f) for f in os.listdir(inc)]
+    objs = []
+    for src, extra in SOURCES.items():
+        sp = os.path.join(CSRC, src)
+        if not os.path.exists(sp):
+            continue
+        obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+        if force or _stale(obj, [sp, __file__] + headers):
+            cmd = [hipcc] + COMMON + extra + ["-c", sp, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        objs.append(obj)
+    if force or _stale(LIB_PATH, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force=False, verbose=True))

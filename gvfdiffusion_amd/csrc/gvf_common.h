@@ -1,0 +1,43 @@
+// gvf_common.h -- shared host/device helpers for the gfx950 kernels (internal; the public C ABI
+// lives in include/*.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define GVF_WAVE 64
+
+#define GVF_CHECK_LAUNCH()                                   \
+    do {                                                     \
+        if (hipGetLastError() != hipSuccess) return GVF_ELAUNCH; \
+    } while (0)
+
+static inline size_t gvf_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Bump allocator over a caller-owned workspace; every carve is 256-byte aligned.
+struct GvfCarver {
+    char* base;
+    size_t off;
+    size_t cap;
+    bool ok;
+    GvfCarver(void* p, size_t bytes) : base((char*)p), off(0), cap(bytes), ok(true) {}
+    template <typename T>
+    T* take(size_t count) {
+        size_t start = gvf_align_up(off, 256);
+        size_t end = start + count * sizeof(T);
+        if (end > cap) ok = false;
+        off = end;
+        return (T*)(base ? base + start : nullptr);
+    }
+};
+
+__device__ __forceinline__ unsigned gvf_lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// Inclusive wave64 prefix sum via DPP-free shuffles.
+__device__ __forceinline__ unsigned gvf_wave_incl_scan(unsigned v, unsigned lane) {
+#pragma unroll
+    for (int d = 1; d < GVF_WAVE; d <<= 1) {
+        unsigned o = __shfl_up(v, d, GVF_WAVE);
+        if (lane >= (unsigned)d) v += o;
+    }
+    return v;
+}

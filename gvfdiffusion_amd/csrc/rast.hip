@@ -1,0 +1,786 @@
+// rast.hip -- tile-based 3D-Gaussian-splatting forward rasteriser for gfx950 (MI355X).
+//
+// Implements the C ABI of include/gvf_rast.h, i.e. the operator behind the reference's
+// GaussianRasterizer seam (renderers/gaussian_render.py:110-143,198-220) with the GaussianModel
+// delta activations (representations/gaussian/gaussian_model.py:84-114) optionally fused in front.
+// Stages follow SURVEY.md section 8a rows R1..R6 + G1; the arithmetic (operation order, fmaf
+// placement, correctly rounded div/sqrt, no contraction: this file is compiled with
+// -ffp-contract=off) is the floating-point contract stated in oracle/rast_oracle.c, so that all
+// discrete decisions (cull, radius, tile rect, sort order) match the oracle bit for bit.
+//
+// Launch structure (F frames per call, everything stream-ordered, no host sync):
+//   preprocess   grid (ceil(P/256), F)   geometry + tiles_touched + per-block sums
+//   scan_sums    1 block                 exclusive scan of the F*nb block sums, per-frame D, total D
+//   duplicate    grid (ceil(P/256), F)   (frame*tiles + tile) << 32 | depth_bits keys, Gaussian-id values
+//   radix sort   sort.hip                one sort over all frames' instances, count read on device
+//   ranges       over instances          per (frame,tile) [start,end)
+//   blend        grid (tiles, F)         16x16 px per workgroup, 4 waves = 4 strips of 16x4 px
+//
+// HBM layout (caller-owned workspace, carved below): per (frame, Gaussian) three records
+//   geomA float4 {x, y, conic_a, conic_b}, geomB float4 {conic_c, opacity, r, g}, geomC float2 {b, depth}
+// (40 B fetched per (splat,tile) instance by the blend), tiles_touched u32; per instance u64 key +
+// u32 id, double-buffered for the sort.
+#include "gvf_common.h"
+#include "gvf_sort.h"
+#include "../../include/gvf_rast.h"
+
+namespace {
+
+constexpr int PRE_THREADS = 256;
+constexpr int TILE = GVF_TILE;
+constexpr int BLEND_THREADS = TILE * TILE;
+constexpr int MAX_SH_COEFFS = 16;
+
+__constant__ float SH_C0 = 0.28209479177387814f;
+__constant__ float SH_C1 = 0.4886025119029199f;
+__constant__ float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                               -1.0925484305920792f, 0.5462742152960396f};
+__constant__ float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                               0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                               -0.5900435899266435f};
+
+struct PreParams {
+    int P, M, deg, H, W, mode;
+    int gx, gy;           // tile grid
+    float kernel_size, scale_modifier;
+    // fused activation (raw GaussianModel parameters) -- used when fused != 0
+    int fused;
+    GvfGaussianActivation act;
+    int n_delta;
+};
+
+// ---------------------------------------------------------------------------------------------
+// G1: GaussianModel activations (gaussian_model.py:84-114); delta layout [xyz3|scale3|rot4|rgb3|op1]
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float act_scale(float x, const GvfGaussianActivation& a) {
+    float s = a.scaling_activation == 0 ? expf(x) : (x > 20.0f ? x : log1pf(expf(x)));
+    return sqrtf(s * s + a.min_kernel_size * a.min_kernel_size);
+}
+
+struct ActGaussian {
+    float p[3], s[3], q[4], op, drgb[3];
+};
+
+__device__ __forceinline__ ActGaussian activate_one(int i, const GvfGaussianActivation& a,
+                                                    const float* __restrict__ xyz_raw,
+                                                    const float* __restrict__ scaling_raw,
+                                                    const float* __restrict__ rotation_raw,
+                                                    const float* __restrict__ opacity_raw,
+                                                    const float* __restrict__ d /* delta row or null */) {
+    ActGaussian g;
+    float dl[14];
+#pragma unroll
+    for (int k = 0; k < 14; ++k) dl[k] = d ? d[k] : 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float v = xyz_raw[3 * (size_t)i + k] * a.aabb[3 + k] + a.aabb[k];
+        g.p[k] = d ? v + dl[k] : v;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float x = scaling_raw[3 * (size_t)i + k] + a.scale_bias;
+        if (d) x = x + dl[3 + k];
+        g.s[k] = act_scale(x, a);
+    }
+    float q[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        q[k] = rotation_raw[4 * (size_t)i + k] + (k == 0 ? 1.0f : 0.0f);
+        if (d) q[k] = q[k] + dl[6 + k];
+    }
+    float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    n = fmaxf(n, 1e-12f);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) g.q[k] = q[k] / n;
+    float x = opacity_raw[i] + a.opacity_bias;
+    if (d) x = x + dl[13];
+    g.op = 1.0f / (1.0f + expf(-x));
+    g.drgb[0] = dl[10]; g.drgb[1] = dl[11]; g.drgb[2] = dl[12];
+    return g;
+}
+
+__global__ __launch_bounds__(256) void activate_kernel(GvfGaussianActivation a, int P, int M,
+                                                       const float* __restrict__ xyz_raw,
+                                                       const float* __restrict__ features_dc,
+                                                       const float* __restrict__ scaling_raw,
+                                                       const float* __restrict__ rotation_raw,
+                                                       const float* __restrict__ opacity_raw,
+                                                       const float* __restrict__ delta, float* __restrict__ means3D,
+                                                       float* __restrict__ scales, float* __restrict__ rotations,
+                                                       float* __restrict__ shs, float* __restrict__ opacities) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const float* d = delta ? delta + 14 * (size_t)i : nullptr;
+    ActGaussian g = activate_one(i, a, xyz_raw, scaling_raw, rotation_raw, opacity_raw, d);
+    for (int k = 0; k < 3; ++k) { means3D[3 * (size_t)i + k] = g.p[k]; scales[3 * (size_t)i + k] = g.s[k]; }
+    for (int k = 0; k < 4; ++k) rotations[4 * (size_t)i + k] = g.q[k];
+    opacities[i] = g.op;
+    for (int m = 0; m < M; ++m)
+        for (int c = 0; c < 3; ++c) {
+            float v = features_dc[((size_t)i * M + m) * 3 + c];
+            shs[((size_t)i * M + m) * 3 + c] = d ? v + g.drgb[c] : v;
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// R1: preprocess
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void xform43(const float* m, const float* p, float* o) {
+    o[0] = m[0] * p[0] + m[4] * p[1] + m[8] * p[2] + m[12];
+    o[1] = m[1] * p[0] + m[5] * p[1] + m[9] * p[2] + m[13];
+    o[2] = m[2] * p[0] + m[6] * p[1] + m[10] * p[2] + m[14];
+}
+__device__ __forceinline__ void xform44(const float* m, const float* p, float* o) {
+    o[0] = m[0] * p[0] + m[4] * p[1] + m[8] * p[2] + m[12];
+    o[1] = m[1] * p[0] + m[5] * p[1] + m[9] * p[2] + m[13];
+    o[2] = m[2] * p[0] + m[6] * p[1] + m[10] * p[2] + m[14];
+    o[3] = m[3] * p[0] + m[7] * p[1] + m[11] * p[2] + m[15];
+}
+
+__device__ __forceinline__ void cov3d_from_scale_rot(const float* s, float mod, const float* q, float* c6) {
+    float sx = mod * s[0], sy = mod * s[1], sz = mod * s[2];
+    float r = q[0], x = q[1], y = q[2], z = q[3];
+    float R00 = 1.f - 2.f * (y * y + z * z), R01 = 2.f * (x * y - r * z), R02 = 2.f * (x * z + r * y);
+    float R10 = 2.f * (x * y + r * z), R11 = 1.f - 2.f * (x * x + z * z), R12 = 2.f * (y * z - r * x);
+    float R20 = 2.f * (x * z - r * y), R21 = 2.f * (y * z + r * x), R22 = 1.f - 2.f * (x * x + y * y);
+    float L00 = R00 * sx, L01 = R01 * sy, L02 = R02 * sz;
+    float L10 = R10 * sx, L11 = R11 * sy, L12 = R12 * sz;
+    float L20 = R20 * sx, L21 = R21 * sy, L22 = R22 * sz;
+    c6[0] = L00 * L00 + L01 * L01 + L02 * L02;
+    c6[1] = L00 * L10 + L01 * L11 + L02 * L12;
+    c6[2] = L00 * L20 + L01 * L21 + L02 * L22;
+    c6[3] = L10 * L10 + L11 * L11 + L12 * L12;
+    c6[4] = L10 * L20 + L11 * L21 + L12 * L22;
+    c6[5] = L20 * L20 + L21 * L21 + L22 * L22;
+}
+
+// sh: this Gaussian's coefficients in LDS, [M][3]; dadd: rgb delta added to every coefficient
+__device__ __forceinline__ void sh_to_rgb(int deg, const float* sh, const float* dadd, const float* p,
+                                          const float* cam, float* rgb) {
+    float dx = p[0] - cam[0], dy = p[1] - cam[1], dz = p[2] - cam[2];
+    float len = sqrtf(dx * dx + dy * dy + dz * dz);
+    float x = dx / len, y = dy / len, z = dz / len;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float da = dadd[c];
+        float res = SH_C0 * (sh[0 * 3 + c] + da);
+        if (deg > 0) {
+            res = res - SH_C1 * y * (sh[1 * 3 + c] + da) + SH_C1 * z * (sh[2 * 3 + c] + da) -
+                  SH_C1 * x * (sh[3 * 3 + c] + da);
+            if (deg > 1) {
+                float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                res = res + SH_C2[0] * xy * (sh[4 * 3 + c] + da) + SH_C2[1] * yz * (sh[5 * 3 + c] + da) +
+                      SH_C2[2] * (2.0f * zz - xx - yy) * (sh[6 * 3 + c] + da) +
+                      SH_C2[3] * xz * (sh[7 * 3 + c] + da) + SH_C2[4] * (xx - yy) * (sh[8 * 3 + c] + da);
+                if (deg > 2) {
+                    res = res + SH_C3[0] * y * (3.0f * xx - yy) * (sh[9 * 3 + c] + da) +
+                          SH_C3[1] * xy * z * (sh[10 * 3 + c] + da) +
+                          SH_C3[2] * y * (4.0f * zz - xx - yy) * (sh[11 * 3 + c] + da) +
+                          SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * (sh[12 * 3 + c] + da) +
+                          SH_C3[4] * x * (4.0f * zz - xx - yy) * (sh[13 * 3 + c] + da) +
+                          SH_C3[5] * z * (xx - yy) * (sh[14 * 3 + c] + da) +
+                          SH_C3[6] * x * (xx - 3.0f * yy) * (sh[15 * 3 + c] + da);
+                }
+            }
+        }
+        res += 0.5f;
+        rgb[c] = res < 0.f ? 0.f : res;
+    }
+}
+
+struct TileRect { int x0, y0, x1, y1; };
+__device__ __forceinline__ TileRect get_rect(float px, float py, float radius, int gx, int gy) {
+    TileRect r;
+    r.x0 = min(gx, max(0, (int)((px - radius) / (float)TILE)));
+    r.y0 = min(gy, max(0, (int)((py - radius) / (float)TILE)));
+    r.x1 = min(gx, max(0, (int)((px + radius + (float)(TILE - 1)) / (float)TILE)));
+    r.y1 = min(gy, max(0, (int)((py + radius + (float)(TILE - 1)) / (float)TILE)));
+    return r;
+}
+
+// Inputs are either activated tensors (fused == 0: a0=means3D, a1=scales, a2=rotations, a3=opacities,
+// sh=shs/colors) or raw GaussianModel parameters (fused != 0: a0=_xyz, a1=_scaling, a2=_rotation,
+// a3=_opacity, sh=_features_dc, delta[n_delta][P][14]).
+__global__ __launch_bounds__(PRE_THREADS) void preprocess_kernel(
+    PreParams pp, const GvfRastFrame* __restrict__ frames, const float* __restrict__ a0,
+    const float* __restrict__ a1, const float* __restrict__ a2, const float* __restrict__ a3,
+    const float* __restrict__ sh, const float* __restrict__ colors_precomp,
+    const float* __restrict__ cov3D_precomp, const float* __restrict__ delta, float4* __restrict__ geomA,
+    float4* __restrict__ geomB, float2* __restrict__ geomC, uint32_t* __restrict__ tiles_touched,
+    int32_t* __restrict__ radii, uint32_t* __restrict__ block_sums) {
+    extern __shared__ __attribute__((aligned(16))) float sh_lds[];  // [PRE_THREADS][M*3] + 4 wave sums
+    const int t = threadIdx.x;
+    const int f = blockIdx.y;
+    const int P = pp.P, M = pp.M;
+    const int i = blockIdx.x * PRE_THREADS + t;
+    const GvfRastFrame* fr = frames + f;
+
+    // Stage this block's SH coefficients through LDS with coalesced 16-byte loads: 256 Gaussians x
+    // M*3 floats are one contiguous span of the [P][M][3] tensor.
+    const int sh_stride = M * 3;
+    if (sh != nullptr) {
+        const size_t span0 = (size_t)blockIdx.x * PRE_THREADS * sh_stride;
+        const int nvalid = min(PRE_THREADS, P - blockIdx.x * PRE_THREADS);
+        const int total = nvalid * sh_stride;
+        const float4* src4 = reinterpret_cast<const float4*>(sh + span0);  // span0*4 B is 16-B aligned
+        float4* dst4 = reinterpret_cast<float4*>(sh_lds);
+        const int n4 = total >> 2;
+        for (int k = t; k < n4; k += PRE_THREADS) dst4[k] = src4[k];
+        for (int k = (n4 << 2) + t; k < total; k += PRE_THREADS) sh_lds[k] = sh[span0 + k];
+    }
+    __syncthreads();
+
+    uint32_t touched = 0;
+    int radius_out = 0;
+    float4 gA = make_float4(0.f, 0.f, 0.f, 0.f), gB = gA;
+    float2 gC = make_float2(0.f, 0.f);
+
+    if (i < P) {
+        float p[3], s[3], q[4], op, dadd[3] = {0.f, 0.f, 0.f};
+        if (pp.fused) {
+            const int di = fr->delta_index;
+            const float* d = (delta != nullptr && di >= 0) ? delta + ((size_t)di * P + i) * 14 : nullptr;
+            ActGaussian g = activate_one(i, pp.act, a0, a1, a2, a3, d);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { p[k] = g.p[k]; s[k] = g.s[k]; dadd[k] = g.drgb[k]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[k] = g.q[k];
+            op = g.op;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) p[k] = a0[3 * (size_t)i + k];
+            if (cov3D_precomp == nullptr) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) s[k] = a1[3 * (size_t)i + k];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) q[k] = a2[4 * (size_t)i + k];
+            }
+            op = a3[i];
+        }
+
+        float pv[3];
+        xform43(fr->viewmatrix, p, pv);
+        bool vis = pv[2] > 0.2f;
+        if (vis) {
+            float ph[4];
+            xform44(fr->projmatrix, p, ph);
+            float pw = 1.0f / (ph[3] + 0.0000001f);
+            float projx = ph[0] * pw, projy = ph[1] * pw;
+
+            float c6[6];
+            if (!pp.fused && cov3D_precomp != nullptr) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) c6[k] = cov3D_precomp[6 * (size_t)i + k];
+            } else {
+                cov3d_from_scale_rot(s, pp.scale_modifier, q, c6);
+            }
+
+            const float tanfovx = fr->tanfovx, tanfovy = fr->tanfovy;
+            float focal_x = (float)pp.W / (2.0f * tanfovx);
+            float focal_y = (float)pp.H / (2.0f * tanfovy);
+            float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
+            float txtz = pv[0] / pv[2], tytz = pv[1] / pv[2];
+            float tx = fminf(limx, fmaxf(-limx, txtz)) * pv[2];
+            float ty = fminf(limy, fmaxf(-limy, tytz)) * pv[2];
+            float tz = pv[2];
+            float J00 = focal_x / tz, J02 = -(focal_x * tx) / (tz * tz);
+            float J11 = focal_y / tz, J12 = -(focal_y * ty) / (tz * tz);
+            float A0[3], A1[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float w0 = fr->viewmatrix[c * 4 + 0], w1 = fr->viewmatrix[c * 4 + 1], w2 = fr->viewmatrix[c * 4 + 2];
+                A0[c] = J00 * w0 + J02 * w2;
+                A1[c] = J11 * w1 + J12 * w2;
+            }
+            float S[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+            float B0[3], B1[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                B0[c] = A0[0] * S[0][c] + A0[1] * S[1][c] + A0[2] * S[2][c];
+                B1[c] = A1[0] * S[0][c] + A1[1] * S[1][c] + A1[2] * S[2][c];
+            }
+            float cxx = B0[0] * A0[0] + B0[1] * A0[1] + B0[2] * A0[2];
+            float cxy = B0[0] * A1[0] + B0[1] * A1[1] + B0[2] * A1[2];
+            float cyy = B1[0] * A1[0] + B1[1] * A1[1] + B1[2] * A1[2];
+
+            float coef = 1.0f;
+            if (pp.mode == GVF_RAST_MODE_MIP) {
+                float det0 = fmaxf(1e-6f, cxx * cyy - cxy * cxy);
+                float det1 = fmaxf(1e-6f, (cxx + pp.kernel_size) * (cyy + pp.kernel_size) - cxy * cxy);
+                coef = sqrtf(det0 / (det1 + 1e-6f) + 1e-6f);
+                if (det0 <= 1e-6f || det1 <= 1e-6f) coef = 0.0f;
+                cxx += pp.kernel_size;
+                cyy += pp.kernel_size;
+            } else {
+                cxx += 0.3f;
+                cyy += 0.3f;
+            }
+            float det = cxx * cyy - cxy * cxy;
+            if (det != 0.0f) {
+                float det_inv = 1.f / det;
+                float ca = cyy * det_inv, cb = -cxy * det_inv, cc = cxx * det_inv;
+                float mid = 0.5f * (cxx + cyy);
+                float lam1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+                float lam2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+                float my_radius = ceilf(3.f * sqrtf(fmaxf(lam1, lam2)));
+                float px = ((projx + 1.0f) * (float)pp.W - 1.0f) * 0.5f;
+                float py = ((projy + 1.0f) * (float)pp.H - 1.0f) * 0.5f;
+                TileRect r = get_rect(px, py, my_radius, pp.gx, pp.gy);
+                uint32_t cnt = (uint32_t)((r.x1 - r.x0) * (r.y1 - r.y0));
+                if (cnt != 0) {
+                    float rgb[3];
+                    if (colors_precomp != nullptr) {
+                        rgb[0] = colors_precomp[3 * (size_t)i + 0];
+                        rgb[1] = colors_precomp[3 * (size_t)i + 1];
+                        rgb[2] = colors_precomp[3 * (size_t)i + 2];
+                    } else {
+                        sh_to_rgb(pp.deg, sh_lds + t * sh_stride, dadd, p, fr->campos, rgb);
+                    }
+                    touched = cnt;
+                    radius_out = (int)my_radius;
+                    gA = make_float4(px, py, ca, cb);
+                    gB = make_float4(cc, op * coef, rgb[0], rgb[1]);
+                    gC = make_float2(rgb[2], pv[2]);
+                }
+            }
+        }
+        const size_t o = (size_t)f * P + i;
+        geomA[o] = gA; geomB[o] = gB; geomC[o] = gC;
+        tiles_touched[o] = touched;
+        if (radii != nullptr) radii[o] = radius_out;
+    }
+
+    // block sum of tiles_touched (feeds the instance-offset scan, R2)
+    const unsigned lane = t & 63, w = t >> 6;
+    uint32_t incl = gvf_wave_incl_scan(touched, lane);
+    __shared__ uint32_t wsum[PRE_THREADS / GVF_WAVE];
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    if (t == 0) block_sums[(size_t)f * gridDim.x + blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// ---------------------------------------------------------------------------------------------
+// R2: exclusive scan of the F*nb block sums (single workgroup), per-frame counts and grand total
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void scan_sums_kernel(uint32_t* __restrict__ block_sums, int nb, int F,
+                                                         uint32_t* __restrict__ frame_base /*[F+1]*/,
+                                                         uint32_t* __restrict__ num_rendered /*[F]*/,
+                                                         uint32_t* __restrict__ total_out, uint32_t max_rendered) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry_s;
+    const int t = threadIdx.x;
+    const unsigned lane = t & 63, w = t >> 6;
+    const int n = nb * F;
+    if (t == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        int j = base + t;
+        uint32_t v = j < n ? block_sums[j] : 0u;
+        uint32_t incl = gvf_wave_incl_scan(v, lane);
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        uint32_t wbase = 0, tot = 0;
+        for (unsigned k = 0; k < 16; ++k) { if (k < w) wbase += wsum[k]; tot += wsum[k]; }
+        uint32_t carry = carry_s;
+        uint32_t excl = carry + wbase + incl - v;
+        if (j < n) {
+            block_sums[j] = excl;
+            if (j % nb == 0) frame_base[j / nb] = excl;
+        }
+        __syncthreads();
+        if (t == 0) carry_s = carry + tot;
+        __syncthreads();
+    }
+    // Overflow (D > workspace capacity): render nothing (n = 0) but still report the true counts, so
+    // the caller can detect it from num_rendered and retry with a larger workspace.
+    if (t == 0) { frame_base[F] = carry_s; *total_out = carry_s > max_rendered ? 0u : carry_s; }
+    __syncthreads();
+    for (int f = t; f < F; f += 1024) num_rendered[f] = frame_base[f + 1] - frame_base[f];
+}
+
+// ---------------------------------------------------------------------------------------------
+// R3: duplicate with keys
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PRE_THREADS) void duplicate_kernel(
+    int P, int gx, int gy, const float4* __restrict__ geomA, const float2* __restrict__ geomC,
+    const uint32_t* __restrict__ tiles_touched, const int32_t* __restrict__ radii_ws,
+    const uint32_t* __restrict__ block_base, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
+    uint32_t max_rendered) {
+    __shared__ uint32_t wsum[PRE_THREADS / GVF_WAVE];
+    const int t = threadIdx.x, f = blockIdx.y;
+    const int i = blockIdx.x * PRE_THREADS + t;
+    const unsigned lane = t & 63, w = t >> 6;
+    const size_t o = (size_t)f * P + i;
+    uint32_t touched = i < P ? tiles_touched[o] : 0u;
+    uint32_t incl = gvf_wave_incl_scan(touched, lane);
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (unsigned k = 0; k < w; ++k) wbase += wsum[k];
+    uint32_t off = block_base[(size_t)f * gridDim.x + blockIdx.x] + wbase + incl - touched;
+    if (touched == 0) return;
+    if ((uint64_t)off + touched > (uint64_t)max_rendered) return;  // overflow: caller checks num_rendered
+    float4 a = geomA[o];
+    float depth = geomC[o].y;
+    TileRect r = get_rect(a.x, a.y, (float)radii_ws[o], gx, gy);
+    const uint64_t tile0 = (uint64_t)f * (uint32_t)(gx * gy);
+    const uint32_t dbits = __float_as_uint(depth);
+    for (int y = r.y0; y < r.y1; ++y)
+        for (int x = r.x0; x < r.x1; ++x) {
+            uint64_t key = ((tile0 + (uint32_t)(y * gx + x)) << 32) | dbits;
+            keys[off] = key;
+            vals[off] = (uint32_t)i;
+            ++off;
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// R5: tile ranges
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ranges_kernel(const uint64_t* __restrict__ keys,
+                                                     const uint32_t* __restrict__ n_ptr, uint32_t n_cap,
+                                                     uint2* __restrict__ ranges, uint32_t n_ranges) {
+    uint32_t n = *n_ptr;
+    n = n < n_cap ? n : n_cap;
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        uint32_t cur = (uint32_t)(keys[k] >> 32);
+        if (cur >= n_ranges) continue;
+        if (k == 0) ranges[cur].x = 0;
+        else {
+            uint32_t prev = (uint32_t)(keys[k - 1] >> 32);
+            if (cur != prev) { if (prev < n_ranges) ranges[prev].y = k; ranges[cur].x = k; }
+        }
+        if (k == n - 1) ranges[cur].y = n;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// R6: blend
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
+    int P, int H, int W, int gx, int gy, float bg0, float bg1, float bg2, const uint2* __restrict__ ranges,
+    const uint32_t* __restrict__ point_list, const float4* __restrict__ geomA, const float4* __restrict__ geomB,
+    const float2* __restrict__ geomC, const float* __restrict__ subpixel_offset, float* __restrict__ out_color,
+    float* __restrict__ out_alpha, float* __restrict__ out_depth) {
+    __shared__ float4 sA[BLEND_THREADS];
+    __shared__ float4 sB[BLEND_THREADS];
+    __shared__ float2 sC[BLEND_THREADS];
+
+    const int t = threadIdx.x;
+    const int f = blockIdx.y;
+    const int tile = blockIdx.x;
+    const int tx = tile % gx, ty = tile / gx;
+    const int px = tx * TILE + (t & (TILE - 1)), py = ty * TILE + (t >> 4);
+    const bool inside = px < W && py < H;
+    const size_t pid = (size_t)py * W + px;
+    float pxf = (float)px, pyf = (float)py;
+    if (subpixel_offset != nullptr && inside) { pxf += subpixel_offset[2 * pid]; pyf += subpixel_offset[2 * pid + 1]; }
+
+    const uint2 rng = ranges[(size_t)f * gx * gy + tile];
+    const size_t gbase = (size_t)f * P;
+    const int rounds = (int)((rng.y - rng.x + BLEND_THREADS - 1) / BLEND_THREADS);
+    int todo = (int)(rng.y - rng.x);
+
+    bool done = !inside;
+    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dacc = 0.f;
+
+    for (int r = 0; r < rounds; ++r, todo -= BLEND_THREADS) {
+        if (__syncthreads_count(done) == BLEND_THREADS) break;
+        if (t < todo) {
+            uint32_t id = point_list[rng.x + (uint32_t)r * BLEND_THREADS + t];
+            sA[t] = geomA[gbase + id];
+            sB[t] = geomB[gbase + id];
+            sC[t] = geomC[gbase + id];
+        }
+        __syncthreads();
+        const int cnt = min(BLEND_THREADS, todo);
+        for (int j = 0; !done && j < cnt; ++j) {
+            const float4 a = sA[j];
+            const float4 b = sB[j];
+            float dx = a.x - pxf, dy = a.y - pyf;
+            float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+            if (power > 0.0f) continue;
+            float alpha = fminf(0.99f, b.y * __expf(power));
+            if (alpha < 1.0f / 255.0f) continue;
+            float test_T = T * (1.f - alpha);
+            if (test_T < 0.0001f) { done = true; continue; }
+            const float2 c = sC[j];
+            float wgt = alpha * T;
+            C0 = __builtin_fmaf(b.z, wgt, C0);
+            C1 = __builtin_fmaf(b.w, wgt, C1);
+            C2 = __builtin_fmaf(c.x, wgt, C2);
+            Dacc = __builtin_fmaf(c.y, wgt, Dacc);
+            T = test_T;
+        }
+    }
+    if (inside) {
+        const size_t hw = (size_t)H * W;
+        float* oc = out_color + (size_t)f * 3 * hw;
+        oc[0 * hw + pid] = __builtin_fmaf(T, bg0, C0);
+        oc[1 * hw + pid] = __builtin_fmaf(T, bg1, C1);
+        oc[2 * hw + pid] = __builtin_fmaf(T, bg2, C2);
+        if (out_alpha != nullptr) out_alpha[(size_t)f * hw + pid] = 1.0f - T;
+        if (out_depth != nullptr) out_depth[(size_t)f * hw + pid] = Dacc;
+    }
+}
+
+// Camera blocks travel as kernel arguments (16 per launch): no host buffer has to outlive the call
+// and the upload is capturable in a hipGraph.
+struct FrameChunk { GvfRastFrame f[16]; };
+__global__ void upload_frames_kernel(FrameChunk c, int count, GvfRastFrame* __restrict__ dst) {
+    const int words = (int)(sizeof(GvfRastFrame) / 4) * count;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&c);
+    for (int k = threadIdx.x; k < words; k += blockDim.x) reinterpret_cast<uint32_t*>(dst)[k] = src[k];
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+// Opt-in stage timing (HIP events on the caller's stream), used by bench.py for the roofline figure.
+// The only process-global state in this library; off by default.
+constexpr int PROF_MAX_CALLS = 256;
+constexpr int PROF_EVENTS = GVF_RAST_NSTAGES + 1;
+struct Profiler {
+    bool on = false;
+    int calls = 0;
+    hipEvent_t ev[PROF_MAX_CALLS][PROF_EVENTS];
+};
+Profiler g_prof;
+inline void prof_mark(hipStream_t s, int slot, int k) {
+    if (slot >= 0) hipEventRecord(g_prof.ev[slot][k], s);
+}
+
+struct Workspace {
+    GvfRastFrame* frames;
+    float4* geomA; float4* geomB; float2* geomC;
+    uint32_t* tiles_touched; int32_t* radii;
+    uint32_t* block_sums; uint32_t* frame_base; uint32_t* total;
+    uint64_t* keys; uint64_t* keys_alt; uint32_t* vals; uint32_t* vals_alt;
+    uint2* ranges;
+    void* sort_tmp; size_t sort_tmp_bytes;
+    size_t bytes; bool ok;
+};
+
+int key_end_bit(int F, int ntiles) {
+    uint64_t m = (uint64_t)F * (uint64_t)ntiles;
+    int bits = 0;
+    while (((uint64_t)1 << bits) < m) ++bits;
+    return 32 + bits;
+}
+
+Workspace carve(void* ws, size_t bytes, int P, int F, int H, int W, int64_t max_rendered) {
+    Workspace w;
+    GvfCarver c(ws, bytes);
+    const int nb = (P + PRE_THREADS - 1) / PRE_THREADS;
+    const int ntiles = ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+    const size_t FP = (size_t)F * (size_t)(P > 0 ? P : 1);
+    const size_t D = (size_t)(max_rendered > 0 ? max_rendered : 1);
+    w.frames = c.take<GvfRastFrame>(F);
+    w.geomA = c.take<float4>(FP);
+    w.geomB = c.take<float4>(FP);
+    w.geomC = c.take<float2>(FP);
+    w.tiles_touched = c.take<uint32_t>(FP);
+    w.radii = c.take<int32_t>(FP);
+    w.block_sums = c.take<uint32_t>((size_t)F * (nb > 0 ? nb : 1));
+    w.frame_base = c.take<uint32_t>(F + 1);
+    w.total = c.take<uint32_t>(1);
+    w.keys = c.take<uint64_t>(D);
+    w.keys_alt = c.take<uint64_t>(D);
+    w.vals = c.take<uint32_t>(D);
+    w.vals_alt = c.take<uint32_t>(D);
+    w.ranges = c.take<uint2>((size_t)F * ntiles);
+    w.sort_tmp_bytes = gvf_sort_tmp_bytes((int64_t)D);
+    w.sort_tmp = c.take<char>(w.sort_tmp_bytes);
+    w.bytes = gvf_align_up(c.off, 256);
+    w.ok = c.ok;
+    return w;
+}
+
+int run_pipeline(const GvfRastSettings& st, const GvfRastFrame* frames_host, int F, int P, int M, bool fused,
+                 const GvfGaussianActivation* act, const float* a0, const float* a1, const float* a2,
+                 const float* a3, const float* sh, const float* colors_precomp, const float* cov3D_precomp,
+                 const float* delta, int n_delta, const float* subpixel_offset, void* workspace,
+                 size_t workspace_bytes, int64_t max_rendered, float* out_color, float* out_alpha,
+                 float* out_depth, int32_t* out_radii, uint32_t* out_num_rendered, hipStream_t stream) {
+    const int H = st.image_height, W = st.image_width;
+    if (H <= 0 || W <= 0 || P < 0 || F <= 0 || max_rendered < 0 || max_rendered > 0xFFFFFFFFll) return GVF_EINVAL;
+    if (st.sh_degree < 0 || st.sh_degree > 3) return GVF_EINVAL;
+    if (st.mode != GVF_RAST_MODE_MIP && st.mode != GVF_RAST_MODE_DILATE) return GVF_EINVAL;
+    if (!out_color || !out_num_rendered || !frames_host || !workspace) return GVF_EINVAL;
+    if (colors_precomp == nullptr) {
+        if (sh == nullptr || M < (st.sh_degree + 1) * (st.sh_degree + 1) || M > MAX_SH_COEFFS) return GVF_EINVAL;
+    }
+    if ((((uintptr_t)sh) & 15) != 0 || (((uintptr_t)workspace) & 255) != 0) return GVF_EINVAL;  // 16-B SH rows, 256-B workspace
+    Workspace w = carve(workspace, workspace_bytes, P, F, H, W, max_rendered);
+    if (!w.ok) return GVF_ENOSPC;
+
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE, ntiles = gx * gy;
+    const int nb = (P + PRE_THREADS - 1) / PRE_THREADS;
+    const int slot = (g_prof.on && g_prof.calls < PROF_MAX_CALLS) ? g_prof.calls++ : -1;
+
+    for (int f0 = 0; f0 < F; f0 += 16) {
+        FrameChunk ch;
+        const int cnt = F - f0 < 16 ? F - f0 : 16;
+        for (int k = 0; k < cnt; ++k) ch.f[k] = frames_host[f0 + k];
+        hipLaunchKernelGGL(upload_frames_kernel, dim3(1), dim3(256), 0, stream, ch, cnt, w.frames + f0);
+    }
+    GVF_CHECK_LAUNCH();
+    if (hipMemsetAsync(w.ranges, 0, sizeof(uint2) * (size_t)F * ntiles, stream) != hipSuccess) return GVF_ELAUNCH;
+
+    if (P == 0 || nb == 0) {
+        // nothing to splat: background only
+        if (hipMemsetAsync(out_num_rendered, 0, sizeof(uint32_t) * F, stream) != hipSuccess) return GVF_ELAUNCH;
+        if (hipMemsetAsync(w.total, 0, sizeof(uint32_t), stream) != hipSuccess) return GVF_ELAUNCH;
+    } else {
+        prof_mark(stream, slot, 0);
+        PreParams pp;
+        pp.P = P; pp.M = colors_precomp ? 0 : M; pp.deg = st.sh_degree; pp.H = H; pp.W = W; pp.mode = st.mode;
+        pp.gx = gx; pp.gy = gy; pp.kernel_size = st.kernel_size; pp.scale_modifier = st.scale_modifier;
+        pp.fused = fused ? 1 : 0; pp.n_delta = n_delta;
+        if (fused) pp.act = *act; else pp.act = GvfGaussianActivation{};
+        const size_t sh_lds_bytes = gvf_align_up((size_t)PRE_THREADS * pp.M * 3 * sizeof(float), 16) + 16;
+        hipLaunchKernelGGL(preprocess_kernel, dim3(nb, F), dim3(PRE_THREADS), sh_lds_bytes, stream, pp, w.frames, a0,
+                           a1, a2, a3, colors_precomp ? nullptr : sh, colors_precomp, cov3D_precomp, delta, w.geomA,
+                           w.geomB, w.geomC, w.tiles_touched, w.radii, w.block_sums);
+        GVF_CHECK_LAUNCH();
+        prof_mark(stream, slot, 1);
+        hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, stream, w.block_sums, nb, F, w.frame_base,
+                           out_num_rendered, w.total, (uint32_t)max_rendered);
+        GVF_CHECK_LAUNCH();
+        prof_mark(stream, slot, 2);
+        if (max_rendered > 0) {
+            hipLaunchKernelGGL(duplicate_kernel, dim3(nb, F), dim3(PRE_THREADS), 0, stream, P, gx, gy, w.geomA, w.geomC,
+                               w.tiles_touched, w.radii, w.block_sums, w.keys, w.vals, (uint32_t)max_rendered);
+            GVF_CHECK_LAUNCH();
+        }
+        if (out_radii != nullptr) {
+            if (hipMemcpyAsync(out_radii, w.radii, sizeof(int32_t) * (size_t)F * P, hipMemcpyDeviceToDevice, stream) != hipSuccess)
+                return GVF_ELAUNCH;
+        }
+    }
+
+    uint64_t* keys_sorted = w.keys;
+    uint32_t* vals_sorted = w.vals;
+    if (P > 0 && max_rendered > 0) {
+        prof_mark(stream, slot, 3);
+        int in_alt = 0;
+        int rc = gvf_sort_pairs_device_n(w.keys, w.keys_alt, w.vals, w.vals_alt, w.total, max_rendered,
+                                         key_end_bit(F, ntiles), w.sort_tmp, w.sort_tmp_bytes, stream, &in_alt);
+        if (rc != GVF_OK) return rc;
+        if (in_alt) { keys_sorted = w.keys_alt; vals_sorted = w.vals_alt; }
+        prof_mark(stream, slot, 4);
+        int rblocks = (int)((max_rendered + 255) / 256);
+        if (rblocks > 4096) rblocks = 4096;
+        hipLaunchKernelGGL(ranges_kernel, dim3(rblocks), dim3(256), 0, stream, keys_sorted, w.total,
+                           (uint32_t)max_rendered, w.ranges, (uint32_t)((size_t)F * ntiles));
+        GVF_CHECK_LAUNCH();
+    }
+    prof_mark(stream, slot, 5);
+    hipLaunchKernelGGL(blend_kernel, dim3(ntiles, F), dim3(BLEND_THREADS), 0, stream, P, H, W, gx, gy, st.bg[0],
+                       st.bg[1], st.bg[2], w.ranges, vals_sorted, w.geomA, w.geomB, w.geomC, subpixel_offset,
+                       out_color, out_alpha, out_depth);
+    GVF_CHECK_LAUNCH();
+    prof_mark(stream, slot, 6);
+    return GVF_OK;
+}
+
+}  // namespace
+
+extern "C" int gvf_rast_workspace_bytes(int P, int F, int H, int W, int64_t max_rendered, size_t* bytes) {
+    if (!bytes || P < 0 || F <= 0 || H <= 0 || W <= 0 || max_rendered < 0) return GVF_EINVAL;
+    Workspace w = carve(nullptr, (size_t)-1, P, F, H, W, max_rendered);
+    *bytes = w.bytes + 256;
+    return GVF_OK;
+}
+
+extern "C" int gvf_rast_forward(const GvfRastSettings* st, const GvfRastFrame* frame_host, int P, int M,
+                                const float* means3D, const float* shs, const float* colors_precomp,
+                                const float* opacities, const float* scales, const float* rotations,
+                                const float* cov3D_precomp, const float* subpixel_offset, void* workspace,
+                                size_t workspace_bytes, int64_t max_rendered, float* out_color, float* out_alpha,
+                                float* out_depth, int32_t* out_radii, uint32_t* out_num_rendered, void* stream) {
+    if (!st || !frame_host) return GVF_EINVAL;
+    if (P > 0) {
+        if (!means3D || !opacities) return GVF_EINVAL;
+        // exactly one colour source and exactly one covariance source (upstream wrapper contract)
+        if ((shs == nullptr) == (colors_precomp == nullptr)) return GVF_EINVAL;
+        const bool have_sr = scales != nullptr && rotations != nullptr;
+        if (have_sr == (cov3D_precomp != nullptr)) return GVF_EINVAL;
+    }
+    return run_pipeline(*st, frame_host, 1, P, M, false, nullptr, means3D, scales, rotations, opacities, shs,
+                        colors_precomp, cov3D_precomp, nullptr, 0, subpixel_offset, workspace, workspace_bytes,
+                        max_rendered, out_color, out_alpha, out_depth, out_radii, out_num_rendered,
+                        (hipStream_t)stream);
+}
+
+extern "C" int gvf_rast_forward_batched(const GvfRastSettings* st, const GvfRastFrame* frames_host, int F,
+                                        const GvfGaussianActivation* act, int P, int M, const float* xyz_raw,
+                                        const float* features_dc, const float* scaling_raw,
+                                        const float* rotation_raw, const float* opacity_raw, const float* delta,
+                                        int n_delta, void* workspace, size_t workspace_bytes,
+                                        int64_t max_rendered, float* out_color, float* out_alpha, float* out_depth,
+                                        int32_t* out_radii, uint32_t* out_num_rendered, void* stream) {
+    if (!st || !frames_host || !act || F <= 0) return GVF_EINVAL;
+    if (P > 0 && (!xyz_raw || !features_dc || !scaling_raw || !rotation_raw || !opacity_raw)) return GVF_EINVAL;
+    if (act->scaling_activation != 0 && act->scaling_activation != 1) return GVF_EINVAL;
+    for (int f = 0; f < F; ++f) {
+        int di = frames_host[f].delta_index;
+        if (di >= 0 && (delta == nullptr || di >= n_delta)) return GVF_EINVAL;
+    }
+    return run_pipeline(*st, frames_host, F, P, M, true, act, xyz_raw, scaling_raw, rotation_raw, opacity_raw,
+                        features_dc, nullptr, nullptr, delta, n_delta, nullptr, workspace, workspace_bytes,
+                        max_rendered, out_color, out_alpha, out_depth, out_radii, out_num_rendered,
+                        (hipStream_t)stream);
+}
+
+extern "C" int gvf_gaussian_activate(const GvfGaussianActivation* act, int P, int M, const float* xyz_raw,
+                                     const float* features_dc, const float* scaling_raw, const float* rotation_raw,
+                                     const float* opacity_raw, const float* delta, float* means3D, float* scales,
+                                     float* rotations, float* shs, float* opacities, void* stream) {
+    if (!act || P < 0 || M < 1) return GVF_EINVAL;
+    if (P == 0) return GVF_OK;
+    if (!xyz_raw || !features_dc || !scaling_raw || !rotation_raw || !opacity_raw || !means3D || !scales ||
+        !rotations || !shs || !opacities)
+        return GVF_EINVAL;
+    hipLaunchKernelGGL(activate_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, *act, P, M, xyz_raw,
+                       features_dc, scaling_raw, rotation_raw, opacity_raw, delta, means3D, scales, rotations, shs,
+                       opacities);
+    GVF_CHECK_LAUNCH();
+    return GVF_OK;
+}
+
+extern "C" int gvf_rast_profile_enable(int on) {
+    if (on && !g_prof.on) {
+        for (int c = 0; c < PROF_MAX_CALLS; ++c)
+            for (int k = 0; k < PROF_EVENTS; ++k)
+                if (hipEventCreate(&g_prof.ev[c][k]) != hipSuccess) return GVF_ELAUNCH;
+        g_prof.on = true;
+        g_prof.calls = 0;
+    } else if (!on && g_prof.on) {
+        for (int c = 0; c < PROF_MAX_CALLS; ++c)
+            for (int k = 0; k < PROF_EVENTS; ++k) hipEventDestroy(g_prof.ev[c][k]);
+        g_prof.on = false;
+        g_prof.calls = 0;
+    }
+    return GVF_OK;
+}
+
+extern "C" int gvf_rast_profile_read(float* ms_sum, int* calls) {
+    if (!ms_sum || !calls) return GVF_EINVAL;
+    for (int k = 0; k < GVF_RAST_NSTAGES; ++k) ms_sum[k] = 0.f;
+    *calls = 0;
+    if (!g_prof.on) return GVF_OK;
+    for (int c = 0; c < g_prof.calls; ++c) {
+        if (hipEventSynchronize(g_prof.ev[c][PROF_EVENTS - 1]) != hipSuccess) return GVF_ELAUNCH;
+        for (int k = 0; k < GVF_RAST_NSTAGES; ++k) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, g_prof.ev[c][k], g_prof.ev[c][k + 1]) != hipSuccess) return GVF_ELAUNCH;
+            ms_sum[k] += ms;
+        }
+    }
+    *calls = g_prof.calls;
+    g_prof.calls = 0;
+    return GVF_OK;
+}
+
+extern "C" const char* gvf_version(void) { return "gvf_hip 0.1.0 gfx950"; }

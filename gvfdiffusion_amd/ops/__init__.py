@@ -1,0 +1,2 @@
+"""Operator-level Python bindings; importing this package registers every C-ABI signature."""
+from .. import _lib  # noqa: F401

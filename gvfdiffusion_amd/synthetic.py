@@ -1,0 +1,73 @@
+"""Synthetic inputs of the shapes BASELINE.json names: random Gaussians,
+orbit cameras with the reference's conventions, per-frame deltas.  There are no datasets or
+checkpoints in this environment; every bench and test input comes from here (seeded, CPU
+generator, then moved to the device)."""
+import math
+
+import torch
+
+from .renderers.sh_utils import RGB2SH
+from .representations.gaussian import GaussianModel
+
+FOV_X_DEG = 49.1  # dataset/dataset_latent_inference.py:182
+NEAR, FAR = 0.8, 1.6  # model/sparse_voxel_diffusion/sparse_vae.py:197-199
+BG = (1.0, 1.0, 1.0)
+KERNEL_2D = 0.1  # configs/diffusion.yml:81 (2d_filter_kernel_size)
+KERNEL_3D = 0.0009
+SCALING_BIAS = 0.004
+OPACITY_BIAS = 0.1
+
+
+def orbit_w2c(azimuth_deg: float, elevation_deg: float = 0.0, radius: float = 2.0) -> torch.Tensor:
+    """World-to-camera (4,4) of a camera orbiting the origin in a z-up world, COLMAP axes
+    (x right, y down, z forward) -- the convention the reference's cameras end in
+    (utils/inference_utils.py:245-254: orbit pose -> y-up to z-up -> flip y,z -> invert)."""
+    az, el = math.radians(azimuth_deg), math.radians(elevation_deg)
+    eye = torch.tensor([radius * math.cos(el) * math.sin(az), -radius * math.cos(el) * math.cos(az),
+                        radius * math.sin(el)], dtype=torch.float64)
+    fwd = -eye / eye.norm()
+    up = torch.tensor([0.0, 0.0, 1.0], dtype=torch.float64)
+    right = torch.linalg.cross(fwd, up)
+    right = right / right.norm()
+    down = torch.linalg.cross(fwd, right)
+    c2w = torch.eye(4, dtype=torch.float64)
+    c2w[:3, 0], c2w[:3, 1], c2w[:3, 2], c2w[:3, 3] = right, down, fwd, eye
+    return torch.linalg.inv(c2w).float()
+
+
+def intrinsics(fov_x_deg: float = FOV_X_DEG) -> torch.Tensor:
+    f = 0.5 / math.tan(math.radians(fov_x_deg) / 2)
+    return torch.tensor([[f, 0, 0.5], [0, f, 0.5], [0, 0, 1]], dtype=torch.float32)
+
+
+def random_gaussians(P: int, sh_degree: int = 2, seed: int = 0, scale_lo: float = 0.003, scale_hi: float = 0.02):
+    """Activated attributes (dict of CPU fp32 tensors): means3D, scales, rotations, opacities (P,1), shs (P,M,3)."""
+    g = torch.Generator().manual_seed(seed)
+    M = (sh_degree + 1) ** 2
+    xyz = torch.rand((P, 3), generator=g) - 0.5
+    scales = torch.exp(torch.rand((P, 3), generator=g) * (math.log(scale_hi) - math.log(scale_lo)) + math.log(scale_lo))
+    rot = torch.nn.functional.normalize(torch.randn((P, 4), generator=g), dim=1)
+    opac = torch.sigmoid(torch.randn((P, 1), generator=g) * 1.5)
+    shs = torch.randn((P, M, 3), generator=g) * 0.1
+    shs[:, 0] = RGB2SH(torch.rand((P, 3), generator=g))
+    return dict(means3D=xyz, scales=scales, rotations=rot, opacities=opac, shs=shs)
+
+
+def gaussian_model_from(attrs, sh_degree: int, device, scaling_activation="softplus") -> GaussianModel:
+    """GaussianModel whose activated accessors reproduce `attrs` (inverse activations applied)."""
+    gm = GaussianModel(sh_degree=sh_degree, aabb=[-0.5, -0.5, -0.5, 1.0, 1.0, 1.0], mininum_kernel_size=KERNEL_3D,
+                       scaling_bias=SCALING_BIAS, opacity_bias=OPACITY_BIAS, scaling_activation=scaling_activation,
+                       device=device)
+    d = {k: v.to(device) for k, v in attrs.items()}
+    gm.from_xyz(d["means3D"])
+    gm.from_scaling(d["scales"])
+    gm.from_rotation(d["rotations"])
+    gm.from_features(d["shs"].contiguous())
+    gm.from_opacity(d["opacities"].clamp(1e-4, 1 - 1e-4))
+    return gm
+
+
+def random_deltas(T: int, P: int, seed: int = 1, std: float = 0.01) -> torch.Tensor:
+    """(T,P,14) per-frame deltas ~ N(0,std) on all channels [xyz3|scale3|rot4|rgb3|op1]."""
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn((T, P, 14), generator=g) * std

@@ -1,0 +1,152 @@
+/*
+ * gvf_rast.h -- C ABI of the MI355X (gfx950) tile-based 3D-Gaussian-splatting rasteriser.
+ *
+ * This is the drop-in boundary for the reference's rasteriser operator seam:
+ *   renderers/gaussian_render.py:110-143  GaussianRasterizationSettings(...)   -> GvfRastSettings / GvfRastFrame
+ *   renderers/gaussian_render.py:198-220  GaussianRasterizer(...)(means3D, ...) -> gvf_rast_forward()
+ *   renderers/gaussian_render.py:154-160 + representations/gaussian/gaussian_model.py:84-114
+ *        (get_*_with_delta, fused in front of the rasteriser)                  -> gvf_rast_forward_batched()
+ * The external CUDA packages behind that seam (diff_gaussian_rasterization [mip-splatting fork]
+ * and diff_gauss [slothfulxtx fork]) are NOT in /root/reference (setup.sh:111,220-227); the two
+ * `mode`s below select their published behaviours.
+ *
+ * Conventions (all entry points):
+ *   - extern "C", plain pointers and sizes, no torch types.
+ *   - every data pointer is a DEVICE pointer unless the name ends in _host.
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*); nothing synchronises,
+ *     nothing allocates: the caller owns every buffer, including the workspace.
+ *   - return value: 0 on success, negative GVF_E* on a host-detectable error. Kernel launch
+ *     failures are returned as GVF_ELAUNCH (hipGetLastError is consulted after each launch).
+ *   - re-entrant per (device, stream); no global mutable state.
+ */
+#ifndef GVF_RAST_H
+#define GVF_RAST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GVF_OK        0
+#define GVF_EINVAL   (-1)   /* bad argument (null pointer, negative size, unsupported SH degree ...) */
+#define GVF_ENOSPC   (-2)   /* workspace too small for the request */
+#define GVF_ELAUNCH  (-3)   /* a kernel launch or HIP runtime call failed */
+
+#define GVF_RAST_MODE_MIP      0   /* diff_gaussian_rasterization (mip-splatting): 2D mip filter, opacity*=coef; returns color,radii */
+#define GVF_RAST_MODE_DILATE   1   /* diff_gauss (slothfulxtx): +0.3 px^2 dilation; also returns depth, alpha */
+
+#define GVF_TILE 16                /* tile edge in pixels (BLOCK_X = BLOCK_Y = 16 upstream) */
+
+/* Per-frame camera block == the camera fields of GaussianRasterizationSettings
+ * (gaussian_render.py:110-125).  Matrices are the 16 floats of the tensors the reference passes:
+ * viewmatrix = world_view_transform = V^T, projmatrix = full_proj_transform = (P V)^T, both
+ * row-major, i.e. element [i] here is column-major V / PV exactly as the upstream kernels index. */
+typedef struct GvfRastFrame {
+    float viewmatrix[16];
+    float projmatrix[16];
+    float campos[3];
+    float tanfovx;
+    float tanfovy;
+    int32_t delta_index;      /* batched path: which (P,14) slice of `delta` this frame uses; -1 = none */
+    int32_t reserved[2];
+} GvfRastFrame;
+
+/* Frame-invariant settings == the remaining GaussianRasterizationSettings fields. */
+typedef struct GvfRastSettings {
+    int32_t image_height;
+    int32_t image_width;
+    int32_t sh_degree;        /* active degree D (0..3); colours come from shs[P][M][3] */
+    int32_t mode;             /* GVF_RAST_MODE_* */
+    float   kernel_size;      /* mip 2D filter variance in px^2 (pipe.kernel_size, 0.1 at inference) */
+    float   scale_modifier;
+    float   bg[3];
+    int32_t prefiltered;      /* accepted for API parity; unused (as upstream when False) */
+    int32_t debug;            /* accepted for API parity */
+} GvfRastSettings;
+
+/* Activation constants of GaussianModel (representations/gaussian/gaussian_model.py:24-41,84-114)
+ * for the fused delta path.  scaling_activation: 0 = exp, 1 = softplus. */
+typedef struct GvfGaussianActivation {
+    float   aabb[6];              /* xyz = _xyz * aabb[3:6] + aabb[0:3] */
+    float   scale_bias;           /* inverse_activation(scaling_bias), added before the activation */
+    float   opacity_bias;         /* logit(opacity_bias) */
+    float   min_kernel_size;      /* 3D filter: scale = sqrt(act(.)^2 + k^2) */
+    int32_t scaling_activation;
+} GvfGaussianActivation;
+
+/* Bytes of workspace gvf_rast_forward*() needs for P Gaussians, F frames in one call, an H x W
+ * image and room for at most `max_rendered` (splat,tile) instances summed over the F frames. */
+int gvf_rast_workspace_bytes(int P, int F, int H, int W, int64_t max_rendered, size_t* bytes);
+
+/* One frame, activated inputs: the GaussianRasterizer.__call__ operator.
+ *   means3D[P][3], opacities[P], scales[P][3], rotations[P][4] (r,x,y,z; used un-normalised),
+ *   exactly one of shs[P][M][3] / colors_precomp[P][3] non-null,
+ *   cov3D_precomp[P][6] may replace scales+rotations (pass those null then),
+ *   subpixel_offset[H][W][2] may be null (= zeros).
+ * Outputs (caller-allocated): out_color[3][H][W]; out_radii[P] int32;
+ *   out_alpha[H][W], out_depth[H][W] may be null;
+ *   out_num_rendered: device uint32 receiving the instance count D. If D > max_rendered the
+ *   frame is NOT rendered correctly: the caller must check it and retry with a larger workspace. */
+int gvf_rast_forward(const GvfRastSettings* settings_host, const GvfRastFrame* frame_host,
+                     int P, int M,
+                     const float* means3D, const float* shs, const float* colors_precomp,
+                     const float* opacities, const float* scales, const float* rotations,
+                     const float* cov3D_precomp, const float* subpixel_offset,
+                     void* workspace, size_t workspace_bytes, int64_t max_rendered,
+                     float* out_color, float* out_alpha, float* out_depth,
+                     int32_t* out_radii, uint32_t* out_num_rendered,
+                     void* stream);
+
+/* F frames in one call, GaussianModel parameters + per-frame deltas activated in-kernel
+ * (render() with delta_pc, gaussian_render.py:154-160).  Raw parameters:
+ *   xyz_raw[P][3], features_dc[P][M][3], scaling_raw[P][3], rotation_raw[P][4], opacity_raw[P];
+ *   delta[n_delta][P][14] laid out [xyz3|scale3|rot4|rgb3|op1] (may be null: static render);
+ *   frames_host[F].
+ * Outputs: out_color[F][3][H][W]; out_alpha/out_depth [F][H][W] or null; out_radii[F][P] or null;
+ *   out_num_rendered[F] device uint32 (per-frame instance counts; their sum must be
+ *   <= max_rendered, else frames past the overflow point are not rendered correctly). */
+int gvf_rast_forward_batched(const GvfRastSettings* settings_host, const GvfRastFrame* frames_host, int F,
+                             const GvfGaussianActivation* act_host,
+                             int P, int M,
+                             const float* xyz_raw, const float* features_dc, const float* scaling_raw,
+                             const float* rotation_raw, const float* opacity_raw,
+                             const float* delta, int n_delta,
+                             void* workspace, size_t workspace_bytes, int64_t max_rendered,
+                             float* out_color, float* out_alpha, float* out_depth,
+                             int32_t* out_radii, uint32_t* out_num_rendered,
+                             void* stream);
+
+/* GaussianModel activations alone (get_*_with_delta), for callers that want the activated
+ * tensors (and for parity tests of the fused path): writes means3D[P][3], scales[P][3],
+ * rotations[P][4], shs[P][M][3], opacities[P].  delta may be null. */
+int gvf_gaussian_activate(const GvfGaussianActivation* act_host, int P, int M,
+                          const float* xyz_raw, const float* features_dc, const float* scaling_raw,
+                          const float* rotation_raw, const float* opacity_raw, const float* delta,
+                          float* means3D, float* scales, float* rotations, float* shs, float* opacities,
+                          void* stream);
+
+/* Stable LSD radix sort of n (key,value) pairs on bits [0,end_bit) of 64-bit keys: the
+ * rasteriser's R4 stage, exported for testing.  keys_alt/values_alt are scratch of the same
+ * size; the sorted result is left in keys/values. tmp: >= gvf_sort_tmp_bytes(n) bytes. */
+size_t gvf_sort_tmp_bytes(int64_t n);
+int gvf_sort_pairs_u64(uint64_t* keys, uint64_t* keys_alt, uint32_t* values, uint32_t* values_alt,
+                       int64_t n, int end_bit, void* tmp, size_t tmp_bytes, void* stream);
+
+/* Opt-in per-stage GPU timing of gvf_rast_forward*(): HIP events are recorded on the caller's
+ * stream at the stage boundaries of the next (at most 256) calls.  Stages, in order:
+ * preprocess, scan, duplicate, sort, ranges, blend.  gvf_rast_profile_read() synchronises on the
+ * recorded events, writes the summed milliseconds per stage over `*calls` calls, and resets.
+ * This is the library's only process-global state (off by default; not thread-safe). */
+#define GVF_RAST_NSTAGES 6
+int gvf_rast_profile_enable(int on);
+int gvf_rast_profile_read(float* ms_sum /*[GVF_RAST_NSTAGES]*/, int* calls);
+
+/* Library identification: returns a static string "gvf_hip <version> gfx950". */
+const char* gvf_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GVF_RAST_H */

@@ -1,0 +1,56 @@
+"""Shared helpers of the rasteriser tests: camera blocks as the reference builds them
+(renderers/gaussian_render.py:285-321), oracle invocation, flagged-pixel comparison."""
+import math
+
+import numpy as np
+import torch
+
+from gvfdiffusion_amd import synthetic
+from gvfdiffusion_amd.renderers.gaussian_render import intrinsics_to_projection
+
+
+def camera_block(azi=0.0, elev=0.0, radius=2.0, fov=synthetic.FOV_X_DEG, near=synthetic.NEAR, far=synthetic.FAR):
+    view = synthetic.orbit_w2c(azi, elev, radius)
+    K = synthetic.intrinsics(fov)
+    persp = intrinsics_to_projection(K, near, far)
+    tan = math.tan(float(2 * torch.atan(0.5 / K[0, 0])) * 0.5)
+    return dict(extrinsics=view, intrinsics=K, viewmatrix=view.T.contiguous(),
+                projmatrix=(persp @ view).T.contiguous(), campos=torch.inverse(view)[:3, 3].contiguous(),
+                tanfovx=tan, tanfovy=tan)
+
+
+def oracle_render(oracle, attrs, cam, H, W, sh_degree, mode=0, kernel_size=synthetic.KERNEL_2D, bg=synthetic.BG,
+                  scale_modifier=1.0, colors_precomp=None, cov3D_precomp=None, subpixel_offset=None, brute=False):
+    n = lambda t: None if t is None else t.detach().cpu().numpy()
+    use_cov = cov3D_precomp is not None
+    return oracle.rast_render(
+        n(attrs["means3D"]), None if colors_precomp is not None else n(attrs["shs"]), n(colors_precomp),
+        n(attrs["opacities"]), None if use_cov else n(attrs["scales"]), None if use_cov else n(attrs["rotations"]),
+        n(cov3D_precomp), H=H, W=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], kernel_size=kernel_size,
+        scale_modifier=scale_modifier, mode=mode, viewmatrix=n(cam["viewmatrix"]), projmatrix=n(cam["projmatrix"]),
+        campos=n(cam["campos"]), sh_degree=sh_degree, bg=np.asarray(bg, np.float32),
+        subpixel_offset=n(subpixel_offset), brute=brute)
+
+
+# Tolerance of the rasteriser parity tests (BASELINE.json north_star: "rendered RGBA frames must
+# match ... within 1e-3 max-abs per pixel").
+RAST_ATOL = 1e-3
+
+
+def compare_images(hip: np.ndarray, ref: np.ndarray, flags: np.ndarray, atol=RAST_ATOL, max_flag_frac=0.03,
+                   flagged_atol=2e-2):
+    """max-abs <= atol on every pixel whose blend decisions are not within float noise of a
+    threshold (oracle `flags` == 0); flagged pixels (alpha ~ 1/255, T ~ 1e-4, power ~ 0: the oracle
+    uses libm expf, the device v_exp_f32) may differ by one skipped/added splat and are bounded
+    separately.  Returns (max_err_unflagged, max_err_flagged, flagged_fraction)."""
+    err = np.abs(hip - ref)
+    if err.ndim == 3:
+        err = err.max(axis=0)
+    clean = flags == 0
+    e_clean = float(err[clean].max()) if clean.any() else 0.0
+    e_flag = float(err[~clean].max()) if (~clean).any() else 0.0
+    frac = float((~clean).mean())
+    assert e_clean <= atol, f"unflagged pixels differ by {e_clean} > {atol}"
+    assert frac <= max_flag_frac, f"{frac:.4f} of the pixels are threshold-flagged"
+    assert e_flag <= flagged_atol, f"flagged pixels differ by {e_flag}"
+    return e_clean, e_flag, frac

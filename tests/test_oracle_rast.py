@@ -1,0 +1,182 @@
+"""CPU tests of the rasteriser oracle itself (oracle/rast_oracle.c): the tile pipeline against the
+brute-force per-pixel compositor and against an independent numpy restatement, plus the sub-results
+the reference's own Python mirrors pin (golden vectors made by tests/golden/make_golden.py)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gvfdiffusion_amd import synthetic
+from rast_util import camera_block, oracle_render
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def numpy_reference(attrs, cam, H, W, deg, mode, kernel_size, bg):
+    """Independent float64 restatement of R1..R6 (no tiles: per pixel over all visible Gaussians whose
+    16x16-tile rect covers the pixel's tile), small inputs only."""
+    m = attrs["means3D"].double().numpy(); s = attrs["scales"].double().numpy()
+    q = attrs["rotations"].double().numpy(); op = attrs["opacities"].double().numpy().reshape(-1)
+    sh = attrs["shs"].double().numpy()
+    V = cam["viewmatrix"].double().numpy().T; PV = cam["projmatrix"].double().numpy().T
+    campos = cam["campos"].double().numpy()
+    P = m.shape[0]
+    ph = np.concatenate([m, np.ones((P, 1))], 1)
+    pv = (V @ ph.T).T[:, :3]
+    hom = (PV @ ph.T).T
+    pw = 1.0 / (hom[:, 3] + 1e-7)
+    ndc = hom[:, :2] * pw[:, None]
+    r, x, y, z = q.T
+    R = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                  2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                  2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], 1).reshape(P, 3, 3)
+    L = R * s[:, None, :]
+    Sig = L @ L.transpose(0, 2, 1)
+    fx = W / (2 * cam["tanfovx"]); fy = H / (2 * cam["tanfovy"])
+    lx, ly = 1.3 * cam["tanfovx"], 1.3 * cam["tanfovy"]
+    tz = pv[:, 2]
+    tx = np.clip(pv[:, 0] / tz, -lx, lx) * tz; ty = np.clip(pv[:, 1] / tz, -ly, ly) * tz
+    J = np.zeros((P, 2, 3)); J[:, 0, 0] = fx / tz; J[:, 0, 2] = -fx * tx / tz ** 2
+    J[:, 1, 1] = fy / tz; J[:, 1, 2] = -fy * ty / tz ** 2
+    A = J @ V[:3, :3]
+    cov = A @ Sig @ A.transpose(0, 2, 1)
+    cxx, cxy, cyy = cov[:, 0, 0], cov[:, 0, 1], cov[:, 1, 1]
+    coef = np.ones(P)
+    if mode == 0:
+        d0 = np.maximum(1e-6, cxx * cyy - cxy ** 2)
+        d1 = np.maximum(1e-6, (cxx + kernel_size) * (cyy + kernel_size) - cxy ** 2)
+        coef = np.sqrt(d0 / (d1 + 1e-6) + 1e-6)
+        coef[(d0 <= 1e-6) | (d1 <= 1e-6)] = 0
+        cxx = cxx + kernel_size; cyy = cyy + kernel_size
+    else:
+        cxx = cxx + 0.3; cyy = cyy + 0.3
+    det = cxx * cyy - cxy ** 2
+    ca, cb, cc = cyy / det, -cxy / det, cxx / det
+    mid = 0.5 * (cxx + cyy)
+    lam = mid + np.sqrt(np.maximum(0.1, mid ** 2 - det))
+    rad = np.ceil(3 * np.sqrt(lam))
+    px = ((ndc[:, 0] + 1) * W - 1) * 0.5; py = ((ndc[:, 1] + 1) * H - 1) * 0.5
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    x0 = np.clip(((px - rad) / 16).astype(int), 0, gx); y0 = np.clip(((py - rad) / 16).astype(int), 0, gy)
+    x1 = np.clip(((px + rad + 15) / 16).astype(int), 0, gx); y1 = np.clip(((py + rad + 15) / 16).astype(int), 0, gy)
+    vis = (tz > 0.2) & ((x1 - x0) * (y1 - y0) > 0)
+    from gvfdiffusion_amd.renderers.sh_utils import eval_sh
+    dirs = m - campos[None]; dirs = dirs / np.linalg.norm(dirs, axis=1, keepdims=True)
+    rgb = eval_sh(deg, torch.from_numpy(sh).transpose(1, 2), torch.from_numpy(dirs)).numpy() + 0.5
+    rgb = np.maximum(rgb, 0)
+    order = np.lexsort((np.arange(P), tz.astype(np.float32)))
+    img = np.zeros((3, H, W)); alpha_img = np.zeros((H, W))
+    for yy in range(H):
+        for xx in range(W):
+            T = 1.0; C = np.zeros(3)
+            for i in order:
+                if not vis[i] or not (x0[i] <= xx // 16 < x1[i] and y0[i] <= yy // 16 < y1[i]):
+                    continue
+                dx, dy = px[i] - xx, py[i] - yy
+                power = -0.5 * (ca[i] * dx * dx + cc[i] * dy * dy) - cb[i] * dx * dy
+                if power > 0:
+                    continue
+                a = min(0.99, op[i] * coef[i] * math.exp(power))
+                if a < 1 / 255:
+                    continue
+                if T * (1 - a) < 1e-4:
+                    break
+                C += rgb[i] * a * T; T *= (1 - a)
+            img[:, yy, xx] = C + T * np.asarray(bg); alpha_img[yy, xx] = 1 - T
+    return img, alpha_img, rad * vis
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("deg", [0, 2, 3])
+def test_oracle_matches_numpy_restatement(oracle_lib, mode, deg):
+    P, H, W = 300, 40, 56
+    attrs = synthetic.random_gaussians(P, sh_degree=deg, seed=3, scale_lo=0.01, scale_hi=0.08)
+    cam = camera_block(azi=30.0, elev=10.0)
+    out = oracle_render(oracle_lib, attrs, cam, H, W, deg, mode=mode)
+    img, alpha, rad = numpy_reference(attrs, cam, H, W, deg, mode, synthetic.KERNEL_2D, synthetic.BG)
+    ok = out["flags"] == 0
+    assert np.abs(out["color"] - img)[:, ok].max() < 2e-4
+    assert np.abs(out["alpha"] - alpha)[ok].max() < 2e-4
+    # radius may differ by one where 3*sqrt(lambda) lands within float noise of an integer
+    assert (np.abs(out["radii"] - rad) > 0).mean() < 0.01
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_tile_pipeline_equals_bruteforce(oracle_lib, mode):
+    P, H, W = 2000, 96, 80
+    attrs = synthetic.random_gaussians(P, sh_degree=2, seed=5, scale_lo=0.005, scale_hi=0.05)
+    cam = camera_block(azi=75.0, elev=-20.0)
+    a = oracle_render(oracle_lib, attrs, cam, H, W, 2, mode=mode)
+    b = oracle_render(oracle_lib, attrs, cam, H, W, 2, mode=mode, brute=True)
+    assert np.array_equal(a["color"], b["color"])
+    assert np.array_equal(a["alpha"], b["alpha"])
+    assert np.array_equal(a["depth"], b["depth"])
+
+
+def test_config1_plumbing(oracle_lib):
+    """BASELINE.json configs[0]: 10k random Gaussians, 1 frame, 256x256, CPU only."""
+    attrs = synthetic.random_gaussians(10_000, sh_degree=2, seed=0)
+    cam = camera_block(azi=0.0)
+    out = oracle_render(oracle_lib, attrs, cam, 256, 256, 2, mode=0)
+    assert out["color"].shape == (3, 256, 256) and np.isfinite(out["color"]).all()
+    assert out["num_rendered"] > 10_000 and (out["radii"] > 0).sum() > 9000
+    assert 0.0 <= out["color"].min() and out["alpha"].max() <= 1.0
+    # background shows through where nothing is splatted (corners of the frame)
+    assert np.allclose(out["color"][:, 0, 0], 1.0)
+
+
+def test_empty_and_culled(oracle_lib):
+    cam = camera_block()
+    attrs = synthetic.random_gaussians(16, sh_degree=0, seed=1)
+    attrs = {k: v[:0] for k, v in attrs.items()}
+    out = oracle_render(oracle_lib, attrs, cam, 32, 32, 0)
+    assert out["num_rendered"] == 0 and np.allclose(out["color"], 1.0)
+    attrs = synthetic.random_gaussians(64, sh_degree=0, seed=1)
+    attrs["means3D"] = attrs["means3D"] * 0 + torch.tensor([0.0, -5.0, 0.0])  # behind the camera
+    out = oracle_render(oracle_lib, attrs, cam, 32, 32, 0)
+    assert out["num_rendered"] == 0 and (out["radii"] == 0).all()
+
+
+def test_golden_sh_and_rotation(oracle_lib):
+    """Sub-results pinned by the reference's own Python (renderers/sh_utils.py, utils/script_util.py
+    build_rotation, renderers/gaussian_render.py intrinsics_to_projection)."""
+    g = np.load(os.path.join(GOLD, "raster_mirrors.npz"))
+    from gvfdiffusion_amd.renderers.sh_utils import eval_sh
+    from gvfdiffusion_amd.representations.gaussian import build_rotation
+    from gvfdiffusion_amd.renderers.gaussian_render import intrinsics_to_projection
+    for deg in range(4):
+        mine = eval_sh(deg, torch.from_numpy(g["sh_coeffs"]), torch.from_numpy(g["sh_dirs"])).numpy()
+        assert np.abs(mine - g[f"sh_out_deg{deg}"]).max() < 1e-6
+    R = build_rotation(torch.from_numpy(g["quats"])).numpy()
+    assert np.abs(R - g["rotmats"]).max() < 1e-6
+    Pm = intrinsics_to_projection(torch.from_numpy(g["intrinsics"]), 0.8, 1.6).numpy()
+    assert np.abs(Pm - g["projection"]).max() < 1e-7
+    # the C oracle's SH->RGB path: one Gaussian at the origin, campos placed so that the viewing
+    # direction equals the golden direction (campos only enters through the SH direction)
+    cam = camera_block()
+    sh = np.ascontiguousarray(np.transpose(g["sh_coeffs"], (0, 2, 1)))  # (n,3,16) -> (n,16,3)
+    for deg in (1, 2, 3):
+        want = np.maximum(g[f"sh_out_deg{deg}"] + 0.5, 0)
+        for i in range(g["sh_dirs"].shape[0]):
+            geom = oracle_lib.rast_preprocess(
+                np.zeros((1, 3)), sh[i:i + 1], None, np.ones(1), np.full((1, 3), 0.01), np.array([[1, 0, 0, 0]]), None,
+                H=64, W=64, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], kernel_size=0.1, scale_modifier=1.0, mode=0,
+                viewmatrix=cam["viewmatrix"].numpy(), projmatrix=cam["projmatrix"].numpy(),
+                campos=-g["sh_dirs"][i] * 1.5, sh_degree=deg)
+            assert geom[0, 15] > 0
+            assert np.abs(geom[0, 7:10] - want[i]).max() < 2e-5
+
+
+def test_golden_activations(oracle_lib):
+    """G1 against the reference's formulas evaluated by torch (make_golden.py restates
+    gaussian_model.py:84-114 with the reference's own torch ops; the module itself needs utils3d/plyfile)."""
+    g = np.load(os.path.join(GOLD, "raster_mirrors.npz"))
+    out = oracle_lib.gaussian_activate(g["act_xyz"], g["act_feat"], g["act_scaling"], g["act_rot"], g["act_opacity"],
+                                       g["act_delta"], aabb=[-0.5, -0.5, -0.5, 1, 1, 1], scale_bias=float(g["act_scale_bias"]),
+                                       opacity_bias=float(g["act_opacity_bias"]), min_kernel_size=0.0009,
+                                       scaling_activation=1)
+    for k in ("means3D", "scales", "rotations", "shs"):
+        assert np.abs(out[k] - g["act_out_" + k]).max() < 2e-6, k
+    assert np.abs(out["opacities"] - g["act_out_opacities"].reshape(-1)).max() < 2e-6

@@ -1,0 +1,263 @@
+"""Parity of the HIP rasteriser (through the C ABI) against the CPU oracle -- needs an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from gvfdiffusion_amd import synthetic
+from rast_util import camera_block, oracle_render, compare_images, RAST_ATOL
+
+pytestmark = pytest.mark.gpu
+
+
+def _to(dev, attrs):
+    return {k: v.to(dev) for k, v in attrs.items()}
+
+
+def _settings(cam, H, W, deg, mode, dev, kernel_size=synthetic.KERNEL_2D, scale_modifier=1.0, bg=synthetic.BG,
+              subpixel_offset=None):
+    common = dict(image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"],
+                  bg=torch.tensor(bg, device=dev), scale_modifier=scale_modifier, viewmatrix=cam["viewmatrix"].to(dev),
+                  projmatrix=cam["projmatrix"].to(dev), sh_degree=deg, campos=cam["campos"].to(dev), prefiltered=False,
+                  debug=False)
+    if mode == 0:
+        from gvfdiffusion_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+        return GaussianRasterizer(GaussianRasterizationSettings(kernel_size=kernel_size, subpixel_offset=subpixel_offset,
+                                                                **common))
+    from gvfdiffusion_amd.diff_gauss import GaussianRasterizationSettings, GaussianRasterizer
+    return GaussianRasterizer(GaussianRasterizationSettings(**common))
+
+
+def _run(rast, a, **over):
+    kw = dict(means3D=a["means3D"], means2D=torch.zeros_like(a["means3D"]), shs=a["shs"], colors_precomp=None,
+              opacities=a["opacities"], scales=a["scales"], rotations=a["rotations"], cov3D_precomp=None)
+    kw.update(over)
+    return rast(**kw)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+@pytest.mark.parametrize("hw", [(256, 256), (200, 312)])
+def test_frame_matches_oracle(cuda, oracle_lib, mode, deg, hw):
+    H, W = hw
+    attrs = synthetic.random_gaussians(20_000, sh_degree=deg, seed=11 + deg, scale_lo=0.003, scale_hi=0.03)
+    cam = camera_block(azi=40.0 * deg + 5, elev=12.0)
+    ref = oracle_render(oracle_lib, attrs, cam, H, W, deg, mode=mode)
+    ret = _run(_settings(cam, H, W, deg, mode, cuda), _to(cuda, attrs))
+    if mode == 0:
+        assert len(ret) == 2
+        color, radii = ret
+    else:
+        assert len(ret) == 6
+        color, depth, normal, alpha, radii, extra = ret
+        assert depth.shape == (1, H, W) and alpha.shape == (1, H, W)
+        compare_images(alpha[0].cpu().numpy(), ref["alpha"], ref["flags"])
+        compare_images(depth[0].cpu().numpy(), ref["depth"], ref["flags"], atol=2e-3, flagged_atol=5e-2)
+    assert color.shape == (3, H, W) and radii.dtype == torch.int32
+    # integer work is bit-exact: radii (hence tile rects and the instance count)
+    assert np.array_equal(radii.cpu().numpy(), ref["radii"])
+    e_clean, e_flag, frac = compare_images(color.cpu().numpy(), ref["color"], ref["flags"])
+    print(f"mode={mode} deg={deg} {H}x{W}: max|d|={e_clean:.2e} flagged={frac:.4f} (max {e_flag:.2e})")
+
+
+def test_instance_count_and_empty_inputs(cuda, oracle_lib):
+    from gvfdiffusion_amd import rasterizer as R, _lib
+    cam = camera_block()
+    attrs = synthetic.random_gaussians(5000, sh_degree=2, seed=2)
+    ref = oracle_render(oracle_lib, attrs, cam, 128, 128, 2)
+    a = _to(cuda, attrs)
+    st = R.make_settings(128, 128, 2, 0, synthetic.KERNEL_2D, 1.0, synthetic.BG)
+    fr = R.make_frame(cam["viewmatrix"], cam["projmatrix"], cam["campos"], cam["tanfovx"], cam["tanfovy"])
+    out = R.rasterize(st, fr, a["means3D"], a["opacities"], shs=a["shs"], scales=a["scales"], rotations=a["rotations"])
+    assert out["num_rendered"] == ref["num_rendered"]
+    # P = 0 -> background only
+    e = {k: v[:0] for k, v in a.items()}
+    out = R.rasterize(st, fr, e["means3D"], e["opacities"], shs=e["shs"], scales=e["scales"], rotations=e["rotations"])
+    assert out["num_rendered"] == 0 and torch.all(out["color"] == 1.0)
+    # everything behind the camera -> background only, radii 0
+    b = dict(a)
+    b["means3D"] = a["means3D"] * 0 + torch.tensor([0.0, -5.0, 0.0], device=cuda)
+    out = R.rasterize(st, fr, b["means3D"], b["opacities"], shs=b["shs"], scales=b["scales"], rotations=b["rotations"])
+    assert out["num_rendered"] == 0 and torch.all(out["radii"] == 0) and torch.all(out["color"] == 1.0)
+    # argument contract of the upstream wrapper
+    with pytest.raises(Exception):
+        R.rasterize(st, fr, a["means3D"], a["opacities"], shs=a["shs"], colors_precomp=a["means3D"], scales=a["scales"],
+                    rotations=a["rotations"])
+    with pytest.raises(Exception):
+        R.rasterize(st, fr, a["means3D"], a["opacities"], shs=a["shs"])
+    with pytest.raises(_lib.GvfError):
+        R.rasterize(st, fr, a["means3D"].cpu(), a["opacities"].cpu(), shs=a["shs"].cpu(), scales=a["scales"].cpu(),
+                    rotations=a["rotations"].cpu())
+
+
+def test_workspace_overflow_is_reported_and_retried(cuda, oracle_lib):
+    from gvfdiffusion_amd import rasterizer as R
+    cam = camera_block()
+    attrs = synthetic.random_gaussians(3000, sh_degree=0, seed=4, scale_lo=0.02, scale_hi=0.06)
+    ref = oracle_render(oracle_lib, attrs, cam, 160, 160, 0)
+    a = _to(cuda, attrs)
+    st = R.make_settings(160, 160, 0, 0, synthetic.KERNEL_2D, 1.0, synthetic.BG)
+    fr = R.make_frame(cam["viewmatrix"], cam["projmatrix"], cam["campos"], cam["tanfovx"], cam["tanfovy"])
+    R._CAP_HINT[(3000, 160, 160, 1)] = 128   # force an undersized first attempt
+    out = R.rasterize(st, fr, a["means3D"], a["opacities"], shs=a["shs"], scales=a["scales"], rotations=a["rotations"])
+    assert out["num_rendered"] == ref["num_rendered"] > 128
+    compare_images(out["color"].cpu().numpy(), ref["color"], ref["flags"])
+
+
+def test_precomputed_colour_cov_and_subpixel(cuda, oracle_lib):
+    H = W = 192
+    attrs = synthetic.random_gaussians(8000, sh_degree=1, seed=21, scale_lo=0.004, scale_hi=0.03)
+    cam = camera_block(azi=200.0, elev=-15.0)
+    a = _to(cuda, attrs)
+    g = torch.Generator().manual_seed(0)
+    colors = torch.rand((8000, 3), generator=g)
+    from gvfdiffusion_amd.representations.gaussian import build_scaling_rotation, strip_symmetric
+    L = build_scaling_rotation(attrs["scales"], attrs["rotations"])
+    cov = strip_symmetric(L @ L.transpose(1, 2)).contiguous()
+    sub = (torch.rand((H, W, 2), generator=g) - 0.5)
+    ref = oracle_render(oracle_lib, attrs, cam, H, W, 1, mode=0, colors_precomp=colors, cov3D_precomp=cov,
+                        subpixel_offset=sub)
+    rast = _settings(cam, H, W, 1, 0, cuda, subpixel_offset=sub.to(cuda))
+    color, radii = _run(rast, a, shs=None, colors_precomp=colors.to(cuda), scales=None, rotations=None,
+                        cov3D_precomp=cov.to(cuda))
+    assert np.array_equal(radii.cpu().numpy(), ref["radii"])
+    compare_images(color.cpu().numpy(), ref["color"], ref["flags"])
+    # scale_modifier applied inside the operator
+    ref2 = oracle_render(oracle_lib, attrs, cam, H, W, 1, mode=0, colors_precomp=colors, scale_modifier=1.3)
+    rast2 = _settings(cam, H, W, 1, 0, cuda, scale_modifier=1.3)
+    color2, radii2 = _run(rast2, a, shs=None, colors_precomp=colors.to(cuda))
+    assert np.array_equal(radii2.cpu().numpy(), ref2["radii"])
+    compare_images(color2.cpu().numpy(), ref2["color"], ref2["flags"])
+
+
+@pytest.mark.parametrize("n,end_bit", [(0, 64), (1, 64), (63, 40), (4095, 44), (4097, 44), (100_003, 48),
+                                      (3_000_000, 44), (5_000_000, 64)])
+def test_radix_sort_is_stable_and_exact(cuda, n, end_bit):
+    from gvfdiffusion_amd.rasterizer import sort_pairs_u64
+    g = torch.Generator().manual_seed(n + end_bit)
+    if n:
+        hi = torch.randint(0, 1 << 12, (n,), generator=g, dtype=torch.int64)  # duplicate keys -> stability matters
+        lo = torch.randint(0, 1 << 8, (n,), generator=g, dtype=torch.int64)
+        keys = (hi << (end_bit - 13)) | (lo << 5) | 1
+    else:
+        keys = torch.zeros((0,), dtype=torch.int64)
+    vals = torch.arange(n, dtype=torch.int32)
+    k, v = sort_pairs_u64(keys.to(cuda), vals.to(cuda), end_bit)
+    order = torch.sort(keys, stable=True).indices
+    assert torch.equal(k.cpu(), keys[order])
+    assert torch.equal(v.cpu(), vals[order])
+
+
+def test_activation_kernel_matches_oracle(cuda, oracle_lib):
+    from gvfdiffusion_amd import rasterizer as R
+    P, M = 10_000, 4
+    g = torch.Generator().manual_seed(9)
+    raw = dict(xyz=torch.rand((P, 3), generator=g), feat=torch.randn((P, M, 3), generator=g),
+               scaling=torch.randn((P, 3), generator=g) * 2, rot=torch.randn((P, 4), generator=g),
+               opacity=torch.randn((P, 1), generator=g) * 3, delta=torch.randn((P, 14), generator=g) * 0.1)
+    raw["scaling"][0, 0] = 30.0
+    for act_name in ("softplus", "exp"):
+        gm = synthetic.GaussianModel(sh_degree=1, mininum_kernel_size=0.0009, scaling_bias=0.004, opacity_bias=0.1,
+                                     scaling_activation=act_name, device="cpu")
+        act = gm.activation_struct()
+        for delta in (raw["delta"], None):
+            out = R.gaussian_activate(act, raw["xyz"].to(cuda), raw["feat"].to(cuda), raw["scaling"].to(cuda),
+                                      raw["rot"].to(cuda), raw["opacity"].to(cuda),
+                                      None if delta is None else delta.to(cuda))
+            ref = oracle_lib.gaussian_activate(raw["xyz"].numpy(), raw["feat"].numpy(), raw["scaling"].numpy(),
+                                               raw["rot"].numpy(), raw["opacity"].numpy(),
+                                               None if delta is None else delta.numpy(), aabb=[-0.5, -0.5, -0.5, 1, 1, 1],
+                                               scale_bias=act.scale_bias, opacity_bias=act.opacity_bias,
+                                               min_kernel_size=0.0009, scaling_activation=act.scaling_activation)
+            # exp/log1p come from two different libms: relative 2e-6; everything else is bit-exact
+            for k in ("means3D", "rotations", "shs"):
+                assert np.array_equal(out[k].cpu().numpy(), ref[k]), k
+            np.testing.assert_allclose(out["scales"].cpu().numpy(), ref["scales"], rtol=2e-6, atol=0)
+            np.testing.assert_allclose(out["opacities"].cpu().numpy().reshape(-1), ref["opacities"], rtol=2e-6, atol=1e-9)
+
+
+def test_batched_fused_path_equals_per_frame_operator(cuda, oracle_lib):
+    """render_frames (F frames, activations + deltas fused into the preprocess kernel) must be
+    bit-identical to activate-kernel + single-frame operator, and match the oracle."""
+    from gvfdiffusion_amd.renderers import GaussianRenderer
+    from gvfdiffusion_amd import rasterizer as R
+    P, deg, S, T = 30_000, 2, 208, 3
+    attrs = synthetic.random_gaussians(P, sh_degree=deg, seed=31, scale_lo=0.003, scale_hi=0.02)
+    gm = synthetic.gaussian_model_from(attrs, deg, cuda)
+    delta = synthetic.random_deltas(T, P, seed=5).to(cuda)
+    n = lambda t: t.detach().cpu().numpy()
+    for use_mip in (True, False):
+        rend = GaussianRenderer({"resolution": S, "near": synthetic.NEAR, "far": synthetic.FAR, "bg_color": synthetic.BG})
+        rend.pipe.use_mip_gaussian = use_mip
+        cams = [camera_block(azi=15.0 * f, elev=5.0) for f in range(4)]
+        ext = torch.stack([c["extrinsics"] for c in cams]).to(cuda)
+        K = cams[0]["intrinsics"].to(cuda)
+        idx = [0, 1, 2, -1]
+        out = rend.render_frames(gm, ext, K, delta_pc=delta, delta_index=idx, want_alpha_depth=True)
+        assert out.rgb.shape == (4, 3, S, S)
+        for f in range(4):
+            d = None if idx[f] < 0 else delta[idx[f]]
+            single = rend.render(gm, ext[f], K, delta_pc=d)          # torch activations -> operator
+            act = R.gaussian_activate(gm.activation_struct(), gm._xyz, gm.get_features, gm._scaling, gm._rotation,
+                                      gm._opacity, d)
+            st = R.make_settings(S, S, deg, 0 if use_mip else 1, rend.pipe.kernel_size, 1.0, synthetic.BG)
+            fr = R.make_frame(cams[f]["viewmatrix"], cams[f]["projmatrix"], cams[f]["campos"], cams[f]["tanfovx"],
+                              cams[f]["tanfovy"])
+            two = R.rasterize(st, fr, act["means3D"], act["opacities"], shs=act["shs"], scales=act["scales"],
+                              rotations=act["rotations"], want_alpha_depth=True)
+            assert torch.equal(out.rgb[f], two["color"])             # same device arithmetic: bit-exact
+            assert torch.equal(out.alpha[f], two["alpha"]) and torch.equal(out.depth[f], two["depth"])
+            assert int(out.num_rendered[f]) == two["num_rendered"]
+            # vs the torch-activated facade path (different exp/log implementations): close
+            assert (single.rgb - out.rgb[f]).abs().max() < 2e-2
+            # vs the oracle (activations + render on the CPU)
+            oa = oracle_lib.gaussian_activate(n(gm._xyz), n(gm.get_features), n(gm._scaling), n(gm._rotation),
+                                              n(gm._opacity), None if d is None else n(d),
+                                              aabb=[-0.5, -0.5, -0.5, 1, 1, 1], scale_bias=float(gm.scale_bias),
+                                              opacity_bias=float(gm.opacity_bias),
+                                              min_kernel_size=synthetic.KERNEL_3D, scaling_activation=1)
+            oattrs = {k: torch.from_numpy(oa[k]) for k in ("means3D", "scales", "rotations", "shs")}
+            oattrs["opacities"] = torch.from_numpy(oa["opacities"])
+            ref = oracle_render(oracle_lib, oattrs, cams[f], S, S, deg, mode=0 if use_mip else 1,
+                                kernel_size=rend.pipe.kernel_size)
+            # the activations differ by ulps between the two libms, so a handful of radii / tile rects may
+            # flip: flagged-pixel rule plus a small budget of tile-level outliers
+            err = np.abs(n(out.rgb[f]) - ref["color"]).max(axis=0)
+            bad = (err > RAST_ATOL) & (ref["flags"] == 0)
+            assert bad.mean() < 2e-3, f"{bad.mean():.5f} of unflagged pixels off by > {RAST_ATOL}"
+            assert err.max() < 0.1
+
+
+def test_full_size_frame_config2(cuda, oracle_lib):
+    """BASELINE.json configs[1] shapes: 262144 Gaussians, 800x800, SH degree 2 -- one frame checked
+    against the oracle (about 1 s of CPU), 24 frames checked through size-independent properties."""
+    from gvfdiffusion_amd.renderers import GaussianRenderer
+    P, deg, S = 262_144, 2, 800
+    attrs = synthetic.random_gaussians(P, sh_degree=deg, seed=0, scale_lo=0.002, scale_hi=0.01)
+    cam = camera_block(azi=15.0)
+    ref = oracle_render(oracle_lib, attrs, cam, S, S, deg, mode=0)
+    color, radii = _run(_settings(cam, S, S, deg, 0, cuda), _to(cuda, attrs))
+    assert np.array_equal(radii.cpu().numpy(), ref["radii"])
+    e_clean, e_flag, frac = compare_images(color.cpu().numpy(), ref["color"], ref["flags"])
+    print(f"config2 frame: D={ref['num_rendered']} max|d|={e_clean:.2e} flagged={frac:.4f}")
+
+    gm = synthetic.gaussian_model_from(attrs, deg, cuda)
+    delta = synthetic.random_deltas(24, P, seed=1).to(cuda)
+    ext = torch.stack([camera_block(azi=15.0 * f)["extrinsics"] for f in range(24)]).to(cuda)
+    K = cam["intrinsics"].to(cuda)
+    white = GaussianRenderer({"resolution": S, "near": synthetic.NEAR, "far": synthetic.FAR, "bg_color": (1.0, 1.0, 1.0)})
+    black = GaussianRenderer({"resolution": S, "near": synthetic.NEAR, "far": synthetic.FAR, "bg_color": (0.0, 0.0, 0.0)})
+    for r in (white, black):
+        r.pipe.use_mip_gaussian = True
+    w = white.render_frames(gm, ext, K, delta_pc=delta, want_alpha_depth=True)
+    b = black.render_frames(gm, ext, K, delta_pc=delta, want_alpha_depth=True)
+    assert torch.isfinite(w.rgb).all() and w.rgb.min() >= 0
+    assert torch.equal(w.alpha, b.alpha) and torch.equal(w.num_rendered, b.num_rendered)
+    # out = C + T*bg  =>  white - black == T == 1 - alpha  (compositing identity, size independent)
+    assert ((w.rgb - b.rgb) - (1 - w.alpha)[:, None]).abs().max() < 2e-6
+    assert w.alpha.min() >= 0 and w.alpha.max() <= 1 - 1e-4 + 1e-6      # T never drops below 1e-4
+    # permuting the Gaussians cannot change a frame (order is by depth; ties are broken by index only)
+    perm = torch.randperm(P, generator=torch.Generator().manual_seed(3))
+    gm2 = synthetic.gaussian_model_from({k: v[perm] for k, v in attrs.items()}, deg, cuda)
+    w2 = white.render_frames(gm2, ext[:2], K, delta_pc=delta[:2][:, perm.to(cuda)].contiguous(), want_alpha_depth=True)
+    assert torch.equal(w2.num_rendered, w.num_rendered[:2])
+    assert (w2.rgb - w.rgb[:2]).abs().max() < 1e-5
