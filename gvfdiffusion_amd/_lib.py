@@ -79,6 +79,11 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise GvfError(f"{LIB_PATH} is missing: build it with `python -m gvfdiffusion_amd._build` "
                            "(hipcc, gfx950). There is no CPU fallback.")
+        # torch must be imported before the dlopen: its wheel bundles libamdhip64.so (SONAME
+        # libamdhip64.so.7) and libgvf_hip.so must bind to THAT runtime instance to share torch's
+        # device context and streams.  Loaded the other way round, the process ends up with two HIP
+        # runtimes and this library's one reports "no ROCm-capable device".
+        import torch  # noqa: F401
         l = ctypes.CDLL(LIB_PATH)
         _bind(l, SIGNATURES)
         _LIB = l

@@ -6,9 +6,17 @@
 
 #define GVF_WAVE 64
 
-#define GVF_CHECK_LAUNCH()                                   \
-    do {                                                     \
-        if (hipGetLastError() != hipSuccess) return GVF_ELAUNCH; \
+#include <stdio.h>
+#include <stdlib.h>
+// Set GVF_DEBUG=1 to have launch failures name the HIP error and source line on stderr.
+#define GVF_CHECK_LAUNCH()                                                                    \
+    do {                                                                                      \
+        hipError_t gvf_e_ = hipGetLastError();                                                \
+        if (gvf_e_ != hipSuccess) {                                                           \
+            if (getenv("GVF_DEBUG"))                                                          \
+                fprintf(stderr, "[gvf] %s:%d: %s\n", __FILE__, __LINE__, hipGetErrorString(gvf_e_)); \
+            return GVF_ELAUNCH;                                                               \
+        }                                                                                     \
     } while (0)
 
 static inline size_t gvf_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -547,7 +547,7 @@ struct Profiler {
 };
 Profiler g_prof;
 inline void prof_mark(hipStream_t s, int slot, int k) {
-    if (slot >= 0) hipEventRecord(g_prof.ev[slot][k], s);
+    if (slot >= 0) (void)hipEventRecord(g_prof.ev[slot][k], s);
 }
 
 struct Workspace {
@@ -607,9 +607,12 @@ int run_pipeline(const GvfRastSettings& st, const GvfRastFrame* frames_host, int
     if (st.sh_degree < 0 || st.sh_degree > 3) return GVF_EINVAL;
     if (st.mode != GVF_RAST_MODE_MIP && st.mode != GVF_RAST_MODE_DILATE) return GVF_EINVAL;
     if (!out_color || !out_num_rendered || !frames_host || !workspace) return GVF_EINVAL;
-    if (colors_precomp == nullptr) {
+    if (P > 0 && colors_precomp == nullptr) {
         if (sh == nullptr || M < (st.sh_degree + 1) * (st.sh_degree + 1) || M > MAX_SH_COEFFS) return GVF_EINVAL;
     }
+    // hipGetLastError() is process-wide: clear what other users of the runtime (e.g. an event query that
+    // returned hipErrorNotReady) left behind, so GVF_CHECK_LAUNCH reports only this call's launches.
+    (void)hipGetLastError();
     if ((((uintptr_t)sh) & 15) != 0 || (((uintptr_t)workspace) & 255) != 0) return GVF_EINVAL;  // 16-B SH rows, 256-B workspace
     Workspace w = carve(workspace, workspace_bytes, P, F, H, W, max_rendered);
     if (!w.ok) return GVF_ENOSPC;
@@ -742,6 +745,7 @@ extern "C" int gvf_gaussian_activate(const GvfGaussianActivation* act, int P, in
     if (!xyz_raw || !features_dc || !scaling_raw || !rotation_raw || !opacity_raw || !means3D || !scales ||
         !rotations || !shs || !opacities)
         return GVF_EINVAL;
+    (void)hipGetLastError();
     hipLaunchKernelGGL(activate_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, *act, P, M, xyz_raw,
                        features_dc, scaling_raw, rotation_raw, opacity_raw, delta, means3D, scales, rotations, shs,
                        opacities);
@@ -758,7 +762,7 @@ extern "C" int gvf_rast_profile_enable(int on) {
         g_prof.calls = 0;
     } else if (!on && g_prof.on) {
         for (int c = 0; c < PROF_MAX_CALLS; ++c)
-            for (int k = 0; k < PROF_EVENTS; ++k) hipEventDestroy(g_prof.ev[c][k]);
+            for (int k = 0; k < PROF_EVENTS; ++k) (void)hipEventDestroy(g_prof.ev[c][k]);
         g_prof.on = false;
         g_prof.calls = 0;
     }

@@ -257,6 +257,7 @@ extern "C" int gvf_sort_pairs_u64(uint64_t* keys, uint64_t* keys_alt, uint32_t* 
     if (n < 0 || n > 0xFFFFFFFFll) return GVF_EINVAL;
     if (n > 0 && (!keys || !keys_alt || !values || !values_alt || !tmp)) return GVF_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();
     size_t need = gvf_sort_tmp_bytes(n);
     if (tmp_bytes < need) return GVF_ENOSPC;
     if (n == 0) return GVF_OK;

@@ -149,6 +149,22 @@ class GaussianRenderer:
         return ret
 
     # ---- MI355X batched path -----------------------------------------------------------------
+    def make_frames(self, extrinsics, intrinsics, delta_index=None):
+        """Camera blocks (GvfRastFrame) of F views, built exactly as render() builds its camera dict."""
+        opts = self.rendering_options
+        size = int(opts["resolution"]) * int(opts["ssaa"])
+        Fn = extrinsics.shape[0]
+        if intrinsics.dim() == 2:
+            intrinsics = intrinsics[None].expand(Fn, 3, 3)
+        ext_c, int_c = extrinsics.detach().float().cpu(), intrinsics.detach().float().cpu()
+        frames = []
+        for f in range(Fn):
+            cam = _camera(ext_c[f], int_c[f], opts["near"], opts["far"], size)
+            frames.append(_r.make_frame(cam.world_view_transform, cam.full_proj_transform, cam.camera_center,
+                                        math.tan(float(cam.FoVx) * 0.5), math.tan(float(cam.FoVy) * 0.5),
+                                        -1 if delta_index is None else int(delta_index[f])))
+        return frames
+
     def render_frames(self, gaussian, extrinsics, intrinsics, delta_pc=None, delta_index=None,
                       want_alpha_depth=False, max_rendered=None, sync=True):
         """Render F frames of one sample in a single fused launch sequence.
@@ -162,19 +178,10 @@ class GaussianRenderer:
         size = int(opts["resolution"])
         dev = extrinsics.device
         bg = self._background(dev)
-        Fn = extrinsics.shape[0]
-        if intrinsics.dim() == 2:
-            intrinsics = intrinsics[None].expand(Fn, 3, 3)
         T = 0 if delta_pc is None else (1 if delta_pc.dim() == 2 else delta_pc.shape[0])
         if delta_index is None:
-            delta_index = [min(f, T - 1) if T > 0 else -1 for f in range(Fn)]
-        ext_c, int_c = extrinsics.detach().float().cpu(), intrinsics.detach().float().cpu()
-        frames = []
-        for f in range(Fn):
-            cam = _camera(ext_c[f], int_c[f], opts["near"], opts["far"], size)
-            frames.append(_r.make_frame(cam.world_view_transform, cam.full_proj_transform, cam.camera_center,
-                                        math.tan(float(cam.FoVx) * 0.5), math.tan(float(cam.FoVy) * 0.5),
-                                        int(delta_index[f])))
+            delta_index = [min(f, T - 1) if T > 0 else -1 for f in range(extrinsics.shape[0])]
+        frames = self.make_frames(extrinsics, intrinsics, delta_index)
         mode = _lib.RAST_MODE_MIP if self.pipe.use_mip_gaussian else _lib.RAST_MODE_DILATE
         st = _r.make_settings(size, size, gaussian.active_sh_degree, mode, self.pipe.kernel_size,
                               self.pipe.scale_modifier, bg, False, self.pipe.debug)

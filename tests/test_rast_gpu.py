@@ -200,11 +200,11 @@ def test_batched_fused_path_equals_per_frame_operator(cuda, oracle_lib):
             act = R.gaussian_activate(gm.activation_struct(), gm._xyz, gm.get_features, gm._scaling, gm._rotation,
                                       gm._opacity, d)
             st = R.make_settings(S, S, deg, 0 if use_mip else 1, rend.pipe.kernel_size, 1.0, synthetic.BG)
-            fr = R.make_frame(cams[f]["viewmatrix"], cams[f]["projmatrix"], cams[f]["campos"], cams[f]["tanfovx"],
-                              cams[f]["tanfovy"])
+            fr = rend.make_frames(ext[f:f + 1], K)[0]                # the same camera block render_frames used
             two = R.rasterize(st, fr, act["means3D"], act["opacities"], shs=act["shs"], scales=act["scales"],
                               rotations=act["rotations"], want_alpha_depth=True)
-            assert torch.equal(out.rgb[f], two["color"])             # same device arithmetic: bit-exact
+            dmax = float((out.rgb[f] - two["color"]).abs().max())
+            assert dmax == 0.0, f"mip={use_mip} frame {f}: fused vs two-step differ by {dmax}"  # bit-exact
             assert torch.equal(out.alpha[f], two["alpha"]) and torch.equal(out.depth[f], two["depth"])
             assert int(out.num_rendered[f]) == two["num_rendered"]
             # vs the torch-activated facade path (different exp/log implementations): close
@@ -255,9 +255,12 @@ def test_full_size_frame_config2(cuda, oracle_lib):
     # out = C + T*bg  =>  white - black == T == 1 - alpha  (compositing identity, size independent)
     assert ((w.rgb - b.rgb) - (1 - w.alpha)[:, None]).abs().max() < 2e-6
     assert w.alpha.min() >= 0 and w.alpha.max() <= 1 - 1e-4 + 1e-6      # T never drops below 1e-4
-    # permuting the Gaussians cannot change a frame (order is by depth; ties are broken by index only)
+    # permuting the Gaussians changes a frame only where two splats of one pixel have bit-identical
+    # depth (ties are broken by index, as upstream's stable sort does): with 262144 depths in [1.5,2.5]
+    # (float spacing 1.2e-7) a few thousand exact ties exist, so allow a tiny fraction of pixels
     perm = torch.randperm(P, generator=torch.Generator().manual_seed(3))
     gm2 = synthetic.gaussian_model_from({k: v[perm] for k, v in attrs.items()}, deg, cuda)
     w2 = white.render_frames(gm2, ext[:2], K, delta_pc=delta[:2][:, perm.to(cuda)].contiguous(), want_alpha_depth=True)
     assert torch.equal(w2.num_rendered, w.num_rendered[:2])
-    assert (w2.rgb - w.rgb[:2]).abs().max() < 1e-5
+    dperm = (w2.rgb - w.rgb[:2]).abs().amax(dim=1)
+    assert float((dperm > 1e-5).float().mean()) < 2e-3 and float(dperm.max()) < 0.1
