@@ -1,0 +1,589 @@
+"""DPM-Solver / DPM-Solver++ sampling loop with the reference's surface (model/dpmsolver.py):
+
+    NoiseScheduleVP(schedule, betas|alphas_cumprod, ...)                      :7-168
+    model_wrapper(model, noise_schedule, model_type, model_kwargs, guidance_type, condition,
+                  unconditional_condition, guidance_scale, guidance_scale2, classifier_fn, ...)  :171-351
+    DPM_Solver(model_fn, noise_schedule, algorithm_type, ...).sample(x, steps, t_start, t_end, order,
+                  skip_type, method, ...)                                     :354-1264
+    interpolate_fn, expand_dims                                               :1270-1321
+
+Same names, arguments, defaults and error behaviour, so inference_dpm_latent.py:156,225-249 runs
+unchanged.  What is different is WHERE the scalar work happens: every quantity that depends only on
+time (alpha_t, sigma_t, lambda_t, the solver coefficients) is computed on the HOST from the fp32
+schedule table -- the reference evaluates them on the device with (1,)-shaped tensors, i.e. a dozen
+sort/gather/elementwise launches and, in `adaptive`, extra syncs per step.  Here one multistep update is
+one device expression over the (B,T,N,C) state and one network evaluation; the only sync left is the
+adaptive solver's accept/reject test, which is inherent to it (model/dpmsolver.py:1019).
+Time tensors therefore live on the CPU inside the solver; the network still receives a device tensor.
+"""
+import math
+
+import torch
+
+
+# --------------------------------------------------------------------------------------------------
+def interpolate_fn(x, xp, yp):
+    """Piecewise-linear y(x) through keypoints (xp, yp) [C,K], x [N,C]; beyond the ends the outermost
+    segments are extended (model/dpmsolver.py:1270-1309).  xp ascending along K."""
+    N, K = x.shape[0], xp.shape[1]
+    xpe = xp.unsqueeze(0).expand(N, -1, -1)
+    ype = yp.unsqueeze(0).expand(N, -1, -1)
+    # segment index i such that xp[i] <= x < xp[i+1], clamped to [0, K-2]
+    idx = torch.searchsorted(xpe.contiguous(), x.unsqueeze(2).contiguous(), right=True).squeeze(2) - 1
+    idx = idx.clamp(0, K - 2)
+    x0 = torch.gather(xpe, 2, idx.unsqueeze(2)).squeeze(2)
+    x1 = torch.gather(xpe, 2, (idx + 1).unsqueeze(2)).squeeze(2)
+    y0 = torch.gather(ype, 2, idx.unsqueeze(2)).squeeze(2)
+    y1 = torch.gather(ype, 2, (idx + 1).unsqueeze(2)).squeeze(2)
+    return y0 + (x - x0) * (y1 - y0) / (x1 - x0)
+
+
+def expand_dims(v, dims):
+    """[N] -> [N,1,...,1] with `dims` dimensions (model/dpmsolver.py:1312-1321)."""
+    return v[(...,) + (None,) * (dims - 1)]
+
+
+class NoiseScheduleVP:
+    def __init__(self, schedule="discrete", betas=None, alphas_cumprod=None, continuous_beta_0=0.1,
+                 continuous_beta_1=20.0, dtype=torch.float32):
+        if schedule not in ["discrete", "linear"]:
+            raise ValueError("Unsupported noise schedule {}. The schedule needs to be 'discrete' or 'linear'".format(schedule))
+        self.schedule = schedule
+        self.T = 1.0
+        if schedule == "discrete":
+            if betas is not None:
+                log_alphas = 0.5 * torch.log(1 - betas).cumsum(dim=0)
+            else:
+                assert alphas_cumprod is not None
+                log_alphas = 0.5 * torch.log(alphas_cumprod)
+            log_alphas = self.numerical_clip_alpha(log_alphas)
+            # tables stay on the host (fp32, as the reference builds them)
+            self.log_alpha_array = log_alphas.reshape((1, -1)).to(dtype=dtype).cpu()
+            self.total_N = self.log_alpha_array.shape[1]
+            self.t_array = torch.linspace(0.0, 1.0, self.total_N + 1)[1:].reshape((1, -1)).to(dtype=dtype)
+            self._la_flip = torch.flip(self.log_alpha_array, [1])
+            self._t_flip = torch.flip(self.t_array, [1])
+        else:
+            self.total_N = 1000
+            self.beta_0 = continuous_beta_0
+            self.beta_1 = continuous_beta_1
+
+    def numerical_clip_alpha(self, log_alphas, clipped_lambda=-5.1):
+        """Drop the tail of the table where lambda < -5.1 (cosine schedules; :115-126)."""
+        log_sigmas = 0.5 * torch.log(1.0 - torch.exp(2.0 * log_alphas))
+        lambs = log_alphas - log_sigmas
+        idx = torch.searchsorted(torch.flip(lambs, [0]), clipped_lambda)
+        if idx > 0:
+            log_alphas = log_alphas[:-idx]
+        return log_alphas
+
+    def marginal_log_mean_coeff(self, t):
+        if self.schedule == "discrete":
+            tc = t.detach().to("cpu")
+            out = interpolate_fn(tc.reshape((-1, 1)).to(self.t_array.dtype), self.t_array, self.log_alpha_array).reshape((-1))
+            return out.to(device=t.device, dtype=t.dtype if t.is_floating_point() else out.dtype)
+        return -0.25 * t ** 2 * (self.beta_1 - self.beta_0) - 0.5 * t * self.beta_0
+
+    def marginal_alpha(self, t):
+        return torch.exp(self.marginal_log_mean_coeff(t))
+
+    def marginal_std(self, t):
+        return torch.sqrt(1.0 - torch.exp(2.0 * self.marginal_log_mean_coeff(t)))
+
+    def marginal_lambda(self, t):
+        log_mean_coeff = self.marginal_log_mean_coeff(t)
+        log_std = 0.5 * torch.log(1.0 - torch.exp(2.0 * log_mean_coeff))
+        return log_mean_coeff - log_std
+
+    def inverse_lambda(self, lamb):
+        if self.schedule == "linear":
+            tmp = 2.0 * (self.beta_1 - self.beta_0) * torch.logaddexp(-2.0 * lamb, torch.zeros((1,)).to(lamb))
+            Delta = self.beta_0 ** 2 + tmp
+            return tmp / (torch.sqrt(Delta) + self.beta_0) / (self.beta_1 - self.beta_0)
+        lc = lamb.detach().to("cpu")
+        log_alpha = -0.5 * torch.logaddexp(torch.zeros((1,), dtype=lc.dtype), -2.0 * lc)
+        t = interpolate_fn(log_alpha.reshape((-1, 1)).to(self._la_flip.dtype), self._la_flip, self._t_flip)
+        return t.reshape((-1,)).to(device=lamb.device, dtype=lamb.dtype)
+
+
+# --------------------------------------------------------------------------------------------------
+def model_wrapper(model, noise_schedule, model_type="noise", model_kwargs={}, guidance_type="uncond", condition=None,
+                  unconditional_condition=None, guidance_scale=1.0, guidance_scale2=1.0, classifier_fn=None,
+                  classifier_kwargs={}):
+    """Continuous-time noise-prediction wrapper (model/dpmsolver.py:171-351), incl. the reference's
+    three-way classifier-free guidance (full-uncond / image-uncond / cond, :332-347)."""
+    assert model_type in ["noise", "x_start", "v", "score"]
+    assert guidance_type in ["uncond", "classifier", "classifier-free"]
+
+    def get_model_input_time(t_continuous):
+        if noise_schedule.schedule == "discrete":
+            return (t_continuous - 1.0 / noise_schedule.total_N) * 1000.0
+        return t_continuous
+
+    def _coef(fn, t, x):
+        return expand_dims(fn(t).to(device=x.device, dtype=x.dtype), x.dim())
+
+    def noise_pred_fn(x, t_continuous, cond=None):
+        t_input = get_model_input_time(t_continuous).to(x.device)
+        C_in = x.shape[1]
+        if cond is None:
+            output = model(x, t_input, **model_kwargs)
+        else:
+            output = model(x, t_input, **cond, **model_kwargs)
+        if output.shape[1] != C_in:
+            output, _ = torch.split(output, C_in, dim=1)
+        if model_type == "noise":
+            return output
+        if model_type == "x_start":
+            return (x - _coef(noise_schedule.marginal_alpha, t_continuous, x) * output) / _coef(noise_schedule.marginal_std, t_continuous, x)
+        if model_type == "v":
+            return _coef(noise_schedule.marginal_alpha, t_continuous, x) * output + _coef(noise_schedule.marginal_std, t_continuous, x) * x
+        return -_coef(noise_schedule.marginal_std, t_continuous, x) * output  # score
+
+    def cond_grad_fn(x, t_input):
+        with torch.enable_grad():
+            x_in = x.detach().requires_grad_(True)
+            log_prob = classifier_fn(x_in, t_input, condition, **classifier_kwargs)
+            return torch.autograd.grad(log_prob.sum(), x_in)[0]
+
+    def model_fn(x, t_continuous):
+        if guidance_type == "uncond":
+            return noise_pred_fn(x, t_continuous)
+        if guidance_type == "classifier":
+            assert classifier_fn is not None
+            t_input = get_model_input_time(t_continuous).to(x.device)
+            cond_grad = cond_grad_fn(x, t_input)
+            noise = noise_pred_fn(x, t_continuous)
+            return noise - guidance_scale * _coef(noise_schedule.marginal_std, t_continuous, x) * cond_grad
+        # classifier-free
+        if (guidance_scale == 1.0 and guidance_scale2 == 1.0) or unconditional_condition is None:
+            return noise_pred_fn(x, t_continuous, cond=condition)
+        x_in = torch.cat([x] * 3)
+        t_in = torch.cat([t_continuous] * 3)
+        full_uncond = dict(unconditional_condition)
+        full_uncond["static_latent"] = torch.zeros_like(full_uncond["static_latent"])
+        if isinstance(condition, dict):
+            assert isinstance(unconditional_condition, dict)
+            c_in = {}
+            for k in condition:
+                if isinstance(condition[k], list):
+                    c_in[k] = [torch.cat([full_uncond[k][i], unconditional_condition[k][i], condition[k][i]])
+                               for i in range(len(condition[k]))]
+                else:
+                    c_in[k] = torch.cat([full_uncond[k], unconditional_condition[k], condition[k]])
+        else:
+            c_in = torch.cat([full_uncond, unconditional_condition, condition])
+        e_full, e_unc, e_cond = noise_pred_fn(x_in, t_in, cond=c_in).chunk(3)
+        return e_full + guidance_scale * (e_unc - e_full) + guidance_scale2 * (e_cond - e_unc)
+
+    return model_fn
+
+
+# --------------------------------------------------------------------------------------------------
+class DPM_Solver:
+    def __init__(self, model_fn, noise_schedule, algorithm_type="dpmsolver++", correcting_x0_fn=None,
+                 correcting_xt_fn=None, thresholding_max_val=1.0, dynamic_thresholding_ratio=0.995):
+        self.model = lambda x, t: model_fn(x, t.expand((x.shape[0])))
+        self.noise_schedule = noise_schedule
+        assert algorithm_type in ["dpmsolver", "dpmsolver++"]
+        self.algorithm_type = algorithm_type
+        self.correcting_x0_fn = self.dynamic_thresholding_fn if correcting_x0_fn == "dynamic_thresholding" else correcting_x0_fn
+        self.correcting_xt_fn = correcting_xt_fn
+        self.dynamic_thresholding_ratio = dynamic_thresholding_ratio
+        self.thresholding_max_val = thresholding_max_val
+
+    # ---- scalar schedule helpers (host) -------------------------------------------------------
+    def _sched(self, t):
+        """t: (1,) CPU tensor -> python floats (log_alpha, sigma, lambda, alpha)."""
+        ns = self.noise_schedule
+        la = ns.marginal_log_mean_coeff(t)
+        sig = torch.sqrt(1.0 - torch.exp(2.0 * la))
+        return float(la), float(sig), float(la - torch.log(sig)), float(torch.exp(la))
+
+    @staticmethod
+    def _host(t):
+        return t.detach().to("cpu").reshape(-1)[:1].float() if torch.is_tensor(t) else torch.tensor([float(t)])
+
+    # ---- model evaluations --------------------------------------------------------------------
+    def dynamic_thresholding_fn(self, x0, t):
+        dims = x0.dim()
+        p = self.dynamic_thresholding_ratio
+        s = torch.quantile(torch.abs(x0).reshape((x0.shape[0], -1)), p, dim=1)
+        s = expand_dims(torch.maximum(s, self.thresholding_max_val * torch.ones_like(s)), dims)
+        return torch.clamp(x0, -s, s) / s
+
+    def noise_prediction_fn(self, x, t):
+        return self.model(x, t)
+
+    def data_prediction_fn(self, x, t):
+        noise = self.noise_prediction_fn(x, t)
+        _, sigma_t, _, alpha_t = self._sched(self._host(t))
+        x0 = (x - sigma_t * noise) / alpha_t
+        if self.correcting_x0_fn is not None:
+            x0 = self.correcting_x0_fn(x0, t)
+        return x0
+
+    def model_fn(self, x, t):
+        return self.data_prediction_fn(x, t) if self.algorithm_type == "dpmsolver++" else self.noise_prediction_fn(x, t)
+
+    # ---- time grids -----------------------------------------------------------------------------
+    def get_time_steps(self, skip_type, t_T, t_0, N, device=None):
+        """(N+1,) time grid, on the host (`device` accepted for signature parity)."""
+        if skip_type == "logSNR":
+            lambda_T = self.noise_schedule.marginal_lambda(torch.tensor(t_T))
+            lambda_0 = self.noise_schedule.marginal_lambda(torch.tensor(t_0))
+            logSNR_steps = torch.linspace(float(lambda_T), float(lambda_0), N + 1)
+            return self.noise_schedule.inverse_lambda(logSNR_steps)
+        if skip_type == "time_uniform":
+            return torch.linspace(t_T, t_0, N + 1)
+        if skip_type == "time_quadratic":
+            t_order = 2
+            return torch.linspace(t_T ** (1.0 / t_order), t_0 ** (1.0 / t_order), N + 1).pow(t_order)
+        raise ValueError("Unsupported skip_type {}, need to be 'logSNR' or 'time_uniform' or 'time_quadratic'".format(skip_type))
+
+    def get_orders_and_timesteps_for_singlestep_solver(self, steps, order, skip_type, t_T, t_0, device=None):
+        if order == 3:
+            K = steps // 3 + 1
+            if steps % 3 == 0:
+                orders = [3] * (K - 2) + [2, 1]
+            elif steps % 3 == 1:
+                orders = [3] * (K - 1) + [1]
+            else:
+                orders = [3] * (K - 1) + [2]
+        elif order == 2:
+            if steps % 2 == 0:
+                K = steps // 2
+                orders = [2] * K
+            else:
+                K = steps // 2 + 1
+                orders = [2] * (K - 1) + [1]
+        elif order == 1:
+            K = steps
+            orders = [1] * steps
+        else:
+            raise ValueError("'order' must be '1' or '2' or '3'.")
+        if skip_type == "logSNR":
+            timesteps_outer = self.get_time_steps(skip_type, t_T, t_0, K)
+        else:
+            cum = torch.cumsum(torch.tensor([0] + orders), 0)
+            timesteps_outer = self.get_time_steps(skip_type, t_T, t_0, steps)[cum]
+        return timesteps_outer, orders
+
+    def denoise_to_zero_fn(self, x, s):
+        return self.data_prediction_fn(x, s)
+
+    # ---- single-step updates ----------------------------------------------------------------------
+    def dpm_solver_first_update(self, x, s, t, model_s=None, return_intermediate=False):
+        s, t = self._host(s), self._host(t)
+        la_s, sig_s, lam_s, _ = self._sched(s)
+        la_t, sig_t, lam_t, alpha_t = self._sched(t)
+        h = lam_t - lam_s
+        if model_s is None:
+            model_s = self.model_fn(x, s)
+        if self.algorithm_type == "dpmsolver++":
+            x_t = (sig_t / sig_s) * x - (alpha_t * math.expm1(-h)) * model_s
+        else:
+            x_t = math.exp(la_t - la_s) * x - (sig_t * math.expm1(h)) * model_s
+        return (x_t, {"model_s": model_s}) if return_intermediate else x_t
+
+    def singlestep_dpm_solver_second_update(self, x, s, t, r1=0.5, model_s=None, return_intermediate=False,
+                                            solver_type="dpmsolver"):
+        if solver_type not in ["dpmsolver", "taylor"]:
+            raise ValueError("'solver_type' must be either 'dpmsolver' or 'taylor', got {}".format(solver_type))
+        if r1 is None:
+            r1 = 0.5
+        r1 = float(r1)
+        ns = self.noise_schedule
+        s, t = self._host(s), self._host(t)
+        la_s, sig_s, lam_s, _ = self._sched(s)
+        la_t, sig_t, lam_t, alpha_t = self._sched(t)
+        h = lam_t - lam_s
+        s1 = ns.inverse_lambda(torch.tensor([lam_s + r1 * h]))
+        la_s1, sig_s1, _, alpha_s1 = self._sched(s1)
+        if model_s is None:
+            model_s = self.model_fn(x, s)
+        if self.algorithm_type == "dpmsolver++":
+            phi_11 = math.expm1(-r1 * h)
+            phi_1 = math.expm1(-h)
+            x_s1 = (sig_s1 / sig_s) * x - (alpha_s1 * phi_11) * model_s
+            model_s1 = self.model_fn(x_s1, s1)
+            if solver_type == "dpmsolver":
+                x_t = (sig_t / sig_s) * x - (alpha_t * phi_1) * model_s - (0.5 / r1) * (alpha_t * phi_1) * (model_s1 - model_s)
+            else:
+                x_t = (sig_t / sig_s) * x - (alpha_t * phi_1) * model_s + (1.0 / r1) * (alpha_t * (phi_1 / h + 1.0)) * (model_s1 - model_s)
+        else:
+            phi_11 = math.expm1(r1 * h)
+            phi_1 = math.expm1(h)
+            x_s1 = math.exp(la_s1 - la_s) * x - (sig_s1 * phi_11) * model_s
+            model_s1 = self.model_fn(x_s1, s1)
+            if solver_type == "dpmsolver":
+                x_t = math.exp(la_t - la_s) * x - (sig_t * phi_1) * model_s - (0.5 / r1) * (sig_t * phi_1) * (model_s1 - model_s)
+            else:
+                x_t = math.exp(la_t - la_s) * x - (sig_t * phi_1) * model_s - (1.0 / r1) * (sig_t * (phi_1 / h - 1.0)) * (model_s1 - model_s)
+        return (x_t, {"model_s": model_s, "model_s1": model_s1}) if return_intermediate else x_t
+
+    def singlestep_dpm_solver_third_update(self, x, s, t, r1=1.0 / 3.0, r2=2.0 / 3.0, model_s=None, model_s1=None,
+                                           return_intermediate=False, solver_type="dpmsolver"):
+        if solver_type not in ["dpmsolver", "taylor"]:
+            raise ValueError("'solver_type' must be either 'dpmsolver' or 'taylor', got {}".format(solver_type))
+        r1 = 1.0 / 3.0 if r1 is None else float(r1)
+        r2 = 2.0 / 3.0 if r2 is None else float(r2)
+        ns = self.noise_schedule
+        s, t = self._host(s), self._host(t)
+        la_s, sig_s, lam_s, _ = self._sched(s)
+        la_t, sig_t, lam_t, alpha_t = self._sched(t)
+        h = lam_t - lam_s
+        s1 = ns.inverse_lambda(torch.tensor([lam_s + r1 * h]))
+        s2 = ns.inverse_lambda(torch.tensor([lam_s + r2 * h]))
+        la_s1, sig_s1, _, alpha_s1 = self._sched(s1)
+        la_s2, sig_s2, _, alpha_s2 = self._sched(s2)
+        if self.algorithm_type == "dpmsolver++":
+            phi_11, phi_12, phi_1 = math.expm1(-r1 * h), math.expm1(-r2 * h), math.expm1(-h)
+            phi_22 = phi_12 / (r2 * h) + 1.0
+            phi_2 = phi_1 / h + 1.0
+            phi_3 = phi_2 / h - 0.5
+            if model_s is None:
+                model_s = self.model_fn(x, s)
+            if model_s1 is None:
+                x_s1 = (sig_s1 / sig_s) * x - (alpha_s1 * phi_11) * model_s
+                model_s1 = self.model_fn(x_s1, s1)
+            x_s2 = (sig_s2 / sig_s) * x - (alpha_s2 * phi_12) * model_s + r2 / r1 * (alpha_s2 * phi_22) * (model_s1 - model_s)
+            model_s2 = self.model_fn(x_s2, s2)
+            if solver_type == "dpmsolver":
+                x_t = (sig_t / sig_s) * x - (alpha_t * phi_1) * model_s + (1.0 / r2) * (alpha_t * phi_2) * (model_s2 - model_s)
+            else:
+                D1_0 = (1.0 / r1) * (model_s1 - model_s)
+                D1_1 = (1.0 / r2) * (model_s2 - model_s)
+                D1 = (r2 * D1_0 - r1 * D1_1) / (r2 - r1)
+                D2 = 2.0 * (D1_1 - D1_0) / (r2 - r1)
+                x_t = (sig_t / sig_s) * x - (alpha_t * phi_1) * model_s + (alpha_t * phi_2) * D1 - (alpha_t * phi_3) * D2
+        else:
+            phi_11, phi_12, phi_1 = math.expm1(r1 * h), math.expm1(r2 * h), math.expm1(h)
+            phi_22 = phi_12 / (r2 * h) - 1.0
+            phi_2 = phi_1 / h - 1.0
+            phi_3 = phi_2 / h - 0.5
+            if model_s is None:
+                model_s = self.model_fn(x, s)
+            if model_s1 is None:
+                x_s1 = math.exp(la_s1 - la_s) * x - (sig_s1 * phi_11) * model_s
+                model_s1 = self.model_fn(x_s1, s1)
+            x_s2 = math.exp(la_s2 - la_s) * x - (sig_s2 * phi_12) * model_s - r2 / r1 * (sig_s2 * phi_22) * (model_s1 - model_s)
+            model_s2 = self.model_fn(x_s2, s2)
+            if solver_type == "dpmsolver":
+                x_t = math.exp(la_t - la_s) * x - (sig_t * phi_1) * model_s - (1.0 / r2) * (sig_t * phi_2) * (model_s2 - model_s)
+            else:
+                D1_0 = (1.0 / r1) * (model_s1 - model_s)
+                D1_1 = (1.0 / r2) * (model_s2 - model_s)
+                D1 = (r2 * D1_0 - r1 * D1_1) / (r2 - r1)
+                D2 = 2.0 * (D1_1 - D1_0) / (r2 - r1)
+                x_t = math.exp(la_t - la_s) * x - (sig_t * phi_1) * model_s - (sig_t * phi_2) * D1 - (sig_t * phi_3) * D2
+        if return_intermediate:
+            return x_t, {"model_s": model_s, "model_s1": model_s1, "model_s2": model_s2}
+        return x_t
+
+    def singlestep_dpm_solver_update(self, x, s, t, order, return_intermediate=False, solver_type="dpmsolver", r1=None,
+                                     r2=None):
+        if order == 1:
+            return self.dpm_solver_first_update(x, s, t, return_intermediate=return_intermediate)
+        if order == 2:
+            return self.singlestep_dpm_solver_second_update(x, s, t, return_intermediate=return_intermediate,
+                                                            solver_type=solver_type, r1=r1)
+        if order == 3:
+            return self.singlestep_dpm_solver_third_update(x, s, t, return_intermediate=return_intermediate,
+                                                           solver_type=solver_type, r1=r1, r2=r2)
+        raise ValueError("Solver order must be 1 or 2 or 3, got {}".format(order))
+
+    # ---- multistep updates --------------------------------------------------------------------------
+    def multistep_dpm_solver_second_update(self, x, model_prev_list, t_prev_list, t, solver_type="dpmsolver"):
+        if solver_type not in ["dpmsolver", "taylor"]:
+            raise ValueError("'solver_type' must be either 'dpmsolver' or 'taylor', got {}".format(solver_type))
+        model_prev_1, model_prev_0 = model_prev_list[-2], model_prev_list[-1]
+        t_prev_1, t_prev_0, t = self._host(t_prev_list[-2]), self._host(t_prev_list[-1]), self._host(t)
+        _, _, lam_p1, _ = self._sched(t_prev_1)
+        la_p0, sig_p0, lam_p0, _ = self._sched(t_prev_0)
+        la_t, sig_t, lam_t, alpha_t = self._sched(t)
+        h_0 = lam_p0 - lam_p1
+        h = lam_t - lam_p0
+        r0 = h_0 / h
+        D1_0 = (1.0 / r0) * (model_prev_0 - model_prev_1)
+        if self.algorithm_type == "dpmsolver++":
+            phi_1 = math.expm1(-h)
+            if solver_type == "dpmsolver":
+                return (sig_t / sig_p0) * x - (alpha_t * phi_1) * model_prev_0 - 0.5 * (alpha_t * phi_1) * D1_0
+            return (sig_t / sig_p0) * x - (alpha_t * phi_1) * model_prev_0 + (alpha_t * (phi_1 / h + 1.0)) * D1_0
+        phi_1 = math.expm1(h)
+        if solver_type == "dpmsolver":
+            return math.exp(la_t - la_p0) * x - (sig_t * phi_1) * model_prev_0 - 0.5 * (sig_t * phi_1) * D1_0
+        return math.exp(la_t - la_p0) * x - (sig_t * phi_1) * model_prev_0 - (sig_t * (phi_1 / h - 1.0)) * D1_0
+
+    def multistep_dpm_solver_third_update(self, x, model_prev_list, t_prev_list, t, solver_type="dpmsolver"):
+        model_prev_2, model_prev_1, model_prev_0 = model_prev_list
+        t2, t1, t0, t = (self._host(v) for v in (t_prev_list[0], t_prev_list[1], t_prev_list[2], t))
+        _, _, lam_p2, _ = self._sched(t2)
+        _, _, lam_p1, _ = self._sched(t1)
+        la_p0, sig_p0, lam_p0, _ = self._sched(t0)
+        la_t, sig_t, lam_t, alpha_t = self._sched(t)
+        h_1 = lam_p1 - lam_p2
+        h_0 = lam_p0 - lam_p1
+        h = lam_t - lam_p0
+        r0, r1 = h_0 / h, h_1 / h
+        D1_0 = (1.0 / r0) * (model_prev_0 - model_prev_1)
+        D1_1 = (1.0 / r1) * (model_prev_1 - model_prev_2)
+        D1 = D1_0 + (r0 / (r0 + r1)) * (D1_0 - D1_1)
+        D2 = (1.0 / (r0 + r1)) * (D1_0 - D1_1)
+        if self.algorithm_type == "dpmsolver++":
+            phi_1 = math.expm1(-h)
+            phi_2 = phi_1 / h + 1.0
+            phi_3 = phi_2 / h - 0.5
+            return (sig_t / sig_p0) * x - (alpha_t * phi_1) * model_prev_0 + (alpha_t * phi_2) * D1 - (alpha_t * phi_3) * D2
+        phi_1 = math.expm1(h)
+        phi_2 = phi_1 / h - 1.0
+        phi_3 = phi_2 / h - 0.5
+        return math.exp(la_t - la_p0) * x - (sig_t * phi_1) * model_prev_0 - (sig_t * phi_2) * D1 - (sig_t * phi_3) * D2
+
+    def multistep_dpm_solver_update(self, x, model_prev_list, t_prev_list, t, order, solver_type="dpmsolver"):
+        if order == 1:
+            return self.dpm_solver_first_update(x, t_prev_list[-1], t, model_s=model_prev_list[-1])
+        if order == 2:
+            return self.multistep_dpm_solver_second_update(x, model_prev_list, t_prev_list, t, solver_type=solver_type)
+        if order == 3:
+            return self.multistep_dpm_solver_third_update(x, model_prev_list, t_prev_list, t, solver_type=solver_type)
+        raise ValueError("Solver order must be 1 or 2 or 3, got {}".format(order))
+
+    # ---- adaptive ---------------------------------------------------------------------------------------
+    def dpm_solver_adaptive(self, x, order, t_T, t_0, h_init=0.05, atol=0.0078, rtol=0.05, theta=0.9, t_err=1e-5,
+                            solver_type="dpmsolver"):
+        ns = self.noise_schedule
+        s = t_T * torch.ones((1,))
+        lambda_s = float(ns.marginal_lambda(s))
+        lambda_0 = float(ns.marginal_lambda(t_0 * torch.ones((1,))))
+        h = h_init
+        x_prev = x
+        nfe = 0
+        if order == 2:
+            r1 = 0.5
+            lower_update = lambda x, s, t: self.dpm_solver_first_update(x, s, t, return_intermediate=True)
+            higher_update = lambda x, s, t, **kw: self.singlestep_dpm_solver_second_update(x, s, t, r1=r1, solver_type=solver_type, **kw)
+        elif order == 3:
+            r1, r2 = 1.0 / 3.0, 2.0 / 3.0
+            lower_update = lambda x, s, t: self.singlestep_dpm_solver_second_update(x, s, t, r1=r1, return_intermediate=True, solver_type=solver_type)
+            higher_update = lambda x, s, t, **kw: self.singlestep_dpm_solver_third_update(x, s, t, r1=r1, r2=r2, solver_type=solver_type, **kw)
+        else:
+            raise ValueError("For adaptive step size solver, order must be 2 or 3, got {}".format(order))
+        while abs(float(s) - t_0) > t_err:
+            t = ns.inverse_lambda(torch.tensor([lambda_s + h], dtype=torch.float32))
+            x_lower, lower_noise_kwargs = lower_update(x, s, t)
+            x_higher = higher_update(x, s, t, **lower_noise_kwargs)
+            delta = torch.max(torch.ones_like(x) * atol, rtol * torch.max(torch.abs(x_lower), torch.abs(x_prev)))
+            v = (x_higher - x_lower) / delta
+            E = float(torch.sqrt(torch.square(v.reshape((v.shape[0], -1))).mean(dim=-1, keepdim=True)).max())  # the one sync
+            if E <= 1.0:
+                x = x_higher
+                s = t
+                x_prev = x_lower
+                lambda_s = float(ns.marginal_lambda(s))
+            h = min(theta * h * float(E) ** (-1.0 / order), lambda_0 - lambda_s)
+            nfe += order
+        print("adaptive solver nfe", nfe)
+        return x
+
+    def add_noise(self, x, t, noise=None):
+        """x_t = alpha_t x + sigma_t eps for a batch of times t (model/dpmsolver.py:1029-1043)."""
+        alpha_t = self.noise_schedule.marginal_alpha(t).to(x)
+        sigma_t = self.noise_schedule.marginal_std(t).to(x)
+        if noise is None:
+            noise = torch.randn((t.shape[0], *x.shape), device=x.device)
+        x = x.reshape((-1, *x.shape))
+        xt = expand_dims(alpha_t, x.dim()) * x + expand_dims(sigma_t, x.dim()) * noise
+        return xt.squeeze(0) if t.shape[0] == 1 else xt
+
+    def inverse(self, x, steps=20, t_start=None, t_end=None, order=2, skip_type="time_uniform", method="multistep",
+                lower_order_final=True, denoise_to_zero=False, solver_type="dpmsolver", atol=0.0078, rtol=0.05,
+                return_intermediate=False):
+        t_0 = 1.0 / self.noise_schedule.total_N if t_start is None else t_start
+        t_T = self.noise_schedule.T if t_end is None else t_end
+        assert t_0 > 0 and t_T > 0
+        return self.sample(x, steps=steps, t_start=t_0, t_end=t_T, order=order, skip_type=skip_type, method=method,
+                           lower_order_final=lower_order_final, denoise_to_zero=denoise_to_zero, solver_type=solver_type,
+                           atol=atol, rtol=rtol, return_intermediate=return_intermediate)
+
+    # ---- driver ---------------------------------------------------------------------------------------------
+    def sample(self, x, steps=20, t_start=None, t_end=None, order=2, skip_type="time_uniform", method="multistep",
+               lower_order_final=True, denoise_to_zero=False, solver_type="dpmsolver", atol=0.0078, rtol=0.05,
+               return_intermediate=False):
+        t_0 = 1.0 / self.noise_schedule.total_N if t_end is None else t_end
+        t_T = self.noise_schedule.T if t_start is None else t_start
+        assert t_0 > 0 and t_T > 0, "Time range needs to be greater than 0. For discrete-time DPMs, it needs to be in [1 / N, 1], where N is the length of betas array"
+        if return_intermediate:
+            assert method in ["multistep", "singlestep", "singlestep_fixed"], "Cannot use adaptive solver when saving intermediate values"
+        if self.correcting_xt_fn is not None:
+            assert method in ["multistep", "singlestep", "singlestep_fixed"], "Cannot use adaptive solver when correcting_xt_fn is not None"
+        intermediates = []
+        with torch.no_grad():
+            if method == "adaptive":
+                x = self.dpm_solver_adaptive(x, order=order, t_T=t_T, t_0=t_0, atol=atol, rtol=rtol, solver_type=solver_type)
+            elif method == "multistep":
+                assert steps >= order
+                timesteps = self.get_time_steps(skip_type=skip_type, t_T=t_T, t_0=t_0, N=steps)
+                assert timesteps.shape[0] - 1 == steps
+                step = 0
+                t = timesteps[step]
+                t_prev_list = [t]
+                model_prev_list = [self.model_fn(x, t)]
+                if self.correcting_xt_fn is not None:
+                    x = self.correcting_xt_fn(x, t, step)
+                if return_intermediate:
+                    intermediates.append(x)
+                for step in range(1, order):
+                    t = timesteps[step]
+                    x = self.multistep_dpm_solver_update(x, model_prev_list, t_prev_list, t, step, solver_type=solver_type)
+                    if self.correcting_xt_fn is not None:
+                        x = self.correcting_xt_fn(x, t, step)
+                    if return_intermediate:
+                        intermediates.append(x)
+                    t_prev_list.append(t)
+                    model_prev_list.append(self.model_fn(x, t))
+                for step in range(order, steps + 1):
+                    t = timesteps[step]
+                    step_order = min(order, steps + 1 - step) if (lower_order_final and steps < 10) else order
+                    x = self.multistep_dpm_solver_update(x, model_prev_list, t_prev_list, t, step_order, solver_type=solver_type)
+                    if self.correcting_xt_fn is not None:
+                        x = self.correcting_xt_fn(x, t, step)
+                    if return_intermediate:
+                        intermediates.append(x)
+                    for i in range(order - 1):
+                        t_prev_list[i] = t_prev_list[i + 1]
+                        model_prev_list[i] = model_prev_list[i + 1]
+                    t_prev_list[-1] = t
+                    if step < steps:  # the final model value is never needed
+                        model_prev_list[-1] = self.model_fn(x, t)
+            elif method in ["singlestep", "singlestep_fixed"]:
+                if method == "singlestep":
+                    timesteps_outer, orders = self.get_orders_and_timesteps_for_singlestep_solver(
+                        steps=steps, order=order, skip_type=skip_type, t_T=t_T, t_0=t_0)
+                else:
+                    K = steps // order
+                    orders = [order] * K
+                    timesteps_outer = self.get_time_steps(skip_type=skip_type, t_T=t_T, t_0=t_0, N=K)
+                for step, order in enumerate(orders):
+                    s, t = timesteps_outer[step], timesteps_outer[step + 1]
+                    timesteps_inner = self.get_time_steps(skip_type=skip_type, t_T=s.item(), t_0=t.item(), N=order)
+                    lambda_inner = self.noise_schedule.marginal_lambda(timesteps_inner)
+                    h = lambda_inner[-1] - lambda_inner[0]
+                    r1 = None if order <= 1 else (lambda_inner[1] - lambda_inner[0]) / h
+                    r2 = None if order <= 2 else (lambda_inner[2] - lambda_inner[0]) / h
+                    x = self.singlestep_dpm_solver_update(x, s, t, order, solver_type=solver_type, r1=r1, r2=r2)
+                    if self.correcting_xt_fn is not None:
+                        x = self.correcting_xt_fn(x, t, step)
+                    if return_intermediate:
+                        intermediates.append(x)
+            else:
+                raise ValueError("Got wrong method {}".format(method))
+            if denoise_to_zero:
+                t = torch.ones((1,)) * t_0
+                x = self.denoise_to_zero_fn(x, t)
+                if self.correcting_xt_fn is not None:
+                    x = self.correcting_xt_fn(x, t, step + 1)
+                if return_intermediate:
+                    intermediates.append(x)
+        return (x, intermediates) if return_intermediate else x

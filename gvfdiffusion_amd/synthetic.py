@@ -71,3 +71,37 @@ def random_deltas(T: int, P: int, seed: int = 1, std: float = 0.01) -> torch.Ten
     """(T,P,14) per-frame deltas ~ N(0,std) on all channels [xyz3|scale3|rot4|rgb3|op1]."""
     g = torch.Generator().manual_seed(seed)
     return torch.randn((T, P, 14), generator=g) * std
+
+
+# ---- DiT (configs/diffusion.yml) -----------------------------------------------------------------
+def dit_state_dict(manifest: dict, seed: int = 0) -> dict:
+    """Deterministic full-size DiT weights from a {name: shape} manifest (tests/golden/dit_manifest.json):
+    no checkpoint exists in this environment.  Matrices ~ N(0, 1/fan_in) so activations stay O(1) through 12
+    blocks, biases ~ N(0, 0.02^2), norm gains 1 + 0.1 N(0,1).  One generator per tensor, seeded by its
+    index in sorted-name order, so the reference and this package build bit-identical tensors."""
+    sd = {}
+    for idx, name in enumerate(sorted(manifest)):
+        shape = tuple(manifest[name])
+        g = torch.Generator().manual_seed(seed * 100003 + idx)
+        if name.endswith("gamma") or (name.endswith("weight") and len(shape) == 1):
+            w = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        elif len(shape) == 2:
+            w = torch.randn(shape, generator=g) / math.sqrt(shape[1])
+            if "adaLN_modulation" in name:
+                w = w * 0.2
+        else:
+            w = 0.02 * torch.randn(shape, generator=g)
+        sd[name] = w
+    return sd
+
+
+def dit_inputs(B: int = 1, T: int = 24, N: int = 512, L_img: int = 1370, L_static: int = 4096, C: int = 16,
+               img_channels: int = 1024, static_channels: int = 14, seed: int = 1) -> dict:
+    """BASELINE configs[2] inputs: x ~ N(0,1) (B,T,N,16), DINOv2-shaped cond_images (B,T,1370,1024),
+    static_latent (B,4096,14), deformation_position_xyz ~ U(-.5,.5) (B,N,3), t (B,)."""
+    g = torch.Generator().manual_seed(seed)
+    return dict(x=torch.randn((B, T, N, C), generator=g),
+                t=torch.full((B,), 498.996),
+                cond_images=torch.randn((B, T, L_img, img_channels), generator=g),
+                static_latent=torch.randn((B, L_static, static_channels), generator=g),
+                deformation_position_xyz=torch.rand((B, N, 3), generator=g) - 0.5)

@@ -120,7 +120,154 @@ def gen_vox2seq():
     print("vox2seq_golden.npz", {k: v.shape for k, v in out.items()})
 
 
-SECTIONS = {"raster": gen_raster, "vox2seq": gen_vox2seq}
+DIT_SMALL = dict(resolution=64, in_channels=16, model_channels=64, static_cond_channels=14, image_cond_channels=32,
+                 out_channels=16, num_blocks=2, num_heads=2, mlp_ratio=4, pe_mode="ape", qk_rms_norm=True,
+                 use_fp16=False, no_temporal_attn=False)
+
+
+def _randomise(model, seed):
+    """Reference init leaves zeros (adaLN_modulation[-1], final layer, all biases) and ones (RMS gamma,
+    LayerNorm weight): re-draw them so that every parameter influences the golden output."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if p.abs().max() == 0:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+            elif (p == 1).all():
+                p.copy_(1 + 0.1 * torch.randn(p.shape, generator=g))
+
+
+def gen_dit():
+    import json
+    import yaml
+    from model.dit import DiT, TimestepEmbedder, AbsolutePositionEmbedder
+    from model.attention import MultiHeadRMSNorm
+    sys.path.insert(0, os.path.join(OUT, "..", ".."))
+    from gvfdiffusion_amd import synthetic
+
+    # (1) reduced model, full structure: weights travel inside the fixture
+    torch.manual_seed(0)
+    model = DiT(**DIT_SMALL).eval()
+    _randomise(model, 1)
+    g = torch.Generator().manual_seed(2)
+    B, T, N, Li, Ls = 2, 3, 40, 37, 50
+    x = torch.randn((B, T, N, 16), generator=g)
+    t = torch.tensor([998.996, 431.25])
+    cond = torch.randn((B, T, Li, 32), generator=g)
+    static = torch.randn((B, Ls, 14), generator=g)
+    xyz = torch.rand((B, N, 3), generator=g) - 0.5
+    out = {"cfg_json": np.frombuffer(json.dumps(DIT_SMALL).encode(), dtype=np.uint8)}
+    with torch.no_grad():
+        y = model(x, t, cond_images=cond, static_latent=static, deformation_position_xyz=xyz)
+        out["t_freq"] = TimestepEmbedder.timestep_embedding(t, 256).numpy()
+        out["t_emb"] = model.t_embedder(t).numpy()
+        out["ape"] = model.pos_embedder(xyz).numpy()
+        h0 = model.input_layer(x) + model.pos_embedder(xyz).unsqueeze(1).repeat(1, T, 1, 1)
+        out["h0"] = h0.numpy()
+        image_emb = model.image_cond_proj(cond)
+        static_emb = model.static_cond_proj(static).unsqueeze(1).repeat(1, T, 1, 1)
+        out["block0"] = model.blocks[0](h0, model.t_embedder(t), image_emb, static_emb).numpy()
+        rms = model.blocks[0].spatial_self_attn.q_rms_norm
+        q = torch.randn((3, 5, 2, 32), generator=g)
+        out["rms_in"], out["rms_out"] = q.numpy(), rms(q).numpy()
+    out.update(x=x.numpy(), t=t.numpy(), cond_images=cond.numpy(), static_latent=static.numpy(), xyz=xyz.numpy(),
+               y=y.numpy())
+    for k, v in model.state_dict().items():
+        out["sd." + k] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "dit_small_golden.npz"), **out)
+    print("dit_small_golden.npz", len(out), "arrays,", y.shape, float(y.abs().mean()))
+
+    # (2) the real configuration (configs/diffusion.yml): state_dict manifest + full-shape forward with
+    #     seed-generated weights (gvfdiffusion_amd.synthetic.dit_state_dict) and seed-generated inputs
+    cfg = yaml.safe_load(open(f"{REF}/configs/diffusion.yml"))["model"]
+    torch.manual_seed(0)
+    model = DiT(**cfg).eval()
+    manifest = {k: list(v.shape) for k, v in model.state_dict().items()}
+    json.dump({"config": cfg, "state_dict": manifest}, open(os.path.join(OUT, "dit_manifest.json"), "w"), indent=0)
+    sd = synthetic.dit_state_dict(manifest, seed=0)
+    model.load_state_dict(sd)
+    inp = synthetic.dit_inputs(B=1, T=24, seed=1)
+    import time
+    t0 = time.time()
+    with torch.no_grad():
+        y = model(inp["x"], inp["t"], cond_images=inp["cond_images"], static_latent=inp["static_latent"],
+                  deformation_position_xyz=inp["deformation_position_xyz"])
+    print("full-config reference forward: %.1f s" % (time.time() - t0), y.shape, float(y.abs().mean()), float(y.std()))
+    np.savez_compressed(os.path.join(OUT, "dit_full_golden.npz"), y=y.numpy(), t=inp["t"].numpy())
+
+
+def gen_sampler():
+    from model.dpmsolver import NoiseScheduleVP, model_wrapper, DPM_Solver
+    from utils.script_util import create_gaussian_diffusion
+    import yaml
+    cfg = yaml.safe_load(open(f"{REF}/configs/diffusion.yml"))["diffusion"]
+    diffusion = create_gaussian_diffusion(**cfg)
+    betas = diffusion.betas
+    ns = NoiseScheduleVP("discrete", betas=torch.from_numpy(betas))   # inference_dpm_latent.py:156
+    out = {"betas": betas, "total_N": np.int64(ns.total_N), "log_alpha_array": ns.log_alpha_array.numpy(),
+           "t_array": ns.t_array.numpy()}
+    tt = torch.cat([torch.linspace(1e-3, 1.0, 61), torch.tensor([0.5, 0.001, 1.0])]).float()
+    out["t_query"] = tt.numpy()
+    out["alpha_t"], out["sigma_t"] = ns.marginal_alpha(tt).numpy(), ns.marginal_std(tt).numpy()
+    out["lambda_t"] = ns.marginal_lambda(tt).numpy()
+    lam = torch.linspace(-5.0, 5.0, 41).float()
+    out["lam_query"], out["inv_lambda"] = lam.numpy(), ns.inverse_lambda(lam).numpy()
+
+    # toy v-prediction model with conditions (kwargs arrive exactly as the DiT's do)
+    calls = {"n": 0}
+
+    def toy(x, t_input, cond_images=None, static_latent=None, deformation_position_xyz=None):
+        calls["n"] += 1
+        c = 0.0
+        if cond_images is not None:
+            c = c + 0.05 * cond_images.mean(dim=(1, 2, 3)).reshape(-1, 1, 1, 1)
+        if static_latent is not None:
+            c = c + 0.03 * static_latent.mean(dim=(1, 2)).reshape(-1, 1, 1, 1)
+        return 0.3 * x * torch.cos(t_input / 200.0).reshape(-1, 1, 1, 1) + 0.1 * torch.sin(3 * x) + c
+
+    g = torch.Generator().manual_seed(5)
+    B, T, N, C = 2, 3, 8, 16
+    xT = torch.randn((B, T, N, C), generator=g)
+    cond = {"cond_images": torch.randn((B, T, 5, 7), generator=g), "static_latent": torch.randn((B, 6, 14), generator=g),
+            "deformation_position_xyz": torch.rand((B, N, 3), generator=g)}
+    uncond = dict(cond); uncond["cond_images"] = torch.zeros_like(cond["cond_images"])
+    out.update(xT=xT.numpy(), cond_images=cond["cond_images"].numpy(), static_latent=cond["static_latent"].numpy(),
+               xyz=cond["deformation_position_xyz"].numpy())
+    for tag, (s1, s2) in {"g11": (1.0, 1.0), "g23": (2.0, 3.0)}.items():
+        mf = model_wrapper(toy, ns, model_type="v", model_kwargs={}, guidance_type="classifier-free", guidance_scale=s1,
+                           guidance_scale2=s2, condition=cond, unconditional_condition=uncond)
+        out[f"wrap_{tag}"] = mf(xT, torch.tensor([0.7, 0.7])).numpy()
+        solver = DPM_Solver(mf, ns, algorithm_type="dpmsolver++")
+        for steps in (4, 20, 32):
+            calls["n"] = 0
+            out[f"multistep_{tag}_{steps}"] = solver.sample(xT, steps=steps, t_start=1.0, t_end=1 / 1000, order=2,
+                                                            skip_type="time_uniform", method="multistep").numpy()
+            out[f"multistep_{tag}_{steps}_nfe"] = np.int64(calls["n"])
+        calls["n"] = 0
+        out[f"adaptive_{tag}"] = solver.sample(xT, steps=100, t_start=1.0, t_end=1 / 1000, order=2,
+                                               skip_type="time_uniform", method="adaptive").numpy()
+        out[f"adaptive_{tag}_nfe"] = np.int64(calls["n"])
+        calls["n"] = 0
+        out[f"singlestep_{tag}_12"] = solver.sample(xT, steps=12, t_start=1.0, t_end=1 / 1000, order=2,
+                                                    skip_type="time_uniform", method="singlestep").numpy()
+        out[f"singlestep_{tag}_12_nfe"] = np.int64(calls["n"])
+    # every solver branch once (algorithm x method x order x solver_type x skip_type), unconditional toy model
+    mf = model_wrapper(toy, ns, model_type="v", guidance_type="uncond")
+    for alg in ("dpmsolver", "dpmsolver++"):
+        solver = DPM_Solver(mf, ns, algorithm_type=alg)
+        for method, order, skip in (("multistep", 1, "time_uniform"), ("multistep", 3, "logSNR"),
+                                    ("singlestep", 3, "time_quadratic"), ("singlestep", 2, "logSNR"),
+                                    ("singlestep_fixed", 2, "time_uniform"), ("singlestep_fixed", 3, "time_uniform"),
+                                    ("adaptive", 3, "time_uniform")):
+            for st in ("dpmsolver", "taylor"):
+                key = f"var_{alg}_{method}_{order}_{skip}_{st}"
+                out[key] = solver.sample(xT, steps=13, t_start=1.0, t_end=1 / 1000, order=order, skip_type=skip,
+                                         method=method, solver_type=st, denoise_to_zero=(st == "taylor")).numpy()
+    np.savez_compressed(os.path.join(OUT, "sampler_golden.npz"), **out)
+    print("sampler_golden.npz", {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if "nfe" in k or k == "total_N"})
+
+
+SECTIONS = {"raster": gen_raster, "vox2seq": gen_vox2seq, "dit": gen_dit, "sampler": gen_sampler}
 
 if __name__ == "__main__":
     install_stubs()

@@ -1,0 +1,63 @@
+"""The torch DiT oracle (oracle/dit_ref.py) against outputs of the reference's model/dit.py
+(tests/golden/dit_small_golden.npz: reduced width, full structure, weights inside the fixture;
+dit_full_golden.npz: configs/diffusion.yml at B=1,T=24 with seed-generated weights and inputs)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from oracle import dit_ref
+from gvfdiffusion_amd import synthetic
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load_small():
+    g = np.load(os.path.join(GOLD, "dit_small_golden.npz"))
+    cfg = json.loads(bytes(g["cfg_json"]).decode())
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")}
+    return g, cfg, sd
+
+
+def test_subops_match_reference():
+    g, cfg, sd = load_small()
+    t = torch.from_numpy(g["t"])
+    assert np.abs(dit_ref.timestep_embedding(t).numpy() - g["t_freq"]).max() < 1e-6      # cos first, then sin
+    ape = dit_ref.absolute_position_embedding(torch.from_numpy(g["xyz"]), cfg["model_channels"])
+    assert np.abs(ape.numpy() - g["ape"]).max() < 1e-6
+    assert (ape[..., (cfg["model_channels"] // 3 // 2) * 6:] == 0).all()                  # zero padding tail
+    gamma = sd["blocks.0.spatial_self_attn.q_rms_norm.gamma"]
+    rms = dit_ref.rms_norm_heads(torch.from_numpy(g["rms_in"]), gamma, "fp32")
+    assert np.abs(rms.numpy() - g["rms_out"]).max() < 1e-5
+
+
+def test_small_model_forward_matches_reference():
+    g, cfg, sd = load_small()
+    args = [torch.from_numpy(g[k]) for k in ("x", "t", "cond_images", "static_latent", "xyz")]
+    with torch.no_grad():
+        y, inter = dit_ref.dit_forward(sd, cfg, *args, precision="fp32", return_intermediates=True)
+    assert np.abs(inter["t_emb"].numpy() - g["t_emb"]).max() < 1e-5
+    assert np.abs(inter["h0"].numpy() - g["h0"]).max() < 1e-5
+    assert np.abs(inter["block0"].numpy() - g["block0"]).max() < 5e-5
+    err = np.abs(y.numpy() - g["y"]).max()
+    assert err < 5e-5, err
+    # the bf16-emulating mode stays close to fp32 (sanity of the rounding model, not a parity claim)
+    with torch.no_grad():
+        yb = dit_ref.dit_forward(sd, cfg, *args, precision="bf16")
+    rel = float((yb - y).norm() / y.norm())
+    assert rel < 3e-2, rel
+
+
+def test_full_config_forward_matches_reference():
+    """configs/diffusion.yml, B=1, T=24, 1370 image tokens, 4096 static tokens (5.04 TFLOP on the CPU)."""
+    man = json.load(open(os.path.join(GOLD, "dit_manifest.json")))
+    assert len(man["state_dict"]) == 446
+    sd = synthetic.dit_state_dict(man["state_dict"], seed=0)
+    inp = synthetic.dit_inputs(B=1, T=24, seed=1)
+    gold = np.load(os.path.join(GOLD, "dit_full_golden.npz"))
+    with torch.no_grad():
+        y = dit_ref.dit_forward(sd, man["config"], inp["x"], inp["t"], inp["cond_images"], inp["static_latent"],
+                                inp["deformation_position_xyz"], precision="fp32")
+    err = np.abs(y.numpy() - gold["y"])
+    assert err.max() < 2e-3 and err.mean() < 5e-5, (err.max(), err.mean())               # fp32 accumulation-order noise
