@@ -1,0 +1,159 @@
+// elem.hip -- memory-bound helpers of the DiT block for gfx950: fused LayerNorm + (affine | adaLN
+// modulate) writing the bf16 GEMM operand, and fp32 -> bf16 cast with zero padding / SiLU.
+//
+// Reference: model/dit.py:168-172,246-277 (norm1..5: LayerNorm(eps 1e-6), affine only on norm3/4;
+// h * (1 + scale) + shift), model/dit.py:217-225,240-242 (SiLU in front of the adaLN Linear).
+// One wave per row (C <= 1024): the row is read once with 16-byte loads and kept in registers for the
+// mean / variance / normalise passes (two-pass variance, as torch's LayerNorm computes it).
+#include "gvf_common.h"
+#include "../../include/gvf_rast.h"
+#include "../../include/gvf_dit.h"
+
+namespace {
+
+__device__ __forceinline__ unsigned short f2bf(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+// VPL = float4 loads per lane: C = 64 * 4 * VPL
+template <int VPL>
+__global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ x, unsigned short* __restrict__ out,
+                                                     int rows, int C, float eps, const float* __restrict__ ln_w,
+                                                     const float* __restrict__ ln_b, const float* __restrict__ shift,
+                                                     const float* __restrict__ scale, int mod_ld, int rpg) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * C);
+    float4 v[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        v[i] = xr[lane + 64 * i];
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+        q += (a * a + b * b) + (c * c + d * d);
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    const int g = row / rpg;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c0 = (lane + 64 * i) * 4;
+        float y[4] = {(v[i].x - mean) * rstd, (v[i].y - mean) * rstd, (v[i].z - mean) * rstd, (v[i].w - mean) * rstd};
+        if (ln_w != nullptr) {
+            const float4 w4 = *reinterpret_cast<const float4*>(ln_w + c0);
+            const float4 b4 = *reinterpret_cast<const float4*>(ln_b + c0);
+            y[0] = y[0] * w4.x + b4.x; y[1] = y[1] * w4.y + b4.y; y[2] = y[2] * w4.z + b4.z; y[3] = y[3] * w4.w + b4.w;
+        }
+        if (scale != nullptr) {
+            const float4 sc = *reinterpret_cast<const float4*>(scale + (size_t)g * mod_ld + c0);
+            const float4 sh = *reinterpret_cast<const float4*>(shift + (size_t)g * mod_ld + c0);
+            y[0] = y[0] * (1.0f + sc.x) + sh.x; y[1] = y[1] * (1.0f + sc.y) + sh.y;
+            y[2] = y[2] * (1.0f + sc.z) + sh.z; y[3] = y[3] * (1.0f + sc.w) + sh.w;
+        }
+        uint2 o;
+        o.x = (unsigned)f2bf(y[0]) | ((unsigned)f2bf(y[1]) << 16);
+        o.y = (unsigned)f2bf(y[2]) | ((unsigned)f2bf(y[3]) << 16);
+        *reinterpret_cast<uint2*>(out + (size_t)row * C + c0) = o;
+    }
+}
+
+// any C (multiple of 4): the row is re-read from cache for each pass
+__global__ __launch_bounds__(256) void ln_mod_generic_kernel(const float* __restrict__ x, unsigned short* __restrict__ out,
+                                                             int rows, int C, float eps, const float* __restrict__ ln_w,
+                                                             const float* __restrict__ ln_b, const float* __restrict__ shift,
+                                                             const float* __restrict__ scale, int mod_ld, int rpg) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += xr[c];
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+    for (int c = lane; c < C; c += 64) { const float a = xr[c] - mean; q += a * a; }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    const int g = row / rpg;
+    for (int c = lane; c < C; c += 64) {
+        float y = (xr[c] - mean) * rstd;
+        if (ln_w != nullptr) y = y * ln_w[c] + ln_b[c];
+        if (scale != nullptr) y = y * (1.0f + scale[(size_t)g * mod_ld + c]) + shift[(size_t)g * mod_ld + c];
+        out[(size_t)row * C + c] = f2bf(y);
+    }
+}
+
+__global__ __launch_bounds__(256) void cast_pad_kernel(const float* __restrict__ src, int ld_src,
+                                                       unsigned short* __restrict__ dst, int ld_dst, long long rows,
+                                                       int cols, int act) {
+    const long long total = rows * (long long)ld_dst;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / ld_dst;
+        const int c = (int)(i - r * ld_dst);
+        float v = 0.f;
+        if (c < cols) {
+            v = src[r * ld_src + c];
+            if (act == 1) v = v / (1.0f + __expf(-v));
+        }
+        dst[i] = f2bf(v);
+    }
+}
+
+}  // namespace
+
+extern "C" int gvf_layernorm_modulate_bf16(const float* x, void* out_bf16, int rows, int C, float eps, const float* ln_w,
+                                           const float* ln_b, const float* shift, const float* scale, int mod_ld,
+                                           int rows_per_group, void* stream_) {
+    if (rows < 0 || C <= 0) return GVF_EINVAL;
+    if (rows == 0) return GVF_OK;
+    if (!x || !out_bf16 || ((ln_w == nullptr) != (ln_b == nullptr)) || ((shift == nullptr) != (scale == nullptr)))
+        return GVF_EINVAL;
+    if (scale != nullptr && (rows_per_group <= 0 || ((C % 256) == 0 && (mod_ld % 4) != 0))) return GVF_EINVAL;
+    if ((((uintptr_t)x) & 15) || (((uintptr_t)out_bf16) & 7)) return GVF_EINVAL;
+    hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();
+    const int rpg = rows_per_group > 0 ? rows_per_group : 1;
+    const dim3 grid((rows + 3) / 4), block(256);
+    unsigned short* o = (unsigned short*)out_bf16;
+    if ((C % 256) != 0 || C > 1024) {
+        hipLaunchKernelGGL(ln_mod_generic_kernel, grid, block, 0, stream, x, o, rows, C, eps, ln_w, ln_b, shift, scale, mod_ld, rpg);
+        GVF_CHECK_LAUNCH();
+        return GVF_OK;
+    }
+    switch (C / 256) {
+        case 1: hipLaunchKernelGGL(ln_mod_kernel<1>, grid, block, 0, stream, x, o, rows, C, eps, ln_w, ln_b, shift, scale, mod_ld, rpg); break;
+        case 2: hipLaunchKernelGGL(ln_mod_kernel<2>, grid, block, 0, stream, x, o, rows, C, eps, ln_w, ln_b, shift, scale, mod_ld, rpg); break;
+        case 3: hipLaunchKernelGGL(ln_mod_kernel<3>, grid, block, 0, stream, x, o, rows, C, eps, ln_w, ln_b, shift, scale, mod_ld, rpg); break;
+        default: hipLaunchKernelGGL(ln_mod_kernel<4>, grid, block, 0, stream, x, o, rows, C, eps, ln_w, ln_b, shift, scale, mod_ld, rpg); break;
+    }
+    GVF_CHECK_LAUNCH();
+    return GVF_OK;
+}
+
+extern "C" int gvf_cast_pad_bf16(const float* src, int ld_src, void* dst, int ld_dst, int64_t rows, int cols, int act,
+                                 void* stream_) {
+    if (rows < 0 || cols <= 0 || ld_src < cols || ld_dst < cols || (act != 0 && act != 1)) return GVF_EINVAL;
+    if (rows == 0) return GVF_OK;
+    if (!src || !dst) return GVF_EINVAL;
+    (void)hipGetLastError();
+    long long total = rows * (long long)ld_dst;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(cast_pad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, src, ld_src,
+                       (unsigned short*)dst, ld_dst, (long long)rows, cols, act);
+    GVF_CHECK_LAUNCH();
+    return GVF_OK;
+}

@@ -1,0 +1,387 @@
+"""Temporal-aware DiT with the reference's module surface (model/dit.py:16-480): same constructor
+keywords, same parameter names (the 446-tensor state_dict of configs/diffusion.yml loads unchanged),
+same forward(x, t, cond_images, static_latent, deformation_position_xyz) contract.
+
+The forward pass does not call the sub-modules one by one: it drives the gfx950 kernels directly
+(csrc/gemm.hip, attn.hip, elem.hip through ops/dit_ops.py) so that
+  * LayerNorm + adaLN modulate / affine is one kernel that writes the bf16 GEMM operand,
+  * gate * h + residual is the epilogue of the to_out / mlp.2 GEMMs on the fp32 residual stream,
+  * GELU-tanh is the epilogue of mlp.0, QK-RMSNorm lives in the attention operand loads,
+  * the (B,T,N,C) <-> (B,N,T,C) transposes of the temporal attention are strides, not copies,
+  * all 25 adaLN projections of a step are ONE GEMM over a concatenated weight,
+  * everything that depends only on the conditions -- image_cond_proj, static_cond_proj, every block's
+    to_kv(context), the position embedding -- is computed once per condition set and reused for all
+    NFEs (static K/V additionally once per sample instead of once per frame: dit.py:465 repeats it over T).
+Numerics follow torch.autocast placement: bf16 contraction operands, fp32 accumulation, fp32 residual
+stream / LayerNorm / softmax / modulation (the reference runs fp16 autocast; bf16 per BASELINE.json).
+There is no CPU path: CPU tensors raise (the fp32 CPU restatement lives in oracle/dit_ref.py, tests only).
+"""
+import math
+from typing import *
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .attention import MultiHeadAttention
+from ..ops import dit_ops
+from .. import _lib
+
+
+class AbsolutePositionEmbedder(nn.Module):
+    """(B, L, in_channels) positions -> (B, L, channels): per axis [sin(x f_i), cos(x f_i)], zero-padded
+    (model/dit.py:16-56).  Step-invariant, evaluated once per condition set with torch device ops."""
+
+    def __init__(self, channels: int, in_channels: int = 3):
+        super().__init__()
+        self.channels = channels
+        self.in_channels = in_channels
+        self.freq_dim = channels // in_channels // 2
+        freqs = torch.arange(self.freq_dim, dtype=torch.float32) / self.freq_dim
+        self.freqs = 1.0 / (10000 ** freqs)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        B, L, D = x.shape
+        assert D == self.in_channels, "Input dimension must match number of input channels"
+        self.freqs = self.freqs.to(x.device)
+        out = torch.outer(x.reshape(-1).float(), self.freqs)
+        emb = torch.cat([torch.sin(out), torch.cos(out)], dim=-1).reshape(B * L, -1)
+        if emb.shape[1] < self.channels:
+            emb = torch.cat([emb, torch.zeros(B * L, self.channels - emb.shape[1], device=emb.device)], dim=-1)
+        return emb.reshape(B, L, -1)
+
+
+class TimestepEmbedder(nn.Module):
+    """[cos | sin](t * 10000^(-i/128)) -> Linear -> SiLU -> Linear (model/dit.py:59-100)."""
+
+    def __init__(self, hidden_size, frequency_embedding_size=256):
+        super().__init__()
+        self.mlp = nn.Sequential(nn.Linear(frequency_embedding_size, hidden_size, bias=True), nn.SiLU(),
+                                 nn.Linear(hidden_size, hidden_size, bias=True))
+        self.frequency_embedding_size = frequency_embedding_size
+
+    @staticmethod
+    def timestep_embedding(t, dim, max_period=10000):
+        half = dim // 2
+        freqs = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32, device=t.device) / half)
+        args = t[:, None].float() * freqs[None]
+        emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+        if dim % 2:
+            emb = torch.cat([emb, torch.zeros_like(emb[:, :1])], dim=-1)
+        return emb
+
+
+class FeedForwardNet(nn.Module):
+    def __init__(self, channels: int, mlp_ratio: float = 4.0):
+        super().__init__()
+        self.mlp = nn.Sequential(nn.Linear(channels, int(channels * mlp_ratio)), nn.GELU(approximate="tanh"),
+                                 nn.Linear(int(channels * mlp_ratio), channels))
+
+
+class ModulatedSparseTransformerCrossBlock(nn.Module):
+    """Parameter container of one block (model/dit.py:141-225); executed by DiT.forward."""
+
+    def __init__(self, channels: int, ctx_channels: int, num_heads: int, mlp_ratio: float = 4.0, attn_mode="full",
+                 window_size=None, shift_sequence=None, shift_window=None, serialize_mode=None, use_checkpoint=False,
+                 use_rope=False, qk_rms_norm=False, qk_rms_norm_cross=False, qkv_bias=True, share_mod=False,
+                 no_temporal_attn=False):
+        super().__init__()
+        self.use_checkpoint = use_checkpoint
+        self.share_mod = share_mod
+        self.no_temporal_attn = no_temporal_attn
+        self.norm1 = nn.LayerNorm(channels, elementwise_affine=False, eps=1e-6)
+        self.norm2 = nn.LayerNorm(channels, elementwise_affine=False, eps=1e-6) if not no_temporal_attn else nn.Identity()
+        self.norm3 = nn.LayerNorm(channels, elementwise_affine=True, eps=1e-6)
+        self.norm4 = nn.LayerNorm(channels, elementwise_affine=True, eps=1e-6)
+        self.norm5 = nn.LayerNorm(channels, elementwise_affine=False, eps=1e-6)
+        mk = dict(num_heads=num_heads, qkv_bias=qkv_bias)
+        self.spatial_self_attn = MultiHeadAttention(channels, type="self", attn_mode=attn_mode, window_size=window_size,
+                                                    shift_window=shift_window, use_rope=use_rope, qk_rms_norm=qk_rms_norm, **mk)
+        self.temporal_self_attn = MultiHeadAttention(channels, type="self", attn_mode=attn_mode, window_size=window_size,
+                                                     shift_window=shift_window, use_rope=use_rope, qk_rms_norm=qk_rms_norm,
+                                                     **mk) if not no_temporal_attn else nn.Identity()
+        self.image_cross_attn = MultiHeadAttention(channels, ctx_channels=ctx_channels, type="cross", attn_mode="full",
+                                                   qk_rms_norm=qk_rms_norm_cross, **mk)
+        self.static_cross_attn = MultiHeadAttention(channels, ctx_channels=ctx_channels, type="cross", attn_mode="full",
+                                                    qk_rms_norm=qk_rms_norm_cross, **mk)
+        self.mlp = FeedForwardNet(channels, mlp_ratio=mlp_ratio)
+        if not share_mod:
+            self.adaLN_modulation = nn.Sequential(nn.SiLU(), nn.Linear(channels, 6 * channels, bias=True))
+            self.adaLN_modulation_temporal = nn.Sequential(nn.SiLU(), nn.Linear(channels, 3 * channels, bias=True)) \
+                if not no_temporal_attn else nn.Identity()
+
+
+class FinalLayer(nn.Module):
+    def __init__(self, hidden_size, out_channels):
+        super().__init__()
+        self.norm_final = nn.LayerNorm(hidden_size, elementwise_affine=False, eps=1e-6)
+        self.linear = nn.Linear(hidden_size, out_channels, bias=True)
+        self.adaLN_modulation = nn.Sequential(nn.SiLU(), nn.Linear(hidden_size, 2 * hidden_size, bias=True))
+
+
+class DiT(nn.Module):
+    def __init__(self, resolution: int, in_channels: int, model_channels: int, static_cond_channels: int,
+                 image_cond_channels: int, out_channels: int, num_blocks: int, num_heads: Optional[int] = None,
+                 num_head_channels: Optional[int] = 64, mlp_ratio: float = 4, patch_size: int = 1,
+                 pe_mode: Literal["ape", "rope", "learnable", "none"] = "learnable", use_fp16: bool = False,
+                 use_checkpoint: bool = False, use_skip_connection: bool = True, share_mod: bool = False,
+                 qk_rms_norm: bool = False, qk_rms_norm_cross: bool = False, no_temporal_attn: bool = True):
+        super().__init__()
+        self.resolution = resolution
+        self.in_channels = in_channels
+        self.model_channels = model_channels
+        self.static_cond_channels = static_cond_channels
+        self.image_cond_channels = image_cond_channels
+        self.out_channels = out_channels
+        self.num_blocks = num_blocks
+        self.num_heads = num_heads or model_channels // num_head_channels
+        self.mlp_ratio = mlp_ratio
+        self.patch_size = patch_size
+        self.pe_mode = pe_mode
+        self.use_fp16 = use_fp16
+        self.use_checkpoint = use_checkpoint
+        self.use_skip_connection = use_skip_connection
+        self.share_mod = share_mod
+        self.qk_rms_norm = qk_rms_norm
+        self.qk_rms_norm_cross = qk_rms_norm_cross
+        self.dtype = torch.float16 if use_fp16 else torch.float32
+        self.no_temporal_attn = no_temporal_attn
+        assert int(np.log2(patch_size)) == np.log2(patch_size), "Patch size must be a power of 2"
+        if share_mod:
+            raise NotImplementedError("share_mod=True is not built (configs/diffusion.yml uses per-block adaLN)")
+        if pe_mode == "rope":
+            raise NotImplementedError("pe_mode='rope' is not built (configs/diffusion.yml uses 'ape')")
+
+        self.t_embedder = TimestepEmbedder(model_channels)
+        if pe_mode == "ape":
+            self.pos_embedder = AbsolutePositionEmbedder(model_channels)
+        elif pe_mode == "learnable":
+            self.pos_embedder = nn.Parameter(torch.randn(1, resolution, model_channels))
+        self.input_layer = nn.Linear(in_channels, model_channels)
+        self.blocks = nn.ModuleList([
+            ModulatedSparseTransformerCrossBlock(model_channels, model_channels, num_heads=self.num_heads,
+                                                 mlp_ratio=self.mlp_ratio, attn_mode="full",
+                                                 use_checkpoint=self.use_checkpoint, use_rope=False,
+                                                 share_mod=self.share_mod, qk_rms_norm=self.qk_rms_norm,
+                                                 qk_rms_norm_cross=self.qk_rms_norm_cross,
+                                                 no_temporal_attn=self.no_temporal_attn)
+            for _ in range(num_blocks)])
+        self.final_layer = FinalLayer(model_channels, out_channels)
+        self.static_cond_proj = nn.Linear(static_cond_channels, model_channels)
+        self.image_cond_proj = nn.Linear(image_cond_channels, model_channels)
+        self.initialize_weights()
+        self._wcache = None       # bf16 weights, rebuilt when any parameter changes
+        self._ctx_cache = {}      # step-invariant condition products
+
+    @property
+    def device(self) -> torch.device:
+        return next(self.parameters()).device
+
+    def initialize_weights(self) -> None:
+        """Same scheme as model/dit.py:401-427 (xavier Linear, zero bias, N(0,0.02) embedders, zero adaLN / head)."""
+        def _basic_init(module):
+            if isinstance(module, nn.Linear):
+                torch.nn.init.xavier_uniform_(module.weight)
+                if module.bias is not None:
+                    nn.init.constant_(module.bias, 0)
+        self.apply(_basic_init)
+        nn.init.normal_(self.t_embedder.mlp[0].weight, std=0.02)
+        nn.init.normal_(self.t_embedder.mlp[2].weight, std=0.02)
+        nn.init.normal_(self.static_cond_proj.weight, std=0.02)
+        nn.init.normal_(self.image_cond_proj.weight, std=0.02)
+        for block in self.blocks:
+            nn.init.constant_(block.adaLN_modulation[-1].weight, 0)
+            nn.init.constant_(block.adaLN_modulation[-1].bias, 0)
+        nn.init.constant_(self.final_layer.adaLN_modulation[-1].weight, 0)
+        nn.init.constant_(self.final_layer.adaLN_modulation[-1].bias, 0)
+        nn.init.constant_(self.final_layer.linear.weight, 0)
+        nn.init.constant_(self.final_layer.linear.bias, 0)
+
+    # ---- weight preparation ---------------------------------------------------------------------
+    def _param_version(self):
+        return tuple((p._version, p.data_ptr()) for p in self.parameters())
+
+    def _weights(self):
+        ver = self._param_version()
+        if self._wcache is not None and self._wcache["ver"] == ver:
+            return self._wcache
+
+        def prep(lin):
+            w = lin.weight.detach().float().contiguous()
+            return dit_ops.cast_pad_bf16(w, dit_ops.pad64(w.shape[1])), \
+                (None if lin.bias is None else lin.bias.detach().float().contiguous())
+
+        W = {"ver": ver}
+        W["input"] = prep(self.input_layer)
+        W["t0"], W["t2"] = prep(self.t_embedder.mlp[0]), prep(self.t_embedder.mlp[2])
+        W["img"], W["static"] = prep(self.image_cond_proj), prep(self.static_cond_proj)
+        W["final"] = prep(self.final_layer.linear)
+        # all adaLN projections of a step as one GEMM: rows = [blk0: 6C | 3C, blk1: ..., final: 2C]
+        mods_w, mods_b, offs, o = [], [], [], 0
+        for blk in self.blocks:
+            parts = [blk.adaLN_modulation[-1]] + ([] if self.no_temporal_attn else [blk.adaLN_modulation_temporal[-1]])
+            offs.append(o)
+            for lin in parts:
+                mods_w.append(lin.weight.detach().float())
+                mods_b.append(lin.bias.detach().float())
+                o += lin.out_features
+        offs.append(o)
+        mods_w.append(self.final_layer.adaLN_modulation[-1].weight.detach().float())
+        mods_b.append(self.final_layer.adaLN_modulation[-1].bias.detach().float())
+        W["mod_w"] = dit_ops.cast_pad_bf16(torch.cat(mods_w).contiguous(), dit_ops.pad64(self.model_channels))
+        W["mod_b"] = torch.cat(mods_b).contiguous()
+        W["mod_offs"], W["mod_total"] = offs, W["mod_b"].numel()
+        W["blocks"] = []
+        for blk in self.blocks:
+            b = {}
+            for name in ("spatial_self_attn", "temporal_self_attn"):
+                m = getattr(blk, name)
+                if isinstance(m, MultiHeadAttention):
+                    b[name] = dict(qkv=prep(m.to_qkv), out=prep(m.to_out), gq=m._gammas()[0], gk=m._gammas()[1])
+            for name in ("image_cross_attn", "static_cross_attn"):
+                m = getattr(blk, name)
+                b[name] = dict(q=prep(m.to_q), kv=prep(m.to_kv), out=prep(m.to_out), gq=m._gammas()[0], gk=m._gammas()[1])
+            b["fc1"], b["fc2"] = prep(blk.mlp.mlp[0]), prep(blk.mlp.mlp[2])
+            b["n3"] = (blk.norm3.weight.detach().float().contiguous(), blk.norm3.bias.detach().float().contiguous())
+            b["n4"] = (blk.norm4.weight.detach().float().contiguous(), blk.norm4.bias.detach().float().contiguous())
+            W["blocks"].append(b)
+        self._wcache = W
+        self._ctx_cache = {}
+        return W
+
+    # ---- step-invariant condition products ------------------------------------------------------------
+    @staticmethod
+    def _key(t):
+        return None if t is None else (t.data_ptr(), t._version, tuple(t.shape), t.dtype)
+
+    def prepare_conditions(self, cond_images, static_latent, deformation_position_xyz, T: int):
+        """image_emb / static_emb -> per-block cross-attention K,V (bf16), and the APE; cached on the identity
+        (pointer, version, shape) of the three condition tensors, so an unmodified model_wrapper reuses them."""
+        W = self._weights()
+        key = (self._key(cond_images), self._key(static_latent), self._key(deformation_position_xyz), T)
+        hit = self._ctx_cache.get("key") == key
+        if hit:
+            return self._ctx_cache
+        C = self.model_channels
+        dev = cond_images.device
+        B, Tc, Li, Ci = cond_images.shape
+        Ls = static_latent.shape[1]
+        ctx = {"key": key, "Li": Li, "Ls": Ls}
+        ci = dit_ops.cast_pad_bf16(cond_images.reshape(B * Tc * Li, Ci).float().contiguous(), dit_ops.pad64(Ci))
+        img_emb = torch.empty((B * Tc * Li, C), dtype=torch.bfloat16, device=dev)
+        dit_ops.gemm_bf16(ci, W["img"][0], W["img"][1], img_emb, dit_ops.EPI_STORE_BF16)
+        cs = dit_ops.cast_pad_bf16(static_latent.reshape(B * Ls, -1).float().contiguous(), dit_ops.pad64(static_latent.shape[-1]))
+        st_emb = torch.empty((B * Ls, C), dtype=torch.bfloat16, device=dev)
+        dit_ops.gemm_bf16(cs, W["static"][0], W["static"][1], st_emb, dit_ops.EPI_STORE_BF16)
+        ctx["kv_img"], ctx["kv_st"] = [], []
+        for b in W["blocks"]:
+            kv = torch.empty((B * Tc * Li, 2 * C), dtype=torch.bfloat16, device=dev)
+            dit_ops.gemm_bf16(img_emb, *b["image_cross_attn"]["kv"], kv, dit_ops.EPI_STORE_BF16)
+            ctx["kv_img"].append(kv)
+            kv = torch.empty((B * Ls, 2 * C), dtype=torch.bfloat16, device=dev)   # once per sample, not per frame
+            dit_ops.gemm_bf16(st_emb, *b["static_cross_attn"]["kv"], kv, dit_ops.EPI_STORE_BF16)
+            ctx["kv_st"].append(kv)
+        if self.pe_mode == "ape":
+            assert deformation_position_xyz is not None, "Deformation position xyz is required for APE mode"
+            ctx["pos"] = self.pos_embedder(deformation_position_xyz).float().contiguous()      # (B, N, C)
+        elif self.pe_mode == "learnable":
+            ctx["pos"] = self.pos_embedder.detach().float().expand(B, -1, -1).contiguous()
+        else:
+            ctx["pos"] = None
+        self._ctx_cache = ctx
+        return ctx
+
+    # ---- forward ------------------------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor, t: torch.Tensor, cond_images: torch.Tensor, static_latent: torch.Tensor,
+                deformation_position_xyz: torch.Tensor = None) -> torch.Tensor:
+        return self._forward(x, t, cond_images, static_latent, deformation_position_xyz)
+
+    def _forward_with_mem_ratio(self, x, t, cond_images, static_latent, deformation_position_xyz=None, mem_ratio=1.0):
+        """ElasticModule contract at inference (elastic_utils.py:166-168): (exact_mem_ratio, output)."""
+        return 1.0, self._forward(x, t, cond_images, static_latent, deformation_position_xyz)
+
+    @torch.no_grad()
+    def _forward(self, x, t, cond_images, static_latent, deformation_position_xyz=None):
+        _lib.require_cuda(x, t, cond_images, static_latent, deformation_position_xyz)
+        B, T, N, Cin = x.shape
+        C, H = self.model_channels, self.num_heads
+        dev = x.device
+        M = B * T * N
+        W = self._weights()
+        ctx = self.prepare_conditions(cond_images, static_latent, deformation_position_xyz, T)
+        Li, Ls = ctx["Li"], ctx["Ls"]
+        bf, f32 = torch.bfloat16, torch.float32
+
+        # timestep embedding -> t_emb (B,C) -> SiLU -> every adaLN projection of the step in one GEMM
+        tf = dit_ops.cast_pad_bf16(TimestepEmbedder.timestep_embedding(t.to(dev), self.t_embedder.frequency_embedding_size).contiguous(),
+                                   dit_ops.pad64(self.t_embedder.frequency_embedding_size))
+        h1 = torch.empty((B, C), dtype=f32, device=dev)
+        dit_ops.gemm_bf16(tf, *W["t0"], h1, dit_ops.EPI_STORE_F32)
+        t_emb = torch.empty((B, C), dtype=f32, device=dev)
+        dit_ops.gemm_bf16(dit_ops.cast_pad_bf16(h1, dit_ops.pad64(C), act=1), *W["t2"], t_emb, dit_ops.EPI_STORE_F32)
+        mod = torch.empty((B, W["mod_total"]), dtype=f32, device=dev)
+        dit_ops.gemm_bf16(dit_ops.cast_pad_bf16(t_emb, dit_ops.pad64(C), act=1), W["mod_w"], W["mod_b"], mod, dit_ops.EPI_STORE_F32)
+        mod_ld = W["mod_total"]
+
+        # residual stream h (fp32): position embedding broadcast over T, plus input_layer(x)
+        if ctx["pos"] is not None:
+            h = ctx["pos"][:, None].expand(B, T, N, C).reshape(M, C).contiguous()
+        else:
+            h = torch.zeros((M, C), dtype=f32, device=dev)
+        xb = dit_ops.cast_pad_bf16(x.reshape(M, Cin).float().contiguous(), dit_ops.pad64(Cin))
+        dit_ops.gemm_bf16(xb, *W["input"], h, dit_ops.EPI_RESID_F32)
+
+        hb = torch.empty((M, C), dtype=bf, device=dev)          # normalised operand
+        qkv = torch.empty((M, 3 * C), dtype=bf, device=dev)
+        ab = torch.empty((M, C), dtype=bf, device=dev)          # attention output
+        hidden = torch.empty((M, int(C * self.mlp_ratio)), dtype=bf, device=dev)
+        TN = T * N
+
+        def mview(off):                                       # (B,) rows of `mod`, columns [off, off+C)
+            return mod[:, off:]
+
+        for i, b in enumerate(W["blocks"]):
+            o = W["mod_offs"][i]
+            sh_s, sc_s, g_s, sh_m, sc_m, g_m = (mview(o + k * C) for k in range(6))
+            # -- spatial self attention over N
+            dit_ops.layernorm_modulate_bf16(h, hb, 1e-6, None, None, sh_s, sc_s, mod_ld, TN)
+            a = b["spatial_self_attn"]
+            dit_ops.gemm_bf16(hb, *a["qkv"], qkv, dit_ops.EPI_STORE_BF16)
+            s3 = (N * 3 * C, 0, 3 * C)
+            dit_ops.attention_bf16(qkv, qkv[:, C:], qkv[:, 2 * C:], ab, B * T, 1, N, N, H, s3, s3, s3, (N * C, 0, C), a["gq"], a["gk"])
+            dit_ops.gemm_bf16(ab, *a["out"], h, dit_ops.EPI_RESID_F32, gate=g_s, gate_ld=mod_ld, rows_per_group=TN)
+            # -- temporal self attention over T (strided views, no transposes)
+            if not self.no_temporal_attn:
+                sh_t, sc_t, g_t = (mview(o + (6 + k) * C) for k in range(3))
+                dit_ops.layernorm_modulate_bf16(h, hb, 1e-6, None, None, sh_t, sc_t, mod_ld, TN)
+                a = b["temporal_self_attn"]
+                dit_ops.gemm_bf16(hb, *a["qkv"], qkv, dit_ops.EPI_STORE_BF16)
+                st = (TN * 3 * C, 3 * C, N * 3 * C)           # outer = sample, inner = token, seq = frame
+                dit_ops.attention_bf16(qkv, qkv[:, C:], qkv[:, 2 * C:], ab, B, N, T, T, H, st, st, st, (TN * C, C, N * C), a["gq"], a["gk"])
+                dit_ops.gemm_bf16(ab, *a["out"], h, dit_ops.EPI_RESID_F32, gate=g_t, gate_ld=mod_ld, rows_per_group=TN)
+            # -- image cross attention (affine LayerNorm, cached K/V)
+            a = b["image_cross_attn"]
+            dit_ops.layernorm_modulate_bf16(h, hb, 1e-6, b["n3"][0], b["n3"][1])
+            dit_ops.gemm_bf16(hb, *a["q"], ab, dit_ops.EPI_STORE_BF16)
+            kv = ctx["kv_img"][i]
+            sk = (Li * 2 * C, 0, 2 * C)
+            dit_ops.attention_bf16(ab, kv, kv[:, C:], hb, B * T, 1, N, Li, H, (N * C, 0, C), sk, sk, (N * C, 0, C), a["gq"], a["gk"])
+            dit_ops.gemm_bf16(hb, *a["out"], h, dit_ops.EPI_RESID_F32)
+            # -- static cross attention: K/V shared by the T frames of a sample (inner stride 0)
+            a = b["static_cross_attn"]
+            dit_ops.layernorm_modulate_bf16(h, hb, 1e-6, b["n4"][0], b["n4"][1])
+            dit_ops.gemm_bf16(hb, *a["q"], ab, dit_ops.EPI_STORE_BF16)
+            kv = ctx["kv_st"][i]
+            sk = (Ls * 2 * C, 0, 2 * C)
+            dit_ops.attention_bf16(ab, kv, kv[:, C:], hb, B, T, N, Ls, H, (TN * C, N * C, C), sk, sk, (TN * C, N * C, C), a["gq"], a["gk"])
+            dit_ops.gemm_bf16(hb, *a["out"], h, dit_ops.EPI_RESID_F32)
+            # -- MLP
+            dit_ops.layernorm_modulate_bf16(h, hb, 1e-6, None, None, sh_m, sc_m, mod_ld, TN)
+            dit_ops.gemm_bf16(hb, *b["fc1"], hidden, dit_ops.EPI_GELU_BF16)
+            dit_ops.gemm_bf16(hidden, *b["fc2"], h, dit_ops.EPI_RESID_F32, gate=g_m, gate_ld=mod_ld, rows_per_group=TN)
+
+        o = W["mod_offs"][-1]
+        dit_ops.layernorm_modulate_bf16(h, hb, 1e-6, None, None, mview(o), mview(o + C), mod_ld, TN)
+        y = torch.empty((M, self.out_channels), dtype=f32, device=dev)
+        dit_ops.gemm_bf16(hb, *W["final"], y, dit_ops.EPI_STORE_F32)
+        return y.reshape(B, T, N, self.out_channels).to(x.dtype if x.dtype.is_floating_point else f32)

@@ -1,2 +1,3 @@
 """Operator-level Python bindings; importing this package registers every C-ABI signature."""
 from .. import _lib  # noqa: F401
+from . import dit_ops  # noqa: F401

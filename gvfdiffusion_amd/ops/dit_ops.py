@@ -1,0 +1,78 @@
+"""ctypes bindings of include/gvf_dit.h (csrc/gemm.hip, attn.hip, elem.hip) on torch device tensors."""
+import ctypes
+
+import torch
+
+from .. import _lib
+
+_vp, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+
+EPI_STORE_BF16, EPI_GELU_BF16, EPI_STORE_F32, EPI_RESID_F32 = 0, 1, 2, 3
+
+_lib.register({
+    "gvf_gemm_bf16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
+    "gvf_attn_fwd_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i] + [_i64] * 12 + [_vp, _vp, _f, _vp]),
+    "gvf_layernorm_modulate_bf16": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "gvf_cast_pad_bf16": (_i, [_vp, _i, _vp, _i, _i64, _i, _i, _vp]),
+})
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(t):
+    return _lib.current_stream(t.device)
+
+
+def pad64(k: int) -> int:
+    return (k + 63) // 64 * 64
+
+
+def cast_pad_bf16(src: torch.Tensor, ld_dst: int = None, act: int = 0, out: torch.Tensor = None) -> torch.Tensor:
+    """fp32 (rows, cols) -> bf16 (rows, ld_dst) zero-padded; act 1 = SiLU."""
+    _lib.require_cuda(src)
+    assert src.dtype == torch.float32 and src.dim() == 2 and src.stride(1) == 1
+    rows, cols = src.shape
+    ld_dst = cols if ld_dst is None else ld_dst
+    if out is None:
+        out = torch.empty((rows, ld_dst), dtype=torch.bfloat16, device=src.device)
+    _lib.check(_lib.lib().gvf_cast_pad_bf16(_p(src), src.stride(0), _p(out), ld_dst, rows, cols, act, _stream(src)),
+               "gvf_cast_pad_bf16")
+    return out
+
+
+def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, epilogue: int, gate: torch.Tensor = None,
+              gate_ld: int = 0, rows_per_group: int = 0, n: int = None):
+    """out (M, >=N) <- epilogue(a (M,K) @ w (N,K)^T + bias).  a, w bf16 with K % 64 == 0."""
+    _lib.require_cuda(a, w, out)
+    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a.stride(1) == 1 and w.stride(1) == 1
+    M, K = a.shape
+    N = w.shape[0] if n is None else n
+    assert w.shape[1] == K and out.stride(-1) == 1
+    _lib.check(_lib.lib().gvf_gemm_bf16(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), M, N, K,
+                                        epilogue, _p(gate), gate_ld, rows_per_group, _stream(a)), "gvf_gemm_bf16")
+    return out
+
+
+def attention_bf16(q, k, v, out, n_outer, n_inner, Lq, Lk, H, q_strides, k_strides, v_strides, o_strides, gamma_q=None,
+                   gamma_k=None, scale=None):
+    """Strided flash attention (head_dim 32).  *_strides = (outer, inner, seq) in elements."""
+    _lib.require_cuda(q, k, v, out)
+    assert q.dtype == k.dtype == v.dtype == out.dtype == torch.bfloat16
+    scale = 32 ** -0.5 if scale is None else scale
+    args = [int(s) for st in (q_strides, k_strides, v_strides, o_strides) for s in st]
+    _lib.check(_lib.lib().gvf_attn_fwd_bf16(_p(q), _p(k), _p(v), _p(out), n_outer, n_inner, Lq, Lk, H, *args, _p(gamma_q),
+                                            _p(gamma_k), float(scale), _stream(q)), "gvf_attn_fwd_bf16")
+    return out
+
+
+def layernorm_modulate_bf16(x, out, eps=1e-6, ln_w=None, ln_b=None, shift=None, scale=None, mod_ld=0, rows_per_group=0):
+    """x fp32 (rows, C) -> out bf16 (rows, C): LN then affine (ln_w, ln_b) and/or adaLN (shift, scale views)."""
+    _lib.require_cuda(x, out)
+    assert x.dtype == torch.float32 and out.dtype == torch.bfloat16 and x.is_contiguous() and out.is_contiguous()
+    rows, C = x.shape
+    _lib.check(_lib.lib().gvf_layernorm_modulate_bf16(_p(x), _p(out), rows, C, float(eps), _p(ln_w), _p(ln_b), _p(shift),
+                                                      _p(scale), mod_ld, rows_per_group, _stream(x)),
+               "gvf_layernorm_modulate_bf16")
+    return out

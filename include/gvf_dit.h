@@ -1,0 +1,65 @@
+/*
+ * gvf_dit.h -- C ABI of the MI355X (gfx950) kernels behind the DiT denoise step.
+ *
+ * Reference seams these replace:
+ *   model/attention/full_attn.py:74-140   scaled_dot_product_attention(qkv | q,kv | q,k,v)   -> gvf_attn_fwd_bf16
+ *   model/attention/modules.py:8-15       MultiHeadRMSNorm (fused into the attention prologue) -> gamma_q / gamma_k
+ *   model/attention/modules.py:112-146    the nn.Linear projections around it                 -> gvf_gemm_bf16
+ *   model/dit.py:128-138, 246-277         FeedForwardNet, adaLN modulate / gate / residual     -> gvf_gemm_bf16 epilogues,
+ *                                                                                               gvf_layernorm_modulate_bf16
+ * Numerics: operands bf16, accumulation fp32 (MFMA 16x16x32 / 32x32x16 bf16), softmax / LayerNorm /
+ * RMSNorm / residual stream in fp32 -- the placement the reference gets from torch.autocast.
+ * Conventions as in gvf_rast.h: device pointers, caller-owned buffers, explicit stream, int status.
+ */
+#ifndef GVF_DIT_H
+#define GVF_DIT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* gvf_gemm_bf16 epilogues:  acc[m][n] = sum_k A[m][k] * W[n][k]  (+ bias[n]) */
+#define GVF_EPI_STORE_BF16   0   /* C bf16 [M][ldc]  = acc                                  */
+#define GVF_EPI_GELU_BF16    1   /* C bf16           = gelu_tanh(acc)      (mlp.0)          */
+#define GVF_EPI_STORE_F32    2   /* C f32  [M][ldc]  = acc                                  */
+#define GVF_EPI_RESID_F32    3   /* C f32 (in place) += gate[m / rows_per_group][n] * acc   (gate null -> 1): x = x + g*h */
+
+/* C = A W^T (+bias): A bf16 [M][lda] row-major, W bf16 [N][ldw] row-major (nn.Linear layout),
+ * K a multiple of 64 (pad activations and weights), lda/ldw multiples of 8, bias f32 [N] or null.
+ * gate f32: row g of `gate` (leading dimension gate_ld) applies to rows [g*rows_per_group, ...). */
+int gvf_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc,
+                  int M, int N, int K, int epilogue, const float* gate, int gate_ld, int rows_per_group,
+                  void* stream);
+
+/* softmax(q k^T * scale) v, head_dim 32, no mask.  Batch index = (outer, inner); element (o,i,l,h,c) of a
+ * tensor sits at  o*so + i*si + l*sl + h*32 + c  (strides in elements), so the q/k/v slices of a packed
+ * qkv / kv projection and the (B,T,N,.)<->(B,N,T,.) view of the temporal attention need no copies.
+ * gamma_q / gamma_k: f32 [H][32] MultiHeadRMSNorm gains (x <- normalize(x) * gamma * sqrt(32)) or null. */
+int gvf_attn_fwd_bf16(const void* q, const void* k, const void* v, void* out,
+                      int n_outer, int n_inner, int Lq, int Lk, int H,
+                      int64_t q_so, int64_t q_si, int64_t q_sl,
+                      int64_t k_so, int64_t k_si, int64_t k_sl,
+                      int64_t v_so, int64_t v_si, int64_t v_sl,
+                      int64_t o_so, int64_t o_si, int64_t o_sl,
+                      const float* gamma_q, const float* gamma_k, float scale, void* stream);
+
+/* out_bf16[r][:] = LN(x[r][:]) (eps, no affine) then either  * ln_w + ln_b  (affine LayerNorm, norm3/4)
+ * or  * (1 + scale[g]) + shift[g]  (adaLN, g = r / rows_per_group; shift/scale rows have stride mod_ld),
+ * x f32 [rows][C]; C a multiple of 256 (<= 1024) takes the register-resident fast path. */
+int gvf_layernorm_modulate_bf16(const float* x, void* out_bf16, int rows, int C, float eps,
+                                const float* ln_w, const float* ln_b,
+                                const float* shift, const float* scale, int mod_ld, int rows_per_group,
+                                void* stream);
+
+/* dst bf16 [rows][ld_dst] = act(src f32 [rows][cols]) with zero padding of columns cols..ld_dst-1.
+ * act: 0 = identity, 1 = SiLU. */
+int gvf_cast_pad_bf16(const float* src, int ld_src, void* dst, int ld_dst, int64_t rows, int cols, int act,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GVF_DIT_H */

@@ -1,0 +1,218 @@
+"""HIP DiT kernels and the assembled denoiser against the torch oracle / the reference goldens (MI355X)."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gvfdiffusion_amd import synthetic
+from gvfdiffusion_amd.ops import dit_ops
+from oracle import dit_ref
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def rel_l2(a, b):
+    return float((a.float() - b.float()).norm() / b.float().norm())
+
+
+# DiT tolerances.  BASELINE.json asks for 1e-4 rel "for bf16" against the same-dtype oracle; a bf16 pipeline
+# cannot meet that element-wise (one bf16 ulp is 3.9e-3 relative and accumulation order moves roundings), so
+# the claims are stated as relative L2 errors, measured values printed by the tests:
+TOL_KERNEL_REL_L2 = 2e-3     # single kernel vs torch on identical bf16 operands (fp32 accumulate)
+TOL_DIT_VS_BF16_ORACLE = 1e-2   # full denoiser vs oracle with the same rounding points (dit_ref precision="bf16")
+TOL_DIT_VS_FP32_REF = 3e-2      # full denoiser vs the fp32 reference output (golden)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 200, 128), (128, 128, 64), (1, 1536, 512), (1000, 16, 512), (257, 3072, 2048)])
+def test_gemm_epilogues(cuda, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    a = bf(torch.randn((M, K), generator=g)).to(cuda)
+    w = bf(torch.randn((N, K), generator=g) / math.sqrt(K)).to(cuda)
+    bias = torch.randn((N,), generator=g).to(cuda)
+    ref = a.float() @ w.float().T + bias
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=cuda)
+    dit_ops.gemm_bf16(a, w, bias, out, dit_ops.EPI_STORE_BF16)
+    assert rel_l2(out, ref) < TOL_KERNEL_REL_L2 + 2e-3      # + output rounding to bf16
+    dit_ops.gemm_bf16(a, w, bias, out, dit_ops.EPI_GELU_BF16)
+    assert rel_l2(out, torch.nn.functional.gelu(ref, approximate="tanh")) < TOL_KERNEL_REL_L2 + 2e-3
+    o32 = torch.empty((M, N), dtype=torch.float32, device=cuda)
+    dit_ops.gemm_bf16(a, w, None, o32, dit_ops.EPI_STORE_F32)
+    assert rel_l2(o32, ref - bias) < 1e-5
+    rpg = 7
+    groups = (M + rpg - 1) // rpg
+    gate = torch.randn((groups, 3 * N), generator=g).to(cuda)
+    x0 = torch.randn((M, N), generator=g).to(cuda)
+    x = x0.clone()
+    dit_ops.gemm_bf16(a, w, bias, x, dit_ops.EPI_RESID_F32, gate=gate[:, N:], gate_ld=3 * N, rows_per_group=rpg)
+    gfull = gate[:, N:2 * N].repeat_interleave(rpg, dim=0)[:M]
+    assert rel_l2(x, x0 + gfull * ref) < 1e-5
+    x = x0.clone()
+    dit_ops.gemm_bf16(a, w, bias, x, dit_ops.EPI_RESID_F32)
+    assert rel_l2(x, x0 + ref) < 1e-5
+
+
+def _attn_ref(q, k, v, gq, gk):
+    if gq is not None:
+        q = dit_ref.rms_norm_heads(q.float(), gq, "bf16")
+        k = dit_ref.rms_norm_heads(k.float(), gk, "bf16")
+    return dit_ref.sdpa(q.float(), k.float(), v.float(), "bf16")
+
+
+@pytest.mark.parametrize("N,Lq,Lk,H", [(3, 200, 77, 2), (2, 512, 512, 16), (1, 130, 1370, 4), (5, 24, 24, 3), (2, 33, 4096, 2)])
+@pytest.mark.parametrize("rms", [False, True])
+def test_attention_matches_oracle(cuda, N, Lq, Lk, H, rms):
+    g = torch.Generator().manual_seed(N * 1000 + Lq + Lk)
+    q = bf(torch.randn((N, Lq, H, 32), generator=g) * 2).to(cuda)
+    k = bf(torch.randn((N, Lk, H, 32), generator=g) * 2).to(cuda)
+    v = bf(torch.randn((N, Lk, H, 32), generator=g)).to(cuda)
+    gq = (1 + 0.2 * torch.randn((H, 32), generator=g)).to(cuda) if rms else None
+    gk = (1 + 0.2 * torch.randn((H, 32), generator=g)).to(cuda) if rms else None
+    out = torch.empty_like(q)
+    sq, sk = (Lq * H * 32, 0, H * 32), (Lk * H * 32, 0, H * 32)
+    dit_ops.attention_bf16(q, k, v, out, N, 1, Lq, Lk, H, sq, sk, sk, sq, gq, gk)
+    ref = _attn_ref(q, k, v, gq, gk)
+    r = rel_l2(out, ref)
+    print(f"attention N{N} Lq{Lq} Lk{Lk} H{H} rms={rms}: rel_l2={r:.2e} max={float((out.float()-ref).abs().max()):.2e}")
+    assert r < 6e-3 and float((out.float() - ref).abs().max()) < 3e-2 * float(ref.abs().max())
+
+
+def test_attention_operator_call_forms_and_strided_views(cuda):
+    from gvfdiffusion_amd.model.attention import scaled_dot_product_attention as sdpa
+    g = torch.Generator().manual_seed(0)
+    qkv = bf(torch.randn((2, 50, 3, 4, 32), generator=g)).to(cuda)
+    q, k, v = qkv.unbind(dim=2)
+    ref = dit_ref.sdpa(q.float(), k.float(), v.float(), "bf16")
+    for got in (sdpa(qkv), sdpa(q, torch.stack([k, v], dim=2)), sdpa(q, k, v), sdpa(q=q, k=k, v=v),
+                sdpa(q.float(), k.float(), v.float())):
+        assert got.shape == (2, 50, 4, 32) and rel_l2(got, ref) < 6e-3
+    assert sdpa(q.float(), k.float(), v.float()).dtype == torch.float32
+    with pytest.raises(AssertionError):
+        sdpa(q, k, v, v)
+    # temporal layout: batch = (sample, token), sequence = frame, read straight out of a (B,T,N,3C) projection
+    B, T, Nn, H, C = 2, 6, 9, 2, 64
+    proj = bf(torch.randn((B, T, Nn, 3 * C), generator=g)).to(cuda)
+    out = torch.empty((B, T, Nn, C), dtype=torch.bfloat16, device=cuda)
+    st = (T * Nn * 3 * C, 3 * C, Nn * 3 * C)
+    dit_ops.attention_bf16(proj, proj[..., C:], proj[..., 2 * C:], out, B, Nn, T, T, H, st, st, st, (T * Nn * C, C, Nn * C))
+    x = proj.float().transpose(1, 2).reshape(B * Nn, T, 3, H, 32)
+    ref = dit_ref.sdpa(x[:, :, 0], x[:, :, 1], x[:, :, 2], "bf16").reshape(B, Nn, T, C).transpose(1, 2)
+    assert rel_l2(out, ref) < 6e-3
+
+
+@pytest.mark.parametrize("C", [512, 64, 768])
+def test_layernorm_modulate(cuda, C):
+    g = torch.Generator().manual_seed(C)
+    rows, rpg = 1000, 300
+    x = (torch.randn((rows, C), generator=g) * 3 + 1).to(cuda)
+    groups = (rows + rpg - 1) // rpg
+    mod = torch.randn((groups, 4 * C), generator=g).to(cuda)
+    w, b = torch.randn((C,), generator=g).to(cuda), torch.randn((C,), generator=g).to(cuda)
+    out = torch.empty((rows, C), dtype=torch.bfloat16, device=cuda)
+    ln = torch.nn.functional.layer_norm(x, (C,), None, None, 1e-6)
+    dit_ops.layernorm_modulate_bf16(x, out, 1e-6, None, None, mod[:, C:], mod[:, 2 * C:], 4 * C, rpg)
+    sh = mod[:, C:2 * C].repeat_interleave(rpg, 0)[:rows]; sc = mod[:, 2 * C:3 * C].repeat_interleave(rpg, 0)[:rows]
+    assert float((out.float() - bf(ln * (1 + sc) + sh).float()).abs().max()) <= 0.04     # 1 bf16 ulp at |y| < 8
+    assert rel_l2(out, ln * (1 + sc) + sh) < 3e-3
+    dit_ops.layernorm_modulate_bf16(x, out, 1e-6, w, b)
+    assert rel_l2(out, ln * w + b) < 3e-3
+    y = torch.empty((5, 64), dtype=torch.bfloat16, device=cuda)
+    src = torch.randn((5, 14), generator=g).to(cuda)
+    dit_ops.cast_pad_bf16(src, 64, act=1, out=y)
+    assert torch.all(y[:, 14:] == 0) and rel_l2(y[:, :14], torch.nn.functional.silu(src)) < 3e-3
+
+
+def _load_small(cuda):
+    from gvfdiffusion_amd.model.dit import DiT
+    g = np.load(os.path.join(GOLD, "dit_small_golden.npz"))
+    cfg = json.loads(bytes(g["cfg_json"]).decode())
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")}
+    model = DiT(**cfg)
+    model.load_state_dict(sd, strict=True)
+    return g, cfg, sd, model.to(cuda).eval()
+
+
+def test_small_dit_forward_matches_reference_golden(cuda):
+    g, cfg, sd, model = _load_small(cuda)
+    args = [torch.from_numpy(g[k]).to(cuda) for k in ("x", "t", "cond_images", "static_latent", "xyz")]
+    y = model(*args)
+    gold = torch.from_numpy(g["y"]).to(cuda)
+    sdc = {k: v.to(cuda) for k, v in sd.items()}
+    yb = dit_ref.dit_forward(sdc, cfg, *args, precision="bf16")
+    r_ref, r_b = rel_l2(y, gold), rel_l2(y, yb)
+    print(f"small DiT: rel_l2 vs fp32 reference golden {r_ref:.2e}; vs bf16-emulating oracle {r_b:.2e}")
+    assert y.shape == gold.shape and r_ref < TOL_DIT_VS_FP32_REF and r_b < TOL_DIT_VS_BF16_ORACLE
+    # module-level drop-in: MultiHeadAttention.forward on its own
+    attn = model.blocks[0].spatial_self_attn
+    x = torch.randn((3, 40, 64), generator=torch.Generator().manual_seed(1)).to(cuda)
+    ref = dit_ref.self_attention(x, sdc, "blocks.0.spatial_self_attn", 2, "bf16")
+    assert rel_l2(attn(x), ref) < 1e-2
+    ca = model.blocks[1].image_cross_attn
+    ctxt = torch.randn((3, 17, 64), generator=torch.Generator().manual_seed(2)).to(cuda)
+    assert rel_l2(ca(x, ctxt), dit_ref.cross_attention(x, ctxt, sdc, "blocks.1.image_cross_attn", 2, "bf16")) < 1e-2
+
+
+def test_condition_cache_is_keyed_on_tensor_identity(cuda):
+    g, cfg, sd, model = _load_small(cuda)
+    args = [torch.from_numpy(g[k]).to(cuda) for k in ("x", "t", "cond_images", "static_latent", "xyz")]
+    y1 = model(*args)
+    key1 = model._ctx_cache["key"]
+    y2 = model(args[0], args[1] * 0.5, *args[2:])            # new step, same conditions -> cache hit
+    assert model._ctx_cache["key"] == key1 and not torch.equal(y1, y2)
+    args[2].mul_(0.5)                                        # in-place change bumps the version -> recompute
+    y3 = model(*args)
+    assert model._ctx_cache["key"] != key1 and not torch.equal(y3, y1)
+    y4 = model(args[0], args[1], args[2].clone(), args[3], args[4])
+    assert torch.equal(y3, y4)
+
+
+def test_full_config_forward_matches_reference_golden(cuda):
+    """configs/diffusion.yml, B=1, T=24, N=512, 1370 image tokens, 4096 static tokens (BASELINE configs[2])."""
+    from gvfdiffusion_amd.model.dit import DiT
+    man = json.load(open(os.path.join(GOLD, "dit_manifest.json")))
+    sd = synthetic.dit_state_dict(man["state_dict"], seed=0)
+    model = DiT(**man["config"])
+    model.load_state_dict(sd, strict=True)
+    model = model.to(cuda).eval()
+    inp = {k: v.to(cuda) for k, v in synthetic.dit_inputs(B=1, T=24, seed=1).items()}
+    y = model(inp["x"], inp["t"], cond_images=inp["cond_images"], static_latent=inp["static_latent"],
+              deformation_position_xyz=inp["deformation_position_xyz"])
+    gold = torch.from_numpy(np.load(os.path.join(GOLD, "dit_full_golden.npz"))["y"]).to(cuda)
+    sdc = {k: v.to(cuda) for k, v in sd.items()}
+    yb = dit_ref.dit_forward(sdc, man["config"], inp["x"], inp["t"], inp["cond_images"], inp["static_latent"],
+                             inp["deformation_position_xyz"], precision="bf16")
+    r_ref, r_b = rel_l2(y, gold), rel_l2(y, yb)
+    print(f"full DiT: rel_l2 vs fp32 reference golden {r_ref:.2e}; vs bf16-emulating oracle {r_b:.2e}; "
+          f"oracle(bf16) vs golden {rel_l2(yb, gold):.2e}")
+    assert r_ref < TOL_DIT_VS_FP32_REF and r_b < TOL_DIT_VS_BF16_ORACLE
+
+
+def test_sampler_drives_the_hip_dit(cuda):
+    """inference_dpm_latent.py:225-249 wiring: NoiseScheduleVP -> model_wrapper(v-pred, CFG) -> DPM_Solver over the DiT."""
+    from gvfdiffusion_amd.model.dpmsolver import NoiseScheduleVP, model_wrapper, DPM_Solver
+    from gvfdiffusion_amd.model.gaussian_diffusion import create_gaussian_diffusion
+    g, cfg, sd, model = _load_small(cuda)
+    sdc = {k: v.to(cuda) for k, v in sd.items()}
+    ns = NoiseScheduleVP("discrete", betas=torch.from_numpy(create_gaussian_diffusion(noise_schedule="cosine", predict_type="v").betas))
+    cond = {"cond_images": torch.from_numpy(g["cond_images"]).to(cuda), "static_latent": torch.from_numpy(g["static_latent"]).to(cuda),
+            "deformation_position_xyz": torch.from_numpy(g["xyz"]).to(cuda)}
+    uncond = dict(cond); uncond["cond_images"] = torch.zeros_like(cond["cond_images"])
+    xT = torch.randn(g["x"].shape, generator=torch.Generator().manual_seed(3)).to(cuda)
+    outs = {}
+    for name, net in (("hip", model), ("oracle", lambda x, t, **kw: dit_ref.dit_forward(sdc, cfg, x, t, kw["cond_images"], kw["static_latent"], kw["deformation_position_xyz"]))):
+        for scales in ((1.0, 1.0), (2.0, 3.0)):
+            mf = model_wrapper(net, ns, model_type="v", model_kwargs={}, guidance_type="classifier-free", guidance_scale=scales[0],
+                               guidance_scale2=scales[1], condition=cond, unconditional_condition=uncond)
+            outs[(name, scales)] = DPM_Solver(mf, ns, algorithm_type="dpmsolver++").sample(
+                xT, steps=6, t_start=1.0, t_end=1 / 1000, order=2, skip_type="time_uniform", method="multistep")
+    for scales in ((1.0, 1.0), (2.0, 3.0)):
+        r = rel_l2(outs[("hip", scales)], outs[("oracle", scales)])
+        print(f"6-step DPM-Solver++ sample, guidance {scales}: rel_l2 hip vs fp32 oracle {r:.2e}")
+        assert r < 5e-2
