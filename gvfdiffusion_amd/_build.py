@@ -19,8 +19,11 @@ SOURCES = {
     "sort.hip": [],
     "rast.hip": ["-ffp-contract=off"],
     "vox2seq.hip": [],
-    "attn.hip": [],
-    "gemm.hip": [],
+    # MFMA results straight into VGPRs (gfx950 has a unified register file): removes the accvgpr
+    # read/write traffic between the MFMAs and the softmax / epilogue VALU code.
+    # -fno-honor-nans: no canonicalising v_max in front of fmaxf (infinities stay honoured: -inf masks keys).
+    "attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"],
+    "gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
     "elem.hip": [],
 }
 

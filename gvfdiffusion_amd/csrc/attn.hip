@@ -35,13 +35,27 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return (unsigned short)(u >> 16);
 }
+// two f32 -> packed bf16x2 (lo in bits 0-15), round-to-nearest-even.  Written as plain conversions: hipcc
+// selects v_cvt_pk_bf16_f32 itself, and (unlike an asm statement) pads the VALU -> MFMA operand hazard.
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    bf16x2 v;
+    v[0] = (__bf16)lo;
+    v[1] = (__bf16)hi;
+    return __builtin_bit_cast(unsigned, v);
+}
+// fmaxf on MFMA results: compiled with -fno-honor-nans (see _build.py), otherwise hipcc puts a canonicalising
+// v_max_f32 x,x (IEEE-mode sNaN quieting) in front of every operand -- 3x the instructions.  No inline asm
+// here on purpose: an asm statement reading an MFMA result is not covered by the compiler's hazard padding.
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+__device__ __forceinline__ float max2f(float a, float b) { return fmaxf(a, b); }
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
 
 struct AttnParams {
     const unsigned short *q, *k, *v;
     unsigned short* out;
     int n_inner, Lq, Lk, H, q_blocks;
-    long long q_so, q_si, q_sl, k_so, k_si, k_sl, v_so, v_si, v_sl, o_so, o_si, o_sl;
+    long long q_so, q_si, q_sl, q_sh, k_so, k_si, k_sl, k_sh, v_so, v_si, v_sl, v_sh, o_so, o_si, o_sl, o_sh;
     const float *gamma_q, *gamma_k;
     float scale_log2e;
 };
@@ -69,9 +83,67 @@ __device__ __forceinline__ float sumsq8(uint4 raw) {
     return s;
 }
 
+// One 32-key sub-tile for the 32 queries of a wave: S^T = K Q^T, online softmax, O^T += V^T P^T.
+template <bool MASKED>
+__device__ __forceinline__ void subtile(const uint4* __restrict__ sKb, const unsigned short* __restrict__ sVTb, int sub,
+                                        int key0, int Lk, float scale_log2e, bf16x8 qf0, bf16x8 qf1, int l31, int half,
+                                        f32x16& o_acc, float& m_run, float& l_run) {
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int krow_l = sub * 32 + l31;
+    const int sw = (krow_l >> 2) & 3;
+    const bf16x8 k0 = __builtin_bit_cast(bf16x8, sKb[krow_l * 4 + ((0 + half) ^ sw)]);
+    const bf16x8 k1 = __builtin_bit_cast(bf16x8, sKb[krow_l * 4 + ((2 + half) ^ sw)]);
+    f32x16 s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf0, zero, 0, 0, 0);
+    s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf1, s_acc, 0, 0, 0);
+    // accumulator row r of this lane is key  key0 + (r&3) + 8*(r>>2) + 4*half
+    if (MASKED) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if ((key0 + (r & 3) + 8 * (r >> 2) + 4 * half) >= Lk) s_acc[r] = -INFINITY;
+    }
+    float mloc = max3f(s_acc[0], s_acc[1], s_acc[2]);
+#pragma unroll
+    for (int r = 3; r < 15; r += 2) mloc = max3f(mloc, s_acc[r], s_acc[r + 1]);
+    mloc = max2f(mloc, s_acc[15]);
+    mloc *= scale_log2e;                            // scale > 0: max commutes with the scaling
+    mloc = max2f(mloc, __shfl_xor(mloc, 32, 64));
+    // rescale only when some query of the wave saw its maximum grow (wave-uniform branch)
+    if (__any(mloc > m_run)) {
+        const float m_new = max2f(m_run, mloc);    // finite: every sub-tile holds >= 1 valid key
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        l_run *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o_acc[r] *= alpha;
+        m_run = m_new;
+    }
+    float psum = 0.f;
+    unsigned pw[8];
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[r], scale_log2e, -m_run));
+        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[r + 1], scale_log2e, -m_run));
+        psum += p0 + p1;
+        pw[r >> 1] = cvt_pk_bf16(p0, p1);
+    }
+    l_run += psum;
+    // O^T[d][q] += sum_slots V^T[d][key(slot)] P^T[key(slot)][q]; slot (u, half, e) = accumulator row 8u+e
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const bf16x8 pf = __builtin_bit_cast(bf16x8, make_uint4(pw[4 * u], pw[4 * u + 1], pw[4 * u + 2], pw[4 * u + 3]));
+        const unsigned short* vrow = sVTb + l31 * VT_LD + sub * 32 + 16 * u + 4 * half;
+        const uint2 va = *reinterpret_cast<const uint2*>(vrow);        // keys +0..3
+        const uint2 vb = *reinterpret_cast<const uint2*>(vrow + 8);    // keys +8..11
+        const bf16x8 vf = __builtin_bit_cast(bf16x8, make_uint4(va.x, va.y, vb.x, vb.y));
+        o_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o_acc, 0, 0, 0);
+    }
+}
+
+// VT: V is given transposed ([d][key], keys contiguous; v_sl = d stride) -- the layout the DiT's
+// step-invariant cross-attention cache is stored in, so staging is a straight 16-byte copy.
+template <bool VT>
 __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(AttnParams p) {
-    __shared__ uint4 sK[KT * 4];                      // [key][4 chunks of 8 bf16], chunk ^= (key >> 2) & 3
-    __shared__ unsigned short sVT[D * VT_LD];         // [d][key]
+    __shared__ uint4 sK[2][KT * 4];                   // [key][4 chunks of 8 bf16], chunk ^= (key >> 2) & 3
+    __shared__ __attribute__((aligned(16))) unsigned short sVT[2][D * VT_LD];   // [d][key]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
@@ -81,10 +153,10 @@ __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(AttnParams p) {
     const int head = bid % p.H; bid /= p.H;
     const int inner = bid % p.n_inner, outer = bid / p.n_inner;
 
-    const unsigned short* qp = p.q + outer * p.q_so + inner * p.q_si + head * D;
-    const unsigned short* kp = p.k + outer * p.k_so + inner * p.k_si + head * D;
-    const unsigned short* vp = p.v + outer * p.v_so + inner * p.v_si + head * D;
-    unsigned short* op = p.out + outer * p.o_so + inner * p.o_si + head * D;
+    const unsigned short* qp = p.q + outer * p.q_so + inner * p.q_si + head * p.q_sh;
+    const unsigned short* kp = p.k + outer * p.k_so + inner * p.k_si + head * p.k_sh;
+    const unsigned short* vp = p.v + outer * p.v_so + inner * p.v_si + head * p.v_sh;
+    unsigned short* op = p.out + outer * p.o_so + inner * p.o_si + head * p.o_sh;
 
     // ---- Q fragments: B operand of S^T = K Q^T.  Lane (q = lane&31, half): Q[q][16s + 8*half .. +7], s = 0,1
     const int qrow = qb * QB + wave * 32 + l31;
@@ -110,97 +182,76 @@ __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(AttnParams p) {
     for (int r = 0; r < 16; ++r) o_acc[r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
-    // staging role of this thread: key row st_key, 16-byte chunk st_c of the 64-byte head row
+    // staging roles.  K: key row st_key, 16-byte chunk st_c.  V (row-major): the same; V (transposed): d row
+    // vt_d, 8-key chunk vt_c.
     const int st_key = tid >> 2, st_c = tid & 3;
+    const int vt_d = tid >> 3, vt_c = tid & 7;
     float gk8[8];
     if (p.gamma_k != nullptr) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) gk8[e] = p.gamma_k[head * D + st_c * 8 + e];
     }
+    const bool has_gk = p.gamma_k != nullptr;
+
+    uint4 kreg, vreg;
+// LOAD only issues the global loads (rows clamped in-bounds); masking / RMSNorm / LDS writes happen in STORE,
+// after the MFMAs of the tile being consumed, so the loads stay in flight across the compute.
+#define GVF_ATTN_LOAD(kt_)                                                                              \
+    {                                                                                                   \
+        const int key = (kt_) * KT + st_key;                                                            \
+        const long long krow = key < p.Lk ? key : 0;                                                    \
+        kreg = *reinterpret_cast<const uint4*>(kp + krow * p.k_sl + st_c * 8);                          \
+        if (VT) {                                                                                       \
+            vreg = *reinterpret_cast<const uint4*>(vp + (long long)vt_d * p.v_sl + (kt_) * KT + vt_c * 8); \
+        } else {                                                                                        \
+            vreg = *reinterpret_cast<const uint4*>(vp + krow * p.v_sl + st_c * 8);                      \
+        }                                                                                               \
+    }
+#define GVF_ATTN_STORE(buf_, kt_)                                                                       \
+    {                                                                                                   \
+        const unsigned m = ((kt_) * KT + st_key) < p.Lk ? 0xffffffffu : 0u;                             \
+        uint4 kw = make_uint4(kreg.x & m, kreg.y & m, kreg.z & m, kreg.w & m);                          \
+        if (has_gk) {                                                                                   \
+            float ss = sumsq8(kw);                                                                      \
+            ss += __shfl_xor(ss, 1, 64);                                                                \
+            ss += __shfl_xor(ss, 2, 64);                                                                \
+            kw = rms_apply(kw, ss, gk8);                                                                \
+        }                                                                                               \
+        sK[buf_][st_key * 4 + (st_c ^ ((st_key >> 2) & 3))] = kw;                                       \
+        if (VT) {                                                                                       \
+            *reinterpret_cast<uint4*>(&sVT[buf_][vt_d * VT_LD + vt_c * 8]) = vreg;                      \
+        } else {                                                                                        \
+            const unsigned w[4] = {vreg.x & m, vreg.y & m, vreg.z & m, vreg.w & m};                     \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                             \
+                sVT[buf_][(st_c * 8 + 2 * i) * VT_LD + st_key] = (unsigned short)(w[i] & 0xffffu);      \
+                sVT[buf_][(st_c * 8 + 2 * i + 1) * VT_LD + st_key] = (unsigned short)(w[i] >> 16);      \
+            }                                                                                           \
+        }                                                                                               \
+    }
 
     const int n_tiles = (p.Lk + KT - 1) / KT;
-    for (int kt = 0; kt < n_tiles; ++kt) {
-        // ---- stage K (row-major, swizzled) and V (transposed) for keys [kt*64, kt*64+64)
-        {
-            const int key = kt * KT + st_key;
-            const bool kvalid = key < p.Lk;
-            const long long krow = kvalid ? key : 0;
-            uint4 kraw = *reinterpret_cast<const uint4*>(kp + krow * p.k_sl + st_c * 8);
-            uint4 vraw = *reinterpret_cast<const uint4*>(vp + krow * p.v_sl + st_c * 8);
-            const unsigned m = kvalid ? 0xffffffffu : 0u;
-            kraw = make_uint4(kraw.x & m, kraw.y & m, kraw.z & m, kraw.w & m);
-            vraw = make_uint4(vraw.x & m, vraw.y & m, vraw.z & m, vraw.w & m);
-            if (p.gamma_k != nullptr) {
-                float ss = sumsq8(kraw);
-                ss += __shfl_xor(ss, 1, 64);
-                ss += __shfl_xor(ss, 2, 64);
-                kraw = rms_apply(kraw, ss, gk8);
-            }
-            __syncthreads();   // previous tile fully consumed
-            sK[st_key * 4 + (st_c ^ ((st_key >> 2) & 3))] = kraw;
-            const unsigned w[4] = {vraw.x, vraw.y, vraw.z, vraw.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                sVT[(st_c * 8 + 2 * i) * VT_LD + st_key] = (unsigned short)(w[i] & 0xffffu);
-                sVT[(st_c * 8 + 2 * i + 1) * VT_LD + st_key] = (unsigned short)(w[i] >> 16);
-            }
-            __syncthreads();
-        }
+    GVF_ATTN_LOAD(0)
+    GVF_ATTN_STORE(0, 0)
+    __syncthreads();
 
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            const int key0 = kt * KT + sub * 32;
-            if (key0 >= p.Lk) break;
-            // ---- S^T[key][q] = sum_d K[key][d] Q[q][d]
-            f32x16 s_acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s_acc[r] = 0.f;
-            {
-                const int krow_l = sub * 32 + l31;
-                const int sw = (krow_l >> 2) & 3;
-                const bf16x8 k0 = __builtin_bit_cast(bf16x8, sK[krow_l * 4 + ((0 + half) ^ sw)]);
-                const bf16x8 k1 = __builtin_bit_cast(bf16x8, sK[krow_l * 4 + ((2 + half) ^ sw)]);
-                s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf0, s_acc, 0, 0, 0);
-                s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf1, s_acc, 0, 0, 0);
-            }
-            // accumulator row r of this lane is key  key0 + (r&3) + 8*(r>>2) + 4*half
-            float mloc = -INFINITY;
-            const bool partial = key0 + 32 > p.Lk;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float sv = s_acc[r] * p.scale_log2e;
-                if (partial && (key0 + (r & 3) + 8 * (r >> 2) + 4 * half) >= p.Lk) sv = -INFINITY;
-                s_acc[r] = sv;
-                mloc = fmaxf(mloc, sv);
-            }
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-            const float m_new = fmaxf(m_run, mloc);        // finite: every sub-tile holds >= 1 valid key
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            float psum = 0.f;
-            unsigned pw[8];
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const float p0 = __builtin_amdgcn_exp2f(s_acc[r] - m_new);
-                const float p1 = __builtin_amdgcn_exp2f(s_acc[r + 1] - m_new);
-                psum += p0 + p1;
-                pw[r >> 1] = (unsigned)f2bf(p0) | ((unsigned)f2bf(p1) << 16);
-            }
-            l_run = l_run * alpha + psum;
-            m_run = m_new;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o_acc[r] *= alpha;
-            // ---- O^T[d][q] += sum_slots V^T[d][key(slot)] P^T[key(slot)][q]; slot (u, half, e) = accumulator row 8u+e
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const bf16x8 pf = __builtin_bit_cast(bf16x8, make_uint4(pw[4 * u], pw[4 * u + 1], pw[4 * u + 2], pw[4 * u + 3]));
-                const unsigned short* vrow = sVT + l31 * VT_LD + sub * 32 + 16 * u + 4 * half;
-                const uint2 va = *reinterpret_cast<const uint2*>(vrow);        // keys +0..3
-                const uint2 vb = *reinterpret_cast<const uint2*>(vrow + 8);    // keys +8..11
-                const bf16x8 vf = __builtin_bit_cast(bf16x8, make_uint4(va.x, va.y, vb.x, vb.y));
-                o_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o_acc, 0, 0, 0);
-            }
+    for (int kt = 0; kt < n_tiles; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < n_tiles) GVF_ATTN_LOAD(kt + 1)      // in flight while this tile is consumed
+
+        if (kt * KT + KT <= p.Lk) {          // full tile: no key masking
+            subtile<false>(sK[buf], sVT[buf], 0, kt * KT, p.Lk, p.scale_log2e, qf0, qf1, l31, half, o_acc, m_run, l_run);
+            subtile<false>(sK[buf], sVT[buf], 1, kt * KT + 32, p.Lk, p.scale_log2e, qf0, qf1, l31, half, o_acc, m_run, l_run);
+        } else {
+            subtile<true>(sK[buf], sVT[buf], 0, kt * KT, p.Lk, p.scale_log2e, qf0, qf1, l31, half, o_acc, m_run, l_run);
+            if (kt * KT + 32 < p.Lk)
+                subtile<true>(sK[buf], sVT[buf], 1, kt * KT + 32, p.Lk, p.scale_log2e, qf0, qf1, l31, half, o_acc, m_run, l_run);
         }
+        // the other buffer was last read in iteration kt-1; every wave has passed that iteration's barrier
+        if (kt + 1 < n_tiles) GVF_ATTN_STORE(buf ^ 1, kt + 1)
+        __syncthreads();
     }
+#undef GVF_ATTN_LOAD
+#undef GVF_ATTN_STORE
 
     // ---- epilogue: O[q][d] / l, d = (r&3) + 8*(r>>2) + 4*half
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -210,8 +261,8 @@ __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             uint2 w;
-            w.x = (unsigned)f2bf(o_acc[4 * g] * inv) | ((unsigned)f2bf(o_acc[4 * g + 1] * inv) << 16);
-            w.y = (unsigned)f2bf(o_acc[4 * g + 2] * inv) | ((unsigned)f2bf(o_acc[4 * g + 3] * inv) << 16);
+            w.x = cvt_pk_bf16(o_acc[4 * g] * inv, o_acc[4 * g + 1] * inv);
+            w.y = cvt_pk_bf16(o_acc[4 * g + 2] * inv, o_acc[4 * g + 3] * inv);
             *reinterpret_cast<uint2*>(orow + 8 * g + 4 * half) = w;
         }
     }
@@ -220,31 +271,35 @@ __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(AttnParams p) {
 }  // namespace
 
 extern "C" int gvf_attn_fwd_bf16(const void* q, const void* k, const void* v, void* out, int n_outer, int n_inner,
-                                 int Lq, int Lk, int H, int64_t q_so, int64_t q_si, int64_t q_sl, int64_t k_so,
-                                 int64_t k_si, int64_t k_sl, int64_t v_so, int64_t v_si, int64_t v_sl, int64_t o_so,
-                                 int64_t o_si, int64_t o_sl, const float* gamma_q, const float* gamma_k, float scale,
-                                 void* stream_) {
+                                 int Lq, int Lk, int H, const int64_t* q_strides, const int64_t* k_strides,
+                                 const int64_t* v_strides, const int64_t* o_strides, int v_transposed,
+                                 const float* gamma_q, const float* gamma_k, float scale, void* stream_) {
     if (n_outer < 0 || n_inner <= 0 || Lq < 0 || Lk <= 0 || H <= 0) return GVF_EINVAL;
     if (n_outer == 0 || Lq == 0) return GVF_OK;
-    if (!q || !k || !v || !out) return GVF_EINVAL;
-    // 16-byte operand chunks: bases and every stride must keep 8-element alignment
-    const int64_t strides[] = {q_so, q_si, q_sl, k_so, k_si, k_sl, v_so, v_si, v_sl};
-    for (int64_t s : strides)
-        if (s % 8 != 0) return GVF_EINVAL;
-    if ((o_so % 4) || (o_si % 4) || (o_sl % 4)) return GVF_EINVAL;
+    if (!q || !k || !v || !out || !q_strides || !k_strides || !v_strides || !o_strides) return GVF_EINVAL;
+    // 16-byte operand chunks: bases and every stride must keep 8-element alignment (outputs: 4)
+    for (int i = 0; i < 4; ++i) {
+        if ((q_strides[i] % 8) || (k_strides[i] % 8) || (v_strides[i] % 8) || (o_strides[i] % 4)) return GVF_EINVAL;
+    }
     if ((((uintptr_t)q) & 15) || (((uintptr_t)k) & 15) || (((uintptr_t)v) & 15) || (((uintptr_t)out) & 7)) return GVF_EINVAL;
     AttnParams p;
     p.q = (const unsigned short*)q; p.k = (const unsigned short*)k; p.v = (const unsigned short*)v;
     p.out = (unsigned short*)out;
     p.n_inner = n_inner; p.Lq = Lq; p.Lk = Lk; p.H = H; p.q_blocks = (Lq + QB - 1) / QB;
-    p.q_so = q_so; p.q_si = q_si; p.q_sl = q_sl; p.k_so = k_so; p.k_si = k_si; p.k_sl = k_sl;
-    p.v_so = v_so; p.v_si = v_si; p.v_sl = v_sl; p.o_so = o_so; p.o_si = o_si; p.o_sl = o_sl;
+    p.q_so = q_strides[0]; p.q_si = q_strides[1]; p.q_sl = q_strides[2]; p.q_sh = q_strides[3];
+    p.k_so = k_strides[0]; p.k_si = k_strides[1]; p.k_sl = k_strides[2]; p.k_sh = k_strides[3];
+    p.v_so = v_strides[0]; p.v_si = v_strides[1]; p.v_sl = v_strides[2]; p.v_sh = v_strides[3];
+    p.o_so = o_strides[0]; p.o_si = o_strides[1]; p.o_sl = o_strides[2]; p.o_sh = o_strides[3];
     p.gamma_q = gamma_q; p.gamma_k = gamma_k;
     p.scale_log2e = scale * 1.4426950408889634f;
+    if (!(scale > 0.0f)) return GVF_EINVAL;
     const long long blocks = (long long)p.q_blocks * H * n_inner * n_outer;
     if (blocks > 0x7fffffffLL) return GVF_EINVAL;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)blocks), dim3(THREADS), 0, (hipStream_t)stream_, p);
+    if (v_transposed)
+        hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3((unsigned)blocks), dim3(THREADS), 0, (hipStream_t)stream_, p);
+    else
+        hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3((unsigned)blocks), dim3(THREADS), 0, (hipStream_t)stream_, p);
     GVF_CHECK_LAUNCH();
     return GVF_OK;
 }

@@ -7,9 +7,9 @@
 //
 // Structure (first correct version; tuning notes in DESIGN.md): 128x128x64 block tile, 4 waves as
 // 2x2, each wave 64x64 = 4x4 fragments of v_mfma_f32_16x16x32_bf16; operands staged
-// global -> registers -> LDS (16-byte chunks, XOR-swizzled rows so the per-fragment ds_read_b128 of a
-// 16-lane group hits 8 distinct 16-byte slots), register prefetch of the next k-tile issued before the
-// MFMAs of the current one, one __syncthreads per k-tile, two LDS buffers.
+// global -> LDS by LDS-DMA (global_load_lds_dwordx4; 16-byte chunks, rows XOR-swizzled on the source side so
+// the per-fragment ds_read_b128 of a 16-lane group hits 8 distinct 16-byte slots), the next k-tile's DMA
+// issued before the MFMAs of the current one, one __syncthreads per k-tile, two LDS buffers.
 #include "gvf_common.h"
 #include "../../include/gvf_rast.h"
 #include "../../include/gvf_dit.h"
@@ -59,33 +59,34 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16_kernel(const unsigned short
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int KT = K / BK;
-    uint4 ra[LOADS], rb[LOADS];
 
-#define GVF_GEMM_LOAD_TILE(kt_)                                                                        \
-    _Pragma("unroll") for (int i = 0; i < LOADS; ++i) {                                                  \
-        const int c = tid + i * THREADS, row = c >> 3, kc = c & 7;                                         \
-        const int gr = bm + row, gn = bn + row;                                                            \
-        const size_t koff = (size_t)(kt_) * BK + kc * 8;                                                   \
-        const uint4 va_ = *reinterpret_cast<const uint4*>(A + (size_t)(gr < M ? gr : M - 1) * lda + koff);  \
-        const uint4 vb_ = *reinterpret_cast<const uint4*>(W + (size_t)(gn < N ? gn : N - 1) * ldw + koff);  \
-        const unsigned ma_ = gr < M ? 0xffffffffu : 0u, mb_ = gn < N ? 0xffffffffu : 0u;                   \
-        ra[i] = make_uint4(va_.x & ma_, va_.y & ma_, va_.z & ma_, va_.w & ma_);                            \
-        rb[i] = make_uint4(vb_.x & mb_, vb_.y & mb_, vb_.z & mb_, vb_.w & mb_);                            \
+    // Staging: global -> LDS directly (global_load_lds_dwordx4, no VGPR round trip, no ds_write pass).  One
+    // wave-instruction fills 64 consecutive 16-byte slots = 8 tile rows; the XOR swizzle that makes the fragment
+    // reads conflict-free is applied to the per-lane SOURCE chunk (LDS side stays linear, as the DMA requires).
+    // Rows past M / N are clamped in-bounds; their products land in accumulator rows / columns the epilogue drops.
+    const int st_row = lane >> 3, st_c = lane & 7;
+    const unsigned short* a_src[LOADS];
+    const unsigned short* w_src[LOADS];
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+        const int row = (i * 4 + wave) * 8 + st_row;          // tile row this lane fills with load i
+        const int gr = bm + row < M ? bm + row : M - 1;
+        const int gn = bn + row < N ? bn + row : N - 1;
+        a_src[i] = A + (size_t)gr * lda + ((st_c ^ (row & 7)) * 8);
+        w_src[i] = W + (size_t)gn * ldw + ((st_c ^ (row & 7)) * 8);
     }
-#define GVF_GEMM_STORE_TILE(buf_)                                                                        \
-    _Pragma("unroll") for (int i = 0; i < LOADS; ++i) {                                                  \
-        const int c = tid + i * THREADS, row = c >> 3, kc = c & 7;                                         \
-        sA[buf_][row * CHUNKS_PER_ROW + (kc ^ (row & 7))] = ra[i];                                         \
-        sB[buf_][row * CHUNKS_PER_ROW + (kc ^ (row & 7))] = rb[i];                                         \
+#define GVF_GEMM_STAGE(kt_, buf_)                                                                          \
+    _Pragma("unroll") for (int i = 0; i < LOADS; ++i) {                                                      \
+        __builtin_amdgcn_global_load_lds(a_src[i] + (size_t)(kt_) * BK, &sA[buf_][(i * 4 + wave) * 64], 16, 0, 0); \
+        __builtin_amdgcn_global_load_lds(w_src[i] + (size_t)(kt_) * BK, &sB[buf_][(i * 4 + wave) * 64], 16, 0, 0); \
     }
 
-    GVF_GEMM_LOAD_TILE(0)
-    GVF_GEMM_STORE_TILE(0)
-    __syncthreads();
+    GVF_GEMM_STAGE(0, 0)
+    __syncthreads();          // drains the DMA (vmcnt(0)) and publishes the tile
 
     for (int kt = 0; kt < KT; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < KT) { GVF_GEMM_LOAD_TILE(kt + 1) }
+        if (kt + 1 < KT) { GVF_GEMM_STAGE(kt + 1, buf ^ 1) }   // lands while this tile is multiplied
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ++ks) {
             bf16x8 af[4], bfr[4];
@@ -103,11 +104,9 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16_kernel(const unsigned short
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < KT) { GVF_GEMM_STORE_TILE(buf ^ 1) }
         __syncthreads();
     }
-#undef GVF_GEMM_LOAD_TILE
-#undef GVF_GEMM_STORE_TILE
+#undef GVF_GEMM_STAGE
 
     // epilogue.  16x16 accumulator fragment: column = lane & 15, rows = (lane >> 4) * 4 + r
     const int col_l = lane & 15, row_l = (lane >> 4) * 4;

@@ -273,14 +273,25 @@ class DiT(nn.Module):
         cs = dit_ops.cast_pad_bf16(static_latent.reshape(B * Ls, -1).float().contiguous(), dit_ops.pad64(static_latent.shape[-1]))
         st_emb = torch.empty((B * Ls, C), dtype=torch.bfloat16, device=dev)
         dit_ops.gemm_bf16(cs, W["static"][0], W["static"][1], st_emb, dit_ops.EPI_STORE_BF16)
+        H = self.num_heads
+
+        def relayout(kv, nb, L):
+            """(nb*L, 2C) [k | v] rows -> K (nb,H,L,32) head-major, V^T (nb,H,32,Lpad) zero-padded to 64 keys:
+            the attention kernel then stages both with plain 16-byte copies (no in-kernel transpose)."""
+            k = kv[:, :C].reshape(nb, L, H, 32).permute(0, 2, 1, 3).contiguous()
+            Lp = (L + 63) // 64 * 64
+            vt = torch.zeros((nb, H, 32, Lp), dtype=torch.bfloat16, device=dev)
+            vt[..., :L] = kv[:, C:].reshape(nb, L, H, 32).permute(0, 2, 3, 1)
+            return k, vt, Lp
+
         ctx["kv_img"], ctx["kv_st"] = [], []
+        kv_i = torch.empty((B * Tc * Li, 2 * C), dtype=torch.bfloat16, device=dev)
+        kv_s = torch.empty((B * Ls, 2 * C), dtype=torch.bfloat16, device=dev)
         for b in W["blocks"]:
-            kv = torch.empty((B * Tc * Li, 2 * C), dtype=torch.bfloat16, device=dev)
-            dit_ops.gemm_bf16(img_emb, *b["image_cross_attn"]["kv"], kv, dit_ops.EPI_STORE_BF16)
-            ctx["kv_img"].append(kv)
-            kv = torch.empty((B * Ls, 2 * C), dtype=torch.bfloat16, device=dev)   # once per sample, not per frame
-            dit_ops.gemm_bf16(st_emb, *b["static_cross_attn"]["kv"], kv, dit_ops.EPI_STORE_BF16)
-            ctx["kv_st"].append(kv)
+            dit_ops.gemm_bf16(img_emb, *b["image_cross_attn"]["kv"], kv_i, dit_ops.EPI_STORE_BF16)
+            ctx["kv_img"].append(relayout(kv_i, B * Tc, Li))
+            dit_ops.gemm_bf16(st_emb, *b["static_cross_attn"]["kv"], kv_s, dit_ops.EPI_STORE_BF16)   # once per sample, not per frame
+            ctx["kv_st"].append(relayout(kv_s, B, Ls))
         if self.pe_mode == "ape":
             assert deformation_position_xyz is not None, "Deformation position xyz is required for APE mode"
             ctx["pos"] = self.pos_embedder(deformation_position_xyz).float().contiguous()      # (B, N, C)
@@ -363,17 +374,17 @@ class DiT(nn.Module):
             a = b["image_cross_attn"]
             dit_ops.layernorm_modulate_bf16(h, hb, 1e-6, b["n3"][0], b["n3"][1])
             dit_ops.gemm_bf16(hb, *a["q"], ab, dit_ops.EPI_STORE_BF16)
-            kv = ctx["kv_img"][i]
-            sk = (Li * 2 * C, 0, 2 * C)
-            dit_ops.attention_bf16(ab, kv, kv[:, C:], hb, B * T, 1, N, Li, H, (N * C, 0, C), sk, sk, (N * C, 0, C), a["gq"], a["gk"])
+            kc, vt, Lp = ctx["kv_img"][i]
+            dit_ops.attention_bf16(ab, kc, vt, hb, B * T, 1, N, Li, H, (N * C, 0, C), (H * Li * 32, 0, 32, Li * 32),
+                                   (H * 32 * Lp, 0, Lp, 32 * Lp), (N * C, 0, C), a["gq"], a["gk"], v_transposed=True)
             dit_ops.gemm_bf16(hb, *a["out"], h, dit_ops.EPI_RESID_F32)
             # -- static cross attention: K/V shared by the T frames of a sample (inner stride 0)
             a = b["static_cross_attn"]
             dit_ops.layernorm_modulate_bf16(h, hb, 1e-6, b["n4"][0], b["n4"][1])
             dit_ops.gemm_bf16(hb, *a["q"], ab, dit_ops.EPI_STORE_BF16)
-            kv = ctx["kv_st"][i]
-            sk = (Ls * 2 * C, 0, 2 * C)
-            dit_ops.attention_bf16(ab, kv, kv[:, C:], hb, B, T, N, Ls, H, (TN * C, N * C, C), sk, sk, (TN * C, N * C, C), a["gq"], a["gk"])
+            kc, vt, Lp = ctx["kv_st"][i]
+            dit_ops.attention_bf16(ab, kc, vt, hb, B, T, N, Ls, H, (TN * C, N * C, C), (H * Ls * 32, 0, 32, Ls * 32),
+                                   (H * 32 * Lp, 0, Lp, 32 * Lp), (TN * C, N * C, C), a["gq"], a["gk"], v_transposed=True)
             dit_ops.gemm_bf16(hb, *a["out"], h, dit_ops.EPI_RESID_F32)
             # -- MLP
             dit_ops.layernorm_modulate_bf16(h, hb, 1e-6, None, None, sh_m, sc_m, mod_ld, TN)

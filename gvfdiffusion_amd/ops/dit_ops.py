@@ -11,7 +11,7 @@ EPI_STORE_BF16, EPI_GELU_BF16, EPI_STORE_F32, EPI_RESID_F32 = 0, 1, 2, 3
 
 _lib.register({
     "gvf_gemm_bf16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
-    "gvf_attn_fwd_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i] + [_i64] * 12 + [_vp, _vp, _f, _vp]),
+    "gvf_attn_fwd_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i] + [ctypes.POINTER(_i64)] * 4 + [_i, _vp, _vp, _f, _vp]),
     "gvf_layernorm_modulate_bf16": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "gvf_cast_pad_bf16": (_i, [_vp, _i, _vp, _i, _i64, _i, _i, _vp]),
 })
@@ -55,15 +55,23 @@ def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, epilogu
     return out
 
 
+def _s4(st):
+    st = tuple(int(x) for x in st)
+    if len(st) == 3:
+        st = st + (32,)          # packed heads: head h starts 32 elements after head h-1
+    return (_i64 * 4)(*st)
+
+
 def attention_bf16(q, k, v, out, n_outer, n_inner, Lq, Lk, H, q_strides, k_strides, v_strides, o_strides, gamma_q=None,
-                   gamma_k=None, scale=None):
-    """Strided flash attention (head_dim 32).  *_strides = (outer, inner, seq) in elements."""
+                   gamma_k=None, scale=None, v_transposed=False):
+    """Strided flash attention (head_dim 32).  *_strides = (outer, inner, seq[, head = 32]) in elements;
+    v_transposed: v stored [..][head][d][key] with v_strides[2] the d stride (see include/gvf_dit.h)."""
     _lib.require_cuda(q, k, v, out)
     assert q.dtype == k.dtype == v.dtype == out.dtype == torch.bfloat16
     scale = 32 ** -0.5 if scale is None else scale
-    args = [int(s) for st in (q_strides, k_strides, v_strides, o_strides) for s in st]
-    _lib.check(_lib.lib().gvf_attn_fwd_bf16(_p(q), _p(k), _p(v), _p(out), n_outer, n_inner, Lq, Lk, H, *args, _p(gamma_q),
-                                            _p(gamma_k), float(scale), _stream(q)), "gvf_attn_fwd_bf16")
+    _lib.check(_lib.lib().gvf_attn_fwd_bf16(_p(q), _p(k), _p(v), _p(out), n_outer, n_inner, Lq, Lk, H, _s4(q_strides),
+                                            _s4(k_strides), _s4(v_strides), _s4(o_strides), int(bool(v_transposed)),
+                                            _p(gamma_q), _p(gamma_k), float(scale), _stream(q)), "gvf_attn_fwd_bf16")
     return out
 
 

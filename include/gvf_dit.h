@@ -34,16 +34,18 @@ int gvf_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* b
                   int M, int N, int K, int epilogue, const float* gate, int gate_ld, int rows_per_group,
                   void* stream);
 
-/* softmax(q k^T * scale) v, head_dim 32, no mask.  Batch index = (outer, inner); element (o,i,l,h,c) of a
- * tensor sits at  o*so + i*si + l*sl + h*32 + c  (strides in elements), so the q/k/v slices of a packed
- * qkv / kv projection and the (B,T,N,.)<->(B,N,T,.) view of the temporal attention need no copies.
+/* softmax(q k^T * scale) v, head_dim 32, no mask, scale > 0.  Batch index = (outer, inner); every tensor
+ * takes 4 strides in elements {outer, inner, seq, head}: element (o,i,l,h,c) sits at
+ * o*s[0] + i*s[1] + l*s[2] + h*s[3] + c, so the q/k/v slices of a packed qkv / kv projection, a K/V set
+ * shared by all `inner` entries (stride 0) and the (B,T,N,.)<->(B,N,T,.) view of the temporal attention
+ * need no copies.  v_transposed != 0: v is stored [.., head][d][key] (keys contiguous, v_strides[2] = d
+ * stride, rows padded with finite values to a multiple of 64 keys) -- the layout of the DiT's
+ * step-invariant cross-attention cache.
  * gamma_q / gamma_k: f32 [H][32] MultiHeadRMSNorm gains (x <- normalize(x) * gamma * sqrt(32)) or null. */
 int gvf_attn_fwd_bf16(const void* q, const void* k, const void* v, void* out,
                       int n_outer, int n_inner, int Lq, int Lk, int H,
-                      int64_t q_so, int64_t q_si, int64_t q_sl,
-                      int64_t k_so, int64_t k_si, int64_t k_sl,
-                      int64_t v_so, int64_t v_si, int64_t v_sl,
-                      int64_t o_so, int64_t o_si, int64_t o_sl,
+                      const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                      const int64_t* o_strides, int v_transposed,
                       const float* gamma_q, const float* gamma_k, float scale, void* stream);
 
 /* out_bf16[r][:] = LN(x[r][:]) (eps, no affine) then either  * ln_w + ln_b  (affine LayerNorm, norm3/4)

@@ -15,4 +15,4 @@ for f in $(find /tmp/prof_$TAG -name "*stats*.csv" -o -name "*kernel_trace.csv" 
 ls -la "$OUT"
 tail -n 1 "$OUT/bench_under_rocprof.log" | cut -c1-400
 K=$(ls "$OUT"/*kernel_stats.csv 2>/dev/null | head -n 1)
-if [ -n "$K" ]; then head -n 25 "$K"; fi
+if [ -n "$K" ]; then head -n 16 "$K" | cut -c1-220; fi

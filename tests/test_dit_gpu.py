@@ -82,6 +82,15 @@ def test_attention_matches_oracle(cuda, N, Lq, Lk, H, rms):
     r = rel_l2(out, ref)
     print(f"attention N{N} Lq{Lq} Lk{Lk} H{H} rms={rms}: rel_l2={r:.2e} max={float((out.float()-ref).abs().max()):.2e}")
     assert r < 6e-3 and float((out.float() - ref).abs().max()) < 3e-2 * float(ref.abs().max())
+    # head-major K and transposed, zero-padded V (the DiT's cross-attention cache layout): same numbers
+    Lp = (Lk + 63) // 64 * 64
+    kh = k.permute(0, 2, 1, 3).contiguous()
+    vt = torch.zeros((N, H, 32, Lp), dtype=torch.bfloat16, device=cuda)
+    vt[..., :Lk] = v.permute(0, 2, 3, 1)
+    out2 = torch.empty_like(q)
+    dit_ops.attention_bf16(q, kh, vt, out2, N, 1, Lq, Lk, H, sq, (H * Lk * 32, 0, 32, Lk * 32), (H * 32 * Lp, 0, Lp, 32 * Lp),
+                           sq, gq, gk, v_transposed=True)
+    assert torch.equal(out2, out)
 
 
 def test_attention_operator_call_forms_and_strided_views(cuda):
