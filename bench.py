@@ -117,7 +117,7 @@ class DiTWorkload:
         self.cfg = man["config"]
         model = DiT(**self.cfg)
         model.load_state_dict(synthetic.dit_state_dict(man["state_dict"], seed=seed), strict=True)
-        self.model = model.to(dev).eval()
+        self.model = model.to(dev).eval().enable_graph(os.environ.get("GVF_DIT_GRAPH", "1") == "1")
         inp = {k: v.to(dev) for k, v in synthetic.dit_inputs(B=1, T=T, seed=seed + 1).items()}
         self.x = inp.pop("x"); inp.pop("t")
         self.cond = inp
@@ -150,6 +150,7 @@ class DiTWorkload:
 
 
 def bench_dit(dev, nfe=32):
+    nfe = int(os.environ.get("GVF_BENCH_DIT_NFE", nfe))
     w = DiTWorkload(dev)
     w.sample(steps=4)                       # warm-up: weight conversion, condition cache, allocator
     torch.cuda.synchronize()

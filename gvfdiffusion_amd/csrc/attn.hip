@@ -27,7 +27,8 @@ constexpr int D = 32;            // head dim
 constexpr int QB = 128;          // queries per workgroup
 constexpr int KT = 64;           // keys per staged tile
 constexpr int THREADS = 256;
-constexpr int VT_LD = KT + 8;    // row stride (bf16 elements) of the transposed V tile
+constexpr int VT_LD = KT + 4;    // row stride (bf16) of the transposed V tile: 34 dwords -> the 32 rows a wave reads with
+                                 // ds_read_b64 start on 32 distinct even banks (conflict-free); rows stay 8-byte aligned
 
 __device__ __forceinline__ unsigned short f2bf(float f) {
     unsigned u = __float_as_uint(f);
@@ -54,7 +55,7 @@ __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float
 struct AttnParams {
     const unsigned short *q, *k, *v;
     unsigned short* out;
-    int n_inner, Lq, Lk, H, q_blocks;
+    int n_outer, n_inner, Lq, Lk, H, q_blocks;
     long long q_so, q_si, q_sl, q_sh, k_so, k_si, k_sl, k_sh, v_so, v_si, v_sl, v_sh, o_so, o_si, o_sl, o_sh;
     const float *gamma_q, *gamma_k;
     float scale_log2e;
@@ -143,15 +144,18 @@ __device__ __forceinline__ void subtile(const uint4* __restrict__ sKb, const uns
 template <bool VT>
 __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(AttnParams p) {
     __shared__ uint4 sK[2][KT * 4];                   // [key][4 chunks of 8 bf16], chunk ^= (key >> 2) & 3
-    __shared__ __attribute__((aligned(16))) unsigned short sVT[2][D * VT_LD];   // [d][key]
+    __shared__ __attribute__((aligned(16))) unsigned short sVT[2][D * VT_LD + 8];   // [d][key]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
 
-    int bid = blockIdx.x;
+    // logical order: head slowest, then (outer, inner), q-block fastest; remapped so that one XCD owns a
+    // contiguous run -- all workgroups that stream the same K/V set (the q-blocks of a sequence; for the DiT's
+    // static cross attention all frames of a sample) read it through ONE L2.
+    int bid = (int)gvf_xcd_remap(blockIdx.x, gridDim.x);
     const int qb = bid % p.q_blocks; bid /= p.q_blocks;
-    const int head = bid % p.H; bid /= p.H;
-    const int inner = bid % p.n_inner, outer = bid / p.n_inner;
+    const int inner = bid % p.n_inner; bid /= p.n_inner;
+    const int outer = bid % p.n_outer, head = bid / p.n_outer;
 
     const unsigned short* qp = p.q + outer * p.q_so + inner * p.q_si + head * p.q_sh;
     const unsigned short* kp = p.k + outer * p.k_so + inner * p.k_si + head * p.k_sh;
@@ -219,7 +223,8 @@ __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(AttnParams p) {
         }                                                                                               \
         sK[buf_][st_key * 4 + (st_c ^ ((st_key >> 2) & 3))] = kw;                                       \
         if (VT) {                                                                                       \
-            *reinterpret_cast<uint4*>(&sVT[buf_][vt_d * VT_LD + vt_c * 8]) = vreg;                      \
+            *reinterpret_cast<uint2*>(&sVT[buf_][vt_d * VT_LD + vt_c * 8]) = make_uint2(vreg.x, vreg.y);     \
+            *reinterpret_cast<uint2*>(&sVT[buf_][vt_d * VT_LD + vt_c * 8 + 4]) = make_uint2(vreg.z, vreg.w); \
         } else {                                                                                        \
             const unsigned w[4] = {vreg.x & m, vreg.y & m, vreg.z & m, vreg.w & m};                     \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                             \
@@ -285,7 +290,7 @@ extern "C" int gvf_attn_fwd_bf16(const void* q, const void* k, const void* v, vo
     AttnParams p;
     p.q = (const unsigned short*)q; p.k = (const unsigned short*)k; p.v = (const unsigned short*)v;
     p.out = (unsigned short*)out;
-    p.n_inner = n_inner; p.Lq = Lq; p.Lk = Lk; p.H = H; p.q_blocks = (Lq + QB - 1) / QB;
+    p.n_outer = n_outer; p.n_inner = n_inner; p.Lq = Lq; p.Lk = Lk; p.H = H; p.q_blocks = (Lq + QB - 1) / QB;
     p.q_so = q_strides[0]; p.q_si = q_strides[1]; p.q_sl = q_strides[2]; p.q_sh = q_strides[3];
     p.k_so = k_strides[0]; p.k_si = k_strides[1]; p.k_sl = k_strides[2]; p.k_sh = k_strides[3];
     p.v_so = v_strides[0]; p.v_si = v_strides[1]; p.v_sl = v_strides[2]; p.v_sh = v_strides[3];

@@ -5,7 +5,8 @@
 // mlp.0 (+GELU-tanh), mlp.2 / to_out fused with the adaLN gate and the fp32 residual add.
 // W is the nn.Linear weight as stored ([N][K], K contiguous) -- exactly the "B^T" operand MFMA wants.
 //
-// Structure (first correct version; tuning notes in DESIGN.md): 128x128x64 block tile, 4 waves as
+// Structure: 128x128x32 block tile (32 KiB of LDS -> 4 workgroups per CU: the k-loop is short, K = 512 for
+// most of the DiT's projections, so DMA latency is hidden by co-resident workgroups), 4 waves as
 // 2x2, each wave 64x64 = 4x4 fragments of v_mfma_f32_16x16x32_bf16; operands staged
 // global -> LDS by LDS-DMA (global_load_lds_dwordx4; 16-byte chunks, rows XOR-swizzled on the source side so
 // the per-fragment ds_read_b128 of a 16-lane group hits 8 distinct 16-byte slots), the next k-tile's DMA
@@ -19,10 +20,14 @@ namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int THREADS = 256;
 constexpr int CHUNKS_PER_ROW = BK / 8;              // 16-byte chunks per tile row
-constexpr int LOADS = BM * CHUNKS_PER_ROW / THREADS;  // 4 chunks of A (and of W) per thread per k-tile
+constexpr int LOADS = BM * CHUNKS_PER_ROW / THREADS;  // 2 chunks of A (and of W) per thread per k-tile
+constexpr int ROWS_PER_DMA = 64 / CHUNKS_PER_ROW;       // tile rows filled by one wave-wide DMA instruction (16)
+// chunk swizzle for 64-byte rows: slot = chunk ^ swz(row); conflict-free for the ds_read_b128 lane groups
+// ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...) when swz(row) = 3 for rows 8..15 of each 16-row group, else 0.
+__device__ __forceinline__ int swz(int row) { return (row & 8) ? 3 : 0; }
 
 __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
     unsigned u = __float_as_uint(f);
@@ -31,25 +36,37 @@ __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
     return (unsigned short)(u >> 16);
 }
 
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    bf16x2 v;
+    v[0] = (__bf16)lo;
+    v[1] = (__bf16)hi;
+    return __builtin_bit_cast(unsigned, v);
+}
+
+// GELU (tanh form): 0.5 x (1 + tanh(u)) = x * sigmoid(2u), u = sqrt(2/pi) (x + 0.044715 x^3): one exp, one rcp
 __device__ __forceinline__ float gelu_tanh(float x) {
     const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    float u = k0 * (x + k1 * x * x * x);
-    return 0.5f * x * (1.0f + tanhf(u));
+    const float u = k0 * (x + k1 * x * x * x);
+    return x / (1.0f + __expf(-2.0f * u));
 }
 
 template <int EPI>
-__global__ __launch_bounds__(THREADS) void gemm_bf16_kernel(const unsigned short* __restrict__ A, int lda,
+__global__ __launch_bounds__(THREADS, 4) void gemm_bf16_kernel(const unsigned short* __restrict__ A, int lda,
                                                             const unsigned short* __restrict__ W, int ldw,
                                                             const float* __restrict__ bias, void* __restrict__ Cv,
                                                             int ldc, int M, int N, int K,
                                                             const float* __restrict__ gate, int gate_ld, int rpg,
-                                                            int tiles_n) {
+                                                            int tiles_n, int ablate) {
     __shared__ uint4 sA[2][BM * CHUNKS_PER_ROW];
     __shared__ uint4 sB[2][BN * CHUNKS_PER_ROW];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+    // XCD-aware order: an XCD walks whole rows of tiles, so the A panel of a tile row is fetched over the
+    // fabric once per chip (not once per XCD) and W (<= a few MiB) stays resident in every L2.
+    const unsigned tile = gvf_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
     const int bm = tile_m * BM, bn = tile_n * BN;
 
     f32x4 acc[4][4];
@@ -64,16 +81,16 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16_kernel(const unsigned short
     // wave-instruction fills 64 consecutive 16-byte slots = 8 tile rows; the XOR swizzle that makes the fragment
     // reads conflict-free is applied to the per-lane SOURCE chunk (LDS side stays linear, as the DMA requires).
     // Rows past M / N are clamped in-bounds; their products land in accumulator rows / columns the epilogue drops.
-    const int st_row = lane >> 3, st_c = lane & 7;
+    const int st_row = lane / CHUNKS_PER_ROW, st_c = lane % CHUNKS_PER_ROW;
     const unsigned short* a_src[LOADS];
     const unsigned short* w_src[LOADS];
 #pragma unroll
     for (int i = 0; i < LOADS; ++i) {
-        const int row = (i * 4 + wave) * 8 + st_row;          // tile row this lane fills with load i
+        const int row = (i * 4 + wave) * ROWS_PER_DMA + st_row;   // tile row this lane fills with load i
         const int gr = bm + row < M ? bm + row : M - 1;
         const int gn = bn + row < N ? bn + row : N - 1;
-        a_src[i] = A + (size_t)gr * lda + ((st_c ^ (row & 7)) * 8);
-        w_src[i] = W + (size_t)gn * ldw + ((st_c ^ (row & 7)) * 8);
+        a_src[i] = A + (size_t)gr * lda + ((st_c ^ swz(row)) * 8);
+        w_src[i] = W + (size_t)gn * ldw + ((st_c ^ swz(row)) * 8);
     }
 #define GVF_GEMM_STAGE(kt_, buf_)                                                                          \
     _Pragma("unroll") for (int i = 0; i < LOADS; ++i) {                                                      \
@@ -86,17 +103,16 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16_kernel(const unsigned short
 
     for (int kt = 0; kt < KT; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < KT) { GVF_GEMM_STAGE(kt + 1, buf ^ 1) }   // lands while this tile is multiplied
-#pragma unroll
-        for (int ks = 0; ks < BK / 32; ++ks) {
+        if (kt + 1 < KT && !(ablate & 1)) { GVF_GEMM_STAGE(kt + 1, buf ^ 1) }   // lands while this tile is multiplied
+        if (!(ablate & 2)) {
             bf16x8 af[4], bfr[4];
-            const int kc = ks * 4 + (lane >> 4);
+            const int kc = lane >> 4;
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
                 const int ar = wm * 64 + f * 16 + (lane & 15);
                 const int br = wn * 64 + f * 16 + (lane & 15);
-                af[f] = __builtin_bit_cast(bf16x8, sA[buf][ar * CHUNKS_PER_ROW + (kc ^ (ar & 7))]);
-                bfr[f] = __builtin_bit_cast(bf16x8, sB[buf][br * CHUNKS_PER_ROW + (kc ^ (br & 7))]);
+                af[f] = __builtin_bit_cast(bf16x8, sA[buf][ar * CHUNKS_PER_ROW + (kc ^ swz(ar))]);
+                bfr[f] = __builtin_bit_cast(bf16x8, sB[buf][br * CHUNKS_PER_ROW + (kc ^ swz(br))]);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -108,34 +124,75 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16_kernel(const unsigned short
     }
 #undef GVF_GEMM_STAGE
 
-    // epilogue.  16x16 accumulator fragment: column = lane & 15, rows = (lane >> 4) * 4 + r
+    // ---- epilogue.  A 16x16 accumulator fragment holds column (lane & 15), rows (lane >> 4) * 4 + r: writing it out
+    // directly costs 64 scattered 2/4-byte stores per lane (measured: half of the kernel's time).  Instead each
+    // wave bounces one 16-row x 64-column slab at a time through its private LDS region and emits whole 16-byte
+    // vectors: one wave-instruction then covers 4 rows x 256 B (fp32) / 128 B (bf16), and the read-modify-write of
+    // the fp32 residual stream, the bias and the gate are float4 accesses.
+    if ((ablate & 4) && acc[0][0][0] != 12345.678f) return;
+    constexpr int EP_LD = 68;                                  // floats per staged row (64 + 4 pad)
+    float* ep = reinterpret_cast<float*>(&sA[0][0]) + wave * (16 * EP_LD);   // 4 x 4352 B <= the 32 KiB of sA
+    __syncthreads();                                           // every wave is done reading the operand tiles
     const int col_l = lane & 15, row_l = (lane >> 4) * 4;
+    const int er = lane >> 4, ec = (lane & 15) * 4;            // read-back role: row er (+4 per step), columns ec..ec+3
+    const int col0 = bn + wn * 64 + ec;
+    const bool vec_ok = (N % 4 == 0) && (ldc % 4 == 0) && (EPI != GVF_EPI_RESID_F32 || gate == nullptr || gate_ld % 4 == 0);
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias != nullptr) {
+        if (vec_ok && col0 + 3 < N) bias4 = *reinterpret_cast<const float4*>(bias + col0);
+        else {
+            bias4.x = col0 < N ? bias[col0] : 0.f; bias4.y = col0 + 1 < N ? bias[col0 + 1] : 0.f;
+            bias4.z = col0 + 2 < N ? bias[col0 + 2] : 0.f; bias4.w = col0 + 3 < N ? bias[col0 + 3] : 0.f;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int col = bn + wn * 64 + j * 16 + col_l;
-            if (col >= N) continue;
-            const float bv = bias != nullptr ? bias[col] : 0.0f;
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = bm + wm * 64 + i * 16 + row_l + r;
-                if (row >= M) continue;
-                float v = acc[i][j][r] + bv;
-                const size_t o = (size_t)row * ldc + col;
-                if (EPI == GVF_EPI_STORE_BF16) {
-                    reinterpret_cast<unsigned short*>(Cv)[o] = f32_to_bf16(v);
-                } else if (EPI == GVF_EPI_GELU_BF16) {
-                    reinterpret_cast<unsigned short*>(Cv)[o] = f32_to_bf16(gelu_tanh(v));
+            for (int r = 0; r < 4; ++r) ep[(row_l + r) * EP_LD + j * 16 + col_l] = acc[i][j][r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int step = 0; step < 4; ++step) {
+            const int lr = step * 4 + er;
+            const int row = bm + wm * 64 + i * 16 + lr;
+            float4 v = *reinterpret_cast<const float4*>(&ep[lr * EP_LD + ec]);
+            v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+            if (row >= M || col0 >= N) continue;
+            if (EPI == GVF_EPI_GELU_BF16) { v.x = gelu_tanh(v.x); v.y = gelu_tanh(v.y); v.z = gelu_tanh(v.z); v.w = gelu_tanh(v.w); }
+            const size_t o = (size_t)row * ldc + col0;
+            if (vec_ok && col0 + 3 < N) {
+                if (EPI == GVF_EPI_STORE_BF16 || EPI == GVF_EPI_GELU_BF16) {
+                    uint2 w2;
+                    w2.x = pack_bf16(v.x, v.y); w2.y = pack_bf16(v.z, v.w);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(Cv) + o) = w2;
                 } else if (EPI == GVF_EPI_STORE_F32) {
-                    reinterpret_cast<float*>(Cv)[o] = v;
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + o) = v;
                 } else {
-                    float g = gate != nullptr ? gate[(size_t)(row / rpg) * gate_ld + col] : 1.0f;
-                    float* c = reinterpret_cast<float*>(Cv) + o;
-                    *c = *c + g * v;
+                    float4 g = make_float4(1.f, 1.f, 1.f, 1.f);
+                    if (gate != nullptr) g = *reinterpret_cast<const float4*>(gate + (size_t)(row / rpg) * gate_ld + col0);
+                    float4* c = reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + o);
+                    float4 x = *c;
+                    x.x += g.x * v.x; x.y += g.y * v.y; x.z += g.z * v.z; x.w += g.w * v.w;
+                    *c = x;
+                }
+            } else {
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (col0 + e >= N) break;
+                    if (EPI == GVF_EPI_STORE_BF16 || EPI == GVF_EPI_GELU_BF16) {
+                        reinterpret_cast<unsigned short*>(Cv)[o + e] = f32_to_bf16(vv[e]);
+                    } else if (EPI == GVF_EPI_STORE_F32) {
+                        reinterpret_cast<float*>(Cv)[o + e] = vv[e];
+                    } else {
+                        const float g = gate != nullptr ? gate[(size_t)(row / rpg) * gate_ld + col0 + e] : 1.0f;
+                        reinterpret_cast<float*>(Cv)[o + e] += g * vv[e];
+                    }
                 }
             }
         }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -157,18 +214,20 @@ extern "C" int gvf_gemm_bf16(const void* A, int lda, const void* W, int ldw, con
     const unsigned short* a = (const unsigned short*)A;
     const unsigned short* w = (const unsigned short*)W;
     const int rpg = rows_per_group > 0 ? rows_per_group : 1;
+    const char* abl_ = getenv("GVF_GEMM_ABLATE");   // perf ablation only (1: no k-loop DMA, 2: no MFMA, 4: no epilogue)
+    const int ablate = abl_ ? atoi(abl_) : 0;
     switch (epilogue) {
         case GVF_EPI_STORE_BF16:
-            hipLaunchKernelGGL(gemm_bf16_kernel<GVF_EPI_STORE_BF16>, grid, block, 0, stream, a, lda, w, ldw, bias, C, ldc, M, N, K, gate, gate_ld, rpg, tiles_n);
+            hipLaunchKernelGGL(gemm_bf16_kernel<GVF_EPI_STORE_BF16>, grid, block, 0, stream, a, lda, w, ldw, bias, C, ldc, M, N, K, gate, gate_ld, rpg, tiles_n, ablate);
             break;
         case GVF_EPI_GELU_BF16:
-            hipLaunchKernelGGL(gemm_bf16_kernel<GVF_EPI_GELU_BF16>, grid, block, 0, stream, a, lda, w, ldw, bias, C, ldc, M, N, K, gate, gate_ld, rpg, tiles_n);
+            hipLaunchKernelGGL(gemm_bf16_kernel<GVF_EPI_GELU_BF16>, grid, block, 0, stream, a, lda, w, ldw, bias, C, ldc, M, N, K, gate, gate_ld, rpg, tiles_n, ablate);
             break;
         case GVF_EPI_STORE_F32:
-            hipLaunchKernelGGL(gemm_bf16_kernel<GVF_EPI_STORE_F32>, grid, block, 0, stream, a, lda, w, ldw, bias, C, ldc, M, N, K, gate, gate_ld, rpg, tiles_n);
+            hipLaunchKernelGGL(gemm_bf16_kernel<GVF_EPI_STORE_F32>, grid, block, 0, stream, a, lda, w, ldw, bias, C, ldc, M, N, K, gate, gate_ld, rpg, tiles_n, ablate);
             break;
         case GVF_EPI_RESID_F32:
-            hipLaunchKernelGGL(gemm_bf16_kernel<GVF_EPI_RESID_F32>, grid, block, 0, stream, a, lda, w, ldw, bias, C, ldc, M, N, K, gate, gate_ld, rpg, tiles_n);
+            hipLaunchKernelGGL(gemm_bf16_kernel<GVF_EPI_RESID_F32>, grid, block, 0, stream, a, lda, w, ldw, bias, C, ldc, M, N, K, gate, gate_ld, rpg, tiles_n, ablate);
             break;
         default:
             return GVF_EINVAL;

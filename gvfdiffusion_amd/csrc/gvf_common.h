@@ -49,3 +49,14 @@ __device__ __forceinline__ unsigned gvf_wave_incl_scan(unsigned v, unsigned lane
     }
     return v;
 }
+
+// XCD-aware workgroup remap (MI355X: 8 XCDs, each with a private 4 MiB L2; the dispatcher is observed to
+// place workgroup b on XCD b % 8).  Returns the logical work index of physical workgroup `bid` such that
+// each XCD owns ONE contiguous range of logical indices: neighbours in logical order (which share operand
+// panels / K-V sets) then hit the same L2 instead of each XCD re-fetching them over the fabric.
+// Bijective for any grid size; a different placement only costs speed, never correctness.
+__device__ __forceinline__ unsigned gvf_xcd_remap(unsigned bid, unsigned nwg) {
+    const unsigned q = nwg >> 3, r = nwg & 7u;
+    const unsigned xcd = bid & 7u, slot = bid >> 3;
+    return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + slot;
+}

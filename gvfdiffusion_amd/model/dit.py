@@ -172,6 +172,8 @@ class DiT(nn.Module):
         self.initialize_weights()
         self._wcache = None       # bf16 weights, rebuilt when any parameter changes
         self._ctx_cache = {}      # step-invariant condition products
+        self.use_graph = False    # replay the whole forward as one hipGraph (set by enable_graph)
+        self._graph = None
 
     @property
     def device(self) -> torch.device:
@@ -305,7 +307,38 @@ class DiT(nn.Module):
     # ---- forward ------------------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor, t: torch.Tensor, cond_images: torch.Tensor, static_latent: torch.Tensor,
                 deformation_position_xyz: torch.Tensor = None) -> torch.Tensor:
+        if self.use_graph:
+            return self._forward_graphed(x, t, cond_images, static_latent, deformation_position_xyz)
         return self._forward(x, t, cond_images, static_latent, deformation_position_xyz)
+
+    def enable_graph(self, on: bool = True):
+        """Capture the ~200 launches of one forward pass into a hipGraph on first use and replay it for
+        every later step with the same shapes and the same condition tensors (the sampling loop's case):
+        removes the per-launch host cost from the denoise step.  Numerics are unchanged (same kernels)."""
+        self.use_graph = bool(on)
+        self._graph = None
+        return self
+
+    @torch.no_grad()
+    def _forward_graphed(self, x, t, cond_images, static_latent, deformation_position_xyz=None):
+        _lib.require_cuda(x, t, cond_images, static_latent, deformation_position_xyz)
+        t = t.to(x.device)
+        key = (tuple(x.shape), x.dtype, tuple(t.shape), t.dtype, self._key(cond_images), self._key(static_latent),
+               self._key(deformation_position_xyz), self._param_version())
+        g = self._graph
+        if g is None or g["key"] != key:
+            sx, st = x.clone(), t.clone()
+            # eager run first: builds the weight / condition caches and warms the allocator outside the capture
+            self._forward(sx, st, cond_images, static_latent, deformation_position_xyz)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                sy = self._forward(sx, st, cond_images, static_latent, deformation_position_xyz)
+            g = self._graph = {"key": key, "graph": graph, "x": sx, "t": st, "y": sy}
+        g["x"].copy_(x)
+        g["t"].copy_(t)
+        g["graph"].replay()
+        return g["y"].clone()
 
     def _forward_with_mem_ratio(self, x, t, cond_images, static_latent, deformation_position_xyz=None, mem_ratio=1.0):
         """ElasticModule contract at inference (elastic_utils.py:166-168): (exact_mem_ratio, output)."""

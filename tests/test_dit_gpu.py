@@ -182,6 +182,18 @@ def test_condition_cache_is_keyed_on_tensor_identity(cuda):
     assert torch.equal(y3, y4)
 
 
+def test_graph_replay_equals_eager(cuda):
+    g, cfg, sd, model = _load_small(cuda)
+    args = [torch.from_numpy(g[k]).to(cuda) for k in ("x", "t", "cond_images", "static_latent", "xyz")]
+    eager = [model(args[0] * s, args[1] * s, *args[2:]) for s in (1.0, 0.5, 0.25)]
+    model.enable_graph(True)
+    graphed = [model(args[0] * s, args[1] * s, *args[2:]) for s in (1.0, 0.5, 0.25)]
+    for a, b in zip(eager, graphed):
+        assert torch.equal(a, b)
+    assert model._graph is not None
+    model.enable_graph(False)
+
+
 def test_full_config_forward_matches_reference_golden(cuda):
     """configs/diffusion.yml, B=1, T=24, N=512, 1370 image tokens, 4096 static tokens (BASELINE configs[2])."""
     from gvfdiffusion_amd.model.dit import DiT
