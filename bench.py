@@ -219,7 +219,7 @@ def main():
     # frame exchange (N > 1): uint8 frames, one all-gather per step on a side stream
     side = torch.cuda.Stream(device=dev) if world > 1 else None
     u8 = [torch.empty((F, 3, S, S), dtype=torch.uint8, device=dev) for _ in range(2)] if world > 1 else None
-    gathered = [torch.empty((world, F, 3, S, S), dtype=torch.uint8, device=dev) for _ in range(2)] if world > 1 else None
+    gathered = [torch.empty((world * F, 3, S, S), dtype=torch.uint8, device=dev) for _ in range(2)] if world > 1 else None
     ready = [torch.cuda.Event() for _ in range(2)] if world > 1 else None
     consumed = [torch.cuda.Event() for _ in range(2)] if world > 1 else None
 
