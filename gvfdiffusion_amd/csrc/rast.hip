@@ -457,6 +457,40 @@ __global__ __launch_bounds__(256) void ranges_kernel(const uint64_t* __restrict_
 // ---------------------------------------------------------------------------------------------
 // R6: blend
 // ---------------------------------------------------------------------------------------------
+// One workgroup per 16x16 tile, as upstream's renderCUDA, but the 4 waves own the four 8x8 QUADRANTS of
+// the tile and each wave only walks the splats that can reach its quadrant:
+//   * the thread that stages splat j of a 256-splat batch into LDS also computes a 4-bit quadrant mask from
+//     the axis-aligned bounding box of the region where alpha = opacity * exp(power) can reach 1/255
+//     ( ca dx^2 + 2 cb dx dy + cc dy^2 <= 2 ln(255 opacity) ), inflated so that float noise can only keep
+//     extra splats, never drop one (a kept splat is evaluated with exactly the upstream arithmetic, so the
+//     image is unchanged; a culled one would have been skipped by the alpha < 1/255 test for every pixel
+//     of the quadrant);
+//   * each wave compacts the batch into its own index list with wave64 ballots (order preserved = depth
+//     order) and iterates over that list only.  A typical splat (3-sigma radius ~9 px) reaches ~40 % of the
+//     quadrants of the tiles it was binned to, so ~60 % of upstream's (pixel, splat) evaluations disappear.
+// Early termination is per wave (all 64 pixels saturated) and per workgroup (stop staging).
+__device__ __forceinline__ unsigned quadrant_mask(const float4 a, const float4 b, float tile_x0, float tile_y0,
+                                                  bool no_cull) {
+    const float op = b.y;
+    if (op < 1.0f / 255.0f) return 0u;                   // alpha <= opacity < 1/255 at every pixel
+    if (no_cull) return 0xFu;
+    const float ca = a.z, cb = a.w, cc = b.x;
+    const float det = ca * cc - cb * cb;
+    if (!(det > 0.0f) || !(ca > 0.0f) || !(cc > 0.0f)) return 0xFu;   // degenerate conic: keep everywhere
+    const float tau = 2.0f * logf(255.0f * op) * 1.001f + 1e-3f;
+    const float inv = 1.0f / det;
+    const float hx = sqrtf(tau * cc * inv) * 1.001f + 0.01f;
+    const float hy = sqrtf(tau * ca * inv) * 1.001f + 0.01f;
+    unsigned m = 0u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float x0 = tile_x0 + (float)((q & 1) * 8), y0 = tile_y0 + (float)((q >> 1) * 8);
+        const bool hit = (a.x + hx >= x0) && (a.x - hx <= x0 + 7.0f) && (a.y + hy >= y0) && (a.y - hy <= y0 + 7.0f);
+        m |= hit ? (1u << q) : 0u;
+    }
+    return m;
+}
+
 __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
     int P, int H, int W, int gx, int gy, float bg0, float bg1, float bg2, const uint2* __restrict__ ranges,
     const uint32_t* __restrict__ point_list, const float4* __restrict__ geomA, const float4* __restrict__ geomB,
@@ -465,12 +499,14 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
     __shared__ float4 sA[BLEND_THREADS];
     __shared__ float4 sB[BLEND_THREADS];
     __shared__ float2 sC[BLEND_THREADS];
+    __shared__ unsigned char sMask[BLEND_THREADS];
+    __shared__ unsigned char sList[4][BLEND_THREADS];     // per-wave compacted splat indices of the batch
 
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int f = blockIdx.y;
     const int tile = blockIdx.x;
     const int tx = tile % gx, ty = tile / gx;
-    const int px = tx * TILE + (t & (TILE - 1)), py = ty * TILE + (t >> 4);
+    const int px = tx * TILE + (wave & 1) * 8 + (lane & 7), py = ty * TILE + (wave >> 1) * 8 + (lane >> 3);
     const bool inside = px < W && py < H;
     const size_t pid = (size_t)py * W + px;
     float pxf = (float)px, pyf = (float)py;
@@ -480,6 +516,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
     const size_t gbase = (size_t)f * P;
     const int rounds = (int)((rng.y - rng.x + BLEND_THREADS - 1) / BLEND_THREADS);
     int todo = (int)(rng.y - rng.x);
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
 
     bool done = !inside;
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dacc = 0.f;
@@ -488,13 +525,29 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
         if (__syncthreads_count(done) == BLEND_THREADS) break;
         if (t < todo) {
             uint32_t id = point_list[rng.x + (uint32_t)r * BLEND_THREADS + t];
-            sA[t] = geomA[gbase + id];
-            sB[t] = geomB[gbase + id];
+            const float4 a = geomA[gbase + id];
+            const float4 b = geomB[gbase + id];
+            sA[t] = a;
+            sB[t] = b;
             sC[t] = geomC[gbase + id];
+            sMask[t] = (unsigned char)quadrant_mask(a, b, (float)(tx * TILE), (float)(ty * TILE), subpixel_offset != nullptr);
         }
         __syncthreads();
         const int cnt = min(BLEND_THREADS, todo);
-        for (int j = 0; !done && j < cnt; ++j) {
+        if (__all(done)) continue;                        // this quadrant is saturated (wave-uniform)
+        // compact the batch into this wave's list (ascending index = depth order)
+        int n_w = 0;
+#pragma unroll
+        for (int k = 0; k < BLEND_THREADS / GVF_WAVE; ++k) {
+            const int idx = k * GVF_WAVE + lane;
+            const bool hit = idx < cnt && ((sMask[idx] >> wave) & 1u);
+            const uint64_t bal = __ballot(hit);
+            if (hit) sList[wave][n_w + __popcll(bal & lt_mask)] = (unsigned char)idx;
+            n_w += __popcll(bal);
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int jj = 0; !done && jj < n_w; ++jj) {
+            const int j = sList[wave][jj];
             const float4 a = sA[j];
             const float4 b = sB[j];
             float dx = a.x - pxf, dy = a.y - pyf;
