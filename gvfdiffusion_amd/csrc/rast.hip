@@ -9,17 +9,18 @@
 // discrete decisions (cull, radius, tile rect, sort order) match the oracle bit for bit.
 //
 // Launch structure (F frames per call, everything stream-ordered, no host sync):
-//   preprocess   grid (ceil(P/256), F)   geometry + tiles_touched + per-block sums
-//   scan_sums    1 block                 exclusive scan of the F*nb block sums, per-frame D, total D
-//   duplicate    grid (ceil(P/256), F)   (frame*tiles + tile) << 32 | depth_bits keys, Gaussian-id values
-//   radix sort   sort.hip                one sort over all frames' instances, count read on device
-//   ranges       over instances          per (frame,tile) [start,end)
-//   blend        grid (tiles, F)         16x16 px per workgroup, 4 waves = 4 strips of 16x4 px
+//   preprocess   grid (ceil(P/256), F)   geometry, tiles_touched, per-(frame,tile) instance counts (atomics)
+//   tile_scan    1 workgroup             exclusive scan of the F*tiles counts = segment bases = tile ranges
+//   scatter      grid (ceil(P/256), F)   (depth_bits << 32 | id) keys into the tile segments (atomic cursors)
+//   tile_sort    grid F*tiles            per-tile bitonic sort in LDS (3 size classes), writes ordered ids
+//   blend        grid (tiles, F)         16x16 px per workgroup, 4 waves = the four 8x8 quadrants
+// Upstream sorts all (tile, depth) keys with a global radix sort (6+ passes over 12 B per instance); binning by
+// tile first and sorting each ~460-key segment on chip needs one 8-byte scatter and one read per instance.
 //
 // HBM layout (caller-owned workspace, carved below): per (frame, Gaussian) three records
 //   geomA float4 {x, y, conic_a, conic_b}, geomB float4 {conic_c, opacity, r, g}, geomC float2 {b, depth}
-// (40 B fetched per (splat,tile) instance by the blend), tiles_touched u32; per instance u64 key +
-// u32 id, double-buffered for the sort.
+// (40 B fetched per (splat,tile) instance by the blend), tiles_touched u32; per instance one u64 key in its
+// tile's segment and, after the sort, one u32 id.
 #include "gvf_common.h"
 #include "gvf_sort.h"
 #include "../../include/gvf_rast.h"
@@ -338,6 +339,7 @@ __global__ __launch_bounds__(PRE_THREADS) void preprocess_kernel(
                     }
                     touched = cnt;
                     radius_out = (int)my_radius;
+
                     gA = make_float4(px, py, ca, cb);
                     gB = make_float4(cc, op * coef, rgb[0], rgb[1]);
                     gC = make_float2(rgb[2], pv[2]);
@@ -452,6 +454,80 @@ __global__ __launch_bounds__(256) void ranges_kernel(const uint64_t* __restrict_
         }
         if (k == n - 1) ranges[cur].y = n;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// R4 (second half): per-tile sort.  The radix sort above only ordered the instances by (frame, tile) -- two 8-bit
+// passes instead of six; one workgroup per (frame, tile) now sorts its segment by (depth, id) with a bitonic
+// network on chip and writes the Gaussian ids in order (identical to upstream's stable (tile, depth) sort).  Three size classes share the code: segments up to
+// SMALL_N keys in 16 KiB of static LDS (256 threads; the common case, ~460 keys per tile at the bench shape),
+// up to LARGE_N keys in 128 KiB of dynamic LDS (1024 threads), anything larger in place in global memory
+// (slow, correct: a whole scene projected onto one tile).  All three are launched over all tiles; a
+// workgroup whose segment is not in its class exits at once.
+// ---------------------------------------------------------------------------------------------
+constexpr int SORT_SMALL_N = 2048;
+constexpr int SORT_LARGE_N = 16384;
+
+// Bitonic sorting network in its "all comparators ascending" form (the first step of every merge compares
+// mirrored partners i <-> block_end - i, the remaining steps are the usual half-cleaners).  Because every
+// compare-exchange puts the larger key at the higher index, virtual +inf padding above n never moves: pairs
+// whose upper index is >= n are simply skipped, so n need not be a power of two and nothing is padded.
+template <typename Ptr>
+__device__ __forceinline__ void bitonic_sort_asc(Ptr keys, int n, int tid, int nthreads) {
+    int npad = 2;
+    while (npad < n) npad <<= 1;
+    const int half = npad >> 1;
+    for (int k = 2; k <= npad; k <<= 1) {
+        for (int i = tid; i < half; i += nthreads) {
+            const int blk = i / (k >> 1), off = i % (k >> 1);
+            const int lo = blk * k + off, hi = blk * k + k - 1 - off;
+            if (hi < n) {
+                const uint64_t a = keys[lo], b = keys[hi];
+                if (a > b) { keys[lo] = b; keys[hi] = a; }
+            }
+        }
+        __syncthreads();
+        for (int j = k >> 2; j > 0; j >>= 1) {
+            for (int i = tid; i < half; i += nthreads) {
+                const int lo = 2 * i - (i & (j - 1));
+                const int hi = lo + j;
+                if (hi < n) {
+                    const uint64_t a = keys[lo], b = keys[hi];
+                    if (a > b) { keys[lo] = b; keys[hi] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int MODE>   // 0: small (static LDS), 1: large (dynamic LDS), 2: huge (global, in place)
+__global__ void tile_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __restrict__ keys,
+                                 const uint32_t* __restrict__ vals, uint32_t* __restrict__ ids) {
+    __shared__ uint64_t s_small[MODE == 0 ? SORT_SMALL_N : 1];
+    extern __shared__ __attribute__((aligned(16))) uint64_t s_large[];
+    const uint2 rng = ranges[blockIdx.x];
+    const int n = (int)(rng.y - rng.x);
+    if (n <= 0) return;
+    if (MODE == 0 && n > SORT_SMALL_N) return;
+    if (MODE == 1 && (n <= SORT_SMALL_N || n > SORT_LARGE_N)) return;
+    if (MODE == 2 && n <= SORT_LARGE_N) return;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    uint64_t* k = keys + rng.x;
+    const uint32_t* v = vals + rng.x;
+    // local key: depth bits (low word of the global key) above the Gaussian id -> unique within the tile
+    if (MODE == 2) {
+        for (int i = tid; i < n; i += nt) k[i] = (k[i] << 32) | v[i];   // in place in global memory
+        __syncthreads();
+        if (n > 1) bitonic_sort_asc(k, n, tid, nt);
+        for (int i = tid; i < n; i += nt) ids[rng.x + i] = (uint32_t)k[i];
+        return;
+    }
+    uint64_t* sk = MODE == 0 ? s_small : s_large;
+    for (int i = tid; i < n; i += nt) sk[i] = (k[i] << 32) | v[i];
+    __syncthreads();
+    if (n > 1) bitonic_sort_asc(sk, n, tid, nt);
+    for (int i = tid; i < n; i += nt) ids[rng.x + i] = (uint32_t)sk[i];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -608,7 +684,7 @@ struct Workspace {
     float4* geomA; float4* geomB; float2* geomC;
     uint32_t* tiles_touched; int32_t* radii;
     uint32_t* block_sums; uint32_t* frame_base; uint32_t* total;
-    uint64_t* keys; uint64_t* keys_alt; uint32_t* vals; uint32_t* vals_alt;
+    uint64_t* keys; uint64_t* keys_alt; uint32_t* vals; uint32_t* vals_alt; uint32_t* ids;
     uint2* ranges;
     void* sort_tmp; size_t sort_tmp_bytes;
     size_t bytes; bool ok;
@@ -641,6 +717,7 @@ Workspace carve(void* ws, size_t bytes, int P, int F, int H, int W, int64_t max_
     w.keys_alt = c.take<uint64_t>(D);
     w.vals = c.take<uint32_t>(D);
     w.vals_alt = c.take<uint32_t>(D);
+    w.ids = c.take<uint32_t>(D);
     w.ranges = c.take<uint2>((size_t)F * ntiles);
     w.sort_tmp_bytes = gvf_sort_tmp_bytes((int64_t)D);
     w.sort_tmp = c.take<char>(w.sort_tmp_bytes);
@@ -686,7 +763,6 @@ int run_pipeline(const GvfRastSettings& st, const GvfRastFrame* frames_host, int
     if (P == 0 || nb == 0) {
         // nothing to splat: background only
         if (hipMemsetAsync(out_num_rendered, 0, sizeof(uint32_t) * F, stream) != hipSuccess) return GVF_ELAUNCH;
-        if (hipMemsetAsync(w.total, 0, sizeof(uint32_t), stream) != hipSuccess) return GVF_ELAUNCH;
     } else {
         prof_mark(stream, slot, 0);
         PreParams pp;
@@ -713,24 +789,39 @@ int run_pipeline(const GvfRastSettings& st, const GvfRastFrame* frames_host, int
             if (hipMemcpyAsync(out_radii, w.radii, sizeof(int32_t) * (size_t)F * P, hipMemcpyDeviceToDevice, stream) != hipSuccess)
                 return GVF_ELAUNCH;
         }
-    }
-
-    uint64_t* keys_sorted = w.keys;
-    uint32_t* vals_sorted = w.vals;
-    if (P > 0 && max_rendered > 0) {
         prof_mark(stream, slot, 3);
-        int in_alt = 0;
-        int rc = gvf_sort_pairs_device_n(w.keys, w.keys_alt, w.vals, w.vals_alt, w.total, max_rendered,
-                                         key_end_bit(F, ntiles), w.sort_tmp, w.sort_tmp_bytes, stream, &in_alt);
-        if (rc != GVF_OK) return rc;
-        if (in_alt) { keys_sorted = w.keys_alt; vals_sorted = w.vals_alt; }
-        prof_mark(stream, slot, 4);
-        int rblocks = (int)((max_rendered + 255) / 256);
-        if (rblocks > 4096) rblocks = 4096;
-        hipLaunchKernelGGL(ranges_kernel, dim3(rblocks), dim3(256), 0, stream, keys_sorted, w.total,
-                           (uint32_t)max_rendered, w.ranges, (uint32_t)((size_t)F * ntiles));
-        GVF_CHECK_LAUNCH();
+        if (max_rendered > 0) {
+            // (a) stable radix sort on the (frame, tile) bits only: segments become contiguous, emission
+            //     (= Gaussian index) order inside a segment is kept but irrelevant; (b) tile ranges;
+            //     (c) per-tile on-chip sort by (depth, id).
+            uint64_t* keys_sorted = w.keys;
+            uint32_t* vals_by_tile = w.vals;
+            int in_alt = 0;
+            int rc = gvf_sort_pairs_device_n(w.keys, w.keys_alt, w.vals, w.vals_alt, w.total, max_rendered, 32,
+                                             key_end_bit(F, ntiles), w.sort_tmp, w.sort_tmp_bytes, stream, &in_alt);
+            if (rc != GVF_OK) return rc;
+            if (in_alt) { keys_sorted = w.keys_alt; vals_by_tile = w.vals_alt; }
+            int rblocks = (int)((max_rendered + 255) / 256);
+            if (rblocks > 4096) rblocks = 4096;
+            hipLaunchKernelGGL(ranges_kernel, dim3(rblocks), dim3(256), 0, stream, keys_sorted, w.total,
+                               (uint32_t)max_rendered, w.ranges, (uint32_t)((size_t)F * ntiles));
+            GVF_CHECK_LAUNCH();
+            prof_mark(stream, slot, 4);
+            const unsigned nseg = (unsigned)((size_t)F * ntiles);
+            hipLaunchKernelGGL(tile_sort_kernel<0>, dim3(nseg), dim3(256), 0, stream, w.ranges, keys_sorted, vals_by_tile, w.ids);
+            static bool large_attr_set = false;
+            if (!large_attr_set) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_sort_kernel<1>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LARGE_N * 8) != hipSuccess)
+                    return GVF_ELAUNCH;
+                large_attr_set = true;
+            }
+            hipLaunchKernelGGL(tile_sort_kernel<1>, dim3(nseg), dim3(1024), SORT_LARGE_N * 8, stream, w.ranges, keys_sorted, vals_by_tile, w.ids);
+            hipLaunchKernelGGL(tile_sort_kernel<2>, dim3(nseg), dim3(1024), 0, stream, w.ranges, keys_sorted, vals_by_tile, w.ids);
+            GVF_CHECK_LAUNCH();
+        }
     }
+    uint32_t* vals_sorted = w.ids;
     prof_mark(stream, slot, 5);
     hipLaunchKernelGGL(blend_kernel, dim3(ntiles, F), dim3(BLEND_THREADS), 0, stream, P, H, W, gx, gy, st.bg[0],
                        st.bg[1], st.bg[2], w.ranges, vals_sorted, w.geomA, w.geomB, w.geomC, subpixel_offset,

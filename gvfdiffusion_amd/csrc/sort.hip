@@ -226,19 +226,19 @@ size_t gvf_sort_tmp_bytes(int64_t n) {
 
 // Internal entry: n on device. Returns (via *result_in_alt) where the sorted data ended up.
 int gvf_sort_pairs_device_n(uint64_t* keys, uint64_t* keys_alt, uint32_t* vals, uint32_t* vals_alt,
-                            const uint32_t* n_ptr, int64_t n_cap, int end_bit, void* tmp, size_t tmp_bytes,
-                            hipStream_t stream, int* result_in_alt) {
-    if (n_cap < 0 || end_bit < 0 || end_bit > 64) return GVF_EINVAL;
+                            const uint32_t* n_ptr, int64_t n_cap, int begin_bit, int end_bit, void* tmp,
+                            size_t tmp_bytes, hipStream_t stream, int* result_in_alt) {
+    if (n_cap < 0 || begin_bit < 0 || end_bit < begin_bit || end_bit > 64) return GVF_EINVAL;
     if (tmp_bytes < gvf_sort_tmp_bytes(n_cap)) return GVF_ENOSPC;
     *result_in_alt = 0;
-    if (n_cap == 0 || end_bit == 0) return GVF_OK;
+    if (n_cap == 0 || end_bit == begin_bit) return GVF_OK;
     const int nb = gvf_sort_num_blocks(n_cap);
     uint32_t* hist = (uint32_t*)tmp;
     uint32_t* digit_tot = (uint32_t*)((char*)tmp + gvf_align_up((size_t)SORT_BINS * nb * sizeof(uint32_t), 256));
     uint64_t* kin = keys; uint64_t* kout = keys_alt;
     uint32_t* vin = vals; uint32_t* vout = vals_alt;
     int flips = 0;
-    for (int shift = 0; shift < end_bit; shift += SORT_BITS) {
+    for (int shift = begin_bit; shift < end_bit; shift += SORT_BITS) {
         hipLaunchKernelGGL(sort_upsweep, dim3(nb), dim3(SORT_THREADS), 0, stream, kin, n_ptr, (uint32_t)n_cap, shift, hist, nb);
         hipLaunchKernelGGL(sort_spine, dim3(SORT_BINS), dim3(SORT_THREADS), 0, stream, hist, digit_tot, nb);
         hipLaunchKernelGGL(sort_downsweep, dim3(nb), dim3(SORT_THREADS), 0, stream, kin, vin, kout, vout, n_ptr,
@@ -266,7 +266,7 @@ extern "C" int gvf_sort_pairs_u64(uint64_t* keys, uint64_t* keys_alt, uint32_t* 
     hipLaunchKernelGGL(sort_set_u32, dim3(1), dim3(1), 0, stream, n_dev, (uint32_t)n);
     GVF_CHECK_LAUNCH();
     int in_alt = 0;
-    int rc = gvf_sort_pairs_device_n(keys, keys_alt, values, values_alt, n_dev, n, end_bit, tmp, need, stream, &in_alt);
+    int rc = gvf_sort_pairs_device_n(keys, keys_alt, values, values_alt, n_dev, n, 0, end_bit, tmp, need, stream, &in_alt);
     if (rc != GVF_OK) return rc;
     if (in_alt) {
         if (hipMemcpyAsync(keys, keys_alt, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, stream) != hipSuccess) return GVF_ELAUNCH;
