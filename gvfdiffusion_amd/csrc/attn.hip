@@ -1,4 +1,4 @@
-// attn.hip -- bf16 MFMA flash attention forward, head_dim 32, for gfx950 (MI355X).
+// attn.hip -- bf16 MFMA flash attention forward, head_dim 32 or 64, dense or variable-length, for gfx950 (MI355X).
 //
 // Replaces the reference's attention operator seam, model/attention/full_attn.py:74-140
 // (flash_attn_func / flash_attn_kvpacked_func / sdpa / naive behind scaled_dot_product_attention) for
@@ -23,7 +23,6 @@ namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-constexpr int D = 32;            // head dim
 constexpr int QB = 128;          // queries per workgroup
 constexpr int KT = 64;           // keys per staged tile
 constexpr int THREADS = 256;
@@ -57,13 +56,15 @@ struct AttnParams {
     unsigned short* out;
     int n_outer, n_inner, Lq, Lk, H, q_blocks;
     long long q_so, q_si, q_sl, q_sh, k_so, k_si, k_sl, k_sh, v_so, v_si, v_sl, v_sh, o_so, o_si, o_sl, o_sh;
+    const int32_t *cu_q, *cu_k;              // varlen: sequence `outer` owns token rows [cu[outer], cu[outer+1])
     const float *gamma_q, *gamma_k;
     float scale_log2e;
 };
 
-// 8 bf16 (one 16-byte chunk of a head row) -> RMS-normalised * gamma * sqrt(32), given the row's sum of squares
+// 8 bf16 (one 16-byte chunk of a head row) -> RMS-normalised * gamma * sqrt(D), given the row's sum of squares
+template <int D>
 __device__ __forceinline__ uint4 rms_apply(uint4 raw, float sumsq, const float* g8) {
-    const float inv = 5.656854249492381f / fmaxf(sqrtf(sumsq), 1e-12f);   // sqrt(32) / max(||x||, eps)
+    const float inv = (D == 32 ? 5.656854249492381f : 8.0f) / fmaxf(sqrtf(sumsq), 1e-12f);   // sqrt(D) / max(||x||, eps)
     unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -84,18 +85,31 @@ __device__ __forceinline__ float sumsq8(uint4 raw) {
     return s;
 }
 
+template <int D>
+struct Cfg {
+    static constexpr int NS = D / 16;        // MFMA steps of the d contraction (S^T = K Q^T)
+    static constexpr int ND = D / 32;        // 32-row tiles of O^T
+    static constexpr int KC = D / 8;         // 16-byte chunks per K row
+    static constexpr int LOADS = KC * KT / THREADS;   // K (and V) chunks staged per thread per tile
+    // chunk swizzle that makes the per-lane 16-byte K fragment reads conflict-free
+    __device__ static __forceinline__ int swz(int key) { return KC == 4 ? ((key >> 2) & 3) : (key & 7); }
+};
+
 // One 32-key sub-tile for the 32 queries of a wave: S^T = K Q^T, online softmax, O^T += V^T P^T.
-template <bool MASKED>
+template <int D, bool MASKED>
 __device__ __forceinline__ void subtile(const uint4* __restrict__ sKb, const unsigned short* __restrict__ sVTb, int sub,
-                                        int key0, int Lk, float scale_log2e, bf16x8 qf0, bf16x8 qf1, int l31, int half,
-                                        f32x16& o_acc, float& m_run, float& l_run) {
+                                        int key0, int Lk, float scale_log2e, const bf16x8 (&qf)[Cfg<D>::NS], int l31,
+                                        int half, f32x16 (&o_acc)[Cfg<D>::ND], float& m_run, float& l_run) {
+    using C = Cfg<D>;
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int krow_l = sub * 32 + l31;
-    const int sw = (krow_l >> 2) & 3;
-    const bf16x8 k0 = __builtin_bit_cast(bf16x8, sKb[krow_l * 4 + ((0 + half) ^ sw)]);
-    const bf16x8 k1 = __builtin_bit_cast(bf16x8, sKb[krow_l * 4 + ((2 + half) ^ sw)]);
-    f32x16 s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf0, zero, 0, 0, 0);
-    s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf1, s_acc, 0, 0, 0);
+    const int sw = C::swz(krow_l);
+    f32x16 s_acc = zero;
+#pragma unroll
+    for (int st = 0; st < C::NS; ++st) {
+        const bf16x8 kf = __builtin_bit_cast(bf16x8, sKb[krow_l * C::KC + ((2 * st + half) ^ sw)]);
+        s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], s_acc, 0, 0, 0);
+    }
     // accumulator row r of this lane is key  key0 + (r&3) + 8*(r>>2) + 4*half
     if (MASKED) {
 #pragma unroll
@@ -114,7 +128,9 @@ __device__ __forceinline__ void subtile(const uint4* __restrict__ sKb, const uns
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         l_run *= alpha;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o_acc[r] *= alpha;
+        for (int dt = 0; dt < C::ND; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o_acc[dt][r] *= alpha;
         m_run = m_new;
     }
     float psum = 0.f;
@@ -131,19 +147,23 @@ __device__ __forceinline__ void subtile(const uint4* __restrict__ sKb, const uns
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const bf16x8 pf = __builtin_bit_cast(bf16x8, make_uint4(pw[4 * u], pw[4 * u + 1], pw[4 * u + 2], pw[4 * u + 3]));
-        const unsigned short* vrow = sVTb + l31 * VT_LD + sub * 32 + 16 * u + 4 * half;
-        const uint2 va = *reinterpret_cast<const uint2*>(vrow);        // keys +0..3
-        const uint2 vb = *reinterpret_cast<const uint2*>(vrow + 8);    // keys +8..11
-        const bf16x8 vf = __builtin_bit_cast(bf16x8, make_uint4(va.x, va.y, vb.x, vb.y));
-        o_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o_acc, 0, 0, 0);
+#pragma unroll
+        for (int dt = 0; dt < C::ND; ++dt) {
+            const unsigned short* vrow = sVTb + (dt * 32 + l31) * VT_LD + sub * 32 + 16 * u + 4 * half;
+            const uint2 va = *reinterpret_cast<const uint2*>(vrow);        // keys +0..3
+            const uint2 vb = *reinterpret_cast<const uint2*>(vrow + 8);    // keys +8..11
+            const bf16x8 vf = __builtin_bit_cast(bf16x8, make_uint4(va.x, va.y, vb.x, vb.y));
+            o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o_acc[dt], 0, 0, 0);
+        }
     }
 }
 
-// VT: V is given transposed ([d][key], keys contiguous; v_sl = d stride) -- the layout the DiT's
-// step-invariant cross-attention cache is stored in, so staging is a straight 16-byte copy.
-template <bool VT>
+// D: head dim (32: the DiT; 64: the VAEs).  VT: V is given transposed ([d][key], keys contiguous; v_sl = d
+// stride) -- the layout the DiT's step-invariant cross-attention cache is stored in, so staging is a straight copy.
+template <int D, bool VT>
 __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(AttnParams p) {
-    __shared__ uint4 sK[2][KT * 4];                   // [key][4 chunks of 8 bf16], chunk ^= (key >> 2) & 3
+    using C = Cfg<D>;
+    __shared__ uint4 sK[2][KT * C::KC];               // [key][KC chunks of 8 bf16], chunk ^= swz(key)
     __shared__ __attribute__((aligned(16))) unsigned short sVT[2][D * VT_LD + 8];   // [d][key]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -157,39 +177,51 @@ __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(AttnParams p) {
     const int inner = bid % p.n_inner; bid /= p.n_inner;
     const int outer = bid % p.n_outer, head = bid / p.n_outer;
 
-    const unsigned short* qp = p.q + outer * p.q_so + inner * p.q_si + head * p.q_sh;
-    const unsigned short* kp = p.k + outer * p.k_so + inner * p.k_si + head * p.k_sh;
-    const unsigned short* vp = p.v + outer * p.v_so + inner * p.v_si + head * p.v_sh;
-    unsigned short* op = p.out + outer * p.o_so + inner * p.o_si + head * p.o_sh;
+    // variable-length batches (packed token lists): sequence `outer` owns rows [cu[outer], cu[outer+1])
+    int Lq = p.Lq, Lk = p.Lk;
+    long long q_row0 = 0, k_row0 = 0;
+    if (p.cu_q != nullptr) {
+        q_row0 = p.cu_q[outer]; Lq = p.cu_q[outer + 1] - (int)q_row0;
+        k_row0 = p.cu_k[outer]; Lk = p.cu_k[outer + 1] - (int)k_row0;
+        if (qb * QB >= Lq || Lk <= 0) return;         // whole workgroup: uniform exit
+    }
+    const unsigned short* qp = p.q + outer * p.q_so + inner * p.q_si + head * p.q_sh + q_row0 * p.q_sl;
+    const unsigned short* kp = p.k + outer * p.k_so + inner * p.k_si + head * p.k_sh + k_row0 * p.k_sl;
+    const unsigned short* vp = p.v + outer * p.v_so + inner * p.v_si + head * p.v_sh + (VT ? 0 : k_row0 * p.v_sl);
+    unsigned short* op = p.out + outer * p.o_so + inner * p.o_si + head * p.o_sh + q_row0 * p.o_sl;
 
-    // ---- Q fragments: B operand of S^T = K Q^T.  Lane (q = lane&31, half): Q[q][16s + 8*half .. +7], s = 0,1
+    // ---- Q fragments: B operand of S^T = K Q^T.  Lane (q = lane&31, half): Q[q][16s + 8*half .. +7]
     const int qrow = qb * QB + wave * 32 + l31;
-    const bool qvalid = qrow < p.Lq;
-    uint4 qraw[2];
+    const bool qvalid = qrow < Lq;
+    uint4 qraw[C::NS];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < C::NS; ++s) {
         const uint4 v4 = *reinterpret_cast<const uint4*>(qp + (long long)(qvalid ? qrow : 0) * p.q_sl + 16 * s + 8 * half);
         const unsigned m = qvalid ? 0xffffffffu : 0u;
         qraw[s] = make_uint4(v4.x & m, v4.y & m, v4.z & m, v4.w & m);
     }
     if (p.gamma_q != nullptr) {
-        float ss = sumsq8(qraw[0]) + sumsq8(qraw[1]);
+        float ss = 0.f;
+#pragma unroll
+        for (int s = 0; s < C::NS; ++s) ss += sumsq8(qraw[s]);
         ss += __shfl_xor(ss, 32, 64);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) qraw[s] = rms_apply(qraw[s], ss, p.gamma_q + head * D + 16 * s + 8 * half);
+        for (int s = 0; s < C::NS; ++s) qraw[s] = rms_apply<D>(qraw[s], ss, p.gamma_q + head * D + 16 * s + 8 * half);
     }
-    const bf16x8 qf0 = __builtin_bit_cast(bf16x8, qraw[0]);
-    const bf16x8 qf1 = __builtin_bit_cast(bf16x8, qraw[1]);
-
-    f32x16 o_acc;
+    bf16x8 qf[C::NS];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o_acc[r] = 0.f;
+    for (int s = 0; s < C::NS; ++s) qf[s] = __builtin_bit_cast(bf16x8, qraw[s]);
+
+    f32x16 o_acc[C::ND];
+#pragma unroll
+    for (int dt = 0; dt < C::ND; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o_acc[dt][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
-    // staging roles.  K: key row st_key, 16-byte chunk st_c.  V (row-major): the same; V (transposed): d row
-    // vt_d, 8-key chunk vt_c.
-    const int st_key = tid >> 2, st_c = tid & 3;
-    const int vt_d = tid >> 3, vt_c = tid & 7;
+    // staging roles, LOADS chunks per thread: chunk c = tid + i*256.  K and row-major V: key c / KC, chunk c % KC
+    // (= tid % KC for every i).  Transposed V: d row c >> 3, 8-key chunk c & 7.
+    const int st_c = tid % C::KC;
     float gk8[8];
     if (p.gamma_k != nullptr) {
 #pragma unroll
@@ -197,96 +229,102 @@ __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(AttnParams p) {
     }
     const bool has_gk = p.gamma_k != nullptr;
 
-    uint4 kreg, vreg;
+    uint4 kreg[C::LOADS], vreg[C::LOADS];
 // LOAD only issues the global loads (rows clamped in-bounds); masking / RMSNorm / LDS writes happen in STORE,
 // after the MFMAs of the tile being consumed, so the loads stay in flight across the compute.
 #define GVF_ATTN_LOAD(kt_)                                                                              \
-    {                                                                                                   \
-        const int key = (kt_) * KT + st_key;                                                            \
-        const long long krow = key < p.Lk ? key : 0;                                                    \
-        kreg = *reinterpret_cast<const uint4*>(kp + krow * p.k_sl + st_c * 8);                          \
+    _Pragma("unroll") for (int i = 0; i < C::LOADS; ++i) {                                              \
+        const int c = tid + i * THREADS;                                                                \
+        const int key = (kt_) * KT + c / C::KC;                                                         \
+        const long long krow = key < Lk ? key : 0;                                                      \
+        kreg[i] = *reinterpret_cast<const uint4*>(kp + krow * p.k_sl + st_c * 8);                       \
         if (VT) {                                                                                       \
-            vreg = *reinterpret_cast<const uint4*>(vp + (long long)vt_d * p.v_sl + (kt_) * KT + vt_c * 8); \
+            vreg[i] = *reinterpret_cast<const uint4*>(vp + (long long)(c >> 3) * p.v_sl + (kt_) * KT + (c & 7) * 8); \
         } else {                                                                                        \
-            vreg = *reinterpret_cast<const uint4*>(vp + krow * p.v_sl + st_c * 8);                      \
+            vreg[i] = *reinterpret_cast<const uint4*>(vp + krow * p.v_sl + st_c * 8);                   \
         }                                                                                               \
     }
 #define GVF_ATTN_STORE(buf_, kt_)                                                                       \
-    {                                                                                                   \
-        const unsigned m = ((kt_) * KT + st_key) < p.Lk ? 0xffffffffu : 0u;                             \
-        uint4 kw = make_uint4(kreg.x & m, kreg.y & m, kreg.z & m, kreg.w & m);                          \
+    _Pragma("unroll") for (int i = 0; i < C::LOADS; ++i) {                                              \
+        const int c = tid + i * THREADS;                                                                \
+        const int st_key = c / C::KC;                                                                   \
+        const unsigned m = ((kt_) * KT + st_key) < Lk ? 0xffffffffu : 0u;                               \
+        uint4 kw = make_uint4(kreg[i].x & m, kreg[i].y & m, kreg[i].z & m, kreg[i].w & m);              \
         if (has_gk) {                                                                                   \
             float ss = sumsq8(kw);                                                                      \
             ss += __shfl_xor(ss, 1, 64);                                                                \
             ss += __shfl_xor(ss, 2, 64);                                                                \
-            kw = rms_apply(kw, ss, gk8);                                                                \
+            if (C::KC == 8) ss += __shfl_xor(ss, 4, 64);                                                \
+            kw = rms_apply<D>(kw, ss, gk8);                                                             \
         }                                                                                               \
-        sK[buf_][st_key * 4 + (st_c ^ ((st_key >> 2) & 3))] = kw;                                       \
+        sK[buf_][st_key * C::KC + (st_c ^ C::swz(st_key))] = kw;                                        \
         if (VT) {                                                                                       \
-            *reinterpret_cast<uint2*>(&sVT[buf_][vt_d * VT_LD + vt_c * 8]) = make_uint2(vreg.x, vreg.y);     \
-            *reinterpret_cast<uint2*>(&sVT[buf_][vt_d * VT_LD + vt_c * 8 + 4]) = make_uint2(vreg.z, vreg.w); \
+            *reinterpret_cast<uint2*>(&sVT[buf_][(c >> 3) * VT_LD + (c & 7) * 8]) = make_uint2(vreg[i].x, vreg[i].y);     \
+            *reinterpret_cast<uint2*>(&sVT[buf_][(c >> 3) * VT_LD + (c & 7) * 8 + 4]) = make_uint2(vreg[i].z, vreg[i].w); \
         } else {                                                                                        \
-            const unsigned w[4] = {vreg.x & m, vreg.y & m, vreg.z & m, vreg.w & m};                     \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                             \
-                sVT[buf_][(st_c * 8 + 2 * i) * VT_LD + st_key] = (unsigned short)(w[i] & 0xffffu);      \
-                sVT[buf_][(st_c * 8 + 2 * i + 1) * VT_LD + st_key] = (unsigned short)(w[i] >> 16);      \
+            const unsigned w[4] = {vreg[i].x & m, vreg[i].y & m, vreg[i].z & m, vreg[i].w & m};         \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                             \
+                sVT[buf_][(st_c * 8 + 2 * e) * VT_LD + st_key] = (unsigned short)(w[e] & 0xffffu);      \
+                sVT[buf_][(st_c * 8 + 2 * e + 1) * VT_LD + st_key] = (unsigned short)(w[e] >> 16);      \
             }                                                                                           \
         }                                                                                               \
     }
 
-    const int n_tiles = (p.Lk + KT - 1) / KT;
+    const int n_tiles = (Lk + KT - 1) / KT;
     GVF_ATTN_LOAD(0)
     GVF_ATTN_STORE(0, 0)
     __syncthreads();
 
     for (int kt = 0; kt < n_tiles; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < n_tiles) GVF_ATTN_LOAD(kt + 1)      // in flight while this tile is consumed
+        if (kt + 1 < n_tiles) { GVF_ATTN_LOAD(kt + 1) }      // in flight while this tile is consumed
 
-        if (kt * KT + KT <= p.Lk) {          // full tile: no key masking
-            subtile<false>(sK[buf], sVT[buf], 0, kt * KT, p.Lk, p.scale_log2e, qf0, qf1, l31, half, o_acc, m_run, l_run);
-            subtile<false>(sK[buf], sVT[buf], 1, kt * KT + 32, p.Lk, p.scale_log2e, qf0, qf1, l31, half, o_acc, m_run, l_run);
+        if (kt * KT + KT <= Lk) {          // full tile: no key masking
+            subtile<D, false>(sK[buf], sVT[buf], 0, kt * KT, Lk, p.scale_log2e, qf, l31, half, o_acc, m_run, l_run);
+            subtile<D, false>(sK[buf], sVT[buf], 1, kt * KT + 32, Lk, p.scale_log2e, qf, l31, half, o_acc, m_run, l_run);
         } else {
-            subtile<true>(sK[buf], sVT[buf], 0, kt * KT, p.Lk, p.scale_log2e, qf0, qf1, l31, half, o_acc, m_run, l_run);
-            if (kt * KT + 32 < p.Lk)
-                subtile<true>(sK[buf], sVT[buf], 1, kt * KT + 32, p.Lk, p.scale_log2e, qf0, qf1, l31, half, o_acc, m_run, l_run);
+            subtile<D, true>(sK[buf], sVT[buf], 0, kt * KT, Lk, p.scale_log2e, qf, l31, half, o_acc, m_run, l_run);
+            if (kt * KT + 32 < Lk)
+                subtile<D, true>(sK[buf], sVT[buf], 1, kt * KT + 32, Lk, p.scale_log2e, qf, l31, half, o_acc, m_run, l_run);
         }
         // the other buffer was last read in iteration kt-1; every wave has passed that iteration's barrier
-        if (kt + 1 < n_tiles) GVF_ATTN_STORE(buf ^ 1, kt + 1)
+        if (kt + 1 < n_tiles) { GVF_ATTN_STORE(buf ^ 1, kt + 1) }
         __syncthreads();
     }
 #undef GVF_ATTN_LOAD
 #undef GVF_ATTN_STORE
 
-    // ---- epilogue: O[q][d] / l, d = (r&3) + 8*(r>>2) + 4*half
+    // ---- epilogue: O[q][d] / l, d = dt*32 + (r&3) + 8*(r>>2) + 4*half
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     if (qvalid) {
         const float inv = 1.0f / l_tot;
         unsigned short* orow = op + (long long)qrow * p.o_sl;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            uint2 w;
-            w.x = cvt_pk_bf16(o_acc[4 * g] * inv, o_acc[4 * g + 1] * inv);
-            w.y = cvt_pk_bf16(o_acc[4 * g + 2] * inv, o_acc[4 * g + 3] * inv);
-            *reinterpret_cast<uint2*>(orow + 8 * g + 4 * half) = w;
-        }
+        for (int dt = 0; dt < C::ND; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 w;
+                w.x = cvt_pk_bf16(o_acc[dt][4 * g] * inv, o_acc[dt][4 * g + 1] * inv);
+                w.y = cvt_pk_bf16(o_acc[dt][4 * g + 2] * inv, o_acc[dt][4 * g + 3] * inv);
+                *reinterpret_cast<uint2*>(orow + dt * 32 + 8 * g + 4 * half) = w;
+            }
     }
 }
 
-}  // namespace
-
-extern "C" int gvf_attn_fwd_bf16(const void* q, const void* k, const void* v, void* out, int n_outer, int n_inner,
-                                 int Lq, int Lk, int H, const int64_t* q_strides, const int64_t* k_strides,
-                                 const int64_t* v_strides, const int64_t* o_strides, int v_transposed,
-                                 const float* gamma_q, const float* gamma_k, float scale, void* stream_) {
-    if (n_outer < 0 || n_inner <= 0 || Lq < 0 || Lk <= 0 || H <= 0) return GVF_EINVAL;
+int launch_attn(const void* q, const void* k, const void* v, void* out, int n_outer, int n_inner, int Lq, int Lk, int H,
+                int D, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                const int64_t* o_strides, int v_transposed, const int32_t* cu_q, const int32_t* cu_k,
+                const float* gamma_q, const float* gamma_k, float scale, hipStream_t stream) {
+    if (n_outer < 0 || n_inner <= 0 || Lq < 0 || Lk <= 0 || H <= 0 || (D != 32 && D != 64)) return GVF_EINVAL;
     if (n_outer == 0 || Lq == 0) return GVF_OK;
     if (!q || !k || !v || !out || !q_strides || !k_strides || !v_strides || !o_strides) return GVF_EINVAL;
+    if ((cu_q == nullptr) != (cu_k == nullptr) || (cu_q != nullptr && v_transposed)) return GVF_EINVAL;
     // 16-byte operand chunks: bases and every stride must keep 8-element alignment (outputs: 4)
     for (int i = 0; i < 4; ++i) {
         if ((q_strides[i] % 8) || (k_strides[i] % 8) || (v_strides[i] % 8) || (o_strides[i] % 4)) return GVF_EINVAL;
     }
     if ((((uintptr_t)q) & 15) || (((uintptr_t)k) & 15) || (((uintptr_t)v) & 15) || (((uintptr_t)out) & 7)) return GVF_EINVAL;
+    if (!(scale > 0.0f)) return GVF_EINVAL;
     AttnParams p;
     p.q = (const unsigned short*)q; p.k = (const unsigned short*)k; p.v = (const unsigned short*)v;
     p.out = (unsigned short*)out;
@@ -295,16 +333,41 @@ extern "C" int gvf_attn_fwd_bf16(const void* q, const void* k, const void* v, vo
     p.k_so = k_strides[0]; p.k_si = k_strides[1]; p.k_sl = k_strides[2]; p.k_sh = k_strides[3];
     p.v_so = v_strides[0]; p.v_si = v_strides[1]; p.v_sl = v_strides[2]; p.v_sh = v_strides[3];
     p.o_so = o_strides[0]; p.o_si = o_strides[1]; p.o_sl = o_strides[2]; p.o_sh = o_strides[3];
+    p.cu_q = cu_q; p.cu_k = cu_k;
     p.gamma_q = gamma_q; p.gamma_k = gamma_k;
     p.scale_log2e = scale * 1.4426950408889634f;
-    if (!(scale > 0.0f)) return GVF_EINVAL;
     const long long blocks = (long long)p.q_blocks * H * n_inner * n_outer;
     if (blocks > 0x7fffffffLL) return GVF_EINVAL;
     (void)hipGetLastError();
-    if (v_transposed)
-        hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3((unsigned)blocks), dim3(THREADS), 0, (hipStream_t)stream_, p);
-    else
-        hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3((unsigned)blocks), dim3(THREADS), 0, (hipStream_t)stream_, p);
+    const dim3 grid((unsigned)blocks), block(THREADS);
+    if (D == 32) {
+        if (v_transposed) hipLaunchKernelGGL((attn_fwd_kernel<32, true>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((attn_fwd_kernel<32, false>), grid, block, 0, stream, p);
+    } else {
+        if (v_transposed) hipLaunchKernelGGL((attn_fwd_kernel<64, true>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((attn_fwd_kernel<64, false>), grid, block, 0, stream, p);
+    }
     GVF_CHECK_LAUNCH();
     return GVF_OK;
+}
+
+}  // namespace
+
+extern "C" int gvf_attn_fwd_bf16(const void* q, const void* k, const void* v, void* out, int n_outer, int n_inner,
+                                 int Lq, int Lk, int H, int head_dim, const int64_t* q_strides,
+                                 const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides,
+                                 int v_transposed, const float* gamma_q, const float* gamma_k, float scale,
+                                 void* stream) {
+    return launch_attn(q, k, v, out, n_outer, n_inner, Lq, Lk, H, head_dim, q_strides, k_strides, v_strides, o_strides,
+                       v_transposed, nullptr, nullptr, gamma_q, gamma_k, scale, (hipStream_t)stream);
+}
+
+extern "C" int gvf_attn_varlen_fwd_bf16(const void* q, const void* k, const void* v, void* out, int n_seqs,
+                                        const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k, int max_Lq, int max_Lk,
+                                        int H, int head_dim, const int64_t* q_strides, const int64_t* k_strides,
+                                        const int64_t* v_strides, const int64_t* o_strides, const float* gamma_q,
+                                        const float* gamma_k, float scale, void* stream) {
+    if (!cu_seqlens_q || !cu_seqlens_k) return GVF_EINVAL;
+    return launch_attn(q, k, v, out, n_seqs, 1, max_Lq, max_Lk > 0 ? max_Lk : 1, H, head_dim, q_strides, k_strides,
+                       v_strides, o_strides, 0, cu_seqlens_q, cu_seqlens_k, gamma_q, gamma_k, scale, (hipStream_t)stream);
 }

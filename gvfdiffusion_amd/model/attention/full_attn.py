@@ -40,11 +40,12 @@ def scaled_dot_product_attention(*args, **kwargs):
     if BACKEND != "hip":
         raise ValueError(f"Unknown attention module: {BACKEND}")
     N, Lq, H, C = q.shape
-    if C != 32:
-        raise NotImplementedError(f"hip attention backend: head_dim {C} (only 32 is built so far)")
+    if C not in (32, 64):
+        raise NotImplementedError(f"hip attention backend: head_dim {C} (32 and 64 are built)")
     dt = q.dtype
     q, k, v = (t if t.dtype == torch.bfloat16 else t.to(torch.bfloat16) for t in (q, k, v))
     q, k, v = (t if (t.stride(3) == 1 and t.stride(2) == C) else t.contiguous() for t in (q, k, v))
     out = torch.empty((N, Lq, H, C), dtype=torch.bfloat16, device=q.device)
-    dit_ops.attention_bf16(q, k, v, out, N, 1, Lq, k.shape[1], H, _strides(q), _strides(k), _strides(v), _strides(out))
+    dit_ops.attention_bf16(q, k, v, out, N, 1, Lq, k.shape[1], H, _strides(q), _strides(k), _strides(v), _strides(out),
+                           head_dim=C)
     return out if dt == torch.bfloat16 else out.to(dt)

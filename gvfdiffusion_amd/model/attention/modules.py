@@ -100,13 +100,13 @@ class MultiHeadAttention(nn.Module):
         if self._type == "self":
             qkv = self._proj(xb, self.to_qkv)                      # (B*L, 3C) = [q | k | v] per token
             s = (L * 3 * C, 0, 3 * C)
-            dit_ops.attention_bf16(qkv, qkv[:, C:], qkv[:, 2 * C:], attn, B, 1, L, L, H, s, s, s, (L * C, 0, C), gq, gk)
+            dit_ops.attention_bf16(qkv, qkv[:, C:], qkv[:, 2 * C:], attn, B, 1, L, L, H, s, s, s, (L * C, 0, C), gq, gk, head_dim=d)
         else:
             Lkv = context.shape[1]
             cb = dit_ops.cast_pad_bf16(context.reshape(B * Lkv, -1).float().contiguous(), dit_ops.pad64(context.shape[-1]))
             q = self._proj(xb, self.to_q)
             kv = self._proj(cb, self.to_kv)                        # (B*Lkv, 2C) = [k | v]
             sk = (Lkv * 2 * C, 0, 2 * C)
-            dit_ops.attention_bf16(q, kv, kv[:, C:], attn, B, 1, L, Lkv, H, (L * C, 0, C), sk, sk, (L * C, 0, C), gq, gk)
+            dit_ops.attention_bf16(q, kv, kv[:, C:], attn, B, 1, L, Lkv, H, (L * C, 0, C), sk, sk, (L * C, 0, C), gq, gk, head_dim=d)
         out = self._proj(attn, self.to_out, out_dtype=torch.float32)
         return out.reshape(B, L, C).to(x.dtype)

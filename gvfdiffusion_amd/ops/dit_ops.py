@@ -11,7 +11,8 @@ EPI_STORE_BF16, EPI_GELU_BF16, EPI_STORE_F32, EPI_RESID_F32 = 0, 1, 2, 3
 
 _lib.register({
     "gvf_gemm_bf16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
-    "gvf_attn_fwd_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i] + [ctypes.POINTER(_i64)] * 4 + [_i, _vp, _vp, _f, _vp]),
+    "gvf_attn_fwd_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i] + [ctypes.POINTER(_i64)] * 4 + [_i, _vp, _vp, _f, _vp]),
+    "gvf_attn_varlen_fwd_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i] + [ctypes.POINTER(_i64)] * 4 + [_vp, _vp, _f, _vp]),
     "gvf_layernorm_modulate_bf16": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "gvf_cast_pad_bf16": (_i, [_vp, _i, _vp, _i, _i64, _i, _i, _vp]),
 })
@@ -55,23 +56,39 @@ def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, epilogu
     return out
 
 
-def _s4(st):
+def _s4(st, head_dim=32):
     st = tuple(int(x) for x in st)
     if len(st) == 3:
-        st = st + (32,)          # packed heads: head h starts 32 elements after head h-1
+        st = st + (head_dim,)    # packed heads: head h starts head_dim elements after head h-1
     return (_i64 * 4)(*st)
 
 
 def attention_bf16(q, k, v, out, n_outer, n_inner, Lq, Lk, H, q_strides, k_strides, v_strides, o_strides, gamma_q=None,
-                   gamma_k=None, scale=None, v_transposed=False):
-    """Strided flash attention (head_dim 32).  *_strides = (outer, inner, seq[, head = 32]) in elements;
-    v_transposed: v stored [..][head][d][key] with v_strides[2] the d stride (see include/gvf_dit.h)."""
+                   gamma_k=None, scale=None, v_transposed=False, head_dim=32):
+    """Strided flash attention (head_dim 32 or 64).  *_strides = (outer, inner, seq[, head = head_dim]) in
+    elements; v_transposed: v stored [..][head][d][key] with v_strides[2] the d stride (see include/gvf_dit.h)."""
     _lib.require_cuda(q, k, v, out)
     assert q.dtype == k.dtype == v.dtype == out.dtype == torch.bfloat16
-    scale = 32 ** -0.5 if scale is None else scale
-    _lib.check(_lib.lib().gvf_attn_fwd_bf16(_p(q), _p(k), _p(v), _p(out), n_outer, n_inner, Lq, Lk, H, _s4(q_strides),
-                                            _s4(k_strides), _s4(v_strides), _s4(o_strides), int(bool(v_transposed)),
-                                            _p(gamma_q), _p(gamma_k), float(scale), _stream(q)), "gvf_attn_fwd_bf16")
+    scale = head_dim ** -0.5 if scale is None else scale
+    _lib.check(_lib.lib().gvf_attn_fwd_bf16(_p(q), _p(k), _p(v), _p(out), n_outer, n_inner, Lq, Lk, H, head_dim,
+                                            _s4(q_strides, head_dim), _s4(k_strides, head_dim), _s4(v_strides, head_dim),
+                                            _s4(o_strides, head_dim), int(bool(v_transposed)), _p(gamma_q), _p(gamma_k),
+                                            float(scale), _stream(q)), "gvf_attn_fwd_bf16")
+    return out
+
+
+def attention_varlen_bf16(q, k, v, out, cu_q, cu_k, max_Lq, max_Lk, H, q_strides, k_strides, v_strides, o_strides,
+                          gamma_q=None, gamma_k=None, scale=None, head_dim=32):
+    """Packed variable-length attention: cu_q / cu_k int32 device tensors [n_seqs + 1]."""
+    _lib.require_cuda(q, k, v, out, cu_q, cu_k)
+    assert q.dtype == k.dtype == v.dtype == out.dtype == torch.bfloat16
+    assert cu_q.dtype == torch.int32 and cu_k.dtype == torch.int32 and cu_q.numel() == cu_k.numel()
+    scale = head_dim ** -0.5 if scale is None else scale
+    _lib.check(_lib.lib().gvf_attn_varlen_fwd_bf16(_p(q), _p(k), _p(v), _p(out), cu_q.numel() - 1, _p(cu_q), _p(cu_k),
+                                                   int(max_Lq), int(max_Lk), H, head_dim, _s4(q_strides, head_dim),
+                                                   _s4(k_strides, head_dim), _s4(v_strides, head_dim),
+                                                   _s4(o_strides, head_dim), _p(gamma_q), _p(gamma_k), float(scale),
+                                                   _stream(q)), "gvf_attn_varlen_fwd_bf16")
     return out
 
 

@@ -34,19 +34,30 @@ int gvf_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* b
                   int M, int N, int K, int epilogue, const float* gate, int gate_ld, int rows_per_group,
                   void* stream);
 
-/* softmax(q k^T * scale) v, head_dim 32, no mask, scale > 0.  Batch index = (outer, inner); every tensor
+/* softmax(q k^T * scale) v, head_dim 32 or 64, no mask, scale > 0.  Batch index = (outer, inner); every tensor
  * takes 4 strides in elements {outer, inner, seq, head}: element (o,i,l,h,c) sits at
  * o*s[0] + i*s[1] + l*s[2] + h*s[3] + c, so the q/k/v slices of a packed qkv / kv projection, a K/V set
  * shared by all `inner` entries (stride 0) and the (B,T,N,.)<->(B,N,T,.) view of the temporal attention
  * need no copies.  v_transposed != 0: v is stored [.., head][d][key] (keys contiguous, v_strides[2] = d
  * stride, rows padded with finite values to a multiple of 64 keys) -- the layout of the DiT's
  * step-invariant cross-attention cache.
- * gamma_q / gamma_k: f32 [H][32] MultiHeadRMSNorm gains (x <- normalize(x) * gamma * sqrt(32)) or null. */
+ * gamma_q / gamma_k: f32 [H][head_dim] MultiHeadRMSNorm gains (x <- normalize(x) * gamma * sqrt(head_dim)) or null. */
 int gvf_attn_fwd_bf16(const void* q, const void* k, const void* v, void* out,
-                      int n_outer, int n_inner, int Lq, int Lk, int H,
+                      int n_outer, int n_inner, int Lq, int Lk, int H, int head_dim,
                       const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                       const int64_t* o_strides, int v_transposed,
                       const float* gamma_q, const float* gamma_k, float scale, void* stream);
+
+/* Variable-length batch over packed token lists (the reference's sparse attention seam,
+ * model/sparse_attention/full_attn.py:189-210: flash_attn_varlen_* / xformers BlockDiagonalMask): sequence s
+ * owns query rows [cu_seqlens_q[s], cu_seqlens_q[s+1]) and key rows [cu_seqlens_k[s], cu_seqlens_k[s+1]) of
+ * the packed tensors; strides as above with strides[0] (outer) normally 0.  cu_seqlens: device int32 [n_seqs+1]. */
+int gvf_attn_varlen_fwd_bf16(const void* q, const void* k, const void* v, void* out, int n_seqs,
+                             const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k, int max_Lq, int max_Lk,
+                             int H, int head_dim,
+                             const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                             const int64_t* o_strides, const float* gamma_q, const float* gamma_k, float scale,
+                             void* stream);
 
 /* out_bf16[r][:] = LN(x[r][:]) (eps, no affine) then either  * ln_w + ln_b  (affine LayerNorm, norm3/4)
  * or  * (1 + scale[g]) + shift[g]  (adaLN, g = r / rows_per_group; shift/scale rows have stride mod_ld),

@@ -267,7 +267,41 @@ def gen_sampler():
     print("sampler_golden.npz", {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if "nfe" in k or k == "total_N"})
 
 
-SECTIONS = {"raster": gen_raster, "vox2seq": gen_vox2seq, "dit": gen_dit, "sampler": gen_sampler}
+def gen_sparse():
+    """Index builders of the sparse attention operators (model/sparse_attention/windowed_attn.py:20-60,
+    serialized_attn.py:36-117), run on a duck-typed tensor (coords, layout, device); vox2seq aliased to the
+    reference's pure-PyTorch fallback."""
+    base = f"{REF}/model/sparse_voxel_diffusion/vox2seq/vox2seq/pytorch"
+    sys.modules["vox2seq"] = load_by_path("vox2seq", f"{base}/__init__.py", [base])
+    from model.sparse_attention.windowed_attn import calc_window_partition
+    from model.sparse_attention.serialized_attn import calc_serialization, SerializeMode
+    g = torch.Generator().manual_seed(11)
+    coords = []
+    for b, n in enumerate((300, 77, 513)):
+        c = torch.unique(torch.randint(0, 24, (n * 2, 3), generator=g), dim=0)
+        c = c[torch.randperm(c.shape[0], generator=g)[:n]]
+        coords.append(torch.cat([torch.full((c.shape[0], 1), b), c], dim=1))
+    coords = torch.cat(coords).int()
+    bs = coords[:, 0]
+    layout = [slice(int((bs < b).sum()), int((bs <= b).sum())) for b in range(3)]
+    T = types.SimpleNamespace(coords=coords, layout=layout, device=coords.device)
+    out = {"coords": coords.numpy()}
+    for ws, sh in ((8, 0), (8, 4), (5, (1, 2, 3))):
+        fwd, bwd, lens, bidx = calc_window_partition(T, ws, sh)
+        key = f"win_{ws}_{sh if isinstance(sh, int) else '_'.join(map(str, sh))}"
+        out[key + "_fwd"], out[key + "_bwd"] = fwd.numpy(), bwd.numpy()
+        out[key + "_lens"], out[key + "_bidx"] = np.array(lens), np.array(bidx)
+    for mode in SerializeMode:
+        for ws, ss, sw in ((32, 0, (0, 0, 0)), (48, 7, (3, 0, 5))):
+            fwd, bwd, lens, bidx = calc_serialization(T, ws, mode, ss, sw)
+            key = f"ser_{mode.name}_{ws}_{ss}"
+            out[key + "_fwd"], out[key + "_bwd"] = fwd.numpy(), bwd.numpy()
+            out[key + "_lens"], out[key + "_bidx"] = np.array(lens), np.array(bidx)
+    np.savez_compressed(os.path.join(OUT, "sparse_index_golden.npz"), **out)
+    print("sparse_index_golden.npz", len(out), "arrays")
+
+
+SECTIONS = {"raster": gen_raster, "vox2seq": gen_vox2seq, "dit": gen_dit, "sampler": gen_sampler, "sparse": gen_sparse}
 
 if __name__ == "__main__":
     install_stubs()
