@@ -228,7 +228,7 @@ def main():
         if world > 1:
             b = i & 1
             torch.cuda.current_stream().wait_event(consumed[b])           # buffer b free again
-            u8[b].copy_((work.color.clamp(0.0, 1.0) * 255.0).to(torch.uint8))
+            work.R.frames_to_uint8(work.color, out=u8[b])
             ready[b].record()
             with torch.cuda.stream(side):
                 side.wait_event(ready[b])

@@ -50,6 +50,7 @@ SIGNATURES = {
                                       _i, _vp, _sz, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gvf_gaussian_activate": (_i, [ctypes.POINTER(GvfGaussianActivation), _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                    _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gvf_rgb_to_u8": (_i, [_vp, _vp, _i64, _vp]),
     "gvf_rast_profile_enable": (_i, [_i]),
     "gvf_rast_profile_read": (_i, [ctypes.POINTER(_f), ctypes.POINTER(_i)]),
     "gvf_sort_tmp_bytes": (_sz, [_i64]),

@@ -501,33 +501,118 @@ __device__ __forceinline__ void bitonic_sort_asc(Ptr keys, int n, int tid, int n
     }
 }
 
-template <int MODE>   // 0: small (static LDS), 1: large (dynamic LDS), 2: huge (global, in place)
+// Small segments (<= 2048 keys, i.e. practically every tile): E = npad / 256 keys per thread live in REGISTERS
+// (key index e = tid * E + r); compare-exchange partners at distance j are in the same thread (j < E), in the same
+// wave (j < 64 E: one 64-bit lane exchange, no LDS, no barrier) or in another wave (LDS round trip).  For a 512-key
+// tile that is 3 LDS steps instead of 45 barrier-separated LDS passes.
+template <int E>
+__device__ __forceinline__ void tile_sort_regs(const uint64_t* __restrict__ k, const uint32_t* __restrict__ v,
+                                               uint32_t* __restrict__ ids, int n, uint64_t* __restrict__ lds) {
+    constexpr int NP = 256 * E;
+    const int tid = threadIdx.x;
+    uint64_t key[E];
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const int e = tid * E + r;
+        key[r] = e < n ? ((k[e] << 32) | v[e]) : ~0ull;    // local key: depth bits above the Gaussian id
+    }
+#pragma unroll
+    for (int k2 = 2; k2 <= NP; k2 <<= 1) {
+#pragma unroll
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            if (j < E) {
+#pragma unroll
+                for (int r = 0; r < E; ++r) {
+                    if ((r & j) == 0) {
+                        const bool up = ((tid * E + r) & k2) == 0;
+                        const uint64_t a = key[r], b = key[r | j];
+                        if ((a > b) == up) { key[r] = b; key[r | j] = a; }
+                    }
+                }
+            } else if (j < 64 * E) {
+#pragma unroll
+                for (int r = 0; r < E; ++r) {
+                    const int e = tid * E + r;
+                    const unsigned lo = __shfl_xor((unsigned)key[r], j / E, 64);
+                    const unsigned hi = __shfl_xor((unsigned)(key[r] >> 32), j / E, 64);
+                    const uint64_t other = ((uint64_t)hi << 32) | lo;
+                    const bool take_min = ((e & j) == 0) == ((e & k2) == 0);
+                    key[r] = take_min ? (other < key[r] ? other : key[r]) : (other > key[r] ? other : key[r]);
+                }
+            } else {
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < E; ++r) lds[tid * E + r] = key[r];
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < E; ++r) {
+                    const int e = tid * E + r;
+                    const uint64_t other = lds[e ^ j];
+                    const bool take_min = ((e & j) == 0) == ((e & k2) == 0);
+                    key[r] = take_min ? (other < key[r] ? other : key[r]) : (other > key[r] ? other : key[r]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const int e = tid * E + r;
+        if (e < n) ids[e] = (uint32_t)key[r];
+    }
+}
+
+// tile lists of the two rare size classes, filled by classify_kernel: [0] count large, [1] count huge, then indices
+__global__ __launch_bounds__(256) void classify_kernel(const uint2* __restrict__ ranges, uint32_t nseg,
+                                                       uint32_t* __restrict__ cls /*[2 + 2*nseg]*/) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nseg) return;
+    const uint2 r = ranges[i];
+    const uint32_t n = r.y - r.x;
+    if (n > (uint32_t)SORT_LARGE_N) cls[2 + nseg + atomicAdd(&cls[1], 1u)] = i;
+    else if (n > (uint32_t)SORT_SMALL_N) cls[2 + atomicAdd(&cls[0], 1u)] = i;
+}
+
+template <int MODE>   // 0: small (registers + shuffles), 1: large (dynamic LDS), 2: huge (global, in place)
 __global__ void tile_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __restrict__ keys,
-                                 const uint32_t* __restrict__ vals, uint32_t* __restrict__ ids) {
+                                 const uint32_t* __restrict__ vals, uint32_t* __restrict__ ids,
+                                 const uint32_t* __restrict__ cls, uint32_t nseg) {
     __shared__ uint64_t s_small[MODE == 0 ? SORT_SMALL_N : 1];
     extern __shared__ __attribute__((aligned(16))) uint64_t s_large[];
-    const uint2 rng = ranges[blockIdx.x];
-    const int n = (int)(rng.y - rng.x);
-    if (n <= 0) return;
-    if (MODE == 0 && n > SORT_SMALL_N) return;
-    if (MODE == 1 && (n <= SORT_SMALL_N || n > SORT_LARGE_N)) return;
-    if (MODE == 2 && n <= SORT_LARGE_N) return;
-    const int tid = threadIdx.x, nt = blockDim.x;
-    uint64_t* k = keys + rng.x;
-    const uint32_t* v = vals + rng.x;
-    // local key: depth bits (low word of the global key) above the Gaussian id -> unique within the tile
-    if (MODE == 2) {
-        for (int i = tid; i < n; i += nt) k[i] = (k[i] << 32) | v[i];   // in place in global memory
-        __syncthreads();
-        if (n > 1) bitonic_sort_asc(k, n, tid, nt);
-        for (int i = tid; i < n; i += nt) ids[rng.x + i] = (uint32_t)k[i];
+    if (MODE == 0) {
+        const uint2 rng = ranges[blockIdx.x];
+        const int n = (int)(rng.y - rng.x);
+        if (n <= 0 || n > SORT_SMALL_N) return;
+        const uint64_t* k = keys + rng.x;
+        const uint32_t* v = vals + rng.x;
+        uint32_t* o = ids + rng.x;
+        if (n <= 256) tile_sort_regs<1>(k, v, o, n, s_small);
+        else if (n <= 512) tile_sort_regs<2>(k, v, o, n, s_small);
+        else if (n <= 1024) tile_sort_regs<4>(k, v, o, n, s_small);
+        else tile_sort_regs<8>(k, v, o, n, s_small);
         return;
     }
-    uint64_t* sk = MODE == 0 ? s_small : s_large;
-    for (int i = tid; i < n; i += nt) sk[i] = (k[i] << 32) | v[i];
-    __syncthreads();
-    if (n > 1) bitonic_sort_asc(sk, n, tid, nt);
-    for (int i = tid; i < n; i += nt) ids[rng.x + i] = (uint32_t)sk[i];
+    // rare classes: a small fixed grid walks the list built by classify_kernel
+    const uint32_t count = cls[MODE == 1 ? 0 : 1];
+    const uint32_t* list = cls + 2 + (MODE == 1 ? 0u : nseg);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (uint32_t li = blockIdx.x; li < count; li += gridDim.x) {
+        const uint2 rng = ranges[list[li]];
+        const int n = (int)(rng.y - rng.x);
+        uint64_t* k = keys + rng.x;
+        const uint32_t* v = vals + rng.x;
+        if (MODE == 2) {
+            for (int i = tid; i < n; i += nt) k[i] = (k[i] << 32) | v[i];   // in place in global memory
+            __syncthreads();
+            bitonic_sort_asc(k, n, tid, nt);
+            for (int i = tid; i < n; i += nt) ids[rng.x + i] = (uint32_t)k[i];
+        } else {
+            for (int i = tid; i < n; i += nt) s_large[i] = (k[i] << 32) | v[i];
+            __syncthreads();
+            bitonic_sort_asc(s_large, n, tid, nt);
+            for (int i = tid; i < n; i += nt) ids[rng.x + i] = (uint32_t)s_large[i];
+        }
+        __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -653,6 +738,24 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
     }
 }
 
+// C1 post-process: rgb float -> uint8 exactly as utils/inference_utils.py:280-286 does on the host
+// (clamp(0,1) * 255, truncating cast), so frames leave the device at 1 byte per channel.
+__global__ __launch_bounds__(256) void rgb_to_u8_kernel(const float4* __restrict__ src, uchar4* __restrict__ dst,
+                                                        long long n4, const float* __restrict__ tail_src,
+                                                        unsigned char* __restrict__ tail_dst, int tail) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 v = src[i];
+        uchar4 o;
+        o.x = (unsigned char)(fminf(fmaxf(v.x, 0.f), 1.f) * 255.0f);
+        o.y = (unsigned char)(fminf(fmaxf(v.y, 0.f), 1.f) * 255.0f);
+        o.z = (unsigned char)(fminf(fmaxf(v.z, 0.f), 1.f) * 255.0f);
+        o.w = (unsigned char)(fminf(fmaxf(v.w, 0.f), 1.f) * 255.0f);
+        dst[i] = o;
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < tail)
+        tail_dst[threadIdx.x] = (unsigned char)(fminf(fmaxf(tail_src[threadIdx.x], 0.f), 1.f) * 255.0f);
+}
+
 // Camera blocks travel as kernel arguments (16 per launch): no host buffer has to outlive the call
 // and the upload is capturable in a hipGraph.
 struct FrameChunk { GvfRastFrame f[16]; };
@@ -685,7 +788,7 @@ struct Workspace {
     uint32_t* tiles_touched; int32_t* radii;
     uint32_t* block_sums; uint32_t* frame_base; uint32_t* total;
     uint64_t* keys; uint64_t* keys_alt; uint32_t* vals; uint32_t* vals_alt; uint32_t* ids;
-    uint2* ranges;
+    uint2* ranges; uint32_t* cls;
     void* sort_tmp; size_t sort_tmp_bytes;
     size_t bytes; bool ok;
 };
@@ -719,6 +822,7 @@ Workspace carve(void* ws, size_t bytes, int P, int F, int H, int W, int64_t max_
     w.vals_alt = c.take<uint32_t>(D);
     w.ids = c.take<uint32_t>(D);
     w.ranges = c.take<uint2>((size_t)F * ntiles);
+    w.cls = c.take<uint32_t>(2 + 2 * (size_t)F * ntiles);
     w.sort_tmp_bytes = gvf_sort_tmp_bytes((int64_t)D);
     w.sort_tmp = c.take<char>(w.sort_tmp_bytes);
     w.bytes = gvf_align_up(c.off, 256);
@@ -808,7 +912,9 @@ int run_pipeline(const GvfRastSettings& st, const GvfRastFrame* frames_host, int
             GVF_CHECK_LAUNCH();
             prof_mark(stream, slot, 4);
             const unsigned nseg = (unsigned)((size_t)F * ntiles);
-            hipLaunchKernelGGL(tile_sort_kernel<0>, dim3(nseg), dim3(256), 0, stream, w.ranges, keys_sorted, vals_by_tile, w.ids);
+            if (hipMemsetAsync(w.cls, 0, 2 * sizeof(uint32_t), stream) != hipSuccess) return GVF_ELAUNCH;
+            hipLaunchKernelGGL(classify_kernel, dim3((nseg + 255) / 256), dim3(256), 0, stream, w.ranges, nseg, w.cls);
+            hipLaunchKernelGGL(tile_sort_kernel<0>, dim3(nseg), dim3(256), 0, stream, w.ranges, keys_sorted, vals_by_tile, w.ids, w.cls, nseg);
             static bool large_attr_set = false;
             if (!large_attr_set) {
                 if (hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_sort_kernel<1>),
@@ -816,8 +922,8 @@ int run_pipeline(const GvfRastSettings& st, const GvfRastFrame* frames_host, int
                     return GVF_ELAUNCH;
                 large_attr_set = true;
             }
-            hipLaunchKernelGGL(tile_sort_kernel<1>, dim3(nseg), dim3(1024), SORT_LARGE_N * 8, stream, w.ranges, keys_sorted, vals_by_tile, w.ids);
-            hipLaunchKernelGGL(tile_sort_kernel<2>, dim3(nseg), dim3(1024), 0, stream, w.ranges, keys_sorted, vals_by_tile, w.ids);
+            hipLaunchKernelGGL(tile_sort_kernel<1>, dim3(64), dim3(1024), SORT_LARGE_N * 8, stream, w.ranges, keys_sorted, vals_by_tile, w.ids, w.cls, nseg);
+            hipLaunchKernelGGL(tile_sort_kernel<2>, dim3(64), dim3(1024), 0, stream, w.ranges, keys_sorted, vals_by_tile, w.ids, w.cls, nseg);
             GVF_CHECK_LAUNCH();
         }
     }
@@ -893,6 +999,22 @@ extern "C" int gvf_gaussian_activate(const GvfGaussianActivation* act, int P, in
     hipLaunchKernelGGL(activate_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, *act, P, M, xyz_raw,
                        features_dc, scaling_raw, rotation_raw, opacity_raw, delta, means3D, scales, rotations, shs,
                        opacities);
+    GVF_CHECK_LAUNCH();
+    return GVF_OK;
+}
+
+extern "C" int gvf_rgb_to_u8(const float* rgb, uint8_t* out, int64_t n, void* stream) {
+    if (n < 0) return GVF_EINVAL;
+    if (n == 0) return GVF_OK;
+    if (!rgb || !out || (((uintptr_t)rgb) & 15) || (((uintptr_t)out) & 3)) return GVF_EINVAL;
+    (void)hipGetLastError();
+    const long long n4 = n / 4;
+    long long blocks = (n4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(rgb_to_u8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(rgb), reinterpret_cast<uchar4*>(out), n4, rgb + n4 * 4,
+                       out + n4 * 4, (int)(n - n4 * 4));
     GVF_CHECK_LAUNCH();
     return GVF_OK;
 }

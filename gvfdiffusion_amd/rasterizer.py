@@ -209,3 +209,15 @@ def sort_pairs_u64(keys: torch.Tensor, values: torch.Tensor, end_bit: int = 64):
                                        ctypes.c_void_p(base), tb, _lib.current_stream(dev))
     _lib.check(rc, "gvf_sort_pairs_u64")
     return k, v
+
+
+def frames_to_uint8(rgb: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    """(.., H, W) float frames -> uint8 on the device: clamp(0,1) * 255 truncated, as the reference's
+    render_and_save_images does on the host (utils/inference_utils.py:280-286)."""
+    _lib.require_cuda(rgb)
+    rgb = _f32c(rgb, "rgb")
+    if out is None:
+        out = torch.empty(rgb.shape, dtype=torch.uint8, device=rgb.device)
+    _lib.check(_lib.lib().gvf_rgb_to_u8(_lib.ptr(rgb), _lib.ptr(out), rgb.numel(), _lib.current_stream(rgb.device)),
+               "gvf_rgb_to_u8")
+    return out

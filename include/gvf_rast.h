@@ -134,6 +134,10 @@ size_t gvf_sort_tmp_bytes(int64_t n);
 int gvf_sort_pairs_u64(uint64_t* keys, uint64_t* keys_alt, uint32_t* values, uint32_t* values_alt,
                        int64_t n, int end_bit, void* tmp, size_t tmp_bytes, void* stream);
 
+/* Frame post-process of the render loop (utils/inference_utils.py:280-286: image.clamp(0,1) -> * 255 ->
+ * astype('uint8')) on the device: out[i] = (uint8)(clamp(rgb[i], 0, 1) * 255), n elements. */
+int gvf_rgb_to_u8(const float* rgb, uint8_t* out, int64_t n, void* stream);
+
 /* Opt-in per-stage GPU timing of gvf_rast_forward*(): HIP events are recorded on the caller's
  * stream at the stage boundaries of the next (at most 256) calls.  Stages, in order:
  * preprocess, scan, duplicate, sort, ranges, blend.  gvf_rast_profile_read() synchronises on the
