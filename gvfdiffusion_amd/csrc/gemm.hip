@@ -57,7 +57,7 @@ __global__ __launch_bounds__(THREADS, 4) void gemm_bf16_kernel(const unsigned sh
                                                             const float* __restrict__ bias, void* __restrict__ Cv,
                                                             int ldc, int M, int N, int K,
                                                             const float* __restrict__ gate, int gate_ld, int rpg,
-                                                            int tiles_n, int ablate) {
+                                                            int tiles_n) {
     __shared__ uint4 sA[2][BM * CHUNKS_PER_ROW];
     __shared__ uint4 sB[2][BN * CHUNKS_PER_ROW];
 
@@ -103,8 +103,8 @@ __global__ __launch_bounds__(THREADS, 4) void gemm_bf16_kernel(const unsigned sh
 
     for (int kt = 0; kt < KT; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < KT && !(ablate & 1)) { GVF_GEMM_STAGE(kt + 1, buf ^ 1) }   // lands while this tile is multiplied
-        if (!(ablate & 2)) {
+        if (kt + 1 < KT) { GVF_GEMM_STAGE(kt + 1, buf ^ 1) }   // lands while this tile is multiplied
+        {
             bf16x8 af[4], bfr[4];
             const int kc = lane >> 4;
 #pragma unroll
@@ -129,7 +129,6 @@ __global__ __launch_bounds__(THREADS, 4) void gemm_bf16_kernel(const unsigned sh
     // wave bounces one 16-row x 64-column slab at a time through its private LDS region and emits whole 16-byte
     // vectors: one wave-instruction then covers 4 rows x 256 B (fp32) / 128 B (bf16), and the read-modify-write of
     // the fp32 residual stream, the bias and the gate are float4 accesses.
-    if ((ablate & 4) && acc[0][0][0] != 12345.678f) return;
     constexpr int EP_LD = 68;                                  // floats per staged row (64 + 4 pad)
     float* ep = reinterpret_cast<float*>(&sA[0][0]) + wave * (16 * EP_LD);   // 4 x 4352 B <= the 32 KiB of sA
     __syncthreads();                                           // every wave is done reading the operand tiles
@@ -214,20 +213,18 @@ extern "C" int gvf_gemm_bf16(const void* A, int lda, const void* W, int ldw, con
     const unsigned short* a = (const unsigned short*)A;
     const unsigned short* w = (const unsigned short*)W;
     const int rpg = rows_per_group > 0 ? rows_per_group : 1;
-    const char* abl_ = getenv("GVF_GEMM_ABLATE");   // perf ablation only (1: no k-loop DMA, 2: no MFMA, 4: no epilogue)
-    const int ablate = abl_ ? atoi(abl_) : 0;
     switch (epilogue) {
         case GVF_EPI_STORE_BF16:
-            hipLaunchKernelGGL(gemm_bf16_kernel<GVF_EPI_STORE_BF16>, grid, block, 0, stream, a, lda, w, ldw, bias, C, ldc, M, N, K, gate, gate_ld, rpg, tiles_n, ablate);
+            hipLaunchKernelGGL(gemm_bf16_kernel<GVF_EPI_STORE_BF16>, grid, block, 0, stream, a, lda, w, ldw, bias, C, ldc, M, N, K, gate, gate_ld, rpg, tiles_n);
             break;
         case GVF_EPI_GELU_BF16:
-            hipLaunchKernelGGL(gemm_bf16_kernel<GVF_EPI_GELU_BF16>, grid, block, 0, stream, a, lda, w, ldw, bias, C, ldc, M, N, K, gate, gate_ld, rpg, tiles_n, ablate);
+            hipLaunchKernelGGL(gemm_bf16_kernel<GVF_EPI_GELU_BF16>, grid, block, 0, stream, a, lda, w, ldw, bias, C, ldc, M, N, K, gate, gate_ld, rpg, tiles_n);
             break;
         case GVF_EPI_STORE_F32:
-            hipLaunchKernelGGL(gemm_bf16_kernel<GVF_EPI_STORE_F32>, grid, block, 0, stream, a, lda, w, ldw, bias, C, ldc, M, N, K, gate, gate_ld, rpg, tiles_n, ablate);
+            hipLaunchKernelGGL(gemm_bf16_kernel<GVF_EPI_STORE_F32>, grid, block, 0, stream, a, lda, w, ldw, bias, C, ldc, M, N, K, gate, gate_ld, rpg, tiles_n);
             break;
         case GVF_EPI_RESID_F32:
-            hipLaunchKernelGGL(gemm_bf16_kernel<GVF_EPI_RESID_F32>, grid, block, 0, stream, a, lda, w, ldw, bias, C, ldc, M, N, K, gate, gate_ld, rpg, tiles_n, ablate);
+            hipLaunchKernelGGL(gemm_bf16_kernel<GVF_EPI_RESID_F32>, grid, block, 0, stream, a, lda, w, ldw, bias, C, ldc, M, N, K, gate, gate_ld, rpg, tiles_n);
             break;
         default:
             return GVF_EINVAL;
