@@ -95,36 +95,47 @@ struct Cfg {
     __device__ static __forceinline__ int swz(int key) { return KC == 4 ? ((key >> 2) & 3) : (key & 7); }
 };
 
-// One 32-key sub-tile for the 32 queries of a wave: S^T = K Q^T, online softmax, O^T += V^T P^T.
+// One staged 64-key tile for the 32 queries of a wave: S^T = K Q^T (both 32-key halves issued back to back),
+// ONE online-softmax update for the 64 keys, O^T += V^T P^T.  Issuing all QK^T MFMAs first and all P V MFMAs
+// last leaves long straight-line stretches in which the matrix pipe works while the VALU does the softmax.
 template <int D, bool MASKED>
-__device__ __forceinline__ void subtile(const uint4* __restrict__ sKb, const unsigned short* __restrict__ sVTb, int sub,
-                                        int key0, int Lk, float scale_log2e, const bf16x8 (&qf)[Cfg<D>::NS], int l31,
-                                        int half, f32x16 (&o_acc)[Cfg<D>::ND], float& m_run, float& l_run) {
+__device__ __forceinline__ void tile64(const uint4* __restrict__ sKb, const unsigned short* __restrict__ sVTb, int key0,
+                                       int Lk, float scale_log2e, const bf16x8 (&qf)[Cfg<D>::NS], int l31, int half,
+                                       f32x16 (&o_acc)[Cfg<D>::ND], float& m_run, float& l_run) {
     using C = Cfg<D>;
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const int krow_l = sub * 32 + l31;
-    const int sw = C::swz(krow_l);
-    f32x16 s_acc = zero;
+    f32x16 s_acc[2];
 #pragma unroll
-    for (int st = 0; st < C::NS; ++st) {
-        const bf16x8 kf = __builtin_bit_cast(bf16x8, sKb[krow_l * C::KC + ((2 * st + half) ^ sw)]);
-        s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], s_acc, 0, 0, 0);
+    for (int sub = 0; sub < 2; ++sub) {
+        const int krow_l = sub * 32 + l31;
+        const int sw = C::swz(krow_l);
+        s_acc[sub] = zero;
+#pragma unroll
+        for (int st = 0; st < C::NS; ++st) {
+            const bf16x8 kf = __builtin_bit_cast(bf16x8, sKb[krow_l * C::KC + ((2 * st + half) ^ sw)]);
+            s_acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], s_acc[sub], 0, 0, 0);
+        }
     }
-    // accumulator row r of this lane is key  key0 + (r&3) + 8*(r>>2) + 4*half
+    // accumulator row r of half-tile `sub` is key  key0 + 32*sub + (r&3) + 8*(r>>2) + 4*half
     if (MASKED) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if ((key0 + (r & 3) + 8 * (r >> 2) + 4 * half) >= Lk) s_acc[r] = -INFINITY;
-    }
-    float mloc = max3f(s_acc[0], s_acc[1], s_acc[2]);
+        for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-    for (int r = 3; r < 15; r += 2) mloc = max3f(mloc, s_acc[r], s_acc[r + 1]);
-    mloc = max2f(mloc, s_acc[15]);
+            for (int r = 0; r < 16; ++r)
+                if ((key0 + 32 * sub + (r & 3) + 8 * (r >> 2) + 4 * half) >= Lk) s_acc[sub][r] = -INFINITY;
+    }
+    float mloc = max3f(s_acc[0][0], s_acc[0][1], s_acc[1][0]);
+    mloc = max2f(mloc, s_acc[1][1]);
+#pragma unroll
+    for (int r = 2; r < 16; r += 2) {
+        mloc = max3f(mloc, s_acc[0][r], s_acc[0][r + 1]);
+        mloc = max3f(mloc, s_acc[1][r], s_acc[1][r + 1]);
+    }
     mloc *= scale_log2e;                            // scale > 0: max commutes with the scaling
     mloc = max2f(mloc, __shfl_xor(mloc, 32, 64));
     // rescale only when some query of the wave saw its maximum grow (wave-uniform branch)
     if (__any(mloc > m_run)) {
-        const float m_new = max2f(m_run, mloc);    // finite: every sub-tile holds >= 1 valid key
+        const float m_new = max2f(m_run, mloc);    // finite: every tile holds >= 1 valid key
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         l_run *= alpha;
 #pragma unroll
@@ -134,28 +145,32 @@ __device__ __forceinline__ void subtile(const uint4* __restrict__ sKb, const uns
         m_run = m_new;
     }
     float psum = 0.f;
-    unsigned pw[8];
+    unsigned pw[2][8];
 #pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[r], scale_log2e, -m_run));
-        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[r + 1], scale_log2e, -m_run));
-        psum += p0 + p1;
-        pw[r >> 1] = cvt_pk_bf16(p0, p1);
-    }
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[sub][r], scale_log2e, -m_run));
+            const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[sub][r + 1], scale_log2e, -m_run));
+            psum += p0 + p1;
+            pw[sub][r >> 1] = cvt_pk_bf16(p0, p1);
+        }
     l_run += psum;
     // O^T[d][q] += sum_slots V^T[d][key(slot)] P^T[key(slot)][q]; slot (u, half, e) = accumulator row 8u+e
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const bf16x8 pf = __builtin_bit_cast(bf16x8, make_uint4(pw[4 * u], pw[4 * u + 1], pw[4 * u + 2], pw[4 * u + 3]));
+    for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-        for (int dt = 0; dt < C::ND; ++dt) {
-            const unsigned short* vrow = sVTb + (dt * 32 + l31) * VT_LD + sub * 32 + 16 * u + 4 * half;
-            const uint2 va = *reinterpret_cast<const uint2*>(vrow);        // keys +0..3
-            const uint2 vb = *reinterpret_cast<const uint2*>(vrow + 8);    // keys +8..11
-            const bf16x8 vf = __builtin_bit_cast(bf16x8, make_uint4(va.x, va.y, vb.x, vb.y));
-            o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o_acc[dt], 0, 0, 0);
+        for (int u = 0; u < 2; ++u) {
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, make_uint4(pw[sub][4 * u], pw[sub][4 * u + 1], pw[sub][4 * u + 2], pw[sub][4 * u + 3]));
+#pragma unroll
+            for (int dt = 0; dt < C::ND; ++dt) {
+                const unsigned short* vrow = sVTb + (dt * 32 + l31) * VT_LD + sub * 32 + 16 * u + 4 * half;
+                const uint2 va = *reinterpret_cast<const uint2*>(vrow);        // keys +0..3
+                const uint2 vb = *reinterpret_cast<const uint2*>(vrow + 8);    // keys +8..11
+                const bf16x8 vf = __builtin_bit_cast(bf16x8, make_uint4(va.x, va.y, vb.x, vb.y));
+                o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o_acc[dt], 0, 0, 0);
+            }
         }
-    }
 }
 
 // D: head dim (32: the DiT; 64: the VAEs).  VT: V is given transposed ([d][key], keys contiguous; v_sl = d
@@ -220,7 +235,8 @@ __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(AttnParams p) {
     float m_run = -INFINITY, l_run = 0.f;
 
     // staging roles, LOADS chunks per thread: chunk c = tid + i*256.  K and row-major V: key c / KC, chunk c % KC
-    // (= tid % KC for every i).  Transposed V: d row c >> 3, 8-key chunk c & 7.
+    // (= tid % KC for every i).  Transposed V: d row c >> 3, 8-key chunk c & 7.  Everything that does not depend on
+    // the tile index (global row pointers, LDS slots) is computed once here; per tile the pointers just advance.
     const int st_c = tid % C::KC;
     float gk8[8];
     if (p.gamma_k != nullptr) {
@@ -228,28 +244,47 @@ __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(AttnParams p) {
         for (int e = 0; e < 8; ++e) gk8[e] = p.gamma_k[head * D + st_c * 8 + e];
     }
     const bool has_gk = p.gamma_k != nullptr;
+    const int n_tiles = (Lk + KT - 1) / KT;
+    const int last_full = Lk / KT;                      // tiles [0, last_full) hold 64 valid keys
+
+    int st_key[C::LOADS], k_slot[C::LOADS], v_slot[C::LOADS];
+    const unsigned short* k_src[C::LOADS];
+    const unsigned short* v_src[C::LOADS];
+#pragma unroll
+    for (int i = 0; i < C::LOADS; ++i) {
+        const int c = tid + i * THREADS;
+        st_key[i] = c / C::KC;
+        k_slot[i] = st_key[i] * C::KC + (st_c ^ C::swz(st_key[i]));
+        k_src[i] = kp + (long long)st_key[i] * p.k_sl + st_c * 8;
+        if (VT) {
+            v_slot[i] = (c >> 3) * VT_LD + (c & 7) * 8;
+            v_src[i] = vp + (long long)(c >> 3) * p.v_sl + (c & 7) * 8;
+        } else {
+            v_slot[i] = st_c * 8 * VT_LD + st_key[i];
+            v_src[i] = vp + (long long)st_key[i] * p.v_sl + st_c * 8;
+        }
+    }
+    const long long k_step = (long long)KT * p.k_sl, v_step = VT ? (long long)KT : (long long)KT * p.v_sl;
 
     uint4 kreg[C::LOADS], vreg[C::LOADS];
-// LOAD only issues the global loads (rows clamped in-bounds); masking / RMSNorm / LDS writes happen in STORE,
-// after the MFMAs of the tile being consumed, so the loads stay in flight across the compute.
+// LOAD only issues the global loads; masking / RMSNorm / LDS writes happen in STORE, after the MFMAs of the tile
+// being consumed, so the loads stay in flight across the compute.  Rows of the last, partial tile are clamped
+// in-bounds here and zeroed in STORE.
 #define GVF_ATTN_LOAD(kt_)                                                                              \
     _Pragma("unroll") for (int i = 0; i < C::LOADS; ++i) {                                              \
-        const int c = tid + i * THREADS;                                                                \
-        const int key = (kt_) * KT + c / C::KC;                                                         \
-        const long long krow = key < Lk ? key : 0;                                                      \
-        kreg[i] = *reinterpret_cast<const uint4*>(kp + krow * p.k_sl + st_c * 8);                       \
-        if (VT) {                                                                                       \
-            vreg[i] = *reinterpret_cast<const uint4*>(vp + (long long)(c >> 3) * p.v_sl + (kt_) * KT + (c & 7) * 8); \
-        } else {                                                                                        \
-            vreg[i] = *reinterpret_cast<const uint4*>(vp + krow * p.v_sl + st_c * 8);                   \
-        }                                                                                               \
+        const bool in_ = (kt_) < last_full || (kt_) * KT + st_key[i] < Lk;                              \
+        kreg[i] = *reinterpret_cast<const uint4*>(in_ ? k_src[i] + (kt_) * k_step : kp + st_c * 8);     \
+        if (VT) vreg[i] = *reinterpret_cast<const uint4*>(v_src[i] + (kt_) * v_step);                   \
+        else vreg[i] = *reinterpret_cast<const uint4*>(in_ ? v_src[i] + (kt_) * v_step : vp + st_c * 8); \
     }
 #define GVF_ATTN_STORE(buf_, kt_)                                                                       \
     _Pragma("unroll") for (int i = 0; i < C::LOADS; ++i) {                                              \
-        const int c = tid + i * THREADS;                                                                \
-        const int st_key = c / C::KC;                                                                   \
-        const unsigned m = ((kt_) * KT + st_key) < Lk ? 0xffffffffu : 0u;                               \
-        uint4 kw = make_uint4(kreg[i].x & m, kreg[i].y & m, kreg[i].z & m, kreg[i].w & m);              \
+        uint4 kw = kreg[i], vw = vreg[i];                                                               \
+        if ((kt_) >= last_full) {                           /* wave-uniform: only the partial tile masks */ \
+            const unsigned m = ((kt_) * KT + st_key[i]) < Lk ? 0xffffffffu : 0u;                        \
+            kw = make_uint4(kw.x & m, kw.y & m, kw.z & m, kw.w & m);                                    \
+            if (!VT) vw = make_uint4(vw.x & m, vw.y & m, vw.z & m, vw.w & m);                           \
+        }                                                                                               \
         if (has_gk) {                                                                                   \
             float ss = sumsq8(kw);                                                                      \
             ss += __shfl_xor(ss, 1, 64);                                                                \
@@ -257,20 +292,19 @@ __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(AttnParams p) {
             if (C::KC == 8) ss += __shfl_xor(ss, 4, 64);                                                \
             kw = rms_apply<D>(kw, ss, gk8);                                                             \
         }                                                                                               \
-        sK[buf_][st_key * C::KC + (st_c ^ C::swz(st_key))] = kw;                                        \
+        sK[buf_][k_slot[i]] = kw;                                                                       \
         if (VT) {                                                                                       \
-            *reinterpret_cast<uint2*>(&sVT[buf_][(c >> 3) * VT_LD + (c & 7) * 8]) = make_uint2(vreg[i].x, vreg[i].y);     \
-            *reinterpret_cast<uint2*>(&sVT[buf_][(c >> 3) * VT_LD + (c & 7) * 8 + 4]) = make_uint2(vreg[i].z, vreg[i].w); \
+            *reinterpret_cast<uint2*>(&sVT[buf_][v_slot[i]]) = make_uint2(vw.x, vw.y);                  \
+            *reinterpret_cast<uint2*>(&sVT[buf_][v_slot[i] + 4]) = make_uint2(vw.z, vw.w);              \
         } else {                                                                                        \
-            const unsigned w[4] = {vreg[i].x & m, vreg[i].y & m, vreg[i].z & m, vreg[i].w & m};         \
+            const unsigned w[4] = {vw.x, vw.y, vw.z, vw.w};                                             \
             _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                             \
-                sVT[buf_][(st_c * 8 + 2 * e) * VT_LD + st_key] = (unsigned short)(w[e] & 0xffffu);      \
-                sVT[buf_][(st_c * 8 + 2 * e + 1) * VT_LD + st_key] = (unsigned short)(w[e] >> 16);      \
+                sVT[buf_][v_slot[i] + (2 * e) * VT_LD] = (unsigned short)(w[e] & 0xffffu);              \
+                sVT[buf_][v_slot[i] + (2 * e + 1) * VT_LD] = (unsigned short)(w[e] >> 16);              \
             }                                                                                           \
         }                                                                                               \
     }
 
-    const int n_tiles = (Lk + KT - 1) / KT;
     GVF_ATTN_LOAD(0)
     GVF_ATTN_STORE(0, 0)
     __syncthreads();
@@ -279,14 +313,10 @@ __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(AttnParams p) {
         const int buf = kt & 1;
         if (kt + 1 < n_tiles) { GVF_ATTN_LOAD(kt + 1) }      // in flight while this tile is consumed
 
-        if (kt * KT + KT <= Lk) {          // full tile: no key masking
-            subtile<D, false>(sK[buf], sVT[buf], 0, kt * KT, Lk, p.scale_log2e, qf, l31, half, o_acc, m_run, l_run);
-            subtile<D, false>(sK[buf], sVT[buf], 1, kt * KT + 32, Lk, p.scale_log2e, qf, l31, half, o_acc, m_run, l_run);
-        } else {
-            subtile<D, true>(sK[buf], sVT[buf], 0, kt * KT, Lk, p.scale_log2e, qf, l31, half, o_acc, m_run, l_run);
-            if (kt * KT + 32 < Lk)
-                subtile<D, true>(sK[buf], sVT[buf], 1, kt * KT + 32, Lk, p.scale_log2e, qf, l31, half, o_acc, m_run, l_run);
-        }
+        if (kt < last_full)                // full tile: no key masking
+            tile64<D, false>(sK[buf], sVT[buf], kt * KT, Lk, p.scale_log2e, qf, l31, half, o_acc, m_run, l_run);
+        else                               // last, partial tile: keys >= Lk get -inf scores (their staged K/V rows are zero)
+            tile64<D, true>(sK[buf], sVT[buf], kt * KT, Lk, p.scale_log2e, qf, l31, half, o_acc, m_run, l_run);
         // the other buffer was last read in iteration kt-1; every wave has passed that iteration's barrier
         if (kt + 1 < n_tiles) { GVF_ATTN_STORE(buf ^ 1, kt + 1) }
         __syncthreads();
