@@ -301,7 +301,51 @@ def gen_sparse():
     print("sparse_index_golden.npz", len(out), "arrays")
 
 
-SECTIONS = {"raster": gen_raster, "vox2seq": gen_vox2seq, "dit": gen_dit, "sampler": gen_sampler, "sparse": gen_sparse}
+VAE_SMALL = dict(depth=2, dim=96, queries_dim=96, output_dim=14, num_inputs=64, num_latents=32, latent_dim=16, heads=3,
+                 dim_head=-1, weight_tie_layers=False, decoder_ff=False, enable_flash_attn=False, num_timesteps=3,
+                 chunk_size=100)
+
+
+def gen_vae():
+    """Motion-VAE decode (model/autoencoder.py:552-609), the step between the sampler and the renderer
+    (inference_dpm_latent.py:256-257).  Extra stubs: torch_cluster.fps, pytorch3d.ops, timm.models.layers."""
+    import json
+    import yaml
+    _stub("torch_cluster", fps=None)
+    p3 = _stub("pytorch3d"); p3.ops = _stub("pytorch3d.ops")
+    tm = _stub("timm"); tmm = _stub("timm.models"); tml = _stub("timm.models.layers", DropPath=torch.nn.Identity,
+                                                               trunc_normal_=torch.nn.init.trunc_normal_)
+    tm.models = tmm; tmm.layers = tml
+    from model.autoencoder import GSKLTemporalVariationalAutoEncoder as VAE
+    torch.manual_seed(0)
+    vae = VAE(**VAE_SMALL).eval()
+    _randomise(vae, 3)
+    g = torch.Generator().manual_seed(4)
+    B, T, P = 2, VAE_SMALL["num_timesteps"], 250
+    x = torch.randn((B * T, VAE_SMALL["num_latents"], VAE_SMALL["latent_dim"]), generator=g)
+    queries = torch.randn((B, P, 14), generator=g) * 0.5
+    with torch.no_grad():
+        y = vae.decode(x, queries)
+        proj = vae.proj(x)
+        l0 = vae.layers[0][0](proj) + proj
+        l0 = vae.layers[0][1](l0) + l0
+    out = {"cfg_json": np.frombuffer(json.dumps(VAE_SMALL).encode(), dtype=np.uint8), "x": x.numpy(), "queries": queries.numpy(),
+           "y": y.numpy(), "layer0": l0.numpy()}
+    for k, v in vae.state_dict().items():
+        if k.startswith(("cross_attend_blocks", "input_embedding", "mean_fc", "logvar_fc")):
+            continue                                   # encoder-only tensors: not needed by decode, keep the fixture small
+        out["sd." + k] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "vae_small_golden.npz"), **out)
+    print("vae_small_golden.npz", y.shape, float(y.abs().mean()))
+    cfg = yaml.safe_load(open(f"{REF}/configs/diffusion.yml"))["motion_vae"]
+    torch.manual_seed(0)
+    full = VAE(**cfg, num_timesteps=24)
+    man = {k: list(v.shape) for k, v in full.state_dict().items()}
+    json.dump({"config": cfg, "state_dict": man}, open(os.path.join(OUT, "vae_manifest.json"), "w"), indent=0)
+    print("vae_manifest.json", len(man), "tensors", sum(int(np.prod(v)) for v in man.values()) / 1e6, "M params")
+
+
+SECTIONS = {"vae": gen_vae, "raster": gen_raster, "vox2seq": gen_vox2seq, "dit": gen_dit, "sampler": gen_sampler, "sparse": gen_sparse}
 
 if __name__ == "__main__":
     install_stubs()
