@@ -25,6 +25,7 @@ SOURCES = {
     "attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"],
     "gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
     "elem.hip": [],
+    "vae.hip": [],
 }
 
 

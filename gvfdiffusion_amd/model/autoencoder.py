@@ -1,0 +1,222 @@
+"""Motion VAE (`GSKLTemporalVariationalAutoEncoder`) -- the DECODE half on the MI355X kernels.
+
+Mirrors model/autoencoder.py:345-609 of the reference: same constructor keywords, same parameter tree (all 121
+tensors of the released checkpoint load with ``strict=True``), same ``decode(x, queries)`` signature and
+output ``(B, T, P, output_dim)``.  Only inference-time ``decode`` is on the hot path (inference_dpm_latent.py:
+252-256 -> utils/inference_utils.py: pred_delta = vae.decode(latents, static_gs)); ``encode`` needs FPS/KNN
+(torch_cluster / pytorch3d) and stays out of scope -- it raises NotImplementedError.
+
+What differs from the reference's op order (results agree to the bf16 tolerance stated in tests/test_vae_gpu.py):
+  * the query embedding (gs_embedding + position_encoding + PreNorm LN) and the decoder to_q projection depend on
+    the static Gaussians only; the reference repeats them for each of the T frames (process_chunk :557), here they
+    run once per sample and the attention kernel reads the same q for every frame (inner stride 0);
+  * to_out (dim -> dim) and to_outputs (dim -> output_dim) have nothing between them (decoder_ff is None in the
+    released config), so they are folded into one (output_dim x dim) matrix at weight-preparation time;
+  * to_q / to_kv of the latent self-attention run as one N = 3*dim GEMM; K and V^T of the decoder cross-attention
+    are laid out head-major once per decode (as the DiT's condition cache).
+Precision placement = the reference under autocast(bf16): bf16 GEMM/attention operands, fp32 accumulate,
+fp32 residual stream, LayerNorm and softmax.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from ..ops import dit_ops, vae_ops
+
+
+class GEGLU(nn.Module):
+    def forward(self, x):  # parameter-less placeholder keeping `net.2` at index 2 (model/autoencoder.py:90-93)
+        raise RuntimeError("GEGLU runs inside gvf_geglu_bf16; call GSKLTemporalVariationalAutoEncoder.decode")
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, mult=4):
+        super().__init__()
+        self.net = nn.Sequential(nn.Linear(dim, dim * mult * 2), GEGLU(), nn.Linear(dim * mult, dim))
+
+
+class Attention(nn.Module):
+    def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64):
+        super().__init__()
+        inner = dim_head * heads
+        context_dim = query_dim if context_dim is None else context_dim
+        self.heads, self.dim_head, self.scale = heads, dim_head, dim_head ** -0.5
+        self.to_q = nn.Linear(query_dim, inner, bias=False)
+        self.to_kv = nn.Linear(context_dim, inner * 2, bias=False)
+        self.to_out = nn.Linear(inner, query_dim)
+
+
+class PreNorm(nn.Module):
+    """Holds `fn`; its LayerNorms (eps 1e-6) have no parameters (model/autoencoder.py:73-88)."""
+
+    def __init__(self, dim, fn, context_dim=None):
+        super().__init__()
+        self.fn = fn
+
+
+class PointEmbed(nn.Module):
+    def __init__(self, hidden_dim=48):
+        super().__init__()
+        assert hidden_dim % 6 == 0
+        self.embedding_dim = hidden_dim // 3 // 2
+        omega = np.arange(self.embedding_dim, dtype=np.float64)
+        omega /= self.embedding_dim / 2.0
+        self.register_buffer("omega", torch.from_numpy(1.0 / 10000 ** omega))
+
+
+class GSKLTemporalVariationalAutoEncoder(nn.Module):
+    def __init__(self, *, depth=24, dim=512, queries_dim=512, input_dim=3, gs_dim=14, output_dim=10, num_inputs=8192,
+                 num_latents=1024, latent_dim=128, heads=8, dim_head=-1, weight_tie_layers=False, decoder_ff=False,
+                 enable_flash_attn=False, num_timesteps=24, chunk_size=8192, knn_k=8, beta=7.0):
+        super().__init__()
+        if dim_head == -1:
+            dim_head = dim // heads
+        if decoder_ff or weight_tie_layers:
+            raise NotImplementedError("decoder_ff / weight_tie_layers are off in every released config")
+        if dim_head not in (32, 64):
+            raise ValueError(f"gvf_attn_fwd_bf16 supports head_dim 32 or 64, got {dim_head}")
+        if queries_dim != dim or dim % 64 != 0 or dim % 6 != 0:
+            raise ValueError("dim must equal queries_dim and be a multiple of 64 (GEMM K) and of 6 (PointEmbed)")
+        self.depth, self.dim, self.heads, self.dim_head = depth, dim, heads, dim_head
+        self.num_inputs, self.num_latents, self.num_timesteps = num_inputs, num_latents, num_timesteps
+        self.knn_k, self.beta, self.chunk_size, self.output_dim, self.gs_dim = knn_k, beta, chunk_size, output_dim, gs_dim
+
+        def attn(qd, cd=None):
+            return Attention(qd, cd, heads=heads, dim_head=dim_head)
+
+        # encoder half: parameters only (so that released checkpoints load strictly)
+        self.cross_attend_blocks = nn.ModuleList([PreNorm(dim, attn(dim, dim), context_dim=dim), PreNorm(dim, FeedForward(dim))])
+        self.input_embedding = nn.Sequential(nn.Linear(input_dim, dim), nn.LayerNorm(dim, elementwise_affine=False))
+        self.gs_embedding = nn.Sequential(nn.Linear(gs_dim, dim), nn.LayerNorm(dim, elementwise_affine=False))
+        self.position_encoding = nn.Sequential(PointEmbed(hidden_dim=dim), nn.LayerNorm(dim, elementwise_affine=False))
+        self.layers = nn.ModuleList([nn.ModuleList([PreNorm(dim, attn(dim)), PreNorm(dim, FeedForward(dim))]) for _ in range(depth)])
+        self.decoder_cross_attn = PreNorm(queries_dim, attn(queries_dim, dim), context_dim=dim)
+        self.decoder_ff = None
+        self.to_outputs = nn.Linear(queries_dim, output_dim)
+        self.proj = nn.Linear(latent_dim, dim)
+        self.mean_fc = nn.Linear(dim, latent_dim)
+        self.logvar_fc = nn.Linear(dim, latent_dim)
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.trunc_normal_(m.weight, std=0.02)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+        nn.init.zeros_(self.to_outputs.weight)       # zero_module(to_outputs), model/autoencoder.py:434
+        nn.init.zeros_(self.to_outputs.bias)
+        self._wcache = None
+        self.max_chunk_rows = 1 << 20                # rows (B*T*Pc) of the bf16 attention-output chunk: 1.5 GiB at dim 768
+
+    # ---- not on the inference path -----------------------------------------------------------------------
+    def encode(self, *a, **k):
+        raise NotImplementedError("motion-VAE encode (FPS + KNN interpolation) is outside the MI355X hot path; "
+                                  "see SURVEY.md section 8f")
+
+    forward = encode
+
+    # ---- weights -----------------------------------------------------------------------------------------
+    def _param_version(self):
+        return tuple((p._version, p.data_ptr()) for p in self.parameters())
+
+    def _weights(self):
+        ver = self._param_version()
+        if self._wcache is not None and self._wcache["ver"] == ver:
+            return self._wcache
+
+        def bf(w):
+            w = w.detach().float().contiguous()
+            return dit_ops.cast_pad_bf16(w, dit_ops.pad64(w.shape[1]))
+
+        def fb(b):
+            return None if b is None else b.detach().float().contiguous()
+
+        W = {"ver": ver, "proj": (bf(self.proj.weight), fb(self.proj.bias)), "layers": []}
+        for a, f in self.layers:
+            W["layers"].append(dict(
+                qkv=bf(torch.cat([a.fn.to_q.weight, a.fn.to_kv.weight], 0)),
+                out=(bf(a.fn.to_out.weight), fb(a.fn.to_out.bias)),
+                fc1=(bf(f.fn.net[0].weight), fb(f.fn.net[0].bias)),
+                fc2=(bf(f.fn.net[2].weight), fb(f.fn.net[2].bias))))
+        d = self.decoder_cross_attn.fn
+        W["dec_q"], W["dec_kv"] = bf(d.to_q.weight), bf(d.to_kv.weight)
+        wo, wy = d.to_out.weight.detach().double(), self.to_outputs.weight.detach().double()
+        W["fold"] = (bf((wy @ wo).float()),
+                     (wy @ d.to_out.bias.detach().double() + self.to_outputs.bias.detach().double()).float().contiguous())
+        W["gs_w"] = self.gs_embedding[0].weight.detach().float().contiguous()
+        W["gs_b"] = self.gs_embedding[0].bias.detach().float().contiguous()
+        W["omega"] = self.position_encoding[0].omega.detach().float().contiguous()
+        self._wcache = W
+        return W
+
+    # ---- decode ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def decode_latents(self, x: torch.Tensor) -> torch.Tensor:
+        """proj + `depth` latent self-attention / GEGLU blocks: (B*T, L, latent_dim) -> fp32 (B*T*L, dim)."""
+        _lib.require_cuda(x)
+        W = self._weights()
+        BT, L, Dl = x.shape
+        C, H, d, dev = self.dim, self.heads, self.dim_head, x.device
+        M = BT * L
+        bf16 = torch.bfloat16
+        xb = dit_ops.cast_pad_bf16(x.reshape(M, Dl).float().contiguous(), dit_ops.pad64(Dl))
+        h = torch.empty((M, C), dtype=torch.float32, device=dev)
+        dit_ops.gemm_bf16(xb, *W["proj"], h, dit_ops.EPI_STORE_F32)
+        hb = torch.empty((M, C), dtype=bf16, device=dev)
+        qkv = torch.empty((M, 3 * C), dtype=bf16, device=dev)
+        hid = torch.empty((M, 8 * C), dtype=bf16, device=dev)
+        act = torch.empty((M, 4 * C), dtype=bf16, device=dev)
+        s3 = (L * 3 * C, 0, 3 * C)
+        for w in W["layers"]:
+            dit_ops.layernorm_modulate_bf16(h, hb, 1e-6)
+            dit_ops.gemm_bf16(hb, w["qkv"], None, qkv, dit_ops.EPI_STORE_BF16)
+            dit_ops.attention_bf16(qkv, qkv[:, C:], qkv[:, 2 * C:], hb, BT, 1, L, L, H, s3, s3, s3, (L * C, 0, C), head_dim=d)
+            dit_ops.gemm_bf16(hb, *w["out"], h, dit_ops.EPI_RESID_F32)
+            dit_ops.layernorm_modulate_bf16(h, hb, 1e-6)
+            dit_ops.gemm_bf16(hb, *w["fc1"], hid, dit_ops.EPI_STORE_BF16)
+            vae_ops.geglu_bf16(hid, act)
+            dit_ops.gemm_bf16(act, *w["fc2"], h, dit_ops.EPI_RESID_F32)
+        return h
+
+    @torch.no_grad()
+    def decode(self, x: torch.Tensor, queries: torch.Tensor) -> torch.Tensor:
+        """x: (B*T, L, latent_dim), queries: (B, P, gs_dim) -> (B, T, P, output_dim)  (model/autoencoder.py:579-609)."""
+        _lib.require_cuda(x, queries)
+        W = self._weights()
+        B, P = queries.shape[:2]
+        T, C, H, d, dev = self.num_timesteps, self.dim, self.heads, self.dim_head, x.device
+        BT, L = x.shape[:2]
+        if BT != B * T:
+            raise ValueError(f"x has {BT} latent sets, queries imply B*T = {B}*{T}")
+        bf16 = torch.bfloat16
+        h = self.decode_latents(x)
+        # context: PreNorm.norm_context -> to_kv, K head-major and V^T zero-padded to 64 keys, per (b, t)
+        hb = torch.empty((BT * L, C), dtype=bf16, device=dev)
+        dit_ops.layernorm_modulate_bf16(h, hb, 1e-6)
+        kv = torch.empty((BT * L, 2 * C), dtype=bf16, device=dev)
+        dit_ops.gemm_bf16(hb, W["dec_kv"], None, kv, dit_ops.EPI_STORE_BF16)
+        kc = kv[:, :C].reshape(BT, L, H, d).permute(0, 2, 1, 3).contiguous()
+        Lp = (L + 63) // 64 * 64
+        vt = torch.zeros((BT, H, d, Lp), dtype=bf16, device=dev)
+        vt[..., :L] = kv[:, C:].reshape(BT, L, H, d).permute(0, 2, 3, 1)
+        # queries: embedding + PreNorm + to_q once per static Gaussian (shared by the T frames)
+        qe = vae_ops.vae_query_embed_bf16(queries.reshape(B * P, -1).float().contiguous(), W["gs_w"], W["gs_b"], W["omega"])
+        qp = torch.empty((B * P, C), dtype=bf16, device=dev)
+        dit_ops.gemm_bf16(qe, W["dec_q"], None, qp, dit_ops.EPI_STORE_BF16)
+        del qe
+        out = torch.empty((B, T, P, self.output_dim), dtype=torch.float32, device=dev)
+        Pc = max(128, self.max_chunk_rows // (B * T) // 128 * 128)
+        Pc = min(Pc, P)
+        ao = torch.empty((B, T, Pc, C), dtype=bf16, device=dev)
+        yo = torch.empty((B * T * Pc, self.output_dim), dtype=torch.float32, device=dev)
+        qp3 = qp.view(B, P, C)
+        for p0 in range(0, P, Pc):
+            n = min(Pc, P - p0)
+            a = ao if n == Pc else ao.view(-1)[:B * T * n * C].view(B, T, n, C)
+            dit_ops.attention_bf16(qp3[:, p0:], kc, vt, a, B, T, n, L, H, (P * C, 0, C), (T * H * L * d, H * L * d, d, L * d),
+                                   (T * H * d * Lp, H * d * Lp, Lp, d * Lp), (T * n * C, n * C, C), v_transposed=True, head_dim=d)
+            y = yo[:B * T * n]
+            dit_ops.gemm_bf16(a.view(B * T * n, C), *W["fold"], y, dit_ops.EPI_STORE_F32)
+            out[:, :, p0:p0 + n] = y.view(B, T, n, self.output_dim)
+        return out.to(queries.dtype if queries.dtype.is_floating_point else torch.float32)

@@ -21,8 +21,8 @@ def _lin(x, sd, name, precision, round_out=False):
     return _r(y, precision) if round_out else y
 
 
-def _ln(x):
-    return F.layer_norm(x, x.shape[-1:], None, None, 1e-6)
+def _ln(x, eps=1e-6):   # PreNorm :77 eps 1e-6; the embedding norms :393-394 keep nn.LayerNorm's default 1e-5
+    return F.layer_norm(x, x.shape[-1:], None, None, eps)
 
 
 def attention(xq, ctx, sd, prefix, heads, precision):
@@ -62,7 +62,7 @@ def vae_decode(sd, cfg, x, queries, num_timesteps, precision="fp32"):
     for i in range(depth):
         h = attention(_ln(h), _ln(h), sd, f"layers.{i}.0.fn", heads, precision) + h
         h = feed_forward(_ln(h), sd, f"layers.{i}.1.fn", precision) + h
-    q_embed = _ln(_lin(queries, sd, "gs_embedding.0", precision)) + _ln(point_embed(queries[..., :3], sd["position_encoding.0.omega"]))
+    q_embed = _ln(_lin(queries, sd, "gs_embedding.0", precision), 1e-5) + _ln(point_embed(queries[..., :3], sd["position_encoding.0.omega"]), 1e-5)
     q_embed = q_embed[:, None].expand(B, T, P, -1).reshape(B * T, P, -1)
     lat = attention(_ln(q_embed), _ln(h), sd, "decoder_cross_attn.fn", heads, precision)
     return _lin(lat, sd, "to_outputs", precision).reshape(B, T, P, -1)

@@ -18,7 +18,7 @@ def test_decode_matches_reference():
     with torch.no_grad():
         y = vae_ref.vae_decode(sd, cfg, torch.from_numpy(g["x"]), torch.from_numpy(g["queries"]), cfg["num_timesteps"])
     assert y.shape == g["y"].shape
-    assert np.abs(y.numpy() - g["y"]).max() < 2e-5, np.abs(y.numpy() - g["y"]).max()
+    assert np.abs(y.numpy() - g["y"]).max() < 1e-6, np.abs(y.numpy() - g["y"]).max()   # measured: 0.0 (same torch ops)
     with torch.no_grad():
         yb = vae_ref.vae_decode(sd, cfg, torch.from_numpy(g["x"]), torch.from_numpy(g["queries"]), cfg["num_timesteps"], "bf16")
     assert float((yb - y).norm() / y.norm()) < 3e-2

@@ -1,0 +1,122 @@
+"""Motion-VAE decode on the HIP kernels (gvfdiffusion_amd/model/autoencoder.py) against the torch oracle
+(oracle/vae_ref.py, pinned bit-exactly to the reference by tests/test_oracle_vae.py).
+
+Tolerances (relative L2 over the whole output, as for the DiT):
+  vs the bf16-placement oracle  1e-2   (same rounding points; differences = accumulation order, exp2 softmax,
+                                        folded to_out∘to_outputs and the fp32 query embedding)
+  vs the fp32 oracle            3e-2   (bf16 operand rounding through `depth` blocks)
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL_VS_BF16_ORACLE = 1e-2
+TOL_VS_FP32_ORACLE = 3e-2
+
+
+def _model(cfg, seed=0, gain=1.0):
+    from gvfdiffusion_amd.model.autoencoder import GSKLTemporalVariationalAutoEncoder
+    torch.manual_seed(seed)
+    m = GSKLTemporalVariationalAutoEncoder(**cfg)
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            if p.dim() == 2:
+                p.copy_(torch.randn_like(p) * (gain / math.sqrt(p.shape[1])))
+            else:
+                p.copy_(torch.randn_like(p) * 0.1)
+    return m
+
+
+def _inputs(cfg, B, P, L, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B * cfg["num_timesteps"], L, cfg["latent_dim"], generator=g)
+    q = torch.randn(B, P, 14, generator=g)
+    q[..., :3] = torch.rand(B, P, 3, generator=g) - 0.5
+    return x, q
+
+
+def _rel(a, b):
+    return float((a - b).norm() / b.norm())
+
+
+def _check(cfg, B, P, L, chunk_rows=None, gain=1.0):
+    from oracle import vae_ref
+    m = _model(cfg, gain=gain)
+    x, q = _inputs(cfg, B, P, L)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref32 = vae_ref.vae_decode(sd, cfg, x, q, cfg["num_timesteps"], "fp32")
+        ref16 = vae_ref.vae_decode(sd, cfg, x, q, cfg["num_timesteps"], "bf16")
+    m = m.cuda()
+    if chunk_rows:
+        m.max_chunk_rows = chunk_rows
+    y = m.decode(x.cuda(), q.cuda()).cpu()
+    assert y.shape == (B, cfg["num_timesteps"], P, cfg["output_dim"]) and torch.isfinite(y).all()
+    e16, e32 = _rel(y, ref16), _rel(y, ref32)
+    print(f"vae decode rel-L2: vs bf16 oracle {e16:.2e}, vs fp32 oracle {e32:.2e}, bf16 oracle vs fp32 oracle {_rel(ref16, ref32):.2e}")
+    assert e16 < TOL_VS_BF16_ORACLE and e32 < TOL_VS_FP32_ORACLE, (e16, e32)
+    return e16, e32
+
+
+BASE = dict(depth=2, dim=192, queries_dim=192, output_dim=14, num_inputs=64, num_latents=40, latent_dim=16, heads=3,
+            dim_head=-1, num_timesteps=3, chunk_size=100)
+
+
+def test_geglu_matches_torch(cuda):
+    from gvfdiffusion_amd.ops import vae_ops
+    torch.manual_seed(0)
+    x = (torch.randn(777, 2 * 264) * 2).to(torch.bfloat16).cuda()
+    y = vae_ops.geglu_bf16(x).float().cpu()
+    a, g = x.float().cpu().chunk(2, dim=-1)
+    ref = (a * torch.nn.functional.gelu(g)).to(torch.bfloat16).float()
+    assert (y - ref).abs().max() <= 2 ** -7 * ref.abs().max()      # at most one bf16 ulp of the largest value
+    assert ((y - ref).abs() > 0).float().mean() < 1e-2             # ... and on <1% of the elements (erff vs torch erf)
+
+
+@pytest.mark.parametrize("C", [96, 192, 768])
+def test_query_embed_matches_torch(cuda, C):
+    from gvfdiffusion_amd.ops import vae_ops
+    from oracle import vae_ref
+    torch.manual_seed(C)
+    P = 1000
+    q = torch.randn(P, 14)
+    q[:, :3] = torch.rand(P, 3) - 0.5
+    w, b = torch.randn(C, 14) * 0.3, torch.randn(C) * 0.1
+    E = C // 6
+    omega = 1.0 / 10000 ** (torch.arange(E, dtype=torch.float64) / (E / 2.0))
+    ref = vae_ref._ln(vae_ref._ln(q @ w.T + b, 1e-5) + vae_ref._ln(vae_ref.point_embed(q[:, :3], omega), 1e-5))
+    y = vae_ops.vae_query_embed_bf16(q.cuda(), w.cuda(), b.cuda(), omega.float().cuda()).float().cpu()
+    assert (y - ref).abs().max() < 2e-2 and _rel(y, ref) < 3e-3     # bf16 output rounding: 2^-9 relative
+
+
+def test_decode_head_dim_64_chunked(cuda):
+    _check(BASE, B=2, P=300, L=40, chunk_rows=6 * 128)     # 3 chunks of 128 Gaussians, the last ragged (44)
+
+
+def test_decode_head_dim_32(cuda):
+    _check(dict(BASE, heads=6), B=1, P=257, L=64)
+
+
+def test_decode_released_config(cuda):
+    """depth 12, dim 768, 12 heads of 64, 512 latents, 24 frames (configs/diffusion.yml: autoencoder section)."""
+    cfg = dict(depth=12, dim=768, queries_dim=768, output_dim=14, num_inputs=8192, num_latents=512, latent_dim=16, heads=12,
+               dim_head=-1, num_timesteps=24, chunk_size=8192)
+    _check(cfg, B=1, P=1500, L=512)
+
+
+def test_strict_load_of_reference_layout_and_loud_failures(cuda):
+    import json, os
+    from gvfdiffusion_amd._lib import GvfError
+    from gvfdiffusion_amd.model.autoencoder import GSKLTemporalVariationalAutoEncoder
+    man = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "vae_manifest.json")))
+    cfg = dict(man["config"])
+    m = GSKLTemporalVariationalAutoEncoder(**cfg)
+    sd = {k: torch.zeros(s, dtype=torch.float64 if k.endswith("omega") else torch.float32) for k, s in man["state_dict"].items()}
+    m.load_state_dict(sd, strict=True)
+    with pytest.raises(GvfError):
+        m.decode(torch.zeros(24, 512, 16), torch.zeros(1, 8, 14))          # CPU tensors: no fallback
+    with pytest.raises(NotImplementedError):
+        m.encode(None)
