@@ -70,9 +70,13 @@ class RasterWorkload:
         self.nr = torch.zeros((F,), dtype=torch.int32, device=dev)
         # size the workspace from one synchronised call
         out = R.rasterize_batched(self.st, list(self.frames), self.act, *self.raw, delta=self.delta)
-        self.D_frames = out["num_rendered"].to(torch.int64).cpu()
-        self.D = int(self.D_frames.sum())
-        self.cap = int(self.D * 1.02) + 4096
+        self.D_binned = int(out["num_rendered"].to(torch.int64).sum())       # instances the HIP path bins (alpha-box culled)
+        self.cap = int(self.D_binned * 1.02) + 4096
+        # D of the algorithm as the reference runs it (every tile of the 3-sigma rect): the roofline's algorithmic
+        # bytes are priced on THIS count, not on the smaller one the HIP path gets away with
+        st_up = R.make_settings(S, S, deg, _lib.RAST_MODE_MIP, synthetic.KERNEL_2D, 1.0, synthetic.BG, upstream_binning=True)
+        out = R.rasterize_batched(st_up, list(self.frames), self.act, *self.raw, delta=self.delta)
+        self.D = int(out["num_rendered"].to(torch.int64).sum())
         self.ws_bytes = R.workspace_bytes(P, F, S, S, self.cap)
         R._WORKSPACES.clear()
         del out
@@ -283,7 +287,7 @@ def main():
                                    f"{F} frames x {S}x{S}, {a.gaussians} Gaussians + per-frame deltas (fused "
                                    f"activations), SH degree {a.sh_degree}, mip 2D filter, white bg",
                        "gaussians": a.gaussians, "resolution": S, "frames_per_step": F, "sh_degree": a.sh_degree,
-                       "instances_per_frame": round(work.D / F, 1), "parallelism": f"sample-sharded x{world}"},
+                       "instances_per_frame": round(work.D / F, 1), "instances_binned_per_frame": round(work.D_binned / F, 1), "parallelism": f"sample-sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": "blend_kernel (R6, one launch = all frames of the step)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,

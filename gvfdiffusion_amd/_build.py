@@ -36,6 +36,22 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: the gfx950 HIP library cannot be built")
 
 
+STAMP_PATH = LIB_PATH + ".srchash"
+
+
+def source_hash() -> str:
+    """sha256 over every file the library is built from (csrc/*.hip, csrc/*.h, include/*.h)."""
+    import hashlib
+    inc = os.path.join(os.path.dirname(_HERE), "include")
+    files = sorted([os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))] +
+                   [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")])
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def _stale(target: str, deps) -> bool:
     if not os.path.exists(target):
         return True
@@ -66,6 +82,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+    with open(STAMP_PATH, "w") as f:       # lets _lib.lib() refuse a library that is older than its sources
+        f.write(source_hash())
     return LIB_PATH
 
 

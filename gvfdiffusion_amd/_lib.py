@@ -29,7 +29,8 @@ class GvfRastFrame(ctypes.Structure):
 class GvfRastSettings(ctypes.Structure):
     _fields_ = [("image_height", ctypes.c_int32), ("image_width", ctypes.c_int32), ("sh_degree", ctypes.c_int32),
                 ("mode", ctypes.c_int32), ("kernel_size", ctypes.c_float), ("scale_modifier", ctypes.c_float),
-                ("bg", ctypes.c_float * 3), ("prefiltered", ctypes.c_int32), ("debug", ctypes.c_int32)]
+                ("bg", ctypes.c_float * 3), ("prefiltered", ctypes.c_int32), ("debug", ctypes.c_int32),
+                ("upstream_binning", ctypes.c_int32)]
 
 
 class GvfGaussianActivation(ctypes.Structure):
@@ -80,6 +81,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise GvfError(f"{LIB_PATH} is missing: build it with `python -m gvfdiffusion_amd._build` "
                            "(hipcc, gfx950). There is no CPU fallback.")
+        # a library older than its sources silently runs yesterday's kernels: refuse (content hash written by _build)
+        stamp = LIB_PATH + ".srchash"
+        if os.path.exists(stamp) and os.environ.get("GVF_ALLOW_STALE_LIB") != "1":
+            from . import _build
+            if open(stamp).read().strip() != _build.source_hash():
+                raise GvfError(f"{LIB_PATH} was built from different sources than the ones in csrc/ and include/: "
+                               "rebuild with `python -m gvfdiffusion_amd._build`")
         # torch must be imported before the dlopen: its wheel bundles libamdhip64.so (SONAME
         # libamdhip64.so.7) and libgvf_hip.so must bind to THAT runtime instance to share torch's
         # device context and streams.  Loaded the other way round, the process ends up with two HIP

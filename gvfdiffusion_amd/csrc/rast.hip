@@ -8,19 +8,26 @@
 // -ffp-contract=off) is the floating-point contract stated in oracle/rast_oracle.c, so that all
 // discrete decisions (cull, radius, tile rect, sort order) match the oracle bit for bit.
 //
-// Launch structure (F frames per call, everything stream-ordered, no host sync):
-//   preprocess   grid (ceil(P/256), F)   geometry, tiles_touched, per-(frame,tile) instance counts (atomics)
-//   tile_scan    1 workgroup             exclusive scan of the F*tiles counts = segment bases = tile ranges
-//   scatter      grid (ceil(P/256), F)   (depth_bits << 32 | id) keys into the tile segments (atomic cursors)
-//   tile_sort    grid F*tiles            per-tile bitonic sort in LDS (3 size classes), writes ordered ids
+// Launch structure (F frames per call, everything stream-ordered, no host sync; D is read from device memory):
+//   preprocess   grid (ceil(P/256), F)   activations (+deltas), EWA covariance, 2D filter, radius, tile rect, SH -> RGB;
+//                                        writes one 64-byte splat record + tiles_touched; per-block sums
+//   scan_sums    1 workgroup             exclusive scan of the block sums -> instance offsets, per-frame D
+//   duplicate    grid (ceil(P/256), F)   (frame*tiles + tile) << 32 | depth_bits keys + Gaussian ids
+//   radix (x2)   <=1024 workgroups       stable 8-bit LSD passes over the (frame, tile) key bits only (sort.hip)
+//   ranges       per instance            [start, end) of every (frame, tile) segment
+//   classify + tile_sort                 per-tile bitonic sort of (depth_bits << 32 | id): registers+shuffles for
+//                                        segments <= 2048, LDS <= 16384, in-place global beyond; writes ordered ids
 //   blend        grid (tiles, F)         16x16 px per workgroup, 4 waves = the four 8x8 quadrants
-// Upstream sorts all (tile, depth) keys with a global radix sort (6+ passes over 12 B per instance); binning by
-// tile first and sorting each ~460-key segment on chip needs one 8-byte scatter and one read per instance.
+// Upstream sorts all 64-bit (tile, depth) keys with one global radix sort (>= 6 passes over 12 B per instance);
+// here only the ~16 tile bits go through global passes and the depth order is produced on chip.
 //
-// HBM layout (caller-owned workspace, carved below): per (frame, Gaussian) three records
-//   geomA float4 {x, y, conic_a, conic_b}, geomB float4 {conic_c, opacity, r, g}, geomC float2 {b, depth}
-// (40 B fetched per (splat,tile) instance by the blend), tiles_touched u32; per instance one u64 key in its
-// tile's segment and, after the sort, one u32 id.
+// HBM layout (caller-owned workspace, carved below): per (frame, Gaussian) ONE 64-byte, 64-byte-aligned record
+//   float4 {x, y, conic_a, conic_b} | float4 {conic_c, opacity, r, g} | float4 {b, depth, hx, hy} | 16 B unused
+// so the blend's gather of a (splat, tile) instance touches exactly one cache line (three 40-B-total arrays cost
+// three lines per instance: 5.7 GB of fabric reads per 24-frame step measured with FETCH_SIZE, vs 1.1 GB
+// algorithmic); hx, hy = half extents of the region where alpha can reach 1/255 (quadrant culling), computed
+// once per visible Gaussian instead of once per instance.  Plus tiles_touched u32 / radii i32; per instance one
+// u64 key + u32 id (double buffered for the radix passes) and one u32 ordered id.
 #include "gvf_common.h"
 #include "gvf_sort.h"
 #include "../../include/gvf_rast.h"
@@ -48,6 +55,7 @@ struct PreParams {
     int fused;
     GvfGaussianActivation act;
     int n_delta;
+    int upstream_binning;   // 1: bin the whole 3-sigma tile rect as upstream does
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -202,12 +210,59 @@ __device__ __forceinline__ TileRect get_rect(float px, float py, float radius, i
 // Inputs are either activated tensors (fused == 0: a0=means3D, a1=scales, a2=rotations, a3=opacities,
 // sh=shs/colors) or raw GaussianModel parameters (fused != 0: a0=_xyz, a1=_scaling, a2=_rotation,
 // a3=_opacity, sh=_features_dc, delta[n_delta][P][14]).
+// Half extents (hx, hy) of the axis-aligned box around the splat centre outside which
+// alpha = opacity * exp(power) < 1/255 for certain ( ca dx^2 + 2 cb dx dy + cc dy^2 <= 2 ln(255 opacity) ),
+// inflated so that float noise can only keep extra splats, never drop one.  hx < 0: never visible;
+// +inf: degenerate conic, keep everywhere.  Built from correctly rounded + * / sqrt and bit operations only
+// (ln_upper: exponent + tangent envelope of log2, no libm), so oracle/rast_oracle.c reproduces them bit for
+// bit and the culled instance counts can be compared exactly.  Used for (1) instance culling: a (Gaussian,
+// tile) pair whose tile the box does not reach is never binned -- the blend would skip it at every pixel --
+// and (2) the blend's per-quadrant culling.
+__device__ __forceinline__ float ln_upper(float z) {
+    const uint32_t b = __float_as_uint(z);
+    const int e = (int)(b >> 23) - 127;
+    const float m = __uint_as_float((b & 0x7fffffu) | 0x3f800000u);
+    float L = (m - 1.0f) * 1.4426951f;
+    L = fminf(L, 0.32192809f + (m - 1.25f) * 1.1541561f);
+    L = fminf(L, 0.5849625f + (m - 1.5f) * 0.96179669f);
+    L = fminf(L, 0.80735492f + (m - 1.75f) * 0.8243972f);
+    L = fminf(L, 1.0f + (m - 2.0f) * 0.72134752f);
+    return ((float)e + (L + 1e-5f)) * 0.69314724f;
+}
+
+__device__ __forceinline__ float2 cull_extent(float ca, float cb, float cc, float op) {
+    if (op < 1.0f / 255.0f) return make_float2(-1.0f, -1.0f);
+    const float det = ca * cc - cb * cb;
+    const float inf = __builtin_inff();
+    if (!(det > 0.0f) || !(ca > 0.0f) || !(cc > 0.0f)) return make_float2(inf, inf);
+    const float tau = 2.0f * ln_upper(255.0f * op) * 1.001f + 1e-3f;
+    const float inv = 1.0f / det;
+    return make_float2(sqrtf(tau * cc * inv) * 1.001f + 0.01f, sqrtf(tau * ca * inv) * 1.001f + 0.01f);
+}
+
+// tiles t owning a pixel p in [16t, 16t+15] with |p - c| <= h, clipped to [lo, hi)
+__device__ __forceinline__ void tight_range(float c, float h, int lo, int hi, int n, int& t0, int& t1) {
+    if (h < 0.0f) { t0 = lo; t1 = lo; return; }
+    const float a = fminf(fmaxf(ceilf((c - h - (float)(TILE - 1)) / (float)TILE), 0.0f), (float)n);
+    const float b = fminf(fmaxf(floorf((c + h) / (float)TILE) + 1.0f, 0.0f), (float)n);
+    t0 = max((int)a, lo);
+    t1 = min((int)b, hi);
+    if (t1 < t0) t1 = t0;
+}
+
+__device__ __forceinline__ TileRect tight_rect(TileRect r, float px, float py, float hx, float hy, int gx, int gy) {
+    TileRect t;
+    tight_range(px, hx, r.x0, r.x1, gx, t.x0, t.x1);
+    tight_range(py, hy, r.y0, r.y1, gy, t.y0, t.y1);
+    return t;
+}
+
 __global__ __launch_bounds__(PRE_THREADS) void preprocess_kernel(
     PreParams pp, const GvfRastFrame* __restrict__ frames, const float* __restrict__ a0,
     const float* __restrict__ a1, const float* __restrict__ a2, const float* __restrict__ a3,
     const float* __restrict__ sh, const float* __restrict__ colors_precomp,
-    const float* __restrict__ cov3D_precomp, const float* __restrict__ delta, float4* __restrict__ geomA,
-    float4* __restrict__ geomB, float2* __restrict__ geomC, uint32_t* __restrict__ tiles_touched,
+    const float* __restrict__ cov3D_precomp, const float* __restrict__ delta, float4* __restrict__ splats,
+    uint32_t* __restrict__ tiles_touched,
     int32_t* __restrict__ radii, uint32_t* __restrict__ block_sums) {
     extern __shared__ __attribute__((aligned(16))) float sh_lds[];  // [PRE_THREADS][M*3] + 4 wave sums
     const int t = threadIdx.x;
@@ -233,8 +288,7 @@ __global__ __launch_bounds__(PRE_THREADS) void preprocess_kernel(
 
     uint32_t touched = 0;
     int radius_out = 0;
-    float4 gA = make_float4(0.f, 0.f, 0.f, 0.f), gB = gA;
-    float2 gC = make_float2(0.f, 0.f);
+    float4 gA = make_float4(0.f, 0.f, 0.f, 0.f), gB = gA, gC = gA;
 
     if (i < P) {
         float p[3], s[3], q[4], op, dadd[3] = {0.f, 0.f, 0.f};
@@ -337,17 +391,24 @@ __global__ __launch_bounds__(PRE_THREADS) void preprocess_kernel(
                     } else {
                         sh_to_rgb(pp.deg, sh_lds + t * sh_stride, dadd, p, fr->campos, rgb);
                     }
-                    touched = cnt;
                     radius_out = (int)my_radius;
-
+                    const float2 ext = cull_extent(ca, cb, cc, op * coef);
+                    if (!pp.upstream_binning) {
+                        r = tight_rect(r, px, py, ext.x, ext.y, pp.gx, pp.gy);
+                        cnt = (uint32_t)((r.x1 - r.x0) * (r.y1 - r.y0));
+                    }
+                    touched = cnt;
                     gA = make_float4(px, py, ca, cb);
                     gB = make_float4(cc, op * coef, rgb[0], rgb[1]);
-                    gC = make_float2(rgb[2], pv[2]);
+                    gC = make_float4(rgb[2], pv[2], ext.x, ext.y);
                 }
             }
         }
         const size_t o = (size_t)f * P + i;
-        geomA[o] = gA; geomB[o] = gB; geomC[o] = gC;
+        if (touched != 0) {   // records of culled Gaussians are never read (no instance refers to them)
+            float4* rec = splats + 4 * o;
+            rec[0] = gA; rec[1] = gB; rec[2] = gC;
+        }
         tiles_touched[o] = touched;
         if (radii != nullptr) radii[o] = radius_out;
     }
@@ -404,10 +465,10 @@ __global__ __launch_bounds__(1024) void scan_sums_kernel(uint32_t* __restrict__ 
 // R3: duplicate with keys
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(PRE_THREADS) void duplicate_kernel(
-    int P, int gx, int gy, const float4* __restrict__ geomA, const float2* __restrict__ geomC,
+    int P, int gx, int gy, const float4* __restrict__ splats,
     const uint32_t* __restrict__ tiles_touched, const int32_t* __restrict__ radii_ws,
     const uint32_t* __restrict__ block_base, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
-    uint32_t max_rendered) {
+    uint32_t max_rendered, int upstream_binning) {
     __shared__ uint32_t wsum[PRE_THREADS / GVF_WAVE];
     const int t = threadIdx.x, f = blockIdx.y;
     const int i = blockIdx.x * PRE_THREADS + t;
@@ -422,9 +483,11 @@ __global__ __launch_bounds__(PRE_THREADS) void duplicate_kernel(
     uint32_t off = block_base[(size_t)f * gridDim.x + blockIdx.x] + wbase + incl - touched;
     if (touched == 0) return;
     if ((uint64_t)off + touched > (uint64_t)max_rendered) return;  // overflow: caller checks num_rendered
-    float4 a = geomA[o];
-    float depth = geomC[o].y;
+    const float4 a = splats[4 * o];
+    const float4 c = splats[4 * o + 2];
+    const float depth = c.y;
     TileRect r = get_rect(a.x, a.y, (float)radii_ws[o], gx, gy);
+    if (!upstream_binning) r = tight_rect(r, a.x, a.y, c.z, c.w, gx, gy);
     const uint64_t tile0 = (uint64_t)f * (uint32_t)(gx * gy);
     const uint32_t dbits = __float_as_uint(depth);
     for (int y = r.y0; y < r.y1; ++y)
@@ -630,23 +693,15 @@ __global__ void tile_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __r
 //     order) and iterates over that list only.  A typical splat (3-sigma radius ~9 px) reaches ~40 % of the
 //     quadrants of the tiles it was binned to, so ~60 % of upstream's (pixel, splat) evaluations disappear.
 // Early termination is per wave (all 64 pixels saturated) and per workgroup (stop staging).
-__device__ __forceinline__ unsigned quadrant_mask(const float4 a, const float4 b, float tile_x0, float tile_y0,
+__device__ __forceinline__ unsigned quadrant_mask(float x, float y, float hx, float hy, float tile_x0, float tile_y0,
                                                   bool no_cull) {
-    const float op = b.y;
-    if (op < 1.0f / 255.0f) return 0u;                   // alpha <= opacity < 1/255 at every pixel
+    if (hx < 0.0f) return 0u;                            // opacity < 1/255: alpha < 1/255 at every pixel
     if (no_cull) return 0xFu;
-    const float ca = a.z, cb = a.w, cc = b.x;
-    const float det = ca * cc - cb * cb;
-    if (!(det > 0.0f) || !(ca > 0.0f) || !(cc > 0.0f)) return 0xFu;   // degenerate conic: keep everywhere
-    const float tau = 2.0f * logf(255.0f * op) * 1.001f + 1e-3f;
-    const float inv = 1.0f / det;
-    const float hx = sqrtf(tau * cc * inv) * 1.001f + 0.01f;
-    const float hy = sqrtf(tau * ca * inv) * 1.001f + 0.01f;
     unsigned m = 0u;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const float x0 = tile_x0 + (float)((q & 1) * 8), y0 = tile_y0 + (float)((q >> 1) * 8);
-        const bool hit = (a.x + hx >= x0) && (a.x - hx <= x0 + 7.0f) && (a.y + hy >= y0) && (a.y - hy <= y0 + 7.0f);
+        const bool hit = (x + hx >= x0) && (x - hx <= x0 + 7.0f) && (y + hy >= y0) && (y - hy <= y0 + 7.0f);
         m |= hit ? (1u << q) : 0u;
     }
     return m;
@@ -654,8 +709,8 @@ __device__ __forceinline__ unsigned quadrant_mask(const float4 a, const float4 b
 
 __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
     int P, int H, int W, int gx, int gy, float bg0, float bg1, float bg2, const uint2* __restrict__ ranges,
-    const uint32_t* __restrict__ point_list, const float4* __restrict__ geomA, const float4* __restrict__ geomB,
-    const float2* __restrict__ geomC, const float* __restrict__ subpixel_offset, float* __restrict__ out_color,
+    const uint32_t* __restrict__ point_list, const float4* __restrict__ splats,
+    const float* __restrict__ subpixel_offset, float* __restrict__ out_color,
     float* __restrict__ out_alpha, float* __restrict__ out_depth) {
     __shared__ float4 sA[BLEND_THREADS];
     __shared__ float4 sB[BLEND_THREADS];
@@ -686,12 +741,13 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
         if (__syncthreads_count(done) == BLEND_THREADS) break;
         if (t < todo) {
             uint32_t id = point_list[rng.x + (uint32_t)r * BLEND_THREADS + t];
-            const float4 a = geomA[gbase + id];
-            const float4 b = geomB[gbase + id];
+            const float4* rec = splats + 4 * (gbase + id);
+            const float4 a = rec[0];
+            const float4 c = rec[2];
             sA[t] = a;
-            sB[t] = b;
-            sC[t] = geomC[gbase + id];
-            sMask[t] = (unsigned char)quadrant_mask(a, b, (float)(tx * TILE), (float)(ty * TILE), subpixel_offset != nullptr);
+            sB[t] = rec[1];
+            sC[t] = make_float2(c.x, c.y);
+            sMask[t] = (unsigned char)quadrant_mask(a.x, a.y, c.z, c.w, (float)(tx * TILE), (float)(ty * TILE), subpixel_offset != nullptr);
         }
         __syncthreads();
         const int cnt = min(BLEND_THREADS, todo);
@@ -784,7 +840,7 @@ inline void prof_mark(hipStream_t s, int slot, int k) {
 
 struct Workspace {
     GvfRastFrame* frames;
-    float4* geomA; float4* geomB; float2* geomC;
+    float4* splats;   // [F*P][4]: 64-byte records
     uint32_t* tiles_touched; int32_t* radii;
     uint32_t* block_sums; uint32_t* frame_base; uint32_t* total;
     uint64_t* keys; uint64_t* keys_alt; uint32_t* vals; uint32_t* vals_alt; uint32_t* ids;
@@ -808,9 +864,7 @@ Workspace carve(void* ws, size_t bytes, int P, int F, int H, int W, int64_t max_
     const size_t FP = (size_t)F * (size_t)(P > 0 ? P : 1);
     const size_t D = (size_t)(max_rendered > 0 ? max_rendered : 1);
     w.frames = c.take<GvfRastFrame>(F);
-    w.geomA = c.take<float4>(FP);
-    w.geomB = c.take<float4>(FP);
-    w.geomC = c.take<float2>(FP);
+    w.splats = c.take<float4>(4 * FP);
     w.tiles_touched = c.take<uint32_t>(FP);
     w.radii = c.take<int32_t>(FP);
     w.block_sums = c.take<uint32_t>((size_t)F * (nb > 0 ? nb : 1));
@@ -873,11 +927,13 @@ int run_pipeline(const GvfRastSettings& st, const GvfRastFrame* frames_host, int
         pp.P = P; pp.M = colors_precomp ? 0 : M; pp.deg = st.sh_degree; pp.H = H; pp.W = W; pp.mode = st.mode;
         pp.gx = gx; pp.gy = gy; pp.kernel_size = st.kernel_size; pp.scale_modifier = st.scale_modifier;
         pp.fused = fused ? 1 : 0; pp.n_delta = n_delta;
+        // per-pixel sub-pixel offsets move the sample positions: no box culling then (as in the blend)
+        pp.upstream_binning = (st.upstream_binning != 0 || subpixel_offset != nullptr) ? 1 : 0;
         if (fused) pp.act = *act; else pp.act = GvfGaussianActivation{};
         const size_t sh_lds_bytes = gvf_align_up((size_t)PRE_THREADS * pp.M * 3 * sizeof(float), 16) + 16;
         hipLaunchKernelGGL(preprocess_kernel, dim3(nb, F), dim3(PRE_THREADS), sh_lds_bytes, stream, pp, w.frames, a0,
-                           a1, a2, a3, colors_precomp ? nullptr : sh, colors_precomp, cov3D_precomp, delta, w.geomA,
-                           w.geomB, w.geomC, w.tiles_touched, w.radii, w.block_sums);
+                           a1, a2, a3, colors_precomp ? nullptr : sh, colors_precomp, cov3D_precomp, delta, w.splats,
+                           w.tiles_touched, w.radii, w.block_sums);
         GVF_CHECK_LAUNCH();
         prof_mark(stream, slot, 1);
         hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, stream, w.block_sums, nb, F, w.frame_base,
@@ -885,8 +941,9 @@ int run_pipeline(const GvfRastSettings& st, const GvfRastFrame* frames_host, int
         GVF_CHECK_LAUNCH();
         prof_mark(stream, slot, 2);
         if (max_rendered > 0) {
-            hipLaunchKernelGGL(duplicate_kernel, dim3(nb, F), dim3(PRE_THREADS), 0, stream, P, gx, gy, w.geomA, w.geomC,
-                               w.tiles_touched, w.radii, w.block_sums, w.keys, w.vals, (uint32_t)max_rendered);
+            hipLaunchKernelGGL(duplicate_kernel, dim3(nb, F), dim3(PRE_THREADS), 0, stream, P, gx, gy, w.splats,
+                               w.tiles_touched, w.radii, w.block_sums, w.keys, w.vals, (uint32_t)max_rendered,
+                               pp.upstream_binning);
             GVF_CHECK_LAUNCH();
         }
         if (out_radii != nullptr) {
@@ -930,7 +987,7 @@ int run_pipeline(const GvfRastSettings& st, const GvfRastFrame* frames_host, int
     uint32_t* vals_sorted = w.ids;
     prof_mark(stream, slot, 5);
     hipLaunchKernelGGL(blend_kernel, dim3(ntiles, F), dim3(BLEND_THREADS), 0, stream, P, H, W, gx, gy, st.bg[0],
-                       st.bg[1], st.bg[2], w.ranges, vals_sorted, w.geomA, w.geomB, w.geomC, subpixel_offset,
+                       st.bg[1], st.bg[2], w.ranges, vals_sorted, w.splats, subpixel_offset,
                        out_color, out_alpha, out_depth);
     GVF_CHECK_LAUNCH();
     prof_mark(stream, slot, 6);

@@ -42,13 +42,15 @@ def _f32c(t: Optional[torch.Tensor], name: str) -> Optional[torch.Tensor]:
     return t.contiguous()
 
 
-def make_settings(H, W, sh_degree, mode, kernel_size, scale_modifier, bg, prefiltered=False, debug=False):
+def make_settings(H, W, sh_degree, mode, kernel_size, scale_modifier, bg, prefiltered=False, debug=False,
+                  upstream_binning=False):
     st = _lib.GvfRastSettings()
     st.image_height, st.image_width, st.sh_degree, st.mode = int(H), int(W), int(sh_degree), int(mode)
     st.kernel_size, st.scale_modifier = float(kernel_size), float(scale_modifier)
     b = [float(x) for x in (bg.detach().cpu().tolist() if torch.is_tensor(bg) else bg)]
     st.bg[0], st.bg[1], st.bg[2] = b
     st.prefiltered, st.debug = int(bool(prefiltered)), int(bool(debug))
+    st.upstream_binning = int(bool(upstream_binning))   # True: num_rendered counts upstream's 3-sigma tile rects
     return st
 
 

@@ -64,6 +64,10 @@ typedef struct GvfRastSettings {
     float   bg[3];
     int32_t prefiltered;      /* accepted for API parity; unused (as upstream when False) */
     int32_t debug;            /* accepted for API parity */
+    int32_t upstream_binning; /* 0 (default): a (Gaussian, tile) pair is binned only if alpha = opacity * exp(power) can
+                                 reach 1/255 somewhere in the tile (conservative box test) -- the blend skips every other
+                                 pair at each pixel, so images are identical and num_rendered is smaller;
+                                 1: bin the whole 3-sigma tile rect, num_rendered equals upstream's count */
 } GvfRastSettings;
 
 /* Activation constants of GaussianModel (representations/gaussian/gaussian_model.py:24-41,84-114)

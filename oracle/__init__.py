@@ -54,23 +54,28 @@ def _common(means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_pr
 
 def rast_preprocess(means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, *, H, W,
                     tanfovx, tanfovy, kernel_size, scale_modifier, mode, viewmatrix, projmatrix, campos,
-                    sh_degree):
+                    sh_degree, tight=False):
+    lib().gvfo_set_tight_binning(int(bool(tight)))
     P, M, m3, sh, cp, op, sc, ro, c3 = _common(means3D, shs, colors_precomp, opacities, scales, rotations,
                                                cov3D_precomp)
-    geom = np.zeros((P, 16), np.float32)
+    geom = np.zeros((P, 24), np.float32)
     v, pj, cam = _f32(np.reshape(viewmatrix, (-1,))), _f32(np.reshape(projmatrix, (-1,))), _f32(campos)
     rc = lib().gvfo_preprocess(P, M, int(sh_degree), _ptr(m3), _ptr(sh), _ptr(cp), _ptr(op), _ptr(sc), _ptr(ro),
                                _ptr(c3), int(H), int(W), ctypes.c_float(tanfovx), ctypes.c_float(tanfovy),
                                ctypes.c_float(kernel_size), ctypes.c_float(scale_modifier), int(mode), _ptr(v),
                                _ptr(pj), _ptr(cam), _ptr(geom))
+    lib().gvfo_set_tight_binning(0)
     assert rc == 0
     return geom
 
 
 def rast_render(means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, *, H, W, tanfovx,
                 tanfovy, kernel_size, scale_modifier, mode, viewmatrix, projmatrix, campos, sh_degree, bg,
-                subpixel_offset=None, nthreads=0, brute=False):
-    """Returns dict(color[3,H,W], alpha[H,W], depth[H,W], radii[P], num_rendered, flags[H,W])."""
+                subpixel_offset=None, nthreads=0, brute=False, tight=False):
+    """Returns dict(color[3,H,W], alpha[H,W], depth[H,W], radii[P], num_rendered, flags[H,W]).
+    tight=True: drop (Gaussian, tile) instances that cannot reach alpha 1/255 anywhere in the tile (the HIP
+    path's default binning; same image, smaller num_rendered) instead of upstream's 3-sigma rect."""
+    lib().gvfo_set_tight_binning(int(bool(tight)))
     P, M, m3, sh, cp, op, sc, ro, c3 = _common(means3D, shs, colors_precomp, opacities, scales, rotations,
                                                cov3D_precomp)
     v, pj, cam = _f32(np.reshape(viewmatrix, (-1,))), _f32(np.reshape(projmatrix, (-1,))), _f32(campos)
@@ -94,6 +99,7 @@ def rast_render(means3D, shs, colors_precomp, opacities, scales, rotations, cov3
                                f(scale_modifier), int(mode), _ptr(v), _ptr(pj), _ptr(cam), _ptr(bg), _ptr(color),
                                _ptr(alpha), _ptr(depth), _ptr(radii, ctypes.c_int32), _ptr(nr, ctypes.c_uint32),
                                _ptr(flags, ctypes.c_uint8), int(nthreads))
+    lib().gvfo_set_tight_binning(0)
     assert rc == 0, rc
     return dict(color=color, alpha=alpha, depth=depth, radii=radii, num_rendered=int(nr[0]), flags=flags)
 

@@ -56,8 +56,54 @@ typedef struct {
     float op;            /* opacity (x mip coef) */
     float r, g, b;
     int radius;
-    int x0, y0, x1, y1;  /* tile rect [x0,x1) x [y0,y1) */
+    int x0, y0, x1, y1;  /* tile rect [x0,x1) x [y0,y1) of the 3-sigma radius (what upstream bins) */
+    float hx, hy;        /* half extents of the alpha >= 1/255 box (see cull_extent) */
+    int tx0, ty0, tx1, ty1; /* (x0..y1) intersected with the tiles that box reaches */
 } Geom;
+
+/* ---- instance culling (an optimisation of the HIP path, restated here so that its instance counts can be
+ * checked bit for bit; OFF by default = upstream binning).  A (Gaussian, tile) instance is dropped when
+ * alpha = op * exp(power) < 1/255 at every pixel of the tile -- the blend would skip it at each of them, so the
+ * image is unchanged (tests/test_oracle_rast.py asserts bit-equal images with the toggle on and off).
+ * Everything is built from correctly rounded +,*,/,sqrt,floor,ceil and bit operations (no libm log), so the
+ * device reproduces hx, hy and the tile set exactly. */
+static int g_tight_binning = 0;
+void gvfo_set_tight_binning(int on) { g_tight_binning = on; }
+
+/* ln(z) upper bound for normal z > 0: exponent + min of the tangents of log2 at 1, 1.25, 1.5, 1.75, 2 */
+static float ln_upper(float z) {
+    uint32_t b; memcpy(&b, &z, 4);
+    int e = (int)(b >> 23) - 127;
+    uint32_t mb = (b & 0x7fffffu) | 0x3f800000u;
+    float m; memcpy(&m, &mb, 4);
+    float L = (m - 1.0f) * 1.4426951f;
+    L = fminf(L, 0.32192809f + (m - 1.25f) * 1.1541561f);
+    L = fminf(L, 0.5849625f + (m - 1.5f) * 0.96179669f);
+    L = fminf(L, 0.80735492f + (m - 1.75f) * 0.8243972f);
+    L = fminf(L, 1.0f + (m - 2.0f) * 0.72134752f);
+    return ((float)e + (L + 1e-5f)) * 0.69314724f;
+}
+
+/* hx < 0: opacity < 1/255, never visible; +inf: degenerate conic, keep everywhere */
+static void cull_extent(float ca, float cb, float cc, float op, float* hx, float* hy) {
+    if (op < 1.0f / 255.0f) { *hx = -1.0f; *hy = -1.0f; return; }
+    float det = ca * cc - cb * cb;
+    if (!(det > 0.0f) || !(ca > 0.0f) || !(cc > 0.0f)) { *hx = INFINITY; *hy = INFINITY; return; }
+    float tau = 2.0f * ln_upper(255.0f * op) * 1.001f + 1e-3f;
+    float inv = 1.0f / det;
+    *hx = sqrtf(tau * cc * inv) * 1.001f + 0.01f;
+    *hy = sqrtf(tau * ca * inv) * 1.001f + 0.01f;
+}
+
+/* tiles t with a pixel p in [16t, 16t+15] such that |p - c| <= h, clipped to [lo, hi) */
+static void tight_range(float c, float h, int lo, int hi, int n, int* t0, int* t1) {
+    if (h < 0.0f) { *t0 = lo; *t1 = lo; return; }
+    float a = fminf(fmaxf(ceilf((c - h - (float)(TILE - 1)) / (float)TILE), 0.0f), (float)n);
+    float b = fminf(fmaxf(floorf((c + h) / (float)TILE) + 1.0f, 0.0f), (float)n);
+    int x0 = (int)a > lo ? (int)a : lo, x1 = (int)b < hi ? (int)b : hi;
+    if (x1 < x0) x1 = x0;
+    *t0 = x0; *t1 = x1;
+}
 
 /* p' = M p with M given as the 16 floats of V^T row-major (column-major V): upstream transformPoint4x3 */
 static void xform43(const float* m, const float* p, float* o) {
@@ -228,11 +274,16 @@ static int preprocess_one(int i, int M, int deg, const float* means3D, const flo
     g->op = opacities[i] * coef;
     g->radius = (int)my_radius;
     g->x0 = x0; g->y0 = y0; g->x1 = x1; g->y1 = y1;
+    cull_extent(ca, cb, cc, g->op, &g->hx, &g->hy);
+    tight_range(px, g->hx, x0, x1, gx, &g->tx0, &g->tx1);
+    tight_range(py, g->hy, y0, y1, gy, &g->ty0, &g->ty1);
+    if (g_tight_binning) { g->x0 = g->tx0; g->x1 = g->tx1; g->y0 = g->ty0; g->y1 = g->ty1; }
     return 1;
 }
 
 /* Exported: per-Gaussian geometry, for stage-level parity tests.
- * geom_out[P][16]: depth,x,y,ca,cb,cc,op,r,g,b,radius,x0,y0,x1,y1,visible (all as float). */
+ * geom_out[P][24]: depth,x,y,ca,cb,cc,op,r,g,b,radius,x0,y0,x1,y1,visible, tx0,ty0,tx1,ty1, hx,hy, 0,0 (all as float);
+ * x0..y1 follow the binning toggle, tx0..ty1 are always the culled rect. */
 int gvfo_preprocess(int P, int M, int deg, const float* means3D, const float* shs,
                     const float* colors_precomp, const float* opacities, const float* scales,
                     const float* rotations, const float* cov3D_precomp, int H, int W, float tanfovx,
@@ -243,11 +294,13 @@ int gvfo_preprocess(int P, int M, int deg, const float* means3D, const float* sh
         int vis = preprocess_one(i, M, deg, means3D, shs, colors_precomp, opacities, scales, rotations,
                                  cov3D_precomp, H, W, tanfovx, tanfovy, kernel_size, scale_modifier, mode,
                                  view, proj, campos, &g);
-        float* o = geom_out + 16 * (size_t)i;
+        float* o = geom_out + 24 * (size_t)i;
         o[0] = g.depth; o[1] = g.x; o[2] = g.y; o[3] = g.ca; o[4] = g.cb; o[5] = g.cc; o[6] = g.op;
         o[7] = g.r; o[8] = g.g; o[9] = g.b; o[10] = (float)g.radius;
         o[11] = (float)g.x0; o[12] = (float)g.y0; o[13] = (float)g.x1; o[14] = (float)g.y1;
         o[15] = (float)vis;
+        o[16] = (float)g.tx0; o[17] = (float)g.ty0; o[18] = (float)g.tx1; o[19] = (float)g.ty1;
+        o[20] = g.hx; o[21] = g.hy; o[22] = 0.0f; o[23] = 0.0f;
     }
     return 0;
 }

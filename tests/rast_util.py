@@ -20,7 +20,7 @@ def camera_block(azi=0.0, elev=0.0, radius=2.0, fov=synthetic.FOV_X_DEG, near=sy
 
 
 def oracle_render(oracle, attrs, cam, H, W, sh_degree, mode=0, kernel_size=synthetic.KERNEL_2D, bg=synthetic.BG,
-                  scale_modifier=1.0, colors_precomp=None, cov3D_precomp=None, subpixel_offset=None, brute=False):
+                  scale_modifier=1.0, colors_precomp=None, cov3D_precomp=None, subpixel_offset=None, brute=False, tight=False):
     n = lambda t: None if t is None else t.detach().cpu().numpy()
     use_cov = cov3D_precomp is not None
     return oracle.rast_render(
@@ -29,7 +29,7 @@ def oracle_render(oracle, attrs, cam, H, W, sh_degree, mode=0, kernel_size=synth
         n(cov3D_precomp), H=H, W=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], kernel_size=kernel_size,
         scale_modifier=scale_modifier, mode=mode, viewmatrix=n(cam["viewmatrix"]), projmatrix=n(cam["projmatrix"]),
         campos=n(cam["campos"]), sh_degree=sh_degree, bg=np.asarray(bg, np.float32),
-        subpixel_offset=n(subpixel_offset), brute=brute)
+        subpixel_offset=n(subpixel_offset), brute=brute, tight=tight)
 
 
 # Tolerance of the rasteriser parity tests (BASELINE.json north_star: "rendered RGBA frames must

@@ -180,3 +180,27 @@ def test_golden_activations(oracle_lib):
     for k in ("means3D", "scales", "rotations", "shs"):
         assert np.abs(out[k] - g["act_out_" + k]).max() < 2e-6, k
     assert np.abs(out["opacities"] - g["act_out_opacities"].reshape(-1)).max() < 2e-6
+
+
+def test_tight_binning_is_image_neutral(oracle_lib):
+    """The HIP path drops (Gaussian, tile) instances that cannot reach alpha 1/255 anywhere in the tile.  The
+    oracle restates that rule behind a toggle: images must be bit-identical with it on and off (both modes,
+    every output), only num_rendered shrinks; and the brute-force compositor agrees with the culled rects."""
+    from gvfdiffusion_amd import synthetic
+    from rast_util import camera_block, oracle_render
+    for seed, (lo, hi) in enumerate([(0.002, 0.01), (0.01, 0.08)]):
+        attrs = synthetic.random_gaussians(20_000, sh_degree=1, seed=40 + seed, scale_lo=lo, scale_hi=hi)
+        attrs["opacities"][::7] *= 0.01            # plenty of nearly transparent splats (some below 1/255)
+        cam = camera_block(azi=20.0 + 50 * seed, elev=10.0)
+        for mode in (0, 1):
+            a = oracle_render(oracle_lib, attrs, cam, 160, 208, 1, mode=mode)
+            b = oracle_render(oracle_lib, attrs, cam, 160, 208, 1, mode=mode, tight=True)
+            for k in ("color", "alpha", "depth", "radii"):
+                assert np.array_equal(a[k], b[k]), (k, mode)
+            assert 0 < b["num_rendered"] < a["num_rendered"]
+            print(f"scale {lo}-{hi} mode {mode}: instances {a['num_rendered']} -> {b['num_rendered']}")
+    small = synthetic.random_gaussians(300, sh_degree=0, seed=3, scale_lo=0.01, scale_hi=0.05)
+    cam = camera_block()
+    t = oracle_render(oracle_lib, small, cam, 48, 64, 0, tight=True)
+    br = oracle_render(oracle_lib, small, cam, 48, 64, 0, tight=True, brute=True)
+    assert np.array_equal(t["color"], br["color"])
