@@ -27,7 +27,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
-STAGES = ["preprocess", "scan", "duplicate", "sort", "ranges", "blend"]
+STAGES = ["order", "preprocess", "scan", "bin", "sort", "tile_sort", "blend"]
 
 
 def parse():
@@ -62,7 +62,9 @@ class RasterWorkload:
         self.frames = (_lib.GvfRastFrame * F)(*[
             R.make_frame(c["viewmatrix"], c["projmatrix"], c["campos"], c["tanfovx"], c["tanfovy"], f)
             for f, c in enumerate(self.cams)])
-        self.st = R.make_settings(S, S, deg, _lib.RAST_MODE_MIP, synthetic.KERNEL_2D, 1.0, synthetic.BG)
+        # GVF_BIN_ALGO=1 benchmarks the radix binning instead of the default bucket binning (include/gvf_rast.h)
+        self.st = R.make_settings(S, S, deg, _lib.RAST_MODE_MIP, synthetic.KERNEL_2D, 1.0, synthetic.BG,
+                                  bin_algo=int(os.environ.get("GVF_BIN_ALGO", "0")))
         self.act = self.gm.activation_struct()
         g = self.gm
         self.raw = [t.contiguous().float() for t in (g._xyz, g.get_features, g._scaling, g._rotation, g._opacity.reshape(-1))]

@@ -263,7 +263,7 @@ __global__ __launch_bounds__(PRE_THREADS) void preprocess_kernel(
     const float* __restrict__ sh, const float* __restrict__ colors_precomp,
     const float* __restrict__ cov3D_precomp, const float* __restrict__ delta, float4* __restrict__ splats,
     uint32_t* __restrict__ tiles_touched,
-    int32_t* __restrict__ radii, uint32_t* __restrict__ block_sums) {
+    int32_t* __restrict__ radii, uint32_t* __restrict__ block_sums, uint4* __restrict__ binrec) {
     extern __shared__ __attribute__((aligned(16))) float sh_lds[];  // [PRE_THREADS][M*3] + 4 wave sums
     const int t = threadIdx.x;
     const int f = blockIdx.y;
@@ -289,6 +289,7 @@ __global__ __launch_bounds__(PRE_THREADS) void preprocess_kernel(
     uint32_t touched = 0;
     int radius_out = 0;
     float4 gA = make_float4(0.f, 0.f, 0.f, 0.f), gB = gA, gC = gA;
+    TileRect rect = {0, 0, 0, 0};
 
     if (i < P) {
         float p[3], s[3], q[4], op, dadd[3] = {0.f, 0.f, 0.f};
@@ -398,6 +399,7 @@ __global__ __launch_bounds__(PRE_THREADS) void preprocess_kernel(
                         cnt = (uint32_t)((r.x1 - r.x0) * (r.y1 - r.y0));
                     }
                     touched = cnt;
+                    rect = r;
                     gA = make_float4(px, py, ca, cb);
                     gB = make_float4(cc, op * coef, rgb[0], rgb[1]);
                     gC = make_float4(rgb[2], pv[2], ext.x, ext.y);
@@ -411,6 +413,10 @@ __global__ __launch_bounds__(PRE_THREADS) void preprocess_kernel(
         }
         tiles_touched[o] = touched;
         if (radii != nullptr) radii[o] = radius_out;
+        // bucket binning: the final tile rect and the depth, 16 B that the count / scatter passes gather by id
+        if (binrec != nullptr)
+            binrec[o] = make_uint4((uint32_t)rect.x0 | ((uint32_t)rect.y0 << 16), (uint32_t)rect.x1 | ((uint32_t)rect.y1 << 16),
+                                   __float_as_uint(gC.y), 0u);
     }
 
     // block sum of tiles_touched (feeds the instance-offset scan, R2)
@@ -500,6 +506,246 @@ __global__ __launch_bounds__(PRE_THREADS) void duplicate_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// R2-R5, bucket form: per-tile counts (preprocess) -> exclusive scan = tile ranges -> scatter into the tile segments.
+// No global sort: the order inside a segment is whatever the atomics produced, the per-tile sort below keys on
+// (depth, id) and makes it deterministic.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void tile_scan_kernel(const uint32_t* __restrict__ tile_count, int ntiles, int F,
+                                                         uint2* __restrict__ ranges, uint32_t* __restrict__ cursor,
+                                                         uint32_t* __restrict__ frame_base /*[F+1]*/,
+                                                         uint32_t* __restrict__ num_rendered /*[F]*/,
+                                                         uint32_t* __restrict__ total_out, uint32_t max_rendered) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry_s;
+    const int t = threadIdx.x;
+    const unsigned lane = t & 63, w = t >> 6;
+    const int n = ntiles * F;
+    if (t == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 4096) {
+        const int j0 = base + 4 * t;
+        uint32_t c[4], s = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { c[k] = j0 + k < n ? tile_count[j0 + k] : 0u; s += c[k]; }
+        const uint32_t incl = gvf_wave_incl_scan(s, lane);
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        uint32_t wbase = 0, tot = 0;
+        for (unsigned k = 0; k < 16; ++k) { if (k < w) wbase += wsum[k]; tot += wsum[k]; }
+        uint32_t run = carry_s + wbase + incl - s;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = j0 + k;
+            if (j < n) {
+                ranges[j] = make_uint2(run, run + c[k]);
+                cursor[j] = run;
+                if (j % ntiles == 0) frame_base[j / ntiles] = run;
+            }
+            run += c[k];
+        }
+        __syncthreads();
+        if (t == 0) carry_s += tot;
+        __syncthreads();
+    }
+    const uint32_t total = carry_s;
+    const bool overflow = total > max_rendered;
+    if (t == 0) { frame_base[F] = total; *total_out = overflow ? 0u : total; }
+    __syncthreads();
+    for (int f = t; f < F; f += 1024) num_rendered[f] = frame_base[f + 1] - frame_base[f];
+    // Overflow (D > workspace capacity): render nothing, but the true counts above let the caller retry.
+    if (overflow)
+        for (int j = t; j < n; j += 1024) ranges[j] = make_uint2(0u, 0u);
+}
+
+// Count / scatter passes over the compact bin records, BIN_SPT slots per thread, slots taken in Morton order
+// (`order`, may be null = identity): the rects of one block then fall into a small window of tiles, instances are
+// counted in an LDS table and every touched tile costs ONE global atomic per block (count pass: += tile_count;
+// scatter pass: cursor allocation, the base is left in the table and an LDS counter hands out the slots).  A block
+// whose window exceeds WIN_MAX tiles (incoherent order) pays one global atomic per instance instead.
+constexpr int WIN_MAX = 2048;
+constexpr int BIN_SPT = 4;
+constexpr int BIN_SLOTS = PRE_THREADS * BIN_SPT;
+
+template <bool SCATTER>
+__global__ __launch_bounds__(PRE_THREADS) void bin_kernel(int P, int gx, int gy, const uint4* __restrict__ binrec,
+                                                          const uint32_t* __restrict__ order,
+                                                          uint32_t* __restrict__ tile_count /* count pass */,
+                                                          uint32_t* __restrict__ cursor /* scatter pass */,
+                                                          const uint32_t* __restrict__ total,
+                                                          uint64_t* __restrict__ payload) {
+    __shared__ uint32_t s_tab[WIN_MAX];
+    __shared__ uint32_t s_run[SCATTER ? WIN_MAX : 1];
+    __shared__ int s_box[4];
+    if (SCATTER && *total == 0u) return;            // nothing visible, or capacity overflow (uniform)
+    const int t = threadIdx.x, lane = t & 63, f = blockIdx.y;
+    if (t == 0) { s_box[0] = 0x7fffffff; s_box[1] = 0x7fffffff; s_box[2] = 0; s_box[3] = 0; }
+    int x0[BIN_SPT], y0[BIN_SPT], x1[BIN_SPT], y1[BIN_SPT];
+    uint64_t key[BIN_SPT];
+    int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = 0, by1 = 0;
+#pragma unroll
+    for (int k = 0; k < BIN_SPT; ++k) {
+        const int s = blockIdx.x * BIN_SLOTS + k * PRE_THREADS + t;
+        x0[k] = y0[k] = x1[k] = y1[k] = 0; key[k] = 0;
+        if (s < P) {
+            const uint32_t id = order != nullptr ? order[s] : (uint32_t)s;
+            const uint4 br = binrec[(size_t)f * P + id];
+            x0[k] = (int)(br.x & 0xffffu); y0[k] = (int)(br.x >> 16);
+            x1[k] = (int)(br.y & 0xffffu); y1[k] = (int)(br.y >> 16);
+            key[k] = ((uint64_t)br.z << 32) | id;                      // depth bits above the Gaussian id
+            if (x1[k] > x0[k] && y1[k] > y0[k]) {
+                bx0 = min(bx0, x0[k]); by0 = min(by0, y0[k]); bx1 = max(bx1, x1[k]); by1 = max(by1, y1[k]);
+            } else {
+                x1[k] = x0[k];                                          // empty: the loops below do nothing
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        bx0 = min(bx0, __shfl_xor(bx0, d, 64)); by0 = min(by0, __shfl_xor(by0, d, 64));
+        bx1 = max(bx1, __shfl_xor(bx1, d, 64)); by1 = max(by1, __shfl_xor(by1, d, 64));
+    }
+    __syncthreads();                                 // s_box initialised
+    if (lane == 0 && bx1 > bx0) {
+        atomicMin(&s_box[0], bx0); atomicMin(&s_box[1], by0); atomicMax(&s_box[2], bx1); atomicMax(&s_box[3], by1);
+    }
+    __syncthreads();
+    const int wx0 = s_box[0], wy0 = s_box[1], ww = s_box[2] - s_box[0], wh = s_box[3] - s_box[1];
+    if (ww <= 0 || wh <= 0) return;                  // no instance in this block (uniform)
+    uint32_t* gtab = (SCATTER ? cursor : tile_count) + (size_t)f * gx * gy;
+    if (ww * wh <= WIN_MAX) {
+        const int area = ww * wh;
+        for (int e = t; e < area; e += PRE_THREADS) { s_tab[e] = 0u; if (SCATTER) s_run[e] = 0u; }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < BIN_SPT; ++k)
+            for (int y = y0[k]; y < y1[k]; ++y)
+                for (int x = x0[k]; x < x1[k]; ++x) atomicAdd(&s_tab[(y - wy0) * ww + (x - wx0)], 1u);
+        __syncthreads();
+        for (int e = t; e < area; e += PRE_THREADS) {
+            const uint32_t c = s_tab[e];
+            if (c != 0u) {
+                const int tile = (wy0 + e / ww) * gx + wx0 + e % ww;
+                if (SCATTER) s_tab[e] = atomicAdd(&gtab[tile], c);
+                else atomicAdd(&gtab[tile], c);
+            }
+        }
+        if (SCATTER) {
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < BIN_SPT; ++k)
+                for (int y = y0[k]; y < y1[k]; ++y)
+                    for (int x = x0[k]; x < x1[k]; ++x) {
+                        const int e = (y - wy0) * ww + (x - wx0);
+                        payload[s_tab[e] + atomicAdd(&s_run[e], 1u)] = key[k];
+                    }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < BIN_SPT; ++k)
+            for (int y = y0[k]; y < y1[k]; ++y)
+                for (int x = x0[k]; x < x1[k]; ++x) {
+                    const uint32_t pos = atomicAdd(&gtab[y * gx + x], 1u);
+                    if (SCATTER) payload[pos] = key[k];
+                }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Spatial order of the Gaussians (once per call, shared by all frames): 15-bit Morton code of the position inside
+// the bounding box, counting-sorted.  Purely a locality device for the bin passes: any order gives the same image.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t float_ordered(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float float_unordered(uint32_t o) {
+    return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+
+__global__ __launch_bounds__(256) void bbox_kernel(int P, const float* __restrict__ xyz, uint32_t* __restrict__ mm) {
+    __shared__ uint32_t s_mm[6];
+    if (threadIdx.x < 6) s_mm[threadIdx.x] = threadIdx.x < 3 ? 0xffffffffu : 0u;
+    __syncthreads();
+    uint32_t lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P; i += gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float v = xyz[3 * (size_t)i + k];
+            if (v == v && fabsf(v) < 3.0e38f) {
+                const uint32_t o = float_ordered(v);
+                lo[k] = min(lo[k], o); hi[k] = max(hi[k], o);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            lo[k] = min(lo[k], (uint32_t)__shfl_xor((int)lo[k], d, 64));
+            hi[k] = max(hi[k], (uint32_t)__shfl_xor((int)hi[k], d, 64));
+        }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&s_mm[k], lo[k]); atomicMax(&s_mm[3 + k], hi[k]); }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) atomicMin(&mm[threadIdx.x], s_mm[threadIdx.x]);
+    else if (threadIdx.x < 6) atomicMax(&mm[threadIdx.x], s_mm[threadIdx.x]);
+}
+
+__device__ __forceinline__ uint32_t spread5(uint32_t v) {   // 5 bits -> every third bit
+    return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6) | ((v & 16u) << 8);
+}
+
+constexpr int MORTON_BINS = 1 << 15;
+
+__device__ __forceinline__ uint32_t morton15(int i, const float* __restrict__ xyz, const uint32_t* __restrict__ mm) {
+    uint32_t code = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float lo = float_unordered(mm[k]), hi = float_unordered(mm[3 + k]);
+        const float v = xyz[3 * (size_t)i + k];
+        float q = (v - lo) / fmaxf(hi - lo, 1e-30f) * 32.0f;
+        q = (q == q) ? fminf(fmaxf(q, 0.0f), 31.0f) : 0.0f;
+        code |= spread5((uint32_t)q) << k;
+    }
+    return code;
+}
+
+// counting sort by Morton cell: histogram -> exclusive scan -> scatter (order inside a cell is arbitrary)
+__global__ __launch_bounds__(256) void morton_count_kernel(int P, const float* __restrict__ xyz,
+                                                           const uint32_t* __restrict__ mm, uint32_t* __restrict__ codes,
+                                                           uint32_t* __restrict__ hist) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const uint32_t c = morton15(i, xyz, mm);
+    codes[i] = c;
+    atomicAdd(&hist[c], 1u);
+}
+
+__global__ __launch_bounds__(1024) void morton_scan_kernel(uint32_t* __restrict__ hist) {
+    __shared__ uint32_t wsum[16];
+    const int t = threadIdx.x;
+    const unsigned lane = t & 63, w = t >> 6;
+    constexpr int PER = MORTON_BINS / 1024;
+    uint32_t v[PER], s = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { v[k] = hist[t * PER + k]; s += v[k]; }
+    const uint32_t incl = gvf_wave_incl_scan(s, lane);
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    uint32_t run = incl - s;
+    for (unsigned k = 0; k < w; ++k) run += wsum[k];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { hist[t * PER + k] = run; run += v[k]; }
+}
+
+__global__ __launch_bounds__(256) void morton_scatter_kernel(int P, const uint32_t* __restrict__ codes,
+                                                             uint32_t* __restrict__ hist, uint32_t* __restrict__ order) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    order[atomicAdd(&hist[codes[i]], 1u)] = (uint32_t)i;
+}
+
+// ---------------------------------------------------------------------------------------------
 // R5: tile ranges
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ranges_kernel(const uint64_t* __restrict__ keys,
@@ -571,13 +817,14 @@ __device__ __forceinline__ void bitonic_sort_asc(Ptr keys, int n, int tid, int n
 template <int E>
 __device__ __forceinline__ void tile_sort_regs(const uint64_t* __restrict__ k, const uint32_t* __restrict__ v,
                                                uint32_t* __restrict__ ids, int n, uint64_t* __restrict__ lds) {
+    // v == nullptr: k already holds (depth bits << 32 | id) (bucket binning); else k = (tile << 32 | depth), v = id
     constexpr int NP = 256 * E;
     const int tid = threadIdx.x;
     uint64_t key[E];
 #pragma unroll
     for (int r = 0; r < E; ++r) {
         const int e = tid * E + r;
-        key[r] = e < n ? ((k[e] << 32) | v[e]) : ~0ull;    // local key: depth bits above the Gaussian id
+        key[r] = e < n ? (v != nullptr ? ((k[e] << 32) | v[e]) : k[e]) : ~0ull;    // depth bits above the Gaussian id
     }
 #pragma unroll
     for (int k2 = 2; k2 <= NP; k2 <<= 1) {
@@ -646,7 +893,7 @@ __global__ void tile_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __r
         const int n = (int)(rng.y - rng.x);
         if (n <= 0 || n > SORT_SMALL_N) return;
         const uint64_t* k = keys + rng.x;
-        const uint32_t* v = vals + rng.x;
+        const uint32_t* v = vals != nullptr ? vals + rng.x : nullptr;
         uint32_t* o = ids + rng.x;
         if (n <= 256) tile_sort_regs<1>(k, v, o, n, s_small);
         else if (n <= 512) tile_sort_regs<2>(k, v, o, n, s_small);
@@ -662,14 +909,15 @@ __global__ void tile_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __r
         const uint2 rng = ranges[list[li]];
         const int n = (int)(rng.y - rng.x);
         uint64_t* k = keys + rng.x;
-        const uint32_t* v = vals + rng.x;
+        const uint32_t* v = vals != nullptr ? vals + rng.x : nullptr;
         if (MODE == 2) {
-            for (int i = tid; i < n; i += nt) k[i] = (k[i] << 32) | v[i];   // in place in global memory
+            if (v != nullptr)
+                for (int i = tid; i < n; i += nt) k[i] = (k[i] << 32) | v[i];   // in place in global memory
             __syncthreads();
             bitonic_sort_asc(k, n, tid, nt);
             for (int i = tid; i < n; i += nt) ids[rng.x + i] = (uint32_t)k[i];
         } else {
-            for (int i = tid; i < n; i += nt) s_large[i] = (k[i] << 32) | v[i];
+            for (int i = tid; i < n; i += nt) s_large[i] = v != nullptr ? ((k[i] << 32) | v[i]) : k[i];
             __syncthreads();
             bitonic_sort_asc(s_large, n, tid, nt);
             for (int i = tid; i < n; i += nt) ids[rng.x + i] = (uint32_t)s_large[i];
@@ -845,6 +1093,9 @@ struct Workspace {
     uint32_t* block_sums; uint32_t* frame_base; uint32_t* total;
     uint64_t* keys; uint64_t* keys_alt; uint32_t* vals; uint32_t* vals_alt; uint32_t* ids;
     uint2* ranges; uint32_t* cls;
+    uint32_t* tile_count; uint32_t* cursor;            // bucket binning: [F*ntiles] each
+    uint32_t* order; uint32_t* order_alt; uint32_t* mhist; uint32_t* mm;
+    uint4* binrec;                                     // [F*P] {x0|y0<<16, x1|y1<<16, depth bits, -}
     void* sort_tmp; size_t sort_tmp_bytes;
     size_t bytes; bool ok;
 };
@@ -877,6 +1128,14 @@ Workspace carve(void* ws, size_t bytes, int P, int F, int H, int W, int64_t max_
     w.ids = c.take<uint32_t>(D);
     w.ranges = c.take<uint2>((size_t)F * ntiles);
     w.cls = c.take<uint32_t>(2 + 2 * (size_t)F * ntiles);
+    w.tile_count = c.take<uint32_t>((size_t)F * ntiles);
+    w.cursor = c.take<uint32_t>((size_t)F * ntiles);
+    const size_t Pp = (size_t)(P > 0 ? P : 1);
+    w.order = c.take<uint32_t>(Pp);
+    w.order_alt = c.take<uint32_t>(Pp);
+    w.mhist = c.take<uint32_t>(1 << 15);
+    w.mm = c.take<uint32_t>(8);
+    w.binrec = c.take<uint4>(FP);
     w.sort_tmp_bytes = gvf_sort_tmp_bytes((int64_t)D);
     w.sort_tmp = c.take<char>(w.sort_tmp_bytes);
     w.bytes = gvf_align_up(c.off, 256);
@@ -922,7 +1181,25 @@ int run_pipeline(const GvfRastSettings& st, const GvfRastFrame* frames_host, int
         // nothing to splat: background only
         if (hipMemsetAsync(out_num_rendered, 0, sizeof(uint32_t) * F, stream) != hipSuccess) return GVF_ELAUNCH;
     } else {
+        const bool bucket = st.bin_algo != GVF_RAST_BIN_RADIX;
+        const unsigned nseg = (unsigned)((size_t)F * ntiles);
         prof_mark(stream, slot, 0);
+        // ---- spatial order of the Gaussians (bucket binning, several frames to amortise it over) ----
+        const uint32_t* order = nullptr;
+        if (bucket && F >= 4 && P >= 4096) {
+            if (hipMemsetAsync(w.mm, 0xff, 3 * sizeof(uint32_t), stream) != hipSuccess) return GVF_ELAUNCH;
+            if (hipMemsetAsync(w.mm + 3, 0, 3 * sizeof(uint32_t), stream) != hipSuccess) return GVF_ELAUNCH;
+            if (hipMemsetAsync(w.mhist, 0, MORTON_BINS * sizeof(uint32_t), stream) != hipSuccess) return GVF_ELAUNCH;
+            int bb = (P + 255) / 256; if (bb > 128) bb = 128;
+            const int pb = (P + 255) / 256;
+            hipLaunchKernelGGL(bbox_kernel, dim3(bb), dim3(256), 0, stream, P, a0, w.mm);
+            hipLaunchKernelGGL(morton_count_kernel, dim3(pb), dim3(256), 0, stream, P, a0, w.mm, w.order_alt, w.mhist);
+            hipLaunchKernelGGL(morton_scan_kernel, dim3(1), dim3(1024), 0, stream, w.mhist);
+            hipLaunchKernelGGL(morton_scatter_kernel, dim3(pb), dim3(256), 0, stream, P, w.order_alt, w.mhist, w.order);
+            order = w.order;
+            GVF_CHECK_LAUNCH();
+        }
+        prof_mark(stream, slot, 1);
         PreParams pp;
         pp.P = P; pp.M = colors_precomp ? 0 : M; pp.deg = st.sh_degree; pp.H = H; pp.W = W; pp.mode = st.mode;
         pp.gx = gx; pp.gy = gy; pp.kernel_size = st.kernel_size; pp.scale_modifier = st.scale_modifier;
@@ -930,45 +1207,59 @@ int run_pipeline(const GvfRastSettings& st, const GvfRastFrame* frames_host, int
         // per-pixel sub-pixel offsets move the sample positions: no box culling then (as in the blend)
         pp.upstream_binning = (st.upstream_binning != 0 || subpixel_offset != nullptr) ? 1 : 0;
         if (fused) pp.act = *act; else pp.act = GvfGaussianActivation{};
+        if (bucket && hipMemsetAsync(w.tile_count, 0, sizeof(uint32_t) * nseg, stream) != hipSuccess) return GVF_ELAUNCH;
         const size_t sh_lds_bytes = gvf_align_up((size_t)PRE_THREADS * pp.M * 3 * sizeof(float), 16) + 16;
         hipLaunchKernelGGL(preprocess_kernel, dim3(nb, F), dim3(PRE_THREADS), sh_lds_bytes, stream, pp, w.frames, a0,
                            a1, a2, a3, colors_precomp ? nullptr : sh, colors_precomp, cov3D_precomp, delta, w.splats,
-                           w.tiles_touched, w.radii, w.block_sums);
-        GVF_CHECK_LAUNCH();
-        prof_mark(stream, slot, 1);
-        hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, stream, w.block_sums, nb, F, w.frame_base,
-                           out_num_rendered, w.total, (uint32_t)max_rendered);
+                           w.tiles_touched, w.radii, w.block_sums, bucket ? w.binrec : nullptr);
+        const int bnb = (P + BIN_SLOTS - 1) / BIN_SLOTS;
+        if (bucket)
+            hipLaunchKernelGGL(bin_kernel<false>, dim3(bnb, F), dim3(PRE_THREADS), 0, stream, P, gx, gy, w.binrec, order,
+                               w.tile_count, w.cursor, w.total, w.keys);
         GVF_CHECK_LAUNCH();
         prof_mark(stream, slot, 2);
+        if (bucket)
+            hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, w.tile_count, ntiles, F, w.ranges, w.cursor,
+                               w.frame_base, out_num_rendered, w.total, (uint32_t)max_rendered);
+        else
+            hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, stream, w.block_sums, nb, F, w.frame_base,
+                               out_num_rendered, w.total, (uint32_t)max_rendered);
+        GVF_CHECK_LAUNCH();
+        prof_mark(stream, slot, 3);
         if (max_rendered > 0) {
-            hipLaunchKernelGGL(duplicate_kernel, dim3(nb, F), dim3(PRE_THREADS), 0, stream, P, gx, gy, w.splats,
-                               w.tiles_touched, w.radii, w.block_sums, w.keys, w.vals, (uint32_t)max_rendered,
-                               pp.upstream_binning);
+            if (bucket)
+                hipLaunchKernelGGL(bin_kernel<true>, dim3(bnb, F), dim3(PRE_THREADS), 0, stream, P, gx, gy, w.binrec, order,
+                                   w.tile_count, w.cursor, w.total, w.keys);
+            else
+                hipLaunchKernelGGL(duplicate_kernel, dim3(nb, F), dim3(PRE_THREADS), 0, stream, P, gx, gy, w.splats,
+                                   w.tiles_touched, w.radii, w.block_sums, w.keys, w.vals, (uint32_t)max_rendered,
+                                   pp.upstream_binning);
             GVF_CHECK_LAUNCH();
         }
         if (out_radii != nullptr) {
             if (hipMemcpyAsync(out_radii, w.radii, sizeof(int32_t) * (size_t)F * P, hipMemcpyDeviceToDevice, stream) != hipSuccess)
                 return GVF_ELAUNCH;
         }
-        prof_mark(stream, slot, 3);
+        prof_mark(stream, slot, 4);
         if (max_rendered > 0) {
-            // (a) stable radix sort on the (frame, tile) bits only: segments become contiguous, emission
-            //     (= Gaussian index) order inside a segment is kept but irrelevant; (b) tile ranges;
-            //     (c) per-tile on-chip sort by (depth, id).
             uint64_t* keys_sorted = w.keys;
-            uint32_t* vals_by_tile = w.vals;
-            int in_alt = 0;
-            int rc = gvf_sort_pairs_device_n(w.keys, w.keys_alt, w.vals, w.vals_alt, w.total, max_rendered, 32,
-                                             key_end_bit(F, ntiles), w.sort_tmp, w.sort_tmp_bytes, stream, &in_alt);
-            if (rc != GVF_OK) return rc;
-            if (in_alt) { keys_sorted = w.keys_alt; vals_by_tile = w.vals_alt; }
-            int rblocks = (int)((max_rendered + 255) / 256);
-            if (rblocks > 4096) rblocks = 4096;
-            hipLaunchKernelGGL(ranges_kernel, dim3(rblocks), dim3(256), 0, stream, keys_sorted, w.total,
-                               (uint32_t)max_rendered, w.ranges, (uint32_t)((size_t)F * ntiles));
-            GVF_CHECK_LAUNCH();
-            prof_mark(stream, slot, 4);
-            const unsigned nseg = (unsigned)((size_t)F * ntiles);
+            uint32_t* vals_by_tile = nullptr;
+            if (!bucket) {
+                // (a) stable radix sort on the (frame, tile) bits only: segments become contiguous; (b) tile ranges
+                vals_by_tile = w.vals;
+                int in_alt = 0;
+                int rc = gvf_sort_pairs_device_n(w.keys, w.keys_alt, w.vals, w.vals_alt, w.total, max_rendered, 32,
+                                                 key_end_bit(F, ntiles), w.sort_tmp, w.sort_tmp_bytes, stream, &in_alt);
+                if (rc != GVF_OK) return rc;
+                if (in_alt) { keys_sorted = w.keys_alt; vals_by_tile = w.vals_alt; }
+                int rblocks = (int)((max_rendered + 255) / 256);
+                if (rblocks > 4096) rblocks = 4096;
+                hipLaunchKernelGGL(ranges_kernel, dim3(rblocks), dim3(256), 0, stream, keys_sorted, w.total,
+                                   (uint32_t)max_rendered, w.ranges, (uint32_t)nseg);
+                GVF_CHECK_LAUNCH();
+            }
+            prof_mark(stream, slot, 5);
+            // per-tile on-chip sort by (depth, id)
             if (hipMemsetAsync(w.cls, 0, 2 * sizeof(uint32_t), stream) != hipSuccess) return GVF_ELAUNCH;
             hipLaunchKernelGGL(classify_kernel, dim3((nseg + 255) / 256), dim3(256), 0, stream, w.ranges, nseg, w.cls);
             hipLaunchKernelGGL(tile_sort_kernel<0>, dim3(nseg), dim3(256), 0, stream, w.ranges, keys_sorted, vals_by_tile, w.ids, w.cls, nseg);
@@ -982,15 +1273,17 @@ int run_pipeline(const GvfRastSettings& st, const GvfRastFrame* frames_host, int
             hipLaunchKernelGGL(tile_sort_kernel<1>, dim3(64), dim3(1024), SORT_LARGE_N * 8, stream, w.ranges, keys_sorted, vals_by_tile, w.ids, w.cls, nseg);
             hipLaunchKernelGGL(tile_sort_kernel<2>, dim3(64), dim3(1024), 0, stream, w.ranges, keys_sorted, vals_by_tile, w.ids, w.cls, nseg);
             GVF_CHECK_LAUNCH();
+        } else {
+            prof_mark(stream, slot, 5);
         }
     }
     uint32_t* vals_sorted = w.ids;
-    prof_mark(stream, slot, 5);
+    prof_mark(stream, slot, 6);
     hipLaunchKernelGGL(blend_kernel, dim3(ntiles, F), dim3(BLEND_THREADS), 0, stream, P, H, W, gx, gy, st.bg[0],
                        st.bg[1], st.bg[2], w.ranges, vals_sorted, w.splats, subpixel_offset,
                        out_color, out_alpha, out_depth);
     GVF_CHECK_LAUNCH();
-    prof_mark(stream, slot, 6);
+    prof_mark(stream, slot, 7);
     return GVF_OK;
 }
 

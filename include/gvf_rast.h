@@ -68,7 +68,17 @@ typedef struct GvfRastSettings {
                                  reach 1/255 somewhere in the tile (conservative box test) -- the blend skips every other
                                  pair at each pixel, so images are identical and num_rendered is smaller;
                                  1: bin the whole 3-sigma tile rect, num_rendered equals upstream's count */
+    int32_t bin_algo;         /* GVF_RAST_BIN_*: how instances reach their tile segment (same image either way) */
 } GvfRastSettings;
+
+/* BUCKET (default): Gaussians are put in Morton order once per call, per-tile instance counts are taken in the
+ * preprocess kernel (LDS histogram per block, one global atomic per touched tile), their scan gives the tile
+ * ranges and a scatter pass writes (depth, id) into the segments; RADIX: upstream's scheme restricted to the
+ * (frame, tile) key bits -- duplicate, two global 8-bit LSD passes, ranges.  Both finish with the per-tile
+ * on-chip sort by (depth, id). */
+#define GVF_RAST_BIN_AUTO   0
+#define GVF_RAST_BIN_RADIX  1
+#define GVF_RAST_BIN_BUCKET 2
 
 /* Activation constants of GaussianModel (representations/gaussian/gaussian_model.py:24-41,84-114)
  * for the fused delta path.  scaling_activation: 0 = exp, 1 = softplus. */
@@ -144,10 +154,11 @@ int gvf_rgb_to_u8(const float* rgb, uint8_t* out, int64_t n, void* stream);
 
 /* Opt-in per-stage GPU timing of gvf_rast_forward*(): HIP events are recorded on the caller's
  * stream at the stage boundaries of the next (at most 256) calls.  Stages, in order:
- * preprocess, scan, duplicate, sort, ranges, blend.  gvf_rast_profile_read() synchronises on the
+ * order (Morton order + input gather), preprocess, scan, bin (scatter | duplicate), sort (radix passes + ranges;
+ * empty for bucket binning), tile_sort, blend.  gvf_rast_profile_read() synchronises on the
  * recorded events, writes the summed milliseconds per stage over `*calls` calls, and resets.
  * This is the library's only process-global state (off by default; not thread-safe). */
-#define GVF_RAST_NSTAGES 6
+#define GVF_RAST_NSTAGES 7
 int gvf_rast_profile_enable(int on);
 int gvf_rast_profile_read(float* ms_sum /*[GVF_RAST_NSTAGES]*/, int* calls);
 

@@ -27,6 +27,16 @@ def _settings(cam, H, W, deg, mode, dev, kernel_size=synthetic.KERNEL_2D, scale_
     return GaussianRasterizer(GaussianRasterizationSettings(**common))
 
 
+@pytest.fixture(autouse=True, params=["bucket", "radix"])
+def bin_algo(request):
+    """Every test of this file runs with both instance-binning algorithms (include/gvf_rast.h GVF_RAST_BIN_*)."""
+    from gvfdiffusion_amd import rasterizer as R, _lib
+    old = R.DEFAULT_BIN_ALGO
+    R.DEFAULT_BIN_ALGO = _lib.RAST_BIN_BUCKET if request.param == "bucket" else _lib.RAST_BIN_RADIX
+    yield request.param
+    R.DEFAULT_BIN_ALGO = old
+
+
 def _run(rast, a, **over):
     kw = dict(means3D=a["means3D"], means2D=torch.zeros_like(a["means3D"]), shs=a["shs"], colors_precomp=None,
               opacities=a["opacities"], scales=a["scales"], rotations=a["rotations"], cov3D_precomp=None)
