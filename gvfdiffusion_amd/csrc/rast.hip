@@ -1011,25 +1011,44 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
             n_w += __popcll(bal);
         }
         __builtin_amdgcn_wave_barrier();
-        for (int jj = 0; !done && jj < n_w; ++jj) {
-            const int j = sList[wave][jj];
-            const float4 a = sA[j];
-            const float4 b = sB[j];
-            float dx = a.x - pxf, dy = a.y - pyf;
-            float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-            if (power > 0.0f) continue;
-            float alpha = fminf(0.99f, b.y * __expf(power));
-            if (alpha < 1.0f / 255.0f) continue;
-            float test_T = T * (1.f - alpha);
-            if (test_T < 0.0001f) { done = true; continue; }
-            const float2 c = sC[j];
-            float wgt = alpha * T;
-            C0 = __builtin_fmaf(b.z, wgt, C0);
-            C1 = __builtin_fmaf(b.w, wgt, C1);
-            C2 = __builtin_fmaf(c.x, wgt, C2);
-            Dacc = __builtin_fmaf(c.y, wgt, Dacc);
-            T = test_T;
+        // Branch-free compositing step (upstream's `continue`s become predicates: a skipped splat gets weight 0,
+        // which leaves C and T bit-identical), two splats per trip so that the second one's LDS reads and alpha
+        // arithmetic overlap the first one's serial T update.
+#define GVF_BLEND_STEP(J)                                                                              \
+        {                                                                                              \
+            const float4 a = sA[J];                                                                    \
+            const float4 b = sB[J];                                                                    \
+            const float2 c = sC[J];                                                                    \
+            const float dx = a.x - pxf, dy = a.y - pyf;                                                \
+            const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;               \
+            const float alpha = fminf(0.99f, b.y * __expf(power));                                     \
+            const bool ok = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);                      \
+            const float test_T = T * (1.f - alpha);                                                    \
+            const bool stop = ok && test_T < 0.0001f;                                                  \
+            done = done || stop;                                                                       \
+            const bool acc = ok && !stop;                                                              \
+            const float wgt = acc ? alpha * T : 0.0f;                                                  \
+            C0 = __builtin_fmaf(b.z, wgt, C0);                                                         \
+            C1 = __builtin_fmaf(b.w, wgt, C1);                                                         \
+            C2 = __builtin_fmaf(c.x, wgt, C2);                                                         \
+            Dacc = __builtin_fmaf(c.y, wgt, Dacc);                                                     \
+            T = acc ? test_T : T;                                                                      \
         }
+        int jj = 0;
+        for (; jj + 3 < n_w; jj += 4) {
+            if (__all(done)) break;
+            const int j0 = sList[wave][jj], j1 = sList[wave][jj + 1], j2 = sList[wave][jj + 2], j3 = sList[wave][jj + 3];
+            GVF_BLEND_STEP(j0)
+            GVF_BLEND_STEP(j1)
+            GVF_BLEND_STEP(j2)
+            GVF_BLEND_STEP(j3)
+        }
+        for (; jj < n_w; ++jj) {
+            if (__all(done)) break;
+            const int j0 = sList[wave][jj];
+            GVF_BLEND_STEP(j0)
+        }
+#undef GVF_BLEND_STEP
     }
     if (inside) {
         const size_t hw = (size_t)H * W;
