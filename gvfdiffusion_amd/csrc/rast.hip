@@ -811,15 +811,18 @@ __device__ __forceinline__ void bitonic_sort_asc(Ptr keys, int n, int tid, int n
 }
 
 // Small segments (<= 2048 keys, i.e. practically every tile): E = npad / 256 keys per thread live in REGISTERS
-// (key index e = tid * E + r); compare-exchange partners at distance j are in the same thread (j < E), in the same
-// wave (j < 64 E: one 64-bit lane exchange, no LDS, no barrier) or in another wave (LDS round trip).  For a 512-key
-// tile that is 3 LDS steps instead of 45 barrier-separated LDS passes.
+// (key index e = tid * E + r).  Same all-ascending network as above: every step pairs e with e ^ m (m = k - 1 for the
+// mirrored first step of a merge, m = j for the half-cleaners), the lower index keeps the minimum.  Partners are in
+// the same thread (m < E), the same wave (one 64-bit lane exchange, no LDS, no barrier) or another wave (LDS round
+// trip).  The +inf padding above n never moves, so a wave that holds nothing but padding (wave 3 for n <= 1536, wave
+// 2 for n <= 1024 at E = 8: the typical dense tile has ~1100 keys) skips everything except the barriers.
 template <int E>
 __device__ __forceinline__ void tile_sort_regs(const uint64_t* __restrict__ k, const uint32_t* __restrict__ v,
                                                uint32_t* __restrict__ ids, int n, uint64_t* __restrict__ lds) {
     // v == nullptr: k already holds (depth bits << 32 | id) (bucket binning); else k = (tile << 32 | depth), v = id
     constexpr int NP = 256 * E;
     const int tid = threadIdx.x;
+    const bool live = (tid & ~63) * E < n;                  // this wave holds at least one real key (wave-uniform)
     uint64_t key[E];
 #pragma unroll
     for (int r = 0; r < E; ++r) {
@@ -829,37 +832,51 @@ __device__ __forceinline__ void tile_sort_regs(const uint64_t* __restrict__ k, c
 #pragma unroll
     for (int k2 = 2; k2 <= NP; k2 <<= 1) {
 #pragma unroll
-        for (int j = k2 >> 1; j > 0; j >>= 1) {
-            if (j < E) {
+        for (int step = 0, j = k2 >> 1; j > 0; ++step, j >>= 1) {
+            const int m = step == 0 ? k2 - 1 : j;           // xor mask in key-index space
+            const int mr = m & (E - 1), mt = m / E;         // ... on the register index / on the thread index
+            if (mt == 0) {
+                if (live) {
 #pragma unroll
-                for (int r = 0; r < E; ++r) {
-                    if ((r & j) == 0) {
-                        const bool up = ((tid * E + r) & k2) == 0;
-                        const uint64_t a = key[r], b = key[r | j];
-                        if ((a > b) == up) { key[r] = b; key[r | j] = a; }
+                    for (int r = 0; r < E; ++r) {
+                        if (r < (r ^ mr)) {
+                            const uint64_t a = key[r], b = key[r ^ mr];
+                            if (a > b) { key[r] = b; key[r ^ mr] = a; }
+                        }
                     }
                 }
-            } else if (j < 64 * E) {
+            } else if (mt < 64) {
+                if (live) {
+                    const int hb = step == 0 ? (k2 / E) >> 1 : mt;          // highest set bit of mt
+                    const bool lower = (tid & hb) == 0;
+                    uint64_t other[E];
 #pragma unroll
-                for (int r = 0; r < E; ++r) {
-                    const int e = tid * E + r;
-                    const unsigned lo = __shfl_xor((unsigned)key[r], j / E, 64);
-                    const unsigned hi = __shfl_xor((unsigned)(key[r] >> 32), j / E, 64);
-                    const uint64_t other = ((uint64_t)hi << 32) | lo;
-                    const bool take_min = ((e & j) == 0) == ((e & k2) == 0);
-                    key[r] = take_min ? (other < key[r] ? other : key[r]) : (other > key[r] ? other : key[r]);
+                    for (int r = 0; r < E; ++r) {
+                        const uint64_t src = key[r ^ mr];
+                        const unsigned lo = __shfl_xor((unsigned)src, mt, 64);
+                        const unsigned hi = __shfl_xor((unsigned)(src >> 32), mt, 64);
+                        other[r] = ((uint64_t)hi << 32) | lo;
+                    }
+#pragma unroll
+                    for (int r = 0; r < E; ++r)
+                        key[r] = lower ? (other[r] < key[r] ? other[r] : key[r]) : (other[r] > key[r] ? other[r] : key[r]);
                 }
             } else {
                 __syncthreads();
+                if (live) {
 #pragma unroll
-                for (int r = 0; r < E; ++r) lds[tid * E + r] = key[r];
+                    for (int r = 0; r < E; ++r) lds[tid * E + r] = key[r];
+                }
                 __syncthreads();
+                if (live) {
 #pragma unroll
-                for (int r = 0; r < E; ++r) {
-                    const int e = tid * E + r;
-                    const uint64_t other = lds[e ^ j];
-                    const bool take_min = ((e & j) == 0) == ((e & k2) == 0);
-                    key[r] = take_min ? (other < key[r] ? other : key[r]) : (other > key[r] ? other : key[r]);
+                    for (int r = 0; r < E; ++r) {
+                        const int e = tid * E + r, pe = e ^ m;
+                        if (pe < n) {                       // partner above n is +inf: an upper partner changes nothing,
+                            const uint64_t other = lds[pe]; // and e < n <= pe cannot be the upper side
+                            key[r] = e < pe ? (other < key[r] ? other : key[r]) : (other > key[r] ? other : key[r]);
+                        }
+                    }
                 }
             }
         }
