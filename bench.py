@@ -175,6 +175,19 @@ def bench_dit(dev, nfe=32):
                                  "the loop); as-written equivalent = %.2f TFLOP/s" % (fa / per / 1e12)}}
 
 
+def pmc_traffic(kernel, a, S, F):
+    """HBM-side bytes per launch of `kernel` from the committed PMC summary (the counters cannot be collected from
+    inside the benchmark process); only for the default workload the summary was taken on, else None."""
+    import glob
+    if (a.gaussians, S, F, a.sh_degree) != (262144, 800, 24, 2):
+        return None
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_raster.json")))
+    if not files:
+        return None
+    k = json.load(open(files[-1]))["kernels"].get(kernel)
+    return None if k is None else int(k["traffic_bytes_per_launch"])
+
+
 def cpu_baseline(work, budget_s=12.0):
     """The CPU oracle (kind "port": the reference has no CPU Gaussian rasteriser)
     timed on this box's host cores on the first frames of the same sample."""
@@ -292,7 +305,10 @@ def main():
                        "instances_per_frame": round(work.D / F, 1), "instances_binned_per_frame": round(work.D_binned / F, 1), "parallelism": f"sample-sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": "blend_kernel (R6, one launch = all frames of the step)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic("blend_kernel", a, S, F),
+                         "traffic_source": "profiles/*_pmc_raster.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                           "workload (scripts/gpu_pmc.sh, scripts/pmc_summary.py; FETCH x2 gfx950 correction), "
+                                           "bytes per launch; not re-measured inside this run",
                          "alg_bytes_per_launch": int(work.alg_bytes_blend_launch()),
                          "avg_launch_ms": round(stage_ms["blend"], 4)},
             "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
