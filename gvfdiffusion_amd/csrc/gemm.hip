@@ -20,10 +20,9 @@ namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int BN = 128, BK = 32;                    // BM (128 or 64) is a template parameter
 constexpr int THREADS = 256;
 constexpr int CHUNKS_PER_ROW = BK / 8;              // 16-byte chunks per tile row
-constexpr int LOADS = BM * CHUNKS_PER_ROW / THREADS;  // 2 chunks of A (and of W) per thread per k-tile
 constexpr int ROWS_PER_DMA = 64 / CHUNKS_PER_ROW;       // tile rows filled by one wave-wide DMA instruction (16)
 // chunk swizzle for 64-byte rows: slot = chunk ^ swz(row); conflict-free for the ds_read_b128 lane groups
 // ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...) when swz(row) = 3 for rows 8..15 of each 16-row group, else 0.
@@ -51,15 +50,30 @@ __device__ __forceinline__ float gelu_tanh(float x) {
     return x / (1.0f + __expf(-2.0f * u));
 }
 
-template <int EPI>
+// LDS-DMA of one 16-byte chunk per lane.  Kept out of the kernel template on purpose: with template-dependent
+// arguments clang checks the builtin only at instantiation, where the HOST pass rejects it silently and then emits
+// no stub for the kernel at all (undefined symbol at dlopen).
+__device__ __forceinline__ void dma16(const unsigned short* g, uint4* l) {
+    __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+// BM = 128: 2x2 waves of 64x64 (4x4 fragments).  BM = 64: 2x2 waves of 32x64 (2x4 fragments), used when the
+// 128-row tiling would leave the chip with fewer than two workgroups per CU (the DiT's N = 512 projections:
+// 384 tiles on 256 CUs) -- twice the workgroups, so twice the DMA tiles in flight to hide the load latency.
+template <int EPI, int BM>
 __global__ __launch_bounds__(THREADS, 4) void gemm_bf16_kernel(const unsigned short* __restrict__ A, int lda,
                                                             const unsigned short* __restrict__ W, int ldw,
                                                             const float* __restrict__ bias, void* __restrict__ Cv,
                                                             int ldc, int M, int N, int K,
                                                             const float* __restrict__ gate, int gate_ld, int rpg,
                                                             int tiles_n) {
-    __shared__ uint4 sA[2][BM * CHUNKS_PER_ROW];
-    __shared__ uint4 sB[2][BN * CHUNKS_PER_ROW];
+    constexpr int MI = BM / 32;                          // 16-row fragments per wave along M
+    constexpr int LOADS_A = BM * CHUNKS_PER_ROW / THREADS, LOADS_B = BN * CHUNKS_PER_ROW / THREADS;
+    // one LDS block: A buffers, then W buffers; indexed through the array itself so that the address space stays
+    // LDS for the DMA builtin (a pointer variable would be generic)
+    __shared__ uint4 smem[2 * (BM + BN) * CHUNKS_PER_ROW];
+#define SA(buf_, idx_) smem[(buf_) * (BM * CHUNKS_PER_ROW) + (idx_)]
+#define SB(buf_, idx_) smem[2 * BM * CHUNKS_PER_ROW + (buf_) * (BN * CHUNKS_PER_ROW) + (idx_)]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -69,9 +83,9 @@ __global__ __launch_bounds__(THREADS, 4) void gemm_bf16_kernel(const unsigned sh
     const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
     const int bm = tile_m * BM, bn = tile_n * BN;
 
-    f32x4 acc[4][4];
+    f32x4 acc[MI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -82,21 +96,25 @@ __global__ __launch_bounds__(THREADS, 4) void gemm_bf16_kernel(const unsigned sh
     // reads conflict-free is applied to the per-lane SOURCE chunk (LDS side stays linear, as the DMA requires).
     // Rows past M / N are clamped in-bounds; their products land in accumulator rows / columns the epilogue drops.
     const int st_row = lane / CHUNKS_PER_ROW, st_c = lane % CHUNKS_PER_ROW;
-    const unsigned short* a_src[LOADS];
-    const unsigned short* w_src[LOADS];
+    const unsigned short* a_src[LOADS_A];
+    const unsigned short* w_src[LOADS_B];
 #pragma unroll
-    for (int i = 0; i < LOADS; ++i) {
+    for (int i = 0; i < LOADS_A; ++i) {
         const int row = (i * 4 + wave) * ROWS_PER_DMA + st_row;   // tile row this lane fills with load i
         const int gr = bm + row < M ? bm + row : M - 1;
-        const int gn = bn + row < N ? bn + row : N - 1;
         a_src[i] = A + (size_t)gr * lda + ((st_c ^ swz(row)) * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < LOADS_B; ++i) {
+        const int row = (i * 4 + wave) * ROWS_PER_DMA + st_row;
+        const int gn = bn + row < N ? bn + row : N - 1;
         w_src[i] = W + (size_t)gn * ldw + ((st_c ^ swz(row)) * 8);
     }
 #define GVF_GEMM_STAGE(kt_, buf_)                                                                          \
-    _Pragma("unroll") for (int i = 0; i < LOADS; ++i) {                                                      \
-        __builtin_amdgcn_global_load_lds(a_src[i] + (size_t)(kt_) * BK, &sA[buf_][(i * 4 + wave) * 64], 16, 0, 0); \
-        __builtin_amdgcn_global_load_lds(w_src[i] + (size_t)(kt_) * BK, &sB[buf_][(i * 4 + wave) * 64], 16, 0, 0); \
-    }
+    _Pragma("unroll") for (int i = 0; i < LOADS_A; ++i)                                                      \
+        dma16(a_src[i] + (size_t)(kt_) * BK, &SA(buf_, (i * 4 + wave) * 64));                              \
+    _Pragma("unroll") for (int i = 0; i < LOADS_B; ++i)                                                      \
+        dma16(w_src[i] + (size_t)(kt_) * BK, &SB(buf_, (i * 4 + wave) * 64));
 
     GVF_GEMM_STAGE(0, 0)
     __syncthreads();          // drains the DMA (vmcnt(0)) and publishes the tile
@@ -105,17 +123,20 @@ __global__ __launch_bounds__(THREADS, 4) void gemm_bf16_kernel(const unsigned sh
         const int buf = kt & 1;
         if (kt + 1 < KT) { GVF_GEMM_STAGE(kt + 1, buf ^ 1) }   // lands while this tile is multiplied
         {
-            bf16x8 af[4], bfr[4];
+            bf16x8 af[MI], bfr[4];
             const int kc = lane >> 4;
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                const int ar = wm * 64 + f * 16 + (lane & 15);
-                const int br = wn * 64 + f * 16 + (lane & 15);
-                af[f] = __builtin_bit_cast(bf16x8, sA[buf][ar * CHUNKS_PER_ROW + (kc ^ swz(ar))]);
-                bfr[f] = __builtin_bit_cast(bf16x8, sB[buf][br * CHUNKS_PER_ROW + (kc ^ swz(br))]);
+            for (int f = 0; f < MI; ++f) {
+                const int ar = wm * (BM / 2) + f * 16 + (lane & 15);
+                af[f] = __builtin_bit_cast(bf16x8, SA(buf, ar * CHUNKS_PER_ROW + (kc ^ swz(ar))));
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int f = 0; f < 4; ++f) {
+                const int br = wn * 64 + f * 16 + (lane & 15);
+                bfr[f] = __builtin_bit_cast(bf16x8, SB(buf, br * CHUNKS_PER_ROW + (kc ^ swz(br))));
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
@@ -123,6 +144,8 @@ __global__ __launch_bounds__(THREADS, 4) void gemm_bf16_kernel(const unsigned sh
         __syncthreads();
     }
 #undef GVF_GEMM_STAGE
+#undef SA
+#undef SB
 
     // ---- epilogue.  A 16x16 accumulator fragment holds column (lane & 15), rows (lane >> 4) * 4 + r: writing it out
     // directly costs 64 scattered 2/4-byte stores per lane (measured: half of the kernel's time).  Instead each
@@ -130,7 +153,8 @@ __global__ __launch_bounds__(THREADS, 4) void gemm_bf16_kernel(const unsigned sh
     // vectors: one wave-instruction then covers 4 rows x 256 B (fp32) / 128 B (bf16), and the read-modify-write of
     // the fp32 residual stream, the bias and the gate are float4 accesses.
     constexpr int EP_LD = 68;                                  // floats per staged row (64 + 4 pad)
-    float* ep = reinterpret_cast<float*>(&sA[0][0]) + wave * (16 * EP_LD);   // 4 x 4352 B <= the 32 KiB of sA
+    static_assert(4 * 16 * EP_LD * 4 <= (int)sizeof(smem), "epilogue slabs must fit the operand buffers");
+    float* ep = reinterpret_cast<float*>(smem) + wave * (16 * EP_LD);       // 4 x 4352 B inside the operand buffers
     __syncthreads();                                           // every wave is done reading the operand tiles
     const int col_l = lane & 15, row_l = (lane >> 4) * 4;
     const int er = lane >> 4, ec = (lane & 15) * 4;            // read-back role: row er (+4 per step), columns ec..ec+3
@@ -145,7 +169,7 @@ __global__ __launch_bounds__(THREADS, 4) void gemm_bf16_kernel(const unsigned sh
         }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MI; ++i) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -154,7 +178,7 @@ __global__ __launch_bounds__(THREADS, 4) void gemm_bf16_kernel(const unsigned sh
 #pragma unroll
         for (int step = 0; step < 4; ++step) {
             const int lr = step * 4 + er;
-            const int row = bm + wm * 64 + i * 16 + lr;
+            const int row = bm + wm * (BM / 2) + i * 16 + lr;
             float4 v = *reinterpret_cast<const float4*>(&ep[lr * EP_LD + ec]);
             v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
             if (row >= M || col0 >= N) continue;
@@ -208,27 +232,27 @@ extern "C" int gvf_gemm_bf16(const void* A, int lda, const void* W, int ldw, con
     if (epilogue == GVF_EPI_RESID_F32 && gate != nullptr && rows_per_group <= 0) return GVF_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
     (void)hipGetLastError();
-    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    const int tiles_n = (N + BN - 1) / BN;
+    const bool small = ((M + 127) / 128) * tiles_n < 512;      // fewer than two 128-row workgroups per CU: use 64-row tiles
+    const int bm = small ? 64 : 128;
+    const int tiles_m = (M + bm - 1) / bm;
     const dim3 grid(tiles_m * tiles_n), block(THREADS);
     const unsigned short* a = (const unsigned short*)A;
     const unsigned short* w = (const unsigned short*)W;
     const int rpg = rows_per_group > 0 ? rows_per_group : 1;
+    // (<<<>>> rather than hipLaunchKernelGGL: a parenthesised two-argument template-id inside the macro is only an
+    // address-of expression and does not make clang emit the host stub of the instantiation)
+#define GVF_GEMM_LAUNCH(EPI_)                                                                                     \
+    if (small) gemm_bf16_kernel<EPI_, 64><<<grid, block, 0, stream>>>(a, lda, w, ldw, bias, C, ldc, M, N, K, gate, gate_ld, rpg, tiles_n); \
+    else gemm_bf16_kernel<EPI_, 128><<<grid, block, 0, stream>>>(a, lda, w, ldw, bias, C, ldc, M, N, K, gate, gate_ld, rpg, tiles_n);
     switch (epilogue) {
-        case GVF_EPI_STORE_BF16:
-            hipLaunchKernelGGL(gemm_bf16_kernel<GVF_EPI_STORE_BF16>, grid, block, 0, stream, a, lda, w, ldw, bias, C, ldc, M, N, K, gate, gate_ld, rpg, tiles_n);
-            break;
-        case GVF_EPI_GELU_BF16:
-            hipLaunchKernelGGL(gemm_bf16_kernel<GVF_EPI_GELU_BF16>, grid, block, 0, stream, a, lda, w, ldw, bias, C, ldc, M, N, K, gate, gate_ld, rpg, tiles_n);
-            break;
-        case GVF_EPI_STORE_F32:
-            hipLaunchKernelGGL(gemm_bf16_kernel<GVF_EPI_STORE_F32>, grid, block, 0, stream, a, lda, w, ldw, bias, C, ldc, M, N, K, gate, gate_ld, rpg, tiles_n);
-            break;
-        case GVF_EPI_RESID_F32:
-            hipLaunchKernelGGL(gemm_bf16_kernel<GVF_EPI_RESID_F32>, grid, block, 0, stream, a, lda, w, ldw, bias, C, ldc, M, N, K, gate, gate_ld, rpg, tiles_n);
-            break;
-        default:
-            return GVF_EINVAL;
+        case GVF_EPI_STORE_BF16: GVF_GEMM_LAUNCH(GVF_EPI_STORE_BF16) break;
+        case GVF_EPI_GELU_BF16: GVF_GEMM_LAUNCH(GVF_EPI_GELU_BF16) break;
+        case GVF_EPI_STORE_F32: GVF_GEMM_LAUNCH(GVF_EPI_STORE_F32) break;
+        case GVF_EPI_RESID_F32: GVF_GEMM_LAUNCH(GVF_EPI_RESID_F32) break;
+        default: return GVF_EINVAL;
     }
+#undef GVF_GEMM_LAUNCH
     GVF_CHECK_LAUNCH();
     return GVF_OK;
 }
