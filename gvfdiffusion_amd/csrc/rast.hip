@@ -35,6 +35,8 @@
 namespace {
 
 constexpr int PRE_THREADS = 256;
+constexpr int PRE_FB = 4;   // frames per preprocess workgroup: the frame-invariant inputs (xyz, scale, rotation, opacity,
+                            // SH: 164 of the 220 input bytes per Gaussian at degree 2) come from HBM once per PRE_FB frames
 constexpr int TILE = GVF_TILE;
 constexpr int BLEND_THREADS = TILE * TILE;
 constexpr int MAX_SH_COEFFS = 16;
@@ -56,6 +58,7 @@ struct PreParams {
     GvfGaussianActivation act;
     int n_delta;
     int upstream_binning;   // 1: bin the whole 3-sigma tile rect as upstream does
+    int F;                  // frames of the call (grid.y covers them PRE_FB at a time)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -266,10 +269,8 @@ __global__ __launch_bounds__(PRE_THREADS) void preprocess_kernel(
     int32_t* __restrict__ radii, uint32_t* __restrict__ block_sums, uint4* __restrict__ binrec) {
     extern __shared__ __attribute__((aligned(16))) float sh_lds[];  // [PRE_THREADS][M*3] + 4 wave sums
     const int t = threadIdx.x;
-    const int f = blockIdx.y;
     const int P = pp.P, M = pp.M;
     const int i = blockIdx.x * PRE_THREADS + t;
-    const GvfRastFrame* fr = frames + f;
 
     // Stage this block's SH coefficients through LDS with coalesced 16-byte loads: 256 Gaussians x
     // M*3 floats are one contiguous span of the [P][M][3] tensor.
@@ -286,6 +287,10 @@ __global__ __launch_bounds__(PRE_THREADS) void preprocess_kernel(
     }
     __syncthreads();
 
+  for (int ff = 0; ff < PRE_FB; ++ff) {
+    const int f = blockIdx.y * PRE_FB + ff;
+    if (f >= pp.F) break;
+    const GvfRastFrame* fr = frames + f;
     uint32_t touched = 0;
     int radius_out = 0;
     float4 gA = make_float4(0.f, 0.f, 0.f, 0.f), gB = gA, gC = gA;
@@ -411,7 +416,7 @@ __global__ __launch_bounds__(PRE_THREADS) void preprocess_kernel(
             float4* rec = splats + 4 * o;
             rec[0] = gA; rec[1] = gB; rec[2] = gC;
         }
-        tiles_touched[o] = touched;
+        if (tiles_touched != nullptr) tiles_touched[o] = touched;   // radix binning only
         if (radii != nullptr) radii[o] = radius_out;
         // bucket binning: the final tile rect and the depth, 16 B that the count / scatter passes gather by id
         if (binrec != nullptr)
@@ -419,13 +424,17 @@ __global__ __launch_bounds__(PRE_THREADS) void preprocess_kernel(
                                    __float_as_uint(gC.y), 0u);
     }
 
-    // block sum of tiles_touched (feeds the instance-offset scan, R2)
-    const unsigned lane = t & 63, w = t >> 6;
-    uint32_t incl = gvf_wave_incl_scan(touched, lane);
-    __shared__ uint32_t wsum[PRE_THREADS / GVF_WAVE];
-    if (lane == 63) wsum[w] = incl;
-    __syncthreads();
-    if (t == 0) block_sums[(size_t)f * gridDim.x + blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    // block sum of tiles_touched (feeds the instance-offset scan, R2; radix binning only)
+    if (block_sums != nullptr) {
+        const unsigned lane = t & 63, w = t >> 6;
+        uint32_t incl = gvf_wave_incl_scan(touched, lane);
+        __shared__ uint32_t wsum[PRE_THREADS / GVF_WAVE];
+        __syncthreads();
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        if (t == 0) block_sums[(size_t)f * gridDim.x + blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1239,15 +1248,16 @@ int run_pipeline(const GvfRastSettings& st, const GvfRastFrame* frames_host, int
         PreParams pp;
         pp.P = P; pp.M = colors_precomp ? 0 : M; pp.deg = st.sh_degree; pp.H = H; pp.W = W; pp.mode = st.mode;
         pp.gx = gx; pp.gy = gy; pp.kernel_size = st.kernel_size; pp.scale_modifier = st.scale_modifier;
-        pp.fused = fused ? 1 : 0; pp.n_delta = n_delta;
+        pp.fused = fused ? 1 : 0; pp.n_delta = n_delta; pp.F = F;
         // per-pixel sub-pixel offsets move the sample positions: no box culling then (as in the blend)
         pp.upstream_binning = (st.upstream_binning != 0 || subpixel_offset != nullptr) ? 1 : 0;
         if (fused) pp.act = *act; else pp.act = GvfGaussianActivation{};
         if (bucket && hipMemsetAsync(w.tile_count, 0, sizeof(uint32_t) * nseg, stream) != hipSuccess) return GVF_ELAUNCH;
         const size_t sh_lds_bytes = gvf_align_up((size_t)PRE_THREADS * pp.M * 3 * sizeof(float), 16) + 16;
-        hipLaunchKernelGGL(preprocess_kernel, dim3(nb, F), dim3(PRE_THREADS), sh_lds_bytes, stream, pp, w.frames, a0,
-                           a1, a2, a3, colors_precomp ? nullptr : sh, colors_precomp, cov3D_precomp, delta, w.splats,
-                           w.tiles_touched, w.radii, w.block_sums, bucket ? w.binrec : nullptr);
+        hipLaunchKernelGGL(preprocess_kernel, dim3(nb, (F + PRE_FB - 1) / PRE_FB), dim3(PRE_THREADS), sh_lds_bytes, stream, pp,
+                           w.frames, a0, a1, a2, a3, colors_precomp ? nullptr : sh, colors_precomp, cov3D_precomp, delta,
+                           w.splats, bucket ? nullptr : w.tiles_touched, (bucket && out_radii == nullptr) ? nullptr : w.radii,
+                           bucket ? nullptr : w.block_sums, bucket ? w.binrec : nullptr);
         const int bnb = (P + BIN_SLOTS - 1) / BIN_SLOTS;
         if (bucket)
             hipLaunchKernelGGL(bin_kernel<false>, dim3(bnb, F), dim3(PRE_THREADS), 0, stream, P, gx, gy, w.binrec, order,
