@@ -35,6 +35,11 @@
 namespace {
 
 constexpr int PRE_THREADS = 256;
+// Depth slabs per tile (bucket binning): segment = (frame, tile, slab), each sorted independently, a tile's slabs are
+// contiguous and ordered.  Measured at the bench shape with 8 slabs: the per-tile sort does 1.8x fewer key-rounds
+// but becomes dispatch-bound (480 k mostly empty workgroups, 0.41 -> 0.63 ms) and the bin passes pay 2-4x more global
+// atomics (+0.24 ms) -- a net loss, so the machinery is kept but compiled for ONE slab.
+constexpr int NSLAB = 1;
 constexpr int PRE_FB = 4;   // frames per preprocess workgroup: the frame-invariant inputs (xyz, scale, rotation, opacity,
                             // SH: 164 of the 220 input bytes per Gaussian at degree 2) come from HBM once per PRE_FB frames
 constexpr int TILE = GVF_TILE;
@@ -266,7 +271,8 @@ __global__ __launch_bounds__(PRE_THREADS) void preprocess_kernel(
     const float* __restrict__ sh, const float* __restrict__ colors_precomp,
     const float* __restrict__ cov3D_precomp, const float* __restrict__ delta, float4* __restrict__ splats,
     uint32_t* __restrict__ tiles_touched,
-    int32_t* __restrict__ radii, uint32_t* __restrict__ block_sums, uint4* __restrict__ binrec) {
+    int32_t* __restrict__ radii, uint32_t* __restrict__ block_sums, uint4* __restrict__ binrec,
+    const float2* __restrict__ zrange /* per frame {z_lo, slabs per unit depth}; null = one slab */) {
     extern __shared__ __attribute__((aligned(16))) float sh_lds[];  // [PRE_THREADS][M*3] + 4 wave sums
     const int t = threadIdx.x;
     const int P = pp.P, M = pp.M;
@@ -419,9 +425,16 @@ __global__ __launch_bounds__(PRE_THREADS) void preprocess_kernel(
         if (tiles_touched != nullptr) tiles_touched[o] = touched;   // radix binning only
         if (radii != nullptr) radii[o] = radius_out;
         // bucket binning: the final tile rect and the depth, 16 B that the count / scatter passes gather by id
-        if (binrec != nullptr)
+        if (binrec != nullptr) {
+            // depth slab: any monotone function of depth keeps the concatenation of the sorted slabs sorted
+            uint32_t slab = 0u;
+            if (zrange != nullptr) {
+                const float2 zr = zrange[f];
+                slab = (uint32_t)fminf(fmaxf((gC.y - zr.x) * zr.y, 0.0f), (float)(NSLAB - 1));
+            }
             binrec[o] = make_uint4((uint32_t)rect.x0 | ((uint32_t)rect.y0 << 16), (uint32_t)rect.x1 | ((uint32_t)rect.y1 << 16),
-                                   __float_as_uint(gC.y), 0u);
+                                   __float_as_uint(gC.y), slab);
+        }
     }
 
     // block sum of tiles_touched (feeds the instance-offset scan, R2; radix binning only)
@@ -519,51 +532,111 @@ __global__ __launch_bounds__(PRE_THREADS) void duplicate_kernel(
 // No global sort: the order inside a segment is whatever the atomics produced, the per-tile sort below keys on
 // (depth, id) and makes it deterministic.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void tile_scan_kernel(const uint32_t* __restrict__ tile_count, int ntiles, int F,
-                                                         uint2* __restrict__ ranges, uint32_t* __restrict__ cursor,
-                                                         uint32_t* __restrict__ frame_base /*[F+1]*/,
-                                                         uint32_t* __restrict__ num_rendered /*[F]*/,
-                                                         uint32_t* __restrict__ total_out, uint32_t max_rendered) {
+// order-preserving float <-> uint32 map (atomicMin / atomicMax on floats of either sign)
+__device__ __forceinline__ uint32_t float_ordered(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float float_unordered(uint32_t o) {
+    return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+
+// Exclusive scan of the per-segment counters (segment = (frame, tile, slab); F * tiles * NSLAB of them) in two
+// launches: block sums of 4096 counters, then every block adds up the sums in front of it (at most a few hundred
+// values) and rescans its own chunk.  Writes segment ranges + cursors, per-frame D, the grand total.
+constexpr int SCAN_CHUNK = 4096;
+__global__ __launch_bounds__(1024) void seg_sums_kernel(const uint32_t* __restrict__ cnt, int n, uint32_t* __restrict__ partial) {
     __shared__ uint32_t wsum[16];
-    __shared__ uint32_t carry_s;
+    const int t = threadIdx.x, j0 = blockIdx.x * SCAN_CHUNK + 4 * t;
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s += j0 + k < n ? cnt[j0 + k] : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    if ((t & 63) == 0) wsum[t >> 6] = s;
+    __syncthreads();
+    if (t == 0) { uint32_t tot = 0; for (int k = 0; k < 16; ++k) tot += wsum[k]; partial[blockIdx.x] = tot; }
+}
+
+__global__ __launch_bounds__(1024) void seg_scan_kernel(const uint32_t* __restrict__ cnt, int n, int per_frame, int F,
+                                                        const uint32_t* __restrict__ partial, int nblocks,
+                                                        uint2* __restrict__ ranges, uint32_t* __restrict__ cursor,
+                                                        uint32_t* __restrict__ frame_base /*[F+1]*/,
+                                                        uint32_t* __restrict__ num_rendered /*[F]*/,
+                                                        uint32_t* __restrict__ total_out, uint32_t max_rendered) {
+    __shared__ uint32_t wsum[16], wtot[16];
+    __shared__ uint32_t s_base, s_total;
     const int t = threadIdx.x;
     const unsigned lane = t & 63, w = t >> 6;
-    const int n = ntiles * F;
-    if (t == 0) carry_s = 0;
+    // offset of this chunk and the grand total from the block sums
+    uint32_t before = 0, all = 0;
+    for (int k = t; k < nblocks; k += 1024) { const uint32_t p = partial[k]; all += p; if (k < (int)blockIdx.x) before += p; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { before += __shfl_xor(before, d, 64); all += __shfl_xor(all, d, 64); }
+    if (lane == 0) { wsum[w] = before; wtot[w] = all; }
     __syncthreads();
-    for (int base = 0; base < n; base += 4096) {
-        const int j0 = base + 4 * t;
-        uint32_t c[4], s = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { c[k] = j0 + k < n ? tile_count[j0 + k] : 0u; s += c[k]; }
-        const uint32_t incl = gvf_wave_incl_scan(s, lane);
-        if (lane == 63) wsum[w] = incl;
-        __syncthreads();
-        uint32_t wbase = 0, tot = 0;
-        for (unsigned k = 0; k < 16; ++k) { if (k < w) wbase += wsum[k]; tot += wsum[k]; }
-        uint32_t run = carry_s + wbase + incl - s;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int j = j0 + k;
-            if (j < n) {
-                ranges[j] = make_uint2(run, run + c[k]);
-                cursor[j] = run;
-                if (j % ntiles == 0) frame_base[j / ntiles] = run;
-            }
-            run += c[k];
-        }
-        __syncthreads();
-        if (t == 0) carry_s += tot;
-        __syncthreads();
+    if (t == 0) {
+        uint32_t b = 0, a = 0;
+        for (int k = 0; k < 16; ++k) { b += wsum[k]; a += wtot[k]; }
+        s_base = b; s_total = a;
     }
-    const uint32_t total = carry_s;
-    const bool overflow = total > max_rendered;
-    if (t == 0) { frame_base[F] = total; *total_out = overflow ? 0u : total; }
     __syncthreads();
-    for (int f = t; f < F; f += 1024) num_rendered[f] = frame_base[f + 1] - frame_base[f];
-    // Overflow (D > workspace capacity): render nothing, but the true counts above let the caller retry.
-    if (overflow)
-        for (int j = t; j < n; j += 1024) ranges[j] = make_uint2(0u, 0u);
+    const uint32_t total = s_total;
+    const bool overflow = total > max_rendered;
+    const int j0 = blockIdx.x * SCAN_CHUNK + 4 * t;
+    uint32_t c[4], s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { c[k] = j0 + k < n ? cnt[j0 + k] : 0u; s += c[k]; }
+    const uint32_t incl = gvf_wave_incl_scan(s, lane);
+    __syncthreads();
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    uint32_t run = s_base + incl - s;
+    for (unsigned k = 0; k < w; ++k) run += wsum[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int j = j0 + k;
+        if (j < n) {
+            // Overflow (D > workspace capacity): render nothing, but the true counts let the caller retry.
+            ranges[j] = overflow ? make_uint2(0u, 0u) : make_uint2(run, run + c[k]);
+            cursor[j] = run;
+            if (j % per_frame == 0) frame_base[j / per_frame] = run;
+        }
+        run += c[k];
+    }
+    if (blockIdx.x == 0 && t == 0) { frame_base[F] = total; *total_out = overflow ? 0u : total; }
+}
+
+// per-frame instance counts from the frame bases (separate tiny launch: needs every block of seg_scan_kernel done)
+__global__ void frame_counts_kernel(const uint32_t* __restrict__ frame_base, int F, uint32_t* __restrict__ num_rendered) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < F) num_rendered[f] = frame_base[f + 1] - frame_base[f];
+}
+
+// Depth range of the scene per frame: view-space z of the 8 corners of the Gaussians' bounding box (the Morton
+// stage's min/max, mapped through the GaussianModel aabb for raw inputs), widened by 2 %.  Only used to balance the
+// depth slabs: instances outside the range land in the first / last slab.
+__global__ void frame_zrange_kernel(const GvfRastFrame* __restrict__ frames, int F, const uint32_t* __restrict__ mm,
+                                    int fused, GvfGaussianActivation act, float2* __restrict__ zrange) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    float lo[3], hi[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        lo[k] = float_unordered(mm[k]); hi[k] = float_unordered(mm[3 + k]);
+        if (fused) { lo[k] = lo[k] * act.aabb[3 + k] + act.aabb[k]; hi[k] = hi[k] * act.aabb[3 + k] + act.aabb[k]; }
+        if (lo[k] > hi[k]) { const float tmp = lo[k]; lo[k] = hi[k]; hi[k] = tmp; }
+    }
+    const float* V = frames[f].viewmatrix;
+    float zmin = 3.0e38f, zmax = -3.0e38f;
+    for (int c = 0; c < 8; ++c) {
+        const float p[3] = {(c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2]};
+        const float z = V[2] * p[0] + V[6] * p[1] + V[10] * p[2] + V[14];
+        zmin = fminf(zmin, z); zmax = fmaxf(zmax, z);
+    }
+    zmin = fmaxf(zmin, 0.2f);
+    const float ext = fmaxf(zmax - zmin, 1e-6f);
+    zrange[f] = make_float2(zmin - 0.02f * ext, (float)NSLAB / (1.04f * ext));
 }
 
 // Count / scatter passes over the compact bin records, BIN_SPT slots per thread, slots taken in Morton order
@@ -581,25 +654,26 @@ __global__ __launch_bounds__(PRE_THREADS) void bin_kernel(int P, int gx, int gy,
                                                           uint32_t* __restrict__ tile_count /* count pass */,
                                                           uint32_t* __restrict__ cursor /* scatter pass */,
                                                           const uint32_t* __restrict__ total,
-                                                          uint64_t* __restrict__ payload) {
+                                                          uint64_t* __restrict__ payload, int nslab) {
     __shared__ uint32_t s_tab[WIN_MAX];
     __shared__ uint32_t s_run[SCATTER ? WIN_MAX : 1];
     __shared__ int s_box[4];
     if (SCATTER && *total == 0u) return;            // nothing visible, or capacity overflow (uniform)
     const int t = threadIdx.x, lane = t & 63, f = blockIdx.y;
     if (t == 0) { s_box[0] = 0x7fffffff; s_box[1] = 0x7fffffff; s_box[2] = 0; s_box[3] = 0; }
-    int x0[BIN_SPT], y0[BIN_SPT], x1[BIN_SPT], y1[BIN_SPT];
+    int x0[BIN_SPT], y0[BIN_SPT], x1[BIN_SPT], y1[BIN_SPT], sl[BIN_SPT];
     uint64_t key[BIN_SPT];
     int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = 0, by1 = 0;
 #pragma unroll
     for (int k = 0; k < BIN_SPT; ++k) {
         const int s = blockIdx.x * BIN_SLOTS + k * PRE_THREADS + t;
-        x0[k] = y0[k] = x1[k] = y1[k] = 0; key[k] = 0;
+        x0[k] = y0[k] = x1[k] = y1[k] = 0; sl[k] = 0; key[k] = 0;
         if (s < P) {
             const uint32_t id = order != nullptr ? order[s] : (uint32_t)s;
             const uint4 br = binrec[(size_t)f * P + id];
             x0[k] = (int)(br.x & 0xffffu); y0[k] = (int)(br.x >> 16);
             x1[k] = (int)(br.y & 0xffffu); y1[k] = (int)(br.y >> 16);
+            sl[k] = (int)br.w;
             key[k] = ((uint64_t)br.z << 32) | id;                      // depth bits above the Gaussian id
             if (x1[k] > x0[k] && y1[k] > y0[k]) {
                 bx0 = min(bx0, x0[k]); by0 = min(by0, y0[k]); bx1 = max(bx1, x1[k]); by1 = max(by1, y1[k]);
@@ -620,22 +694,23 @@ __global__ __launch_bounds__(PRE_THREADS) void bin_kernel(int P, int gx, int gy,
     __syncthreads();
     const int wx0 = s_box[0], wy0 = s_box[1], ww = s_box[2] - s_box[0], wh = s_box[3] - s_box[1];
     if (ww <= 0 || wh <= 0) return;                  // no instance in this block (uniform)
-    uint32_t* gtab = (SCATTER ? cursor : tile_count) + (size_t)f * gx * gy;
-    if (ww * wh <= WIN_MAX) {
-        const int area = ww * wh;
+    uint32_t* gtab = (SCATTER ? cursor : tile_count) + (size_t)f * gx * gy * nslab;   // [tile][slab]
+    if (ww * wh * nslab <= WIN_MAX) {
+        const int area = ww * wh * nslab;
         for (int e = t; e < area; e += PRE_THREADS) { s_tab[e] = 0u; if (SCATTER) s_run[e] = 0u; }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < BIN_SPT; ++k)
             for (int y = y0[k]; y < y1[k]; ++y)
-                for (int x = x0[k]; x < x1[k]; ++x) atomicAdd(&s_tab[(y - wy0) * ww + (x - wx0)], 1u);
+                for (int x = x0[k]; x < x1[k]; ++x) atomicAdd(&s_tab[((y - wy0) * ww + (x - wx0)) * nslab + sl[k]], 1u);
         __syncthreads();
         for (int e = t; e < area; e += PRE_THREADS) {
             const uint32_t c = s_tab[e];
             if (c != 0u) {
-                const int tile = (wy0 + e / ww) * gx + wx0 + e % ww;
-                if (SCATTER) s_tab[e] = atomicAdd(&gtab[tile], c);
-                else atomicAdd(&gtab[tile], c);
+                const int wt = e / nslab;
+                const int seg = ((wy0 + wt / ww) * gx + wx0 + wt % ww) * nslab + (e - wt * nslab);
+                if (SCATTER) s_tab[e] = atomicAdd(&gtab[seg], c);
+                else atomicAdd(&gtab[seg], c);
             }
         }
         if (SCATTER) {
@@ -644,7 +719,7 @@ __global__ __launch_bounds__(PRE_THREADS) void bin_kernel(int P, int gx, int gy,
             for (int k = 0; k < BIN_SPT; ++k)
                 for (int y = y0[k]; y < y1[k]; ++y)
                     for (int x = x0[k]; x < x1[k]; ++x) {
-                        const int e = (y - wy0) * ww + (x - wx0);
+                        const int e = ((y - wy0) * ww + (x - wx0)) * nslab + sl[k];
                         payload[s_tab[e] + atomicAdd(&s_run[e], 1u)] = key[k];
                     }
         }
@@ -653,7 +728,7 @@ __global__ __launch_bounds__(PRE_THREADS) void bin_kernel(int P, int gx, int gy,
         for (int k = 0; k < BIN_SPT; ++k)
             for (int y = y0[k]; y < y1[k]; ++y)
                 for (int x = x0[k]; x < x1[k]; ++x) {
-                    const uint32_t pos = atomicAdd(&gtab[y * gx + x], 1u);
+                    const uint32_t pos = atomicAdd(&gtab[(y * gx + x) * nslab + sl[k]], 1u);
                     if (SCATTER) payload[pos] = key[k];
                 }
     }
@@ -663,14 +738,6 @@ __global__ __launch_bounds__(PRE_THREADS) void bin_kernel(int P, int gx, int gy,
 // Spatial order of the Gaussians (once per call, shared by all frames): 15-bit Morton code of the position inside
 // the bounding box, counting-sorted.  Purely a locality device for the bin passes: any order gives the same image.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t float_ordered(float f) {
-    const uint32_t u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float float_unordered(uint32_t o) {
-    return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
-}
-
 __global__ __launch_bounds__(256) void bbox_kernel(int P, const float* __restrict__ xyz, uint32_t* __restrict__ mm) {
     __shared__ uint32_t s_mm[6];
     if (threadIdx.x < 6) s_mm[threadIdx.x] = threadIdx.x < 3 ? 0xffffffffu : 0u;
@@ -825,11 +892,11 @@ __device__ __forceinline__ void bitonic_sort_asc(Ptr keys, int n, int tid, int n
 // the same thread (m < E), the same wave (one 64-bit lane exchange, no LDS, no barrier) or another wave (LDS round
 // trip).  The +inf padding above n never moves, so a wave that holds nothing but padding (wave 3 for n <= 1536, wave
 // 2 for n <= 1024 at E = 8: the typical dense tile has ~1100 keys) skips everything except the barriers.
-template <int E>
+template <int E, int NP>
 __device__ __forceinline__ void tile_sort_regs(const uint64_t* __restrict__ k, const uint32_t* __restrict__ v,
                                                uint32_t* __restrict__ ids, int n, uint64_t* __restrict__ lds) {
     // v == nullptr: k already holds (depth bits << 32 | id) (bucket binning); else k = (tile << 32 | depth), v = id
-    constexpr int NP = 256 * E;
+    // NP <= 256 * E keys take part (threads >= NP / E only ever hold padding and idle with their wave)
     const int tid = threadIdx.x;
     const bool live = (tid & ~63) * E < n;                  // this wave holds at least one real key (wave-uniform)
     uint64_t key[E];
@@ -921,10 +988,12 @@ __global__ void tile_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __r
         const uint64_t* k = keys + rng.x;
         const uint32_t* v = vals != nullptr ? vals + rng.x : nullptr;
         uint32_t* o = ids + rng.x;
-        if (n <= 256) tile_sort_regs<1>(k, v, o, n, s_small);
-        else if (n <= 512) tile_sort_regs<2>(k, v, o, n, s_small);
-        else if (n <= 1024) tile_sort_regs<4>(k, v, o, n, s_small);
-        else tile_sort_regs<8>(k, v, o, n, s_small);
+        if (n <= 64) tile_sort_regs<1, 64>(k, v, o, n, s_small);
+        else if (n <= 128) tile_sort_regs<1, 128>(k, v, o, n, s_small);
+        else if (n <= 256) tile_sort_regs<1, 256>(k, v, o, n, s_small);
+        else if (n <= 512) tile_sort_regs<2, 512>(k, v, o, n, s_small);
+        else if (n <= 1024) tile_sort_regs<4, 1024>(k, v, o, n, s_small);
+        else tile_sort_regs<8, 2048>(k, v, o, n, s_small);
         return;
     }
     // rare classes: a small fixed grid walks the list built by classify_kernel
@@ -985,7 +1054,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
     int P, int H, int W, int gx, int gy, float bg0, float bg1, float bg2, const uint2* __restrict__ ranges,
     const uint32_t* __restrict__ point_list, const float4* __restrict__ splats,
     const float* __restrict__ subpixel_offset, float* __restrict__ out_color,
-    float* __restrict__ out_alpha, float* __restrict__ out_depth) {
+    float* __restrict__ out_alpha, float* __restrict__ out_depth, int nslab) {
     __shared__ float4 sA[BLEND_THREADS];
     __shared__ float4 sB[BLEND_THREADS];
     __shared__ float2 sC[BLEND_THREADS];
@@ -1002,7 +1071,9 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
     float pxf = (float)px, pyf = (float)py;
     if (subpixel_offset != nullptr && inside) { pxf += subpixel_offset[2 * pid]; pyf += subpixel_offset[2 * pid + 1]; }
 
-    const uint2 rng = ranges[(size_t)f * gx * gy + tile];
+    // a tile's instances = its nslab consecutive depth-slab segments (contiguous in memory, each sorted, slabs ordered)
+    const size_t seg0 = ((size_t)f * gx * gy + tile) * nslab;
+    const uint2 rng = make_uint2(ranges[seg0].x, ranges[seg0 + nslab - 1].y);
     const size_t gbase = (size_t)f * P;
     const int rounds = (int)((rng.y - rng.x + BLEND_THREADS - 1) / BLEND_THREADS);
     int todo = (int)(rng.y - rng.x);
@@ -1138,7 +1209,8 @@ struct Workspace {
     uint32_t* block_sums; uint32_t* frame_base; uint32_t* total;
     uint64_t* keys; uint64_t* keys_alt; uint32_t* vals; uint32_t* vals_alt; uint32_t* ids;
     uint2* ranges; uint32_t* cls;
-    uint32_t* tile_count; uint32_t* cursor;            // bucket binning: [F*ntiles] each
+    uint32_t* tile_count; uint32_t* cursor;            // bucket binning: [F*ntiles*NSLAB] each
+    uint32_t* partial; float2* zrange;
     uint32_t* order; uint32_t* order_alt; uint32_t* mhist; uint32_t* mm;
     uint4* binrec;                                     // [F*P] {x0|y0<<16, x1|y1<<16, depth bits, -}
     void* sort_tmp; size_t sort_tmp_bytes;
@@ -1171,10 +1243,12 @@ Workspace carve(void* ws, size_t bytes, int P, int F, int H, int W, int64_t max_
     w.vals = c.take<uint32_t>(D);
     w.vals_alt = c.take<uint32_t>(D);
     w.ids = c.take<uint32_t>(D);
-    w.ranges = c.take<uint2>((size_t)F * ntiles);
-    w.cls = c.take<uint32_t>(2 + 2 * (size_t)F * ntiles);
-    w.tile_count = c.take<uint32_t>((size_t)F * ntiles);
-    w.cursor = c.take<uint32_t>((size_t)F * ntiles);
+    w.ranges = c.take<uint2>((size_t)F * ntiles * NSLAB);
+    w.cls = c.take<uint32_t>(2 + 2 * (size_t)F * ntiles * NSLAB);
+    w.tile_count = c.take<uint32_t>((size_t)F * ntiles * NSLAB);
+    w.cursor = c.take<uint32_t>((size_t)F * ntiles * NSLAB);
+    w.partial = c.take<uint32_t>(((size_t)F * ntiles * NSLAB + SCAN_CHUNK - 1) / SCAN_CHUNK + 1);
+    w.zrange = c.take<float2>(F);
     const size_t Pp = (size_t)(P > 0 ? P : 1);
     w.order = c.take<uint32_t>(Pp);
     w.order_alt = c.take<uint32_t>(Pp);
@@ -1220,14 +1294,14 @@ int run_pipeline(const GvfRastSettings& st, const GvfRastFrame* frames_host, int
         hipLaunchKernelGGL(upload_frames_kernel, dim3(1), dim3(256), 0, stream, ch, cnt, w.frames + f0);
     }
     GVF_CHECK_LAUNCH();
-    if (hipMemsetAsync(w.ranges, 0, sizeof(uint2) * (size_t)F * ntiles, stream) != hipSuccess) return GVF_ELAUNCH;
+    if (hipMemsetAsync(w.ranges, 0, sizeof(uint2) * (size_t)F * ntiles * NSLAB, stream) != hipSuccess) return GVF_ELAUNCH;
 
+    int nslab_blend = 1;
     if (P == 0 || nb == 0) {
         // nothing to splat: background only
         if (hipMemsetAsync(out_num_rendered, 0, sizeof(uint32_t) * F, stream) != hipSuccess) return GVF_ELAUNCH;
     } else {
         const bool bucket = st.bin_algo != GVF_RAST_BIN_RADIX;
-        const unsigned nseg = (unsigned)((size_t)F * ntiles);
         prof_mark(stream, slot, 0);
         // ---- spatial order of the Gaussians (bucket binning, several frames to amortise it over) ----
         const uint32_t* order = nullptr;
@@ -1242,8 +1316,15 @@ int run_pipeline(const GvfRastSettings& st, const GvfRastFrame* frames_host, int
             hipLaunchKernelGGL(morton_scan_kernel, dim3(1), dim3(1024), 0, stream, w.mhist);
             hipLaunchKernelGGL(morton_scatter_kernel, dim3(pb), dim3(256), 0, stream, P, w.order_alt, w.mhist, w.order);
             order = w.order;
+            if (NSLAB > 1)
+                hipLaunchKernelGGL(frame_zrange_kernel, dim3((F + 63) / 64), dim3(64), 0, stream, w.frames, F, w.mm, fused ? 1 : 0,
+                                   fused ? *act : GvfGaussianActivation{}, w.zrange);
             GVF_CHECK_LAUNCH();
         }
+        // depth slabs need the scene's depth range, which comes with the Morton stage: one slab otherwise
+        const int nslab = order != nullptr ? NSLAB : 1;
+        nslab_blend = nslab;
+        const unsigned nseg = (unsigned)((size_t)F * ntiles * nslab);
         prof_mark(stream, slot, 1);
         PreParams pp;
         pp.P = P; pp.M = colors_precomp ? 0 : M; pp.deg = st.sh_degree; pp.H = H; pp.W = W; pp.mode = st.mode;
@@ -1257,16 +1338,23 @@ int run_pipeline(const GvfRastSettings& st, const GvfRastFrame* frames_host, int
         hipLaunchKernelGGL(preprocess_kernel, dim3(nb, (F + PRE_FB - 1) / PRE_FB), dim3(PRE_THREADS), sh_lds_bytes, stream, pp,
                            w.frames, a0, a1, a2, a3, colors_precomp ? nullptr : sh, colors_precomp, cov3D_precomp, delta,
                            w.splats, bucket ? nullptr : w.tiles_touched, (bucket && out_radii == nullptr) ? nullptr : w.radii,
-                           bucket ? nullptr : w.block_sums, bucket ? w.binrec : nullptr);
+                           bucket ? nullptr : w.block_sums, bucket ? w.binrec : nullptr,
+                           (bucket && nslab > 1) ? w.zrange : nullptr);
         const int bnb = (P + BIN_SLOTS - 1) / BIN_SLOTS;
         if (bucket)
             hipLaunchKernelGGL(bin_kernel<false>, dim3(bnb, F), dim3(PRE_THREADS), 0, stream, P, gx, gy, w.binrec, order,
-                               w.tile_count, w.cursor, w.total, w.keys);
+                               w.tile_count, w.cursor, w.total, w.keys, nslab);
         GVF_CHECK_LAUNCH();
         prof_mark(stream, slot, 2);
         if (bucket)
-            hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, w.tile_count, ntiles, F, w.ranges, w.cursor,
-                               w.frame_base, out_num_rendered, w.total, (uint32_t)max_rendered);
+        {
+            const int sblocks = (int)((nseg + SCAN_CHUNK - 1) / SCAN_CHUNK);
+            hipLaunchKernelGGL(seg_sums_kernel, dim3(sblocks), dim3(1024), 0, stream, w.tile_count, (int)nseg, w.partial);
+            hipLaunchKernelGGL(seg_scan_kernel, dim3(sblocks), dim3(1024), 0, stream, w.tile_count, (int)nseg, ntiles * nslab, F,
+                               w.partial, sblocks, w.ranges, w.cursor, w.frame_base, out_num_rendered, w.total,
+                               (uint32_t)max_rendered);
+            hipLaunchKernelGGL(frame_counts_kernel, dim3((F + 63) / 64), dim3(64), 0, stream, w.frame_base, F, out_num_rendered);
+        }
         else
             hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, stream, w.block_sums, nb, F, w.frame_base,
                                out_num_rendered, w.total, (uint32_t)max_rendered);
@@ -1275,7 +1363,7 @@ int run_pipeline(const GvfRastSettings& st, const GvfRastFrame* frames_host, int
         if (max_rendered > 0) {
             if (bucket)
                 hipLaunchKernelGGL(bin_kernel<true>, dim3(bnb, F), dim3(PRE_THREADS), 0, stream, P, gx, gy, w.binrec, order,
-                                   w.tile_count, w.cursor, w.total, w.keys);
+                                   w.tile_count, w.cursor, w.total, w.keys, nslab);
             else
                 hipLaunchKernelGGL(duplicate_kernel, dim3(nb, F), dim3(PRE_THREADS), 0, stream, P, gx, gy, w.splats,
                                    w.tiles_touched, w.radii, w.block_sums, w.keys, w.vals, (uint32_t)max_rendered,
@@ -1327,7 +1415,7 @@ int run_pipeline(const GvfRastSettings& st, const GvfRastFrame* frames_host, int
     prof_mark(stream, slot, 6);
     hipLaunchKernelGGL(blend_kernel, dim3(ntiles, F), dim3(BLEND_THREADS), 0, stream, P, H, W, gx, gy, st.bg[0],
                        st.bg[1], st.bg[2], w.ranges, vals_sorted, w.splats, subpixel_offset,
-                       out_color, out_alpha, out_depth);
+                       out_color, out_alpha, out_depth, nslab_blend);
     GVF_CHECK_LAUNCH();
     prof_mark(stream, slot, 7);
     return GVF_OK;
