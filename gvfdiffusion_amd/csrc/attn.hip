@@ -341,6 +341,115 @@ __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(AttnParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Short sequences (Lq, Lk <= 32, head_dim 32): the DiT's temporal self-attention is 512 tokens x 16 heads = 8192
+// independent (sequence, head) problems of 24 x 24 scores per sample.  The tiled kernel above gives each of them a
+// 128-query workgroup (81 % padding) and a staged 64-key tile; here ONE WAVE owns one problem: Q and K rows go
+// straight from global memory into MFMA operand registers (lane = row, two 16-byte chunks), S^T = K Q^T is one
+// 32x32 accumulator, the softmax is a 16-element in-lane reduction plus one exchange with lane ^ 32, V is bounced
+// through a 2 KiB per-wave LDS slab to be read back key-major -> d-major, O^T = V^T P^T, 8-byte stores.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int SM_VLD = 36;                       // bf16 pitch of the staged V rows (72 B: conflict-free column reads)
+
+__global__ __launch_bounds__(THREADS) void attn_small_kernel(AttnParams p, long long n_problems) {
+    __shared__ unsigned short sV[THREADS / 64][32 * SM_VLD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long prob = (long long)blockIdx.x * (THREADS / 64) + wave;
+    if (prob >= n_problems) return;
+    const int h = (int)(prob % p.H);
+    const long long oi = prob / p.H;
+    const int inner = (int)(oi % p.n_inner);
+    const long long outer = oi / p.n_inner;
+    const int l31 = lane & 31, half = lane >> 5;
+    const unsigned short* qb = p.q + outer * p.q_so + inner * p.q_si + h * p.q_sh;
+    const unsigned short* kb = p.k + outer * p.k_so + inner * p.k_si + h * p.k_sh;
+    const unsigned short* vb = p.v + outer * p.v_so + inner * p.v_si + h * p.v_sh;
+    unsigned short* ob = p.out + outer * p.o_so + inner * p.o_si + h * p.o_sh;
+
+    // lane (row l31, half): 16-byte chunks `half` and `2 + half` of the row = the two k-steps of its MFMA operand
+    const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+    uint4 qc[2] = {z4, z4}, kc[2] = {z4, z4}, vc[2] = {z4, z4};
+    if (l31 < p.Lq) {
+        const uint4* r = reinterpret_cast<const uint4*>(qb + (long long)l31 * p.q_sl);
+        qc[0] = r[half]; qc[1] = r[2 + half];
+    }
+    if (l31 < p.Lk) {
+        const uint4* r = reinterpret_cast<const uint4*>(kb + (long long)l31 * p.k_sl);
+        kc[0] = r[half]; kc[1] = r[2 + half];
+        const uint4* rv = reinterpret_cast<const uint4*>(vb + (long long)l31 * p.v_sl);
+        vc[0] = rv[half]; vc[1] = rv[2 + half];
+    }
+    // stage V row-major (pitch SM_VLD): chunk c of row l31 at element offset l31 * SM_VLD + 8 * c
+    {
+        unsigned short* dst = &sV[wave][l31 * SM_VLD];
+        *reinterpret_cast<uint2*>(dst + 8 * half) = make_uint2(vc[0].x, vc[0].y);
+        *reinterpret_cast<uint2*>(dst + 8 * half + 4) = make_uint2(vc[0].z, vc[0].w);
+        *reinterpret_cast<uint2*>(dst + 8 * (2 + half)) = make_uint2(vc[1].x, vc[1].y);
+        *reinterpret_cast<uint2*>(dst + 8 * (2 + half) + 4) = make_uint2(vc[1].z, vc[1].w);
+    }
+    // fused MultiHeadRMSNorm: a row's 32 elements live in this lane's two chunks and in lane ^ 32's
+    if (p.gamma_q != nullptr) {
+        float ss = sumsq8(qc[0]) + sumsq8(qc[1]);
+        ss += __shfl_xor(ss, 32, 64);
+        const float* g = p.gamma_q + h * 32;
+        qc[0] = rms_apply<32>(qc[0], ss, g + 8 * half);
+        qc[1] = rms_apply<32>(qc[1], ss, g + 8 * (2 + half));
+    }
+    if (p.gamma_k != nullptr) {
+        float ss = sumsq8(kc[0]) + sumsq8(kc[1]);
+        ss += __shfl_xor(ss, 32, 64);
+        const float* g = p.gamma_k + h * 32;
+        kc[0] = rms_apply<32>(kc[0], ss, g + 8 * half);
+        kc[1] = rms_apply<32>(kc[1], ss, g + 8 * (2 + half));
+    }
+    // S^T = K Q^T : accumulator column = query l31, row r = key (r & 3) + 8 (r >> 2) + 4 half
+    f32x16 s_acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+        s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kc[st]), __builtin_bit_cast(bf16x8, qc[st]),
+                                                        s_acc, 0, 0, 0);
+    float m = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        if (((r & 3) + 8 * (r >> 2) + 4 * half) >= p.Lk) s_acc[r] = -INFINITY;
+        m = max2f(m, s_acc[r]);
+    }
+    m = max2f(m, __shfl_xor(m, 32, 64));                 // Lk >= 1: finite
+    const float ms = m * p.scale_log2e;
+    float pr[16], l = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { pr[r] = exp2f(s_acc[r] * p.scale_log2e - ms); l += pr[r]; }
+    l += __shfl_xor(l, 32, 64);
+    // O^T = V^T P^T.  MFMA k-slot (half, e) of step t <-> key 16 t + 4 half + (e & 3) + 8 (e >> 2): the order the
+    // probabilities already have in this lane; V^T's operand gathers the matching keys from the staged rows.
+    __builtin_amdgcn_wave_barrier();
+    f32x16 o_acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        uint4 pf, vf;
+        pf.x = cvt_pk_bf16(pr[8 * t + 0], pr[8 * t + 1]); pf.y = cvt_pk_bf16(pr[8 * t + 2], pr[8 * t + 3]);
+        pf.z = cvt_pk_bf16(pr[8 * t + 4], pr[8 * t + 5]); pf.w = cvt_pk_bf16(pr[8 * t + 6], pr[8 * t + 7]);
+        const unsigned short* col = &sV[wave][(16 * t + 4 * half) * SM_VLD + l31];      // V[key][d = l31]
+        vf.x = (unsigned)col[0 * SM_VLD] | ((unsigned)col[1 * SM_VLD] << 16);
+        vf.y = (unsigned)col[2 * SM_VLD] | ((unsigned)col[3 * SM_VLD] << 16);
+        vf.z = (unsigned)col[8 * SM_VLD] | ((unsigned)col[9 * SM_VLD] << 16);
+        vf.w = (unsigned)col[10 * SM_VLD] | ((unsigned)col[11 * SM_VLD] << 16);
+        o_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), __builtin_bit_cast(bf16x8, pf), o_acc, 0, 0, 0);
+    }
+    // accumulator column = query l31, row r = d (r & 3) + 8 (r >> 2) + 4 half : four 8-byte stores per lane
+    if (l31 < p.Lq) {
+        const float inv = 1.0f / l;
+        unsigned short* orow = ob + (long long)l31 * p.o_sl;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint2 w2;
+            w2.x = cvt_pk_bf16(o_acc[4 * i + 0] * inv, o_acc[4 * i + 1] * inv);
+            w2.y = cvt_pk_bf16(o_acc[4 * i + 2] * inv, o_acc[4 * i + 3] * inv);
+            *reinterpret_cast<uint2*>(orow + 8 * i + 4 * half) = w2;
+        }
+    }
+}
+
 int launch_attn(const void* q, const void* k, const void* v, void* out, int n_outer, int n_inner, int Lq, int Lk, int H,
                 int D, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                 const int64_t* o_strides, int v_transposed, const int32_t* cu_q, const int32_t* cu_k,
@@ -370,6 +479,12 @@ int launch_attn(const void* q, const void* k, const void* v, void* out, int n_ou
     if (blocks > 0x7fffffffLL) return GVF_EINVAL;
     (void)hipGetLastError();
     const dim3 grid((unsigned)blocks), block(THREADS);
+    if (D == 32 && !v_transposed && cu_q == nullptr && Lq <= 32 && Lk <= 32) {
+        const long long n_problems = (long long)H * n_inner * n_outer;
+        hipLaunchKernelGGL(attn_small_kernel, dim3((unsigned)((n_problems + 3) / 4)), block, 0, stream, p, n_problems);
+        GVF_CHECK_LAUNCH();
+        return GVF_OK;
+    }
     if (D == 32) {
         if (v_transposed) hipLaunchKernelGGL((attn_fwd_kernel<32, true>), grid, block, 0, stream, p);
         else hipLaunchKernelGGL((attn_fwd_kernel<32, false>), grid, block, 0, stream, p);

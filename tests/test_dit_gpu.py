@@ -66,7 +66,8 @@ def _attn_ref(q, k, v, gq, gk):
     return dit_ref.sdpa(q.float(), k.float(), v.float(), "bf16")
 
 
-@pytest.mark.parametrize("N,Lq,Lk,H", [(3, 200, 77, 2), (2, 512, 512, 16), (1, 130, 1370, 4), (5, 24, 24, 3), (2, 33, 4096, 2)])
+@pytest.mark.parametrize("N,Lq,Lk,H", [(3, 200, 77, 2), (2, 512, 512, 16), (1, 130, 1370, 4), (5, 24, 24, 3), (2, 33, 4096, 2),
+                                        (7, 17, 32, 2), (4, 32, 9, 1), (3, 1, 1, 2), (6, 33, 24, 2)])   # <= 32 x 32: one-wave kernel
 @pytest.mark.parametrize("rms", [False, True])
 def test_attention_matches_oracle(cuda, N, Lq, Lk, H, rms):
     g = torch.Generator().manual_seed(N * 1000 + Lq + Lk)
@@ -90,7 +91,10 @@ def test_attention_matches_oracle(cuda, N, Lq, Lk, H, rms):
     out2 = torch.empty_like(q)
     dit_ops.attention_bf16(q, kh, vt, out2, N, 1, Lq, Lk, H, sq, (H * Lk * 32, 0, 32, Lk * 32), (H * 32 * Lp, 0, Lp, 32 * Lp),
                            sq, gq, gk, v_transposed=True)
-    assert torch.equal(out2, out)
+    if Lq <= 32 and Lk <= 32:     # `out` came from the one-wave short-sequence kernel, `out2` from the tiled one
+        assert rel_l2(out2, out) < 3e-3
+    else:
+        assert torch.equal(out2, out)
 
 
 def test_attention_operator_call_forms_and_strided_views(cuda):
