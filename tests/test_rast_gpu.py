@@ -272,6 +272,18 @@ def test_full_size_frame_config2(cuda, oracle_lib):
     # out = C + T*bg  =>  white - black == T == 1 - alpha  (compositing identity, size independent)
     assert ((w.rgb - b.rgb) - (1 - w.alpha)[:, None]).abs().max() < 2e-6
     assert w.alpha.min() >= 0 and w.alpha.max() <= 1 - 1e-4 + 1e-6      # T never drops below 1e-4
+    # the two binning algorithms (Morton-ordered bucket passes vs radix on the tile bits) and upstream's 3-sigma
+    # binning must give the same 24 frames bit for bit: the per-tile (depth, id) order is a total order
+    from gvfdiffusion_amd import rasterizer as R, _lib
+    this_algo = R.DEFAULT_BIN_ALGO
+    R.DEFAULT_BIN_ALGO = _lib.RAST_BIN_RADIX if this_algo != _lib.RAST_BIN_RADIX else _lib.RAST_BIN_BUCKET
+    try:
+        w_other = white.render_frames(gm, ext, K, delta_pc=delta, want_alpha_depth=True)
+    finally:
+        R.DEFAULT_BIN_ALGO = this_algo
+    assert torch.equal(w_other.rgb, w.rgb) and torch.equal(w_other.alpha, w.alpha) and torch.equal(w_other.depth, w.depth)
+    assert torch.equal(w_other.num_rendered, w.num_rendered)
+    del w_other
     # permuting the Gaussians changes a frame only where two splats of one pixel have bit-identical
     # depth (ties are broken by index, as upstream's stable sort does): with 262144 depths in [1.5,2.5]
     # (float spacing 1.2e-7) a few thousand exact ties exist, so allow a tiny fraction of pixels
