@@ -8,26 +8,31 @@
 // -ffp-contract=off) is the floating-point contract stated in oracle/rast_oracle.c, so that all
 // discrete decisions (cull, radius, tile rect, sort order) match the oracle bit for bit.
 //
-// Launch structure (F frames per call, everything stream-ordered, no host sync; D is read from device memory):
-//   preprocess   grid (ceil(P/256), F)   activations (+deltas), EWA covariance, 2D filter, radius, tile rect, SH -> RGB;
-//                                        writes one 64-byte splat record + tiles_touched; per-block sums
-//   scan_sums    1 workgroup             exclusive scan of the block sums -> instance offsets, per-frame D
-//   duplicate    grid (ceil(P/256), F)   (frame*tiles + tile) << 32 | depth_bits keys + Gaussian ids
-//   radix (x2)   <=1024 workgroups       stable 8-bit LSD passes over the (frame, tile) key bits only (sort.hip)
-//   ranges       per instance            [start, end) of every (frame, tile) segment
-//   classify + tile_sort                 per-tile bitonic sort of (depth_bits << 32 | id): registers+shuffles for
-//                                        segments <= 2048, LDS <= 16384, in-place global beyond; writes ordered ids
+// Launch structure (F frames per call, everything stream-ordered, no host sync; D is read from device memory).
+// Default = BUCKET binning (GvfRastSettings.bin_algo):
+//   bbox, morton_count/scan/scatter      once per call: 15-bit Morton order of the Gaussians (locality for the bin passes)
+//   preprocess   grid (ceil(P/256), F/4) activations (+deltas), EWA covariance, 2D filter, radius, tile rect, alpha-box
+//                                        instance culling, SH -> RGB; writes one 64-byte splat record + a 16-byte bin record
+//   bin<count>   grid (ceil(P/1024), F)  per-(frame, tile) instance counts: LDS histogram per block, one global atomic
+//                                        per touched tile
+//   seg_sums, seg_scan, frame_counts     exclusive scan of the counters = tile ranges + cursors, per-frame D, overflow guard
+//   bin<scatter> grid (ceil(P/1024), F)  (depth_bits << 32 | id) into the tile segments (order inside a segment arbitrary)
+//   classify + tile_sort                 per-tile bitonic sort: registers+shuffles for segments <= 2048, LDS <= 16384,
+//                                        in-place global beyond; writes ordered ids (= upstream's stable (tile, depth) order)
 //   blend        grid (tiles, F)         16x16 px per workgroup, 4 waves = the four 8x8 quadrants
+// RADIX binning (kept for comparison): preprocess (+block sums) -> scan_sums -> duplicate ((frame*tiles + tile) << 32 |
+// depth keys + ids) -> two stable 8-bit LSD passes over the (frame, tile) key bits (sort.hip) -> ranges -> tile_sort.
 // Upstream sorts all 64-bit (tile, depth) keys with one global radix sort (>= 6 passes over 12 B per instance);
-// here only the ~16 tile bits go through global passes and the depth order is produced on chip.
+// here no global sort is left and the depth order is produced on chip.
 //
 // HBM layout (caller-owned workspace, carved below): per (frame, Gaussian) ONE 64-byte, 64-byte-aligned record
 //   float4 {x, y, conic_a, conic_b} | float4 {conic_c, opacity, r, g} | float4 {b, depth, hx, hy} | 16 B unused
 // so the blend's gather of a (splat, tile) instance touches exactly one cache line (three 40-B-total arrays cost
 // three lines per instance: 5.7 GB of fabric reads per 24-frame step measured with FETCH_SIZE, vs 1.1 GB
-// algorithmic); hx, hy = half extents of the region where alpha can reach 1/255 (quadrant culling), computed
-// once per visible Gaussian instead of once per instance.  Plus tiles_touched u32 / radii i32; per instance one
-// u64 key + u32 id (double buffered for the radix passes) and one u32 ordered id.
+// algorithmic); hx, hy = half extents of the region where alpha can reach 1/255 (instance and quadrant culling),
+// computed once per visible Gaussian.  A 16-byte bin record {x0|y0<<16, x1|y1<<16, depth bits, slab}; per
+// (frame, tile) a range, a counter and a cursor; per instance one u64 key and one u32 ordered id (radix path:
+// u64 key + u32 id, double buffered).
 #include "gvf_common.h"
 #include "gvf_sort.h"
 #include "../../include/gvf_rast.h"
