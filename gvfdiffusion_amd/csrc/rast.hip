@@ -897,9 +897,10 @@ __device__ __forceinline__ void bitonic_sort_asc(Ptr keys, int n, int tid, int n
 // the same thread (m < E), the same wave (one 64-bit lane exchange, no LDS, no barrier) or another wave (LDS round
 // trip).  The +inf padding above n never moves, so a wave that holds nothing but padding (wave 3 for n <= 1536, wave
 // 2 for n <= 1024 at E = 8: the typical dense tile has ~1100 keys) skips everything except the barriers.
-template <int E, int NP>
+template <int E, int NP, bool OUT_LDS = false>
 __device__ __forceinline__ void tile_sort_regs(const uint64_t* __restrict__ k, const uint32_t* __restrict__ v,
                                                uint32_t* __restrict__ ids, int n, uint64_t* __restrict__ lds) {
+    // OUT_LDS: leave the sorted 64-bit keys in lds[0, n) (for the two-run merge below) instead of writing the ids
     // v == nullptr: k already holds (depth bits << 32 | id) (bucket binning); else k = (tile << 32 | depth), v = id
     // NP <= 256 * E keys take part (threads >= NP / E only ever hold padding and idle with their wave)
     const int tid = threadIdx.x;
@@ -962,11 +963,30 @@ __device__ __forceinline__ void tile_sort_regs(const uint64_t* __restrict__ k, c
             }
         }
     }
+    if (OUT_LDS) {
+        __syncthreads();                                    // the last exchange step may still be reading lds
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            const int e = tid * E + r;
+            if (e < n) lds[e] = key[r];
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < E; ++r) {
         const int e = tid * E + r;
         if (e < n) ids[e] = (uint32_t)key[r];
     }
+}
+
+// number of keys < x in the sorted run a[0, n)
+__device__ __forceinline__ int lower_bound_u64(const uint64_t* a, int n, uint64_t x) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    return lo;
 }
 
 // tile lists of the two rare size classes, filled by classify_kernel: [0] count large, [1] count huge, then indices
@@ -998,7 +1018,28 @@ __global__ void tile_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __r
         else if (n <= 256) tile_sort_regs<1, 256>(k, v, o, n, s_small);
         else if (n <= 512) tile_sort_regs<2, 512>(k, v, o, n, s_small);
         else if (n <= 1024) tile_sort_regs<4, 1024>(k, v, o, n, s_small);
-        else tile_sort_regs<8, 2048>(k, v, o, n, s_small);
+        else {
+            // 1024 < n <= 2048.  One 2048-key network would cost 66 rounds x 8 keys per thread even for 1025 keys (and
+            // dense tiles sit just above 1024: 61 % of all keys at the bench shape are in segments of 1025-1280).
+            // Instead: sort the first 1024 keys and the remaining n - 1024 as two runs (55 rounds x 4 keys + a small
+            // network), then merge by rank -- keys are unique (they end in the Gaussian id), so an element's final
+            // position is its index in its own run plus the number of smaller keys in the other run.
+            const int nb = n - 1024;
+            const uint32_t* vb = v != nullptr ? v + 1024 : nullptr;
+            tile_sort_regs<4, 1024, true>(k, v, o, 1024, s_small);
+            if (nb <= 64) tile_sort_regs<1, 64, true>(k + 1024, vb, o, nb, s_small + 1024);
+            else if (nb <= 128) tile_sort_regs<1, 128, true>(k + 1024, vb, o, nb, s_small + 1024);
+            else if (nb <= 256) tile_sort_regs<1, 256, true>(k + 1024, vb, o, nb, s_small + 1024);
+            else if (nb <= 512) tile_sort_regs<2, 512, true>(k + 1024, vb, o, nb, s_small + 1024);
+            else tile_sort_regs<4, 1024, true>(k + 1024, vb, o, nb, s_small + 1024);
+            __syncthreads();
+            for (int e = threadIdx.x; e < n; e += 256) {
+                const uint64_t key = s_small[e];
+                const int pos = e < 1024 ? e + lower_bound_u64(s_small + 1024, nb, key)
+                                         : (e - 1024) + lower_bound_u64(s_small, 1024, key);
+                o[pos] = (uint32_t)key;
+            }
+        }
         return;
     }
     // rare classes: a small fixed grid walks the list built by classify_kernel
