@@ -2,7 +2,7 @@
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package
 (never gvfdiffusion_amd/).  It wraps the plain-C restatements in this directory
-(rast_oracle.c, vox2seq_oracle.c -> libgvf_oracle.so, built by `make -C oracle`) and holds the
+(rast_oracle.c, rast_bwd_oracle.c, vox2seq_oracle.c -> libgvf_oracle.so, built by `make -C oracle`) and holds the
 torch-fp32 restatements of the floating-point DiT / sampler path (dit_ref.py, dpm_ref.py).
 """
 import ctypes
@@ -17,7 +17,7 @@ _LIB = None
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "libgvf_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("rast_oracle.c", "vox2seq_oracle.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("rast_oracle.c", "rast_bwd_oracle.c", "vox2seq_oracle.c", "Makefile")]
     stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-B", "libgvf_oracle.so"], stdout=subprocess.DEVNULL)
@@ -147,3 +147,56 @@ def vox2seq_encode(coords, mode="z_order"):
 def vox2seq_decode(codes, mode="z_order"):
     fn = lib().gvfo_z_order_decode if mode == "z_order" else lib().gvfo_hilbert_decode
     return _vox(fn, codes, None, None, 3)
+
+
+# ---- double-precision forward + backward of the rasteriser operator (rast_bwd_oracle.c) -----------------------
+def _f64(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p64(a):
+    return None if a is None else a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def _scene64(means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, H, W, tanfovx, tanfovy,
+             kernel_size, scale_modifier, mode, viewmatrix, projmatrix, campos, sh_degree, bg):
+    m3 = _f64(means3D); P = m3.shape[0]
+    sh = _f64(shs); M = 0 if sh is None else sh.shape[1]
+    keep = (m3, sh, _f64(colors_precomp), _f64(np.reshape(opacities, (-1,))), _f64(scales), _f64(rotations),
+            _f64(cov3D_precomp), _f64(np.reshape(viewmatrix, (-1,))), _f64(np.reshape(projmatrix, (-1,))), _f64(campos), _f64(bg))
+    d = ctypes.c_double
+    args = [P, M, int(sh_degree)] + [_p64(a) for a in keep[:7]] + [int(H), int(W), d(tanfovx), d(tanfovy), d(kernel_size),
+                                                                   d(scale_modifier), int(mode)] + [_p64(a) for a in keep[7:]]
+    return P, M, keep, args
+
+
+def rast64_forward(means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, *, H, W, tanfovx, tanfovy,
+                   kernel_size, scale_modifier, mode, viewmatrix, projmatrix, campos, sh_degree, bg):
+    """Double-precision forward: dict(color[3,H,W], alpha[H,W], depth[H,W])."""
+    P, M, keep, args = _scene64(means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, H, W, tanfovx,
+                                tanfovy, kernel_size, scale_modifier, mode, viewmatrix, projmatrix, campos, sh_degree, bg)
+    color, alpha, depth = np.zeros((3, H, W)), np.zeros((H, W)), np.zeros((H, W))
+    rc = lib().gvfo64_forward(*args, _p64(color), _p64(alpha), _p64(depth))
+    assert rc == 0
+    return dict(color=color, alpha=alpha, depth=depth)
+
+
+def rast64_backward(means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, dL_dcolor, dL_dalpha=None,
+                    dL_ddepth=None, *, H, W, tanfovx, tanfovy, kernel_size, scale_modifier, mode, viewmatrix, projmatrix,
+                    campos, sh_degree, bg):
+    """Double-precision gradients of sum(dL_dcolor*color) + sum(dL_dalpha*alpha) + sum(dL_ddepth*depth):
+    dict(means3D, means2D [NDC units], shs | colors_precomp, opacities, scales, rotations | cov3D_precomp)."""
+    P, M, keep, args = _scene64(means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, H, W, tanfovx,
+                                tanfovy, kernel_size, scale_modifier, mode, viewmatrix, projmatrix, campos, sh_degree, bg)
+    gc, ga, gd = _f64(dL_dcolor), _f64(dL_dalpha), _f64(dL_ddepth)
+    out = dict(means3D=np.zeros((P, 3)), means2D=np.zeros((P, 2)), opacities=np.zeros((P,)))
+    g_shs = np.zeros((P, M, 3)) if shs is not None else None
+    g_col = np.zeros((P, 3)) if colors_precomp is not None else None
+    g_sc = np.zeros((P, 3)) if cov3D_precomp is None else None
+    g_ro = np.zeros((P, 4)) if cov3D_precomp is None else None
+    g_c6 = np.zeros((P, 6))
+    rc = lib().gvfo64_backward(*args, _p64(gc), _p64(ga), _p64(gd), _p64(out["means3D"]), _p64(out["means2D"]), _p64(g_shs),
+                               _p64(g_col), _p64(out["opacities"]), _p64(g_sc), _p64(g_ro), _p64(g_c6))
+    assert rc == 0
+    out.update(shs=g_shs, colors_precomp=g_col, scales=g_sc, rotations=g_ro, cov3D_precomp=g_c6)
+    return out
