@@ -1467,6 +1467,374 @@ int run_pipeline(const GvfRastSettings& st, const GvfRastFrame* frames_host, int
     return GVF_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// R7: backward of the operator (SURVEY.md section 8f NEXT #4; upstream backward.cu restated from its published
+// algorithm, checked against oracle/rast_bwd_oracle.c which is pinned by finite differences).
+// Conventions taken over from upstream: the gradient passes THROUGH alpha = min(0.99, .); a clamped EWA view
+// coordinate gets no gradient; the screen-space mean's gradient is reported in NDC units.
+// ---------------------------------------------------------------------------------------------
+constexpr int BWD_ACC = 10;   // per Gaussian: d/dx, d/dy [pixels], d/d(conic a, b, c), d/d(opacity_eff), d/d(r, g, b), d/d(depth)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// One workgroup per 16x16 tile.  Phase A replays the forward compositing over the tile's sorted list (same
+// arithmetic as blend_kernel, so the same skip / stop decisions) to get each pixel's final transmittance and the
+// list position after its last contributor; phase B walks the list back to front, forms the per-(pixel, splat)
+// gradients, sums them over the 64 pixels of a wave and adds the wave sums to the per-Gaussian accumulators with
+// hardware fp32 atomics.
+__global__ __launch_bounds__(BLEND_THREADS) void blend_backward_kernel(
+    int P, int H, int W, int gx, float bg0, float bg1, float bg2, const uint2* __restrict__ ranges,
+    const uint32_t* __restrict__ point_list, const float4* __restrict__ splats, const float* __restrict__ subpixel_offset,
+    const float* __restrict__ dL_dcolor, const float* __restrict__ dL_dalpha, const float* __restrict__ dL_ddepth,
+    float* __restrict__ acc) {
+    __shared__ float4 sA[BLEND_THREADS];
+    __shared__ float4 sB[BLEND_THREADS];
+    __shared__ float2 sC[BLEND_THREADS];
+    __shared__ uint32_t sId[BLEND_THREADS];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int tile = blockIdx.x;
+    const int tx = tile % gx, ty = tile / gx;
+    const int px = tx * TILE + (wave & 1) * 8 + (lane & 7), py = ty * TILE + (wave >> 1) * 8 + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const size_t pid = (size_t)py * W + px, hw = (size_t)H * W;
+    float pxf = (float)px, pyf = (float)py;
+    if (subpixel_offset != nullptr && inside) { pxf += subpixel_offset[2 * pid]; pyf += subpixel_offset[2 * pid + 1]; }
+    const uint2 rng = ranges[tile];
+    const int n = (int)(rng.y - rng.x);
+    const int rounds = (n + BLEND_THREADS - 1) / BLEND_THREADS;
+
+#define GVF_BWD_STAGE(r_)                                                                          \
+    {                                                                                               \
+        const int k_ = (r_) * BLEND_THREADS + t;                                                    \
+        if (k_ < n) {                                                                               \
+            const uint32_t id_ = point_list[rng.x + (uint32_t)k_];                                  \
+            const float4* rec_ = splats + 4 * (size_t)id_;                                          \
+            const float4 c_ = rec_[2];                                                              \
+            sA[t] = rec_[0]; sB[t] = rec_[1]; sC[t] = make_float2(c_.x, c_.y); sId[t] = id_;        \
+        }                                                                                           \
+    }
+    // ---- phase A: forward replay
+    bool done = !inside;
+    float T = 1.0f;
+    int last = 0;
+    for (int r = 0; r < rounds; ++r) {
+        if (__syncthreads_count(done) == BLEND_THREADS) break;
+        GVF_BWD_STAGE(r)
+        __syncthreads();
+        const int cnt = min(BLEND_THREADS, n - r * BLEND_THREADS);
+        for (int j = 0; j < cnt; ++j) {
+            const float4 a = sA[j];
+            const float4 b = sB[j];
+            const float dx = a.x - pxf, dy = a.y - pyf;
+            const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+            const float alpha = fminf(0.99f, b.y * __expf(power));
+            const bool ok = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+            const float test_T = T * (1.f - alpha);
+            const bool stop = ok && test_T < 0.0001f;
+            done = done || stop;
+            if (ok && !stop) { T = test_T; last = r * BLEND_THREADS + j + 1; }
+        }
+    }
+    const float T_final = T;
+    float dch[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (inside) {
+        dch[0] = dL_dcolor[pid]; dch[1] = dL_dcolor[hw + pid]; dch[2] = dL_dcolor[2 * hw + pid];
+        if (dL_ddepth != nullptr) dch[3] = dL_ddepth[pid];
+        if (dL_dalpha != nullptr) dch[4] = dL_dalpha[pid];
+    }
+    // what lies behind the current splat, per channel (r, g, b, depth, one); backgrounds (bg, 0, 0)
+    float suf[5] = {T_final * bg0, T_final * bg1, T_final * bg2, 0.f, 0.f};
+    int max_last = last;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) max_last = max(max_last, __shfl_xor(max_last, o, 64));
+    // ---- phase B: back to front
+    for (int r = rounds - 1; r >= 0; --r) {
+        __syncthreads();                                   // everyone is done with the previous batch
+        GVF_BWD_STAGE(r)
+        __syncthreads();
+        const int cnt = min(BLEND_THREADS, n - r * BLEND_THREADS);
+        if (r * BLEND_THREADS >= max_last) continue;       // nothing in this batch contributed to this wave's pixels
+        for (int j = cnt - 1; j >= 0; --j) {
+            const int k = r * BLEND_THREADS + j;
+            if (k >= max_last) continue;                   // wave-uniform
+            const float4 a = sA[j];
+            const float4 b = sB[j];
+            const float2 c = sC[j];
+            const float dx = a.x - pxf, dy = a.y - pyf;
+            const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+            const float G = __expf(power);
+            const float alpha = fminf(0.99f, b.y * G);
+            const bool on = inside && k < last && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+            if (!__any(on)) continue;
+            float g[BWD_ACC];
+#pragma unroll
+            for (int e = 0; e < BWD_ACC; ++e) g[e] = 0.f;
+            if (on) {
+                T = T / (1.f - alpha);                     // transmittance in front of this splat
+                const float cch[5] = {b.z, b.w, c.x, c.y, 1.0f};
+                const float inv1ma = 1.0f / (1.f - alpha);
+                float dL_da = 0.f;
+#pragma unroll
+                for (int ch = 0; ch < 5; ++ch) {
+                    dL_da += (cch[ch] * T - suf[ch] * inv1ma) * dch[ch];
+                    suf[ch] += cch[ch] * alpha * T;
+                }
+                const float w = alpha * T;
+                g[6] = w * dch[0]; g[7] = w * dch[1]; g[8] = w * dch[2]; g[9] = w * dch[3];
+                g[5] = G * dL_da;
+                const float dG = b.y * dL_da * G;          // dL/dpower (gradient passes through the 0.99 clamp)
+                g[0] = dG * (-a.z * dx - a.w * dy);
+                g[1] = dG * (-b.x * dy - a.w * dx);
+                g[2] = dG * (-0.5f * dx * dx);
+                g[3] = dG * (-dx * dy);
+                g[4] = dG * (-0.5f * dy * dy);
+            }
+#pragma unroll
+            for (int e = 0; e < BWD_ACC; ++e) g[e] = wave_sum(g[e]);
+            if (lane == 0) {
+                float* dst = acc + (size_t)sId[j] * BWD_ACC;
+#pragma unroll
+                for (int e = 0; e < BWD_ACC; ++e) unsafeAtomicAdd(dst + e, g[e]);
+            }
+        }
+    }
+#undef GVF_BWD_STAGE
+}
+
+struct BwdParams {
+    int P, M, deg, H, W, mode;
+    float kernel_size, scale_modifier;
+    GvfRastFrame fr;
+};
+
+// Per-Gaussian chain rule from the blend's accumulators to the operator's inputs (the forward intermediates are
+// recomputed: 3D covariance, EWA Jacobian, 2D covariance, mip coefficient, SH basis).
+__global__ __launch_bounds__(PRE_THREADS) void preprocess_backward_kernel(
+    BwdParams bp, const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ colors_precomp,
+    const float* __restrict__ opacities, const float* __restrict__ scales, const float* __restrict__ rotations,
+    const float* __restrict__ cov3D_precomp, const float* __restrict__ acc, float* __restrict__ g_means3D,
+    float* __restrict__ g_means2D, float* __restrict__ g_shs, float* __restrict__ g_colors, float* __restrict__ g_opac,
+    float* __restrict__ g_scales, float* __restrict__ g_rots, float* __restrict__ g_cov3D) {
+    const int i = blockIdx.x * PRE_THREADS + threadIdx.x;
+    if (i >= bp.P) return;
+    const GvfRastFrame& fr = bp.fr;
+    const int M = bp.M, deg = bp.deg;
+    float gm[3] = {0.f, 0.f, 0.f}, gsc[3] = {0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f}, gc6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float gop = 0.f, gcol[3] = {0.f, 0.f, 0.f}, gm2[2] = {0.f, 0.f};
+    bool vis = false;
+    float dirv[3] = {0.f, 0.f, 0.f}, gcol_sh[3] = {0.f, 0.f, 0.f};
+
+    float a[BWD_ACC];
+#pragma unroll
+    for (int e = 0; e < BWD_ACC; ++e) a[e] = acc[(size_t)i * BWD_ACC + e];
+    float p[3] = {means3D[3 * (size_t)i], means3D[3 * (size_t)i + 1], means3D[3 * (size_t)i + 2]};
+    float pv[3];
+    xform43(fr.viewmatrix, p, pv);
+    if (pv[2] > 0.2f) {
+        float ph[4];
+        xform44(fr.projmatrix, p, ph);
+        const float pw = 1.0f / (ph[3] + 0.0000001f);
+        float c6[6], s[3] = {0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+        if (cov3D_precomp != nullptr) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) c6[k] = cov3D_precomp[6 * (size_t)i + k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s[k] = scales[3 * (size_t)i + k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[k] = rotations[4 * (size_t)i + k];
+            cov3d_from_scale_rot(s, bp.scale_modifier, q, c6);
+        }
+        const float fx = (float)bp.W / (2.0f * fr.tanfovx), fy = (float)bp.H / (2.0f * fr.tanfovy);
+        const float limx = 1.3f * fr.tanfovx, limy = 1.3f * fr.tanfovy;
+        const float txtz = pv[0] / pv[2], tytz = pv[1] / pv[2];
+        const float xmul = (txtz < -limx || txtz > limx) ? 0.f : 1.f, ymul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+        const float tx = fminf(limx, fmaxf(-limx, txtz)) * pv[2], ty = fminf(limy, fmaxf(-limy, tytz)) * pv[2], tz = pv[2];
+        const float J00 = fx / tz, J02 = -(fx * tx) / (tz * tz), J11 = fy / tz, J12 = -(fy * ty) / (tz * tz);
+        float A0[3], A1[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float w0 = fr.viewmatrix[c * 4 + 0], w1 = fr.viewmatrix[c * 4 + 1], w2 = fr.viewmatrix[c * 4 + 2];
+            A0[c] = J00 * w0 + J02 * w2;
+            A1[c] = J11 * w1 + J12 * w2;
+        }
+        const float S[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+        float SA0[3], SA1[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            SA0[r] = S[r][0] * A0[0] + S[r][1] * A0[1] + S[r][2] * A0[2];
+            SA1[r] = S[r][0] * A1[0] + S[r][1] * A1[1] + S[r][2] * A1[2];
+        }
+        const float cxx = A0[0] * SA0[0] + A0[1] * SA0[1] + A0[2] * SA0[2];
+        const float cxy = A0[0] * SA1[0] + A0[1] * SA1[1] + A0[2] * SA1[2];
+        const float cyy = A1[0] * SA1[0] + A1[1] * SA1[1] + A1[2] * SA1[2];
+        const float kf = bp.mode == GVF_RAST_MODE_MIP ? bp.kernel_size : 0.3f;
+        float coef = 1.0f;
+        const float det0r = cxx * cyy - cxy * cxy, det1r = (cxx + kf) * (cyy + kf) - cxy * cxy;
+        if (bp.mode == GVF_RAST_MODE_MIP) {
+            const float det0 = fmaxf(1e-6f, det0r), det1 = fmaxf(1e-6f, det1r);
+            coef = sqrtf(det0 / (det1 + 1e-6f) + 1e-6f);
+            if (det0 <= 1e-6f || det1 <= 1e-6f) coef = 0.0f;
+        }
+        const float ap = cxx + kf, bq = cxy, cp = cyy + kf;
+        const float det = ap * cp - bq * bq;
+        if (det != 0.0f) {
+            vis = true;
+            // screen-space mean (NDC units) and its path into the 3D mean
+            gm2[0] = a[0] * 0.5f * (float)bp.W; gm2[1] = a[1] * 0.5f * (float)bp.H;
+            const float* m = fr.projmatrix;
+            const float mul1 = ph[0] * pw * pw, mul2 = ph[1] * pw * pw;
+            gm[0] += (m[0] * pw - m[3] * mul1) * gm2[0] + (m[1] * pw - m[3] * mul2) * gm2[1];
+            gm[1] += (m[4] * pw - m[7] * mul1) * gm2[0] + (m[5] * pw - m[7] * mul2) * gm2[1];
+            gm[2] += (m[8] * pw - m[11] * mul1) * gm2[0] + (m[9] * pw - m[11] * mul2) * gm2[1];
+            // depth output
+            gm[0] += fr.viewmatrix[2] * a[9]; gm[1] += fr.viewmatrix[6] * a[9]; gm[2] += fr.viewmatrix[10] * a[9];
+            // colour: precomputed colours directly; SH below (needs the per-coefficient loop)
+            if (colors_precomp != nullptr) { gcol[0] = a[6]; gcol[1] = a[7]; gcol[2] = a[8]; }
+            else { gcol_sh[0] = a[6]; gcol_sh[1] = a[7]; gcol_sh[2] = a[8]; }
+            // opacity and the mip coefficient
+            gop = a[5] * coef;
+            float gcxx = 0.f, gcxy = 0.f, gcyy = 0.f;
+            if (bp.mode == GVF_RAST_MODE_MIP && coef > 0.0f) {
+                const float dcoef = a[5] * opacities[i];
+                const float dr = dcoef * 0.5f / coef;
+                const float d1e = det1r + 1e-6f;
+                const float dd0 = dr / d1e, dd1 = -dr * det0r / (d1e * d1e);
+                gcxx += dd0 * cyy + dd1 * (cyy + kf);
+                gcyy += dd0 * cxx + dd1 * (cxx + kf);
+                gcxy += -2.0f * cxy * (dd0 + dd1);
+            }
+            {
+                const float d2 = 1.0f / (det * det);
+                const float gA = a[2], gB = a[3], gC = a[4];
+                gcxx += d2 * (-cp * cp * gA + bq * cp * gB - bq * bq * gC);
+                gcxy += d2 * (2.f * bq * cp * gA - (det + 2.f * bq * bq) * gB + 2.f * ap * bq * gC);
+                gcyy += d2 * (-bq * bq * gA + ap * bq * gB - ap * ap * gC);
+            }
+            float Gm[3][3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) Gm[r][c] = gcxx * A0[r] * A0[c] + gcxy * A0[r] * A1[c] + gcyy * A1[r] * A1[c];
+            gc6[0] = Gm[0][0]; gc6[3] = Gm[1][1]; gc6[5] = Gm[2][2];
+            gc6[1] = Gm[0][1] + Gm[1][0]; gc6[2] = Gm[0][2] + Gm[2][0]; gc6[4] = Gm[1][2] + Gm[2][1];
+            float dJ00 = 0.f, dJ02 = 0.f, dJ11 = 0.f, dJ12 = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float dA0 = 2.f * gcxx * SA0[c] + gcxy * SA1[c], dA1 = 2.f * gcyy * SA1[c] + gcxy * SA0[c];
+                const float w0 = fr.viewmatrix[c * 4 + 0], w1 = fr.viewmatrix[c * 4 + 1], w2 = fr.viewmatrix[c * 4 + 2];
+                dJ00 += dA0 * w0; dJ02 += dA0 * w2; dJ11 += dA1 * w1; dJ12 += dA1 * w2;
+            }
+            const float tz2 = 1.0f / (tz * tz), tz3 = tz2 / tz;
+            const float dtx = xmul * (-fx * tz2 * dJ02), dty = ymul * (-fy * tz2 * dJ12);
+            const float dtz = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + 2.f * fx * tx * tz3 * dJ02 + 2.f * fy * ty * tz3 * dJ12;
+            const float* v = fr.viewmatrix;
+            gm[0] += v[0] * dtx + v[1] * dty + v[2] * dtz;
+            gm[1] += v[4] * dtx + v[5] * dty + v[6] * dtz;
+            gm[2] += v[8] * dtx + v[9] * dty + v[10] * dtz;
+            if (cov3D_precomp == nullptr) {
+                const float r = q[0], x = q[1], y = q[2], z = q[3];
+                const float R[3][3] = {{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
+                                       {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
+                                       {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}};
+                const float sc[3] = {bp.scale_modifier * s[0], bp.scale_modifier * s[1], bp.scale_modifier * s[2]};
+                const float Gs[3][3] = {{gc6[0], 0.5f * gc6[1], 0.5f * gc6[2]}, {0.5f * gc6[1], gc6[3], 0.5f * gc6[4]},
+                                        {0.5f * gc6[2], 0.5f * gc6[4], gc6[5]}};
+                float dR[3][3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float acc_s = 0.f;
+#pragma unroll
+                    for (int r2 = 0; r2 < 3; ++r2) {
+                        float dl = 0.f;
+#pragma unroll
+                        for (int kk = 0; kk < 3; ++kk) dl += 2.f * Gs[r2][kk] * R[kk][c] * sc[c];
+                        acc_s += dl * R[r2][c];
+                        dR[r2][c] = dl * sc[c];
+                    }
+                    gsc[c] = bp.scale_modifier * acc_s;
+                }
+                gq[0] = 2.f * (-z * dR[0][1] + y * dR[0][2] + z * dR[1][0] - x * dR[1][2] - y * dR[2][0] + x * dR[2][1]);
+                gq[1] = 2.f * (y * dR[0][1] + z * dR[0][2] + y * dR[1][0] - 2.f * x * dR[1][1] - r * dR[1][2] + z * dR[2][0] + r * dR[2][1] - 2.f * x * dR[2][2]);
+                gq[2] = 2.f * (-2.f * y * dR[0][0] + x * dR[0][1] + r * dR[0][2] + x * dR[1][0] + z * dR[1][2] - r * dR[2][0] + z * dR[2][1] - 2.f * y * dR[2][2]);
+                gq[3] = 2.f * (-2.f * z * dR[0][0] - r * dR[0][1] + x * dR[0][2] + r * dR[1][0] - 2.f * z * dR[1][1] + y * dR[1][2] + x * dR[2][0] + y * dR[2][1]);
+            }
+        }
+    }
+    // SH colours: d/d(coefficients) = basis * d/d(rgb) where the +0.5 / clamp let it through; d/d(direction) -> mean
+    if (shs != nullptr && g_shs != nullptr) {
+        float* gs = g_shs + (size_t)i * M * 3;
+        if (!vis) {
+            for (int k = 0; k < M * 3; ++k) gs[k] = 0.f;
+        } else {
+            const float dxc = p[0] - fr.campos[0], dyc = p[1] - fr.campos[1], dzc = p[2] - fr.campos[2];
+            const float len = sqrtf(dxc * dxc + dyc * dyc + dzc * dzc);
+            const float x = dxc / len, y = dyc / len, z = dzc / len;
+            dirv[0] = x; dirv[1] = y; dirv[2] = z;
+            float bas[16], db[16][3];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { bas[k] = 0.f; db[k][0] = 0.f; db[k][1] = 0.f; db[k][2] = 0.f; }
+            bas[0] = SH_C0;
+            if (deg > 0) {
+                bas[1] = -SH_C1 * y; bas[2] = SH_C1 * z; bas[3] = -SH_C1 * x;
+                db[1][1] = -SH_C1; db[2][2] = SH_C1; db[3][0] = -SH_C1;
+                if (deg > 1) {
+                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                    bas[4] = SH_C2[0] * xy; bas[5] = SH_C2[1] * yz; bas[6] = SH_C2[2] * (2.f * zz - xx - yy);
+                    bas[7] = SH_C2[3] * xz; bas[8] = SH_C2[4] * (xx - yy);
+                    db[4][0] = SH_C2[0] * y; db[4][1] = SH_C2[0] * x;
+                    db[5][1] = SH_C2[1] * z; db[5][2] = SH_C2[1] * y;
+                    db[6][0] = SH_C2[2] * -2.f * x; db[6][1] = SH_C2[2] * -2.f * y; db[6][2] = SH_C2[2] * 4.f * z;
+                    db[7][0] = SH_C2[3] * z; db[7][2] = SH_C2[3] * x;
+                    db[8][0] = SH_C2[4] * 2.f * x; db[8][1] = SH_C2[4] * -2.f * y;
+                    if (deg > 2) {
+                        bas[9] = SH_C3[0] * y * (3.f * xx - yy); bas[10] = SH_C3[1] * xy * z; bas[11] = SH_C3[2] * y * (4.f * zz - xx - yy);
+                        bas[12] = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy); bas[13] = SH_C3[4] * x * (4.f * zz - xx - yy);
+                        bas[14] = SH_C3[5] * z * (xx - yy); bas[15] = SH_C3[6] * x * (xx - 3.f * yy);
+                        db[9][0] = SH_C3[0] * 6.f * xy; db[9][1] = SH_C3[0] * (3.f * xx - 3.f * yy);
+                        db[10][0] = SH_C3[1] * yz; db[10][1] = SH_C3[1] * xz; db[10][2] = SH_C3[1] * xy;
+                        db[11][0] = SH_C3[2] * -2.f * xy; db[11][1] = SH_C3[2] * (4.f * zz - xx - 3.f * yy); db[11][2] = SH_C3[2] * 8.f * yz;
+                        db[12][0] = SH_C3[3] * -6.f * xz; db[12][1] = SH_C3[3] * -6.f * yz; db[12][2] = SH_C3[3] * (6.f * zz - 3.f * xx - 3.f * yy);
+                        db[13][0] = SH_C3[4] * (4.f * zz - 3.f * xx - yy); db[13][1] = SH_C3[4] * -2.f * xy; db[13][2] = SH_C3[4] * 8.f * xz;
+                        db[14][0] = SH_C3[5] * 2.f * xz; db[14][1] = SH_C3[5] * -2.f * yz; db[14][2] = SH_C3[5] * (xx - yy);
+                        db[15][0] = SH_C3[6] * (3.f * xx - 3.f * yy); db[15][1] = SH_C3[6] * -6.f * xy;
+                    }
+                }
+            }
+            const int nb = (deg + 1) * (deg + 1);
+            const float* sh = shs + (size_t)i * M * 3;
+            float ddir[3] = {0.f, 0.f, 0.f};
+            for (int c = 0; c < 3; ++c) {
+                float res = 0.f;
+                for (int k = 0; k < nb; ++k) res += bas[k] * sh[k * 3 + c];
+                const float gr = (res + 0.5f < 0.f) ? 0.f : gcol_sh[c];
+                for (int k = 0; k < M; ++k) gs[k * 3 + c] = k < nb ? bas[k] * gr : 0.f;
+                for (int k = 0; k < nb; ++k) {
+                    ddir[0] += db[k][0] * sh[k * 3 + c] * gr; ddir[1] += db[k][1] * sh[k * 3 + c] * gr; ddir[2] += db[k][2] * sh[k * 3 + c] * gr;
+                }
+            }
+            const float dot = ddir[0] * dirv[0] + ddir[1] * dirv[1] + ddir[2] * dirv[2];
+            gm[0] += (ddir[0] - dirv[0] * dot) / len; gm[1] += (ddir[1] - dirv[1] * dot) / len; gm[2] += (ddir[2] - dirv[2] * dot) / len;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 3; ++e) g_means3D[3 * (size_t)i + e] = gm[e];
+    if (g_means2D != nullptr) { g_means2D[2 * (size_t)i] = gm2[0]; g_means2D[2 * (size_t)i + 1] = gm2[1]; }
+    if (g_colors != nullptr) { g_colors[3 * (size_t)i] = gcol[0]; g_colors[3 * (size_t)i + 1] = gcol[1]; g_colors[3 * (size_t)i + 2] = gcol[2]; }
+    g_opac[i] = gop;
+    if (g_scales != nullptr) { g_scales[3 * (size_t)i] = gsc[0]; g_scales[3 * (size_t)i + 1] = gsc[1]; g_scales[3 * (size_t)i + 2] = gsc[2]; }
+    if (g_rots != nullptr) { g_rots[4 * (size_t)i] = gq[0]; g_rots[4 * (size_t)i + 1] = gq[1]; g_rots[4 * (size_t)i + 2] = gq[2]; g_rots[4 * (size_t)i + 3] = gq[3]; }
+    if (g_cov3D != nullptr) {
+#pragma unroll
+        for (int e = 0; e < 6; ++e) g_cov3D[6 * (size_t)i + e] = gc6[e];
+    }
+}
+
 }  // namespace
 
 extern "C" int gvf_rast_workspace_bytes(int P, int F, int H, int W, int64_t max_rendered, size_t* bytes) {
@@ -1514,6 +1882,60 @@ extern "C" int gvf_rast_forward_batched(const GvfRastSettings* st, const GvfRast
                         features_dc, nullptr, nullptr, delta, n_delta, nullptr, workspace, workspace_bytes,
                         max_rendered, out_color, out_alpha, out_depth, out_radii, out_num_rendered,
                         (hipStream_t)stream);
+}
+
+extern "C" int gvf_rast_backward_scratch_bytes(int P, size_t* bytes) {
+    if (!bytes || P < 0) return GVF_EINVAL;
+    *bytes = gvf_align_up((size_t)(P > 0 ? P : 1) * BWD_ACC * sizeof(float), 256);
+    return GVF_OK;
+}
+
+extern "C" int gvf_rast_backward(const GvfRastSettings* st, const GvfRastFrame* frame_host, int P, int M,
+                                 const float* means3D, const float* shs, const float* colors_precomp,
+                                 const float* opacities, const float* scales, const float* rotations,
+                                 const float* cov3D_precomp, const float* subpixel_offset, const void* workspace,
+                                 size_t workspace_bytes, int64_t max_rendered, const float* dL_dcolor,
+                                 const float* dL_dalpha, const float* dL_ddepth, void* scratch, size_t scratch_bytes,
+                                 float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs, float* dL_dcolors,
+                                 float* dL_dopacities, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
+                                 void* stream_) {
+    if (!st || !frame_host || !workspace || !dL_dcolor || P < 0) return GVF_EINVAL;
+    const int H = st->image_height, W = st->image_width;
+    if (H <= 0 || W <= 0 || st->sh_degree < 0 || st->sh_degree > 3) return GVF_EINVAL;
+    if (st->mode != GVF_RAST_MODE_MIP && st->mode != GVF_RAST_MODE_DILATE) return GVF_EINVAL;
+    if (P == 0) return GVF_OK;
+    if (!means3D || !opacities || !scratch || !dL_dmeans3D || !dL_dopacities) return GVF_EINVAL;
+    if ((shs == nullptr) == (colors_precomp == nullptr)) return GVF_EINVAL;
+    const bool have_sr = scales != nullptr && rotations != nullptr;
+    if (have_sr == (cov3D_precomp != nullptr)) return GVF_EINVAL;
+    if (shs != nullptr && (M < (st->sh_degree + 1) * (st->sh_degree + 1) || M > MAX_SH_COEFFS || !dL_dshs)) return GVF_EINVAL;
+    if (colors_precomp != nullptr && !dL_dcolors) return GVF_EINVAL;
+    if (have_sr && (!dL_dscales || !dL_drotations)) return GVF_EINVAL;
+    if (!have_sr && !dL_dcov3D) return GVF_EINVAL;
+    size_t need = 0;
+    gvf_rast_backward_scratch_bytes(P, &need);
+    if (scratch_bytes < need) return GVF_ENOSPC;
+    if ((((uintptr_t)workspace) & 255) != 0 || (((uintptr_t)scratch) & 15) != 0) return GVF_EINVAL;
+    hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();
+    // the layout of the forward call's workspace: same (P, F = 1, H, W, max_rendered) => same carve
+    Workspace w = carve(const_cast<void*>(workspace), workspace_bytes, P, 1, H, W, max_rendered);
+    if (!w.ok) return GVF_ENOSPC;
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE, ntiles = gx * gy;
+    float* acc = (float*)scratch;
+    if (hipMemsetAsync(acc, 0, (size_t)P * BWD_ACC * sizeof(float), stream) != hipSuccess) return GVF_ELAUNCH;
+    if (max_rendered > 0)
+        hipLaunchKernelGGL(blend_backward_kernel, dim3(ntiles), dim3(BLEND_THREADS), 0, stream, P, H, W, gx, st->bg[0], st->bg[1],
+                           st->bg[2], w.ranges, w.ids, w.splats, subpixel_offset, dL_dcolor, dL_dalpha, dL_ddepth, acc);
+    GVF_CHECK_LAUNCH();
+    BwdParams bp;
+    bp.P = P; bp.M = M; bp.deg = st->sh_degree; bp.H = H; bp.W = W; bp.mode = st->mode;
+    bp.kernel_size = st->kernel_size; bp.scale_modifier = st->scale_modifier; bp.fr = *frame_host;
+    hipLaunchKernelGGL(preprocess_backward_kernel, dim3((P + PRE_THREADS - 1) / PRE_THREADS), dim3(PRE_THREADS), 0, stream, bp,
+                       means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, acc, dL_dmeans3D, dL_dmeans2D,
+                       dL_dshs, dL_dcolors, dL_dopacities, dL_dscales, dL_drotations, dL_dcov3D);
+    GVF_CHECK_LAUNCH();
+    return GVF_OK;
 }
 
 extern "C" int gvf_gaussian_activate(const GvfGaussianActivation* act, int P, int M, const float* xyz_raw,

@@ -30,7 +30,7 @@ class GaussianRasterizer(_MipRasterizer):
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                 cov3D_precomp=None, extra_attrs=None):
-        out = self._run(means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, True)
+        out = self._run(means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, True, means2D)
         H, W = out["alpha"].shape
         # depth = sum_i z_i a_i T_i, alpha = 1 - T_final, both (1,H,W) as upstream; the normal map and
         # the extra-attribute channel are never read by the reference (gaussian_render.py:220-238).

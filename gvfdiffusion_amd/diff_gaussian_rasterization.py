@@ -33,7 +33,7 @@ class GaussianRasterizer(nn.Module):
         super().__init__()
         self.raster_settings = raster_settings
 
-    def _run(self, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, want_ad):
+    def _run(self, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, want_ad, means2D=None):
         rs = self.raster_settings
         st = _r.make_settings(rs.image_height, rs.image_width, rs.sh_degree, self._MODE,
                               getattr(rs, "kernel_size", 0.0), rs.scale_modifier, rs.bg, rs.prefiltered, rs.debug)
@@ -43,10 +43,10 @@ class GaussianRasterizer(nn.Module):
             sub = None  # the reference always passes zeros (gaussian_render.py:108)
         return _r.rasterize(st, fr, means3D, opacities, shs=shs, colors_precomp=colors_precomp, scales=scales,
                             rotations=rotations, cov3D_precomp=cov3D_precomp, subpixel_offset=sub,
-                            want_alpha_depth=want_ad)
+                            want_alpha_depth=want_ad, means2D=means2D)
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                 cov3D_precomp=None):
-        # means2D only carries screen-space gradients upstream; the forward pass ignores it.
-        out = self._run(means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, False)
+        # means2D only carries screen-space gradients upstream (screenspace_points.grad); the forward pass ignores it.
+        out = self._run(means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, False, means2D)
         return out["color"], out["radii"]

@@ -3,7 +3,8 @@
 Reference seam: renderers/gaussian_render.py:110-143 (settings) and :198-220 (operator call) --
 the reference imports the two classes from the external CUDA packages `diff_gaussian_rasterization`
 (mip-splatting fork) and `diff_gauss`; here they are backed by libgvf_hip.so (csrc/rast.hip).
-Forward only (the rasteriser backward is SURVEY.md section 8f NEXT #4).
+Differentiable: when an input requires grad, rasterize() runs through _RasterizeFn (forward keeps its
+workspace, backward calls gvf_rast_backward) -- upstream's _RasterizeGaussians autograd.Function.
 """
 import ctypes
 import math
@@ -79,8 +80,26 @@ _CAP_HINT = {}  # (P,H,W,F) -> last capacity that sufficed
 
 def rasterize(settings: "_lib.GvfRastSettings", frame: "_lib.GvfRastFrame", means3D, opacities, shs=None,
               colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, subpixel_offset=None,
-              want_alpha_depth=False):
-    """One frame, activated inputs (GaussianRasterizer.__call__).  Returns dict of device tensors."""
+              want_alpha_depth=False, means2D=None):
+    """One frame, activated inputs (GaussianRasterizer.__call__).  Returns dict of device tensors.  Differentiable
+    w.r.t. means3D, means2D, shs | colors_precomp, opacities, scales, rotations | cov3D_precomp when grad is enabled
+    and one of them requires it."""
+    diff = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in
+                                           (means3D, means2D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp))
+    if not diff:
+        return _rasterize_impl(settings, frame, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp,
+                               subpixel_offset, want_alpha_depth)
+    _lib.require_cuda(means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, means2D)
+    color, alpha, depth, radii = _RasterizeFn.apply(settings, frame, bool(want_alpha_depth), subpixel_offset, means3D, means2D,
+                                                    shs, colors_precomp, opacities, scales, rotations, cov3D_precomp)
+    return dict(color=color, alpha=alpha if want_alpha_depth else None, depth=depth if want_alpha_depth else None,
+                radii=radii, num_rendered=None)
+
+
+def _rasterize_impl(settings, frame, means3D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                    cov3D_precomp=None, subpixel_offset=None, want_alpha_depth=False, private_workspace=False):
+    """private_workspace: the call gets its own workspace tensor, returned in the dict (the backward pass reads the
+    splat records / sorted lists / tile ranges the forward left there)."""
     _lib.require_cuda(means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp)
     if (shs is None) == (colors_precomp is None):
         raise Exception("Please provide excatly one of either SHs or precomputed colors!")
@@ -110,7 +129,7 @@ def rasterize(settings: "_lib.GvfRastSettings", frame: "_lib.GvfRastFrame", mean
     cap = _CAP_HINT.get(key, max(4 * P, 1 << 16))
     while True:
         nbytes = workspace_bytes(P, 1, H, W, cap)
-        ws = _workspace(dev, nbytes + 256)
+        ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev) if private_workspace else _workspace(dev, nbytes + 256)
         base = (ws.data_ptr() + 255) // 256 * 256
         rc = _lib.lib().gvf_rast_forward(
             ctypes.byref(settings), ctypes.byref(frame), P, M, _lib.ptr(means3D), _lib.ptr(shs),
@@ -124,7 +143,81 @@ def rasterize(settings: "_lib.GvfRastSettings", frame: "_lib.GvfRastFrame", mean
             break
         cap = int(n * 1.25) + 1024
     _CAP_HINT[key] = cap
-    return dict(color=color, alpha=alpha, depth=depth, radii=radii, num_rendered=n)
+    out = dict(color=color, alpha=alpha, depth=depth, radii=radii, num_rendered=n)
+    if private_workspace:
+        out.update(workspace=ws, workspace_bytes=nbytes, max_rendered=cap)
+    return out
+
+
+class _RasterizeFn(torch.autograd.Function):
+    """autograd wrapper of one operator call (upstream: diff_gaussian_rasterization._RasterizeGaussians).
+    Inputs that may carry gradients: means3D, means2D (receives the screen-space gradient, NDC units, z = 0),
+    shs | colors_precomp, opacities, scales + rotations | cov3D_precomp.  Outputs: color, alpha, depth (the last
+    two are zeros-like placeholders unless want_alpha_depth), radii."""
+
+    @staticmethod
+    def forward(ctx, settings, frame, want_ad, subpixel_offset, means3D, means2D, shs, colors_precomp, opacities, scales,
+                rotations, cov3D_precomp):
+        out = _rasterize_impl(settings, frame, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp,
+                              subpixel_offset, want_ad, private_workspace=True)
+        ctx.settings, ctx.frame, ctx.want_ad = settings, frame, want_ad
+        ctx.ws, ctx.ws_bytes, ctx.cap = out["workspace"], out["workspace_bytes"], out["max_rendered"]
+        ctx.has = (shs is not None, colors_precomp is not None, scales is not None, cov3D_precomp is not None,
+                   means2D is not None)
+        ctx.save_for_backward(*[t if t is not None else torch.empty(0) for t in
+                                (means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, subpixel_offset)])
+        ctx.shapes = (opacities.shape, None if means2D is None else means2D.shape)
+        dev = means3D.device
+        H, W = settings.image_height, settings.image_width
+        alpha = out["alpha"] if want_ad else torch.zeros((H, W), device=dev)
+        depth = out["depth"] if want_ad else torch.zeros((H, W), device=dev)
+        ctx.mark_non_differentiable(out["radii"])
+        ctx.num_rendered = out["num_rendered"]
+        return out["color"], alpha, depth, out["radii"]
+
+    @staticmethod
+    def backward(ctx, g_color, g_alpha, g_depth, _g_radii):
+        means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, sub = \
+            [t if t.numel() > 0 or k == 0 else None for k, t in enumerate(ctx.saved_tensors)]
+        has_shs, has_col, has_sr, has_cov, has_m2 = ctx.has
+        shs = shs if has_shs else None
+        colors_precomp = colors_precomp if has_col else None
+        scales, rotations = (scales, rotations) if has_sr else (None, None)
+        cov3D_precomp = cov3D_precomp if has_cov else None
+        sub = sub if (sub is not None and sub.numel() > 0) else None
+        dev = means3D.device
+        P = means3D.shape[0]
+        M = 0 if shs is None else shs.shape[1]
+        f32 = dict(dtype=torch.float32, device=dev)
+        g_color = _f32c(g_color if g_color is not None else torch.zeros((3, ctx.settings.image_height, ctx.settings.image_width), **f32), "g")
+        g_alpha = _f32c(g_alpha, "g") if ctx.want_ad and g_alpha is not None else None
+        g_depth = _f32c(g_depth, "g") if ctx.want_ad and g_depth is not None else None
+        nb = ctypes.c_size_t(0)
+        _lib.check(_lib.lib().gvf_rast_backward_scratch_bytes(P, ctypes.byref(nb)), "gvf_rast_backward_scratch_bytes")
+        scratch = torch.empty(int(nb.value) + 16, dtype=torch.uint8, device=dev)
+        sbase = (scratch.data_ptr() + 15) // 16 * 16
+        d_m3 = torch.empty((P, 3), **f32)
+        d_m2 = torch.empty((P, 2), **f32)
+        d_shs = torch.empty((P, M, 3), **f32) if shs is not None else None
+        d_col = torch.empty((P, 3), **f32) if colors_precomp is not None else None
+        d_op = torch.empty((P,), **f32)
+        d_sc = torch.empty((P, 3), **f32) if scales is not None else None
+        d_ro = torch.empty((P, 4), **f32) if rotations is not None else None
+        d_c6 = torch.empty((P, 6), **f32) if cov3D_precomp is not None else None
+        base = (ctx.ws.data_ptr() + 255) // 256 * 256
+        rc = _lib.lib().gvf_rast_backward(
+            ctypes.byref(ctx.settings), ctypes.byref(ctx.frame), P, M, _lib.ptr(means3D), _lib.ptr(shs), _lib.ptr(colors_precomp),
+            _lib.ptr(opacities), _lib.ptr(scales), _lib.ptr(rotations), _lib.ptr(cov3D_precomp), _lib.ptr(sub),
+            ctypes.c_void_p(base), ctx.ws_bytes, ctx.cap, _lib.ptr(g_color), _lib.ptr(g_alpha), _lib.ptr(g_depth),
+            ctypes.c_void_p(sbase), int(nb.value), _lib.ptr(d_m3), _lib.ptr(d_m2), _lib.ptr(d_shs), _lib.ptr(d_col),
+            _lib.ptr(d_op), _lib.ptr(d_sc), _lib.ptr(d_ro), _lib.ptr(d_c6), _lib.current_stream(dev))
+        _lib.check(rc, "gvf_rast_backward")
+        op_shape, m2_shape = ctx.shapes
+        g_m2 = None
+        if has_m2:
+            g_m2 = torch.zeros(m2_shape, **f32)
+            g_m2[:, :2] = d_m2
+        return (None, None, None, None, d_m3, g_m2, d_shs, d_col, d_op.reshape(op_shape), d_sc, d_ro, d_c6)
 
 
 def rasterize_batched(settings, frames, act, xyz_raw, features_dc, scaling_raw, rotation_raw, opacity_raw,

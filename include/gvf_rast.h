@@ -113,6 +113,29 @@ int gvf_rast_forward(const GvfRastSettings* settings_host, const GvfRastFrame* f
                      int32_t* out_radii, uint32_t* out_num_rendered,
                      void* stream);
 
+/* Backward of gvf_rast_forward() (the operator is differentiable: renderers/gaussian_render.py:198-220 is called
+ * under autograd, train_vae.py:321-352 back-propagates a render loss through it; upstream RasterizeGaussiansBackward).
+ * `workspace` must be the workspace of the forward call for the SAME inputs, untouched since (it holds the splat
+ * records, the per-tile sorted lists and the tile ranges), with the same workspace_bytes / max_rendered.
+ * dL_dcolor[3][H][W] is required; dL_dalpha[H][W], dL_ddepth[H][W] may be null (mode DILATE outputs).
+ * scratch: >= gvf_rast_backward_scratch_bytes(P) bytes, 16-byte aligned (per-Gaussian accumulators, zeroed here).
+ * Outputs (caller-allocated, fully written): dL_dmeans3D[P][3]; dL_dmeans2D[P][2] or null -- the screen-space
+ * gradient in NDC units, as upstream reports it in screenspace_points.grad; dL_dshs[P][M][3] xor dL_dcolors[P][3];
+ * dL_dopacities[P]; dL_dscales[P][3] + dL_drotations[P][4], or dL_dcov3D[P][6] (also written when non-null with
+ * scales/rotations given).  Conventions taken over from upstream: the gradient passes through the alpha <= 0.99 clamp;
+ * a view-space coordinate clamped to 1.3 tan(fov) gets no gradient. */
+int gvf_rast_backward_scratch_bytes(int P, size_t* bytes);
+int gvf_rast_backward(const GvfRastSettings* settings_host, const GvfRastFrame* frame_host, int P, int M,
+                      const float* means3D, const float* shs, const float* colors_precomp,
+                      const float* opacities, const float* scales, const float* rotations,
+                      const float* cov3D_precomp, const float* subpixel_offset,
+                      const void* workspace, size_t workspace_bytes, int64_t max_rendered,
+                      const float* dL_dcolor, const float* dL_dalpha, const float* dL_ddepth,
+                      void* scratch, size_t scratch_bytes,
+                      float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs, float* dL_dcolors,
+                      float* dL_dopacities, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
+                      void* stream);
+
 /* F frames in one call, GaussianModel parameters + per-frame deltas activated in-kernel
  * (render() with delta_pc, gaussian_render.py:154-160).  Raw parameters:
  *   xyz_raw[P][3], features_dc[P][M][3], scaling_raw[P][3], rotation_raw[P][4], opacity_raw[P];
