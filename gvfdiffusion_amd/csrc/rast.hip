@@ -1476,17 +1476,39 @@ int run_pipeline(const GvfRastSettings& st, const GvfRastFrame* frames_host, int
 // ---------------------------------------------------------------------------------------------
 constexpr int BWD_ACC = 10;   // per Gaussian: d/dx, d/dy [pixels], d/d(conic a, b, c), d/d(opacity_eff), d/d(r, g, b), d/d(depth)
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+// Sums over the lanes of a wave without LDS round trips (a __shfl_xor butterfly is six ds_bpermute / ds_swizzle per
+// value): rows of 16 lanes by DPP (quad permutes, then the two mirror patterns: after each step a lane holds the sum
+// of a group twice as large); the four rows and the two halves by the gfx950 lane-swap instructions.
+__device__ __forceinline__ float row_sum(float v) {          // every lane: sum of its row of 16 lanes
+    int x;
+#define GVF_DPP_ADD(ctrl_)                                                                                   \
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl_, 0xf, 0xf, false);                          \
+    v += __int_as_float(x);
+    GVF_DPP_ADD(0xB1)      // quad_perm [1,0,3,2]
+    GVF_DPP_ADD(0x4E)      // quad_perm [2,3,0,1]
+    GVF_DPP_ADD(0x141)     // row_half_mirror
+    GVF_DPP_ADD(0x140)     // row_mirror
+#undef GVF_DPP_ADD
+    return v;
+}
+__device__ __forceinline__ float across_rows_sum(float v) {  // every lane: sum of the lanes at its position in the 4 rows
+    {   // rows (r0, r1, r2, r3) -> r0 + r1 resp. r2 + r3
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+    {   // halves
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
     return v;
 }
 
-// One workgroup per 16x16 tile.  Phase A replays the forward compositing over the tile's sorted list (same
-// arithmetic as blend_kernel, so the same skip / stop decisions) to get each pixel's final transmittance and the
-// list position after its last contributor; phase B walks the list back to front, forms the per-(pixel, splat)
-// gradients, sums them over the 64 pixels of a wave and adds the wave sums to the per-Gaussian accumulators with
-// hardware fp32 atomics.
+// One workgroup per 16x16 tile, the 4 waves own its four 8x8 quadrants and walk per-wave lists of the splats whose
+// alpha >= 1/255 box reaches the quadrant (exactly blend_kernel's culling, so the same splats are evaluated).
+// Phase A replays the forward compositing (same arithmetic as blend_kernel: same skip / stop decisions) to get
+// each pixel's final transmittance and the list position after its last contributor; phase B walks the lists back
+// to front, forms the per-(pixel, splat) gradients, sums them over the 64 pixels of the wave and adds the wave
+// sums to the per-Gaussian accumulators with hardware fp32 atomics.
 __global__ __launch_bounds__(BLEND_THREADS) void blend_backward_kernel(
     int P, int H, int W, int gx, float bg0, float bg1, float bg2, const uint2* __restrict__ ranges,
     const uint32_t* __restrict__ point_list, const float4* __restrict__ splats, const float* __restrict__ subpixel_offset,
@@ -1496,6 +1518,8 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_backward_kernel(
     __shared__ float4 sB[BLEND_THREADS];
     __shared__ float2 sC[BLEND_THREADS];
     __shared__ uint32_t sId[BLEND_THREADS];
+    __shared__ unsigned char sMask[BLEND_THREADS];
+    __shared__ unsigned char sList[4][BLEND_THREADS];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int tile = blockIdx.x;
     const int tx = tile % gx, ty = tile / gx;
@@ -1507,16 +1531,31 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_backward_kernel(
     const uint2 rng = ranges[tile];
     const int n = (int)(rng.y - rng.x);
     const int rounds = (n + BLEND_THREADS - 1) / BLEND_THREADS;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
 
-#define GVF_BWD_STAGE(r_)                                                                          \
+// stage batch r_ (records, ids, quadrant masks) and compact it into this wave's list (ascending = depth order)
+#define GVF_BWD_STAGE(r_, n_w_)                                                                     \
     {                                                                                               \
         const int k_ = (r_) * BLEND_THREADS + t;                                                    \
         if (k_ < n) {                                                                               \
             const uint32_t id_ = point_list[rng.x + (uint32_t)k_];                                  \
             const float4* rec_ = splats + 4 * (size_t)id_;                                          \
+            const float4 a_ = rec_[0];                                                              \
             const float4 c_ = rec_[2];                                                              \
-            sA[t] = rec_[0]; sB[t] = rec_[1]; sC[t] = make_float2(c_.x, c_.y); sId[t] = id_;        \
+            sA[t] = a_; sB[t] = rec_[1]; sC[t] = make_float2(c_.x, c_.y); sId[t] = id_;             \
+            sMask[t] = (unsigned char)quadrant_mask(a_.x, a_.y, c_.z, c_.w, (float)(tx * TILE), (float)(ty * TILE), subpixel_offset != nullptr); \
         }                                                                                           \
+        __syncthreads();                                                                            \
+        const int cnt_ = min(BLEND_THREADS, n - (r_) * BLEND_THREADS);                              \
+        n_w_ = 0;                                                                                   \
+        _Pragma("unroll") for (int q_ = 0; q_ < BLEND_THREADS / GVF_WAVE; ++q_) {                   \
+            const int idx_ = q_ * GVF_WAVE + lane;                                                  \
+            const bool hit_ = idx_ < cnt_ && ((sMask[idx_] >> wave) & 1u);                          \
+            const uint64_t bal_ = __ballot(hit_);                                                   \
+            if (hit_) sList[wave][n_w_ + __popcll(bal_ & lt_mask)] = (unsigned char)idx_;           \
+            n_w_ += __popcll(bal_);                                                                 \
+        }                                                                                           \
+        __builtin_amdgcn_wave_barrier();                                                            \
     }
     // ---- phase A: forward replay
     bool done = !inside;
@@ -1524,10 +1563,11 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_backward_kernel(
     int last = 0;
     for (int r = 0; r < rounds; ++r) {
         if (__syncthreads_count(done) == BLEND_THREADS) break;
-        GVF_BWD_STAGE(r)
-        __syncthreads();
-        const int cnt = min(BLEND_THREADS, n - r * BLEND_THREADS);
-        for (int j = 0; j < cnt; ++j) {
+        int n_w;
+        GVF_BWD_STAGE(r, n_w)
+        for (int jj = 0; jj < n_w; ++jj) {
+            if (__all(done)) break;
+            const int j = sList[wave][jj];
             const float4 a = sA[j];
             const float4 b = sB[j];
             const float dx = a.x - pxf, dy = a.y - pyf;
@@ -1539,6 +1579,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_backward_kernel(
             done = done || stop;
             if (ok && !stop) { T = test_T; last = r * BLEND_THREADS + j + 1; }
         }
+        __syncthreads();                                   // the batch is restaged next round
     }
     const float T_final = T;
     float dch[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
@@ -1553,55 +1594,59 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_backward_kernel(
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) max_last = max(max_last, __shfl_xor(max_last, o, 64));
     // ---- phase B: back to front
+    __syncthreads();
     for (int r = rounds - 1; r >= 0; --r) {
-        __syncthreads();                                   // everyone is done with the previous batch
-        GVF_BWD_STAGE(r)
-        __syncthreads();
-        const int cnt = min(BLEND_THREADS, n - r * BLEND_THREADS);
-        if (r * BLEND_THREADS >= max_last) continue;       // nothing in this batch contributed to this wave's pixels
-        for (int j = cnt - 1; j >= 0; --j) {
-            const int k = r * BLEND_THREADS + j;
-            if (k >= max_last) continue;                   // wave-uniform
-            const float4 a = sA[j];
-            const float4 b = sB[j];
-            const float2 c = sC[j];
-            const float dx = a.x - pxf, dy = a.y - pyf;
-            const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-            const float G = __expf(power);
-            const float alpha = fminf(0.99f, b.y * G);
-            const bool on = inside && k < last && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-            if (!__any(on)) continue;
-            float g[BWD_ACC];
+        int n_w;
+        GVF_BWD_STAGE(r, n_w)
+        if (r * BLEND_THREADS < max_last) {                // else: nothing of this batch reached this wave's pixels
+            for (int jj = n_w - 1; jj >= 0; --jj) {
+                const int j = sList[wave][jj];
+                const int k = r * BLEND_THREADS + j;
+                if (k >= max_last) continue;               // wave-uniform
+                const float4 a = sA[j];
+                const float4 b = sB[j];
+                const float2 c = sC[j];
+                const float dx = a.x - pxf, dy = a.y - pyf;
+                const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+                const float G = __expf(power);
+                const float alpha = fminf(0.99f, b.y * G);
+                const bool on = inside && k < last && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+                if (!__any(on)) continue;
+                float g[BWD_ACC];
 #pragma unroll
-            for (int e = 0; e < BWD_ACC; ++e) g[e] = 0.f;
-            if (on) {
-                T = T / (1.f - alpha);                     // transmittance in front of this splat
-                const float cch[5] = {b.z, b.w, c.x, c.y, 1.0f};
-                const float inv1ma = 1.0f / (1.f - alpha);
-                float dL_da = 0.f;
+                for (int e = 0; e < BWD_ACC; ++e) g[e] = 0.f;
+                if (on) {
+                    T = T / (1.f - alpha);                 // transmittance in front of this splat
+                    const float cch[5] = {b.z, b.w, c.x, c.y, 1.0f};
+                    const float inv1ma = 1.0f / (1.f - alpha);
+                    float dL_da = 0.f;
 #pragma unroll
-                for (int ch = 0; ch < 5; ++ch) {
-                    dL_da += (cch[ch] * T - suf[ch] * inv1ma) * dch[ch];
-                    suf[ch] += cch[ch] * alpha * T;
+                    for (int ch = 0; ch < 5; ++ch) {
+                        dL_da += (cch[ch] * T - suf[ch] * inv1ma) * dch[ch];
+                        suf[ch] += cch[ch] * alpha * T;
+                    }
+                    const float w = alpha * T;
+                    g[6] = w * dch[0]; g[7] = w * dch[1]; g[8] = w * dch[2]; g[9] = w * dch[3];
+                    g[5] = G * dL_da;
+                    const float dG = b.y * dL_da * G;      // dL/dpower (gradient passes through the 0.99 clamp)
+                    g[0] = dG * (-a.z * dx - a.w * dy);
+                    g[1] = dG * (-b.x * dy - a.w * dx);
+                    g[2] = dG * (-0.5f * dx * dx);
+                    g[3] = dG * (-dx * dy);
+                    g[4] = dG * (-0.5f * dy * dy);
                 }
-                const float w = alpha * T;
-                g[6] = w * dch[0]; g[7] = w * dch[1]; g[8] = w * dch[2]; g[9] = w * dch[3];
-                g[5] = G * dL_da;
-                const float dG = b.y * dL_da * G;          // dL/dpower (gradient passes through the 0.99 clamp)
-                g[0] = dG * (-a.z * dx - a.w * dy);
-                g[1] = dG * (-b.x * dy - a.w * dx);
-                g[2] = dG * (-0.5f * dx * dx);
-                g[3] = dG * (-dx * dy);
-                g[4] = dG * (-0.5f * dy * dy);
-            }
+                // row sums of the ten components, then position e of every row keeps component e, so that ONE
+                // cross-row reduction finishes all ten; lanes 0-9 add them with one atomic instruction
 #pragma unroll
-            for (int e = 0; e < BWD_ACC; ++e) g[e] = wave_sum(g[e]);
-            if (lane == 0) {
-                float* dst = acc + (size_t)sId[j] * BWD_ACC;
+                for (int e = 0; e < BWD_ACC; ++e) g[e] = row_sum(g[e]);
+                float mine = g[0];
 #pragma unroll
-                for (int e = 0; e < BWD_ACC; ++e) unsafeAtomicAdd(dst + e, g[e]);
+                for (int e = 1; e < BWD_ACC; ++e) mine = (lane & 15) == e ? g[e] : mine;
+                mine = across_rows_sum(mine);
+                if (lane < BWD_ACC) unsafeAtomicAdd(acc + (size_t)sId[j] * BWD_ACC + lane, mine);
             }
         }
+        __syncthreads();                                   // everyone is done with this batch
     }
 #undef GVF_BWD_STAGE
 }
