@@ -56,7 +56,14 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, delta_pc=None, de
     tanfovy = math.tan(float(viewpoint_camera.FoVy) * 0.5)
     H, W = int(viewpoint_camera.image_height), int(viewpoint_camera.image_width)
     dev = pc.get_xyz.device
+    # zero tensor whose .grad receives the screen-space (2D mean) gradients, as at gaussian_render.py:96-100
     screenspace_points = torch.zeros_like(pc.get_xyz)
+    if torch.is_grad_enabled():
+        screenspace_points = torch.zeros_like(pc.get_xyz, requires_grad=True) + 0
+        try:
+            screenspace_points.retain_grad()
+        except Exception:
+            pass
 
     common = dict(image_height=H, image_width=W, tanfovx=tanfovx, tanfovy=tanfovy, bg=bg_color,
                   scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,

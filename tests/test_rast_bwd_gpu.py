@@ -112,3 +112,51 @@ def test_no_grad_path_is_unchanged_and_backward_needs_its_own_workspace(cuda):
         (wgt * c.sum()).backward()
         acc += lv["means3D"].grad
     assert rel(g_both.cpu().numpy(), acc.cpu().numpy()) < 1e-4
+
+
+def test_render_loss_gradient_reaches_the_deltas_through_the_facade(cuda):
+    """The training-step shape (train_vae.py:321-352): GaussianRenderer.render(gaussian, ..., delta_pc) under autograd; the
+    gradient w.r.t. the (P,14) delta and the screen-space gradient in `viewspace_points`, against the oracle chained
+    through the same GaussianModel activations on the CPU."""
+    from gvfdiffusion_amd.renderers import GaussianRenderer
+    from gvfdiffusion_amd.renderers.gaussian_render import render as render_fn
+    P, S, deg = 2500, 128, 2
+    attrs = _scene(P, deg, 41)
+    cam = camera_block(azi=55.0, elev=5.0)
+    rend = GaussianRenderer({"resolution": S, "near": synthetic.NEAR, "far": synthetic.FAR, "bg_color": (0.3, 0.3, 0.3)})
+    rend.pipe.use_mip_gaussian = True
+    wc = torch.randn((3, S, S), generator=torch.Generator().manual_seed(4))
+    d0 = synthetic.random_deltas(1, P, seed=2, std=0.01)[0]
+
+    gm = synthetic.gaussian_model_from(attrs, deg, cuda)
+    delta = d0.clone().to(cuda).requires_grad_(True)
+    out = rend.render(gm, cam["extrinsics"].to(cuda), cam["intrinsics"].to(cuda), delta_pc=delta)
+    (out.rgb * wc.to(cuda)).sum().backward()
+    assert delta.grad is not None and torch.isfinite(delta.grad).all()
+
+    # oracle chain: activations on the CPU under autograd (same module, torch ops), operator gradient from the oracle
+    gmc = synthetic.gaussian_model_from(attrs, deg, torch.device("cpu"))
+    dc = d0.clone().requires_grad_(True)
+    act = [gmc.get_xyz_with_delta(dc[..., :3]), gmc.get_features_with_delta(dc[..., 10:13].unsqueeze(1)),
+           gmc.get_opacity_with_delta(dc[..., 13:]), gmc.get_scaling_with_delta(dc[..., 3:6]), gmc.get_rotation_with_delta(dc[..., 6:10])]
+    n = lambda t: t.detach().double().numpy()
+    kw = dict(H=S, W=S, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], kernel_size=float(rend.pipe.kernel_size),
+              scale_modifier=float(rend.pipe.scale_modifier), viewmatrix=cam["viewmatrix"].numpy(), projmatrix=cam["projmatrix"].numpy(),
+              campos=cam["campos"].numpy(), sh_degree=deg, bg=np.asarray([0.3, 0.3, 0.3]), mode=0)
+    ref = oracle.rast64_backward(n(act[0]), n(act[1]), None, n(act[2]), n(act[3]), n(act[4]), None, n(wc), **kw)
+    gouts = [torch.tensor(ref[k].reshape(t.shape), dtype=torch.float32) for k, t in
+             zip(("means3D", "shs", "opacities", "scales", "rotations"), act)]
+    (gref,) = torch.autograd.grad(act, dc, grad_outputs=gouts)
+    e = rel(delta.grad.cpu().numpy(), gref.numpy())
+    print(f"facade: d loss / d delta rel {e:.1e}")
+    assert e < 2e-3
+
+    # viewspace_points.grad, as the reference's densification statistics read it
+    cam_dict = None
+    from gvfdiffusion_amd.renderers.gaussian_render import _camera
+    cam_dict = _camera(cam["extrinsics"].to(cuda), cam["intrinsics"].to(cuda), synthetic.NEAR, synthetic.FAR, S)
+    delta2 = d0.clone().to(cuda).requires_grad_(True)
+    res = render_fn(cam_dict, gm, rend.pipe, torch.tensor([0.3, 0.3, 0.3], device=cuda), delta_pc=delta2)
+    (res["render"] * wc.to(cuda)).sum().backward()
+    vs = res["viewspace_points"].grad
+    assert vs is not None and rel(vs[:, :2].cpu().numpy(), ref["means2D"]) < 2e-3
