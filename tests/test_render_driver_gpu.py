@@ -46,7 +46,8 @@ def test_driver_matches_per_frame_renders(cuda):
     rend.pipe.use_mip_gaussian = True
     for k in (0, 4, 7, 14):
         t, c = order[k]
-        one = rend.render(gm, cams[c].to(cuda), K, delta_pc=delta[t])["rgb"]     # the reference's per-frame call
+        with torch.no_grad():                                                     # as inference_dpm_latent.py:171 runs it
+            one = rend.render(gm, cams[c].to(cuda), K, delta_pc=delta[t])["rgb"]     # the reference's per-frame call
         ref = (one.clamp(0.0, 1.0).cpu().numpy() * 255).astype("uint8")         # inference_utils.py:276-281
         d = np.abs(got[k].cpu().numpy().astype(int) - ref.astype(int))
         # torch activations (facade) vs fused activations (driver): sub-ulp colour differences can flip a uint8 step
