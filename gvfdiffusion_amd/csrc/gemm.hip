@@ -11,6 +11,7 @@
 // global -> LDS by LDS-DMA (global_load_lds_dwordx4; 16-byte chunks, rows XOR-swizzled on the source side so
 // the per-fragment ds_read_b128 of a 16-lane group hits 8 distinct 16-byte slots), the next k-tile's DMA
 // issued before the MFMAs of the current one, one __syncthreads per k-tile, two LDS buffers.
+#include <cstdlib>
 #include "gvf_common.h"
 #include "../../include/gvf_rast.h"
 #include "../../include/gvf_dit.h"
@@ -20,13 +21,13 @@ namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-constexpr int BN = 128, BK = 32;                    // BM (128 or 64) is a template parameter
+constexpr int BN = 128;                             // BM (128 or 64) and BK (32 or 64) are template parameters
 constexpr int THREADS = 256;
-constexpr int CHUNKS_PER_ROW = BK / 8;              // 16-byte chunks per tile row
-constexpr int ROWS_PER_DMA = 64 / CHUNKS_PER_ROW;       // tile rows filled by one wave-wide DMA instruction (16)
-// chunk swizzle for 64-byte rows: slot = chunk ^ swz(row); conflict-free for the ds_read_b128 lane groups
-// ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...) when swz(row) = 3 for rows 8..15 of each 16-row group, else 0.
-__device__ __forceinline__ int swz(int row) { return (row & 8) ? 3 : 0; }
+// chunk swizzle, slot = chunk ^ swz(row): conflict-free for the ds_read_b128 lane groups ({0-3,12-15,20-27},
+// {4-11,16-19,28-31}, ...).  64-byte rows (BK = 32): 3 for rows 8..15 of each 16-row group, else 0; 128-byte rows
+// (BK = 64): row & 7 (the 16 lanes of a group then hit 16 distinct 16-byte slots of the 256-byte bank row).
+template <int CPR>
+__device__ __forceinline__ int swz(int row) { return CPR == 4 ? ((row & 8) ? 3 : 0) : (row & 7); }
 
 __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
     unsigned u = __float_as_uint(f);
@@ -60,14 +61,17 @@ __device__ __forceinline__ void dma16(const unsigned short* g, uint4* l) {
 // BM = 128: 2x2 waves of 64x64 (4x4 fragments).  BM = 64: 2x2 waves of 32x64 (2x4 fragments), used when the
 // 128-row tiling would leave the chip with fewer than two workgroups per CU (the DiT's N = 512 projections:
 // 384 tiles on 256 CUs) -- twice the workgroups, so twice the DMA tiles in flight to hide the load latency.
-template <int EPI, int BM>
-__global__ __launch_bounds__(THREADS, 4) void gemm_bf16_kernel(const unsigned short* __restrict__ A, int lda,
+// BK = 64 halves the number of k-tiles (barriers, DMA issue points) for the long-K projection (mlp.2, K = 2048).
+template <int EPI, int BM, int BK>
+__global__ __launch_bounds__(THREADS, BK == 32 ? 4 : (BM == 64 ? 3 : 2)) void gemm_bf16_kernel(const unsigned short* __restrict__ A, int lda,
                                                             const unsigned short* __restrict__ W, int ldw,
                                                             const float* __restrict__ bias, void* __restrict__ Cv,
                                                             int ldc, int M, int N, int K,
                                                             const float* __restrict__ gate, int gate_ld, int rpg,
                                                             int tiles_n) {
     constexpr int MI = BM / 32;                          // 16-row fragments per wave along M
+    constexpr int CHUNKS_PER_ROW = BK / 8;               // 16-byte chunks per tile row
+    constexpr int ROWS_PER_DMA = 64 / CHUNKS_PER_ROW;    // tile rows filled by one wave-wide DMA instruction
     constexpr int LOADS_A = BM * CHUNKS_PER_ROW / THREADS, LOADS_B = BN * CHUNKS_PER_ROW / THREADS;
     // one LDS block: A buffers, then W buffers; indexed through the array itself so that the address space stays
     // LDS for the DMA builtin (a pointer variable would be generic)
@@ -102,13 +106,13 @@ __global__ __launch_bounds__(THREADS, 4) void gemm_bf16_kernel(const unsigned sh
     for (int i = 0; i < LOADS_A; ++i) {
         const int row = (i * 4 + wave) * ROWS_PER_DMA + st_row;   // tile row this lane fills with load i
         const int gr = bm + row < M ? bm + row : M - 1;
-        a_src[i] = A + (size_t)gr * lda + ((st_c ^ swz(row)) * 8);
+        a_src[i] = A + (size_t)gr * lda + ((st_c ^ swz<CHUNKS_PER_ROW>(row)) * 8);
     }
 #pragma unroll
     for (int i = 0; i < LOADS_B; ++i) {
         const int row = (i * 4 + wave) * ROWS_PER_DMA + st_row;
         const int gn = bn + row < N ? bn + row : N - 1;
-        w_src[i] = W + (size_t)gn * ldw + ((st_c ^ swz(row)) * 8);
+        w_src[i] = W + (size_t)gn * ldw + ((st_c ^ swz<CHUNKS_PER_ROW>(row)) * 8);
     }
 #define GVF_GEMM_STAGE(kt_, buf_)                                                                          \
     _Pragma("unroll") for (int i = 0; i < LOADS_A; ++i)                                                      \
@@ -122,18 +126,19 @@ __global__ __launch_bounds__(THREADS, 4) void gemm_bf16_kernel(const unsigned sh
     for (int kt = 0; kt < KT; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < KT) { GVF_GEMM_STAGE(kt + 1, buf ^ 1) }   // lands while this tile is multiplied
-        {
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ++ks) {
             bf16x8 af[MI], bfr[4];
-            const int kc = lane >> 4;
+            const int kc = ks * 4 + (lane >> 4);
 #pragma unroll
             for (int f = 0; f < MI; ++f) {
                 const int ar = wm * (BM / 2) + f * 16 + (lane & 15);
-                af[f] = __builtin_bit_cast(bf16x8, SA(buf, ar * CHUNKS_PER_ROW + (kc ^ swz(ar))));
+                af[f] = __builtin_bit_cast(bf16x8, SA(buf, ar * CHUNKS_PER_ROW + (kc ^ swz<CHUNKS_PER_ROW>(ar))));
             }
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
                 const int br = wn * 64 + f * 16 + (lane & 15);
-                bfr[f] = __builtin_bit_cast(bf16x8, SB(buf, br * CHUNKS_PER_ROW + (kc ^ swz(br))));
+                bfr[f] = __builtin_bit_cast(bf16x8, SB(buf, br * CHUNKS_PER_ROW + (kc ^ swz<CHUNKS_PER_ROW>(br))));
             }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
@@ -224,7 +229,7 @@ __global__ __launch_bounds__(THREADS, 4) void gemm_bf16_kernel(const unsigned sh
 extern "C" int gvf_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc,
                              int M, int N, int K, int epilogue, const float* gate, int gate_ld, int rows_per_group,
                              void* stream_) {
-    if (M < 0 || N <= 0 || K <= 0 || (K % BK) != 0 || (lda % 8) != 0 || (ldw % 8) != 0 || lda < K || ldw < K || ldc < N)
+    if (M < 0 || N <= 0 || K <= 0 || (K % 32) != 0 || (lda % 8) != 0 || (ldw % 8) != 0 || lda < K || ldw < K || ldc < N)
         return GVF_EINVAL;
     if (M == 0) return GVF_OK;
     if (!A || !W || !C) return GVF_EINVAL;
@@ -242,9 +247,19 @@ extern "C" int gvf_gemm_bf16(const void* A, int lda, const void* W, int ldw, con
     const int rpg = rows_per_group > 0 ? rows_per_group : 1;
     // (<<<>>> rather than hipLaunchKernelGGL: a parenthesised two-argument template-id inside the macro is only an
     // address-of expression and does not make clang emit the host stub of the instantiation)
+    static const int bk_override = []() { const char* e = getenv("GVF_GEMM_BK"); return e ? atoi(e) : 0; }();   // tuning aid
+    // 64-deep k-tiles only for the long-K projection (mlp.2, K = 2048: 47 -> 40 us).  On the K = 512 shapes they win
+    // 4-7 % in a back-to-back micro-benchmark (scripts/bench_gemm.py, operands cache-hot) and LOSE 3 % of the whole
+    // denoise step in place (8.65 -> 8.92 ms / NFE, A/B in one process): fewer resident workgroups per CU.
+    const bool bk64 = bk_override ? bk_override == 64 : K >= 1024;
 #define GVF_GEMM_LAUNCH(EPI_)                                                                                     \
-    if (small) gemm_bf16_kernel<EPI_, 64><<<grid, block, 0, stream>>>(a, lda, w, ldw, bias, C, ldc, M, N, K, gate, gate_ld, rpg, tiles_n); \
-    else gemm_bf16_kernel<EPI_, 128><<<grid, block, 0, stream>>>(a, lda, w, ldw, bias, C, ldc, M, N, K, gate, gate_ld, rpg, tiles_n);
+    if (bk64 && (K % 64) == 0) {                                                                                   \
+        if (small) gemm_bf16_kernel<EPI_, 64, 64><<<grid, block, 0, stream>>>(a, lda, w, ldw, bias, C, ldc, M, N, K, gate, gate_ld, rpg, tiles_n); \
+        else gemm_bf16_kernel<EPI_, 128, 64><<<grid, block, 0, stream>>>(a, lda, w, ldw, bias, C, ldc, M, N, K, gate, gate_ld, rpg, tiles_n); \
+    } else {                                                                                                       \
+        if (small) gemm_bf16_kernel<EPI_, 64, 32><<<grid, block, 0, stream>>>(a, lda, w, ldw, bias, C, ldc, M, N, K, gate, gate_ld, rpg, tiles_n); \
+        else gemm_bf16_kernel<EPI_, 128, 32><<<grid, block, 0, stream>>>(a, lda, w, ldw, bias, C, ldc, M, N, K, gate, gate_ld, rpg, tiles_n); \
+    }
     switch (epilogue) {
         case GVF_EPI_STORE_BF16: GVF_GEMM_LAUNCH(GVF_EPI_STORE_BF16) break;
         case GVF_EPI_GELU_BF16: GVF_GEMM_LAUNCH(GVF_EPI_GELU_BF16) break;
