@@ -17,7 +17,9 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-
 # (no implicit fma contraction; fmaf only where written).
 SOURCES = {
     "sort.hip": [],
-    "rast.hip": ["-ffp-contract=off"],
+    # -fno-slp-vectorize: left on, clang packs neighbouring scalar fp32 operations of the compositing loop into
+    # v_pk_* instructions (4 cycles each against 2.8 for the scalar form, plus the v_mov traffic that builds the pairs)
+    "rast.hip": ["-ffp-contract=off", "-fno-slp-vectorize"],
     "vox2seq.hip": [],
     # MFMA results straight into VGPRs (gfx950 has a unified register file): removes the accvgpr
     # read/write traffic between the MFMAs and the softmax / epilogue VALU code.

@@ -50,6 +50,18 @@ constexpr int PRE_FB = 4;   // frames per preprocess workgroup: the frame-invari
 constexpr int TILE = GVF_TILE;
 constexpr int BLEND_THREADS = TILE * TILE;
 constexpr int MAX_SH_COEFFS = 16;
+// The splat record holds the conic PRE-SCALED for the blend: (a, b, c) -> (CONIC_K1 a, CONIC_K2 b, CONIC_K1 c), so that
+//   log2(e) * power = log2(e) * (-0.5 (a dx^2 + c dy^2) - b dx dy) = a' dx^2 + c' dy^2 + b' dx dy
+// is three multiplies and two fmas straight into v_exp_f32 (upstream's form costs nine VALU instructions plus the
+// exp's own log2(e) multiply; the compositing loop is VALU-bound).  Readers that need the conic itself un-scale it.
+constexpr float CONIC_K1 = -0.7213475204444817f;   // -0.5 log2(e)
+constexpr float CONIC_K2 = -1.4426950408889634f;   // -log2(e)
+constexpr float CONIC_IK1 = -1.3862943611198906f;  // 1 / CONIC_K1 = -2 ln 2
+constexpr float CONIC_IK2 = -0.6931471805599453f;  // 1 / CONIC_K2 = -ln 2
+// exponent (in octaves) of the Gaussian weight at offset (dx, dy) from the splat centre; `power > 0` <=> result > 0
+__device__ __forceinline__ float splat_exponent(float ap, float bp, float cp, float dx, float dy) {
+    return __builtin_fmaf(bp * dx, dy, __builtin_fmaf(cp * dy, dy, (ap * dx) * dx));
+}
 
 __constant__ float SH_C0 = 0.28209479177387814f;
 __constant__ float SH_C1 = 0.4886025119029199f;
@@ -416,8 +428,8 @@ __global__ __launch_bounds__(PRE_THREADS) void preprocess_kernel(
                     }
                     touched = cnt;
                     rect = r;
-                    gA = make_float4(px, py, ca, cb);
-                    gB = make_float4(cc, op * coef, rgb[0], rgb[1]);
+                    gA = make_float4(px, py, ca * CONIC_K1, cb * CONIC_K2);
+                    gB = make_float4(cc * CONIC_K1, op * coef, rgb[0], rgb[1]);
                     gC = make_float4(rgb[2], pv[2], ext.x, ext.y);
                 }
             }
@@ -1163,8 +1175,8 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
             const float4 b = sB[J];                                                                    \
             const float2 c = sC[J];                                                                    \
             const float dx = a.x - pxf, dy = a.y - pyf;                                                \
-            const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;               \
-            const float alpha = fminf(0.99f, b.y * __expf(power));                                     \
+            const float power = splat_exponent(a.z, a.w, b.x, dx, dy);      /* in octaves */            \
+            const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(power));                     \
             const bool ok = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);                      \
             const float test_T = T * (1.f - alpha);                                                    \
             const bool stop = ok && test_T < 0.0001f;                                                  \
@@ -1571,8 +1583,8 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_backward_kernel(
             const float4 a = sA[j];
             const float4 b = sB[j];
             const float dx = a.x - pxf, dy = a.y - pyf;
-            const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-            const float alpha = fminf(0.99f, b.y * __expf(power));
+            const float power = splat_exponent(a.z, a.w, b.x, dx, dy);
+            const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(power));
             const bool ok = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
             const float test_T = T * (1.f - alpha);
             const bool stop = ok && test_T < 0.0001f;
@@ -1607,8 +1619,8 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_backward_kernel(
                 const float4 b = sB[j];
                 const float2 c = sC[j];
                 const float dx = a.x - pxf, dy = a.y - pyf;
-                const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-                const float G = __expf(power);
+                const float power = splat_exponent(a.z, a.w, b.x, dx, dy);
+                const float G = __builtin_amdgcn_exp2f(power);
                 const float alpha = fminf(0.99f, b.y * G);
                 const bool on = inside && k < last && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
                 if (!__any(on)) continue;
@@ -1629,8 +1641,9 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_backward_kernel(
                     g[6] = w * dch[0]; g[7] = w * dch[1]; g[8] = w * dch[2]; g[9] = w * dch[3];
                     g[5] = G * dL_da;
                     const float dG = b.y * dL_da * G;      // dL/dpower (gradient passes through the 0.99 clamp)
-                    g[0] = dG * (-a.z * dx - a.w * dy);
-                    g[1] = dG * (-b.x * dy - a.w * dx);
+                    const float ca = a.z * CONIC_IK1, cb = a.w * CONIC_IK2, cc = b.x * CONIC_IK1;   // the conic itself
+                    g[0] = dG * (-ca * dx - cb * dy);
+                    g[1] = dG * (-cc * dy - cb * dx);
                     g[2] = dG * (-0.5f * dx * dx);
                     g[3] = dG * (-dx * dy);
                     g[4] = dG * (-0.5f * dy * dy);
