@@ -1094,20 +1094,40 @@ __global__ void tile_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __r
 //     order) and iterates over that list only.  A typical splat (3-sigma radius ~9 px) reaches ~40 % of the
 //     quadrants of the tiles it was binned to, so ~60 % of upstream's (pixel, splat) evaluations disappear.
 // Early termination is per wave (all 64 pixels saturated) and per workgroup (stop staging).
-__device__ __forceinline__ unsigned quadrant_mask(float x, float y, float hx, float hy, float tile_x0, float tile_y0,
-                                                  bool no_cull) {
+// Which of the tile's four 8x8 quadrants can a splat reach with alpha >= 1/255?  Exact (up to a safety margin) test of
+// the ellipse  e(dx, dy) = a' dx^2 + b' dx dy + c' dy^2 >= -log2(255 opacity)  against each quadrant's rectangle: e is
+// concave, so its maximum over a rectangle that does not contain the centre sits on one of the four edges, at the
+// clamped vertex of a 1-D parabola.  (The axis-aligned box (hx, hy) that the binning uses keeps ~25 % more pairs: the
+// corners of the box of a rotated, elongated ellipse.)  The test only decides which (splat, quadrant) pairs are
+// evaluated; a kept splat is evaluated with the usual arithmetic and a culled one would have failed alpha >= 1/255 at
+// every pixel of the quadrant (margin: 0.02 octaves on the threshold against ~1e-5 of rounding), so images do not change.
+__device__ __forceinline__ float edge_max(float qa, float qb, float qc, float fixed, float lo, float hi) {
+    // max over t in [lo, hi] of  qa fixed^2 + qb fixed t + qc t^2   (qc < 0)
+    const float t = fminf(fmaxf(-0.5f * qb * fixed / qc, lo), hi);
+    return qa * fixed * fixed + (qb * fixed + qc * t) * t;
+}
+__device__ __forceinline__ unsigned quadrant_mask(float x, float y, float ap, float bp, float cp, float op, float hx,
+                                                  float tile_x0, float tile_y0, bool no_cull) {
     if (hx < 0.0f) return 0u;                            // opacity < 1/255: alpha < 1/255 at every pixel
-    if (no_cull) return 0xFu;
+    if (no_cull || !(hx < __builtin_inff())) return 0xFu; // sub-pixel offsets / degenerate conic: keep everywhere
+    const float lim = -(__log2f(255.0f * op) + 0.02f);
     unsigned m = 0u;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const float x0 = tile_x0 + (float)((q & 1) * 8), y0 = tile_y0 + (float)((q >> 1) * 8);
-        const bool hit = (x + hx >= x0) && (x - hx <= x0 + 7.0f) && (y + hy >= y0) && (y - hy <= y0 + 7.0f);
-        m |= hit ? (1u << q) : 0u;
+        const float dxl = x - (x0 + 7.0f), dxh = x - x0, dyl = y - (y0 + 7.0f), dyh = y - y0;   // offset ranges over the quadrant
+        const bool inside = dxl <= 0.0f && dxh >= 0.0f && dyl <= 0.0f && dyh >= 0.0f;
+        float e = edge_max(ap, bp, cp, dxl, dyl, dyh);
+        e = fmaxf(e, edge_max(ap, bp, cp, dxh, dyl, dyh));
+        e = fmaxf(e, edge_max(cp, bp, ap, dyl, dxl, dxh));
+        e = fmaxf(e, edge_max(cp, bp, ap, dyh, dxl, dxh));
+        m |= (inside || e >= lim) ? (1u << q) : 0u;
     }
     return m;
 }
 
+// DEPTH: accumulate the depth channel (diff_gauss outputs; one fma per evaluated splat that the mip path does not pay)
+template <bool DEPTH>
 __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
     int P, int H, int W, int gx, int gy, float bg0, float bg1, float bg2, const uint2* __restrict__ ranges,
     const uint32_t* __restrict__ point_list, const float4* __restrict__ splats,
@@ -1115,7 +1135,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
     float* __restrict__ out_alpha, float* __restrict__ out_depth, int nslab) {
     __shared__ float4 sA[BLEND_THREADS];
     __shared__ float4 sB[BLEND_THREADS];
-    __shared__ float2 sC[BLEND_THREADS];
+    __shared__ float4 sC[BLEND_THREADS];                  // {b, depth, -, -}: 16-byte stride like sA / sB, one index shift per splat
     __shared__ unsigned char sMask[BLEND_THREADS];
     __shared__ unsigned char sList[4][BLEND_THREADS];     // per-wave compacted splat indices of the batch
 
@@ -1148,9 +1168,10 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
             const float4 a = rec[0];
             const float4 c = rec[2];
             sA[t] = a;
-            sB[t] = rec[1];
-            sC[t] = make_float2(c.x, c.y);
-            sMask[t] = (unsigned char)quadrant_mask(a.x, a.y, c.z, c.w, (float)(tx * TILE), (float)(ty * TILE), subpixel_offset != nullptr);
+            sC[t] = make_float4(c.x, c.y, 0.f, 0.f);
+            const float4 b = rec[1];
+            sB[t] = b;
+            sMask[t] = (unsigned char)quadrant_mask(a.x, a.y, a.z, a.w, b.x, b.y, c.z, (float)(tx * TILE), (float)(ty * TILE), subpixel_offset != nullptr);
         }
         __syncthreads();
         const int cnt = min(BLEND_THREADS, todo);
@@ -1173,7 +1194,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
         {                                                                                              \
             const float4 a = sA[J];                                                                    \
             const float4 b = sB[J];                                                                    \
-            const float2 c = sC[J];                                                                    \
+            const float2 c = DEPTH ? make_float2(sC[J].x, sC[J].y) : make_float2(sC[J].x, 0.f);        \
             const float dx = a.x - pxf, dy = a.y - pyf;                                                \
             const float power = splat_exponent(a.z, a.w, b.x, dx, dy);      /* in octaves */            \
             const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(power));                     \
@@ -1186,7 +1207,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
             C0 = __builtin_fmaf(b.z, wgt, C0);                                                         \
             C1 = __builtin_fmaf(b.w, wgt, C1);                                                         \
             C2 = __builtin_fmaf(c.x, wgt, C2);                                                         \
-            Dacc = __builtin_fmaf(c.y, wgt, Dacc);                                                     \
+            if (DEPTH) Dacc = __builtin_fmaf(c.y, wgt, Dacc);                                          \
             T = acc ? test_T : T;                                                                      \
         }
         int jj = 0;
@@ -1471,9 +1492,14 @@ int run_pipeline(const GvfRastSettings& st, const GvfRastFrame* frames_host, int
     }
     uint32_t* vals_sorted = w.ids;
     prof_mark(stream, slot, 6);
-    hipLaunchKernelGGL(blend_kernel, dim3(ntiles, F), dim3(BLEND_THREADS), 0, stream, P, H, W, gx, gy, st.bg[0],
-                       st.bg[1], st.bg[2], w.ranges, vals_sorted, w.splats, subpixel_offset,
-                       out_color, out_alpha, out_depth, nslab_blend);
+    if (out_depth != nullptr)
+        hipLaunchKernelGGL(blend_kernel<true>, dim3(ntiles, F), dim3(BLEND_THREADS), 0, stream, P, H, W, gx, gy, st.bg[0],
+                           st.bg[1], st.bg[2], w.ranges, vals_sorted, w.splats, subpixel_offset,
+                           out_color, out_alpha, out_depth, nslab_blend);
+    else
+        hipLaunchKernelGGL(blend_kernel<false>, dim3(ntiles, F), dim3(BLEND_THREADS), 0, stream, P, H, W, gx, gy, st.bg[0],
+                           st.bg[1], st.bg[2], w.ranges, vals_sorted, w.splats, subpixel_offset,
+                           out_color, out_alpha, out_depth, nslab_blend);
     GVF_CHECK_LAUNCH();
     prof_mark(stream, slot, 7);
     return GVF_OK;
@@ -1554,8 +1580,9 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_backward_kernel(
             const float4* rec_ = splats + 4 * (size_t)id_;                                          \
             const float4 a_ = rec_[0];                                                              \
             const float4 c_ = rec_[2];                                                              \
-            sA[t] = a_; sB[t] = rec_[1]; sC[t] = make_float2(c_.x, c_.y); sId[t] = id_;             \
-            sMask[t] = (unsigned char)quadrant_mask(a_.x, a_.y, c_.z, c_.w, (float)(tx * TILE), (float)(ty * TILE), subpixel_offset != nullptr); \
+            const float4 b_ = rec_[1];                                                              \
+            sA[t] = a_; sB[t] = b_; sC[t] = make_float2(c_.x, c_.y); sId[t] = id_;                  \
+            sMask[t] = (unsigned char)quadrant_mask(a_.x, a_.y, a_.z, a_.w, b_.x, b_.y, c_.z, (float)(tx * TILE), (float)(ty * TILE), subpixel_offset != nullptr); \
         }                                                                                           \
         __syncthreads();                                                                            \
         const int cnt_ = min(BLEND_THREADS, n - (r_) * BLEND_THREADS);                              \
