@@ -1199,11 +1199,12 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
             const float power = splat_exponent(a.z, a.w, b.x, dx, dy);      /* in octaves */            \
             const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(power));                     \
             const bool ok = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);                      \
-            const float test_T = T * (1.f - alpha);                                                    \
+            const float w_raw = alpha * T;                                                             \
+            const float test_T = T - w_raw;        /* = T (1 - alpha) up to one rounding; one op less */ \
             const bool stop = ok && test_T < 0.0001f;                                                  \
             done = done || stop;                                                                       \
             const bool acc = ok && !stop;                                                              \
-            const float wgt = acc ? alpha * T : 0.0f;                                                  \
+            const float wgt = acc ? w_raw : 0.0f;                                                      \
             C0 = __builtin_fmaf(b.z, wgt, C0);                                                         \
             C1 = __builtin_fmaf(b.w, wgt, C1);                                                         \
             C2 = __builtin_fmaf(c.x, wgt, C2);                                                         \
@@ -1613,7 +1614,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_backward_kernel(
             const float power = splat_exponent(a.z, a.w, b.x, dx, dy);
             const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(power));
             const bool ok = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-            const float test_T = T * (1.f - alpha);
+            const float test_T = T - alpha * T;            // the forward's form
             const bool stop = ok && test_T < 0.0001f;
             done = done || stop;
             if (ok && !stop) { T = test_T; last = r * BLEND_THREADS + j + 1; }
