@@ -24,7 +24,8 @@ SOURCES = {
     # MFMA results straight into VGPRs (gfx950 has a unified register file): removes the accvgpr
     # read/write traffic between the MFMAs and the softmax / epilogue VALU code.
     # -fno-honor-nans: no canonicalising v_max in front of fmaxf (infinities stay honoured: -inf masks keys).
-    "attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"],
+    "attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans", "-fno-slp-vectorize"],
+    # (SLP left ON here: the GELU / LayerNorm epilogues measure 2 % slower in the denoise step without it)
     "gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
     "elem.hip": [],
     "vae.hip": [],
