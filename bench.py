@@ -184,7 +184,8 @@ def pmc_traffic(kernel, a, S, F):
     files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_raster.json")))
     if not files:
         return None
-    k = json.load(open(files[-1]))["kernels"].get(kernel)
+    kernels = json.load(open(files[-1]))["kernels"]
+    k = kernels.get(kernel) or next((v for n, v in kernels.items() if n.startswith(kernel + "<")), None)   # template instance
     return None if k is None else int(k["traffic_bytes_per_launch"])
 
 
