@@ -33,6 +33,7 @@
 // computed once per visible Gaussian.  A 16-byte bin record {x0|y0<<16, x1|y1<<16, depth bits, slab}; per
 // (frame, tile) a range, a counter and a cursor; per instance one u64 key and one u32 ordered id (radix path:
 // u64 key + u32 id, double buffered).
+#include <cstdlib>
 #include "gvf_common.h"
 #include "gvf_sort.h"
 #include "../../include/gvf_rast.h"
@@ -1548,6 +1549,8 @@ __device__ __forceinline__ float across_rows_sum(float v) {  // every lane: sum 
 // each pixel's final transmittance and the list position after its last contributor; phase B walks the lists back
 // to front, forms the per-(pixel, splat) gradients, sums them over the 64 pixels of the wave and adds the wave
 // sums to the per-Gaussian accumulators with hardware fp32 atomics.
+// AUX: the depth / alpha outputs carry gradients (diff_gauss); the mip path has three channels and nine partials.
+template <bool AUX>
 __global__ __launch_bounds__(BLEND_THREADS) void blend_backward_kernel(
     int P, int H, int W, int gx, float bg0, float bg1, float bg2, const uint2* __restrict__ ranges,
     const uint32_t* __restrict__ point_list, const float4* __restrict__ splats, const float* __restrict__ subpixel_offset,
@@ -1622,11 +1625,13 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_backward_kernel(
         __syncthreads();                                   // the batch is restaged next round
     }
     const float T_final = T;
+    constexpr int NCH = AUX ? 5 : 3;                        // channels r, g, b (, depth, one)
+    constexpr int NACC = AUX ? BWD_ACC : BWD_ACC - 1;       // without AUX the depth partial is identically zero
     float dch[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     if (inside) {
         dch[0] = dL_dcolor[pid]; dch[1] = dL_dcolor[hw + pid]; dch[2] = dL_dcolor[2 * hw + pid];
-        if (dL_ddepth != nullptr) dch[3] = dL_ddepth[pid];
-        if (dL_dalpha != nullptr) dch[4] = dL_dalpha[pid];
+        if (AUX && dL_ddepth != nullptr) dch[3] = dL_ddepth[pid];
+        if (AUX && dL_dalpha != nullptr) dch[4] = dL_dalpha[pid];
     }
     // what lies behind the current splat, per channel (r, g, b, depth, one); backgrounds (bg, 0, 0)
     float suf[5] = {T_final * bg0, T_final * bg1, T_final * bg2, 0.f, 0.f};
@@ -1661,12 +1666,13 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_backward_kernel(
                     const float inv1ma = 1.0f / (1.f - alpha);
                     float dL_da = 0.f;
 #pragma unroll
-                    for (int ch = 0; ch < 5; ++ch) {
+                    for (int ch = 0; ch < NCH; ++ch) {
                         dL_da += (cch[ch] * T - suf[ch] * inv1ma) * dch[ch];
                         suf[ch] += cch[ch] * alpha * T;
                     }
                     const float w = alpha * T;
-                    g[6] = w * dch[0]; g[7] = w * dch[1]; g[8] = w * dch[2]; g[9] = w * dch[3];
+                    g[6] = w * dch[0]; g[7] = w * dch[1]; g[8] = w * dch[2];
+                    if (AUX) g[9] = w * dch[3];
                     g[5] = G * dL_da;
                     const float dG = b.y * dL_da * G;      // dL/dpower (gradient passes through the 0.99 clamp)
                     const float ca = a.z * CONIC_IK1, cb = a.w * CONIC_IK2, cc = b.x * CONIC_IK1;   // the conic itself
@@ -1679,12 +1685,12 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_backward_kernel(
                 // row sums of the ten components, then position e of every row keeps component e, so that ONE
                 // cross-row reduction finishes all ten; lanes 0-9 add them with one atomic instruction
 #pragma unroll
-                for (int e = 0; e < BWD_ACC; ++e) g[e] = row_sum(g[e]);
+                for (int e = 0; e < NACC; ++e) g[e] = row_sum(g[e]);
                 float mine = g[0];
 #pragma unroll
-                for (int e = 1; e < BWD_ACC; ++e) mine = (lane & 15) == e ? g[e] : mine;
+                for (int e = 1; e < NACC; ++e) mine = (lane & 15) == e ? g[e] : mine;
                 mine = across_rows_sum(mine);
-                if (lane < BWD_ACC) unsafeAtomicAdd(acc + (size_t)sId[j] * BWD_ACC + lane, mine);
+                if (lane < NACC) unsafeAtomicAdd(acc + (size_t)sId[j] * BWD_ACC + lane, mine);
             }
         }
         __syncthreads();                                   // everyone is done with this batch
@@ -1700,6 +1706,7 @@ struct BwdParams {
 
 // Per-Gaussian chain rule from the blend's accumulators to the operator's inputs (the forward intermediates are
 // recomputed: 3D covariance, EWA Jacobian, 2D covariance, mip coefficient, SH basis).
+template <int DEG>      // SH degree: compile-time trip counts keep the basis arrays in registers
 __global__ __launch_bounds__(PRE_THREADS) void preprocess_backward_kernel(
     BwdParams bp, const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ colors_precomp,
     const float* __restrict__ opacities, const float* __restrict__ scales, const float* __restrict__ rotations,
@@ -1709,7 +1716,8 @@ __global__ __launch_bounds__(PRE_THREADS) void preprocess_backward_kernel(
     const int i = blockIdx.x * PRE_THREADS + threadIdx.x;
     if (i >= bp.P) return;
     const GvfRastFrame& fr = bp.fr;
-    const int M = bp.M, deg = bp.deg;
+    const int M = bp.M;
+    constexpr int deg = DEG;
     float gm[3] = {0.f, 0.f, 0.f}, gsc[3] = {0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f}, gc6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float gop = 0.f, gcol[3] = {0.f, 0.f, 0.f}, gm2[2] = {0.f, 0.f};
     bool vis = false;
@@ -1892,18 +1900,27 @@ __global__ __launch_bounds__(PRE_THREADS) void preprocess_backward_kernel(
                     }
                 }
             }
-            const int nb = (deg + 1) * (deg + 1);
+            constexpr int nb = (DEG + 1) * (DEG + 1);
             const float* sh = shs + (size_t)i * M * 3;
             float ddir[3] = {0.f, 0.f, 0.f};
-            for (int c = 0; c < 3; ++c) {
-                float res = 0.f;
-                for (int k = 0; k < nb; ++k) res += bas[k] * sh[k * 3 + c];
-                const float gr = (res + 0.5f < 0.f) ? 0.f : gcol_sh[c];
-                for (int k = 0; k < M; ++k) gs[k * 3 + c] = k < nb ? bas[k] * gr : 0.f;
-                for (int k = 0; k < nb; ++k) {
-                    ddir[0] += db[k][0] * sh[k * 3 + c] * gr; ddir[1] += db[k][1] * sh[k * 3 + c] * gr; ddir[2] += db[k][2] * sh[k * 3 + c] * gr;
+            float shc[nb][3];
+            float res[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < nb; ++k)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { shc[k][c] = sh[k * 3 + c]; res[c] += bas[k] * shc[k][c]; }
+            float gr[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) gr[c] = (res[c] + 0.5f < 0.f) ? 0.f : gcol_sh[c];
+#pragma unroll
+            for (int k = 0; k < nb; ++k)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    gs[k * 3 + c] = bas[k] * gr[c];
+                    const float sg = shc[k][c] * gr[c];
+                    ddir[0] += db[k][0] * sg; ddir[1] += db[k][1] * sg; ddir[2] += db[k][2] * sg;
                 }
-            }
+            for (int k = nb * 3; k < M * 3; ++k) gs[k] = 0.f;      // coefficients above the active degree
             const float dot = ddir[0] * dirv[0] + ddir[1] * dirv[1] + ddir[2] * dirv[2];
             gm[0] += (ddir[0] - dirv[0] * dot) / len; gm[1] += (ddir[1] - dirv[1] * dot) / len; gm[2] += (ddir[2] - dirv[2] * dot) / len;
         }
@@ -2010,16 +2027,29 @@ extern "C" int gvf_rast_backward(const GvfRastSettings* st, const GvfRastFrame* 
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE, ntiles = gx * gy;
     float* acc = (float*)scratch;
     if (hipMemsetAsync(acc, 0, (size_t)P * BWD_ACC * sizeof(float), stream) != hipSuccess) return GVF_ELAUNCH;
-    if (max_rendered > 0)
-        hipLaunchKernelGGL(blend_backward_kernel, dim3(ntiles), dim3(BLEND_THREADS), 0, stream, P, H, W, gx, st->bg[0], st->bg[1],
-                           st->bg[2], w.ranges, w.ids, w.splats, subpixel_offset, dL_dcolor, dL_dalpha, dL_ddepth, acc);
+    if (max_rendered > 0) {
+        if (dL_dalpha != nullptr || dL_ddepth != nullptr)
+            hipLaunchKernelGGL(blend_backward_kernel<true>, dim3(ntiles), dim3(BLEND_THREADS), 0, stream, P, H, W, gx, st->bg[0],
+                               st->bg[1], st->bg[2], w.ranges, w.ids, w.splats, subpixel_offset, dL_dcolor, dL_dalpha, dL_ddepth, acc);
+        else
+            hipLaunchKernelGGL(blend_backward_kernel<false>, dim3(ntiles), dim3(BLEND_THREADS), 0, stream, P, H, W, gx, st->bg[0],
+                               st->bg[1], st->bg[2], w.ranges, w.ids, w.splats, subpixel_offset, dL_dcolor, dL_dalpha, dL_ddepth, acc);
+    }
     GVF_CHECK_LAUNCH();
     BwdParams bp;
     bp.P = P; bp.M = M; bp.deg = st->sh_degree; bp.H = H; bp.W = W; bp.mode = st->mode;
     bp.kernel_size = st->kernel_size; bp.scale_modifier = st->scale_modifier; bp.fr = *frame_host;
-    hipLaunchKernelGGL(preprocess_backward_kernel, dim3((P + PRE_THREADS - 1) / PRE_THREADS), dim3(PRE_THREADS), 0, stream, bp,
-                       means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, acc, dL_dmeans3D, dL_dmeans2D,
-                       dL_dshs, dL_dcolors, dL_dopacities, dL_dscales, dL_drotations, dL_dcov3D);
+#define GVF_PRE_BWD(D_)                                                                                                         \
+    hipLaunchKernelGGL(preprocess_backward_kernel<D_>, dim3((P + PRE_THREADS - 1) / PRE_THREADS), dim3(PRE_THREADS), 0, stream, bp, \
+                       means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, acc, dL_dmeans3D, dL_dmeans2D,    \
+                       dL_dshs, dL_dcolors, dL_dopacities, dL_dscales, dL_drotations, dL_dcov3D)
+    switch (shs != nullptr ? st->sh_degree : 0) {
+        case 0: GVF_PRE_BWD(0); break;
+        case 1: GVF_PRE_BWD(1); break;
+        case 2: GVF_PRE_BWD(2); break;
+        default: GVF_PRE_BWD(3); break;
+    }
+#undef GVF_PRE_BWD
     GVF_CHECK_LAUNCH();
     return GVF_OK;
 }
