@@ -23,6 +23,7 @@ def declared_functions():
 def test_library_exports_every_declared_symbol():
     from gvfdiffusion_amd import _build, _lib
     import gvfdiffusion_amd.ops  # noqa: F401  (registers the remaining entry points)
+    import gvfdiffusion_amd.utils  # noqa: F401  (gvf_fps)
     assert os.path.exists(_build.LIB_PATH), "libgvf_hip.so not built (python -m gvfdiffusion_amd._build)"
     lib = ctypes.CDLL(_build.LIB_PATH)
     declared = declared_functions()
