@@ -175,6 +175,39 @@ def bench_dit(dev, nfe=32):
                                  "the loop); as-written equivalent = %.2f TFLOP/s" % (fa / per / 1e12)}}
 
 
+def bench_backward(dev, attrs, S, deg, iters=8):
+    """The operator as a training step sees it (train_vae.py:321-352): one frame per call under autograd, forward +
+    backward, same Gaussians / resolution as the headline workload.  Secondary figure, not part of `value`."""
+    from gvfdiffusion_amd import synthetic
+    from gvfdiffusion_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from rast_util import camera_block
+    leaves = {k: v.to(dev).requires_grad_(True) for k, v in attrs.items()}
+    P = leaves["means3D"].shape[0]
+    w = torch.randn((3, S, S), device=dev)
+    cams = [camera_block(azi=15.0 * f) for f in range(4)]
+
+    def one(i):
+        c = cams[i % 4]
+        rast = GaussianRasterizer(GaussianRasterizationSettings(
+            image_height=S, image_width=S, tanfovx=c["tanfovx"], tanfovy=c["tanfovy"], kernel_size=synthetic.KERNEL_2D,
+            subpixel_offset=None, bg=torch.tensor(synthetic.BG, device=dev), scale_modifier=1.0, viewmatrix=c["viewmatrix"].to(dev),
+            projmatrix=c["projmatrix"].to(dev), sh_degree=deg, campos=c["campos"].to(dev), prefiltered=False, debug=False))
+        color, _ = rast(means3D=leaves["means3D"], means2D=torch.zeros((P, 3), device=dev), shs=leaves["shs"], colors_precomp=None,
+                        opacities=leaves["opacities"], scales=leaves["scales"], rotations=leaves["rotations"], cov3D_precomp=None)
+        (color * w).sum().backward()
+
+    for i in range(3):
+        one(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(iters):
+        one(i)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / iters * 1e3
+    return {"metric": "differentiable render, forward + backward, one frame per call (incl. the host sync on num_rendered)",
+            "ms_per_frame": round(ms, 3), "frames_per_s": round(1e3 / ms, 1), "gaussians": P, "resolution": S, "sh_degree": deg}
+
+
 def pmc_traffic(kernel, a, S, F):
     """HBM-side bytes per launch of `kernel` from the committed PMC summary (the counters cannot be collected from
     inside the benchmark process); only for the default workload the summary was taken on, else None."""
@@ -320,6 +353,7 @@ def main():
         if world == 1 and not a.no_dit:
             del work.ws
             torch.cuda.empty_cache()
+            out["differentiable_render"] = bench_backward(dev, work.attrs, a.res, a.sh_degree)
             out["dit"] = bench_dit(dev)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(work)
