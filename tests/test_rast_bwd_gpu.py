@@ -160,3 +160,35 @@ def test_render_loss_gradient_reaches_the_deltas_through_the_facade(cuda):
     (res["render"] * wc.to(cuda)).sum().backward()
     vs = res["viewspace_points"].grad
     assert vs is not None and rel(vs[:, :2].cpu().numpy(), ref["means2D"]) < 2e-3
+
+
+def test_crowded_tiles_and_empty_input(cuda):
+    """Tiles with well over 256 instances (several staging rounds in both phases of the blend backward) and P = 0."""
+    P, S, deg = 6000, 64, 1
+    a = synthetic.random_gaussians(P, sh_degree=deg, seed=77, scale_lo=0.01, scale_hi=0.05)
+    a["means3D"] = a["means3D"] * 0.35                         # everything lands on ~16 tiles
+    a["opacities"] = a["opacities"].clamp(0.01, 0.6)           # low opacity: long lists before saturation
+    cam = camera_block(azi=12.0, elev=-6.0)
+    wc = torch.randn((3, S, S), generator=torch.Generator().manual_seed(8))
+    leaves = {k: v.clone().to(cuda).requires_grad_(True) for k, v in a.items()}
+    rast = _settings(cam, S, S, deg, 0, cuda)
+    color, radii = rast(means3D=leaves["means3D"], means2D=torch.zeros((P, 3), device=cuda), shs=leaves["shs"], colors_precomp=None,
+                        opacities=leaves["opacities"], scales=leaves["scales"], rotations=leaves["rotations"], cov3D_precomp=None)
+    (color * wc.to(cuda)).sum().backward()
+    n = lambda t: t.detach().double().cpu().numpy()
+    kw = dict(H=S, W=S, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], kernel_size=synthetic.KERNEL_2D, scale_modifier=1.0,
+              viewmatrix=cam["viewmatrix"].numpy(), projmatrix=cam["projmatrix"].numpy(), campos=cam["campos"].numpy(),
+              sh_degree=deg, bg=np.asarray(synthetic.BG, np.float64), mode=0)
+    ref = oracle.rast64_backward(n(a["means3D"]), n(a["shs"]), None, n(a["opacities"]), n(a["scales"]), n(a["rotations"]), None, n(wc), **kw)
+    per_tile = int((radii > 0).sum()) * 4 // 16
+    assert per_tile > 512, per_tile
+    for k in ("means3D", "shs", "opacities", "scales", "rotations"):
+        e = rel(n(leaves[k].grad).reshape(ref[k].shape), ref[k])
+        assert e < 2e-3, (k, e)
+    # P = 0: background only, empty gradients
+    z = lambda *s: torch.zeros(s, device=cuda, requires_grad=True)
+    m3, sh, op, sc, ro = z(0, 3), z(0, 4, 3), z(0, 1), z(0, 3), z(0, 4)
+    color0, _ = rast(means3D=m3, means2D=torch.zeros((0, 3), device=cuda), shs=sh, colors_precomp=None, opacities=op, scales=sc,
+                     rotations=ro, cov3D_precomp=None)
+    color0.sum().backward()
+    assert m3.grad.shape == (0, 3) and torch.allclose(color0, torch.tensor(synthetic.BG, device=cuda)[:, None, None].expand(3, S, S))
