@@ -70,7 +70,8 @@ __device__ __forceinline__ void wave_layernorm(float (&v)[QE_MAXI], int ni, int 
 __global__ __launch_bounds__(256) void query_embed_kernel(const float* __restrict__ queries, int qdim,
                                                           const float* __restrict__ W, const float* __restrict__ bias,
                                                           const float* __restrict__ omega, unsigned short* __restrict__ out,
-                                                          long long P, int C, float eps, float eps_pre, int rows_per_block) {
+                                                          float* __restrict__ out_embed, long long P, int C, float eps,
+                                                          float eps_pre, int rows_per_block) {
     extern __shared__ float sW[];   // [C][qdim + 1] (odd-ish pitch keeps lanes on distinct banks), then bias[C], omega[C/6]
     const int pitch = qdim | 1;
     float* sB = sW + (size_t)C * pitch;
@@ -109,7 +110,14 @@ __global__ __launch_bounds__(256) void query_embed_kernel(const float* __restric
         wave_layernorm(e2, ni, lane, C, eps);
 #pragma unroll
         for (int i = 0; i < QE_MAXI; ++i) e1[i] += e2[i];
-        wave_layernorm(e1, ni, lane, C, eps);
+        if (out_embed != nullptr) {                      // the embedding itself (the encoder's residual stream starts from it)
+#pragma unroll
+            for (int i = 0; i < QE_MAXI; ++i) {
+                const int c = lane + 64 * i;
+                if (i < ni && c < C) out_embed[row * C + c] = e1[i];
+            }
+        }
+        wave_layernorm(e1, ni, lane, C, eps_pre);
 #pragma unroll
         for (int i = 0; i < QE_MAXI; ++i) {
             const int c = lane + 64 * i;
@@ -136,6 +144,12 @@ extern "C" int gvf_geglu_bf16(const void* in_bf16, int ld_in, void* out_bf16, in
 
 extern "C" int gvf_vae_query_embed_bf16(const float* queries, int qdim, const float* W, const float* bias, const float* omega,
                                         void* out_bf16, int64_t P, int C, float eps_embed, float eps_prenorm, void* stream_) {
+    return gvf_vae_embed_bf16_f32(queries, qdim, W, bias, omega, out_bf16, nullptr, P, C, eps_embed, eps_prenorm, stream_);
+}
+
+extern "C" int gvf_vae_embed_bf16_f32(const float* queries, int qdim, const float* W, const float* bias, const float* omega,
+                                      void* out_bf16, float* out_embed_f32, int64_t P, int C, float eps_embed, float eps_prenorm,
+                                      void* stream_) {
     if (P < 0 || qdim < 3 || qdim > QE_MAXQ || C <= 0 || C > 64 * QE_MAXI || (C % 6) != 0) return GVF_EINVAL;
     if (P == 0) return GVF_OK;
     if (!queries || !W || !bias || !omega || !out_bf16) return GVF_EINVAL;
@@ -144,7 +158,7 @@ extern "C" int gvf_vae_query_embed_bf16(const float* queries, int qdim, const fl
     const size_t smem = ((size_t)C * (qdim | 1) + C + C / 6) * sizeof(float);
     const long long blocks = (P + rows_per_block - 1) / rows_per_block;
     hipLaunchKernelGGL(query_embed_kernel, dim3((unsigned)blocks), dim3(256), smem, (hipStream_t)stream_, queries, qdim, W, bias,
-                       omega, (unsigned short*)out_bf16, (long long)P, C, eps_embed, eps_prenorm, rows_per_block);
+                       omega, (unsigned short*)out_bf16, out_embed_f32, (long long)P, C, eps_embed, eps_prenorm, rows_per_block);
     GVF_CHECK_LAUNCH();
     return GVF_OK;
 }

@@ -1,10 +1,11 @@
-"""Motion VAE (`GSKLTemporalVariationalAutoEncoder`) -- the DECODE half on the MI355X kernels.
+"""Motion VAE (`GSKLTemporalVariationalAutoEncoder`) on the MI355X kernels: decode (the inference path) and encode.
 
 Mirrors model/autoencoder.py:345-609 of the reference: same constructor keywords, same parameter tree (all 121
 tensors of the released checkpoint load with ``strict=True``), same ``decode(x, queries)`` signature and
 output ``(B, T, P, output_dim)``.  Only inference-time ``decode`` is on the hot path (inference_dpm_latent.py:
-252-256 -> utils/inference_utils.py: pred_delta = vae.decode(latents, static_gs)); ``encode`` needs FPS/KNN
-(torch_cluster / pytorch3d) and stays out of scope -- it raises NotImplementedError.
+252-256 -> utils/inference_utils.py: pred_delta = vae.decode(latents, static_gs)); ``encode`` (encode_latent.py,
+training) runs on the same kernels plus csrc/fps.hip for the farthest point sampling; its KNN interpolation is a
+brute-force torch.topk (pytorch3d.ops.knn_points upstream).
 
 What differs from the reference's op order (results agree to the bf16 tolerance stated in tests/test_vae_gpu.py):
   * the query embedding (gs_embedding + position_encoding + PreNorm LN) and the decoder to_q projection depend on
@@ -67,6 +68,30 @@ class PointEmbed(nn.Module):
         self.register_buffer("omega", torch.from_numpy(1.0 / 10000 ** omega))
 
 
+class DiagonalGaussianDistribution:
+    """model/autoencoder.py:304-342 (the members encode()'s callers use)."""
+
+    def __init__(self, mean, logvar, deterministic=False):
+        self.mean = mean
+        self.logvar = torch.clamp(logvar, -30.0, 20.0)
+        self.deterministic = deterministic
+        self.std = torch.exp(0.5 * self.logvar)
+        self.var = torch.exp(self.logvar)
+        if deterministic:
+            self.var = self.std = torch.zeros_like(self.mean)
+
+    def sample(self):
+        return self.mean + self.std * torch.randn(self.mean.shape, device=self.mean.device)
+
+    def kl(self):
+        if self.deterministic:
+            return torch.zeros(1)
+        return 0.5 * torch.mean(torch.pow(self.mean, 2) + self.var - 1.0 - self.logvar, dim=[1, 2])
+
+    def mode(self):
+        return self.mean
+
+
 class GSKLTemporalVariationalAutoEncoder(nn.Module):
     def __init__(self, *, depth=24, dim=512, queries_dim=512, input_dim=3, gs_dim=14, output_dim=10, num_inputs=8192,
                  num_latents=1024, latent_dim=128, heads=8, dim_head=-1, weight_tie_layers=False, decoder_ff=False,
@@ -109,12 +134,87 @@ class GSKLTemporalVariationalAutoEncoder(nn.Module):
         self._wcache = None
         self.max_chunk_rows = 1 << 20                # rows (B*T*Pc) of the bf16 attention-output chunk: 1.5 GiB at dim 768
 
-    # ---- not on the inference path -----------------------------------------------------------------------
-    def encode(self, *a, **k):
-        raise NotImplementedError("motion-VAE encode (FPS + KNN interpolation) is outside the MI355X hot path; "
-                                  "see SURVEY.md section 8f")
+    # ---- encode (encode_latent.py / training; not on the inference path) ---------------------------------------------
+    @staticmethod
+    @torch.no_grad()
+    def compute_delta_interp(static_gs, micro_static_pc, micro_moving_pc, knn_k=8, beta=7.0, adaptive_radius=True):
+        """KNN-interpolated motion of the sampled Gaussians (model/autoencoder.py:449-500; pytorch3d.ops.knn_points is a
+        brute-force K-nearest search here: squared distances ascending).  static_gs (B,L,3), micro_static_pc (B,N,3),
+        micro_moving_pc (B,T,N,3) -> (B,T,L,3)."""
+        d2 = ((static_gs[:, :, None, :] - micro_static_pc[:, None, :, :]) ** 2).sum(-1)             # (B, L, N)
+        knn_dists, knn_idx = torch.topk(d2, knn_k, dim=-1, largest=False, sorted=True)
+        radii = knn_dists.mean(dim=-1).sqrt() + 1e-6
+        if adaptive_radius:
+            w = torch.exp(-beta * knn_dists / radii[..., None] ** 2) * (knn_dists <= radii[..., None] ** 2).float()
+        else:
+            w = torch.exp(-beta * knn_dists)
+        w = w / (w.sum(dim=-1, keepdim=True) + 1e-8)
+        B, L, K = knn_idx.shape
+        T = micro_moving_pc.shape[1]
+        idx = knn_idx.reshape(B, 1, L * K, 1).expand(B, T, L * K, 3)
+        nb = torch.gather(micro_moving_pc, 2, idx).reshape(B, T, L, K, 3)                            # neighbour positions per frame
+        nb0 = torch.gather(micro_static_pc, 1, knn_idx.reshape(B, L * K, 1).expand(B, L * K, 3)).reshape(B, 1, L, K, 3)
+        return ((nb - nb0) * w[:, None, :, :, None]).sum(dim=3)
 
-    forward = encode
+    @torch.no_grad()
+    def encode(self, static_pc, delta_pc, static_gs_list, random_start: bool = True, sample_posterior: bool = True):
+        """static_pc (B,N,3), delta_pc (B,T,N,3), static_gs_list [ (N_gs,14) ] -> (kl, x, posterior, sampled_static_gs)
+        (model/autoencoder.py:502-550).  random_start=False makes the farthest point sampling start at each sample's
+        first Gaussian (upstream's default is a random start)."""
+        from ..utils.points import sample_gs
+        _lib.require_cuda(static_pc, delta_pc)
+        W = self._weights()
+        B, N, _ = static_pc.shape
+        T = delta_pc.shape[1]
+        C, H, d, L, dev = self.dim, self.heads, self.dim_head, self.num_latents, static_pc.device
+        bf16 = torch.bfloat16
+        sampled_static_gs = sample_gs(static_gs_list, L, random_start=random_start)                  # (B, L, 14)
+        input_static_gs = sampled_static_gs[..., :3].float().contiguous()
+        static_pc, delta_pc = static_pc.float(), delta_pc.float()
+        moving_pc = delta_pc + static_pc[:, None]
+        est = self.compute_delta_interp(input_static_gs, static_pc, moving_pc, knn_k=self.knn_k, beta=self.beta)   # (B,T,L,3)
+        # embeddings: rows [xyz | delta]; the Linear sees only the delta (zero weights on xyz), PointEmbed only the xyz
+        qrows = torch.cat([input_static_gs[:, None].expand(B, T, L, 3), est], dim=-1).reshape(B * T * L, 6).contiguous()
+        crows = torch.cat([static_pc[:, None].expand(B, T, N, 3), delta_pc], dim=-1).reshape(B * T * N, 6).contiguous()
+        xn, x = vae_ops.vae_embed_bf16_f32(qrows, W["in_w6"], W["in_b"], W["omega"])
+        cn, _ = vae_ops.vae_embed_bf16_f32(crows, W["in_w6"], W["in_b"], W["omega"], want_embed=False)
+        M, Mc = B * T * L, B * T * N
+        e = W["enc"]
+        q = torch.empty((M, C), dtype=bf16, device=dev)
+        dit_ops.gemm_bf16(xn, e["q"], None, q, dit_ops.EPI_STORE_BF16)
+        kv = torch.empty((Mc, 2 * C), dtype=bf16, device=dev)
+        dit_ops.gemm_bf16(cn, e["kv"], None, kv, dit_ops.EPI_STORE_BF16)
+        del cn
+        ao = torch.empty((M, C), dtype=bf16, device=dev)
+        skv = (N * 2 * C, 0, 2 * C)
+        dit_ops.attention_bf16(q, kv, kv[:, C:], ao, B * T, 1, L, N, H, (L * C, 0, C), skv, skv, (L * C, 0, C), head_dim=d)
+        dit_ops.gemm_bf16(ao, *e["out"], x, dit_ops.EPI_RESID_F32)
+        hb = torch.empty((M, C), dtype=bf16, device=dev)
+        dit_ops.layernorm_modulate_bf16(x, hb, 1e-6)
+        hid = torch.empty((M, 8 * C), dtype=bf16, device=dev)
+        dit_ops.gemm_bf16(hb, *e["fc1"], hid, dit_ops.EPI_STORE_BF16)
+        act = vae_ops.geglu_bf16(hid)
+        dit_ops.gemm_bf16(act, *e["fc2"], x, dit_ops.EPI_RESID_F32)
+        xb = dit_ops.cast_pad_bf16(x, C)
+        Dl = self.mean_fc.out_features
+        mean = torch.empty((M, Dl), dtype=torch.float32, device=dev)
+        logvar = torch.empty((M, Dl), dtype=torch.float32, device=dev)
+        dit_ops.gemm_bf16(xb, *e["mean"], mean, dit_ops.EPI_STORE_F32)
+        dit_ops.gemm_bf16(xb, *e["logvar"], logvar, dit_ops.EPI_STORE_F32)
+        posterior = DiagonalGaussianDistribution(mean.view(B * T, L, Dl), logvar.view(B * T, L, Dl))
+        z = posterior.sample() if sample_posterior else posterior.mode()
+        return posterior.kl(), z, posterior, sampled_static_gs
+
+    def pad_static_gs(self, static_gs):
+        """model/autoencoder.py:611-619."""
+        from ..utils.points import pad_static_gs
+        return pad_static_gs(static_gs)
+
+    def forward(self, static_gs, static_pc, delta_pc, **kw):
+        """encode -> decode over the padded static Gaussians (model/autoencoder.py:621-627; same argument order)."""
+        kl, x, posterior, _ = self.encode(static_pc, delta_pc, static_gs, **kw)
+        padded, _ = self.pad_static_gs(static_gs)
+        return {"logits": self.decode(x, padded).squeeze(-1), "kl": kl, "posterior": posterior}
 
     # ---- weights -----------------------------------------------------------------------------------------
     def _param_version(self):
@@ -144,6 +244,14 @@ class GSKLTemporalVariationalAutoEncoder(nn.Module):
         wo, wy = d.to_out.weight.detach().double(), self.to_outputs.weight.detach().double()
         W["fold"] = (bf((wy @ wo).float()),
                      (wy @ d.to_out.bias.detach().double() + self.to_outputs.bias.detach().double()).float().contiguous())
+        # encoder half
+        c = self.cross_attend_blocks
+        W["enc"] = dict(q=bf(c[0].fn.to_q.weight), kv=bf(c[0].fn.to_kv.weight), out=(bf(c[0].fn.to_out.weight), fb(c[0].fn.to_out.bias)),
+                        fc1=(bf(c[1].fn.net[0].weight), fb(c[1].fn.net[0].bias)), fc2=(bf(c[1].fn.net[2].weight), fb(c[1].fn.net[2].bias)),
+                        mean=(bf(self.mean_fc.weight), fb(self.mean_fc.bias)), logvar=(bf(self.logvar_fc.weight), fb(self.logvar_fc.bias)))
+        wi = self.input_embedding[0].weight.detach().float()                      # (dim, input_dim = 3): acts on the delta columns
+        W["in_w6"] = torch.cat([torch.zeros_like(wi), wi], dim=1).contiguous()     # rows are [xyz | delta]
+        W["in_b"] = self.input_embedding[0].bias.detach().float().contiguous()
         W["gs_w"] = self.gs_embedding[0].weight.detach().float().contiguous()
         W["gs_b"] = self.gs_embedding[0].bias.detach().float().contiguous()
         W["omega"] = self.position_encoding[0].omega.detach().float().contiguous()

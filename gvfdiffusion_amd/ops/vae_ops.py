@@ -10,6 +10,7 @@ _vp, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_floa
 _lib.register({
     "gvf_geglu_bf16": (_i, [_vp, _i, _vp, _i, _i64, _i, _vp]),
     "gvf_vae_query_embed_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i64, _i, _f, _f, _vp]),
+    "gvf_vae_embed_bf16_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _f, _vp]),
 })
 
 
@@ -43,3 +44,18 @@ def vae_query_embed_bf16(queries: torch.Tensor, weight: torch.Tensor, bias: torc
     _lib.check(_lib.lib().gvf_vae_query_embed_bf16(_p(queries), qdim, _p(weight), _p(bias), _p(omega), _p(out), P, C, float(eps_embed), float(eps_prenorm),
                                                    _lib.current_stream(queries.device)), "gvf_vae_query_embed_bf16")
     return out
+
+
+def vae_embed_bf16_f32(rows: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, omega: torch.Tensor, want_embed: bool = True,
+                       eps_embed: float = 1e-5, eps_prenorm: float = 1e-6):
+    """rows fp32 (P, qdim) -> (bf16 (P, C) PreNorm-normalised operand, fp32 (P, C) embedding or None): the encoder's
+    input_embedding + position_encoding (model/autoencoder.py:520-524)."""
+    _lib.require_cuda(rows, weight, bias, omega)
+    assert rows.dtype == weight.dtype == bias.dtype == omega.dtype == torch.float32 and rows.is_contiguous() and weight.is_contiguous()
+    P, qdim = rows.shape
+    C = weight.shape[0]
+    out = torch.empty((P, C), dtype=torch.bfloat16, device=rows.device)
+    emb = torch.empty((P, C), dtype=torch.float32, device=rows.device) if want_embed else None
+    _lib.check(_lib.lib().gvf_vae_embed_bf16_f32(_p(rows), qdim, _p(weight), _p(bias), _p(omega), _p(out), _p(emb), P, C, float(eps_embed),
+                                                 float(eps_prenorm), _lib.current_stream(rows.device)), "gvf_vae_embed_bf16_f32")
+    return out, emb

@@ -31,6 +31,14 @@ int gvf_geglu_bf16(const void* in_bf16, int ld_in, void* out_bf16, int ld_out, i
 int gvf_vae_query_embed_bf16(const float* queries, int qdim, const float* W, const float* bias, const float* omega,
                              void* out_bf16, int64_t P, int C, float eps_embed, float eps_prenorm, void* stream);
 
+/* The same embedding for the ENCODER (model/autoencoder.py:520-524: input_embedding(delta) + position_encoding(xyz)):
+ * additionally writes the embedding itself, out_embed_f32 [P][C] = LN_emb(q W^T + b) + LN_emb(point_embed(q[:, :3]))
+ * (may be null), which the encoder's residual stream starts from; out_bf16 is its PreNorm-normalised GEMM operand.
+ * The encoder passes rows [xyz | delta] with zero weights on the xyz columns. */
+int gvf_vae_embed_bf16_f32(const float* queries, int qdim, const float* W, const float* bias, const float* omega,
+                           void* out_bf16, float* out_embed_f32, int64_t P, int C, float eps_embed, float eps_prenorm,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

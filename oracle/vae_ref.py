@@ -66,3 +66,42 @@ def vae_decode(sd, cfg, x, queries, num_timesteps, precision="fp32"):
     q_embed = q_embed[:, None].expand(B, T, P, -1).reshape(B * T, P, -1)
     lat = attention(_ln(q_embed), _ln(h), sd, "decoder_cross_attn.fn", heads, precision)
     return _lin(lat, sd, "to_outputs", precision).reshape(B, T, P, -1)
+
+
+# ---- encode (model/autoencoder.py:449-550) ------------------------------------------------------------------------
+def delta_interp(static_gs, micro_static_pc, micro_moving_pc, knn_k=8, beta=7.0):
+    """compute_delta_interp :449-500 with pytorch3d.ops.knn_points restated as a brute-force K-nearest search
+    (squared distances ascending).  (B,L,3), (B,N,3), (B,T,N,3) -> (B,T,L,3)."""
+    d2 = ((static_gs[:, :, None, :] - micro_static_pc[:, None, :, :]) ** 2).sum(-1)
+    knn_dists, knn_idx = torch.topk(d2, knn_k, dim=-1, largest=False, sorted=True)
+    radii = knn_dists.mean(dim=-1).sqrt() + 1e-6
+    w = torch.exp(-beta * knn_dists / radii[..., None] ** 2) * (knn_dists <= radii[..., None] ** 2).float()
+    w = w / (w.sum(dim=-1, keepdim=True) + 1e-8)
+    B, L, K = knn_idx.shape
+    T = micro_moving_pc.shape[1]
+    out = torch.zeros((B, T, L, 3), dtype=static_gs.dtype)
+    for b in range(B):
+        nb0 = micro_static_pc[b][knn_idx[b]]                      # (L, K, 3)
+        for t in range(T):
+            out[b, t] = ((micro_moving_pc[b, t][knn_idx[b]] - nb0) * w[b][..., None]).sum(dim=1)
+    return out
+
+
+def vae_encode(sd, cfg, static_pc, delta_pc, input_static_gs, knn_k=8, beta=7.0, precision="fp32"):
+    """-> (mean, logvar, estimated deltas); input_static_gs (B, L, 3) = xyz of the FPS-sampled Gaussians.  The point
+    embeddings are fp32 in every precision (as in the HIP kernel); GEMM / attention operands are rounded for "bf16"."""
+    heads = cfg["heads"]
+    B, T = delta_pc.shape[:2]
+    L, N = input_static_gs.shape[1], static_pc.shape[1]
+    moving = delta_pc + static_pc[:, None]
+    est = delta_interp(input_static_gs, static_pc, moving, knn_k, beta)
+    om = sd["position_encoding.0.omega"]
+
+    def embed(delta, xyz):
+        return _ln(_lin(delta, sd, "input_embedding.0", "fp32"), 1e-5) + _ln(point_embed(xyz, om), 1e-5)[:, None]
+
+    xq = embed(est, input_static_gs).reshape(B * T, L, -1)
+    ctx = embed(delta_pc, static_pc).reshape(B * T, N, -1)
+    x = attention(_ln(xq), _ln(ctx), sd, "cross_attend_blocks.0.fn", heads, precision) + xq
+    x = feed_forward(_ln(x), sd, "cross_attend_blocks.1.fn", precision) + x
+    return _lin(x, sd, "mean_fc", precision), _lin(x, sd, "logvar_fc", precision), est

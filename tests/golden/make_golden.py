@@ -345,7 +345,58 @@ def gen_vae():
     print("vae_manifest.json", len(man), "tensors", sum(int(np.prod(v)) for v in man.values()) / 1e6, "M params")
 
 
-SECTIONS = {"vae": gen_vae, "raster": gen_raster, "vox2seq": gen_vox2seq, "dit": gen_dit, "sampler": gen_sampler, "sparse": gen_sparse}
+def gen_vae_encode():
+    """Motion-VAE encode (model/autoencoder.py:502-550) with its two third-party calls replaced by deterministic
+    stand-ins: torch_cluster.fps -> oracle/points_ref.py (start at each sample's first Gaussian), pytorch3d.ops.knn_points
+    -> brute-force torch.topk.  Everything else is the reference's own code."""
+    import json
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle import points_ref
+
+    def fps_stub(pos, batch, ratio=None, **kw):
+        counts = torch.bincount(batch).tolist()
+        ptr = [0]
+        for c in counts:
+            ptr.append(ptr[-1] + c)
+        k = [int(round(float(r) * c)) for r, c in zip(ratio.tolist(), counts)]
+        return torch.from_numpy(points_ref.fps_indices(pos.numpy(), ptr, k, [0] * len(k)))
+
+    def knn_stub(p1, p2, K=8):
+        d2 = ((p1[:, :, None, :] - p2[:, None, :, :]) ** 2).sum(-1)
+        dist, idx = torch.topk(d2, K, dim=-1, largest=False, sorted=True)
+        return dist, idx, None
+
+    _stub("torch_cluster", fps=fps_stub)
+    p3 = _stub("pytorch3d"); p3.ops = _stub("pytorch3d.ops", knn_points=knn_stub)
+    tm = _stub("timm"); tmm = _stub("timm.models"); tml = _stub("timm.models.layers", DropPath=torch.nn.Identity,
+                                                               trunc_normal_=torch.nn.init.trunc_normal_)
+    tm.models = tmm; tmm.layers = tml
+    import model.autoencoder as ae
+    ae.fps = fps_stub
+    ae.pytorch3d = p3
+    torch.manual_seed(0)
+    vae = ae.GSKLTemporalVariationalAutoEncoder(**VAE_SMALL).eval()
+    _randomise(vae, 5)
+    g = torch.Generator().manual_seed(6)
+    B, T, N = 2, VAE_SMALL["num_timesteps"], VAE_SMALL["num_inputs"]
+    static_pc = torch.rand((B, N, 3), generator=g) - 0.5
+    delta_pc = torch.randn((B, T, N, 3), generator=g) * 0.05
+    gs_list = [torch.rand((150, 14), generator=g) - 0.5, torch.rand((97, 14), generator=g) - 0.5]
+    with torch.no_grad():
+        kl, x, posterior, sampled = vae.encode(static_pc, delta_pc, gs_list)
+        est = vae.interpolation_func(sampled[..., :3], static_pc, delta_pc + static_pc[:, None], knn_k=vae.knn_k, beta=vae.beta)
+    out = {"cfg_json": np.frombuffer(json.dumps(VAE_SMALL).encode(), dtype=np.uint8), "static_pc": static_pc.numpy(),
+           "delta_pc": delta_pc.numpy(), "gs0": gs_list[0].numpy(), "gs1": gs_list[1].numpy(), "mean": posterior.mean.numpy(),
+           "logvar": posterior.logvar.numpy(), "kl": kl.numpy(), "sampled": sampled.numpy(), "est": est.numpy(),
+           "knn_k": np.asarray(vae.knn_k), "beta": np.asarray(vae.beta)}
+    for k, v in vae.state_dict().items():
+        if k.startswith(("cross_attend_blocks", "input_embedding", "mean_fc", "logvar_fc", "position_encoding")):
+            out["sd." + k] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "vae_encode_golden.npz"), **out)
+    print("vae_encode_golden.npz", posterior.mean.shape, float(posterior.mean.abs().mean()), "kl", kl.tolist())
+
+
+SECTIONS = {"vae_encode": gen_vae_encode, "vae": gen_vae, "raster": gen_raster, "vox2seq": gen_vox2seq, "dit": gen_dit, "sampler": gen_sampler, "sparse": gen_sparse}
 
 if __name__ == "__main__":
     install_stubs()

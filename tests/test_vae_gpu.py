@@ -118,5 +118,63 @@ def test_strict_load_of_reference_layout_and_loud_failures(cuda):
     m.load_state_dict(sd, strict=True)
     with pytest.raises(GvfError):
         m.decode(torch.zeros(24, 512, 16), torch.zeros(1, 8, 14))          # CPU tensors: no fallback
-    with pytest.raises(NotImplementedError):
-        m.encode(None)
+    with pytest.raises(GvfError):
+        m.encode(torch.zeros(1, 8192, 3), torch.zeros(1, 24, 8192, 3), [torch.zeros(2000, 14)])   # CPU tensors: no fallback
+
+
+# ---- encode (model/autoencoder.py:502-550) -------------------------------------------------------------------------
+def _encode_inputs(cfg, B, n_gs, seed=2):
+    g = torch.Generator().manual_seed(seed)
+    T, N = cfg["num_timesteps"], cfg["num_inputs"]
+    static_pc = torch.rand((B, N, 3), generator=g) - 0.5
+    delta_pc = torch.randn((B, T, N, 3), generator=g) * 0.05
+    gs = [torch.rand((n, 14), generator=g) - 0.5 for n in n_gs]
+    return static_pc, delta_pc, gs
+
+
+def _check_encode(cfg, B, n_gs):
+    import numpy as np
+    from oracle import points_ref, vae_ref
+    m = _model(cfg, seed=3)
+    static_pc, delta_pc, gs = _encode_inputs(cfg, B, n_gs)
+    L = cfg["num_latents"]
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    ptr = np.concatenate([[0], np.cumsum(n_gs)]).tolist()
+    idx = points_ref.fps_indices(np.concatenate([t[:, :3].numpy() for t in gs]), ptr, [L] * B, [0] * B)
+    sampled_ref = torch.cat(gs)[torch.from_numpy(idx)].reshape(B, L, 14)
+    with torch.no_grad():
+        ref32 = vae_ref.vae_encode(sd, cfg, static_pc, delta_pc, sampled_ref[..., :3].contiguous(), m.knn_k, m.beta, "fp32")
+        ref16 = vae_ref.vae_encode(sd, cfg, static_pc, delta_pc, sampled_ref[..., :3].contiguous(), m.knn_k, m.beta, "bf16")
+    m = m.cuda()
+    kl, z, post, sampled = m.encode(static_pc.cuda(), delta_pc.cuda(), [t.cuda() for t in gs], random_start=False, sample_posterior=False)
+    assert torch.equal(sampled.cpu(), sampled_ref)                         # farthest point sampling: index-exact
+    est = m.compute_delta_interp(sampled[..., :3].contiguous(), static_pc.cuda(), (delta_pc + static_pc[:, None]).cuda(), m.knn_k, m.beta)
+    assert (est.cpu() - ref32[2]).abs().max() < 1e-6
+    T = cfg["num_timesteps"]
+    assert post.mean.shape == (B * T, L, cfg["latent_dim"]) and torch.equal(z, post.mean) and kl.shape == (B * T,)
+    for got, r16, r32, name in ((post.mean.cpu(), ref16[0], ref32[0], "mean"), (post.logvar.cpu(), ref16[1], ref32[1], "logvar")):
+        e16, e32 = _rel(got, r16), _rel(got, r32)
+        print(f"vae encode {name} rel-L2: vs bf16 oracle {e16:.2e}, vs fp32 oracle {e32:.2e}")
+        assert e16 < TOL_VS_BF16_ORACLE and e32 < TOL_VS_FP32_ORACLE, (name, e16, e32)
+    kl_ref = 0.5 * (ref32[0] ** 2 + ref32[1].exp() - 1.0 - ref32[1]).mean(dim=(1, 2))
+    assert _rel(kl.cpu(), kl_ref) < TOL_VS_FP32_ORACLE
+    return m, (static_pc, delta_pc, gs)
+
+
+def test_encode_head_dim_64(cuda):
+    _check_encode(BASE, B=2, n_gs=(150, 97))
+
+
+def test_encode_head_dim_32_ragged_context(cuda):
+    _check_encode(dict(BASE, heads=6, num_inputs=200, num_latents=64), B=1, n_gs=(333,))
+
+
+def test_encode_samples_the_posterior_and_round_trips_through_decode(cuda):
+    m, (static_pc, delta_pc, gs) = _check_encode(BASE, B=2, n_gs=(150, 97))
+    torch.manual_seed(0)
+    kl, z, post, sampled = m.encode(static_pc.cuda(), delta_pc.cuda(), [t.cuda() for t in gs])
+    assert sampled.shape == (2, BASE["num_latents"], 14) and torch.isfinite(z).all()
+    zs = (z - post.mean) / post.std                                        # standard normal draws
+    assert abs(float(zs.mean())) < 0.1 and abs(float(zs.std()) - 1.0) < 0.1
+    out = m([t.cuda() for t in gs], static_pc.cuda(), delta_pc.cuda())
+    assert out["logits"].shape == (2, BASE["num_timesteps"], 150, BASE["output_dim"]) and torch.isfinite(out["logits"]).all()
