@@ -38,7 +38,7 @@ class SparseMultiHeadAttention(nn.Module):
                  attn_mode: Literal["full", "serialized", "windowed"] = "full", window_size: Optional[int] = None,
                  shift_sequence: Optional[int] = None, shift_window: Optional[Tuple[int, int, int]] = None,
                  serialize_mode: Optional[SerializeMode] = None, qkv_bias: bool = True, use_rope: bool = False,
-                 qk_rms_norm: bool = False):
+                 qk_rms_norm: bool = False, use_old_attn_impl: bool = False):
         super().__init__()
         assert channels % num_heads == 0
         assert type in ["self", "cross"], f"Invalid attention type: {type}"
@@ -58,6 +58,7 @@ class SparseMultiHeadAttention(nn.Module):
         self.serialize_mode = serialize_mode
         self.use_rope = use_rope
         self.qk_rms_norm = qk_rms_norm
+        self.use_old_attn_impl = use_old_attn_impl
         if self._type == "self":
             self.to_qkv = nn.Linear(channels, channels * 3, bias=qkv_bias)
         else:
@@ -82,11 +83,20 @@ class SparseMultiHeadAttention(nn.Module):
             return x.replace(self._linear(lin, x.feats).to(x.dtype))
         return self._linear(lin, x.reshape(-1, x.shape[-1])).reshape(*x.shape[:-1], -1).to(x.dtype)
 
+    def _fused_pre(self, x, num_fused: int):
+        """channels -> [num_fused, H, C]; the old implementation stored them [H, num_fused, C] (modules.py:150-162)."""
+        H = self.num_heads
+        f = x.feats.unsqueeze(0) if isinstance(x, SparseTensor) else x
+        if self.use_old_attn_impl:
+            f = torch.stack(f.reshape(*f.shape[:2], H, -1).chunk(num_fused, dim=-1), dim=2)
+        else:
+            f = f.reshape(*f.shape[:2], num_fused, H, -1)
+        return x.replace(f.squeeze(0)) if isinstance(x, SparseTensor) else f
+
     def forward(self, x: Union[SparseTensor, torch.Tensor], context: Optional[Union[SparseTensor, torch.Tensor]] = None):
         H = self.num_heads
         if self._type == "self":
-            qkv = self._project(self.to_qkv, x)
-            qkv = qkv.reshape(3, H, -1) if isinstance(qkv, SparseTensor) else qkv.reshape(*qkv.shape[:2], 3, H, -1)
+            qkv = self._fused_pre(self._project(self.to_qkv, x), 3)
             if self.qk_rms_norm:
                 q, k, v = qkv.unbind(dim=1 if isinstance(qkv, SparseTensor) else 2)
                 q, k = self.q_rms_norm(q), self.k_rms_norm(k)
@@ -105,8 +115,7 @@ class SparseMultiHeadAttention(nn.Module):
         else:
             q = self._project(self.to_q, x)
             q = q.reshape(H, -1) if isinstance(q, SparseTensor) else q.reshape(*q.shape[:2], H, -1)
-            kv = self._project(self.to_kv, context)
-            kv = kv.reshape(2, H, -1) if isinstance(kv, SparseTensor) else kv.reshape(*kv.shape[:2], 2, H, -1)
+            kv = self._fused_pre(self._project(self.to_kv, context), 2)
             if self.qk_rms_norm:
                 q = self.q_rms_norm(q)
                 k, v = kv.unbind(dim=1 if isinstance(kv, SparseTensor) else 2)

@@ -396,7 +396,77 @@ def gen_vae_encode():
     print("vae_encode_golden.npz", posterior.mean.shape, float(posterior.mean.abs().mean()), "kl", kl.tolist())
 
 
-SECTIONS = {"vae_encode": gen_vae_encode, "vae": gen_vae, "raster": gen_raster, "vox2seq": gen_vox2seq, "dit": gen_dit, "sampler": gen_sampler, "sparse": gen_sparse}
+SVAE_SMALL = dict(resolution=16, in_channels=64, model_channels=128, out_channels=112, latent_channels=8, num_blocks=2,
+                  num_heads=2, mlp_ratio=4, attn_mode="swin", window_size=8, use_fp16=False, use_old_attn_impl=False,
+                  norm_output=True)
+
+
+def gen_sparse_vae():
+    """Static-VAE backbone (model/sparse_voxel_diffusion/sparse_transformer_vae.py) encode / decode, fp32, on the reference's
+    own classes.  Third-party stand-ins: spconv's SparseConvTensor as a plain record of the fields sparse/basic.py touches
+    (no convolution is executed on this path), flash_attn's two packed-qkv entry points as softmax attention in torch,
+    vox2seq as the reference's own pure-PyTorch fallback."""
+    import json
+
+    class SparseConvTensor:
+        def __init__(self, features, indices, spatial_shape, batch_size, grid=None, voxel_num=None, indice_dict=None,
+                     benchmark=False):
+            self._features, self.indices, self.spatial_shape, self.batch_size = features, indices, spatial_shape, batch_size
+            self.grid, self.voxel_num, self.indice_dict, self.benchmark = grid, voxel_num, indice_dict, benchmark
+            self.benchmark_record = self.thrust_allocator = self._timer = self.force_algo = self.int8_scale = None
+
+        @property
+        def features(self):
+            return self._features
+
+    def attn(q, k, v):                                   # (n, H, d) -> (n, H, d)
+        s = torch.einsum("nhd,mhd->hnm", q, k) * q.shape[-1] ** -0.5
+        return torch.einsum("hnm,mhd->nhd", torch.softmax(s, dim=-1), v)
+
+    def varlen_qkvpacked(qkv, cu_seqlens, max_seqlen, **kw):
+        out = torch.empty_like(qkv[:, 0])
+        for a, b in zip(cu_seqlens[:-1].tolist(), cu_seqlens[1:].tolist()):
+            out[a:b] = attn(*qkv[a:b].unbind(dim=1))
+        return out
+
+    def qkvpacked(qkv, **kw):
+        return torch.stack([attn(*x.unbind(dim=1)) for x in qkv])
+
+    sp_mod = _stub("spconv"); sp_mod.pytorch = _stub("spconv.pytorch", SparseConvTensor=SparseConvTensor)
+    _stub("flash_attn", flash_attn_varlen_qkvpacked_func=varlen_qkvpacked, flash_attn_qkvpacked_func=qkvpacked)
+    base = f"{REF}/model/sparse_voxel_diffusion/vox2seq/vox2seq/pytorch"
+    sys.modules["vox2seq"] = load_by_path("vox2seq", f"{base}/__init__.py", [base])
+    pkg = _stub("model.sparse_voxel_diffusion"); pkg.__path__ = [f"{REF}/model/sparse_voxel_diffusion"]
+    import importlib
+    import sparse as sp
+    stv = importlib.import_module("model.sparse_voxel_diffusion.sparse_transformer_vae")
+    out = {"cfg_json": np.frombuffer(json.dumps(SVAE_SMALL).encode(), dtype=np.uint8)}
+    g = torch.Generator().manual_seed(21)
+    coords = []
+    for b, n in enumerate((700, 333)):                   # 16^3 grid: windows of 8 -> 8 (+ shifted: 27) windows per sample, ragged
+        c = torch.unique(torch.randint(0, 16, (n * 2, 3), generator=g), dim=0)
+        c = c[torch.randperm(c.shape[0], generator=g)[:n]]
+        coords.append(torch.cat([torch.full((c.shape[0], 1), b), c], dim=1))
+    coords = torch.cat(coords).int()
+    feats = torch.randn((coords.shape[0], SVAE_SMALL["in_channels"]), generator=g)
+    for tag, old in (("new", False), ("old", True)):
+        torch.manual_seed(0)
+        vae = stv.SparseTransformerVAE(**dict(SVAE_SMALL, use_old_attn_impl=old)).eval()
+        _randomise(vae, 9)
+        with torch.no_grad():
+            x = sp.SparseTensor(feats, coords)
+            z, mean, logvar = vae.encode(x, sample_posterior=False, return_raw=True)
+            y = vae.decode(z)
+        out[f"{tag}_mean"], out[f"{tag}_logvar"], out[f"{tag}_out"] = mean.numpy(), logvar.numpy(), y.feats.numpy()
+        if tag == "new":
+            for k, v in vae.state_dict().items():
+                out["sd." + k] = v.numpy()
+        print("sparse_vae", tag, mean.shape, float(mean.abs().mean()), y.feats.shape, float(y.feats.abs().mean()))
+    out["coords"], out["feats"] = coords.numpy(), feats.numpy()
+    np.savez_compressed(os.path.join(OUT, "sparse_vae_golden.npz"), **out)
+
+
+SECTIONS = {"sparse_vae": gen_sparse_vae, "vae_encode": gen_vae_encode, "vae": gen_vae, "raster": gen_raster, "vox2seq": gen_vox2seq, "dit": gen_dit, "sampler": gen_sampler, "sparse": gen_sparse}
 
 if __name__ == "__main__":
     install_stubs()
