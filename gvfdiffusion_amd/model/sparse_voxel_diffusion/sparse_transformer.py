@@ -99,7 +99,7 @@ def token_partition(st: sp.SparseTensor, attn_mode: str, window_size, shift_sequ
 class SparseTransformerBlock(nn.Module):
     def __init__(self, hidden_size, num_heads, mlp_ratio=4.0, attn_mode="full", window_size=1024, shift_sequence=0,
                  shift_window=(0, 0, 0), serialize_mode=SerializeMode.Z_ORDER, use_checkpoint=False, modulated=True,
-                 use_rope=False, use_old_attn_impl=False):
+                 use_rope=False, use_old_attn_impl=False, qk_rms_norm=False):
         super().__init__()
         if modulated:
             raise NotImplementedError("adaLN-modulated sparse blocks belong to the spconv flow models (out of scope, DESIGN.md section 7)")
@@ -107,7 +107,8 @@ class SparseTransformerBlock(nn.Module):
         self.norm1 = nn.LayerNorm(hidden_size, elementwise_affine=False, eps=1e-6)
         self.attn = SparseMultiHeadAttention(hidden_size, num_heads=num_heads, attn_mode=attn_mode, window_size=window_size,
                                              shift_sequence=shift_sequence, shift_window=shift_window, qkv_bias=True,
-                                             serialize_mode=serialize_mode, use_rope=use_rope, use_old_attn_impl=use_old_attn_impl)
+                                             serialize_mode=serialize_mode, use_rope=use_rope, use_old_attn_impl=use_old_attn_impl,
+                                             qk_rms_norm=qk_rms_norm)
         self.norm2 = nn.LayerNorm(hidden_size, elementwise_affine=False, eps=1e-6)
         self.mlp = SparseFeedForward(hidden_size, mlp_ratio=mlp_ratio)
         self.modulated = modulated
@@ -124,6 +125,8 @@ class SparseTransformerBlock(nn.Module):
             wq = wq.reshape(H, 3, C // H, C).permute(1, 0, 2, 3).reshape(3 * C, C)
             bq = bq.reshape(H, 3, C // H).permute(1, 0, 2).reshape(3 * C)
         W = dict(qkv=(_bf(wq), _fb(bq)), out=(_bf(a.to_out.weight), _fb(a.to_out.bias)),
+                 gq=a.q_rms_norm.gamma.detach().float().contiguous() if a.qk_rms_norm else None,
+                 gk=a.k_rms_norm.gamma.detach().float().contiguous() if a.qk_rms_norm else None,
                  fc1=(_bf(self.mlp.mlp[0].weight), _fb(self.mlp.mlp[0].bias)), fc2=(_bf(self.mlp.mlp[2].weight), _fb(self.mlp.mlp[2].bias)))
         self._wcache = (ver, W)
         return W
@@ -145,7 +148,8 @@ class SparseTransformerBlock(nn.Module):
         g = qkv if fwd is None else qkv.index_select(0, fwd)                      # (M, 3C) in sequence order
         ao = torch.empty((g.shape[0], C), dtype=bf16, device=dev)
         s3 = (0, 0, 3 * C)
-        dit_ops.attention_varlen_bf16(g, g[:, C:], g[:, 2 * C:], ao, cu, cu, longest, longest, H, s3, s3, s3, (0, 0, C), head_dim=d)
+        dit_ops.attention_varlen_bf16(g, g[:, C:], g[:, 2 * C:], ao, cu, cu, longest, longest, H, s3, s3, s3, (0, 0, C),
+                                      W["gq"], W["gk"], head_dim=d)
         if bwd is not None:
             ao = ao.index_select(0, bwd)
         dit_ops.gemm_bf16(ao, *W["out"], x, dit_ops.EPI_RESID_F32)

@@ -1,0 +1,87 @@
+"""SLatGaussianDecoder (trellis/models/structured_latent_vae/decoder_gs.py:11-122): structured latent (8 channels per
+active voxel) -> `num_gaussians` Gaussians per voxel.  forward = transformer torso -> LayerNorm -> out_layer ->
+to_representation; the result objects are this package's GaussianModel (the accessors the renderer reads are the same in
+TRELLIS' `Gaussian` twin)."""
+from typing import *
+
+import torch
+import torch.nn as nn
+
+from .... import sparse as sp
+from ....model.sparse_voxel_diffusion.sparse_vae import hammersley_sequence
+from ....ops import dit_ops
+from ....representations.gaussian import GaussianModel as Gaussian
+from .base import SparseTransformerBase
+
+__all__ = ["SLatGaussianDecoder"]
+
+
+class SLatGaussianDecoder(SparseTransformerBase):
+    def __init__(self, resolution: int, model_channels: int, latent_channels: int, num_blocks: int, num_heads: Optional[int] = None,
+                 num_head_channels: Optional[int] = 64, mlp_ratio: float = 4, attn_mode: str = "swin", window_size: int = 8,
+                 pe_mode: str = "ape", use_fp16: bool = False, use_checkpoint: bool = False, qk_rms_norm: bool = False,
+                 representation_config: dict = None):
+        super().__init__(in_channels=latent_channels, model_channels=model_channels, num_blocks=num_blocks, num_heads=num_heads,
+                         num_head_channels=num_head_channels, mlp_ratio=mlp_ratio, attn_mode=attn_mode, window_size=window_size,
+                         pe_mode=pe_mode, use_fp16=use_fp16, use_checkpoint=use_checkpoint, qk_rms_norm=qk_rms_norm)
+        self.resolution = resolution
+        self.rep_config = representation_config
+        self._calc_layout()
+        self.out_layer = sp.SparseLinear(model_channels, self.out_channels)
+        self._build_perturbation()
+        self.initialize_weights()
+
+    def initialize_weights(self) -> None:
+        super().initialize_weights()
+        nn.init.constant_(self.out_layer.weight, 0)
+        nn.init.constant_(self.out_layer.bias, 0)
+
+    def _build_perturbation(self) -> None:
+        n = self.rep_config["num_gaussians"]
+        p = torch.tensor([hammersley_sequence(3, i, n) for i in range(n)]).float() * 2 - 1
+        self.register_buffer("offset_perturbation", torch.atanh(p / self.rep_config["voxel_size"]))
+
+    def _calc_layout(self) -> None:
+        n = self.rep_config["num_gaussians"]
+        self.layout = {"_xyz": {"shape": (n, 3), "size": n * 3}, "_features_dc": {"shape": (n, 1, 3), "size": n * 3},
+                       "_scaling": {"shape": (n, 3), "size": n * 3}, "_rotation": {"shape": (n, 4), "size": n * 4},
+                       "_opacity": {"shape": (n, 1), "size": n}}
+        start = 0
+        for v in self.layout.values():
+            v["range"] = (start, start + v["size"])
+            start += v["size"]
+        self.out_channels = start
+
+    def to_representation(self, x: sp.SparseTensor) -> List[Gaussian]:
+        cfg = self.rep_config
+        ret = []
+        for i in range(x.shape[0]):
+            rows = x.feats[x.layout[i]]
+            rep = Gaussian(sh_degree=0, aabb=[-0.5, -0.5, -0.5, 1.0, 1.0, 1.0], mininum_kernel_size=cfg["3d_filter_kernel_size"],
+                           scaling_bias=cfg["scaling_bias"], opacity_bias=cfg["opacity_bias"], scaling_activation=cfg["scaling_activation"],
+                           device=rows.device)
+            xyz = (x.coords[x.layout[i]][:, 1:].float() + 0.5) / self.resolution
+            for k, v in self.layout.items():
+                f = rows[:, v["range"][0]:v["range"][1]].reshape(-1, *v["shape"]) * cfg["lr"][k]
+                if k == "_xyz":
+                    if cfg["perturb_offset"]:
+                        f = f + self.offset_perturbation
+                    f = xyz.unsqueeze(1) + torch.tanh(f) / self.resolution * 0.5 * cfg["voxel_size"]
+                setattr(rep, k, f.flatten(0, 1))
+            ret.append(rep)
+        return ret
+
+    @torch.no_grad()
+    def decode_rows(self, x: sp.SparseTensor) -> sp.SparseTensor:
+        """-> the (T, out_channels) output rows before to_representation."""
+        h = self.forward_rows(x)
+        hb = torch.empty(h.shape, dtype=torch.bfloat16, device=h.device)
+        dit_ops.layernorm_modulate_bf16(h, hb, 1e-5)                              # F.layer_norm default eps (:119)
+        lin = self.out_layer
+        out = torch.empty((h.shape[0], self.out_channels), dtype=torch.float32, device=h.device)
+        dit_ops.gemm_bf16(hb, lin.weight.detach().to(torch.bfloat16).contiguous(), lin.bias.detach().float().contiguous(), out,
+                          dit_ops.EPI_STORE_F32)
+        return x.replace(out.to(x.dtype))
+
+    def forward(self, x: sp.SparseTensor) -> List[Gaussian]:
+        return self.to_representation(self.decode_rows(x))

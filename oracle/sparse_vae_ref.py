@@ -58,7 +58,7 @@ def attention_groups(q, k, v, gid, precision):
     return out
 
 
-def block(x, gid, sd, prefix, heads, precision, old_impl):
+def block(x, gid, sd, prefix, heads, precision, old_impl, qk_rms_norm=False):
     T, C = x.shape
     d = C // heads
     h = _r(F.layer_norm(x, (C,), eps=1e-6), precision)
@@ -67,6 +67,9 @@ def block(x, gid, sd, prefix, heads, precision, old_impl):
         q, k, v = qkv.reshape(T, heads, 3 * d).chunk(3, dim=-1)
     else:
         q, k, v = qkv.reshape(T, 3, heads, d).unbind(dim=1)
+    if qk_rms_norm:   # SparseMultiHeadRMSNorm, trellis/modules/sparse/attention/modules.py:11-25: normalize * gamma * sqrt(d)
+        q = _r(F.normalize(q, dim=-1) * sd[prefix + ".attn.q_rms_norm.gamma"] * d ** 0.5, precision)
+        k = _r(F.normalize(k, dim=-1) * sd[prefix + ".attn.k_rms_norm.gamma"] * d ** 0.5, precision)
     a = _r(attention_groups(q, k, v, gid, precision).reshape(T, C), precision)
     x = x + _lin(a, sd, prefix + ".attn.to_out", precision)
     h = _r(F.layer_norm(x, (C,), eps=1e-6), precision)
@@ -93,3 +96,14 @@ def encode(sd, cfg, feats, coords, precision="fp32"):
 
 def decode(sd, cfg, z, coords, precision="fp32"):
     return _torso(z, coords, sd, cfg, "from_latent", "decoder", "out_layer", precision)
+
+
+def slat_decode_rows(sd, cfg, feats, coords, precision="fp32"):
+    """TRELLIS SLatGaussianDecoder up to its output rows (trellis/models/structured_latent_vae/base.py:108-117,
+    decoder_gs.py:117-121): input layer + APE, swin blocks ([q|k|v][head][c] layout, optional QK-RMSNorm), LayerNorm, out_layer."""
+    C, heads, window = cfg["model_channels"], cfg["num_heads"], cfg["window_size"]
+    x = _lin(feats, sd, "input_layer", precision) + ape(coords[:, 1:], C)
+    for i in range(cfg["num_blocks"]):
+        gid = window_ids(coords, window, window // 2 * (i % 2))
+        x = block(x, gid, sd, f"blocks.{i}", heads, precision, False, cfg.get("qk_rms_norm", False))
+    return _lin(F.layer_norm(x, (C,)), sd, "out_layer", precision)

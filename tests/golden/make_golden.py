@@ -401,13 +401,9 @@ SVAE_SMALL = dict(resolution=16, in_channels=64, model_channels=128, out_channel
                   norm_output=True)
 
 
-def gen_sparse_vae():
-    """Static-VAE backbone (model/sparse_voxel_diffusion/sparse_transformer_vae.py) encode / decode, fp32, on the reference's
-    own classes.  Third-party stand-ins: spconv's SparseConvTensor as a plain record of the fields sparse/basic.py touches
-    (no convolution is executed on this path), flash_attn's two packed-qkv entry points as softmax attention in torch,
-    vox2seq as the reference's own pure-PyTorch fallback."""
-    import json
-
+def _svae_stubs():
+    """spconv's SparseConvTensor as a plain record of the fields sparse/basic.py touches, flash_attn's two packed-qkv entry
+    points as softmax attention in torch, vox2seq as the reference's own pure-PyTorch fallback."""
     class SparseConvTensor:
         def __init__(self, features, indices, spatial_shape, batch_size, grid=None, voxel_num=None, indice_dict=None,
                      benchmark=False):
@@ -436,6 +432,16 @@ def gen_sparse_vae():
     _stub("flash_attn", flash_attn_varlen_qkvpacked_func=varlen_qkvpacked, flash_attn_qkvpacked_func=qkvpacked)
     base = f"{REF}/model/sparse_voxel_diffusion/vox2seq/vox2seq/pytorch"
     sys.modules["vox2seq"] = load_by_path("vox2seq", f"{base}/__init__.py", [base])
+
+
+def gen_sparse_vae():
+    """Static-VAE backbone (model/sparse_voxel_diffusion/sparse_transformer_vae.py) encode / decode, fp32, on the reference's
+    own classes.  Third-party stand-ins: spconv's SparseConvTensor as a plain record of the fields sparse/basic.py touches
+    (no convolution is executed on this path), flash_attn's two packed-qkv entry points as softmax attention in torch,
+    vox2seq as the reference's own pure-PyTorch fallback."""
+    import json
+
+    _svae_stubs()
     pkg = _stub("model.sparse_voxel_diffusion"); pkg.__path__ = [f"{REF}/model/sparse_voxel_diffusion"]
     import importlib
     import sparse as sp
@@ -466,7 +472,60 @@ def gen_sparse_vae():
     np.savez_compressed(os.path.join(OUT, "sparse_vae_golden.npz"), **out)
 
 
-SECTIONS = {"sparse_vae": gen_sparse_vae, "vae_encode": gen_vae_encode, "vae": gen_vae, "raster": gen_raster, "vox2seq": gen_vox2seq, "dit": gen_dit, "sampler": gen_sampler, "sparse": gen_sparse}
+SLAT_DEC_SMALL = dict(resolution=16, model_channels=128, latent_channels=8, num_blocks=2, num_heads=2, mlp_ratio=4, attn_mode="swin",
+                      window_size=8, use_fp16=False, qk_rms_norm=True,
+                      representation_config={"lr": {"_xyz": 1.0, "_features_dc": 1.0, "_opacity": 1.0, "_scaling": 1.0, "_rotation": 0.1},
+                                             "perturb_offset": True, "voxel_size": 1.5, "num_gaussians": 4, "2d_filter_kernel_size": 0.1,
+                                             "3d_filter_kernel_size": 0.0009, "scaling_bias": 0.004, "opacity_bias": 0.1,
+                                             "scaling_activation": "softplus"})
+
+
+def gen_slat_decoder():
+    """TRELLIS SLatGaussianDecoder (trellis/models/structured_latent_vae/decoder_gs.py) on the reference's own classes, fp32,
+    with and without QK-RMSNorm.  Third-party stand-ins as in gen_sparse_vae; the trellis package is entered through
+    path-only package stubs so that its pipelines / renderers (nvdiffrast, kaolin, ...) are never imported."""
+    import importlib
+    import json
+    _svae_stubs()
+    for name in ("trellis", "trellis.models", "trellis.models.structured_latent_vae", "trellis.representations", "trellis.utils"):
+        pkg = _stub(name); pkg.__path__ = [f"{REF}/" + name.replace(".", "/")]
+    gm = importlib.import_module("trellis.representations.gaussian.gaussian_model")
+    sys.modules["trellis.representations"].Gaussian = gm.Gaussian
+    dec = importlib.import_module("trellis.models.structured_latent_vae.decoder_gs")
+    tsp = importlib.import_module("trellis.modules.sparse")
+    dec.Gaussian = lambda **kw: gm.Gaussian(device="cpu", **kw)      # the class defaults to device="cuda" (gaussian_model.py:17)
+    out = {"cfg_json": np.frombuffer(json.dumps(SLAT_DEC_SMALL).encode(), dtype=np.uint8)}
+    g = torch.Generator().manual_seed(31)
+    coords = []
+    for b, n in enumerate((500, 280)):
+        c = torch.unique(torch.randint(0, 16, (n * 2, 3), generator=g), dim=0)
+        c = c[torch.randperm(c.shape[0], generator=g)[:n]]
+        coords.append(torch.cat([torch.full((c.shape[0], 1), b), c], dim=1))
+    coords = torch.cat(coords).int()
+    feats = torch.randn((coords.shape[0], 8), generator=g)
+    for tag, rms in (("rms", True), ("plain", False)):
+        torch.manual_seed(0)
+        m = dec.SLatGaussianDecoder(**dict(SLAT_DEC_SMALL, qk_rms_norm=rms)).eval()
+        _randomise(m, 12)
+        with torch.no_grad():
+            x = tsp.SparseTensor(feats, coords)
+            h = dec.SparseTransformerBase.forward(m, x)
+            rows = m.out_layer(h.replace(torch.nn.functional.layer_norm(h.feats, h.feats.shape[-1:])))
+            reps = m(x)
+        out[f"{tag}_rows"] = rows.feats.numpy()
+        r = reps[1]
+        out[f"{tag}_rep1_xyz"], out[f"{tag}_rep1_rot"] = r._xyz.numpy(), r._rotation.numpy()
+        out[f"{tag}_rep1_get_xyz"], out[f"{tag}_rep1_get_scaling"] = r.get_xyz.numpy(), r.get_scaling.numpy()
+        out[f"{tag}_rep1_get_opacity"] = r.get_opacity.numpy()
+        for k, v in m.state_dict().items():
+            if tag == "rms" or not np.array_equal(out["sd_rms." + k], v.numpy()):   # store the plain model's differences only
+                out[f"sd_{tag}." + k] = v.numpy()
+        print("slat_decoder", tag, rows.feats.shape, float(rows.feats.abs().mean()), r._xyz.shape)
+    out["coords"], out["feats"] = coords.numpy(), feats.numpy()
+    np.savez_compressed(os.path.join(OUT, "slat_decoder_golden.npz"), **out)
+
+
+SECTIONS = {"slat_decoder": gen_slat_decoder, "sparse_vae": gen_sparse_vae, "vae_encode": gen_vae_encode, "vae": gen_vae, "raster": gen_raster, "vox2seq": gen_vox2seq, "dit": gen_dit, "sampler": gen_sampler, "sparse": gen_sparse}
 
 if __name__ == "__main__":
     install_stubs()

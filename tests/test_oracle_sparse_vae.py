@@ -55,3 +55,22 @@ def test_window_ids_group_tokens_like_the_device_partition():
             assert len(set(gid[fwd[start:start + n]].tolist())) == 1
             start += n
         assert len(lens) == len(torch.unique(gid))
+
+
+SLAT = os.path.join(os.path.dirname(__file__), "golden", "slat_decoder_golden.npz")
+
+
+def slat_state_dict(z, tag):
+    sd = {k[7:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd_rms.")}
+    sd.update({k[len(tag) + 4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(f"sd_{tag}.")})
+    return {k: v for k, v in sd.items() if tag == "rms" or "rms_norm" not in k}
+
+
+@pytest.mark.parametrize("tag,rms", [("rms", True), ("plain", False)])
+def test_slat_decoder_rows_match_reference(tag, rms):
+    """TRELLIS SLatGaussianDecoder (tests/golden/make_golden.py::gen_slat_decoder), with and without QK-RMSNorm."""
+    z = np.load(SLAT)
+    cfg = dict(json.loads(bytes(z["cfg_json"]).decode()), qk_rms_norm=rms)
+    sd = slat_state_dict(z, tag)
+    rows = ref.slat_decode_rows(sd, cfg, torch.from_numpy(z["feats"]), torch.from_numpy(z["coords"]))
+    assert np.abs(rows.numpy() - z[f"{tag}_rows"]).max() < 2e-5

@@ -145,3 +145,36 @@ def test_framework_representation_and_render(cuda):
         out = vae.render_batch(reps, cam["extrinsics"].cuda()[None].repeat(2, 1, 1), cam["intrinsics"].cuda()[None].repeat(2, 1, 1))
     rgb = out["MipGS"]["rgb"]
     assert rgb.shape == (2, 3, 64, 64) and torch.isfinite(rgb).all() and float((rgb < 0.99).float().mean()) > 0.01   # something drawn
+
+
+# ---- TRELLIS SLatGaussianDecoder (trellis/models/structured_latent_vae/decoder_gs.py) --------------------------------------
+SLAT = os.path.join(os.path.dirname(__file__), "golden", "slat_decoder_golden.npz")
+
+
+@pytest.mark.parametrize("tag,rms", [("rms", True), ("plain", False)])
+def test_slat_gaussian_decoder(cuda, tag, rms):
+    from gvfdiffusion_amd import sparse as sp
+    from gvfdiffusion_amd.trellis.models import SLatGaussianDecoder
+    from oracle import sparse_vae_ref as ref
+    from test_oracle_sparse_vae import slat_state_dict
+    z = np.load(SLAT)
+    cfg = dict(json.loads(bytes(z["cfg_json"]).decode()), qk_rms_norm=rms)
+    sd = slat_state_dict(z, tag)
+    m = SLatGaussianDecoder(**cfg)
+    m.load_state_dict(sd, strict=True)                       # incl. the offset_perturbation buffer of the reference
+    assert torch.allclose(SLatGaussianDecoder(**cfg).offset_perturbation, sd["offset_perturbation"], atol=1e-6)
+    m = m.cuda()
+    feats, coords = torch.from_numpy(z["feats"]), torch.from_numpy(z["coords"])
+    x = sp.SparseTensor(feats.cuda(), coords.cuda())
+    rows = m.decode_rows(x).feats.cpu()
+    r16, r32 = ref.slat_decode_rows(sd, cfg, feats, coords, "bf16"), ref.slat_decode_rows(sd, cfg, feats, coords)
+    print(f"slat decoder ({tag}) rows: rel-L2 vs bf16 oracle {_rel(rows, r16):.2e}, vs fp32 oracle {_rel(rows, r32):.2e}")
+    assert _rel(rows, r16) < TOL16 and _rel(rows, r32) < TOL32
+    assert _rel(rows, torch.from_numpy(z[f"{tag}_rows"])) < TOL32           # the reference's own output
+    # representation: feed the reference's rows through to_representation -> its Gaussians, accessor by accessor
+    reps = m.to_representation(x.replace(torch.from_numpy(z[f"{tag}_rows"]).cuda()))
+    g = reps[1]
+    for got, key, tol in ((g._xyz, "xyz", 1e-6), (g._rotation, "rot", 1e-7), (g.get_xyz, "get_xyz", 1e-6),
+                          (g.get_scaling, "get_scaling", 1e-6), (g.get_opacity, "get_opacity", 1e-6)):
+        assert np.abs(got.cpu().numpy() - z[f"{tag}_rep1_{key}"]).max() < tol, key
+    assert len(m(x)) == 2
