@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--sh-degree", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dit", action="store_true")
+    ap.add_argument("--e2e-only", action="store_true", help="profiling aid: run only the end-to-end leg and print its object")
     ap.add_argument("--dit-only", action="store_true", help="profiling aid: run only the DiT leg and print its object")
     return ap.parse_args()
 
@@ -175,6 +176,69 @@ def bench_dit(dev, nfe=32):
                                  "the loop); as-written equivalent = %.2f TFLOP/s" % (fa / per / 1e12)}}
 
 
+def bench_e2e(dev, P=262_144, S=800, T=24):
+    """BASELINE configs[3]: the inference_dpm_latent.py chain on one MI355X at the named shapes -- adaptive DPM-Solver over
+    the DiT (configs/diffusion.yml, B=1, steps=100 as the script's --rescale_timesteps default) -> de-normalise -> motion-VAE
+    decode of P static Gaussians x T frames (released VAE config) -> batched render of the T frames (SH degree 0, mip filter,
+    per-frame 14-channel deltas).  Random-init weights of the released architectures, synthetic conditions.  Secondary
+    figure, not part of `value`."""
+    import json
+    from gvfdiffusion_amd import synthetic
+    from gvfdiffusion_amd.model.autoencoder import GSKLTemporalVariationalAutoEncoder
+    from gvfdiffusion_amd.renderers import GaussianRenderer
+    w = DiTWorkload(dev, T=T)
+    calls = {"n": 0}
+    inner = w.solver.model
+    def counted(x, t):
+        calls["n"] += 1
+        return inner(x, t)
+    w.solver.model = counted
+    man = json.load(open(os.path.join(ROOT, "tests", "golden", "vae_manifest.json")))
+    torch.manual_seed(0)
+    vae = GSKLTemporalVariationalAutoEncoder(**man["config"], num_timesteps=T)
+    with torch.no_grad():
+        for p in vae.parameters():
+            p.copy_(torch.randn_like(p) * (1.0 / p.shape[1] ** 0.5 if p.dim() == 2 else 0.05))
+        vae.to_outputs.weight.mul_(0.02)            # deltas of a few per cent of the object size, as a trained decoder gives
+    vae = vae.to(dev)
+    attrs = synthetic.random_gaussians(P, sh_degree=0, seed=0)
+    gm = synthetic.gaussian_model_from(attrs, 0, dev)
+    queries = torch.cat([gm._xyz, gm._features_dc.reshape(P, 3), gm._scaling, gm._rotation, gm._opacity], 1)[None].float()
+    rend = GaussianRenderer({"resolution": S, "near": synthetic.NEAR, "far": synthetic.FAR, "ssaa": 1, "bg_color": (1, 1, 1)})
+    rend.pipe.use_mip_gaussian = True
+    rend.pipe.kernel_size = synthetic.KERNEL_2D
+    ext = torch.stack([synthetic.orbit_w2c(360.0 * f / T, 15.0) for f in range(T)]).to(dev)
+    K = synthetic.intrinsics().to(dev)
+
+    def chain(timed):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        calls["n"] = 0
+        ev[0].record()
+        x = w.solver.sample(w.x, steps=100, t_start=1.0, t_end=1 / 1000, order=2, skip_type="time_uniform", method="adaptive")
+        ev[1].record()
+        lat = (x * 1.5 + 0.02).reshape(T, x.shape[2], x.shape[3])
+        delta = vae.decode(lat, queries).float()
+        ev[2].record()
+        out = rend.render_frames(gm, ext, K, delta_pc=delta[0].contiguous(), sync=False)
+        ev[3].record()
+        torch.cuda.synchronize()
+        assert out.rgb.shape == (T, 3, S, S)
+        return [ev[i].elapsed_time(ev[i + 1]) for i in range(3)], calls["n"], out
+
+    import contextlib
+    with torch.no_grad(), contextlib.redirect_stdout(sys.stderr):     # the solver reports its NFE on stdout, as upstream does
+        chain(False)                                 # warm-up: weight conversion, graph capture, workspace
+        t0 = time.perf_counter()
+        (ms_sample, ms_decode, ms_render), nfe, out = chain(True)
+        wall = time.perf_counter() - t0
+    assert bool(torch.isfinite(out.rgb).all())
+    return {"metric": "end-to-end 4D sample (adaptive DPM-Solver -> VAE decode -> 24-frame render), BASELINE configs[3]",
+            "value": round(T / wall, 2), "unit": "frames/s", "wall_ms": round(wall * 1e3, 2), "nfe": nfe,
+            "stage_ms": {"sample": round(ms_sample, 2), "vae_decode": round(ms_decode, 2), "render": round(ms_render, 2)},
+            "config": {"gaussians": P, "resolution": S, "frames": T, "sampler": "dpmsolver++ adaptive, steps=100, order 2",
+                       "dtype": "bf16 models, f32 rasteriser"}}
+
+
 def bench_backward(dev, attrs, S, deg, iters=8):
     """The operator as a training step sees it (train_vae.py:321-352): one frame per call under autograd, forward +
     backward, same Gaussians / resolution as the headline workload.  Secondary figure, not part of `value`."""
@@ -264,6 +328,9 @@ def main():
 
     if a.dit_only:
         print(json.dumps(bench_dit(dev)))
+        return
+    if a.e2e_only:
+        print(json.dumps(bench_e2e(dev, a.gaussians, a.res, a.frames)))
         return
     from gvfdiffusion_amd import _lib
     work = RasterWorkload(dev, a.gaussians, a.res, a.frames, a.sh_degree, seed=rank)
@@ -355,6 +422,8 @@ def main():
             torch.cuda.empty_cache()
             out["differentiable_render"] = bench_backward(dev, work.attrs, a.res, a.sh_degree)
             out["dit"] = bench_dit(dev)
+            torch.cuda.empty_cache()
+            out["end_to_end"] = bench_e2e(dev, a.gaussians, a.res, a.frames)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(work)
         print(json.dumps(out))
