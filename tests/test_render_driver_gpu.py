@@ -53,3 +53,23 @@ def test_driver_matches_per_frame_renders(cuda):
         # torch activations (facade) vs fused activations (driver): sub-ulp colour differences can flip a uint8 step
         assert d.max() <= 1 and (d > 0).mean() < 0.02, (k, d.max(), (d > 0).mean())
     assert (got[0].float() - got[V].float()).abs().max() > 0          # the deltas move the object between timesteps
+
+
+def test_all_delta_module_is_the_rgb_only_facade(cuda):
+    """renderers/gaussian_render_all_delta.py (named by BASELINE.json's north_star): same frames as gaussian_render, rgb only."""
+    from gvfdiffusion_amd.renderers import GaussianRenderer
+    from gvfdiffusion_amd.renderers import gaussian_render_all_delta as ad
+    P, S = 5000, 96
+    attrs = synthetic.random_gaussians(P, sh_degree=0, seed=9, scale_lo=0.004, scale_hi=0.02)
+    gm = synthetic.gaussian_model_from(attrs, 0, cuda)
+    delta = synthetic.random_deltas(1, P, seed=10, std=0.02).to(cuda)[0]
+    K = synthetic.intrinsics().to(cuda)
+    opts = {"resolution": S, "near": synthetic.NEAR, "far": synthetic.FAR, "bg_color": (1, 1, 1)}
+    a, b = ad.GaussianRenderer(opts), GaussianRenderer(opts)
+    for r in (a, b):
+        r.pipe.use_mip_gaussian = True
+        r.pipe.kernel_size = synthetic.KERNEL_2D
+    ext = synthetic.orbit_w2c(40.0, 10.0).to(cuda)
+    with torch.no_grad():
+        ra, rb = a.render(gm, ext, K, delta_pc=delta), b.render(gm, ext, K, delta_pc=delta)
+    assert set(ra.keys()) == {"rgb"} and torch.equal(ra["rgb"], rb["rgb"])
