@@ -21,6 +21,7 @@ SOURCES = {
     # v_pk_* instructions (4 cycles each against 2.8 for the scalar form, plus the v_mov traffic that builds the pairs)
     "rast.hip": ["-ffp-contract=off", "-fno-slp-vectorize"],
     "vox2seq.hip": [],
+    "resize.hip": [],
     # the squared distances must round exactly as the oracle's binary32 expression does (index-exact parity)
     "fps.hip": ["-ffp-contract=off"],
     # MFMA results straight into VGPRs (gfx950 has a unified register file): removes the accvgpr

@@ -4,16 +4,23 @@
 The reference renders B x 32 x 128 views one at a time, each followed by `.cpu()`, a PIL LANCZOS resize and a PNG
 write.  Here all (timestep, camera) pairs of a sample go through `GaussianRenderer.render_frames` in chunks (one
 fused launch sequence per chunk, deltas applied inside the preprocess kernel) and leave the device as uint8
-(`gvf_rgb_to_u8` = the reference's clamp(0,1) * 255 -> astype('uint8'), inference_utils.py:276-281).  Resizing to
-512, padding / cropping and PNG / MP4 encoding stay host-side consumers of these frames (out of scope).
+(`gvf_rgb_to_u8` = the reference's clamp(0,1) * 255 -> astype('uint8'), inference_utils.py:276-281), optionally already
+resized / padded / cropped to 512x512 on the device with Pillow's own arithmetic (`resize_to=`, csrc/resize.hip, bit-identical
+to :283-296).  `render_and_save_images` keeps the reference's signature and file names; PNG encoding is the only host work
+left (a writer thread per call), MP4 assembly needs imageio and is skipped when it is absent.
 """
 import math
 from typing import Iterator, List, Optional, Sequence, Tuple
+
+import os
+import random
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 import torch
 
 from ..rasterizer import frames_to_uint8
+from .image_ops import resize_pad_crop_u8
 
 
 def _orbit_pose_opengl(elevation_deg: float, azimuth_deg: float, radius: float) -> np.ndarray:
@@ -54,14 +61,19 @@ def frame_schedule(n_timesteps: int, n_views: int) -> List[Tuple[int, int]]:
 def render_sample_frames(renderer, gaussian, pred_delta: torch.Tensor, intrinsics: torch.Tensor,
                          extrinsics: Optional[torch.Tensor] = None, n_views: int = 128,
                          timesteps: Optional[Sequence[int]] = None, n_valid: Optional[int] = None,
-                         chunk_frames: int = 96, as_uint8: bool = True) -> Iterator[Tuple[List[Tuple[int, int]], torch.Tensor]]:
+                         chunk_frames: int = 96, as_uint8: bool = True, resize_to: Optional[int] = None,
+                         out_size: int = 512) -> Iterator[Tuple[List[Tuple[int, int]], torch.Tensor]]:
     """Render every (timestep, camera) view of ONE sample; yields `(schedule_chunk, frames)` with frames
     `(F, 3, H, W)` on the device, uint8 (`as_uint8`) or fp32.
 
     renderer: a gvfdiffusion_amd GaussianRenderer (`static_vae.renderers["MipGS"]`); gaussian: its GaussianModel
     (`static_gs_model[b]`); pred_delta: (T, P, 14) = `pred_delta[b]`; n_valid: `valid_idx[b]` (the reference slices
     `pred_delta[b][t, :valid_idx[b]]`; rows past it must belong to padding and are ignored by passing a model of
-    n_valid Gaussians); extrinsics: (V, 4, 4) world-to-camera, default the 128-view orbit."""
+    n_valid Gaussians); extrinsics: (V, 4, 4) world-to-camera, default the 128-view orbit; resize_to: LANCZOS-resize the
+    uint8 frames to resize_to x resize_to and pad (white) / centre-crop to out_size x out_size on the device
+    (`target_size = int(512 * scale_factors[b])`, inference_utils.py:272-296)."""
+    if resize_to is not None and not as_uint8:
+        raise ValueError("resize_to works on the uint8 frames")
     dev = pred_delta.device
     T = pred_delta.shape[0]
     if n_valid is not None and n_valid != pred_delta.shape[1]:
@@ -76,6 +88,55 @@ def render_sample_frames(renderer, gaussian, pred_delta: torch.Tensor, intrinsic
             e = ext[torch.tensor([c for _, c in part], device=dev)]
             out = renderer.render_frames(gaussian, e, intrinsics.to(dev), delta_pc=pred_delta,
                                          delta_index=[t for t, _ in part])
-            yield part, (frames_to_uint8(out.rgb) if as_uint8 else out.rgb)
+            frames = frames_to_uint8(out.rgb) if as_uint8 else out.rgb
+            if resize_to is not None:
+                frames = resize_pad_crop_u8(frames, resize_to, out_size=out_size, pad_value=255)
+            yield part, frames
     finally:
         renderer.pipe.use_mip_gaussian = old_mip
+
+
+def seed_everything(seed: int):
+    """utils/inference_utils.py:200-205."""
+    random.seed(seed)
+    os.environ["PYTHONHASHSEED"] = str(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed(seed)
+
+
+def render_and_save_images(args, static_vae, static_gs_model, pred_delta, model_kwargs, valid_idx, img_id, accelerator,
+                           scale_factors, save_dir="inference_images", out_root: Optional[str] = None, n_timesteps: int = 32,
+                           n_views: int = 128, chunk_frames: int = 96):
+    """Same arguments, same files as the reference (utils/inference_utils.py:208-306):
+    `<root>/<save_dir>/rank_RR_render_IIIIII_cam_CCC_timesteps_TT.png`, 512x512, for every (timestep < 32, camera < 128) of
+    every sample.  Frames are rendered, quantised, resized and padded / cropped on the device; the host only encodes PNGs.
+    `out_root` replaces `logger.get_dir()` (the reference's logger is not part of this package; default: args.exp_name).
+    `accelerator` needs `.device` and `.process_index` only.  Returns the list of files written."""
+    from PIL import Image
+    root = out_root if out_root is not None else getattr(args, "exp_name", ".")
+    s_path = os.path.join(root, save_dir)
+    os.makedirs(s_path, exist_ok=True)
+    os.makedirs(os.path.join(root, "inference_videos"), exist_ok=True)
+    renderer = static_vae.renderers["MipGS"]
+    dev = accelerator.device
+    intrinsics = model_kwargs["cams"]["intrinsics"][0][0].to(dev)
+    rank = getattr(accelerator, "process_index", 0)
+    written = []
+
+    def save(arr, path):
+        Image.fromarray(arr).save(path)
+
+    with ThreadPoolExecutor(max_workers=8) as pool:
+        for b in range(pred_delta.shape[0]):
+            T = min(n_timesteps, pred_delta.shape[1])
+            target = int(512 * scale_factors[b])
+            for part, frames in render_sample_frames(renderer, static_gs_model[b], pred_delta[b][:T].to(dev), intrinsics, n_views=n_views,
+                                                     n_valid=valid_idx[b], chunk_frames=chunk_frames, resize_to=target, out_size=512):
+                host = frames.permute(0, 2, 3, 1).contiguous().cpu().numpy()          # one transfer per chunk
+                for k, (t, c) in enumerate(part):
+                    path = os.path.join(s_path, f"rank_{rank:02d}_render_{img_id + b:06d}_cam_{c:03d}_timesteps_{t:02d}.png")
+                    pool.submit(save, host[k], path)
+                    written.append(path)
+    return written

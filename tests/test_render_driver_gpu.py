@@ -1,6 +1,8 @@
 """Batched render driver (gvfdiffusion_amd/utils/inference_utils.py) = the reference's render_and_save_images loop
 (utils/inference_utils.py:239-281) without the per-frame host round trips: same cameras, same (timestep, camera)
 order, uint8 frames equal to the per-frame facade render followed by the reference's clamp -> *255 -> uint8."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -73,3 +75,38 @@ def test_all_delta_module_is_the_rgb_only_facade(cuda):
     with torch.no_grad():
         ra, rb = a.render(gm, ext, K, delta_pc=delta), b.render(gm, ext, K, delta_pc=delta)
     assert set(ra.keys()) == {"rgb"} and torch.equal(ra["rgb"], rb["rgb"])
+
+
+def test_render_and_save_images_writes_the_reference_files(cuda, tmp_path):
+    """utils/inference_utils.py:208-297: file names, 512x512 frames, content = PIL's resize / pad of the per-frame render."""
+    from types import SimpleNamespace
+    from PIL import Image
+    from gvfdiffusion_amd.attrdict import edict
+    from gvfdiffusion_amd.renderers import GaussianRenderer
+    from gvfdiffusion_amd.utils import orbit_cameras, render_and_save_images
+    P, T, V, S = 4000, 2, 3, 200
+    attrs = synthetic.random_gaussians(P + 50, sh_degree=0, seed=11, scale_lo=0.004, scale_hi=0.02)
+    full = synthetic.gaussian_model_from(attrs, 0, cuda)
+    gm = synthetic.gaussian_model_from({k: v[:P] for k, v in attrs.items()}, 0, cuda)
+    delta = synthetic.random_deltas(T, P + 50, seed=12, std=0.02).to(cuda)             # 50 padded rows past valid_idx
+    rend = GaussianRenderer({"resolution": S, "near": synthetic.NEAR, "far": synthetic.FAR, "bg_color": (1, 1, 1)})
+    rend.pipe.kernel_size = synthetic.KERNEL_2D
+    K = synthetic.intrinsics()
+    files = render_and_save_images(SimpleNamespace(exp_name=str(tmp_path)), SimpleNamespace(renderers=edict({"MipGS": rend})), [gm], delta[None],
+                                   {"cams": {"intrinsics": K[None, None]}}, [P], 7, SimpleNamespace(device=cuda, process_index=1), [0.8],
+                                   n_timesteps=T, n_views=V, chunk_frames=4)
+    assert len(files) == T * V and os.path.basename(files[4]) == "rank_01_render_000007_cam_001_timesteps_01.png"
+    rend.pipe.use_mip_gaussian = True
+    cams = orbit_cameras(V)
+    for path, (t, c) in ((files[0], (0, 0)), (files[4], (1, 1))):
+        got = np.asarray(Image.open(path))
+        assert got.shape == (512, 512, 3)
+        with torch.no_grad():
+            one = rend.render(gm, cams[c].to(cuda), K.to(cuda), delta_pc=delta[t, :P])["rgb"]
+        rgb = (one.clamp(0.0, 1.0).permute(1, 2, 0).cpu().numpy() * 255).astype("uint8")
+        img = Image.fromarray(rgb).resize((409, 409), resample=Image.Resampling.LANCZOS)       # int(512 * 0.8)
+        want = Image.new("RGB", (512, 512), (255, 255, 255))
+        want.paste(img, ((512 - 409) // 2, (512 - 409) // 2))
+        d = np.abs(got.astype(int) - np.asarray(want).astype(int))
+        assert d.max() <= 2 and (d > 0).mean() < 0.02, (d.max(), (d > 0).mean())       # fused vs torch activations: rare 1-step flips
+    del full
