@@ -57,6 +57,7 @@ def test_driver_matches_per_frame_renders(cuda):
     assert (got[0].float() - got[V].float()).abs().max() > 0          # the deltas move the object between timesteps
 
 
+@pytest.mark.gpu
 def test_all_delta_module_is_the_rgb_only_facade(cuda):
     """renderers/gaussian_render_all_delta.py (named by BASELINE.json's north_star): same frames as gaussian_render, rgb only."""
     from gvfdiffusion_amd.renderers import GaussianRenderer
@@ -77,6 +78,7 @@ def test_all_delta_module_is_the_rgb_only_facade(cuda):
     assert set(ra.keys()) == {"rgb"} and torch.equal(ra["rgb"], rb["rgb"])
 
 
+@pytest.mark.gpu
 def test_render_and_save_images_writes_the_reference_files(cuda, tmp_path):
     """utils/inference_utils.py:208-297: file names, 512x512 frames, content = PIL's resize / pad of the per-frame render."""
     from types import SimpleNamespace
