@@ -18,6 +18,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 
 from ..rasterizer import frames_to_uint8
 from .image_ops import resize_pad_crop_u8
@@ -49,6 +50,114 @@ def orbit_cameras(n_views: int = 128, elevation: float = 0.0, radius: float = 2.
         pose[:3, 1:3] *= -1
         out.append(np.linalg.inv(pose))
     return torch.from_numpy(np.stack(out)).float()
+
+
+def azimuth_cameras(azimuths, elevation: float = 0.0, radius: float = 2.0) -> torch.Tensor:
+    """World-to-camera matrices for arbitrary azimuths (degrees), built as `orbit_cameras` builds its ring
+    (utils/inference_utils.py:53-58)."""
+    convert = np.array([[1, 0, 0, 0], [0, 0, -1, 0], [0, 1, 0, 0], [0, 0, 0, 1]], dtype=np.float64)
+    out = []
+    for azi in azimuths:
+        pose = convert @ _orbit_pose_opengl(elevation, float(azi), radius)
+        pose[:3, 1:3] *= -1
+        out.append(np.linalg.inv(pose))
+    return torch.from_numpy(np.stack(out)).float()
+
+
+def build_rotation(r: torch.Tensor) -> torch.Tensor:
+    """Quaternion (r, x, y, z), any norm -> rotation matrix (utils/script_util.py:102-123)."""
+    q = r / r.norm(dim=1, keepdim=True)
+    w, x, y, z = q.unbind(dim=1)
+    return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                        2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                        2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], dim=1).reshape(-1, 3, 3)
+
+
+def matrix_to_quaternion(m: torch.Tensor) -> torch.Tensor:
+    """Rotation matrices (N, 3, 3) -> unit quaternions (r, x, y, z) with r >= 0 (pytorch3d.transforms.matrix_to_quaternion,
+    a third-party call at utils/inference_utils.py:174, restated from its definition: of the four candidate solutions the
+    one with the largest divisor is taken)."""
+    m00, m01, m02, m10, m11, m12, m20, m21, m22 = m.reshape(-1, 9).unbind(dim=1)
+    q_abs = torch.sqrt(torch.clamp(torch.stack([1 + m00 + m11 + m22, 1 + m00 - m11 - m22, 1 - m00 + m11 - m22,
+                                                1 - m00 - m11 + m22], dim=1), min=0.0))
+    cand = torch.stack([torch.stack([q_abs[:, 0] ** 2, m21 - m12, m02 - m20, m10 - m01], dim=1),
+                        torch.stack([m21 - m12, q_abs[:, 1] ** 2, m10 + m01, m02 + m20], dim=1),
+                        torch.stack([m02 - m20, m10 + m01, q_abs[:, 2] ** 2, m12 + m21], dim=1),
+                        torch.stack([m10 - m01, m20 + m02, m21 + m12, q_abs[:, 3] ** 2], dim=1)], dim=1)
+    cand = cand / (2.0 * q_abs[:, :, None].clamp(min=0.1))
+    best = cand[torch.arange(m.shape[0], device=m.device), q_abs.argmax(dim=1)]
+    return torch.where(best[:, :1] < 0, -best, best)
+
+
+def _mask_extent(mask: torch.Tensor) -> torch.Tensor:
+    """(F, H, W) bool -> (F,) max(height, width) of the mask's bounding box as the reference measures it
+    (`max - min` of the indices, :71-77); -1 where the mask is empty."""
+    out = []
+    for axis in (2, 1):                                   # rows that contain a pixel, then columns
+        hit = mask.any(dim=axis)
+        n = hit.shape[1]
+        idx = torch.arange(n, device=mask.device)
+        lo = torch.where(hit, idx, n).amin(dim=1)
+        hi = torch.where(hit, idx, -1).amax(dim=1)
+        out.append(hi - lo)
+    ext = torch.maximum(out[0], out[1])
+    return torch.where(mask.flatten(1).any(dim=1), ext, torch.full_like(ext, -1))
+
+
+@torch.no_grad()
+def align_gaussian_to_canonical(static_gs_model, canonical_image, canonical_alpha, intrinsics, static_vae, id, device,
+                                in_the_wild=True, clip_score=None, chunk_frames: int = 60):
+    """Find the azimuth (and the image-space scale) at which the static Gaussians look like the canonical view, then turn
+    the model so that this view becomes the front view (utils/inference_utils.py:38-178; same arguments and return value
+    `(static_gs_model, best_scale_factor)`).
+
+    The reference renders the 360 (or 4) azimuths one at a time and scores each with an L1 term plus 0.2 x (1 - CLIP
+    similarity) from a downloaded ViT-B/32.  Here the azimuths are rendered in batches by the alpha-output rasteriser
+    variant, the bounding boxes come from the alpha masks on the device, and the score's CLIP term is a callback:
+    `clip_score(image (3,512,512) in [0,1], canonical_image) -> similarity`; with None (no CLIP weights on this machine) the
+    score is the L1 term alone."""
+    renderer = static_vae.renderers["MipGS"]
+    renderer.pipe.use_mip_gaussian = False                                       # :50
+    azimuths = np.arange(-180, 180, 1) if in_the_wild else np.arange(-180, 180, 90)
+    cams = azimuth_cameras(azimuths).to(device)
+    canonical_image = canonical_image.to(device)
+    cmask = (canonical_alpha.to(device) > 0.5)
+    canonical_size = int(_mask_extent(cmask[None])[0])
+    best = (1e8, 0, 1.0)
+    if canonical_size >= 0:
+        K = intrinsics.to(device)
+        for s0 in range(0, len(azimuths), chunk_frames):
+            out = renderer.render_frames(static_gs_model, cams[s0:s0 + chunk_frames], K, want_alpha_depth=True)
+            sizes = _mask_extent(out.alpha > 0.5).tolist()
+            for k, rendered_size in enumerate(sizes):
+                if rendered_size < 0:
+                    continue                                                      # nothing visible from here (:66-67)
+                scale_factor = canonical_size / rendered_size if rendered_size > 0 else float("inf")
+                if not math.isfinite(scale_factor):
+                    continue
+                target = int(512 * scale_factor)
+                if target < 1 or target > 8192:
+                    continue
+                image = F.interpolate(out.rgb[k].clamp(0.0, 1.0)[None], size=(target, target), mode="bicubic", align_corners=False)[0]
+                if target < 512:
+                    p = max(0, (512 - target) // 2)
+                    image = F.pad(image, (p, 512 - target - p, p, 512 - target - p), mode="constant", value=1.0)
+                else:
+                    o = (target - 512) // 2
+                    image = image[:, o:o + 512, o:o + 512]
+                image = image.clamp(0.0, 1.0)
+                diff = float((image - canonical_image).abs().mean())
+                if clip_score is not None:
+                    diff += (1.0 - float(clip_score(image, canonical_image))) * 0.2
+                if diff < best[0]:
+                    best = (diff, int(azimuths[s0 + k]), float(scale_factor))
+    _, best_azi, best_scale_factor = best
+    print(f"\nID: {id} \tBest azimuth: {best_azi} \tBest scale factor: {best_scale_factor}")
+    a = math.radians(-best_azi)
+    rot = torch.tensor([[math.cos(a), -math.sin(a), 0], [math.sin(a), math.cos(a), 0], [0, 0, 1]], device=device, dtype=torch.float32)
+    static_gs_model.from_xyz((rot @ static_gs_model.get_xyz.T).T)
+    static_gs_model.from_rotation(matrix_to_quaternion(rot @ build_rotation(static_gs_model.get_rotation).to(device)))
+    return static_gs_model, best_scale_factor
 
 
 def frame_schedule(n_timesteps: int, n_views: int) -> List[Tuple[int, int]]:

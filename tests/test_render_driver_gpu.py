@@ -112,3 +112,61 @@ def test_render_and_save_images_writes_the_reference_files(cuda, tmp_path):
         d = np.abs(got.astype(int) - np.asarray(want).astype(int))
         assert d.max() <= 2 and (d > 0).mean() < 0.02, (d.max(), (d > 0).mean())       # fused vs torch activations: rare 1-step flips
     del full
+
+
+def test_matrix_to_quaternion_round_trip():
+    from gvfdiffusion_amd.utils.inference_utils import build_rotation, matrix_to_quaternion
+    q = torch.randn(500, 4, generator=torch.Generator().manual_seed(0))
+    R = build_rotation(q)
+    q2 = matrix_to_quaternion(R)
+    assert (build_rotation(q2) - R).abs().max() < 2e-6 and (q2[:, 0] >= 0).all() and (q2.norm(dim=1) - 1).abs().max() < 1e-6
+    half = torch.tensor([[0.0, 1.0, 0.0, 0.0], [0.0, 0.0, 0.0, 1.0]])              # 180-degree turns: real part 0
+    assert (build_rotation(matrix_to_quaternion(build_rotation(half))) - build_rotation(half)).abs().max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_align_gaussian_to_canonical_recovers_a_known_azimuth(cuda):
+    """utils/inference_utils.py:38-178 without its CLIP term: an asymmetric object seen from azimuth 37 (zoomed by 1.2) as the
+    canonical view -> best azimuth 37, scale factor ~1.2, and the turned model looks like the canonical view from the front."""
+    from types import SimpleNamespace
+    from gvfdiffusion_amd.attrdict import edict
+    from gvfdiffusion_amd.renderers import GaussianRenderer
+    from gvfdiffusion_amd.utils.inference_utils import align_gaussian_to_canonical, azimuth_cameras, build_rotation
+    P = 6000
+    g = torch.Generator().manual_seed(5)
+    attrs = synthetic.random_gaussians(P, sh_degree=0, seed=13, scale_lo=0.006, scale_hi=0.015)
+    xyz = (torch.rand(P, 3, generator=g) - 0.5) * torch.tensor([0.5, 0.12, 0.35])         # a slab ...
+    xyz[: P // 3] = (torch.rand(P // 3, 3, generator=g) - 0.5) * torch.tensor([0.1, 0.3, 0.1]) + torch.tensor([0.2, 0.2, 0.1])  # ... with a fin
+    attrs["means3D"] = xyz
+    attrs["shs"][: P // 3] = 1.5
+    attrs["opacities"] = attrs["opacities"].clamp(min=0.6)
+    gm = synthetic.gaussian_model_from(attrs, 0, cuda)
+    rend = GaussianRenderer({"resolution": 512, "near": synthetic.NEAR, "far": synthetic.FAR, "bg_color": (1, 1, 1)})
+    rend.pipe.kernel_size = synthetic.KERNEL_2D
+    K = synthetic.intrinsics().to(cuda)
+    Kz = K.clone(); Kz[0, 0] *= 1.2; Kz[1, 1] *= 1.2                                     # the canonical photo is closer
+    with torch.no_grad():
+        canon = rend.render_frames(gm, azimuth_cameras([37]).to(cuda), Kz, want_alpha_depth=True)
+    xyz0, cov0 = gm.get_xyz.clone(), gm.get_covariance().clone()
+    vae = SimpleNamespace(renderers=edict({"MipGS": rend}))
+    model, scale = align_gaussian_to_canonical(gm, canon.rgb[0].clamp(0, 1), canon.alpha[0], K, vae, id=0, device=cuda, in_the_wild=True)
+    assert model is gm and abs(scale - 1.2) < 0.04, scale
+    a = np.radians(-37.0)
+    R = torch.tensor([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], dtype=torch.float32, device=cuda)
+    assert (gm.get_xyz - xyz0 @ R.T).abs().max() < 1e-5                                   # positions turned by -37 degrees about z
+    S6 = lambda c: torch.stack([c[:, 0], c[:, 1], c[:, 2], c[:, 1], c[:, 3], c[:, 4], c[:, 2], c[:, 4], c[:, 5]], 1).reshape(-1, 3, 3)
+    want = R @ S6(cov0) @ R.T
+    assert (S6(gm.get_covariance()) - want).abs().max() < 1e-6 + 1e-3 * float(want.abs().max())   # ... and so did the covariances
+    with torch.no_grad():
+        front = rend.render_frames(gm, azimuth_cameras([0]).to(cuda), Kz).rgb[0]
+    mse = float(((front.clamp(0, 1) - canon.rgb[0].clamp(0, 1)) ** 2).mean())
+    assert 10 * np.log10(1.0 / max(mse, 1e-12)) > 35.0
+    # the coarse search (4 azimuths) picks the closest quarter turn
+    gm2 = synthetic.gaussian_model_from(attrs, 0, cuda)
+    with torch.no_grad():
+        canon2 = rend.render_frames(gm2, azimuth_cameras([-90]).to(cuda), K, want_alpha_depth=True)
+    xyz2 = gm2.get_xyz.clone()
+    align_gaussian_to_canonical(gm2, canon2.rgb[0].clamp(0, 1), canon2.alpha[0], K, vae, id=1, device=cuda, in_the_wild=False)
+    a = np.radians(90.0)
+    R2 = torch.tensor([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], dtype=torch.float32, device=cuda)
+    assert (gm2.get_xyz - xyz2 @ R2.T).abs().max() < 1e-5
