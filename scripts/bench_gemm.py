@@ -31,3 +31,14 @@ for name, N, K, epi in (("to_qkv", 1536, 512, 0), ("to_q", 512, 512, 0), ("to_ou
     us_t = timeit(lambda: torch.matmul(a, w.t()))
     fl = 2.0 * M * N * K
     print(f"{name:14s} N={N:5d} K={K:5d}: gvf {us:7.1f} us {fl/us/1e6:7.1f} TF/s {byts/us/1e3:6.0f} GB/s | torch.matmul (bf16 out, no epilogue) {us_t:7.1f} us {fl/us_t/1e6:7.1f} TF/s")
+
+# fixed cost vs per-k-step cost of the N = 512 projections: sweep K
+print("K sweep, N = 512 (us):  K  store_bf16  resid_f32")
+for K in (64, 128, 256, 512, 1024, 2048):
+    a, w = rn(M, K), rn(512, K)
+    bias = torch.randn(512, generator=g).to(dev)
+    o16 = torch.empty((M, 512), dtype=torch.bfloat16, device=dev)
+    o32 = torch.randn((M, 512), generator=g).to(dev)
+    t0 = timeit(lambda: dit_ops.gemm_bf16(a, w, bias, o16, 0))
+    t3 = timeit(lambda: dit_ops.gemm_bf16(a, w, bias, o32, 3))
+    print(f"  K={K:5d}  {t0:7.1f}  {t3:7.1f}")
