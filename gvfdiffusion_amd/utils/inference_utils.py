@@ -232,7 +232,7 @@ def render_and_save_images(args, static_vae, static_gs_model, pred_delta, model_
     dev = accelerator.device
     intrinsics = model_kwargs["cams"]["intrinsics"][0][0].to(dev)
     rank = getattr(accelerator, "process_index", 0)
-    written = []
+    written, pending = [], []
 
     def save(arr, path):
         Image.fromarray(arr).save(path)
@@ -246,6 +246,8 @@ def render_and_save_images(args, static_vae, static_gs_model, pred_delta, model_
                 host = frames.permute(0, 2, 3, 1).contiguous().cpu().numpy()          # one transfer per chunk
                 for k, (t, c) in enumerate(part):
                     path = os.path.join(s_path, f"rank_{rank:02d}_render_{img_id + b:06d}_cam_{c:03d}_timesteps_{t:02d}.png")
-                    pool.submit(save, host[k], path)
+                    pending.append(pool.submit(save, host[k], path))
                     written.append(path)
+        for f in pending:
+            f.result()                                     # a failed write raises here instead of disappearing
     return written
