@@ -1,10 +1,12 @@
 """Sparse-voxel side of the path (secondary rows SP1-SP5): the SparseTensor container,
 vox2seq voxel serialisation, the full / windowed / serialized sparse attention operators and the row-wise layers
-(SparseLinear, activations) the static-VAE backbone is made of."""
+(SparseLinear, activations, norms, down / up-sampling) of the reference's `sparse/` package."""
 from . import vox2seq  # noqa: F401
 from .basic import *   # noqa: F401,F403
 from .linear import SparseLinear  # noqa: F401
 from .nonlinearity import *  # noqa: F401,F403
+from .norm import *  # noqa: F401,F403
+from .spatial import *  # noqa: F401,F403
 
 
 def __getattr__(name):

@@ -525,7 +525,37 @@ def gen_slat_decoder():
     np.savez_compressed(os.path.join(OUT, "slat_decoder_golden.npz"), **out)
 
 
-SECTIONS = {"slat_decoder": gen_slat_decoder, "sparse_vae": gen_sparse_vae, "vae_encode": gen_vae_encode, "vae": gen_vae, "raster": gen_raster, "vox2seq": gen_vox2seq, "dit": gen_dit, "sampler": gen_sampler, "sparse": gen_sparse}
+def gen_sparse_layers():
+    """sparse/norm.py, sparse/spatial.py of the reference on a small ragged batch (no spconv op executed)."""
+    _svae_stubs()
+    import sparse as sp
+    g = torch.Generator().manual_seed(41)
+    coords = []
+    for b, n in enumerate((60, 45)):
+        c = torch.unique(torch.randint(0, 8, (n * 2, 3), generator=g), dim=0)
+        c = c[torch.randperm(c.shape[0], generator=g)[:n]]
+        c = c[torch.argsort(c[:, 0] * 64 + c[:, 1] * 8 + c[:, 2])]
+        coords.append(torch.cat([torch.full((c.shape[0], 1), b), c], dim=1))
+    coords = torch.cat(coords).int()
+    feats = torch.randn((coords.shape[0], 12), generator=g)
+    x = sp.SparseTensor(feats, coords)
+    out = {"coords": coords.numpy(), "feats": feats.numpy()}
+    gn = sp.SparseGroupNorm(3, 12)
+    with torch.no_grad():
+        gn.weight.copy_(torch.randn(12, generator=g)); gn.bias.copy_(torch.randn(12, generator=g))
+        out["gn_w"], out["gn_b"], out["gn_out"] = gn.weight.numpy().copy(), gn.bias.numpy().copy(), gn(x).feats.numpy()
+        for tag, f in (("2", 2), ("211", (2, 1, 1))):
+            d = sp.SparseDownsample(f)(x)
+            out[f"down{tag}_coords"], out[f"down{tag}_feats"] = d.coords.numpy(), d.feats.numpy()
+            u = sp.SparseUpsample(f)(d)
+            out[f"up{tag}_coords"], out[f"up{tag}_feats"] = u.coords.numpy(), u.feats.numpy()
+        s = sp.SparseSubdivide()(x)
+        out["sub_coords"], out["sub_feats"] = s.coords.numpy(), s.feats.numpy()
+    np.savez_compressed(os.path.join(OUT, "sparse_layers_golden.npz"), **out)
+    print("sparse_layers_golden.npz", {k: v.shape for k, v in out.items()})
+
+
+SECTIONS = {"sparse_layers": gen_sparse_layers, "slat_decoder": gen_slat_decoder, "sparse_vae": gen_sparse_vae, "vae_encode": gen_vae_encode, "vae": gen_vae, "raster": gen_raster, "vox2seq": gen_vox2seq, "dit": gen_dit, "sampler": gen_sampler, "sparse": gen_sparse}
 
 if __name__ == "__main__":
     install_stubs()

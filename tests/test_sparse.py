@@ -161,3 +161,27 @@ def test_sparse_multi_head_attention_module(cuda):
     cross = SparseMultiHeadAttention(128, 4, ctx_channels=64, type="cross").to(cuda)
     ctx = torch.randn((3, 20, 64)).to(cuda)
     assert cross(x, ctx).feats.shape == (coords.shape[0], 128)
+
+
+def test_sparse_norm_and_spatial_layers_match_the_reference():
+    """sparse/norm.py:12-27, sparse/spatial.py:13-110 on a ragged two-sample batch: outputs of the reference's own classes
+    (tests/golden/make_golden.py::gen_sparse_layers).  Container-level torch plumbing: runs wherever the tensors live."""
+    import os
+    import numpy as np
+    from gvfdiffusion_amd import sparse as sp
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "sparse_layers_golden.npz"))
+    x = sp.SparseTensor(torch.from_numpy(z["feats"]), torch.from_numpy(z["coords"]))
+    gn = sp.SparseGroupNorm(3, 12)
+    with torch.no_grad():
+        gn.weight.copy_(torch.from_numpy(z["gn_w"])); gn.bias.copy_(torch.from_numpy(z["gn_b"]))
+        assert np.abs(gn(x).feats.numpy() - z["gn_out"]).max() < 1e-5
+        for tag, f in (("2", 2), ("211", (2, 1, 1))):
+            d = sp.SparseDownsample(f)(x)
+            assert np.array_equal(d.coords.numpy(), z[f"down{tag}_coords"]) and np.abs(d.feats.numpy() - z[f"down{tag}_feats"]).max() < 1e-6
+            u = sp.SparseUpsample(f)(d)
+            assert np.array_equal(u.coords.numpy(), z[f"up{tag}_coords"]) and np.abs(u.feats.numpy() - z[f"up{tag}_feats"]).max() < 1e-6
+            assert u.layout == x.layout
+        s = sp.SparseSubdivide()(x)
+        assert np.array_equal(s.coords.numpy(), z["sub_coords"]) and np.array_equal(s.feats.numpy(), z["sub_feats"])
+    with pytest.raises(ValueError):
+        sp.SparseUpsample(4)(x)
