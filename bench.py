@@ -338,10 +338,26 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    # GVF_BENCH_FORCE_DIST=1: take the N > 1 code path (RCCL init, frame all-gather on the side stream, reductions) with a
+    # single rank -- the only way to execute it on a one-GPU box
+    multi = world > 1 or os.environ.get("GVF_BENCH_FORCE_DIST") == "1"
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        # the image exports NCCL_DEBUG=VERSION and RCCL printf()s its banner to stdout when the communicator is created:
+        # point fd 1 at stderr while that happens, so that stdout carries the one JSON line only
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=dev)
+            warm = torch.zeros(1, device=dev)
+            dist.all_reduce(warm)                      # forces communicator creation now
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     if a.dit_only:
         print(json.dumps(bench_dit(dev)))
@@ -354,15 +370,15 @@ def main():
     F, S = a.frames, a.res
 
     # frame exchange (N > 1): uint8 frames, one all-gather per step on a side stream
-    side = torch.cuda.Stream(device=dev) if world > 1 else None
-    u8 = [torch.empty((F, 3, S, S), dtype=torch.uint8, device=dev) for _ in range(2)] if world > 1 else None
-    gathered = [torch.empty((world * F, 3, S, S), dtype=torch.uint8, device=dev) for _ in range(2)] if world > 1 else None
-    ready = [torch.cuda.Event() for _ in range(2)] if world > 1 else None
-    consumed = [torch.cuda.Event() for _ in range(2)] if world > 1 else None
+    side = torch.cuda.Stream(device=dev) if multi else None
+    u8 = [torch.empty((F, 3, S, S), dtype=torch.uint8, device=dev) for _ in range(2)] if multi else None
+    gathered = [torch.empty((world * F, 3, S, S), dtype=torch.uint8, device=dev) for _ in range(2)] if multi else None
+    ready = [torch.cuda.Event() for _ in range(2)] if multi else None
+    consumed = [torch.cuda.Event() for _ in range(2)] if multi else None
 
     def step(i):
         work.step()
-        if world > 1:
+        if multi:
             b = i & 1
             torch.cuda.current_stream().wait_event(consumed[b])           # buffer b free again
             work.R.frames_to_uint8(work.color, out=u8[b])
@@ -373,11 +389,11 @@ def main():
                 consumed[b].record(side)
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
-    if world > 1:
+    if multi:
         for e in consumed:
             e.record()
     for i in range(a.warmup):
@@ -395,7 +411,7 @@ def main():
     _lib.lib().gvf_rast_profile_enable(0)
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if multi:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
@@ -434,17 +450,17 @@ def main():
                                   "achieved_GBs": round(work.alg_bytes_frame() / gpu_frame_s / 1e9, 2) if gpu_frame_s else 0,
                                   "frac": round(work.alg_bytes_frame() / gpu_frame_s / 1e9 / HBM_PEAK_GBS, 5) if gpu_frame_s else 0},
         }
-        if world == 1 and not a.no_dit:
+        if not multi and not a.no_dit:
             del work.ws
             torch.cuda.empty_cache()
             out["differentiable_render"] = bench_backward(dev, work.attrs, a.res, a.sh_degree)
             out["dit"] = bench_dit(dev)
             torch.cuda.empty_cache()
             out["end_to_end"] = bench_e2e(dev, a.gaussians, a.res, a.frames)
-        if world == 1 and not a.no_cpu_baseline:
+        if not multi and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(work)
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 
