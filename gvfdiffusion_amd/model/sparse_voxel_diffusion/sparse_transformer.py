@@ -19,7 +19,7 @@ from ...sparse.attention.modules import SparseMultiHeadAttention
 from ...sparse.attention.serialized_attn import SerializeMode, SerializeModes, calc_serialization
 from ...sparse.attention.windowed_attn import calc_window_partition
 
-__all__ = ["block_attn_config", "AbsolutePositionEmbedder", "SparseFeedForward", "SparseTransformerBlock"]
+__all__ = ["block_attn_config", "AbsolutePositionEmbedder", "SparseFeedForward", "SparseTransformerBlock", "edge_weights", "run_torso", "build_blocks"]
 
 
 def block_attn_config(self):
@@ -162,3 +162,34 @@ class SparseTransformerBlock(nn.Module):
     def forward(self, x: sp.SparseTensor, c: torch.Tensor = None) -> sp.SparseTensor:
         rows = x.feats.float().contiguous().clone()
         return x.replace(self.forward_rows(rows, x).to(x.dtype))
+
+
+def edge_weights(lin: nn.Linear):
+    """(weight as bf16 with K zero-padded to a multiple of 64, fp32 bias) of an input / output layer."""
+    return (dit_ops.cast_pad_bf16(lin.weight.detach().float().contiguous(), dit_ops.pad64(lin.in_features)),
+            lin.bias.detach().float().contiguous())
+
+
+@torch.no_grad()
+def run_torso(st: sp.SparseTensor, rows: torch.Tensor, w_in, pos_embedder, blocks, channels: int) -> torch.Tensor:
+    """rows (T, K) of `st` -> fp32 residual stream (T, channels) after  rows @ W_in^T + b (+ position embedding)  and every block.
+    The embedding is written first and the input GEMM accumulates onto it (residual epilogue)."""
+    T = rows.shape[0]
+    if pos_embedder is not None:
+        x = pos_embedder(st.coords[:, 1:]).float().contiguous()
+    else:
+        x = torch.zeros((T, channels), dtype=torch.float32, device=rows.device)
+    a = dit_ops.cast_pad_bf16(rows.float().contiguous(), w_in[0].shape[1])
+    dit_ops.gemm_bf16(a, *w_in, x, dit_ops.EPI_RESID_F32)
+    for blk in blocks:
+        blk.forward_rows(x, st)
+    return x
+
+
+def build_blocks(owner, channels: int, num_heads: int, mlp_ratio: float, use_checkpoint: bool = False, **block_kw) -> nn.ModuleList:
+    """One unmodulated SparseTransformerBlock per entry of block_attn_config(owner) (owner: num_blocks, attn_mode, window_size)."""
+    return nn.ModuleList([
+        SparseTransformerBlock(channels, num_heads=num_heads, mlp_ratio=mlp_ratio, attn_mode=mode, window_size=window,
+                               shift_sequence=shift_seq, shift_window=shift_win, serialize_mode=order, use_checkpoint=use_checkpoint,
+                               modulated=False, use_rope=False, **block_kw)
+        for mode, window, shift_seq, shift_win, order in block_attn_config(owner)])

@@ -15,7 +15,7 @@ import torch.nn as nn
 from ... import sparse as sp
 from ..._lib import require_cuda
 from ...ops import dit_ops
-from .sparse_transformer import AbsolutePositionEmbedder, SparseTransformerBlock, block_attn_config
+from .sparse_transformer import AbsolutePositionEmbedder, build_blocks, edge_weights, run_torso
 
 __all__ = ["SparseTransformerVAE"]
 
@@ -46,11 +46,7 @@ class SparseTransformerVAE(nn.Module):
             raise NotImplementedError("RoPE is not built (the released static VAE uses pe_mode='ape')")
 
         def blocks():
-            return nn.ModuleList([
-                SparseTransformerBlock(model_channels, num_heads=self.num_heads, mlp_ratio=self.mlp_ratio, attn_mode=mode,
-                                       window_size=ws, shift_sequence=shift_seq, shift_window=shift_win, serialize_mode=ser,
-                                       use_checkpoint=use_checkpoint, modulated=False, use_rope=False, use_old_attn_impl=use_old_attn_impl)
-                for mode, ws, shift_seq, shift_win, ser in block_attn_config(self)])
+            return build_blocks(self, model_channels, self.num_heads, self.mlp_ratio, use_checkpoint, use_old_attn_impl=use_old_attn_impl)
 
         self.input_layer = sp.SparseLinear(in_channels, model_channels)
         self.encoder = blocks()
@@ -91,22 +87,14 @@ class SparseTransformerVAE(nn.Module):
         ver = tuple((p.data_ptr(), p._version) for lin in edge for p in lin.parameters())
         if self._wcache is not None and self._wcache[0] == ver:
             return self._wcache[1]
-        W = {}
-        for name, lin in zip(("input", "to_latent", "from_latent", "out"), edge):
-            W[name] = (dit_ops.cast_pad_bf16(lin.weight.detach().float().contiguous(), dit_ops.pad64(lin.in_features)),
-                       lin.bias.detach().float().contiguous())
+        W = {name: edge_weights(lin) for name, lin in zip(("input", "to_latent", "from_latent", "out"), edge)}
         self._wcache = (ver, W)
         return W
 
     def _torso(self, st: sp.SparseTensor, rows: torch.Tensor, w_in, blocks, w_out) -> torch.Tensor:
         """rows fp32 (T, K) -> edge GEMM (+ APE) -> blocks -> [LayerNorm] -> edge GEMM: fp32 (T, N_out)."""
-        T = rows.shape[0]
-        C = self.model_channels
-        x = self.pos_embedder(st.coords[:, 1:]).float().contiguous() if self.pe_mode == "ape" else torch.zeros((T, C), device=rows.device)
-        a = dit_ops.cast_pad_bf16(rows.float().contiguous(), w_in[0].shape[1])
-        dit_ops.gemm_bf16(a, *w_in, x, dit_ops.EPI_RESID_F32)                       # x = APE + rows @ W^T + b
-        for blk in blocks:
-            blk.forward_rows(x, st)
+        T, C = rows.shape[0], self.model_channels
+        x = run_torso(st, rows, w_in, self.pos_embedder if self.pe_mode == "ape" else None, blocks, C)
         if self.norm_output:                                                       # F.layer_norm default eps (:166,194)
             hb = torch.empty((T, C), dtype=torch.bfloat16, device=rows.device)
             dit_ops.layernorm_modulate_bf16(x, hb, 1e-5)

@@ -10,7 +10,7 @@ import torch
 
 from ...attrdict import edict
 from ...renderers import GaussianRenderer
-from ...representations.gaussian import GaussianModel
+from ...representations.gaussian.voxel_rows import gaussian_row_layout, rows_to_gaussian
 
 __all__ = ["SparseVAE", "hammersley_sequence"]
 
@@ -76,17 +76,10 @@ class SparseVAE:
         return torch.atanh(offsets).to(_unwrap(self.backbones["vae"]).device)
 
     def _calc_layout(self, rep_config):
-        self.layouts = {}
-        start = 0
-        for k, v in rep_config.items():
-            n = v["num_gaussians"]
-            lay = {"_xyz": {"shape": (n, 3), "size": n * 3}, "_features_dc": {"shape": (n, 1, 3), "size": n * 3},
-                   "_scaling": {"shape": (n, 3), "size": n * 3}, "_rotation": {"shape": (n, 4), "size": n * 4},
-                   "_opacity": {"shape": (n, 1), "size": n}}
-            for vv in lay.values():
-                vv["range"] = (start, start + vv["size"])
-                start += vv["size"]
-            self.layouts[k] = lay
+        self.layouts, start = {}, 0
+        for kind, cfg in rep_config.items():                 # channel ranges run on across the representation kinds (:202-227)
+            self.layouts[kind] = gaussian_row_layout(cfg["num_gaussians"], start)
+            start = self.layouts[kind]["_opacity"]["range"][1]
         self.layouts = edict(self.layouts)
 
     def get_renderer(self, type, rendering_options):
@@ -105,26 +98,18 @@ class SparseVAE:
     def to_representation(self, x):
         """(N x * x C) sparse output rows -> {kind: [GaussianModel per sample]}  (:114-182)."""
         ret = {k: [] for k in self.rep_config.keys()}
-        for i in range(x.shape[0]):
-            rows = x.feats[x.layout[i]]
-            xyz = (x.coords[x.layout[i]][:, 1:].float() + 0.5) / self.resolution
+        vae = _unwrap(self.backbones["vae"])
+        for sl in x.layout:
             for kind, cfg in self.rep_config.items():
-                rep = GaussianModel(sh_degree=0, aabb=[-0.5, -0.5, -0.5, 1.0, 1.0, 1.0],
-                                    mininum_kernel_size=cfg.get("3d_filter_kernel_size", 0.0) if kind == "MipGS" else 0.0,
-                                    scaling_bias=cfg["scaling_bias"], opacity_bias=cfg["opacity_bias"],
-                                    scaling_activation=cfg["scaling_activation"], device=rows.device)
-                for k, v in self.layouts[kind].items():
-                    f = rows[:, v["range"][0]:v["range"][1]].reshape(-1, *v["shape"]) * cfg["lr"][k]
-                    if k == "_xyz":
-                        if cfg["perturb_offset"]:
-                            f = f + getattr(_unwrap(self.backbones["vae"]), f"{kind}_perturbation")
-                        if cfg["reg_mode"] == "invoxel":
-                            f = torch.tanh(f) / self.resolution
-                        elif cfg["reg_mode"] == "soft_invoxel":
-                            f = torch.tanh(f) / self.resolution * 0.5 * (cfg["voxel_size"] if kind == "MipGS" else 1.25)
-                        f = xyz.unsqueeze(1) + f
-                    setattr(rep, k, f.flatten(0, 1))
-                ret[kind].append(rep)
+                # offsets: tanh / resolution inside the voxel ("invoxel"), or half a `voxel_size` ("soft_invoxel"; the GS kind
+                # hard-codes 1.25 there, :139)
+                scale = {"invoxel": 1.0, "soft_invoxel": 0.5 * (cfg["voxel_size"] if kind == "MipGS" else 1.25)}.get(cfg["reg_mode"])
+                if scale is None:
+                    raise ValueError(f"unknown reg_mode {cfg['reg_mode']}")
+                kw = dict(mininum_kernel_size=cfg.get("3d_filter_kernel_size", 0.0) if kind == "MipGS" else 0.0,
+                          scaling_bias=cfg["scaling_bias"], opacity_bias=cfg["opacity_bias"], scaling_activation=cfg["scaling_activation"])
+                ret[kind].append(rows_to_gaussian(x.feats[sl], x.coords[sl][:, 1:], self.resolution, self.layouts[kind], cfg["lr"], scale,
+                                                  getattr(vae, f"{kind}_perturbation") if cfg["perturb_offset"] else None, kw))
         return ret
 
     def render_batch(self, reps, extrinsics: torch.Tensor, intrinsics: torch.Tensor):

@@ -1,6 +1,11 @@
-"""SparseMultiHeadRMSNorm / SparseMultiHeadAttention with the reference's constructor and parameter names
-(model/sparse_attention/modules.py:56-185; the stray debug prints at :152,154 are not reproduced).
-Projections run on the bf16 MFMA GEMM, attention on the varlen flash kernel; RoPE is not built."""
+"""Multi-head attention over SparseTensors (or dense (B, L, C) tensors) with the constructor surface and parameter names of
+the reference's model/sparse_attention/modules.py:56-185, so its state dicts load unchanged:
+`to_qkv` | (`to_q`, `to_kv`), `to_out`, `q_rms_norm.gamma` / `k_rms_norm.gamma`.
+
+How a call runs here: the projections are the bf16 MFMA GEMM (fp32 accumulate, fp32 bias), the channels are viewed as
+[q|k|v][head][c] (or, with `use_old_attn_impl`, the older [head][q|k|v][c] of sparse/attention/modules.py:150-162), and the
+token lists go to the varlen flash kernel directly or after the window / serialisation gather.  QK-RMSNorm is not a separate
+pass: the per-head gains are handed to the kernel, which normalises q and k in its prologue.  RoPE is not built."""
 from typing import *
 
 import torch
@@ -8,28 +13,36 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..basic import SparseTensor
-from .full_attn import sparse_scaled_dot_product_attention, packed_varlen_attention
-from .serialized_attn import SerializeMode, sparse_serialized_scaled_dot_product_self_attention
-from .windowed_attn import sparse_windowed_scaled_dot_product_self_attention
-from ...ops import dit_ops
+from ..linear import linear_rows
+from .full_attn import packed_varlen_attention
+from .serialized_attn import SerializeMode, calc_serialization
+from .windowed_attn import calc_window_partition
 
 __all__ = ["SparseMultiHeadRMSNorm", "SparseMultiHeadAttention"]
 
+Tokens = Union[SparseTensor, torch.Tensor]
+
 
 class SparseMultiHeadRMSNorm(nn.Module):
+    """x / |x| * gamma[head] * sqrt(dim) over the last axis, computed in fp32 (modules.py:56-69).  Holds the gains; inside
+    SparseMultiHeadAttention the attention kernel applies them."""
+
     def __init__(self, dim: int, heads: int):
         super().__init__()
         self.scale = dim ** 0.5
         self.gamma = nn.Parameter(torch.ones(heads, dim))
 
-    def forward(self, x: Union[SparseTensor, torch.Tensor]) -> Union[SparseTensor, torch.Tensor]:
-        x_type = x.dtype
-        x = x.float()
-        if isinstance(x, SparseTensor):
-            x = x.replace(F.normalize(x.feats, dim=-1))
-        else:
-            x = F.normalize(x, dim=-1)
-        return (x * self.gamma * self.scale).to(x_type)
+    def forward(self, x: Tokens) -> Tokens:
+        f = x.feats if isinstance(x, SparseTensor) else x
+        y = (F.normalize(f.float(), dim=-1) * self.gamma * self.scale).to(f.dtype)
+        return x.replace(y) if isinstance(x, SparseTensor) else y
+
+
+def _rows(x: Tokens) -> Tuple[torch.Tensor, List[int]]:
+    """-> (token rows (T, C), tokens per batch element)."""
+    if isinstance(x, SparseTensor):
+        return x.feats, [s.stop - s.start for s in x.layout]
+    return x.reshape(-1, x.shape[-1]), [x.shape[1]] * x.shape[0]
 
 
 class SparseMultiHeadAttention(nn.Module):
@@ -40,88 +53,83 @@ class SparseMultiHeadAttention(nn.Module):
                  serialize_mode: Optional[SerializeMode] = None, qkv_bias: bool = True, use_rope: bool = False,
                  qk_rms_norm: bool = False, use_old_attn_impl: bool = False):
         super().__init__()
-        assert channels % num_heads == 0
-        assert type in ["self", "cross"], f"Invalid attention type: {type}"
-        assert attn_mode in ["full", "serialized", "windowed"], f"Invalid attention mode: {attn_mode}"
-        assert type == "self" or attn_mode == "full", "Cross-attention only supports full attention"
-        assert type == "self" or use_rope is False, "Rotary position embeddings only supported for self-attention"
+        if channels % num_heads:
+            raise AssertionError("channels must be a multiple of num_heads")
+        if type not in ("self", "cross"):
+            raise AssertionError(f"Invalid attention type: {type}")
+        if attn_mode not in ("full", "serialized", "windowed"):
+            raise AssertionError(f"Invalid attention mode: {attn_mode}")
+        if type == "cross" and attn_mode != "full":
+            raise AssertionError("Cross-attention only supports full attention")
         if use_rope:
             raise NotImplementedError("RoPE is not built")
-        self.channels = channels
-        self.ctx_channels = ctx_channels if ctx_channels is not None else channels
-        self.num_heads = num_heads
-        self._type = type
-        self.attn_mode = attn_mode
-        self.window_size = window_size
-        self.shift_sequence = shift_sequence
-        self.shift_window = shift_window
+        self.channels, self.num_heads = channels, num_heads
+        self.ctx_channels = channels if ctx_channels is None else ctx_channels
+        self._type, self.attn_mode = type, attn_mode
+        self.window_size, self.shift_sequence, self.shift_window = window_size, shift_sequence, shift_window
         self.serialize_mode = serialize_mode
-        self.use_rope = use_rope
-        self.qk_rms_norm = qk_rms_norm
-        self.use_old_attn_impl = use_old_attn_impl
-        if self._type == "self":
-            self.to_qkv = nn.Linear(channels, channels * 3, bias=qkv_bias)
+        self.use_rope, self.qk_rms_norm, self.use_old_attn_impl = use_rope, qk_rms_norm, use_old_attn_impl
+        if type == "self":
+            self.to_qkv = nn.Linear(channels, 3 * channels, bias=qkv_bias)
         else:
             self.to_q = nn.Linear(channels, channels, bias=qkv_bias)
-            self.to_kv = nn.Linear(self.ctx_channels, channels * 2, bias=qkv_bias)
-        if self.qk_rms_norm:
+            self.to_kv = nn.Linear(self.ctx_channels, 2 * channels, bias=qkv_bias)
+        if qk_rms_norm:
             self.q_rms_norm = SparseMultiHeadRMSNorm(channels // num_heads, num_heads)
             self.k_rms_norm = SparseMultiHeadRMSNorm(channels // num_heads, num_heads)
         self.to_out = nn.Linear(channels, channels)
 
-    @staticmethod
-    def _linear(lin: nn.Linear, x: torch.Tensor) -> torch.Tensor:
-        """x (T, K) any float dtype -> (T, N) fp32 through the bf16 MFMA GEMM."""
-        xb = dit_ops.cast_pad_bf16(x.float().contiguous(), dit_ops.pad64(x.shape[1]))
-        wb = dit_ops.cast_pad_bf16(lin.weight.detach().float().contiguous(), dit_ops.pad64(x.shape[1]))
-        out = torch.empty((x.shape[0], lin.out_features), dtype=torch.float32, device=x.device)
-        bias = None if lin.bias is None else lin.bias.detach().float().contiguous()
-        return dit_ops.gemm_bf16(xb, wb, bias, out, dit_ops.EPI_STORE_F32)
-
-    def _project(self, lin, x):
-        if isinstance(x, SparseTensor):
-            return x.replace(self._linear(lin, x.feats).to(x.dtype))
-        return self._linear(lin, x.reshape(-1, x.shape[-1])).reshape(*x.shape[:-1], -1).to(x.dtype)
-
-    def _fused_pre(self, x, num_fused: int):
-        """channels -> [num_fused, H, C]; the old implementation stored them [H, num_fused, C] (modules.py:150-162)."""
-        H = self.num_heads
-        f = x.feats.unsqueeze(0) if isinstance(x, SparseTensor) else x
+    # ---- pieces ------------------------------------------------------------------------------------------------------
+    def _split(self, rows: torch.Tensor, parts: int) -> List[torch.Tensor]:
+        """(T, parts * channels) projection output -> `parts` views (T, H, c) in the configured channel layout."""
+        T, H = rows.shape[0], self.num_heads
         if self.use_old_attn_impl:
-            f = torch.stack(f.reshape(*f.shape[:2], H, -1).chunk(num_fused, dim=-1), dim=2)
-        else:
-            f = f.reshape(*f.shape[:2], num_fused, H, -1)
-        return x.replace(f.squeeze(0)) if isinstance(x, SparseTensor) else f
+            return list(rows.reshape(T, H, parts, -1).unbind(dim=2))
+        return list(rows.reshape(T, parts, H, -1).unbind(dim=1))
 
-    def forward(self, x: Union[SparseTensor, torch.Tensor], context: Optional[Union[SparseTensor, torch.Tensor]] = None):
-        H = self.num_heads
+    def _gains(self):
+        if not self.qk_rms_norm:
+            return None, None
+        return self.q_rms_norm.gamma.detach().float().contiguous(), self.k_rms_norm.gamma.detach().float().contiguous()
+
+    def _token_order(self, x: Tokens, lens: List[int]):
+        """(gather index or None, scatter index or None, sequence lengths) of the configured attention mode."""
+        if self.attn_mode == "full":
+            return None, None, lens
+        if not isinstance(x, SparseTensor):
+            raise TypeError(f"{self.attn_mode} attention needs voxel coordinates: pass a SparseTensor")
+        name = f"order_{self.attn_mode}_{self.window_size}_{self.shift_sequence}_{self.shift_window}_{self.serialize_mode}"
+        hit = x.get_spatial_cache(name)
+        if hit is None:
+            if self.attn_mode == "windowed":
+                fwd, bwd, seq, _ = calc_window_partition(x, self.window_size, self.shift_window if self.shift_window is not None else 0)
+            else:
+                fwd, bwd, seq, _ = calc_serialization(x, self.window_size, self.serialize_mode or SerializeMode.Z_ORDER,
+                                                      self.shift_sequence or 0, self.shift_window or (0, 0, 0))
+            hit = (fwd, bwd, seq)
+            x.register_spatial_cache(name, hit)
+        return hit
+
+    # ---- call --------------------------------------------------------------------------------------------------------
+    def forward(self, x: Tokens, context: Optional[Tokens] = None) -> Tokens:
+        xr, q_lens = _rows(x)
+        gq, gk = self._gains()
         if self._type == "self":
-            qkv = self._fused_pre(self._project(self.to_qkv, x), 3)
-            if self.qk_rms_norm:
-                q, k, v = qkv.unbind(dim=1 if isinstance(qkv, SparseTensor) else 2)
-                q, k = self.q_rms_norm(q), self.k_rms_norm(k)
-                if isinstance(qkv, SparseTensor):
-                    qkv = qkv.replace(torch.stack([q.feats, k.feats, v.feats], dim=1))
-                else:
-                    qkv = torch.stack([q, k, v], dim=2)
-            if self.attn_mode == "full":
-                h = sparse_scaled_dot_product_attention(qkv)
-            elif self.attn_mode == "serialized":
-                h = sparse_serialized_scaled_dot_product_self_attention(
-                    qkv, self.window_size, serialize_mode=self.serialize_mode, shift_sequence=self.shift_sequence,
-                    shift_window=self.shift_window)
-            else:
-                h = sparse_windowed_scaled_dot_product_self_attention(qkv, self.window_size, shift_window=self.shift_window)
+            q, k, v = self._split(linear_rows(self.to_qkv, xr).to(xr.dtype), 3)
+            fwd, bwd, seq = self._token_order(x, q_lens)
+            if fwd is not None:
+                q, k, v = q[fwd], k[fwd], v[fwd]
+            out = packed_varlen_attention(q, k, v, seq, seq, gq, gk)
+            if bwd is not None:
+                out = out[bwd]
         else:
-            q = self._project(self.to_q, x)
-            q = q.reshape(H, -1) if isinstance(q, SparseTensor) else q.reshape(*q.shape[:2], H, -1)
-            kv = self._fused_pre(self._project(self.to_kv, context), 2)
-            if self.qk_rms_norm:
-                q = self.q_rms_norm(q)
-                k, v = kv.unbind(dim=1 if isinstance(kv, SparseTensor) else 2)
-                k = self.k_rms_norm(k)
-                h = sparse_scaled_dot_product_attention(q, k, v)
-            else:
-                h = sparse_scaled_dot_product_attention(q, kv)
-        h = h.reshape(-1) if isinstance(h, SparseTensor) else h.reshape(*h.shape[:2], -1)
-        return self._project(self.to_out, h)
+            if context is None:
+                raise ValueError("cross attention needs a context")
+            cr, kv_lens = _rows(context)
+            if len(kv_lens) != len(q_lens):
+                raise AssertionError(f"Batch size mismatch, got {len(q_lens)} and {len(kv_lens)}")
+            q = linear_rows(self.to_q, xr).to(xr.dtype).reshape(xr.shape[0], self.num_heads, -1)
+            k, v = self._split(linear_rows(self.to_kv, cr).to(xr.dtype), 2)
+            out = packed_varlen_attention(q, k, v, q_lens, kv_lens, gq, gk)
+        y = linear_rows(self.to_out, out.reshape(out.shape[0], -1)).to(xr.dtype)
+        return x.replace(y) if isinstance(x, SparseTensor) else y.reshape(*x.shape[:-1], -1)

@@ -11,6 +11,7 @@ from .... import sparse as sp
 from ....model.sparse_voxel_diffusion.sparse_vae import hammersley_sequence
 from ....ops import dit_ops
 from ....representations.gaussian import GaussianModel as Gaussian
+from ....representations.gaussian.voxel_rows import gaussian_row_layout, rows_to_gaussian
 from .base import SparseTransformerBase
 
 __all__ = ["SLatGaussianDecoder"]
@@ -42,34 +43,15 @@ class SLatGaussianDecoder(SparseTransformerBase):
         self.register_buffer("offset_perturbation", torch.atanh(p / self.rep_config["voxel_size"]))
 
     def _calc_layout(self) -> None:
-        n = self.rep_config["num_gaussians"]
-        self.layout = {"_xyz": {"shape": (n, 3), "size": n * 3}, "_features_dc": {"shape": (n, 1, 3), "size": n * 3},
-                       "_scaling": {"shape": (n, 3), "size": n * 3}, "_rotation": {"shape": (n, 4), "size": n * 4},
-                       "_opacity": {"shape": (n, 1), "size": n}}
-        start = 0
-        for v in self.layout.values():
-            v["range"] = (start, start + v["size"])
-            start += v["size"]
-        self.out_channels = start
+        self.layout = gaussian_row_layout(self.rep_config["num_gaussians"])
+        self.out_channels = self.layout["_opacity"]["range"][1]
 
     def to_representation(self, x: sp.SparseTensor) -> List[Gaussian]:
         cfg = self.rep_config
-        ret = []
-        for i in range(x.shape[0]):
-            rows = x.feats[x.layout[i]]
-            rep = Gaussian(sh_degree=0, aabb=[-0.5, -0.5, -0.5, 1.0, 1.0, 1.0], mininum_kernel_size=cfg["3d_filter_kernel_size"],
-                           scaling_bias=cfg["scaling_bias"], opacity_bias=cfg["opacity_bias"], scaling_activation=cfg["scaling_activation"],
-                           device=rows.device)
-            xyz = (x.coords[x.layout[i]][:, 1:].float() + 0.5) / self.resolution
-            for k, v in self.layout.items():
-                f = rows[:, v["range"][0]:v["range"][1]].reshape(-1, *v["shape"]) * cfg["lr"][k]
-                if k == "_xyz":
-                    if cfg["perturb_offset"]:
-                        f = f + self.offset_perturbation
-                    f = xyz.unsqueeze(1) + torch.tanh(f) / self.resolution * 0.5 * cfg["voxel_size"]
-                setattr(rep, k, f.flatten(0, 1))
-            ret.append(rep)
-        return ret
+        kw = dict(mininum_kernel_size=cfg["3d_filter_kernel_size"], scaling_bias=cfg["scaling_bias"], opacity_bias=cfg["opacity_bias"],
+                  scaling_activation=cfg["scaling_activation"])
+        return [rows_to_gaussian(x.feats[sl], x.coords[sl][:, 1:], self.resolution, self.layout, cfg["lr"], 0.5 * cfg["voxel_size"],
+                                 self.offset_perturbation if cfg["perturb_offset"] else None, kw) for sl in x.layout]
 
     @torch.no_grad()
     def decode_rows(self, x: sp.SparseTensor) -> sp.SparseTensor:

@@ -158,6 +158,14 @@ def test_sparse_multi_head_attention_module(cuda):
                 outs.append(torch.einsum("hqk,khc->qhc", a, qkv[sl, 2]).reshape(-1, 128))
             ref = torch.nn.functional.linear(torch.cat(outs), m.to_out.weight, m.to_out.bias)
             assert float((y.feats - ref).norm() / ref.norm()) < 2e-2
+    # the older channel layout [head][q|k|v][c] (sparse/attention/modules.py:150-162) = the same attention with permuted rows
+    new = SparseMultiHeadAttention(128, 4, attn_mode="windowed", window_size=8, shift_window=4, qk_rms_norm=True).to(cuda)
+    old = SparseMultiHeadAttention(128, 4, attn_mode="windowed", window_size=8, shift_window=4, qk_rms_norm=True, use_old_attn_impl=True).to(cuda)
+    with torch.no_grad():
+        old.load_state_dict(new.state_dict())
+        old.to_qkv.weight.copy_(new.to_qkv.weight.reshape(3, 4, 32, 128).permute(1, 0, 2, 3).reshape(384, 128))
+        old.to_qkv.bias.copy_(new.to_qkv.bias.reshape(3, 4, 32).permute(1, 0, 2).reshape(384))
+        assert float((old(x).feats - new(x).feats).abs().max()) < 1e-5
     cross = SparseMultiHeadAttention(128, 4, ctx_channels=64, type="cross").to(cuda)
     ctx = torch.randn((3, 20, 64)).to(cuda)
     assert cross(x, ctx).feats.shape == (coords.shape[0], 128)
