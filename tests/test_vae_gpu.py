@@ -178,3 +178,20 @@ def test_encode_samples_the_posterior_and_round_trips_through_decode(cuda):
     assert abs(float(zs.mean())) < 0.1 and abs(float(zs.std()) - 1.0) < 0.1
     out = m([t.cuda() for t in gs], static_pc.cuda(), delta_pc.cuda())
     assert out["logits"].shape == (2, BASE["num_timesteps"], 150, BASE["output_dim"]) and torch.isfinite(out["logits"]).all()
+
+
+def test_kv_resident_attention_variant_forced_everywhere(cuda):
+    """csrc/attn.hip has a K/V-resident variant for key sets <= 512 that by default only the decoder's cross attention takes;
+    GVF_ATTN_KVRES=2 forces it for every eligible call (head_dim 32 and 64, row-major and transposed V, RMS-normed q / k,
+    varlen windows).  The switch is read once per process, so the parity tests are re-run in a child process with it set."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GVF_ATTN_KVRES="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_dit_gpu.py::test_attention_matches_oracle",
+                        "tests/test_dit_gpu.py::test_attention_operator_call_forms_and_strided_views",
+                        "tests/test_vae_gpu.py::test_decode_head_dim_64_chunked", "tests/test_vae_gpu.py::test_decode_head_dim_32",
+                        "tests/test_vae_gpu.py::test_encode_head_dim_64", "tests/test_sparse.py", "tests/test_sparse_vae_gpu.py::test_released_width_ragged_batch"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
