@@ -26,23 +26,34 @@ def fps_counts(pos: torch.Tensor, ptr: List[int], k: List[int], start: List[int]
     pos = pos.float().contiguous()
     dev = pos.device
     out = torch.empty((int(sum(k)),), dtype=torch.int64, device=dev)
-    status = torch.zeros((1,), dtype=torch.int32, device=dev)
-    o = 0
-    for b0 in range(0, len(k), MAX_BATCH):
-        kb, sb = list(k[b0:b0 + MAX_BATCH]), list(start[b0:b0 + MAX_BATCH])
-        pb = list(ptr[b0:b0 + len(kb) + 1])
-        nb = len(kb)
+    # one call = up to MAX_BATCH examples whose workgroups (one per 4096 points) are all resident at once (<= 1024)
+    calls, cur, wgs = [], [], 0
+    for b in range(len(k)):
+        w = (int(ptr[b + 1]) - int(ptr[b]) + 4095) // 4096
+        if cur and (len(cur) == MAX_BATCH or wgs + w > 1024):
+            calls.append(cur)
+            cur, wgs = [], 0
+        cur.append(b)
+        wgs += w
+    if cur:
+        calls.append(cur)
+    status = torch.zeros((len(calls),), dtype=torch.int32, device=dev)           # one word per call: a later call must not hide
+    o = 0                                                                         # an earlier time-out
+    I32 = ctypes.c_int32
+    for ci, members in enumerate(calls):
+        b0, nb = members[0], len(members)
+        kb, sb = [int(k[b]) for b in members], [int(start[b]) for b in members]
+        pb = [int(x) for x in ptr[b0:b0 + nb + 1]]
         need = _sz(0)
         _lib.check(_lib.lib().gvf_fps_scratch_bytes(nb, max(kb), ctypes.byref(need)), "gvf_fps_scratch_bytes")
         scratch = torch.empty(int(need.value) + 256, dtype=torch.uint8, device=dev)
         base = (scratch.data_ptr() + 255) // 256 * 256
-        I32 = ctypes.c_int32
         rc = _lib.lib().gvf_fps(_lib.ptr(pos), (I32 * (nb + 1))(*pb), nb, (I32 * nb)(*kb), (I32 * nb)(*sb),
-                                ctypes.c_void_p(out.data_ptr() + 8 * o), ctypes.c_void_p(base), int(need.value), _lib.ptr(status),
-                                _lib.current_stream(dev))
+                                ctypes.c_void_p(out.data_ptr() + 8 * o), ctypes.c_void_p(base), int(need.value),
+                                ctypes.c_void_p(status.data_ptr() + 4 * ci), _lib.current_stream(dev))
         _lib.check(rc, "gvf_fps")
         o += sum(kb)
-    if int(status.item()) != 0:
+    if bool((status != 0).any()):
         raise _lib.GvfError("gvf_fps: the in-kernel hand-off timed out (workgroups of the call were not co-resident)")
     return out
 

@@ -66,3 +66,18 @@ def test_torch_cluster_signature_and_sample_gs(cuda):
     padded, lens = pad_static_gs(gs)
     assert padded.shape == (2, 3000, 14) and lens == [3000, 1800]
     assert torch.equal(padded[1, 1800:, 10], torch.ones(1200, device=cuda)) and float(padded[1, 1800:, :10].abs().sum()) == 0.0
+
+
+@pytest.mark.gpu
+def test_many_examples_are_split_into_resident_calls(cuda):
+    """20 examples (> 16 per call) of which two are large: the wrapper splits them into calls of <= 16 examples and <= 1024
+    workgroups; every example still matches the oracle index for index."""
+    from gvfdiffusion_amd.utils.points import fps_counts
+    g = np.random.default_rng(3)
+    sizes = [700, 5000] * 9 + [300_000, 150_000]
+    ks = [16] * 18 + [8, 8]
+    pos = g.random((sum(sizes), 3), dtype=np.float32)
+    ptr = np.concatenate([[0], np.cumsum(sizes)]).tolist()
+    got = fps_counts(torch.from_numpy(pos).cuda(), ptr, ks, [0] * 20).cpu().numpy()
+    want = points_ref.fps_indices(pos, ptr, ks, [0] * 20)
+    assert np.array_equal(got, want)
