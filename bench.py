@@ -15,7 +15,6 @@ rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and
 import argparse
 import ctypes
 import json
-import math
 import os
 import sys
 import time

@@ -18,7 +18,6 @@ What differs from the reference's op order (results agree to the bf16 tolerance 
 Precision placement = the reference under autocast(bf16): bf16 GEMM/attention operands, fp32 accumulate,
 fp32 residual stream, LayerNorm and softmax.
 """
-import math
 
 import numpy as np
 import torch

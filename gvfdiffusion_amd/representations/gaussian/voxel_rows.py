@@ -3,7 +3,7 @@
 decoder_gs.py:78-115 `SLatGaussianDecoder.to_representation`).  A row holds, for `n` Gaussians of one active voxel, the channel
 groups [_xyz 3n | _features_dc 3n | _scaling 3n | _rotation 4n | _opacity n]; every group is scaled by its `lr` factor, and the
 position group becomes an offset from the voxel centre, squashed by tanh to a fraction of the voxel pitch."""
-from typing import Callable, Dict, Optional
+from typing import Dict, Optional
 
 import torch
 

@@ -5,8 +5,6 @@ src/libImaging/Resample.c: a few thousand doubles per size pair, cached); the pa
 import ctypes
 import functools
 import math
-from typing import Tuple
-
 import torch
 
 from .. import _lib
