@@ -7,7 +7,6 @@ Differentiable: when an input requires grad, rasterize() runs through _Rasterize
 workspace, backward calls gvf_rast_backward) -- upstream's _RasterizeGaussians autograd.Function.
 """
 import ctypes
-import math
 from typing import Optional
 
 import torch

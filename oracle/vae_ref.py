@@ -4,8 +4,6 @@ Follows model/autoencoder.py: decode :579-609, process_chunk/chunk_forward :552-
 Attention :109-163 (softmax(q k^T * dim_head^-0.5) v, to_out with bias, to_q/to_kv without), FeedForward/GEGLU
 :90-107 (x * gelu(gates), exact erf GELU), PointEmbed :250-301, embeddings :392-394.  Pinned by
 tests/golden/vae_small_golden.npz (outputs of the reference class imported in the build container)."""
-import math
-
 import torch
 import torch.nn.functional as F
 
