@@ -157,7 +157,7 @@ def test_sparse_multi_head_attention_module(cuda):
                 a = torch.softmax(torch.einsum("qhc,khc->hqk", q[sl], k[sl]) / 32 ** 0.5, dim=-1)
                 outs.append(torch.einsum("hqk,khc->qhc", a, qkv[sl, 2]).reshape(-1, 128))
             ref = torch.nn.functional.linear(torch.cat(outs), m.to_out.weight, m.to_out.bias)
-            assert float((y.feats - ref).norm() / ref.norm()) < 2e-2
+            assert float((y.feats - ref).detach().norm() / ref.detach().norm()) < 2e-2
     # the older channel layout [head][q|k|v][c] (sparse/attention/modules.py:150-162) = the same attention with permuted rows
     new = SparseMultiHeadAttention(128, 4, attn_mode="windowed", window_size=8, shift_window=4, qk_rms_norm=True).to(cuda)
     old = SparseMultiHeadAttention(128, 4, attn_mode="windowed", window_size=8, shift_window=4, qk_rms_norm=True, use_old_attn_impl=True).to(cuda)
