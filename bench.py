@@ -327,6 +327,28 @@ def cpu_baseline(work, budget_s=12.0):
                       "reference has no CPU Gaussian path (renderers/pytorch_renderer is CUDA-only Strivec)"}
 
 
+def dit_cpu_baseline(T_sample=6, T=24):
+    """The DiT leg's CPU figure: the fp32 torch restatement of the reference's DiT._forward (oracle/dit_ref.py, pinned to the
+    reference by tests/test_oracle_dit.py; kind "port") on this box's host cores, on a bounded sample -- ONE network evaluation
+    of the same model and conditions restricted to the first T_sample of the T frames (every sub-layer but the temporal attention
+    is per frame, so an NFE costs T / T_sample of this)."""
+    import json
+    from gvfdiffusion_amd import synthetic
+    from oracle import dit_ref
+    man = json.load(open(os.path.join(ROOT, "tests", "golden", "dit_manifest.json")))
+    sd = synthetic.dit_state_dict(man["state_dict"], seed=0)
+    inp = synthetic.dit_inputs(B=1, T=T_sample, seed=1)
+    with torch.no_grad():
+        t0 = time.time()
+        y = dit_ref.dit_forward(sd, man["config"], inp["x"], inp["t"], inp["cond_images"], inp["static_latent"],
+                                inp["deformation_position_xyz"], precision="fp32")
+        dt = time.time() - t0
+    assert bool(torch.isfinite(y).all())
+    return {"value": round(1.0 / (dt * T / T_sample), 5), "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"one forward of the same DiT at {T_sample} of the {T} frames in {dt:.1f} s, scaled by {T // T_sample} "
+                      "(torch fp32 restatement of model/dit.py:449-480)"}
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -458,6 +480,8 @@ def main():
             out["end_to_end"] = bench_e2e(dev, a.gaussians, a.res, a.frames)
         if not multi and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(work)
+            if "dit" in out:
+                out["dit"]["cpu_baseline"] = dit_cpu_baseline()
         print(json.dumps(out))
     if multi:
         dist.barrier()
