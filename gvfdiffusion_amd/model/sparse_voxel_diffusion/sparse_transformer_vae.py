@@ -94,6 +94,8 @@ class SparseTransformerVAE(nn.Module):
     def _torso(self, st: sp.SparseTensor, rows: torch.Tensor, w_in, blocks, w_out) -> torch.Tensor:
         """rows fp32 (T, K) -> edge GEMM (+ APE) -> blocks -> [LayerNorm] -> edge GEMM: fp32 (T, N_out)."""
         T, C = rows.shape[0], self.model_channels
+        if T == 0:                                                                 # an empty voxel list maps to an empty one
+            return torch.zeros((0, w_out[0].shape[0]), dtype=torch.float32, device=rows.device)
         x = run_torso(st, rows, w_in, self.pos_embedder if self.pe_mode == "ape" else None, blocks, C)
         if self.norm_output:                                                       # F.layer_norm default eps (:166,194)
             hb = torch.empty((T, C), dtype=torch.bfloat16, device=rows.device)

@@ -56,6 +56,8 @@ class SLatGaussianDecoder(SparseTransformerBase):
     @torch.no_grad()
     def decode_rows(self, x: sp.SparseTensor) -> sp.SparseTensor:
         """-> the (T, out_channels) output rows before to_representation."""
+        if x.feats.shape[0] == 0:
+            return x.replace(torch.zeros((0, self.out_channels), dtype=x.dtype, device=x.device))
         h = self.forward_rows(x)
         hb = torch.empty(h.shape, dtype=torch.bfloat16, device=h.device)
         dit_ops.layernorm_modulate_bf16(h, hb, 1e-5)                              # F.layer_norm default eps (:119)

@@ -87,3 +87,14 @@ def test_device_other_filters_and_loud_failures(cuda):
         resize_pad_crop_u8(torch.from_numpy(f), 75)                     # host tensor: no CPU fallback
     with pytest.raises(ValueError):
         resize_pad_crop_u8(torch.from_numpy(f).cuda().float(), 75)
+
+
+@pytest.mark.gpu
+def test_device_empty_batch_and_single_row_images(cuda):
+    from gvfdiffusion_amd.utils.image_ops import resize_pad_crop_u8
+    out = resize_pad_crop_u8(torch.zeros((0, 3, 40, 40), dtype=torch.uint8, device=cuda), 20, out_size=32)
+    assert out.shape == (0, 3, 32, 32)
+    f = frames(1, 9, 1)                                        # smaller than the filter support in both axes
+    got = resize_pad_crop_u8(torch.from_numpy(f).cuda(), 3, out_size=8).cpu().numpy()
+    want = pil_pad_crop(np.ascontiguousarray(f[0].transpose(1, 2, 0)), 3, 8).transpose(2, 0, 1)
+    assert np.array_equal(got[0], want)

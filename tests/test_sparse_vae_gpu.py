@@ -178,3 +178,17 @@ def test_slat_gaussian_decoder(cuda, tag, rms):
                           (g.get_scaling, "get_scaling", 1e-6), (g.get_opacity, "get_opacity", 1e-6)):
         assert np.abs(got.cpu().numpy() - z[f"{tag}_rep1_{key}"]).max() < tol, key
     assert len(m(x)) == 2
+
+
+def test_empty_voxel_list(cuda):
+    from gvfdiffusion_amd import sparse as sp
+    from gvfdiffusion_amd.model.sparse_voxel_diffusion import SparseTransformerVAE
+    z, cfg, sd = _golden()
+    m = SparseTransformerVAE(**cfg)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda()
+    x = sp.SparseTensor(torch.zeros((0, cfg["in_channels"]), device=cuda), torch.zeros((0, 4), dtype=torch.int32, device=cuda),
+                        shape=torch.Size([0, cfg["in_channels"]]), layout=[])
+    lat = m.encode(x, sample_posterior=False)
+    assert lat.feats.shape == (0, cfg["latent_channels"])
+    assert m.decode(lat).feats.shape == (0, cfg["out_channels"])
