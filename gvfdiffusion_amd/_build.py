@@ -30,6 +30,8 @@ SOURCES = {
     # iterative-ilp: the scheduler variant that measured best for the attention kernels in the denoise step (8.5 -> 8.4 ms
     # per NFE; max-ilp and the default are slower; for rast.hip every non-default strategy slows the blend)
     "attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp"],
+    # tiled-cache cross attention: the issue order of its inner loop is written out (sched_barrier fences), so no scheduler flag
+    "attn_xt.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans", "-fno-slp-vectorize"],
     # (SLP left ON here: the GELU / LayerNorm epilogues measure 2 % slower in the denoise step without it)
     "gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
     "elem.hip": [],

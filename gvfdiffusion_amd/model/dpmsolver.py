@@ -146,6 +146,39 @@ def model_wrapper(model, noise_schedule, model_type="noise", model_kwargs={}, gu
             log_prob = classifier_fn(x_in, t_input, condition, **classifier_kwargs)
             return torch.autograd.grad(log_prob.sum(), x_in)[0]
 
+    _cfg_cache = {}
+
+    def _cfg_sources():
+        src = []
+        for c in (condition, unconditional_condition):
+            for v in (c.values() if isinstance(c, dict) else [c]):
+                src.extend(v if isinstance(v, list) else [v])
+        return [t for t in src if torch.is_tensor(t)]
+
+    def _cfg_condition():
+        """[full-uncond | image-uncond | cond] batch of the three-way guidance (model/dpmsolver.py:332-343).  The
+        reference concatenates it on every call; the conditions are constants of the wrapper, so it is built once and
+        rebuilt only if a source tensor was replaced or written in place -- the SAME tensor objects then reach the
+        model on every step, which is what its step-invariant condition cache is keyed on."""
+        key = tuple((id(t), t._version) for t in _cfg_sources())
+        if _cfg_cache.get("key") == key:
+            return _cfg_cache["c_in"]
+        full_uncond = dict(unconditional_condition) if isinstance(unconditional_condition, dict) else unconditional_condition
+        if isinstance(condition, dict):
+            assert isinstance(unconditional_condition, dict)
+            full_uncond["static_latent"] = torch.zeros_like(full_uncond["static_latent"])
+            c_in = {}
+            for k in condition:
+                if isinstance(condition[k], list):
+                    c_in[k] = [torch.cat([full_uncond[k][i], unconditional_condition[k][i], condition[k][i]])
+                               for i in range(len(condition[k]))]
+                else:
+                    c_in[k] = torch.cat([full_uncond[k], unconditional_condition[k], condition[k]])
+        else:
+            c_in = torch.cat([full_uncond, unconditional_condition, condition])
+        _cfg_cache["key"], _cfg_cache["c_in"] = key, c_in
+        return c_in
+
     def model_fn(x, t_continuous):
         if guidance_type == "uncond":
             return noise_pred_fn(x, t_continuous)
@@ -160,19 +193,7 @@ def model_wrapper(model, noise_schedule, model_type="noise", model_kwargs={}, gu
             return noise_pred_fn(x, t_continuous, cond=condition)
         x_in = torch.cat([x] * 3)
         t_in = torch.cat([t_continuous] * 3)
-        full_uncond = dict(unconditional_condition)
-        full_uncond["static_latent"] = torch.zeros_like(full_uncond["static_latent"])
-        if isinstance(condition, dict):
-            assert isinstance(unconditional_condition, dict)
-            c_in = {}
-            for k in condition:
-                if isinstance(condition[k], list):
-                    c_in[k] = [torch.cat([full_uncond[k][i], unconditional_condition[k][i], condition[k][i]])
-                               for i in range(len(condition[k]))]
-                else:
-                    c_in[k] = torch.cat([full_uncond[k], unconditional_condition[k], condition[k]])
-        else:
-            c_in = torch.cat([full_uncond, unconditional_condition, condition])
+        c_in = _cfg_condition()
         e_full, e_unc, e_cond = noise_pred_fn(x_in, t_in, cond=c_in).chunk(3)
         return e_full + guidance_scale * (e_unc - e_full) + guidance_scale2 * (e_cond - e_unc)
 
@@ -482,7 +503,8 @@ class DPM_Solver:
                 s = t
                 x_prev = x_lower
                 lambda_s = float(ns.marginal_lambda(s))
-            h = min(theta * h * float(E) ** (-1.0 / order), lambda_0 - lambda_s)
+            E_f = float(E)      # E == 0 (both orders agree exactly): float_power gives inf upstream, the min() clamps it
+            h = min(theta * h * (math.inf if E_f == 0.0 else E_f ** (-1.0 / order)), lambda_0 - lambda_s)
             nfe += order
         print("adaptive solver nfe", nfe)
         return x

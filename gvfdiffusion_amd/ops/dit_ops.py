@@ -13,6 +13,9 @@ _lib.register({
     "gvf_gemm_bf16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "gvf_attn_fwd_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i] + [ctypes.POINTER(_i64)] * 4 + [_i, _vp, _vp, _f, _vp]),
     "gvf_attn_varlen_fwd_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i] + [ctypes.POINTER(_i64)] * 4 + [_vp, _vp, _f, _vp]),
+    "gvf_attn_pack_kv_bf16": (_i, [_vp, _i, _i64, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
+    "gvf_attn_tiled_fwd_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, ctypes.POINTER(_i64), ctypes.POINTER(_i64), _i64, _i64,
+                                    _vp, _i, _i, _vp, _vp]),
     "gvf_layernorm_modulate_bf16": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "gvf_cast_pad_bf16": (_i, [_vp, _i, _vp, _i, _i64, _i, _i, _vp]),
 })
@@ -89,6 +92,41 @@ def attention_varlen_bf16(q, k, v, out, cu_q, cu_k, max_Lq, max_Lk, H, q_strides
                                                    _s4(k_strides, head_dim), _s4(v_strides, head_dim),
                                                    _s4(o_strides, head_dim), _p(gamma_q), _p(gamma_k), float(scale),
                                                    _stream(q)), "gvf_attn_varlen_fwd_bf16")
+    return out
+
+
+LOG2E = 1.4426950408889634
+
+
+def attention_pack_kv(kv: torch.Tensor, n_sets: int, L: int, H: int, k_col0: int, v_col0: int, scale: float = None,
+                      gamma_k: torch.Tensor = None, out=None):
+    """kv rows (n_sets * L, ld) fp32 or bf16 -> (k_tiles, v_tiles) uint8 device buffers in the tiled cache image of
+    csrc/attn_xt.hip (K pre-multiplied by scale * log2 e, optional RMSNorm gain)."""
+    _lib.require_cuda(kv)
+    assert kv.dim() == 2 and kv.stride(1) == 1 and kv.dtype in (torch.float32, torch.bfloat16)
+    n_tiles = (L + 63) // 64
+    nbytes = n_sets * H * n_tiles * 4096
+    if out is None:
+        out = (torch.empty(nbytes, dtype=torch.uint8, device=kv.device), torch.empty(nbytes, dtype=torch.uint8, device=kv.device))
+    kt, vt = out
+    assert kt.numel() >= nbytes and vt.numel() >= nbytes
+    scale = 32 ** -0.5 if scale is None else scale
+    _lib.check(_lib.lib().gvf_attn_pack_kv_bf16(_p(kv), int(kv.dtype == torch.float32), kv.stride(0), k_col0, v_col0, n_sets, L, H,
+                                                float(scale * LOG2E), _p(gamma_k), _p(kt), _p(vt), _stream(kv)),
+               "gvf_attn_pack_kv_bf16")
+    return kt, vt
+
+
+def attention_tiled_bf16(q, k_tiles, v_tiles, out, n_outer, n_inner, Lq, Lk, H, q_strides, o_strides, kv_stride_outer,
+                         kv_stride_inner, gamma_q=None, force_exact=False, fallback_counter=None):
+    """Cross attention against a tiled K/V cache (head_dim 32); see include/gvf_dit.h."""
+    _lib.require_cuda(q, k_tiles, v_tiles, out)
+    assert q.dtype == torch.bfloat16 and out.dtype in (torch.bfloat16, torch.float32)
+    _lib.check(_lib.lib().gvf_attn_tiled_fwd_bf16(_p(q), _p(k_tiles), _p(v_tiles), _p(out), n_outer, n_inner, Lq, Lk, H,
+                                                  _s4(q_strides), _s4(o_strides), int(kv_stride_outer), int(kv_stride_inner),
+                                                  _p(gamma_q), int(out.dtype == torch.float32), int(bool(force_exact)),
+                                                  _p(fallback_counter), _stream(q)),
+               "gvf_attn_tiled_fwd_bf16")
     return out
 
 

@@ -13,11 +13,15 @@ import torch
 
 from . import _lib
 
-_WORKSPACES = {}  # (device index) -> uint8 tensor, grown on demand
+_WORKSPACES = {}  # (device index, stream handle) -> uint8 tensor, grown on demand
 
 
 def _workspace(device, nbytes: int) -> torch.Tensor:
-    key = device.index if device.index is not None else torch.cuda.current_device()
+    """Scratch of the non-differentiable calls.  One buffer per (device, stream): a buffer is only ever touched by
+    work queued on the stream it was allocated on, so two renders on different streams never share scratch, and
+    replacing a buffer that is too small is ordered after its last use by the caching allocator (same stream)."""
+    dev_index = device.index if device.index is not None else torch.cuda.current_device()
+    key = (dev_index, int(torch.cuda.current_stream(device).cuda_stream))
     ws = _WORKSPACES.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = None
@@ -157,6 +161,13 @@ class _RasterizeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, settings, frame, want_ad, subpixel_offset, means3D, means2D, shs, colors_precomp, opacities, scales,
                 rotations, cov3D_precomp):
+        # what backward hands to the C ABI must be what forward rendered: dense fp32.  Normalise BEFORE saving (a
+        # strided view such as x[:, :3] or a half-precision tensor would otherwise be read as dense fp32 in backward);
+        # the gradients are cast back to each input's dtype on the way out.
+        ctx.in_dtypes = tuple(None if t is None else t.dtype for t in
+                              (means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp))
+        means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp = (
+            _f32c(t, "input") for t in (means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp))
         out = _rasterize_impl(settings, frame, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp,
                               subpixel_offset, want_ad, private_workspace=True)
         ctx.settings, ctx.frame, ctx.want_ad = settings, frame, want_ad
@@ -216,7 +227,9 @@ class _RasterizeFn(torch.autograd.Function):
         if has_m2:
             g_m2 = torch.zeros(m2_shape, **f32)
             g_m2[:, :2] = d_m2
-        return (None, None, None, None, d_m3, g_m2, d_shs, d_col, d_op.reshape(op_shape), d_sc, d_ro, d_c6)
+        grads = (d_m3, g_m2, d_shs, d_col, d_op.reshape(op_shape), d_sc, d_ro, d_c6)
+        grads = tuple(g if g is None or dt is None or g.dtype == dt else g.to(dt) for g, dt in zip(grads, ctx.in_dtypes))
+        return (None, None, None, None) + grads
 
 
 def rasterize_batched(settings, frames, act, xyz_raw, features_dc, scaling_raw, rotation_raw, opacity_raw,

@@ -59,6 +59,30 @@ int gvf_attn_varlen_fwd_bf16(const void* q, const void* k, const void* v, void* 
                              const int64_t* o_strides, const float* gamma_q, const float* gamma_k, float scale,
                              void* stream);
 
+/* ---- cross attention against a pre-tiled, step-invariant K/V cache (csrc/attn_xt.hip), head_dim 32 ----------------
+ * The two cross attentions of the DiT block (model/dit.py:263-270 -> model/attention/full_attn.py:74-140) read keys /
+ * values that depend on the conditions only.  gvf_attn_pack_kv_bf16 stores them ONCE per condition set in the image
+ * the attention workgroups stage into LDS: per (set, head) ceil(L / 64) tiles of 64 keys, 4 KiB of K (pre-multiplied by
+ * k_scale = softmax_scale * log2(e) in fp32 before the rounding to bf16; optional MultiHeadRMSNorm gain gamma_k
+ * f32 [H][32]) and 4 KiB of V^T each.  kv: f32 (kv_is_f32 != 0) or bf16 rows, row (set * L + key), leading dimension ld
+ * (elements); K of head h at columns [k_col0 + 32 h, +32), V at [v_col0 + 32 h, +32).
+ * k_tiles / v_tiles: n_sets * H * ceil(L / 64) * 4096 bytes each, 16-byte aligned. */
+int gvf_attn_pack_kv_bf16(const void* kv, int kv_is_f32, int64_t ld, int k_col0, int v_col0, int n_sets, int L, int H,
+                          float k_scale, const float* gamma_k, void* k_tiles, void* v_tiles, void* stream);
+
+/* out = softmax(q k^T * scale) v over such a cache (the scale is inside k_tiles).  q / out: bf16, strides
+ * {outer, inner, seq, head} in elements as for gvf_attn_fwd_bf16; (outer, inner) reads K/V set
+ * outer * kv_set_stride_outer + inner * kv_set_stride_inner (inner stride 0: one set shared by all frames of a sample).
+ * gamma_q: optional MultiHeadRMSNorm gain of q, f32 [H][32].  out_is_f32 != 0: out is float with the same element strides
+ * (the kernel's arithmetic without the final rounding to bf16; used by the parity tests).
+ * Numerics: P = exp2(s) without the running maximum while every query's denominator stays inside [2^-100, 2^100];
+ * a workgroup with a query outside recomputes its 256 queries with the exact online softmax (force_exact != 0: always).
+ * fallback_counter (optional, device int32): += 1 per workgroup that took the exact path. */
+int gvf_attn_tiled_fwd_bf16(const void* q, const void* k_tiles, const void* v_tiles, void* out, int n_outer, int n_inner,
+                            int Lq, int Lk, int H, const int64_t* q_strides, const int64_t* o_strides,
+                            int64_t kv_set_stride_outer, int64_t kv_set_stride_inner, const float* gamma_q,
+                            int out_is_f32, int force_exact, int32_t* fallback_counter, void* stream);
+
 /* out_bf16[r][:] = LN(x[r][:]) (eps, no affine) then either  * ln_w + ln_b  (affine LayerNorm, norm3/4)
  * or  * (1 + scale[g]) + shift[g]  (adaLN, g = r / rows_per_group; shift/scale rows have stride mod_ld),
  * x f32 [rows][C]; C a multiple of 256 (<= 1024) takes the register-resident fast path. */

@@ -64,6 +64,27 @@ def sdpa(q, k, v, precision):
     return _r(o.permute(0, 2, 1, 3), precision)
 
 
+LOG2E = 1.4426950408889634
+
+
+def sdpa_tiled(q, k, v, precision, gamma_k=None):
+    """Cross attention with the rounding points of the tiled-cache kernel (gvfdiffusion_amd/csrc/attn_xt.hip):
+    q [N,Lq,H,d] already rounded; k, v [N,Lk,H,d] are the UNROUNDED fp32 projections.  The cache builder folds the
+    (optional) MultiHeadRMSNorm of k and the factor softmax_scale * log2(e) into k in fp32 and rounds ONCE; the kernel
+    then takes P = bf16(exp2(q . k')) with no running maximum (softmax is shift invariant) and divides by the sum of the
+    same bf16-rounded probabilities.  precision="fp32" is the plain softmax(q k^T / sqrt(d)) v."""
+    d = q.shape[-1]
+    if gamma_k is not None:
+        k = F.normalize(k.float(), dim=-1) * gamma_k * (d ** 0.5)
+    if precision != "bf16":
+        return sdpa(q, k, v, precision)
+    q, k, v = (t.permute(0, 2, 1, 3) for t in (q, k, v))
+    k2 = _r(k * (LOG2E / math.sqrt(d)), precision)
+    p = _r(torch.exp2(q @ k2.transpose(-2, -1)), precision)
+    o = (p @ _r(v, precision)) / p.sum(dim=-1, keepdim=True)
+    return _r(o.permute(0, 2, 1, 3), precision)
+
+
 def self_attention(x, sd, prefix, heads, precision):
     B, L, C = x.shape
     qkv = linear(x, sd, prefix + ".to_qkv", precision, round_out=True).reshape(B, L, 3, heads, C // heads)
@@ -79,12 +100,13 @@ def cross_attention(x, ctx, sd, prefix, heads, precision):
     B, L, C = x.shape
     Lk = ctx.shape[1]
     q = linear(x, sd, prefix + ".to_q", precision, round_out=True).reshape(B, L, heads, C // heads)
-    kv = linear(ctx, sd, prefix + ".to_kv", precision, round_out=True).reshape(B, Lk, 2, heads, C // heads)
+    kv = linear(ctx, sd, prefix + ".to_kv", precision).reshape(B, Lk, 2, heads, C // heads)     # fp32: rounded by the cache builder
     k, v = kv.unbind(dim=2)
+    gk = None
     if prefix + ".q_rms_norm.gamma" in sd:
         q = rms_norm_heads(q, sd[prefix + ".q_rms_norm.gamma"], precision)
-        k = rms_norm_heads(k, sd[prefix + ".k_rms_norm.gamma"], precision)
-    h = sdpa(q, k, v, precision).reshape(B, L, C)
+        gk = sd[prefix + ".k_rms_norm.gamma"]
+    h = sdpa_tiled(q, k, v, precision, gamma_k=gk).reshape(B, L, C)
     return linear(h, sd, prefix + ".to_out", precision)
 
 

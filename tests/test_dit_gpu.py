@@ -97,6 +97,105 @@ def test_attention_matches_oracle(cuda, N, Lq, Lk, H, rms):
         assert torch.equal(out2, out)
 
 
+def _tiled_case(cuda, n_outer, n_inner, Lq, Lk, H, shared, rms, seed, k_gain=1.0):
+    g = torch.Generator().manual_seed(seed)
+    n_sets = n_outer if shared else n_outer * n_inner
+    q = bf(torch.randn((n_outer, n_inner, Lq, H, 32), generator=g) * 1.5).to(cuda)
+    kv = torch.randn((n_sets * Lk, 2 * H * 32), generator=g).to(cuda)
+    kv[:, :H * 32] *= 1.5 * k_gain
+    gq = (1 + 0.2 * torch.randn((H, 32), generator=g)).to(cuda) if rms else None
+    gk = (1 + 0.2 * torch.randn((H, 32), generator=g)).to(cuda) if rms else None
+    kt, vt = dit_ops.attention_pack_kv(kv, n_sets, Lk, H, 0, H * 32, gamma_k=gk)
+    C = H * 32
+    strides = (n_inner * Lq * C, Lq * C, C)
+    kset = kv.reshape(n_sets, Lk, 2, H, 32)
+    if shared:
+        kset = kset[:, None].expand(n_outer, n_inner, Lk, 2, H, 32)
+    kset = kset.reshape(n_outer * n_inner, Lk, 2, H, 32)
+    qq = q.reshape(n_outer * n_inner, Lq, H, 32).float()
+    if rms:
+        qq = dit_ref.rms_norm_heads(qq, gq, "bf16")
+    ref = dit_ref.sdpa_tiled(qq, kset[:, :, 0], kset[:, :, 1], "bf16", gamma_k=gk)      # rounded to bf16 at the end
+    return q, kt, vt, gq, strides, ref.reshape(n_outer, n_inner, Lq, H, 32)
+
+
+@pytest.mark.parametrize("n_outer,n_inner,Lq,Lk,H,shared", [(1, 3, 512, 4096, 2, True), (2, 2, 512, 1370, 3, False), (2, 3, 300, 70, 4, False),
+                                                            (1, 1, 1, 1, 1, True), (1, 2, 257, 64, 2, True), (3, 1, 64, 129, 16, False)])
+@pytest.mark.parametrize("rms", [False, True])
+def test_tiled_cache_attention_matches_oracle(cuda, n_outer, n_inner, Lq, Lk, H, shared, rms):
+    """csrc/attn_xt.hip (the DiT's two cross attentions) against the oracle with the kernel's rounding points.  The fp32-output
+    form checks the kernel's own arithmetic (bf16 P, fp32 accumulation) at ~1e-4; the bf16 form adds the output rounding."""
+    q, kt, vt, gq, st, ref = _tiled_case(cuda, n_outer, n_inner, Lq, Lk, H, shared, rms, seed=Lq * 7 + Lk)
+    fb = torch.zeros(1, dtype=torch.int32, device=cuda)
+    kso, ksi = (1, 0) if shared else (n_inner, 1)
+    out = torch.empty_like(q)
+    dit_ops.attention_tiled_bf16(q, kt, vt, out, n_outer, n_inner, Lq, Lk, H, st, st, kso, ksi, gamma_q=gq, fallback_counter=fb)
+    o32 = torch.empty(q.shape, dtype=torch.float32, device=cuda)
+    dit_ops.attention_tiled_bf16(q, kt, vt, o32, n_outer, n_inner, Lq, Lk, H, st, st, kso, ksi, gamma_q=gq)
+    ex32 = torch.empty_like(o32)
+    dit_ops.attention_tiled_bf16(q, kt, vt, ex32, n_outer, n_inner, Lq, Lk, H, st, st, kso, ksi, gamma_q=gq, force_exact=True)
+    r16, rex = rel_l2(out, ref), rel_l2(ex32, o32)
+    print(f"tiled attention o{n_outer} i{n_inner} Lq{Lq} Lk{Lk} H{H} shared={shared} rms={rms}: bf16-out rel_l2 {r16:.2e}, "
+          f"exact-vs-fast (fp32 out) {rex:.2e}, fallbacks {int(fb.item())}")
+    assert int(fb.item()) == 0                      # ordinary logits never leave the fast path
+    assert r16 < 3e-3 and float((out.float() - ref.float()).abs().max()) < 2e-2 * float(ref.float().abs().max()) + 1e-3
+    assert rel_l2(bf(o32), ref) < 3e-3
+    assert rex < 2e-3                               # running-max softmax == max-free softmax up to the rounding of P
+
+
+def test_tiled_cache_attention_fp32_output_is_tight(cuda):
+    """Kernel arithmetic at full precision of its own contract: fp32 output against an fp64 evaluation of the same rounded
+    operands (bf16 q, k', v and bf16 probabilities)."""
+    n_outer, n_inner, Lq, Lk, H = 1, 2, 256, 1000, 2
+    q, kt, vt, _, st, _ = _tiled_case(cuda, n_outer, n_inner, Lq, Lk, H, True, False, seed=5)
+    g = torch.Generator().manual_seed(5)
+    _ = torch.randn((n_outer, n_inner, Lq, H, 32), generator=g)
+    kv = torch.randn((n_outer * Lk, 2 * H * 32), generator=g).to(cuda)
+    kv[:, :H * 32] *= 1.5
+    o32 = torch.empty(q.shape, dtype=torch.float32, device=cuda)
+    dit_ops.attention_tiled_bf16(q, kt, vt, o32, n_outer, n_inner, Lq, Lk, H, st, st, 1, 0)
+    kset = kv.reshape(n_outer, Lk, 2, H, 32)
+    k2 = bf(kset[:, :, 0] * (dit_ref.LOG2E / math.sqrt(32))).double().permute(0, 2, 1, 3)          # (o, H, Lk, 32)
+    v2 = bf(kset[:, :, 1]).double().permute(0, 2, 1, 3)
+    qd = q.double().permute(0, 1, 3, 2, 4)                                                          # (o, i, H, Lq, 32)
+    p = bf(torch.exp2(qd @ k2[:, None].transpose(-2, -1)).float()).double()
+    ref = ((p @ v2[:, None]) / p.sum(-1, keepdim=True)).permute(0, 1, 3, 2, 4)
+    r = rel_l2(o32.double(), ref)
+    print(f"tiled attention fp32 output vs fp64 on the same rounded operands: rel_l2 {r:.2e}")
+    assert r < 2e-4
+
+
+def test_tiled_cache_attention_range_guard_falls_back_exactly(cuda):
+    """Rule: a rare data-dependent branch needs its own test.  Keys scaled so that log2-domain scores leave +-100 octaves:
+    exp2 overflows on the fast path, the guard must send those workgroups through the running-max softmax, results stay exact.
+    A second case spikes ONE key row against ONE query so that a single workgroup falls back."""
+    for k_gain, tag in ((40.0, "all"), (1.0, "spike")):
+        n_outer, n_inner, Lq, Lk, H = 1, 2, 512, 1000, 2
+        g = torch.Generator().manual_seed(11)
+        q = bf(torch.randn((n_outer, n_inner, Lq, H, 32), generator=g) * 1.5).to(cuda)
+        kv = torch.randn((n_outer * Lk, 2 * H * 32), generator=g).to(cuda)
+        kv[:, :H * 32] *= 1.5 * k_gain
+        if tag == "spike":
+            kv[777, 32:64] = q[0, 1, 300, 1].float() * 9.0           # key 777, head 1: aligned with query (0,1,300): ~ +160 octaves
+        kt, vt = dit_ops.attention_pack_kv(kv, n_outer, Lk, H, 0, H * 32)
+        C = H * 32
+        st = (n_inner * Lq * C, Lq * C, C)
+        fb = torch.zeros(1, dtype=torch.int32, device=cuda)
+        out = torch.empty_like(q)
+        dit_ops.attention_tiled_bf16(q, kt, vt, out, n_outer, n_inner, Lq, Lk, H, st, st, 1, 0, fallback_counter=fb)
+        kset = kv.reshape(n_outer, Lk, 2, H, 32)[:, None].expand(n_outer, n_inner, Lk, 2, H, 32).reshape(n_outer * n_inner, Lk, 2, H, 32)
+        k2 = bf(kset[:, :, 0] * (dit_ref.LOG2E / math.sqrt(32))).double().permute(0, 2, 1, 3)
+        s = q.reshape(n_outer * n_inner, Lq, H, 32).double().permute(0, 2, 1, 3) @ k2.transpose(-2, -1)
+        p = torch.exp2(s - s.amax(-1, keepdim=True))
+        ref = ((p @ bf(kset[:, :, 1]).double().permute(0, 2, 1, 3)) / p.sum(-1, keepdim=True)).permute(0, 2, 1, 3).reshape(q.shape)
+        n_fb = int(fb.item())
+        r = rel_l2(out.double(), ref)
+        print(f"range guard [{tag}]: {n_fb} workgroups fell back, rel_l2 vs fp64 {r:.2e}, finite {bool(torch.isfinite(out.float()).all())}")
+        assert torch.isfinite(out.float()).all() and r < 6e-3
+        total = n_outer * n_inner * H * 2
+        assert n_fb == total if tag == "all" else 1 <= n_fb < total
+
+
 def test_attention_operator_call_forms_and_strided_views(cuda):
     from gvfdiffusion_amd.model.attention import scaled_dot_product_attention as sdpa
     g = torch.Generator().manual_seed(0)
@@ -176,14 +275,37 @@ def test_condition_cache_is_keyed_on_tensor_identity(cuda):
     g, cfg, sd, model = _load_small(cuda)
     args = [torch.from_numpy(g[k]).to(cuda) for k in ("x", "t", "cond_images", "static_latent", "xyz")]
     y1 = model(*args)
-    key1 = model._ctx_cache["key"]
+    c1 = model._ctx_cache
     y2 = model(args[0], args[1] * 0.5, *args[2:])            # new step, same conditions -> cache hit
-    assert model._ctx_cache["key"] == key1 and not torch.equal(y1, y2)
+    assert model._ctx_cache is c1 and not torch.equal(y1, y2)
     args[2].mul_(0.5)                                        # in-place change bumps the version -> recompute
     y3 = model(*args)
-    assert model._ctx_cache["key"] != key1 and not torch.equal(y3, y1)
+    assert model._ctx_cache is not c1 and not torch.equal(y3, y1)
     y4 = model(args[0], args[1], args[2].clone(), args[3], args[4])
     assert torch.equal(y3, y4)
+
+
+def test_condition_cache_survives_address_recycling(cuda):
+    """A second sample whose condition tensors land on the SAME device addresses (caching allocator) with version 0 and the
+    same shapes must not hit the first sample's cache: the cache pins the tensors it was built from."""
+    g, cfg, sd, model = _load_small(cuda)
+    x, t = torch.from_numpy(g["x"]).to(cuda), torch.from_numpy(g["t"]).to(cuda)
+    base = [torch.from_numpy(g[k]) for k in ("cond_images", "static_latent", "xyz")]
+
+    def run(scale):
+        conds = [torch.cat([b * scale]).to(cuda) for b in base]     # fresh tensors every sample, as model_wrapper's torch.cat makes
+        ptrs = [c.data_ptr() for c in conds]
+        return model(x, t, *conds), ptrs
+
+    y1, p1 = run(1.0)
+    y2, p2 = run(0.5)                      # sample 1's tensors are dead here unless the cache holds them
+    fresh = type(model)(**cfg).to(cuda).eval()
+    fresh.load_state_dict(sd, strict=True)
+    y2_ref, _ = (fresh(x, t, *[(b * 0.5).to(cuda) for b in base]), None)
+    assert torch.equal(y2, y2_ref), "stale condition cache: sample 2 was denoised with sample 1's conditions"
+    assert not torch.equal(y1, y2)
+    model.invalidate_conditions()
+    assert model._ctx_cache == {}
 
 
 def test_graph_replay_equals_eager(cuda):
