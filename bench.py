@@ -113,7 +113,7 @@ class DiTWorkload:
     """BASELINE configs[2]: configs/diffusion.yml DiT, batch 1, T=24, 32-step DPM-Solver++(2M) sampling on
     synthetic latents + random DINOv2-shaped conditions; weights seed-generated (no checkpoint here)."""
 
-    def __init__(self, dev, T=24, seed=0, guidance=(1.0, 1.0)):
+    def __init__(self, dev, T=24, seed=0, guidance=(1.0, 1.0), input_seed=None):
         import json
         from gvfdiffusion_amd import synthetic
         from gvfdiffusion_amd.model.dit import DiT
@@ -124,7 +124,7 @@ class DiTWorkload:
         model = DiT(**self.cfg)
         model.load_state_dict(synthetic.dit_state_dict(man["state_dict"], seed=seed), strict=True)
         self.model = model.to(dev).eval().enable_graph(os.environ.get("GVF_DIT_GRAPH", "1") == "1")
-        inp = {k: v.to(dev) for k, v in synthetic.dit_inputs(B=1, T=T, seed=seed + 1).items()}
+        inp = {k: v.to(dev) for k, v in synthetic.dit_inputs(B=1, T=T, seed=seed + 1 if input_seed is None else input_seed).items()}
         self.x = inp.pop("x"); inp.pop("t")
         self.cond = inp
         uncond = dict(inp); uncond["cond_images"] = torch.zeros_like(inp["cond_images"])
@@ -192,60 +192,71 @@ def bench_dit(dev, nfe=32):
                                  "the loop); as-written equivalent = %.2f TFLOP/s" % (fa / per / 1e12)}}
 
 
-def bench_e2e(dev, P=262_144, S=800, T=24):
-    """BASELINE configs[3]: the inference_dpm_latent.py chain on one MI355X at the named shapes -- adaptive DPM-Solver over
-    the DiT (configs/diffusion.yml, B=1, steps=100 as the script's --rescale_timesteps default) -> de-normalise -> motion-VAE
-    decode of P static Gaussians x T frames (released VAE config) -> batched render of the T frames (SH degree 0, mip filter,
-    per-frame 14-channel deltas).  Random-init weights of the released architectures, synthetic conditions.  Secondary
-    figure, not part of `value`."""
-    import json
-    from gvfdiffusion_amd import synthetic
-    from gvfdiffusion_amd.model.autoencoder import GSKLTemporalVariationalAutoEncoder
-    from gvfdiffusion_amd.renderers import GaussianRenderer
-    w = DiTWorkload(dev, T=T)
-    calls = {"n": 0}
-    inner = w.solver.model
-    def counted(x, t):
-        calls["n"] += 1
-        return inner(x, t)
-    w.solver.model = counted
-    man = json.load(open(os.path.join(ROOT, "tests", "golden", "vae_manifest.json")))
-    torch.manual_seed(0)
-    vae = GSKLTemporalVariationalAutoEncoder(**man["config"], num_timesteps=T)
-    with torch.no_grad():
-        for p in vae.parameters():
-            p.copy_(torch.randn_like(p) * (1.0 / p.shape[1] ** 0.5 if p.dim() == 2 else 0.05))
-        vae.to_outputs.weight.mul_(0.02)            # deltas of a few per cent of the object size, as a trained decoder gives
-    vae = vae.to(dev)
-    attrs = synthetic.random_gaussians(P, sh_degree=0, seed=0)
-    gm = synthetic.gaussian_model_from(attrs, 0, dev)
-    queries = torch.cat([gm._xyz, gm._features_dc.reshape(P, 3), gm._scaling, gm._rotation, gm._opacity], 1)[None].float()
-    rend = GaussianRenderer({"resolution": S, "near": synthetic.NEAR, "far": synthetic.FAR, "ssaa": 1, "bg_color": (1, 1, 1)})
-    rend.pipe.use_mip_gaussian = True
-    rend.pipe.kernel_size = synthetic.KERNEL_2D
-    ext = torch.stack([synthetic.orbit_w2c(360.0 * f / T, 15.0) for f in range(T)]).to(dev)
-    K = synthetic.intrinsics().to(dev)
+class E2EWorkload:
+    """The inference_dpm_latent.py chain at the named shapes (BASELINE configs[3] / [4]): DPM-Solver over the DiT
+    (configs/diffusion.yml, B=1) -> de-normalise -> motion-VAE decode of P static Gaussians x T frames (released VAE
+    config) -> batched render of the T frames (SH degree 0, mip filter, per-frame 14-channel deltas).  Random-init weights
+    of the released architectures, synthetic conditions; `sample_seed` picks the sample (its noise and conditions)."""
 
-    def chain(timed):
+    def __init__(self, dev, P=262_144, S=800, T=24, sample_seed=0):
+        import json
+        from gvfdiffusion_amd import synthetic
+        from gvfdiffusion_amd.model.autoencoder import GSKLTemporalVariationalAutoEncoder
+        from gvfdiffusion_amd.renderers import GaussianRenderer
+        self.dev, self.P, self.S, self.T = dev, P, S, T
+        self.w = DiTWorkload(dev, T=T, input_seed=1 + sample_seed)
+        self.calls = {"n": 0}
+        inner = self.w.solver.model
+
+        def counted(x, t):
+            self.calls["n"] += 1
+            return inner(x, t)
+        self.w.solver.model = counted
+        man = json.load(open(os.path.join(ROOT, "tests", "golden", "vae_manifest.json")))
+        torch.manual_seed(0)
+        vae = GSKLTemporalVariationalAutoEncoder(**man["config"], num_timesteps=T)
+        with torch.no_grad():
+            for p in vae.parameters():
+                p.copy_(torch.randn_like(p) * (1.0 / p.shape[1] ** 0.5 if p.dim() == 2 else 0.05))
+            vae.to_outputs.weight.mul_(0.02)            # deltas of a few per cent of the object size, as a trained decoder gives
+        self.vae = vae.to(dev)
+        attrs = synthetic.random_gaussians(P, sh_degree=0, seed=sample_seed)
+        self.gm = synthetic.gaussian_model_from(attrs, 0, dev)
+        gm = self.gm
+        self.queries = torch.cat([gm._xyz, gm._features_dc.reshape(P, 3), gm._scaling, gm._rotation, gm._opacity], 1)[None].float()
+        self.rend = GaussianRenderer({"resolution": S, "near": synthetic.NEAR, "far": synthetic.FAR, "ssaa": 1, "bg_color": (1, 1, 1)})
+        self.rend.pipe.use_mip_gaussian = True
+        self.rend.pipe.kernel_size = synthetic.KERNEL_2D
+        self.ext = torch.stack([synthetic.orbit_w2c(360.0 * f / T, 15.0) for f in range(T)]).to(dev)
+        self.K = synthetic.intrinsics().to(dev)
+
+    def chain(self, method="adaptive", steps=100):
+        """-> ([ms sample, ms decode, ms render], NFE count, rendered frames)."""
+        T, S = self.T, self.S
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-        calls["n"] = 0
+        self.calls["n"] = 0
         ev[0].record()
-        x = w.solver.sample(w.x, steps=100, t_start=1.0, t_end=1 / 1000, order=2, skip_type="time_uniform", method="adaptive")
+        x = self.w.solver.sample(self.w.x, steps=steps, t_start=1.0, t_end=1 / 1000, order=2, skip_type="time_uniform", method=method)
         ev[1].record()
         lat = (x * 1.5 + 0.02).reshape(T, x.shape[2], x.shape[3])
-        delta = vae.decode(lat, queries).float()
+        delta = self.vae.decode(lat, self.queries).float()
         ev[2].record()
-        out = rend.render_frames(gm, ext, K, delta_pc=delta[0].contiguous(), sync=False)
+        out = self.rend.render_frames(self.gm, self.ext, self.K, delta_pc=delta[0].contiguous(), sync=False)
         ev[3].record()
         torch.cuda.synchronize()
         assert out.rgb.shape == (T, 3, S, S)
-        return [ev[i].elapsed_time(ev[i + 1]) for i in range(3)], calls["n"], out
+        return [ev[i].elapsed_time(ev[i + 1]) for i in range(3)], self.calls["n"], out
 
+
+def bench_e2e(dev, P=262_144, S=800, T=24):
+    """BASELINE configs[3] on one MI355X: adaptive DPM-Solver (steps=100 as the script's --rescale_timesteps default).
+    Secondary figure, not part of `value`."""
     import contextlib
+    e = E2EWorkload(dev, P, S, T)
     with torch.no_grad(), contextlib.redirect_stdout(sys.stderr):     # the solver reports its NFE on stdout, as upstream does
-        chain(False)                                 # warm-up: weight conversion, graph capture, workspace
+        e.chain()                                    # warm-up: weight conversion, graph capture, workspace
         t0 = time.perf_counter()
-        (ms_sample, ms_decode, ms_render), nfe, out = chain(True)
+        (ms_sample, ms_decode, ms_render), nfe, out = e.chain()
         wall = time.perf_counter() - t0
     assert bool(torch.isfinite(out.rgb).all())
     return {"metric": "end-to-end 4D sample (adaptive DPM-Solver -> VAE decode -> 24-frame render), BASELINE configs[3]",
@@ -253,6 +264,50 @@ def bench_e2e(dev, P=262_144, S=800, T=24):
             "stage_ms": {"sample": round(ms_sample, 2), "vae_decode": round(ms_decode, 2), "render": round(ms_render, 2)},
             "config": {"gaussians": P, "resolution": S, "frames": T, "sampler": "dpmsolver++ adaptive, steps=100, order 2",
                        "dtype": "bf16 models, f32 rasteriser"}}
+
+
+def bench_sharded_sampling(dev, dist, rank, world, P, S, T, total_batch=8, steps=32):
+    """BASELINE configs[4]: batch-sharded sampling (inference_dpm_latent.py:168-273 processes its batch sample by sample with no
+    cross-sample operation).  Rank r owns samples r, r + world, ... of a batch of `total_batch`: 32-step DPM-Solver++(2M) on the
+    DiT -> VAE decode -> 24-frame render, uint8 frames, then the ONE collective of the path: an all-gather of every rank's
+    frames (RCCL over xGMI).  Reported: whole-job samples / frames / denoise steps per second from the max-over-ranks wall
+    time, the slowest rank's per-NFE time, and the gather on its own."""
+    import contextlib
+    from gvfdiffusion_amd import rasterizer as R
+    b_loc = max(1, total_batch // world)
+    e = E2EWorkload(dev, P, S, T, sample_seed=rank)
+    u8 = torch.empty((b_loc, T, 3, S, S), dtype=torch.uint8, device=dev)
+    gathered = torch.empty((world * b_loc, T, 3, S, S), dtype=torch.uint8, device=dev)
+    with torch.no_grad(), contextlib.redirect_stdout(sys.stderr):
+        e.chain(method="multistep", steps=4)         # warm-up
+        dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ms_sample = ms_decode = ms_render = 0.0
+        nfe = 0
+        for i in range(b_loc):
+            (a_, b_, c_), n, out = e.chain(method="multistep", steps=steps)
+            ms_sample += a_; ms_decode += b_; ms_render += c_; nfe += n
+            R.frames_to_uint8(out.rgb, out=u8[i])
+        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        g0.record()
+        dist.all_gather_into_tensor(gathered, u8)
+        g1.record()
+        dist.barrier(); torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    t = torch.tensor([dt, ms_sample / max(nfe, 1), g0.elapsed_time(g1)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt, ms_nfe, ms_gather = (float(v) for v in t.tolist())
+    n_samples = world * b_loc
+    return {"metric": "batch-sharded sampling (BASELINE configs[4]): 32-step DPM-Solver++ on the DiT -> VAE decode -> 24-frame "
+                      "800x800 render per sample, one frame all-gather at the end",
+            "samples": n_samples, "samples_per_rank": b_loc, "wall_ms": round(dt * 1e3, 2),
+            "samples_per_s": round(n_samples / dt, 3), "frames_per_s": round(n_samples * T / dt, 2),
+            "denoise_steps_per_s": round(n_samples * steps / dt, 2), "ms_per_nfe_slowest_rank": round(ms_nfe, 3),
+            "gather_ms": round(ms_gather, 3), "gather_bytes_per_rank": int(u8.numel()),
+            "rank0_stage_ms_per_sample": {"sample": round(ms_sample / b_loc, 2), "vae_decode": round(ms_decode / b_loc, 2),
+                                          "render": round(ms_render / b_loc, 2)},
+            "dit_roofline_frac": round(e.w.flops_per_nfe(True) / (ms_nfe * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 5),
+            "scaling": "weak" if world <= total_batch else "replicas"}
 
 
 def bench_backward(dev, attrs, S, deg, iters=8):
@@ -289,17 +344,39 @@ def bench_backward(dev, attrs, S, deg, iters=8):
 
 
 def pmc_traffic(kernel, a, S, F):
-    """HBM-side bytes per launch of `kernel` from the committed PMC summary (the counters cannot be collected from
-    inside the benchmark process); only for the default workload the summary was taken on, else None."""
+    """(bytes, note): HBM-side bytes per launch of `kernel` from the newest committed PMC summary (the counters cannot be
+    collected from inside the benchmark process).  None unless the summary was taken on THIS workload and on THESE kernel
+    sources (profiles/*_pmc_raster.json carries gvfdiffusion_amd._build.raster_source_hash() of the build it profiled)."""
     import glob
+    from gvfdiffusion_amd._build import raster_source_hash
     if (a.gaussians, S, F, a.sh_degree) != (262144, 800, 24, 2):
-        return None
+        return None, "not the profiled workload"
     files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_raster.json")))
     if not files:
-        return None
-    kernels = json.load(open(files[-1]))["kernels"]
+        return None, "no PMC summary committed"
+    doc = json.load(open(files[-1]))
+    if doc.get("raster_source_hash") != raster_source_hash():
+        return None, f"stale: {os.path.basename(files[-1])} was collected on other rasteriser sources (re-run scripts/gpu_pmc.sh)"
+    kernels = doc["kernels"]
     k = kernels.get(kernel) or next((v for n, v in kernels.items() if n.startswith(kernel + "<")), None)   # template instance
-    return None if k is None else int(k["traffic_bytes_per_launch"])
+    return (None, "kernel not in the summary") if k is None else (int(k["traffic_bytes_per_launch"]), os.path.basename(files[-1]))
+
+
+def pmc_valu_issue(kernel, a, S, F):
+    """VALU-issue roofline of a compute-bound kernel from the committed SQ-counter summary (profiles/*_pmc_raster_sq.json,
+    same source-hash stamp): SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES-normalised issue fraction.  None when absent or stale."""
+    import glob
+    from gvfdiffusion_amd._build import raster_source_hash
+    if (a.gaussians, S, F, a.sh_degree) != (262144, 800, 24, 2):
+        return None
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_raster_sq.json")))
+    if not files:
+        return None
+    doc = json.load(open(files[-1]))
+    if doc.get("raster_source_hash") != raster_source_hash():
+        return None
+    k = doc["kernels"].get(kernel) or next((v for n, v in doc["kernels"].items() if n.startswith(kernel + "<")), None)
+    return None if k is None else dict(k, source=os.path.basename(files[-1]))
 
 
 def cpu_baseline(work, budget_s=12.0):
@@ -327,11 +404,10 @@ def cpu_baseline(work, budget_s=12.0):
                       "reference has no CPU Gaussian path (renderers/pytorch_renderer is CUDA-only Strivec)"}
 
 
-def dit_cpu_baseline(T_sample=6, T=24):
+def dit_cpu_baseline(T_sample=24, T=24):
     """The DiT leg's CPU figure: the fp32 torch restatement of the reference's DiT._forward (oracle/dit_ref.py, pinned to the
-    reference by tests/test_oracle_dit.py; kind "port") on this box's host cores, on a bounded sample -- ONE network evaluation
-    of the same model and conditions restricted to the first T_sample of the T frames (every sub-layer but the temporal attention
-    is per frame, so an NFE costs T / T_sample of this)."""
+    reference by tests/test_oracle_dit.py; kind "port") on this box's host cores: ONE whole network evaluation of the same
+    model and conditions (all T frames -- the temporal attention couples them, so nothing is extrapolated)."""
     import json
     from gvfdiffusion_amd import synthetic
     from oracle import dit_ref
@@ -345,7 +421,7 @@ def dit_cpu_baseline(T_sample=6, T=24):
         dt = time.time() - t0
     assert bool(torch.isfinite(y).all())
     return {"value": round(1.0 / (dt * T / T_sample), 5), "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"one forward of the same DiT at {T_sample} of the {T} frames in {dt:.1f} s, scaled by {T // T_sample} "
+            "sample": f"one full forward of the same DiT (all {T_sample} frames, one NFE) in {dt:.1f} s "
                       "(torch fp32 restatement of model/dit.py:449-480)"}
 
 
@@ -440,6 +516,8 @@ def main():
     assert int(work.nr.to(torch.int64).sum()) <= work.cap, "workspace overflow during the timed region"
 
     if rank == 0:
+        traffic, traffic_note = pmc_traffic("blend_kernel", a, S, F)
+        valu_issue = pmc_valu_issue("blend_kernel", a, S, F)
         ncalls = max(1, calls.value)
         stage_ms = {s: ms[k] / ncalls for k, s in enumerate(STAGES)}
         blend_s = stage_ms["blend"] * 1e-3
@@ -460,10 +538,13 @@ def main():
                        "instances_per_frame": round(work.D / F, 1), "instances_binned_per_frame": round(work.D_binned / F, 1), "parallelism": f"sample-sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": "blend_kernel (R6, one launch = all frames of the step)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic("blend_kernel", a, S, F),
-                         "traffic_source": "profiles/*_pmc_raster.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                           "workload (scripts/gpu_pmc.sh, scripts/pmc_summary.py; FETCH x2 gfx950 correction), "
-                                           "bytes per launch; not re-measured inside this run",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload (scripts/gpu_pmc.sh, "
+                                           "scripts/pmc_summary.py; FETCH x2 gfx950 correction), bytes per launch, from the committed "
+                                           "summary stamped with the rasteriser source hash: " + traffic_note,
+                         # the same launch priced on the instances the kernel actually touches (alpha-box culled binning), 36 B each
+                         "frac_on_binned_instances": round((work.D_binned * 36 + F * S * S * 12) / blend_s / 1e9 / HBM_PEAK_GBS, 5) if blend_s > 0 else 0,
+                         "valu_issue": valu_issue,
                          "alg_bytes_per_launch": int(work.alg_bytes_blend_launch()),
                          "avg_launch_ms": round(stage_ms["blend"], 4)},
             "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
@@ -478,10 +559,26 @@ def main():
             out["dit"] = bench_dit(dev)
             torch.cuda.empty_cache()
             out["end_to_end"] = bench_e2e(dev, a.gaussians, a.res, a.frames)
+        if multi and not a.no_dit:
+            del work.ws
+            torch.cuda.empty_cache()
         if not multi and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(work)
             if "dit" in out:
                 out["dit"]["cpu_baseline"] = dit_cpu_baseline()
+    if multi and not a.no_dit:
+        # every rank takes part; rank 0 prints (the driver reads ONE JSON line)
+        if rank != 0:
+            del work.ws
+            torch.cuda.empty_cache()
+        shard = bench_sharded_sampling(dev, dist, rank, world, a.gaussians, a.res, a.frames)
+        if rank == 0:
+            out["dit"] = {"metric": "DiT denoise steps/sec, whole job (sample-sharded, 32-step DPM-Solver++ multistep per sample)",
+                          "value": shard["denoise_steps_per_s"], "unit": "steps/s", "ms_per_nfe": shard["ms_per_nfe_slowest_rank"],
+                          "dtype": "bf16", "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_PEAK_TFLOPS,
+                                                        "frac": shard["dit_roofline_frac"]}}
+            out["end_to_end"] = shard
+    if rank == 0:
         print(json.dumps(out))
     if multi:
         dist.barrier()

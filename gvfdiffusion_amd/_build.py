@@ -62,6 +62,18 @@ def source_hash() -> str:
     return h.hexdigest()
 
 
+def raster_source_hash() -> str:
+    """sha256 over the sources of the rasteriser kernels only: stamps profiles/*_pmc_raster.json so that bench.py can tell
+    whether the committed HBM-traffic counters were taken on the kernels it is running."""
+    import hashlib
+    inc = os.path.join(os.path.dirname(_HERE), "include")
+    h = hashlib.sha256()
+    for f in (os.path.join(CSRC, "rast.hip"), os.path.join(CSRC, "sort.hip"), os.path.join(CSRC, "gvf_common.h"), os.path.join(inc, "gvf_rast.h")):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def _stale(target: str, deps) -> bool:
     if not os.path.exists(target):
         return True

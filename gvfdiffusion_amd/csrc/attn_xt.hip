@@ -458,57 +458,76 @@ __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Cache builder: kv rows (fp32 or bf16; K at column k_col0 + h*32, V at v_col0 + h*32 of row set*L + key) -> tiled images
+// Cache builder: kv rows (fp32 or bf16; K at column k_col0 + h*32, V at v_col0 + h*32 of row set*L + key) -> tiled images.
+// One workgroup = one (set, head, 64-key tile): thread (key = tid >> 2, c = tid & 3) loads the 8 K values and the 8 V values
+// of its 16-byte chunk (coalesced 64 / 128-byte row pieces), K goes out directly (RMSNorm over the 4 lanes of a key row,
+// scale, one rounding), V is transposed through LDS; both 4 KiB images are written as contiguous 16-byte chunks.
+// Cheap enough (~2 x the bytes it moves at HBM speed) to run per denoise step for the self attention's K / V as well.
 // ---------------------------------------------------------------------------------------------------------------
 template <typename TIn>
-__device__ __forceinline__ float xt_ld(const TIn* p);
+__device__ __forceinline__ void xt_ld8(const TIn* p, float (&v)[8]);
 template <>
-__device__ __forceinline__ float xt_ld<float>(const float* p) { return *p; }
+__device__ __forceinline__ void xt_ld8<float>(const float* p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
 template <>
-__device__ __forceinline__ float xt_ld<unsigned short>(const unsigned short* p) { return __uint_as_float(((unsigned)*p) << 16); }
+__device__ __forceinline__ void xt_ld8<unsigned short>(const unsigned short* p, float (&v)[8]) {
+    const uint4 r = *reinterpret_cast<const uint4*>(p);
+    const unsigned w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = xt_bf2f((unsigned short)(w[i] & 0xffffu)); v[2 * i + 1] = xt_bf2f((unsigned short)(w[i] >> 16)); }
+}
+
+constexpr int XT_PK_LD = 40;     // bf16 pitch of the staged V rows (80 B): the column gathers of a wave spread over the banks
 
 template <typename TIn>
-__global__ __launch_bounds__(256) void attn_pack_kv_kernel(const TIn* __restrict__ kv, long long ld, int k_col0, int v_col0, int n_sets,
-                                                           int L, int H, int n_tiles, float k_scale, const float* __restrict__ gamma_k,
+__global__ __launch_bounds__(256) void attn_pack_kv_kernel(const TIn* __restrict__ kv, long long ld, int k_col0, int v_col0, int L, int H,
+                                                           int n_tiles, float k_scale, const float* __restrict__ gamma_k,
                                                            uint4* __restrict__ kt, uint4* __restrict__ vt) {
-    const long long total = (long long)n_sets * H * n_tiles * 512;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int pos = (int)(i & 255);
-        const bool is_v = ((i >> 8) & 1) != 0;
-        long long rest = i >> 9;
-        const int tile = (int)(rest % n_tiles); rest /= n_tiles;
-        const int h = (int)(rest % H);
-        const long long set = rest / H;
-        float v8[8];
-        if (!is_v) {
-            const int key_l = pos >> 2, c = (pos & 3) ^ ((key_l >> 2) & 3);
-            const int key = tile * XT_KT + key_l;
-            float mul = k_scale;
-            if (gamma_k != nullptr && key < L) {   // MultiHeadRMSNorm of the key row (fp32), then the softmax scale: one rounding
-                float ss = 0.f;
-                for (int e = 0; e < 32; ++e) { const float x = xt_ld<TIn>(kv + (set * L + key) * ld + k_col0 + h * 32 + e); ss += x * x; }
-                mul = k_scale * 5.656854249492381f / fmaxf(sqrtf(ss), 1e-12f);
-            }
+    __shared__ unsigned short sV[XT_KT * XT_PK_LD];
+    const int tid = threadIdx.x;
+    long long rest = blockIdx.x;
+    const int tile = (int)(rest % n_tiles); rest /= n_tiles;
+    const int h = (int)(rest % H);
+    const long long set = rest / H;
+    const int key_l = tid >> 2, c = tid & 3, key = tile * XT_KT + key_l;
+    const bool valid = key < L;
+    const TIn* row = kv + (set * L + (valid ? key : 0)) * ld + h * 32 + 8 * c;
+    float k8[8], v8[8];
+    xt_ld8<TIn>(row + k_col0, k8);
+    xt_ld8<TIn>(row + v_col0, v8);
+    float mul = k_scale;
+    if (gamma_k != nullptr) {           // MultiHeadRMSNorm of the key row in fp32, then the softmax scale: ONE rounding
+        float ss = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float g = gamma_k != nullptr ? gamma_k[h * 32 + 8 * c + e] : 1.0f;
-                v8[e] = key < L ? xt_ld<TIn>(kv + (set * L + key) * ld + k_col0 + h * 32 + 8 * c + e) * mul * g : 0.f;
-            }
-        } else {
-            const int d = pos >> 3, j = (pos & 7) ^ ((d >> 1) & 7);
-            const int g = j >> 1, hf = j & 1;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int key = tile * XT_KT + 16 * g + 4 * hf + (e & 3) + 8 * (e >> 2);
-                v8[e] = key < L ? xt_ld<TIn>(kv + (set * L + key) * ld + v_col0 + h * 32 + d) : 0.f;
-            }
-        }
-        uint4 w;
-        w.x = cvt_pk_bf16(v8[0], v8[1]); w.y = cvt_pk_bf16(v8[2], v8[3]);
-        w.z = cvt_pk_bf16(v8[4], v8[5]); w.w = cvt_pk_bf16(v8[6], v8[7]);
-        const long long o = ((set * H + h) * n_tiles + tile) * 256 + pos;
-        (is_v ? vt : kt)[o] = w;
+        for (int e = 0; e < 8; ++e) ss += k8[e] * k8[e];
+        ss += __shfl_xor(ss, 1, 64);
+        ss += __shfl_xor(ss, 2, 64);
+        mul = k_scale * 5.656854249492381f / fmaxf(sqrtf(ss), 1e-12f);
     }
+    unsigned kw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float g0 = gamma_k != nullptr ? gamma_k[h * 32 + 8 * c + 2 * i] : 1.0f, g1 = gamma_k != nullptr ? gamma_k[h * 32 + 8 * c + 2 * i + 1] : 1.0f;
+        kw[i] = valid ? cvt_pk_bf16(k8[2 * i] * mul * g0, k8[2 * i + 1] * mul * g1) : 0u;
+    }
+    const long long base = ((set * H + h) * n_tiles + tile) * 256;
+    kt[base + key_l * 4 + (c ^ ((key_l >> 2) & 3))] = make_uint4(kw[0], kw[1], kw[2], kw[3]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<unsigned*>(&sV[key_l * XT_PK_LD + 8 * c + 2 * i]) = valid ? cvt_pk_bf16(v8[2 * i], v8[2 * i + 1]) : 0u;
+    __syncthreads();
+    const int d = tid >> 3, pos = tid & 7, j = pos ^ ((d >> 1) & 7), g = j >> 1, hf = j & 1;
+    unsigned vw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e0 = 2 * i, e1 = 2 * i + 1;
+        const unsigned lo = sV[(16 * g + 4 * hf + (e0 & 3) + 8 * (e0 >> 2)) * XT_PK_LD + d];
+        const unsigned hi = sV[(16 * g + 4 * hf + (e1 & 3) + 8 * (e1 >> 2)) * XT_PK_LD + d];
+        vw[i] = lo | (hi << 16);
+    }
+    vt[base + d * 8 + pos] = make_uint4(vw[0], vw[1], vw[2], vw[3]);
 }
 
 }  // namespace
@@ -520,18 +539,20 @@ extern "C" int gvf_attn_pack_kv_bf16(const void* kv, int kv_is_f32, int64_t ld, 
     if (!kv || !k_tiles || !v_tiles) return GVF_EINVAL;
     if ((((uintptr_t)k_tiles) & 15) || (((uintptr_t)v_tiles) & 15)) return GVF_EINVAL;
     const int n_tiles = (L + XT_KT - 1) / XT_KT;
-    const long long total = (long long)n_sets * H * n_tiles * 512;
-    long long blocks = (total + 255) / 256;
-    if (blocks > 65536) blocks = 65536;
+    const long long blocks = (long long)n_sets * H * n_tiles;
+    if (blocks > 0x7fffffffLL) return GVF_EINVAL;
+    // 16-byte (bf16) / 2 x 16-byte (fp32) row pieces: the row pitch and the two column offsets must keep that alignment
+    const int al = kv_is_f32 ? 4 : 8;
+    if ((ld % al) || (k_col0 % al) || (v_col0 % al) || (((uintptr_t)kv) & 15)) return GVF_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
     (void)hipGetLastError();
     if (kv_is_f32)
-        attn_pack_kv_kernel<float><<<dim3((unsigned)blocks), dim3(256), 0, stream>>>((const float*)kv, ld, k_col0, v_col0, n_sets, L, H,
-                                                                                     n_tiles, k_scale, gamma_k, (uint4*)k_tiles, (uint4*)v_tiles);
+        attn_pack_kv_kernel<float><<<dim3((unsigned)blocks), dim3(256), 0, stream>>>((const float*)kv, ld, k_col0, v_col0, L, H, n_tiles, k_scale,
+                                                                                     gamma_k, (uint4*)k_tiles, (uint4*)v_tiles);
     else
-        attn_pack_kv_kernel<unsigned short><<<dim3((unsigned)blocks), dim3(256), 0, stream>>>((const unsigned short*)kv, ld, k_col0, v_col0,
-                                                                                              n_sets, L, H, n_tiles, k_scale, gamma_k,
-                                                                                              (uint4*)k_tiles, (uint4*)v_tiles);
+        attn_pack_kv_kernel<unsigned short><<<dim3((unsigned)blocks), dim3(256), 0, stream>>>((const unsigned short*)kv, ld, k_col0, v_col0, L, H,
+                                                                                              n_tiles, k_scale, gamma_k, (uint4*)k_tiles,
+                                                                                              (uint4*)v_tiles);
     GVF_CHECK_LAUNCH();
     return GVF_OK;
 }

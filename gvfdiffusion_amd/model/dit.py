@@ -396,6 +396,8 @@ class DiT(nn.Module):
         ab = torch.empty((M, C), dtype=bf, device=dev)          # attention output
         hidden = torch.empty((M, int(C * self.mlp_ratio)), dtype=bf, device=dev)
         TN = T * N
+        nb_self = B * T * H * ((N + 63) // 64) * 4096
+        kv_self = (torch.empty(nb_self, dtype=torch.uint8, device=dev), torch.empty(nb_self, dtype=torch.uint8, device=dev))
 
         def mview(off):                                       # (B,) rows of `mod`, columns [off, off+C)
             return mod[:, off:]
@@ -407,8 +409,10 @@ class DiT(nn.Module):
             dit_ops.layernorm_modulate_bf16(h, hb, 1e-6, None, None, sh_s, sc_s, mod_ld, TN)
             a = b["spatial_self_attn"]
             dit_ops.gemm_bf16(hb, *a["qkv"], qkv, dit_ops.EPI_STORE_BF16)
-            s3 = (N * 3 * C, 0, 3 * C)
-            dit_ops.attention_bf16(qkv, qkv[:, C:], qkv[:, 2 * C:], ab, B * T, 1, N, N, H, s3, s3, s3, (N * C, 0, C), a["gq"], a["gk"])
+            # K (RMS-normed, pre-scaled) and V^T of this step's projection into the tiled image, then the tiled-cache kernel
+            dit_ops.attention_pack_kv(qkv, B * T, N, H, C, 2 * C, gamma_k=a["gk"], out=kv_self)
+            dit_ops.attention_tiled_bf16(qkv, kv_self[0], kv_self[1], ab, B * T, 1, N, N, H, (N * 3 * C, 0, 3 * C), (N * C, 0, C), 1, 0,
+                                         gamma_q=a["gq"])
             dit_ops.gemm_bf16(ab, *a["out"], h, dit_ops.EPI_RESID_F32, gate=g_s, gate_ld=mod_ld, rows_per_group=TN)
             # -- temporal self attention over T (strided views, no transposes)
             if not self.no_temporal_attn:

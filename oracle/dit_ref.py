@@ -85,14 +85,21 @@ def sdpa_tiled(q, k, v, precision, gamma_k=None):
     return _r(o.permute(0, 2, 1, 3), precision)
 
 
-def self_attention(x, sd, prefix, heads, precision):
+def self_attention(x, sd, prefix, heads, precision, tiled=False):
+    """tiled=True: the rounding points of the path the DiT's spatial self attention takes (K / V^T of the packed qkv
+    projection re-tiled per step, csrc/attn_xt.hip); False: the streaming / one-wave kernels (csrc/attn.hip)."""
     B, L, C = x.shape
     qkv = linear(x, sd, prefix + ".to_qkv", precision, round_out=True).reshape(B, L, 3, heads, C // heads)
     q, k, v = qkv.unbind(dim=2)
-    if prefix + ".q_rms_norm.gamma" in sd:
+    has_rms = prefix + ".q_rms_norm.gamma" in sd
+    if has_rms:
         q = rms_norm_heads(q, sd[prefix + ".q_rms_norm.gamma"], precision)
-        k = rms_norm_heads(k, sd[prefix + ".k_rms_norm.gamma"], precision)
-    h = sdpa(q, k, v, precision).reshape(B, L, C)
+    if tiled:
+        h = sdpa_tiled(q, k, v, precision, gamma_k=sd[prefix + ".k_rms_norm.gamma"] if has_rms else None).reshape(B, L, C)
+    else:
+        if has_rms:
+            k = rms_norm_heads(k, sd[prefix + ".k_rms_norm.gamma"], precision)
+        h = sdpa(q, k, v, precision).reshape(B, L, C)
     return linear(h, sd, prefix + ".to_out", precision)
 
 
@@ -142,7 +149,7 @@ def block_forward(x, mod, image_emb, static_emb, sd, p, heads, precision):
     sh_t, sc_t, g_t = linear(silu, sd, p + ".adaLN_modulation_temporal.1", precision).chunk(3, dim=1)
     # spatial self attention over the N tokens of each frame
     h = modulate(layer_norm(x), sh_s, sc_s)
-    h = self_attention(h.reshape(B * T, N, C), sd, p + ".spatial_self_attn", heads, precision).reshape(B, T, N, C)
+    h = self_attention(h.reshape(B * T, N, C), sd, p + ".spatial_self_attn", heads, precision, tiled=True).reshape(B, T, N, C)
     x = x + h * g_s[:, None, None]
     # temporal self attention over the T frames of each token
     h = modulate(layer_norm(x), sh_t, sc_t).transpose(1, 2).reshape(B * N, T, C)

@@ -2,7 +2,9 @@
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies 128-B read requests at 64 B
 (/opt/skills/guides/MI355X_MICROARCH.md, HBM section) -> doubled here.  Writes the JSON bench.py reads for
 `roofline.traffic`.   usage: python scripts/pmc_summary.py <fetch.csv> <write.csv> <out.json> <frames_per_launch>"""
-import collections, csv, json, re, sys
+import collections, csv, json, os, re, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gvfdiffusion_amd._build import raster_source_hash
 
 
 def per_kernel(path):
@@ -16,7 +18,8 @@ def per_kernel(path):
 
 fetch, write = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace; bench.py --steps 3 --warmup 1 "
-                 "--no-cpu-baseline --no-dit", "fetch_correction": "x2 (gfx950: 128-B requests tallied at 64 B)", "kernels": {}}
+                 "--no-cpu-baseline --no-dit", "fetch_correction": "x2 (gfx950: 128-B requests tallied at 64 B)",
+       "raster_source_hash": raster_source_hash(), "kernels": {}}
 for k in fetch:
     if not any(s in k for s in ("kernel", "sort_")) or "elementwise" in k:
         continue

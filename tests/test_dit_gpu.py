@@ -27,8 +27,17 @@ def rel_l2(a, b):
 # cannot meet that element-wise (one bf16 ulp is 3.9e-3 relative and accumulation order moves roundings), so
 # the claims are stated as relative L2 errors, measured values printed by the tests:
 TOL_KERNEL_REL_L2 = 2e-3     # single kernel vs torch on identical bf16 operands (fp32 accumulate)
-TOL_DIT_VS_BF16_ORACLE = 1e-2   # full denoiser vs oracle with the same rounding points (dit_ref precision="bf16")
-TOL_DIT_VS_FP32_REF = 3e-2      # full denoiser vs the fp32 reference output (golden)
+TOL_DIT_VS_BF16_ORACLE = 6e-3   # full denoiser vs oracle with the same rounding points (dit_ref precision="bf16"): measured 3.4e-3
+#   at the full config / 2.7e-4 at the small one.  Single kernels agree with the oracle to 1e-5 .. 2e-4 (tests above); what is
+#   left after 12 blocks is decorrelated rounding noise (a probability or an activation that rounds the other way), not bias.
+TOL_DIT_VS_FP32_REF = 3e-2      # loose sanity bound vs the fp32 reference output (golden); the REAL bar is REF_AUTOCAST_SLACK:
+REF_AUTOCAST_SLACK = 1.1        # err(HIP vs fp32 golden) <= 1.1 x err(the reference's own bf16 autocast run vs fp32 golden),
+#   tests/golden/dit_autocast_golden.npz (tests/golden/make_golden.py::gen_dit_autocast, model/dit.py under torch.autocast)
+
+
+def _ref_autocast_err(tag):
+    g = np.load(os.path.join(GOLD, "dit_autocast_golden.npz"))
+    return float(g[f"{tag}_rel_l2_bf16"]), float(g[f"{tag}_rel_l2_fp16"])
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 200, 128), (128, 128, 64), (1, 1536, 512), (1000, 16, 512), (257, 3072, 2048)])
@@ -140,7 +149,7 @@ def test_tiled_cache_attention_matches_oracle(cuda, n_outer, n_inner, Lq, Lk, H,
     assert int(fb.item()) == 0                      # ordinary logits never leave the fast path
     assert r16 < 3e-3 and float((out.float() - ref.float()).abs().max()) < 2e-2 * float(ref.float().abs().max()) + 1e-3
     assert rel_l2(bf(o32), ref) < 3e-3
-    assert rex < 2e-3                               # running-max softmax == max-free softmax up to the rounding of P
+    assert rex < 4e-3                               # running-max softmax == max-free softmax up to the bf16 rounding of P
 
 
 def test_tiled_cache_attention_fp32_output_is_tight(cuda):
@@ -261,6 +270,9 @@ def test_small_dit_forward_matches_reference_golden(cuda):
     r_ref, r_b = rel_l2(y, gold), rel_l2(y, yb)
     print(f"small DiT: rel_l2 vs fp32 reference golden {r_ref:.2e}; vs bf16-emulating oracle {r_b:.2e}")
     assert y.shape == gold.shape and r_ref < TOL_DIT_VS_FP32_REF and r_b < TOL_DIT_VS_BF16_ORACLE
+    ref_bf16, ref_fp16 = _ref_autocast_err("small")
+    print(f"small DiT: reference's own autocast error vs fp32: bf16 {ref_bf16:.2e}, fp16 {ref_fp16:.2e}; HIP {r_ref:.2e}")
+    assert r_ref <= REF_AUTOCAST_SLACK * ref_bf16
     # module-level drop-in: MultiHeadAttention.forward on its own
     attn = model.blocks[0].spatial_self_attn
     x = torch.randn((3, 40, 64), generator=torch.Generator().manual_seed(1)).to(cuda)
@@ -339,6 +351,9 @@ def test_full_config_forward_matches_reference_golden(cuda):
     print(f"full DiT: rel_l2 vs fp32 reference golden {r_ref:.2e}; vs bf16-emulating oracle {r_b:.2e}; "
           f"oracle(bf16) vs golden {rel_l2(yb, gold):.2e}")
     assert r_ref < TOL_DIT_VS_FP32_REF and r_b < TOL_DIT_VS_BF16_ORACLE
+    ref_bf16, ref_fp16 = _ref_autocast_err("full")
+    print(f"full DiT: reference's own autocast error vs fp32: bf16 {ref_bf16:.2e}, fp16 {ref_fp16:.2e}; HIP {r_ref:.2e}")
+    assert r_ref <= REF_AUTOCAST_SLACK * ref_bf16, "the HIP denoiser is less accurate than the reference's own bf16 autocast run"
 
 
 def test_sampler_drives_the_hip_dit(cuda):
@@ -363,3 +378,36 @@ def test_sampler_drives_the_hip_dit(cuda):
         r = rel_l2(outs[("hip", scales)], outs[("oracle", scales)])
         print(f"6-step DPM-Solver++ sample, guidance {scales}: rel_l2 hip vs fp32 oracle {r:.2e}")
         assert r < 5e-2
+
+
+def test_adaptive_solver_on_the_hip_dit_matches_fp32_oracle(cuda):
+    """BASELINE configs[3] uses the adaptive DPM-Solver (model/dpmsolver.py:973-1027): its accept / reject decisions are data
+    dependent, so reduced-precision noise in the denoiser can change the number of network evaluations.  Covered size: the
+    small golden model, HIP denoiser vs the fp32 oracle through the same solver -- identical NFE count, close samples."""
+    from gvfdiffusion_amd.model.dpmsolver import NoiseScheduleVP, model_wrapper, DPM_Solver
+    from gvfdiffusion_amd.model.gaussian_diffusion import create_gaussian_diffusion
+    g, cfg, sd, model = _load_small(cuda)
+    sdc = {k: v.to(cuda) for k, v in sd.items()}
+    ns = NoiseScheduleVP("discrete", betas=torch.from_numpy(create_gaussian_diffusion(noise_schedule="cosine", predict_type="v").betas))
+    cond = {"cond_images": torch.from_numpy(g["cond_images"]).to(cuda), "static_latent": torch.from_numpy(g["static_latent"]).to(cuda),
+            "deformation_position_xyz": torch.from_numpy(g["xyz"]).to(cuda)}
+    xT = torch.randn(g["x"].shape, generator=torch.Generator().manual_seed(7)).to(cuda)
+    res = {}
+    for name, net in (("hip", model), ("oracle", lambda x, t, **kw: dit_ref.dit_forward(sdc, cfg, x, t, kw["cond_images"], kw["static_latent"],
+                                                                                       kw["deformation_position_xyz"]))):
+        calls = {"n": 0}
+
+        def counted(x, t, _net=net, _c=calls, **kw):
+            _c["n"] += 1
+            return _net(x, t, **kw)
+        mf = model_wrapper(counted, ns, model_type="v", model_kwargs={}, guidance_type="classifier-free", guidance_scale=1.0,
+                           guidance_scale2=1.0, condition=cond, unconditional_condition=None)
+        x0 = DPM_Solver(mf, ns, algorithm_type="dpmsolver++").sample(xT, steps=100, t_start=1.0, t_end=1 / 1000, order=2,
+                                                                    skip_type="time_uniform", method="adaptive")
+        res[name] = (x0, calls["n"])
+    (xh, nh), (xo, no) = res["hip"], res["oracle"]
+    r = rel_l2(xh, xo)
+    print(f"adaptive DPM-Solver++: NFE hip {nh} / fp32 oracle {no}; sample rel_l2 {r:.2e}"
+          + ("" if nh == no else "  <- step acceptance diverged: a trial sat within bf16 noise of the error threshold"))
+    assert torch.isfinite(xh).all() and r < 5e-2
+    assert nh == no, f"NFE {nh} != {no}: the bf16 denoiser changed an accept / reject decision of the adaptive solver"

@@ -47,6 +47,12 @@ def test_small_model_forward_matches_reference():
         yb = dit_ref.dit_forward(sd, cfg, *args, precision="bf16")
     rel = float((yb - y).norm() / y.norm())
     assert rel < 3e-2, rel
+    # ... and is not less accurate than the reference's OWN bf16 autocast run of model/dit.py on the same inputs
+    # (tests/golden/dit_autocast_golden.npz, make_golden.py::gen_dit_autocast): the rounding model is not optimistic either
+    ac = np.load(os.path.join(GOLD, "dit_autocast_golden.npz"))
+    ref_bf16 = float(ac["small_rel_l2_bf16"])
+    assert abs(float((torch.from_numpy(ac["small_y_bf16"]) - torch.from_numpy(g["y"])).norm() / torch.from_numpy(g["y"]).norm()) - ref_bf16) < 1e-6
+    assert 0.3 * ref_bf16 < rel <= 1.1 * ref_bf16, (rel, ref_bf16)
 
 
 def test_full_config_forward_matches_reference():
