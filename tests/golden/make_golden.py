@@ -254,6 +254,79 @@ def gen_dit_autocast():
     print("dit_autocast_golden.npz", sorted(out))
 
 
+def gen_align():
+    """utils/inference_utils.py:37-177 align_gaussian_to_canonical, the REFERENCE function, on a stand-in renderer
+    (tests/align_util.py: the image an object shows from azimuth index v) with its CLIP term neutralised (constant image
+    features -> clip_diff = 0).  Third-party modules it imports at module level are stubbed: torch_cluster, torchvision,
+    kiui.cam (poses are ignored by the stand-in renderer), clip, imageio (file names carry the per-azimuth L1 scores: they
+    are parsed into the fixture), pytorch3d.transforms.matrix_to_quaternion (the standard real-part-positive conversion)."""
+    import re
+    import tempfile
+    sys.path.insert(0, os.path.join(OUT, ".."))
+    import align_util
+
+    class _Clip:
+        def encode_image(self, x):
+            return torch.ones((1, 4))
+    scores = {}
+
+    def imwrite(path, arr):
+        m = re.search(r"render_(-?\d+)_diff_([0-9.]+)_([0-9.]+)\.png", os.path.basename(path))
+        scores[int(m.group(1))] = (float(m.group(2)), float(m.group(3)))
+
+    def m2q(R):                                   # pytorch3d.transforms.matrix_to_quaternion semantics: (w,x,y,z), w >= 0
+        out = []
+        for M in R:
+            m = M.double().numpy()
+            tr = m[0, 0] + m[1, 1] + m[2, 2]
+            cand = [np.array([1 + tr, m[2, 1] - m[1, 2], m[0, 2] - m[2, 0], m[1, 0] - m[0, 1]]),
+                    np.array([m[2, 1] - m[1, 2], 1 + m[0, 0] - m[1, 1] - m[2, 2], m[0, 1] + m[1, 0], m[0, 2] + m[2, 0]]),
+                    np.array([m[0, 2] - m[2, 0], m[0, 1] + m[1, 0], 1 - m[0, 0] + m[1, 1] - m[2, 2], m[1, 2] + m[2, 1]]),
+                    np.array([m[1, 0] - m[0, 1], m[0, 2] + m[2, 0], m[1, 2] + m[2, 1], 1 - m[0, 0] - m[1, 1] + m[2, 2]])]
+            q = max(cand, key=lambda c: np.linalg.norm(c))
+            q = q / np.linalg.norm(q)
+            out.append(q if q[0] >= 0 else -q)
+        return torch.tensor(np.stack(out), dtype=torch.float32)
+
+    _stub("torch_cluster", fps=lambda *a, **k: None)
+    tv = _stub("torchvision"); tv.transforms = _stub("torchvision.transforms", ToPILImage=lambda: (lambda t: t))
+    _stub("kiui"); _stub("kiui.cam", orbit_camera=lambda elev, azi, radius=2.0, opengl=True: np.eye(4, dtype=np.float32))
+    p3 = _stub("pytorch3d"); p3.transforms = _stub("pytorch3d.transforms", matrix_to_quaternion=m2q)
+    _stub("clip", load=lambda name, device=None: (_Clip(), lambda pil: torch.zeros((3, 8, 8))))
+    _stub("imageio", imwrite=imwrite)
+    tmp = tempfile.mkdtemp()
+    _stub("tensorboard"); tb = _stub("torch.utils.tensorboard", SummaryWriter=object)
+    _stub("mpi4py", MPI=None)
+    import utils.logger as ref_logger
+    ref_logger.get_dir = lambda: tmp
+    from utils.inference_utils import align_gaussian_to_canonical
+
+    out = {}
+    for tag, wild, v_star, zoom in (("wild", True, 217, 1.13), ("coarse", False, 3, 0.9)):
+        az = np.arange(-180, 180, 1) if wild else np.arange(-180, 180, 90)
+        calls = {"n": 0}
+
+        class _Renderer:
+            pipe = types.SimpleNamespace(use_mip_gaussian=True)
+
+            def render(self, model, extrinsics, intrinsics):
+                rgb, alpha = align_util.view(calls["n"], len(az))
+                calls["n"] += 1
+                return {"rgb": rgb, "alpha": alpha[None]}
+        vae = types.SimpleNamespace(renderers={"MipGS": _Renderer()})
+        model = align_util.ToyGaussians(seed=3)
+        canon_rgb, canon_alpha = align_util.canonical(v_star, len(az), zoom)
+        scores.clear()
+        model, scale = align_gaussian_to_canonical(model, canon_rgb, canon_alpha, torch.eye(3), vae, 0, torch.device("cpu"), in_the_wild=wild)
+        out[f"{tag}.params"] = np.array([v_star, zoom])
+        out[f"{tag}.scale_factor"] = np.float64(float(scale))
+        out[f"{tag}.xyz"], out[f"{tag}.rotation"] = model.get_xyz.numpy(), model.get_rotation.numpy()
+        out[f"{tag}.l1"] = np.array([scores[int(a)][0] for a in az])          # 4-decimal strings of the reference's own scores
+        out[f"{tag}.best_azimuth"] = np.int64(az[int(np.argmin([scores[int(a)][0] + 0.2 * scores[int(a)][1] for a in az]))])
+        print(tag, "best azimuth", int(out[f"{tag}.best_azimuth"]), "expected", int(az[v_star]), "scale", float(scale))
+    np.savez_compressed(os.path.join(OUT, "align_golden.npz"), **out)
+
+
 def gen_sampler():
     from model.dpmsolver import NoiseScheduleVP, model_wrapper, DPM_Solver
     from utils.script_util import create_gaussian_diffusion
@@ -613,7 +686,7 @@ def gen_sparse_layers():
     print("sparse_layers_golden.npz", {k: v.shape for k, v in out.items()})
 
 
-SECTIONS = {"sparse_layers": gen_sparse_layers, "slat_decoder": gen_slat_decoder, "sparse_vae": gen_sparse_vae, "vae_encode": gen_vae_encode, "vae": gen_vae, "raster": gen_raster, "vox2seq": gen_vox2seq, "dit": gen_dit, "dit_autocast": gen_dit_autocast, "sampler": gen_sampler, "sparse": gen_sparse}
+SECTIONS = {"sparse_layers": gen_sparse_layers, "slat_decoder": gen_slat_decoder, "sparse_vae": gen_sparse_vae, "vae_encode": gen_vae_encode, "vae": gen_vae, "raster": gen_raster, "vox2seq": gen_vox2seq, "dit": gen_dit, "dit_autocast": gen_dit_autocast, "align": gen_align, "sampler": gen_sampler, "sparse": gen_sparse}
 
 if __name__ == "__main__":
     install_stubs()
