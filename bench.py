@@ -441,6 +441,8 @@ def main():
     if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        for k_, v_ in (("MASTER_PORT", "29533"), ("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")):
+            os.environ.setdefault(k_, v_)          # GVF_BENCH_FORCE_DIST=1 without a launcher
         # the image exports NCCL_DEBUG=VERSION and RCCL printf()s its banner to stdout when the communicator is created:
         # point fd 1 at stderr while that happens, so that stdout carries the one JSON line only
         sys.stdout.flush()

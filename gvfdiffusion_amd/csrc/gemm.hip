@@ -121,6 +121,23 @@ __global__ __launch_bounds__(THREADS, BK == 32 ? 4 : (BM == 64 ? 3 : 2)) void ge
         dma16(w_src[i] + (size_t)(kt_) * BK, &SB(buf_, (i * 4 + wave) * 64));
 
     GVF_GEMM_STAGE(0, 0)
+    // Residual epilogue (x += gate * acc on the fp32 stream): fetch this thread's 4-float pieces of the C tile NOW, so that the
+    // 25 MB read of the stream overlaps the k-loop instead of sitting, latency-exposed, between the last MFMA and the store
+    // (64-row tiles only: 8 float4 = 32 VGPRs; the 128-row variant has no registers to spare at 4 waves per SIMD).
+    constexpr bool PRE_C = (EPI == GVF_EPI_RESID_F32) && BM == 64;
+    float4 cpre[PRE_C ? MI * 4 : 1];
+    const bool pre_ok = PRE_C && (N % 4 == 0) && (ldc % 4 == 0) && (gate == nullptr || gate_ld % 4 == 0) &&
+                        (bn + wn * 64 + (lane & 15) * 4 + 3 < N);
+    if (PRE_C && pre_ok) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int step = 0; step < 4; ++step) {
+                const int row = bm + wm * (BM / 2) + i * 16 + step * 4 + (lane >> 4);
+                cpre[i * 4 + step] = row < M ? *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(Cv) + (size_t)row * ldc + bn + wn * 64 + (lane & 15) * 4)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+    }
     __syncthreads();          // drains the DMA (vmcnt(0)) and publishes the tile
 
     for (int kt = 0; kt < KT; ++kt) {
@@ -200,7 +217,9 @@ __global__ __launch_bounds__(THREADS, BK == 32 ? 4 : (BM == 64 ? 3 : 2)) void ge
                     float4 g = make_float4(1.f, 1.f, 1.f, 1.f);
                     if (gate != nullptr) g = *reinterpret_cast<const float4*>(gate + (size_t)(row / rpg) * gate_ld + col0);
                     float4* c = reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + o);
-                    float4 x = *c;
+                    float4 x;
+                    if (PRE_C && pre_ok) x = cpre[i * 4 + step];
+                    else x = *c;
                     x.x += g.x * v.x; x.y += g.y * v.y; x.z += g.z * v.z; x.w += g.w * v.w;
                     *c = x;
                 }
