@@ -62,20 +62,37 @@ __device__ __forceinline__ void dma16(const unsigned short* g, uint4* l) {
 // 128-row tiling would leave the chip with fewer than two workgroups per CU (the DiT's N = 512 projections:
 // 384 tiles on 256 CUs) -- twice the workgroups, so twice the DMA tiles in flight to hide the load latency.
 // BK = 64 halves the number of k-tiles (barriers, DMA issue points) for the long-K projection (mlp.2, K = 2048).
-template <int EPI, int BM, int BK>
+// ALN: the A operand is LayerNorm(X) * s + t computed on the fly from the FP32 residual stream X (lda in floats): the row
+// statistics come as `n_part` partial (sum, sum of squares) pairs per row, written by the residual epilogue of the GEMM that
+// produced X (STATS below); s, t = per-column gain / shift of the row group (affine LayerNorm and / or adaLN modulate).  The
+// LayerNorm pass -- a 37.7 MB read + write and a launch per sub-layer of the DiT block -- disappears; the rounding point is
+// unchanged (the bf16 operand is the rounded normalised value, exactly what gvf_layernorm_modulate_bf16 writes).
+struct GemmLnArgs {
+    const float* stats;      // [M][n_part][2]
+    int n_part;
+    float eps;
+    const float* ln_w; const float* ln_b;       // [K] or null
+    const float* shift; const float* scale;     // row g of leading dimension mod_ld, or null
+    int mod_ld, rpg;
+};
+constexpr int ALN_MAX_K = 1024;
+
+template <int EPI, int BM, int BK, bool ALN = false>
 __global__ __launch_bounds__(THREADS, BK == 32 ? 4 : (BM == 64 ? 3 : 2)) void gemm_bf16_kernel(const unsigned short* __restrict__ A, int lda,
                                                             const unsigned short* __restrict__ W, int ldw,
                                                             const float* __restrict__ bias, void* __restrict__ Cv,
                                                             int ldc, int M, int N, int K,
                                                             const float* __restrict__ gate, int gate_ld, int rpg,
-                                                            int tiles_n) {
+                                                            int tiles_n, float* __restrict__ stats_out, GemmLnArgs ln) {
     constexpr int MI = BM / 32;                          // 16-row fragments per wave along M
     constexpr int CHUNKS_PER_ROW = BK / 8;               // 16-byte chunks per tile row
     constexpr int ROWS_PER_DMA = 64 / CHUNKS_PER_ROW;    // tile rows filled by one wave-wide DMA instruction
     constexpr int LOADS_A = BM * CHUNKS_PER_ROW / THREADS, LOADS_B = BN * CHUNKS_PER_ROW / THREADS;
     // one LDS block: A buffers, then W buffers; indexed through the array itself so that the address space stays
     // LDS for the DMA builtin (a pointer variable would be generic)
-    __shared__ uint4 smem[2 * (BM + BN) * CHUNKS_PER_ROW];
+    __shared__ uint4 smem[2 * (BM + BN) * CHUNKS_PER_ROW + (ALN ? 2 * ALN_MAX_K / 4 : 0)];
+    float* sS = reinterpret_cast<float*>(&smem[2 * (BM + BN) * CHUNKS_PER_ROW]);      // ALN: column gain / shift of this tile's row group
+    float* sT = sS + ALN_MAX_K;
 #define SA(buf_, idx_) smem[(buf_) * (BM * CHUNKS_PER_ROW) + (idx_)]
 #define SB(buf_, idx_) smem[2 * BM * CHUNKS_PER_ROW + (buf_) * (BN * CHUNKS_PER_ROW) + (idx_)]
 
@@ -115,11 +132,71 @@ __global__ __launch_bounds__(THREADS, BK == 32 ? 4 : (BM == 64 ? 3 : 2)) void ge
         w_src[i] = W + (size_t)gn * ldw + ((st_c ^ swz<CHUNKS_PER_ROW>(row)) * 8);
     }
 #define GVF_GEMM_STAGE(kt_, buf_)                                                                          \
-    _Pragma("unroll") for (int i = 0; i < LOADS_A; ++i)                                                      \
-        dma16(a_src[i] + (size_t)(kt_) * BK, &SA(buf_, (i * 4 + wave) * 64));                              \
+    if (!ALN) {                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < LOADS_A; ++i)                                                  \
+            dma16(a_src[i] + (size_t)(kt_) * BK, &SA(buf_, (i * 4 + wave) * 64));                          \
+    }                                                                                                      \
     _Pragma("unroll") for (int i = 0; i < LOADS_B; ++i)                                                      \
         dma16(w_src[i] + (size_t)(kt_) * BK, &SB(buf_, (i * 4 + wave) * 64));
 
+    // ---- ALN: register-staged A.  Thread owns chunk (st_c ^ swz) of LOADS_A rows per k-tile (the slots the DMA would fill)
+    const float* x_src[ALN ? LOADS_A : 1];
+    float ln_a[ALN ? LOADS_A : 1], ln_b2[ALN ? LOADS_A : 1];
+    float4 araw[ALN ? LOADS_A : 1][2];
+    int a_col[ALN ? LOADS_A : 1];
+    if (ALN) {
+        const float* X = reinterpret_cast<const float*>(A);
+        const int g = bm / ln.rpg;                              // the tile lies inside one row group (checked by the host)
+        for (int k = tid; k < K; k += THREADS) {
+            float sv = ln.ln_w != nullptr ? ln.ln_w[k] : 1.0f, tv = ln.ln_b != nullptr ? ln.ln_b[k] : 0.0f;
+            if (ln.scale != nullptr) {
+                const float sc = 1.0f + ln.scale[(size_t)g * ln.mod_ld + k];
+                sv *= sc; tv = tv * sc + ln.shift[(size_t)g * ln.mod_ld + k];
+            }
+            sS[k] = sv; sT[k] = tv;
+        }
+#pragma unroll
+        for (int i = 0; i < LOADS_A; ++i) {
+            const int row = (i * 4 + wave) * ROWS_PER_DMA + st_row;
+            const int gr = bm + row < M ? bm + row : M - 1;
+            a_col[i] = (st_c ^ swz<CHUNKS_PER_ROW>(row)) * 8;
+            x_src[i] = X + (size_t)gr * lda + a_col[i];
+            float sum = 0.f, sq = 0.f;
+            for (int pt = 0; pt < ln.n_part; ++pt) {
+                const float2 st2 = *reinterpret_cast<const float2*>(ln.stats + ((size_t)gr * ln.n_part + pt) * 2);
+                sum += st2.x; sq += st2.y;
+            }
+            const float mean = sum / (float)K;
+            const float var = fmaxf(sq / (float)K - mean * mean, 0.0f);
+            ln_a[i] = rsqrtf(var + ln.eps);
+            ln_b2[i] = -mean * ln_a[i];
+        }
+    }
+#define GVF_GEMM_LOADA(kt_)                                                                                \
+    if (ALN) {                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < LOADS_A; ++i) {                                                \
+            araw[i][0] = *reinterpret_cast<const float4*>(x_src[i] + (size_t)(kt_) * BK);                  \
+            araw[i][1] = *reinterpret_cast<const float4*>(x_src[i] + (size_t)(kt_) * BK + 4);              \
+        }                                                                                                  \
+    }
+#define GVF_GEMM_STOREA(kt_, buf_)                                                                         \
+    if (ALN) {                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < LOADS_A; ++i) {                                                \
+            const int kc_ = (kt_) * BK + a_col[i];                                                         \
+            const float4 s0 = *reinterpret_cast<const float4*>(sS + kc_), s1 = *reinterpret_cast<const float4*>(sS + kc_ + 4);   \
+            const float4 t0 = *reinterpret_cast<const float4*>(sT + kc_), t1 = *reinterpret_cast<const float4*>(sT + kc_ + 4);   \
+            const float4 x0 = araw[i][0], x1 = araw[i][1];                                                 \
+            const float a_ = ln_a[i], b_ = ln_b2[i];                                                       \
+            uint4 pk;                                                                                      \
+            pk.x = pack_bf16(__builtin_fmaf(__builtin_fmaf(x0.x, a_, b_), s0.x, t0.x), __builtin_fmaf(__builtin_fmaf(x0.y, a_, b_), s0.y, t0.y)); \
+            pk.y = pack_bf16(__builtin_fmaf(__builtin_fmaf(x0.z, a_, b_), s0.z, t0.z), __builtin_fmaf(__builtin_fmaf(x0.w, a_, b_), s0.w, t0.w)); \
+            pk.z = pack_bf16(__builtin_fmaf(__builtin_fmaf(x1.x, a_, b_), s1.x, t1.x), __builtin_fmaf(__builtin_fmaf(x1.y, a_, b_), s1.y, t1.y)); \
+            pk.w = pack_bf16(__builtin_fmaf(__builtin_fmaf(x1.z, a_, b_), s1.z, t1.z), __builtin_fmaf(__builtin_fmaf(x1.w, a_, b_), s1.w, t1.w)); \
+            SA(buf_, (i * 4 + wave) * 64 + lane) = pk;                                                     \
+        }                                                                                                  \
+    }
+
+    GVF_GEMM_LOADA(0)
     GVF_GEMM_STAGE(0, 0)
     // Residual epilogue (x += gate * acc on the fp32 stream): fetch this thread's 4-float pieces of the C tile NOW, so that the
     // 25 MB read of the stream overlaps the k-loop instead of sitting, latency-exposed, between the last MFMA and the store
@@ -138,11 +215,15 @@ __global__ __launch_bounds__(THREADS, BK == 32 ? 4 : (BM == 64 ? 3 : 2)) void ge
                                              : make_float4(0.f, 0.f, 0.f, 0.f);
             }
     }
+    if (ALN) {
+        __syncthreads();      // sS / sT complete
+        GVF_GEMM_STOREA(0, 0)
+    }
     __syncthreads();          // drains the DMA (vmcnt(0)) and publishes the tile
 
     for (int kt = 0; kt < KT; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < KT) { GVF_GEMM_STAGE(kt + 1, buf ^ 1) }   // lands while this tile is multiplied
+        if (kt + 1 < KT) { GVF_GEMM_STAGE(kt + 1, buf ^ 1) GVF_GEMM_LOADA(kt + 1) }   // land while this tile is multiplied
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ++ks) {
             bf16x8 af[MI], bfr[4];
@@ -163,9 +244,12 @@ __global__ __launch_bounds__(THREADS, BK == 32 ? 4 : (BM == 64 ? 3 : 2)) void ge
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
+        if (kt + 1 < KT) { GVF_GEMM_STOREA(kt + 1, buf ^ 1) }  // buffer buf ^ 1 was last read in iteration kt - 1 (barrier in between)
         __syncthreads();
     }
 #undef GVF_GEMM_STAGE
+#undef GVF_GEMM_LOADA
+#undef GVF_GEMM_STOREA
 #undef SA
 #undef SB
 
@@ -222,6 +306,13 @@ __global__ __launch_bounds__(THREADS, BK == 32 ? 4 : (BM == 64 ? 3 : 2)) void ge
                     else x = *c;
                     x.x += g.x * v.x; x.y += g.y * v.y; x.z += g.z * v.z; x.w += g.w * v.w;
                     *c = x;
+                    if (stats_out != nullptr) {     // LayerNorm statistics of the UPDATED stream: this wave's 64 columns of the row
+                        float rs = (x.x + x.y) + (x.z + x.w), rq = (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
+#pragma unroll
+                        for (int d = 1; d < 16; d <<= 1) { rs += __shfl_xor(rs, d, 64); rq += __shfl_xor(rq, d, 64); }
+                        if ((lane & 15) == 0)
+                            *reinterpret_cast<float2*>(stats_out + ((size_t)row * (2 * tiles_n) + tile_n * 2 + wn) * 2) = make_float2(rs, rq);
+                    }
                 }
             } else {
                 const float vv[4] = {v.x, v.y, v.z, v.w};
@@ -245,16 +336,19 @@ __global__ __launch_bounds__(THREADS, BK == 32 ? 4 : (BM == 64 ? 3 : 2)) void ge
 
 }  // namespace
 
-extern "C" int gvf_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc,
-                             int M, int N, int K, int epilogue, const float* gate, int gate_ld, int rows_per_group,
-                             void* stream_) {
+namespace {
+
+int launch_gemm(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M, int N, int K, int epilogue,
+                const float* gate, int gate_ld, int rows_per_group, float* stats_out, const GemmLnArgs* ln, hipStream_t stream) {
+    const bool aln = ln != nullptr;
     if (M < 0 || N <= 0 || K <= 0 || (K % 32) != 0 || (lda % 8) != 0 || (ldw % 8) != 0 || lda < K || ldw < K || ldc < N)
         return GVF_EINVAL;
     if (M == 0) return GVF_OK;
     if (!A || !W || !C) return GVF_EINVAL;
     if ((((uintptr_t)A) & 15) != 0 || (((uintptr_t)W) & 15) != 0) return GVF_EINVAL;
     if (epilogue == GVF_EPI_RESID_F32 && gate != nullptr && rows_per_group <= 0) return GVF_EINVAL;
-    hipStream_t stream = (hipStream_t)stream_;
+    if (stats_out != nullptr && (epilogue != GVF_EPI_RESID_F32 || (N % 128) != 0 || (ldc % 4) != 0 || (gate != nullptr && (gate_ld % 4) != 0)))
+        return GVF_EINVAL;
     (void)hipGetLastError();
     const int tiles_n = (N + BN - 1) / BN;
     const bool small = ((M + 127) / 128) * tiles_n < 512;      // fewer than two 128-row workgroups per CU: use 64-row tiles
@@ -264,20 +358,33 @@ extern "C" int gvf_gemm_bf16(const void* A, int lda, const void* W, int ldw, con
     const unsigned short* a = (const unsigned short*)A;
     const unsigned short* w = (const unsigned short*)W;
     const int rpg = rows_per_group > 0 ? rows_per_group : 1;
+    GemmLnArgs lnv = {};
+    if (aln) {
+        lnv = *ln;
+        // every tile must lie inside one row group (one (shift, scale) row), and s / t are staged for K <= ALN_MAX_K columns
+        if (K > ALN_MAX_K || lnv.n_part <= 0 || !lnv.stats || ((lnv.shift == nullptr) != (lnv.scale == nullptr)) ||
+            ((lnv.ln_w == nullptr) != (lnv.ln_b == nullptr)) || (lnv.scale != nullptr && (lnv.rpg <= 0 || (lnv.rpg % bm) != 0)))
+            return GVF_EINVAL;
+        if (lnv.rpg <= 0) lnv.rpg = 0x7fffffff;
+    }
     // (<<<>>> rather than hipLaunchKernelGGL: a parenthesised two-argument template-id inside the macro is only an
     // address-of expression and does not make clang emit the host stub of the instantiation)
     static const int bk_override = []() { const char* e = getenv("GVF_GEMM_BK"); return e ? atoi(e) : 0; }();   // tuning aid
     // 64-deep k-tiles only for the long-K projection (mlp.2, K = 2048: 47 -> 40 us).  On the K = 512 shapes they win
     // 4-7 % in a back-to-back micro-benchmark (scripts/bench_gemm.py, operands cache-hot) and LOSE 3 % of the whole
     // denoise step in place (8.65 -> 8.92 ms / NFE, A/B in one process): fewer resident workgroups per CU.
-    const bool bk64 = bk_override ? bk_override == 64 : K >= 1024;
+    const bool bk64 = !aln && (bk_override ? bk_override == 64 : K >= 1024);
+#define GVF_GEMM_ARGS a, lda, w, ldw, bias, C, ldc, M, N, K, gate, gate_ld, rpg, tiles_n, stats_out, lnv
 #define GVF_GEMM_LAUNCH(EPI_)                                                                                     \
-    if (bk64 && (K % 64) == 0) {                                                                                   \
-        if (small) gemm_bf16_kernel<EPI_, 64, 64><<<grid, block, 0, stream>>>(a, lda, w, ldw, bias, C, ldc, M, N, K, gate, gate_ld, rpg, tiles_n); \
-        else gemm_bf16_kernel<EPI_, 128, 64><<<grid, block, 0, stream>>>(a, lda, w, ldw, bias, C, ldc, M, N, K, gate, gate_ld, rpg, tiles_n); \
+    if (aln) {                                                                                                     \
+        if (small) gemm_bf16_kernel<EPI_, 64, 32, true><<<grid, block, 0, stream>>>(GVF_GEMM_ARGS);               \
+        else gemm_bf16_kernel<EPI_, 128, 32, true><<<grid, block, 0, stream>>>(GVF_GEMM_ARGS);                    \
+    } else if (bk64 && (K % 64) == 0) {                                                                            \
+        if (small) gemm_bf16_kernel<EPI_, 64, 64><<<grid, block, 0, stream>>>(GVF_GEMM_ARGS);                     \
+        else gemm_bf16_kernel<EPI_, 128, 64><<<grid, block, 0, stream>>>(GVF_GEMM_ARGS);                          \
     } else {                                                                                                       \
-        if (small) gemm_bf16_kernel<EPI_, 64, 32><<<grid, block, 0, stream>>>(a, lda, w, ldw, bias, C, ldc, M, N, K, gate, gate_ld, rpg, tiles_n); \
-        else gemm_bf16_kernel<EPI_, 128, 32><<<grid, block, 0, stream>>>(a, lda, w, ldw, bias, C, ldc, M, N, K, gate, gate_ld, rpg, tiles_n); \
+        if (small) gemm_bf16_kernel<EPI_, 64, 32><<<grid, block, 0, stream>>>(GVF_GEMM_ARGS);                     \
+        else gemm_bf16_kernel<EPI_, 128, 32><<<grid, block, 0, stream>>>(GVF_GEMM_ARGS);                          \
     }
     switch (epilogue) {
         case GVF_EPI_STORE_BF16: GVF_GEMM_LAUNCH(GVF_EPI_STORE_BF16) break;
@@ -287,6 +394,36 @@ extern "C" int gvf_gemm_bf16(const void* A, int lda, const void* W, int ldw, con
         default: return GVF_EINVAL;
     }
 #undef GVF_GEMM_LAUNCH
+#undef GVF_GEMM_ARGS
     GVF_CHECK_LAUNCH();
     return GVF_OK;
+}
+
+}  // namespace
+
+extern "C" int gvf_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc,
+                             int M, int N, int K, int epilogue, const float* gate, int gate_ld, int rows_per_group,
+                             void* stream_) {
+    return launch_gemm(A, lda, W, ldw, bias, C, ldc, M, N, K, epilogue, gate, gate_ld, rows_per_group, nullptr, nullptr, (hipStream_t)stream_);
+}
+
+extern "C" int gvf_gemm_stats_parts(int N) { return 2 * ((N + BN - 1) / BN); }
+
+extern "C" int gvf_gemm_bf16_resid_stats(const void* A, int lda, const void* W, int ldw, const float* bias, float* C, int ldc, int M, int N,
+                                         int K, const float* gate, int gate_ld, int rows_per_group, float* row_stats, void* stream_) {
+    if (!row_stats) return GVF_EINVAL;
+    return launch_gemm(A, lda, W, ldw, bias, C, ldc, M, N, K, GVF_EPI_RESID_F32, gate, gate_ld, rows_per_group, row_stats, nullptr,
+                       (hipStream_t)stream_);
+}
+
+extern "C" int gvf_gemm_ln_bf16(const float* X, int ldx, const float* row_stats, int n_part, float eps, const float* ln_w, const float* ln_b,
+                                const float* shift, const float* scale, int mod_ld, int rows_per_group, const void* W, int ldw,
+                                const float* bias, void* C, int ldc, int M, int N, int K, int epilogue, void* stream_) {
+    if (epilogue == GVF_EPI_RESID_F32) return GVF_EINVAL;
+    GemmLnArgs ln;
+    ln.stats = row_stats; ln.n_part = n_part; ln.eps = eps; ln.ln_w = ln_w; ln.ln_b = ln_b; ln.shift = shift; ln.scale = scale;
+    ln.mod_ld = mod_ld; ln.rpg = rows_per_group;
+    if ((ldx % 4) != 0) return GVF_EINVAL;
+    // launch_gemm's operand checks are written for bf16 rows (lda % 8): the fp32 rows need 16-byte alignment only
+    return launch_gemm(X, (ldx % 8) == 0 ? ldx : -1, W, ldw, bias, C, ldc, M, N, K, epilogue, nullptr, 0, 0, nullptr, &ln, (hipStream_t)stream_);
 }

@@ -173,6 +173,14 @@ class DiT(nn.Module):
         self._wcache = None       # bf16 weights, rebuilt when any parameter changes
         self._ctx_cache = {}      # step-invariant condition products
         self.use_graph = False    # replay the whole forward as one hipGraph (set by enable_graph)
+        import os
+        # LayerNorm folded into the GEMMs (see _forward): 0 = off (default), 1 = every projection, 2 = only the narrow ones
+        # (N <= 512).  Built, bit-checked (tests/test_dit_gpu.py::test_layernorm_folded_into_the_gemms) and measured on the
+        # denoise step: 7.35-7.49 / 7.67-7.91 / 7.35-7.48 ms per NFE for 0 / 1 / 2 -- the register-staged, re-normalised A
+        # operand costs the wide projections (12-16 column tiles re-normalise the same rows) more than the LayerNorm pass it
+        # removes (to_qkv 36.6 + 9.1 -> 50.7 us, mlp.0 50 + 9.1 -> 64.4 us; to_q 15.8 + 9.1 -> 20.7 us), and the statistics
+        # add 2.4 us to every residual GEMM.
+        self.fuse_layernorm = int(os.environ.get("GVF_DIT_FUSE_LN", "0"))
         self._graph = None
 
     @property
@@ -389,15 +397,37 @@ class DiT(nn.Module):
         else:
             h = torch.zeros((M, C), dtype=f32, device=dev)
         xb = dit_ops.cast_pad_bf16(x.reshape(M, Cin).float().contiguous(), dit_ops.pad64(Cin))
-        dit_ops.gemm_bf16(xb, *W["input"], h, dit_ops.EPI_RESID_F32)
-
-        hb = torch.empty((M, C), dtype=bf, device=dev)          # normalised operand
+        hb = torch.empty((M, C), dtype=bf, device=dev)          # attention-output scratch of the cross attentions
         qkv = torch.empty((M, 3 * C), dtype=bf, device=dev)
-        ab = torch.empty((M, C), dtype=bf, device=dev)          # attention output
+        ab = torch.empty((M, C), dtype=bf, device=dev)          # attention output / q projection
         hidden = torch.empty((M, int(C * self.mlp_ratio)), dtype=bf, device=dev)
         TN = T * N
         nb_self = B * T * H * ((N + 63) // 64) * 4096
         kv_self = (torch.empty(nb_self, dtype=torch.uint8, device=dev), torch.empty(nb_self, dtype=torch.uint8, device=dev))
+        # LayerNorm is folded into the GEMMs around it (csrc/gemm.hip): every update of the stream x = x + g * h also writes
+        # the row statistics of the new x, and the projection that follows normalises its A operand on the fly
+        fuse_ln = self.fuse_layernorm != 0 and TN % 128 == 0 and C % 128 == 0 and C <= 1024
+        fuse_max_n = 1 << 30 if self.fuse_layernorm == 1 else 512
+        n_part = dit_ops.gemm_stats_parts(C)
+        stats = torch.empty((M, n_part, 2), dtype=f32, device=dev) if fuse_ln else None
+
+        def resid(a_, wb, gate=None):
+            """h += gate * (a_ @ W^T + b)  (+ statistics of the new h)"""
+            kw = dict(gate=gate, gate_ld=mod_ld, rows_per_group=TN) if gate is not None else {}
+            if fuse_ln:
+                dit_ops.gemm_resid_stats(a_, wb[0], wb[1], h, stats, **kw)
+            else:
+                dit_ops.gemm_bf16(a_, wb[0], wb[1], h, dit_ops.EPI_RESID_F32, **kw)
+
+        def ln_gemm(wb, out, epi, ln_w=None, ln_b=None, shift=None, scale=None):
+            """out = epi((LN(h) * s + t) @ W^T + b)"""
+            if fuse_ln and wb[0].shape[0] <= fuse_max_n:
+                dit_ops.gemm_ln_bf16(h, stats, n_part, wb[0], wb[1], out, epi, 1e-6, ln_w, ln_b, shift, scale, mod_ld, TN)
+            else:
+                dit_ops.layernorm_modulate_bf16(h, hb, 1e-6, ln_w, ln_b, shift, scale, mod_ld, TN)
+                dit_ops.gemm_bf16(hb, wb[0], wb[1], out, epi)
+
+        resid(xb, W["input"])           # h = pos + input_layer(x)
 
         def mview(off):                                       # (B,) rows of `mod`, columns [off, off+C)
             return mod[:, off:]
@@ -406,44 +436,38 @@ class DiT(nn.Module):
             o = W["mod_offs"][i]
             sh_s, sc_s, g_s, sh_m, sc_m, g_m = (mview(o + k * C) for k in range(6))
             # -- spatial self attention over N
-            dit_ops.layernorm_modulate_bf16(h, hb, 1e-6, None, None, sh_s, sc_s, mod_ld, TN)
             a = b["spatial_self_attn"]
-            dit_ops.gemm_bf16(hb, *a["qkv"], qkv, dit_ops.EPI_STORE_BF16)
+            ln_gemm(a["qkv"], qkv, dit_ops.EPI_STORE_BF16, shift=sh_s, scale=sc_s)
             # K (RMS-normed, pre-scaled) and V^T of this step's projection into the tiled image, then the tiled-cache kernel
             dit_ops.attention_pack_kv(qkv, B * T, N, H, C, 2 * C, gamma_k=a["gk"], out=kv_self)
             dit_ops.attention_tiled_bf16(qkv, kv_self[0], kv_self[1], ab, B * T, 1, N, N, H, (N * 3 * C, 0, 3 * C), (N * C, 0, C), 1, 0,
                                          gamma_q=a["gq"])
-            dit_ops.gemm_bf16(ab, *a["out"], h, dit_ops.EPI_RESID_F32, gate=g_s, gate_ld=mod_ld, rows_per_group=TN)
+            resid(ab, a["out"], g_s)
             # -- temporal self attention over T (strided views, no transposes)
             if not self.no_temporal_attn:
                 sh_t, sc_t, g_t = (mview(o + (6 + k) * C) for k in range(3))
-                dit_ops.layernorm_modulate_bf16(h, hb, 1e-6, None, None, sh_t, sc_t, mod_ld, TN)
                 a = b["temporal_self_attn"]
-                dit_ops.gemm_bf16(hb, *a["qkv"], qkv, dit_ops.EPI_STORE_BF16)
+                ln_gemm(a["qkv"], qkv, dit_ops.EPI_STORE_BF16, shift=sh_t, scale=sc_t)
                 st = (TN * 3 * C, 3 * C, N * 3 * C)           # outer = sample, inner = token, seq = frame
                 dit_ops.attention_bf16(qkv, qkv[:, C:], qkv[:, 2 * C:], ab, B, N, T, T, H, st, st, st, (TN * C, C, N * C), a["gq"], a["gk"])
-                dit_ops.gemm_bf16(ab, *a["out"], h, dit_ops.EPI_RESID_F32, gate=g_t, gate_ld=mod_ld, rows_per_group=TN)
+                resid(ab, a["out"], g_t)
             # -- image cross attention (affine LayerNorm, cached K/V)
             a = b["image_cross_attn"]
-            dit_ops.layernorm_modulate_bf16(h, hb, 1e-6, b["n3"][0], b["n3"][1])
-            dit_ops.gemm_bf16(hb, *a["q"], ab, dit_ops.EPI_STORE_BF16)
+            ln_gemm(a["q"], ab, dit_ops.EPI_STORE_BF16, ln_w=b["n3"][0], ln_b=b["n3"][1])
             kt, vt = ctx["kv_img"][i]
             dit_ops.attention_tiled_bf16(ab, kt, vt, hb, B * T, 1, N, Li, H, (N * C, 0, C), (N * C, 0, C), 1, 0, gamma_q=a["gq"])
-            dit_ops.gemm_bf16(hb, *a["out"], h, dit_ops.EPI_RESID_F32)
+            resid(hb, a["out"])
             # -- static cross attention: K/V shared by the T frames of a sample (inner stride 0)
             a = b["static_cross_attn"]
-            dit_ops.layernorm_modulate_bf16(h, hb, 1e-6, b["n4"][0], b["n4"][1])
-            dit_ops.gemm_bf16(hb, *a["q"], ab, dit_ops.EPI_STORE_BF16)
+            ln_gemm(a["q"], ab, dit_ops.EPI_STORE_BF16, ln_w=b["n4"][0], ln_b=b["n4"][1])
             kt, vt = ctx["kv_st"][i]
             dit_ops.attention_tiled_bf16(ab, kt, vt, hb, B, T, N, Ls, H, (TN * C, N * C, C), (TN * C, N * C, C), 1, 0, gamma_q=a["gq"])
-            dit_ops.gemm_bf16(hb, *a["out"], h, dit_ops.EPI_RESID_F32)
+            resid(hb, a["out"])
             # -- MLP
-            dit_ops.layernorm_modulate_bf16(h, hb, 1e-6, None, None, sh_m, sc_m, mod_ld, TN)
-            dit_ops.gemm_bf16(hb, *b["fc1"], hidden, dit_ops.EPI_GELU_BF16)
-            dit_ops.gemm_bf16(hidden, *b["fc2"], h, dit_ops.EPI_RESID_F32, gate=g_m, gate_ld=mod_ld, rows_per_group=TN)
+            ln_gemm(b["fc1"], hidden, dit_ops.EPI_GELU_BF16, shift=sh_m, scale=sc_m)
+            resid(hidden, b["fc2"], g_m)
 
         o = W["mod_offs"][-1]
-        dit_ops.layernorm_modulate_bf16(h, hb, 1e-6, None, None, mview(o), mview(o + C), mod_ld, TN)
         y = torch.empty((M, self.out_channels), dtype=f32, device=dev)
-        dit_ops.gemm_bf16(hb, *W["final"], y, dit_ops.EPI_STORE_F32)
+        ln_gemm(W["final"], y, dit_ops.EPI_STORE_F32, shift=mview(o), scale=mview(o + C))
         return y.reshape(B, T, N, self.out_channels).to(x.dtype if x.dtype.is_floating_point else f32)

@@ -11,6 +11,9 @@ EPI_STORE_BF16, EPI_GELU_BF16, EPI_STORE_F32, EPI_RESID_F32 = 0, 1, 2, 3
 
 _lib.register({
     "gvf_gemm_bf16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
+    "gvf_gemm_stats_parts": (_i, [_i]),
+    "gvf_gemm_bf16_resid_stats": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
+    "gvf_gemm_ln_bf16": (_i, [_vp, _i, _vp, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "gvf_attn_fwd_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i] + [ctypes.POINTER(_i64)] * 4 + [_i, _vp, _vp, _f, _vp]),
     "gvf_attn_varlen_fwd_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i] + [ctypes.POINTER(_i64)] * 4 + [_vp, _vp, _f, _vp]),
     "gvf_attn_pack_kv_bf16": (_i, [_vp, _i, _i64, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
@@ -56,6 +59,36 @@ def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, epilogu
     assert w.shape[1] == K and out.stride(-1) == 1
     _lib.check(_lib.lib().gvf_gemm_bf16(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), M, N, K,
                                         epilogue, _p(gate), gate_ld, rows_per_group, _stream(a)), "gvf_gemm_bf16")
+    return out
+
+
+def gemm_stats_parts(n: int) -> int:
+    return int(_lib.lib().gvf_gemm_stats_parts(int(n)))
+
+
+def gemm_resid_stats(a, w, bias, x, stats, gate=None, gate_ld=0, rows_per_group=0):
+    """x (M, N) fp32 += gate * (a @ w^T + bias), and stats (M, parts(N), 2) <- per-row partial (sum, sum of squares) of the
+    UPDATED x (input of gemm_ln_bf16)."""
+    _lib.require_cuda(a, w, x, stats)
+    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.dtype == torch.float32 and stats.dtype == torch.float32
+    M, K = a.shape
+    N = w.shape[0]
+    assert stats.is_contiguous() and stats.numel() >= M * gemm_stats_parts(N) * 2
+    _lib.check(_lib.lib().gvf_gemm_bf16_resid_stats(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(x), x.stride(0), M, N, K,
+                                                    _p(gate), gate_ld, rows_per_group, _p(stats), _stream(a)), "gvf_gemm_bf16_resid_stats")
+    return x
+
+
+def gemm_ln_bf16(x, stats, n_part, w, bias, out, epilogue, eps=1e-6, ln_w=None, ln_b=None, shift=None, scale=None, mod_ld=0,
+                 rows_per_group=0):
+    """out <- epilogue((LayerNorm(x) * s + t) @ w^T + bias) with LN statistics from gemm_resid_stats; see include/gvf_dit.h."""
+    _lib.require_cuda(x, stats, w, out)
+    assert x.dtype == torch.float32 and w.dtype == torch.bfloat16 and x.stride(1) == 1
+    M, K = x.shape
+    N = w.shape[0]
+    _lib.check(_lib.lib().gvf_gemm_ln_bf16(_p(x), x.stride(0), _p(stats), int(n_part), float(eps), _p(ln_w), _p(ln_b), _p(shift), _p(scale),
+                                           int(mod_ld), int(rows_per_group), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), M, N, K,
+                                           int(epilogue), _stream(x)), "gvf_gemm_ln_bf16")
     return out
 
 

@@ -34,6 +34,23 @@ int gvf_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* b
                   int M, int N, int K, int epilogue, const float* gate, int gate_ld, int rows_per_group,
                   void* stream);
 
+/* ---- LayerNorm folded into the GEMMs around it (the DiT block: x = x + g * h, then LN(x) feeds the next projection) ----
+ * gvf_gemm_bf16_resid_stats = gvf_gemm_bf16 with GVF_EPI_RESID_F32 that ALSO writes, per row of the updated fp32 stream,
+ * gvf_gemm_stats_parts(N) partial (sum, sum of squares) pairs (one per 64-column slice; row_stats f32 [M][parts][2]; N a
+ * multiple of 128).  gvf_gemm_ln_bf16 consumes them:  C = epilogue( (LN(X) * s + t) W^T + bias )  with X the fp32 stream
+ * (ldx floats, K = its width <= 1024), LN over the K columns from the partial statistics (eps), s / t the optional affine
+ * (ln_w, ln_b) and / or adaLN (1 + scale[g], shift[g]; g = row / rows_per_group, rows_per_group a multiple of 128) terms.
+ * The bf16 operand is the rounded normalised value -- exactly what gvf_layernorm_modulate_bf16 would have written --
+ * but the 37.7 MB LayerNorm pass and its launch are gone.  epilogue: STORE_BF16, GELU_BF16 or STORE_F32. */
+int gvf_gemm_stats_parts(int N);
+int gvf_gemm_bf16_resid_stats(const void* A, int lda, const void* W, int ldw, const float* bias, float* C, int ldc,
+                              int M, int N, int K, const float* gate, int gate_ld, int rows_per_group, float* row_stats,
+                              void* stream);
+int gvf_gemm_ln_bf16(const float* X, int ldx, const float* row_stats, int n_part, float eps, const float* ln_w,
+                     const float* ln_b, const float* shift, const float* scale, int mod_ld, int rows_per_group,
+                     const void* W, int ldw, const float* bias, void* C, int ldc, int M, int N, int K, int epilogue,
+                     void* stream);
+
 /* softmax(q k^T * scale) v, head_dim 32 or 64, no mask, scale > 0.  Batch index = (outer, inner); every tensor
  * takes 4 strides in elements {outer, inner, seq, head}: element (o,i,l,h,c) sits at
  * o*s[0] + i*s[1] + l*s[2] + h*s[3] + c, so the q/k/v slices of a packed qkv / kv projection, a K/V set
