@@ -97,3 +97,81 @@ def test_sample_decode_render(cuda):
     psnr = 10 * math.log10(1.0 / max(mse, 1e-20))
     print(f"pipeline: delta rel-L2 {rel:.2e}, frame PSNR {psnr:.1f} dB")
     assert psnr > TOL_FRAME_PSNR_DB, psnr
+
+
+def test_full_size_adaptive_chain_matches_fp32_oracle_chain(cuda):
+    """BASELINE configs[3] at its named sizes: configs/diffusion.yml DiT (B=1, T=24, 1370 + 4096 context tokens), adaptive
+    DPM-Solver++ (steps=100 as inference_dpm_latent.py), released motion-VAE config decoding 262 144 Gaussians x 24 frames,
+    24-frame 800x800 render -- the HIP chain against the fp32 torch oracles (oracle/dit_ref.py, oracle/vae_ref.py, run ON the
+    device as checkers; the rasteriser is pinned against oracle/rast_oracle.c at this size by tests/test_rast_gpu.py).  The
+    adaptive solver's accept / reject decisions are data dependent (model/dpmsolver.py:973-1027): the NFE counts are reported
+    and must agree to within two trial steps; samples, deltas and frames must agree."""
+    from gvfdiffusion_amd import synthetic
+    from gvfdiffusion_amd.model.autoencoder import GSKLTemporalVariationalAutoEncoder
+    from gvfdiffusion_amd.model.dit import DiT
+    from gvfdiffusion_amd.model.dpmsolver import DPM_Solver, NoiseScheduleVP, model_wrapper
+    from gvfdiffusion_amd.model.gaussian_diffusion import create_gaussian_diffusion
+    from gvfdiffusion_amd.renderers import GaussianRenderer
+    from oracle import dit_ref, vae_ref
+
+    T, P, S = 24, 262_144, 800
+    man = json.load(open(os.path.join(GOLD, "dit_manifest.json")))
+    sd = synthetic.dit_state_dict(man["state_dict"], seed=0)
+    dit = DiT(**man["config"])
+    dit.load_state_dict(sd, strict=True)
+    dit = dit.to(cuda).eval()
+    sdc = {k: v.to(cuda) for k, v in sd.items()}
+    inp = {k: v.to(cuda) for k, v in synthetic.dit_inputs(B=1, T=T, seed=1).items()}
+    xT = inp.pop("x"); inp.pop("t")
+    ns = NoiseScheduleVP("discrete", betas=torch.from_numpy(create_gaussian_diffusion(noise_schedule="cosine", predict_type="v").betas))
+
+    vman = json.load(open(os.path.join(GOLD, "vae_manifest.json")))
+    vcfg = dict(vman["config"], num_timesteps=T)
+    torch.manual_seed(0)
+    vae = GSKLTemporalVariationalAutoEncoder(**vcfg)
+    with torch.no_grad():
+        for p in vae.parameters():
+            p.copy_(torch.randn_like(p) * (1.0 / p.shape[1] ** 0.5 if p.dim() == 2 else 0.05))
+        vae.to_outputs.weight.mul_(0.02)
+    vsd = {k: v.detach().clone().to(cuda) for k, v in vae.state_dict().items()}
+    vae = vae.to(cuda)
+    attrs = synthetic.random_gaussians(P, sh_degree=0, seed=0)
+    gm = synthetic.gaussian_model_from(attrs, 0, cuda)
+    queries = torch.cat([gm._xyz, gm._features_dc.reshape(P, 3), gm._scaling, gm._rotation, gm._opacity], 1)[None].float()
+
+    def sample(net):
+        calls = {"n": 0}
+
+        def counted(x, t, **kw):
+            calls["n"] += 1
+            return net(x, t, **kw)
+        mf = model_wrapper(counted, ns, model_type="v", model_kwargs={}, guidance_type="classifier-free", guidance_scale=1.0,
+                           guidance_scale2=1.0, condition=inp, unconditional_condition=None)
+        x0 = DPM_Solver(mf, ns, algorithm_type="dpmsolver++").sample(xT, steps=100, t_start=1.0, t_end=1 / 1000, order=2,
+                                                                    skip_type="time_uniform", method="adaptive")
+        return x0, calls["n"]
+
+    with torch.no_grad():
+        x_hip, n_hip = sample(dit)
+        x_ref, n_ref = sample(lambda x, t, **kw: dit_ref.dit_forward(sdc, man["config"], x, t, kw["cond_images"], kw["static_latent"],
+                                                                     kw["deformation_position_xyz"], precision="fp32"))
+        r_x = float((x_hip - x_ref).norm() / x_ref.norm())
+        lat_h = (x_hip * 1.5 + 0.02).reshape(T, x_hip.shape[2], x_hip.shape[3])
+        lat_r = (x_ref * 1.5 + 0.02).reshape(T, x_ref.shape[2], x_ref.shape[3])
+        d_hip = vae.decode(lat_h, queries).float()
+        d_ref = torch.cat([vae_ref.vae_decode(vsd, vcfg, lat_r, queries[:, s:s + 16384], T, "fp32") for s in range(0, P, 16384)], dim=2)
+        r_d = float((d_hip - d_ref).norm() / d_ref.norm())
+        rend = GaussianRenderer({"resolution": S, "near": synthetic.NEAR, "far": synthetic.FAR, "ssaa": 1, "bg_color": (1, 1, 1)})
+        rend.pipe.use_mip_gaussian = True
+        rend.pipe.kernel_size = synthetic.KERNEL_2D
+        ext = torch.stack([synthetic.orbit_w2c(360.0 * f / T, 15.0) for f in range(T)]).to(cuda)
+        K = synthetic.intrinsics().to(cuda)
+        f_hip = rend.render_frames(gm, ext, K, delta_pc=d_hip[0].contiguous()).rgb
+        f_ref = rend.render_frames(gm, ext, K, delta_pc=d_ref[0].contiguous()).rgb
+    mse = float(((f_hip - f_ref) ** 2).mean())
+    psnr = 10 * math.log10(1.0 / max(mse, 1e-20))
+    print(f"configs[3] full size: adaptive NFE hip {n_hip} / fp32 oracle {n_ref}; sample rel_l2 {r_x:.2e}; delta rel_l2 {r_d:.2e}; "
+          f"frame PSNR {psnr:.1f} dB" + ("" if n_hip == n_ref else "  <- the bf16 denoiser moved an accept / reject decision"))
+    assert torch.isfinite(f_hip).all() and f_hip.shape == (T, 3, S, S)
+    assert abs(n_hip - n_ref) <= 4
+    assert r_x < 5e-2 and r_d < 5e-2 and psnr > 40.0
