@@ -21,7 +21,7 @@ namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-constexpr int BN = 128;                             // BM (128 or 64) and BK (32 or 64) are template parameters
+constexpr int BN_DEFAULT = 128;                     // BM (128 or 64), BK (32 or 64) and BN (128 or 192) are template parameters
 constexpr int THREADS = 256;
 // chunk swizzle, slot = chunk ^ swz(row): conflict-free for the ds_read_b128 lane groups ({0-3,12-15,20-27},
 // {4-11,16-19,28-31}, ...).  64-byte rows (BK = 32): 3 for rows 8..15 of each 16-row group, else 0; 128-byte rows
@@ -77,14 +77,17 @@ struct GemmLnArgs {
 };
 constexpr int ALN_MAX_K = 1024;
 
-template <int EPI, int BM, int BK, bool ALN = false>
-__global__ __launch_bounds__(THREADS, BK == 32 ? 4 : (BM == 64 ? 3 : 2)) void gemm_bf16_kernel(const unsigned short* __restrict__ A, int lda,
+// BN = 192 (2x2 waves of 64x96): for shapes whose 128-wide tiling leaves a mostly empty last round of workgroups -- the
+// DiT's to_qkv (M = 12288, N = 1536): 1152 tiles of 128x128 on 1024 resident slots against 768 tiles of 128x192 on 768.
+template <int EPI, int BM, int BK, bool ALN = false, int BN = BN_DEFAULT>
+__global__ __launch_bounds__(THREADS, BN == 192 ? 3 : (BK == 32 ? 4 : (BM == 64 ? 3 : 2))) void gemm_bf16_kernel(const unsigned short* __restrict__ A, int lda,
                                                             const unsigned short* __restrict__ W, int ldw,
                                                             const float* __restrict__ bias, void* __restrict__ Cv,
                                                             int ldc, int M, int N, int K,
                                                             const float* __restrict__ gate, int gate_ld, int rpg,
                                                             int tiles_n, float* __restrict__ stats_out, GemmLnArgs ln) {
     constexpr int MI = BM / 32;                          // 16-row fragments per wave along M
+    constexpr int NJ = BN / 32;                          // 16-column fragments per wave along N (wave tile = BM/2 x BN/2)
     constexpr int CHUNKS_PER_ROW = BK / 8;               // 16-byte chunks per tile row
     constexpr int ROWS_PER_DMA = 64 / CHUNKS_PER_ROW;    // tile rows filled by one wave-wide DMA instruction
     constexpr int LOADS_A = BM * CHUNKS_PER_ROW / THREADS, LOADS_B = BN * CHUNKS_PER_ROW / THREADS;
@@ -104,11 +107,11 @@ __global__ __launch_bounds__(THREADS, BK == 32 ? 4 : (BM == 64 ? 3 : 2)) void ge
     const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
     const int bm = tile_m * BM, bn = tile_n * BN;
 
-    f32x4 acc[MI][4];
+    f32x4 acc[MI][NJ];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int KT = K / BK;
 
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(THREADS, BK == 32 ? 4 : (BM == 64 ? 3 : 2)) void ge
     // Residual epilogue (x += gate * acc on the fp32 stream): fetch this thread's 4-float pieces of the C tile NOW, so that the
     // 25 MB read of the stream overlaps the k-loop instead of sitting, latency-exposed, between the last MFMA and the store
     // (64-row tiles only: 8 float4 = 32 VGPRs; the 128-row variant has no registers to spare at 4 waves per SIMD).
-    constexpr bool PRE_C = (EPI == GVF_EPI_RESID_F32) && BM == 64;
+    constexpr bool PRE_C = (EPI == GVF_EPI_RESID_F32) && BM == 64 && BN == 128;
     float4 cpre[PRE_C ? MI * 4 : 1];
     const bool pre_ok = PRE_C && (N % 4 == 0) && (ldc % 4 == 0) && (gate == nullptr || gate_ld % 4 == 0) &&
                         (bn + wn * 64 + (lane & 15) * 4 + 3 < N);
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(THREADS, BK == 32 ? 4 : (BM == 64 ? 3 : 2)) void ge
         if (kt + 1 < KT) { GVF_GEMM_STAGE(kt + 1, buf ^ 1) GVF_GEMM_LOADA(kt + 1) }   // land while this tile is multiplied
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ++ks) {
-            bf16x8 af[MI], bfr[4];
+            bf16x8 af[MI], bfr[NJ];
             const int kc = ks * 4 + (lane >> 4);
 #pragma unroll
             for (int f = 0; f < MI; ++f) {
@@ -234,14 +237,14 @@ __global__ __launch_bounds__(THREADS, BK == 32 ? 4 : (BM == 64 ? 3 : 2)) void ge
                 af[f] = __builtin_bit_cast(bf16x8, SA(buf, ar * CHUNKS_PER_ROW + (kc ^ swz<CHUNKS_PER_ROW>(ar))));
             }
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                const int br = wn * 64 + f * 16 + (lane & 15);
+            for (int f = 0; f < NJ; ++f) {
+                const int br = wn * (BN / 2) + f * 16 + (lane & 15);
                 bfr[f] = __builtin_bit_cast(bf16x8, SB(buf, br * CHUNKS_PER_ROW + (kc ^ swz<CHUNKS_PER_ROW>(br))));
             }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < KT) { GVF_GEMM_STOREA(kt + 1, buf ^ 1) }  // buffer buf ^ 1 was last read in iteration kt - 1 (barrier in between)
@@ -264,8 +267,14 @@ __global__ __launch_bounds__(THREADS, BK == 32 ? 4 : (BM == 64 ? 3 : 2)) void ge
     __syncthreads();                                           // every wave is done reading the operand tiles
     const int col_l = lane & 15, row_l = (lane >> 4) * 4;
     const int er = lane >> 4, ec = (lane & 15) * 4;            // read-back role: row er (+4 per step), columns ec..ec+3
-    const int col0 = bn + wn * 64 + ec;
     const bool vec_ok = (N % 4 == 0) && (ldc % 4 == 0) && (EPI != GVF_EPI_RESID_F32 || gate == nullptr || gate_ld % 4 == 0);
+    constexpr int NCG = (NJ * 16 + 63) / 64;                   // 64-column groups of the wave tile (BN = 192: 64 + 32 columns)
+#pragma unroll
+  for (int cg = 0; cg < NCG; ++cg) {
+    constexpr int dummy_ = 0; (void)dummy_;
+    const int gcols = (NJ * 16 - cg * 64) < 64 ? (NJ * 16 - cg * 64) : 64;
+    const bool lane_on = ec < gcols;                            // the narrow last group leaves the upper lanes idle
+    const int col0 = lane_on ? bn + wn * (BN / 2) + cg * 64 + ec : N;
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (bias != nullptr) {
         if (vec_ok && col0 + 3 < N) bias4 = *reinterpret_cast<const float4*>(bias + col0);
@@ -279,7 +288,8 @@ __global__ __launch_bounds__(THREADS, BK == 32 ? 4 : (BM == 64 ? 3 : 2)) void ge
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ep[(row_l + r) * EP_LD + j * 16 + col_l] = acc[i][j][r];
+            for (int r = 0; r < 4; ++r)
+                if (cg * 4 + j < NJ) ep[(row_l + r) * EP_LD + j * 16 + col_l] = acc[i][cg * 4 + j][r];
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int step = 0; step < 4; ++step) {
@@ -332,6 +342,7 @@ __global__ __launch_bounds__(THREADS, BK == 32 ? 4 : (BM == 64 ? 3 : 2)) void ge
         }
         __builtin_amdgcn_wave_barrier();
     }
+  }
 }
 
 }  // namespace
@@ -350,7 +361,7 @@ int launch_gemm(const void* A, int lda, const void* W, int ldw, const float* bia
     if (stats_out != nullptr && (epilogue != GVF_EPI_RESID_F32 || (N % 128) != 0 || (ldc % 4) != 0 || (gate != nullptr && (gate_ld % 4) != 0)))
         return GVF_EINVAL;
     (void)hipGetLastError();
-    const int tiles_n = (N + BN - 1) / BN;
+    const int tiles_n = (N + BN_DEFAULT - 1) / BN_DEFAULT;
     const bool small = ((M + 127) / 128) * tiles_n < 512;      // fewer than two 128-row workgroups per CU: use 64-row tiles
     const int bm = small ? 64 : 128;
     const int tiles_m = (M + bm - 1) / bm;
@@ -375,8 +386,19 @@ int launch_gemm(const void* A, int lda, const void* W, int ldw, const float* bia
     // denoise step in place (8.65 -> 8.92 ms / NFE, A/B in one process): fewer resident workgroups per CU.
     const bool bk64 = !aln && (bk_override ? bk_override == 64 : K >= 1024);
 #define GVF_GEMM_ARGS a, lda, w, ldw, bias, C, ldc, M, N, K, gate, gate_ld, rpg, tiles_n, stats_out, lnv
+    // 192-wide tiles: when N is a multiple of 192 and the 128-wide grid would spill a small tail round over the resident slots
+    // (measured on the denoise step: to_qkv at B = 1 -- 1152 tiles = one full round of the 1024 resident slots + a 12 % tail --
+    // gains 1.4 % of the step; at B = 3 -- 3456 tiles, tail 37 % of a round -- the wider tile loses 1.7 %.)
+    const int tiles128 = tiles_m * tiles_n, tiles192 = tiles_m * (N / 192), tail128 = tiles128 % 1024, tail192 = tiles192 % 768;
+    const bool wide = !aln && !small && !bk64 && stats_out == nullptr && (N % 192) == 0 && epilogue != GVF_EPI_RESID_F32 &&
+                      tail128 > 0 && tail128 <= 256 && (tail192 == 0 || tail192 > 384) &&
+                      [] { const char* e = getenv("GVF_GEMM_BN192"); return e == nullptr || atoi(e) != 0; }();
+    const dim3 grid_w(tiles_m * (N / 192 > 0 ? N / 192 : 1));
+    const int tiles_n_w = N / 192;
 #define GVF_GEMM_LAUNCH(EPI_)                                                                                     \
-    if (aln) {                                                                                                     \
+    if (wide) {                                                                                                    \
+        gemm_bf16_kernel<EPI_, 128, 32, false, 192><<<grid_w, block, 0, stream>>>(a, lda, w, ldw, bias, C, ldc, M, N, K, gate, gate_ld, rpg, tiles_n_w, stats_out, lnv); \
+    } else if (aln) {                                                                                                     \
         if (small) gemm_bf16_kernel<EPI_, 64, 32, true><<<grid, block, 0, stream>>>(GVF_GEMM_ARGS);               \
         else gemm_bf16_kernel<EPI_, 128, 32, true><<<grid, block, 0, stream>>>(GVF_GEMM_ARGS);                    \
     } else if (bk64 && (K % 64) == 0) {                                                                            \
@@ -407,7 +429,7 @@ extern "C" int gvf_gemm_bf16(const void* A, int lda, const void* W, int ldw, con
     return launch_gemm(A, lda, W, ldw, bias, C, ldc, M, N, K, epilogue, gate, gate_ld, rows_per_group, nullptr, nullptr, (hipStream_t)stream_);
 }
 
-extern "C" int gvf_gemm_stats_parts(int N) { return 2 * ((N + BN - 1) / BN); }
+extern "C" int gvf_gemm_stats_parts(int N) { return 2 * ((N + BN_DEFAULT - 1) / BN_DEFAULT); }
 
 extern "C" int gvf_gemm_bf16_resid_stats(const void* A, int lda, const void* W, int ldw, const float* bias, float* C, int ldc, int M, int N,
                                          int K, const float* gate, int gate_ld, int rows_per_group, float* row_stats, void* stream_) {

@@ -40,7 +40,8 @@ def _ref_autocast_err(tag):
     return float(g[f"{tag}_rel_l2_bf16"]), float(g[f"{tag}_rel_l2_fp16"])
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 200, 128), (128, 128, 64), (1, 1536, 512), (1000, 16, 512), (257, 3072, 2048)])
+@pytest.mark.parametrize("M,N,K", [(300, 200, 128), (128, 128, 64), (1, 1536, 512), (1000, 16, 512), (257, 3072, 2048),
+                                   (8200, 1536, 512), (4100, 3072, 64)])      # the last two take the 192-wide tiles
 def test_gemm_epilogues(cuda, M, N, K):
     g = torch.Generator().manual_seed(M + N + K)
     a = bf(torch.randn((M, K), generator=g)).to(cuda)
