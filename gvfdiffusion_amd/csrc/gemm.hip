@@ -389,10 +389,10 @@ int launch_gemm(const void* A, int lda, const void* W, int ldw, const float* bia
     // 192-wide tiles: when N is a multiple of 192 and the 128-wide grid would spill a small tail round over the resident slots
     // (measured on the denoise step: to_qkv at B = 1 -- 1152 tiles = one full round of the 1024 resident slots + a 12 % tail --
     // gains 1.4 % of the step; at B = 3 -- 3456 tiles, tail 37 % of a round -- the wider tile loses 1.7 %.)
+    static const int bn192_mode = [] { const char* e = getenv("GVF_GEMM_BN192"); return e == nullptr ? 1 : atoi(e); }();   // 0 off, 1 auto, 2 always
     const int tiles128 = tiles_m * tiles_n, tiles192 = tiles_m * (N / 192), tail128 = tiles128 % 1024, tail192 = tiles192 % 768;
     const bool wide = !aln && !small && !bk64 && stats_out == nullptr && (N % 192) == 0 && epilogue != GVF_EPI_RESID_F32 &&
-                      tail128 > 0 && tail128 <= 256 && (tail192 == 0 || tail192 > 384) &&
-                      [] { const char* e = getenv("GVF_GEMM_BN192"); return e == nullptr || atoi(e) != 0; }();
+                      bn192_mode != 0 && (bn192_mode == 2 || (tail128 > 0 && tail128 <= 256 && (tail192 == 0 || tail192 > 384)));
     const dim3 grid_w(tiles_m * (N / 192 > 0 ? N / 192 : 1));
     const int tiles_n_w = N / 192;
 #define GVF_GEMM_LAUNCH(EPI_)                                                                                     \

@@ -41,7 +41,7 @@ def _ref_autocast_err(tag):
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 200, 128), (128, 128, 64), (1, 1536, 512), (1000, 16, 512), (257, 3072, 2048),
-                                   (8200, 1536, 512), (4100, 3072, 64)])      # the last two take the 192-wide tiles
+                                   (12200, 1536, 64), (8200, 1536, 512)])     # (12200, 1536): the 192-wide tiles (small tail round at 128)
 def test_gemm_epilogues(cuda, M, N, K):
     g = torch.Generator().manual_seed(M + N + K)
     a = bf(torch.randn((M, K), generator=g)).to(cuda)
