@@ -1,7 +1,8 @@
 """MultiHeadRMSNorm / MultiHeadAttention with the reference's constructor, parameter names and
 forward contract (model/attention/modules.py:8-15,63-146), computed by the gfx950 kernels:
 bf16 MFMA projections (csrc/gemm.hip) and flash attention with the QK-RMSNorm fused into its operand
-loads (csrc/attn.hip).  RoPE (`use_rope`, off in configs/diffusion.yml) is not built."""
+loads (csrc/attn.hip).  RoPE is not built: DiT passes use_rope=False to every block (model/dit.py:357-366) and the reference's
+RotaryPositionEmbedder does not broadcast against the dense (B, L, H, d) tensors this module would hand it (dead code upstream)."""
 from typing import *
 
 import torch
