@@ -70,6 +70,9 @@
 #ifndef XT_SUM2
 #define XT_SUM2 1            // 1: two row-sum accumulators per sub-tile (no dependent pair of 4x4x4 MFMAs), 0: one (8 VGPRs less)
 #endif
+#ifndef XT_Q_LDS
+#define XT_Q_LDS 0            // 1: Q fragments parked in LDS (16 VGPRs less), re-read per phase
+#endif
 #ifndef XT_SETPRIO
 #define XT_SETPRIO 0
 #endif
@@ -164,12 +167,16 @@ __device__ __forceinline__ bf16x8 xt_ld_v(const uint4* sV, int g, int l31, int h
 }
 
 template <bool DO_QK, bool DO_SM, bool MASK, int PF>
-__device__ __forceinline__ void xt_phase(bf16x8 (&kf)[2][2], bf16x8 (&vf)[4], const uint4* __restrict__ sNext, const bf16x8 (&qf)[2],
+__device__ __forceinline__ void xt_phase(bf16x8 (&kf)[2][2], bf16x8 (&vf)[4], const uint4* __restrict__ sNext, const bf16x8 (&qf_in)[2],
+                                         const uint4* __restrict__ sQ,
                                          f32x16 (&s_out)[2], const f32x16 (&s_in)[2], f32x16& o_acc, float (&l_acc)[4], f32x4& l4, f32x4& l4b,
                                          int l31, int half, int n_valid) {
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float pe[8];
     unsigned pw[4][4];
+    bf16x8 qf[2];
+    if (XT_Q_LDS && DO_QK) { qf[0] = __builtin_bit_cast(bf16x8, sQ[0]); qf[1] = __builtin_bit_cast(bf16x8, sQ[64]); }
+    else { qf[0] = qf_in[0]; qf[1] = qf_in[1]; }
 #if XT_PIPELINE
 #define XT_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
@@ -283,7 +290,7 @@ __device__ __forceinline__ void xt_safe_tile(const uint4* __restrict__ sK, const
 __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(XtParams p, int force_safe) {
     // ring of XT_NBUF stages x XT_TPS tiles x (256 K chunks + 256 V^T chunks) + one chunk for the guard flag.  ONE LDS object on purpose:
     // with a second __shared__ variable hipcc drains the LDS-DMA queue (vmcnt(0)) in front of every ds_read.
-    __shared__ uint4 smem[XT_NBUF * XT_TPS * XT_TILE_CHUNKS + 1 + XT_ABL_LDSPAD];
+    __shared__ uint4 smem[XT_NBUF * XT_TPS * XT_TILE_CHUNKS + 1 + XT_ABL_LDSPAD + (XT_Q_LDS ? XT_THREADS * 4 : 0)];
     volatile int* s_bad = reinterpret_cast<volatile int*>(&smem[XT_NBUF * XT_TPS * XT_TILE_CHUNKS]);
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -326,6 +333,15 @@ __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(
         }
 #pragma unroll
         for (int st = 0; st < 2; ++st) qf[a][st] = __builtin_bit_cast(bf16x8, qraw[st]);
+    }
+    // XT_Q_LDS: the wave's four Q fragments live in its own 4 KiB of LDS ([sub-tile][k-step][lane]); no barrier needed (wave-private)
+    uint4* sQw = &smem[XT_NBUF * XT_TPS * XT_TILE_CHUNKS + 1 + XT_ABL_LDSPAD] + wave * 256 + lane;
+    if (XT_Q_LDS) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int st = 0; st < 2; ++st) sQw[(a * 2 + st) * 64] = __builtin_bit_cast(uint4, qf[a][st]);
+        __builtin_amdgcn_wave_barrier();
     }
 
     // ---- staging: stage s = tiles [s * TPS, (s+1) * TPS) -> ring slot s % 3.  Wave w copies chunks [64w, 64w+64) of every
@@ -371,9 +387,9 @@ __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(
 #pragma unroll
             for (int i = 0; i < 4; ++i) kf[i >> 1][i & 1] = xt_ld_k(XT_K(0), i >> 1, i & 1, l31, half);
         }
-        xt_phase<true, false, false, 1>(kf, vf, XT_V(0), qf[0], sA, sB, oB, lB4, l4B, l4Bb, l31, half, XT_KT);
+        xt_phase<true, false, false, 1>(kf, vf, XT_V(0), qf[0], sQw, sA, sB, oB, lB4, l4B, l4Bb, l31, half, XT_KT);
         if (T > 1) {
-            xt_phase<true, true, false, 2>(kf, vf, XT_K(1), qf[1], sB, sA, oA, lA4, l4A, l4Ab, l31, half, XT_KT);
+            xt_phase<true, true, false, 2>(kf, vf, XT_K(1), qf[1], sQw + 128, sB, sA, oA, lA4, l4A, l4Ab, l31, half, XT_KT);
             // steady state, iterations t = 1 .. T-2.  Entering stage s = t / TPS: one barrier -- stage s+1 has landed
             // (iteration t may prefetch K(t+1) from it) and every wave is done with stage s-1, whose ring slot takes the
             // DMA of stage s+2.
@@ -383,14 +399,14 @@ __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(
                     const int s2 = t / XT_TPS + 2;
                     if (s2 < n_stages) { XT_STAGE(s2) }
                 }
-                xt_phase<true, true, false, 1>(kf, vf, XT_V(t), qf[0], sA, sB, oB, lB4, l4B, l4Bb, l31, half, XT_KT);
-                xt_phase<true, true, false, 2>(kf, vf, XT_K(t + 1), qf[1], sB, sA, oA, lA4, l4A, l4Ab, l31, half, XT_KT);
+                xt_phase<true, true, false, 1>(kf, vf, XT_V(t), qf[0], sQw, sA, sB, oB, lB4, l4B, l4Bb, l31, half, XT_KT);
+                xt_phase<true, true, false, 2>(kf, vf, XT_K(t + 1), qf[1], sQw + 128, sB, sA, oA, lA4, l4A, l4Ab, l31, half, XT_KT);
             }
             if ((T - 1) % XT_TPS == 0) __syncthreads();      // the last tile opens a stage: it must have landed
-            xt_phase<true, true, false, 1>(kf, vf, XT_V(T - 1), qf[0], sA, sB, oB, lB4, l4B, l4Bb, l31, half, XT_KT);
+            xt_phase<true, true, false, 1>(kf, vf, XT_V(T - 1), qf[0], sQw, sA, sB, oB, lB4, l4B, l4Bb, l31, half, XT_KT);
         }
-        xt_phase<true, true, true, 0>(kf, vf, XT_K(0), qf[1], sB, sA, oA, lA4, l4A, l4Ab, l31, half, last_valid);
-        xt_phase<false, true, true, 0>(kf, vf, XT_K(0), qf[1], sA, sB, oB, lB4, l4B, l4Bb, l31, half, last_valid);
+        xt_phase<true, true, true, 0>(kf, vf, XT_K(0), qf[1], sQw + 128, sB, sA, oA, lA4, l4A, l4Ab, l31, half, last_valid);
+        xt_phase<false, true, true, 0>(kf, vf, XT_K(0), qf[1], sQw, sA, sB, oB, lB4, l4B, l4Bb, l31, half, last_valid);
 #if XT_SUM_MFMA
         lA = l4A[0] + l4Ab[0]; lB = l4B[0] + l4Bb[0];
 #else
