@@ -34,6 +34,8 @@ SOURCES = {
     "attn_xt.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans", "-fno-slp-vectorize"],
     # (SLP left ON here: the GELU / LayerNorm epilogues measure 2 % slower in the denoise step without it)
     "gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+    # row-block kernel: default flags (accumulators in AGPRs: the kernel lives on the 512-register file of a 2-waves-per-SIMD launch)
+    "rowblock.hip": [],
     "elem.hip": [],
     "vae.hip": [],
 }

@@ -1,0 +1,536 @@
+// rowblock.hip -- one launch per sub-layer boundary of the DiT block, for gfx950 (MI355X), model_channels = 512:
+//
+//     x   <- x + gate * (A W1^T + b1)                      (the projection that closes a sub-layer: to_out / mlp.2 / input_layer)
+//     hb  <- bf16( LayerNorm(x) * mul + add )              (the LayerNorm that opens the next one: adaLN modulate or affine)
+//     out <- epi( hb W2^T + b2 )                           (its first projection: to_qkv / to_q / mlp.0 [+GELU])
+//
+// i.e. model/dit.py:236-277 of the reference (x = x + gate * attn(...); h = norm(x); h = h * (1 + scale) + shift; attn.to_q(h) ...)
+// cut at the attention calls instead of at the nn.Module boundaries.  Unfused this is three launches (gemm.hip RESID epilogue,
+// elem.hip ln_mod, gemm.hip) that move the fp32 stream x through HBM three times and the normalised copy twice.
+//
+// Shape of the work: M = B*T*N rows (12288 for one sample) by exactly 512 columns.  A workgroup owns 48 FULL rows -- 256
+// workgroups for one sample, one per CU -- so that the row statistics of LayerNorm are available in the epilogue of the
+// first GEMM, and the normalised rows never leave the CU: they are written to LDS already in MFMA-fragment order and are
+// the activation operand of the second GEMM.
+//
+// Data flow per workgroup (4 waves; wave w owns output columns [128w, 128w + 128) of every 512-column pass):
+//   * weights: pre-packed once (gvf_rowblock_pack_weight) in fragment order [pass][k-step][wave][column tile][lane][8 bf16], so a
+//     wave's operand for one k-step (32 deep) is 8 fully coalesced 1 KiB loads, global -> VGPR, no LDS: every wave reads columns
+//     nobody else in the workgroup needs.  Two k-steps are kept in flight (refilled in place behind the MFMAs that consume a
+//     fragment); the stream runs on across the phase-1 / phase-2 boundary and across the passes of phase 2.  With 48 rows per
+//     CU this stream (0.5 MiB of L2 reads per 512x512 weight matrix per CU) is what bounds the kernel: ~56 B/clk/CU of L2
+//     bandwidth against 16 cycles per MFMA.
+//   * activations of phase 1: 48 x 512 bf16 per chunk, LDS-DMA (global_load_lds_dwordx4) straight into fragment order
+//     [k-step][row tile][lane][16 B] -- the gather is on the source side, the LDS side is linear -- two chunk buffers for K > 512.
+//   * MFMA v_mfma_f32_16x16x32_bf16 with the WEIGHT fragment as the A operand: D[n][m], so a lane ends up with 4 consecutive
+//     columns of one row: 16-byte accesses to the fp32 stream, 8-byte bf16 stores, and the LayerNorm row reduction is
+//     4 lanes + 4 waves wide.
+//   * the residual tile of x (96 VGPRs) is fetched before the k-loop; the per-column vectors (bias, gate, LayerNorm gain / shift)
+//     sit in LDS.
+#include <cstdlib>
+#include "gvf_common.h"
+#include "../../include/gvf_rast.h"
+#include "../../include/gvf_dit.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#ifndef RB_DEPTH
+#define RB_DEPTH 4                               // k-steps of weight fragments in flight per wave (16 VGPRs each)
+#endif
+#ifndef RB_DEPTH_MLP
+#define RB_DEPTH_MLP 4
+#endif
+constexpr int RB_C = 512;                        // columns of the stream (model_channels)
+constexpr int RB_BM = 48;                        // rows per workgroup: 3 MFMA row tiles
+constexpr int RB_THREADS = 512;                  // 8 waves, two per SIMD: wave w owns output columns [64w, 64w + 64) of every 512-column pass
+constexpr int RB_NW = 8, RB_CT = 4;              // waves, 16-column tiles per wave
+constexpr int RB_KS = 16;                        // k-steps (32 deep) of a 512-deep GEMM
+constexpr int RB_BUF = RB_KS * 3 * 64;           // uint4 per 48 x 512 bf16 activation block in fragment order (48 KiB)
+constexpr int RB_MAX_HIDDEN = 2048;
+constexpr int RB_PAR = 2 * RB_BUF;               // floats: [b1 | gate1 | mul1 | add1 | b_fc2 | gate_m | mul2 | add2] x 512, b_fc1 x 2048, b3 x 1536
+constexpr int RB_MAX_N3 = 1536;
+constexpr int RB_PAR_FLOATS = 8 * RB_C + RB_MAX_HIDDEN + RB_MAX_N3;
+constexpr int RB_RED = RB_PAR + RB_PAR_FLOATS / 4;       // [2][8 waves][48 rows] floats
+constexpr int RB_SMEM = RB_RED + 2 * RB_NW * RB_BM / 4;
+constexpr int RB_KPAD = 128;                      // K of a packed weight is padded to this (k-steps come in groups of RB_DEPTH)
+constexpr int RB_STEP = 4 * 8 * 64;              // uint4 per k-step of a packed weight stream (32 KiB)
+
+struct RbLn {                                    // LayerNorm(x) * (1 + scale) + shift and / or affine
+    const float* ln_w; const float* ln_b;        // [512] or null
+    const float* shift; const float* scale;      // row g of leading dimension mod_ld, or null
+};
+
+struct RbParams {
+    const unsigned short* A; int lda, K1;        // phase-1 activations, bf16 [M][lda], K1 <= 512
+    const uint4* W; const float* b1;             // the packed weight stream: W1 [K1/32 steps] | MLP [2 * 16 * hidden/512] | W3 [16 * N3/512]; bias [512] or null
+    float* x; int M;                             // fp32 stream [M][512], updated in place
+    const float* gate1;                          // row g of leading dimension mod_ld, or null (-> 1)
+    RbLn ln1;
+    int mod_ld, rpg; float eps;
+    // optional MLP section: x += gate_m * (gelu(hb Wfc1^T + b_fc1) Wfc2^T + b_fc2), then LayerNorm ln2
+    const float* b_fc1; const float* b_fc2; int hidden;      // stream: per 512 hidden units, 16 steps of mlp.0 then 16 of mlp.2
+    const float* gate_m;
+    RbLn ln2;
+    // last projection, fed by the last LayerNorm
+    const float* b3;                             // bias [N3] or null
+    unsigned short* out3; int N3;          // bf16 [M][N3], or null: no last projection
+    unsigned short* hb_out;                      // optional: the rows of the last LayerNorm, bf16 [M][512]
+};
+
+__device__ __forceinline__ unsigned rb_pack_bf16(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    bf16x2 v;
+    v[0] = (__bf16)lo;
+    v[1] = (__bf16)hi;
+    return __builtin_bit_cast(unsigned, v);
+}
+
+// same expression as gemm.hip's GELU epilogue
+__device__ __forceinline__ float rb_gelu_tanh(float x) {
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    const float u = k0 * (x + k1 * x * x * x);
+    return x / (1.0f + __expf(-2.0f * u));
+}
+
+__device__ __forceinline__ void rb_dma16(const unsigned short* g, uint4* l) {
+    __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+__device__ __forceinline__ bf16x8 rb_ldw(const uint4* p) { return __builtin_bit_cast(bf16x8, *p); }
+
+// The weight stream of one wave: the k-steps of W1, then of the MLP section, then of W3, packed back to back (32 KiB per step).
+// Past the end it repeats its last step (the refills behind the last MFMAs are redundant, never out of bounds).
+struct RbStream {
+    const uint4* w; int Gt;
+    __device__ __forceinline__ const uint4* at(int s) const { return w + (long long)(s < Gt ? s : Gt - 1) * RB_STEP; }
+};
+
+// `steps` k-steps (a multiple of D) of acc += act * W: 3 activation fragments per step from LDS (act = block base + lane), 24 MFMAs,
+// the weight fragments refilled in place D steps ahead.  g = index of the first step in the stream.  D: the stream is new to the L2 in
+// every launch (the DiT's weights are 100+ MB), so a refill is a miss to the Infinity Cache / HBM for the first workgroup of an XCD that
+// asks and a wait on that miss for the others: ~1 us, i.e. 4+ k-steps of MFMA work.
+template <int D>
+__device__ __forceinline__ void rb_gemm(f32x4 (&acc)[3][RB_CT], bf16x8 (&wf)[D][RB_CT], const uint4* act, int steps, int& g, const RbStream& st) {
+    // (not unrolled: in straight-line code the scheduler sinks every refill to just before its use and the prefetch is gone)
+#pragma clang loop unroll(disable)
+    for (int ksl = 0; ksl < steps; ksl += D, g += D) {
+#pragma unroll
+        for (int b = 0; b < D; ++b) {
+            bf16x8 af[3];
+#pragma unroll
+            for (int rt = 0; rt < 3; ++rt) af[rt] = __builtin_bit_cast(bf16x8, act[((ksl + b) * 3 + rt) * 64]);
+            const uint4* sn = st.at(g + b + D);
+#pragma unroll
+            for (int ct = 0; ct < RB_CT; ++ct) {
+#pragma unroll
+                for (int rt = 0; rt < 3; ++rt)
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b][ct], af[rt], acc[rt][ct], 0, 0, 0);
+                wf[b][ct] = rb_ldw(sn + ct * 64);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // the refills stay in the step that frees their registers
+        }
+    }
+}
+
+// Workgroup barrier that orders LDS traffic only: s_waitcnt lgkmcnt(0) + s_barrier.  __syncthreads() also drains vmcnt, i.e. waits for
+// the whole weight prefetch in flight (a memory latency per barrier, ~20 barriers per launch).
+__device__ __forceinline__ void rb_lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+__device__ __forceinline__ void rb_zero(f32x4 (&acc)[3][RB_CT]) {
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < RB_CT; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+}
+
+// Column n = 64 wave + 16 ct + 4 lq + i of a 48 x 512 block is k index n of the GEMM that consumes it: k-step 2 wave + ct / 2,
+// fragment lane (2 (ct & 1) + lq / 2) * 16 + l15, elements 4 (lq & 1) .. + 4 -> one 8-byte LDS write per (row tile, column tile).
+__device__ __forceinline__ uint2* rb_frag_base(uint4* block, int wave, int lq, int l15) {      // the lane's part of the address
+    return reinterpret_cast<uint2*>(block) + (wave * 6 * 64 + (lq >> 1) * 16 + l15) * 2 + (lq & 1);
+}
+__device__ __forceinline__ void rb_put_frag(uint2* base, int ct, int rt, uint2 o) {                // + a compile-time offset
+    base[(((ct >> 1) * 3 + rt) * 64 + 2 * (ct & 1) * 16) * 2] = o;
+}
+
+// LayerNorm of the 48 rows held in v (row 16 rt + l15, columns colw + 16 ct + i), times mul plus add, as bf16 fragments into
+// `block` (and to hb_out).  v is left centred.  Two barriers; the caller adds the one that publishes `block`.
+__device__ __forceinline__ void rb_layernorm(f32x4 (&v)[3][RB_CT], float* sRed, const float* mul, const float* add, float eps, uint4* block,
+                                             unsigned short* hb_out_row0, int wave, int lane, int lq, int l15, int colw) {
+    float rsum[3];
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt) {
+        float s = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < RB_CT; ++ct) s += (v[rt][ct][0] + v[rt][ct][1]) + (v[rt][ct][2] + v[rt][ct][3]);
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        rsum[rt] = s;
+        if (lane < 16) sRed[wave * RB_BM + 16 * rt + lane] = s;
+    }
+    rb_lds_barrier();                             // also: every wave is past the GEMM that read `block`'s previous contents
+    float rstd[3];
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt) {
+        const int r = 16 * rt + l15;
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < RB_NW; ++w) tot += sRed[w * RB_BM + r];
+        const float mean = tot * (1.0f / RB_C);
+        float q = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < RB_CT; ++ct)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const float d = v[rt][ct][i] - mean; v[rt][ct][i] = d; q += d * d; }
+        q += __shfl_xor(q, 16, 64);
+        q += __shfl_xor(q, 32, 64);
+        if (lane < 16) sRed[RB_NW * RB_BM + wave * RB_BM + 16 * rt + lane] = q;
+    }
+    rb_lds_barrier();
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt) {
+        const int r = RB_NW * RB_BM + 16 * rt + l15;
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < RB_NW; ++w) tot += sRed[w * RB_BM + r];
+        rstd[rt] = rsqrtf(tot * (1.0f / RB_C) + eps);
+    }
+    uint2* fb = rb_frag_base(block, wave, lq, l15);
+    unsigned short* hbr[3];
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt) hbr[rt] = hb_out_row0 + (16 * rt + l15) * RB_C + colw;
+#pragma unroll
+    for (int ct = 0; ct < RB_CT; ++ct) {
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mul + colw + 16 * ct);
+        const f32x4 ad = *reinterpret_cast<const f32x4*>(add + colw + 16 * ct);
+#pragma unroll
+        for (int rt = 0; rt < 3; ++rt) {
+            float y[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) y[i] = (v[rt][ct][i] * rstd[rt]) * mu[i] + ad[i];
+            uint2 o;
+            o.x = rb_pack_bf16(y[0], y[1]);
+            o.y = rb_pack_bf16(y[2], y[3]);
+            rb_put_frag(fb, ct, rt, o);
+            if (hb_out_row0 != nullptr) *reinterpret_cast<uint2*>(hbr[rt] + 16 * ct) = o;
+        }
+    }
+}
+
+template <bool MLP, int D>
+__global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
+    __shared__ uint4 smem[RB_SMEM];              // the ONE LDS object (a second one makes hipcc drain vmcnt before every ds_read)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, lq = lane >> 4;
+    const int m0 = blockIdx.x * RB_BM;           // M % 48 == 0: no row guards anywhere
+    uint4* R0 = &smem[0];                        // normalised rows (operand of mlp.0 / of the last projection)
+    uint4* R1 = &smem[RB_BUF];                   // phase-1 activations, then the GELU'd hidden units of one 512-wide slice
+    float* sPar = reinterpret_cast<float*>(&smem[RB_PAR]);
+    float* sRed = reinterpret_cast<float*>(&smem[RB_RED]);
+
+    const int G1 = p.K1 >> 5;
+    const int Pm = MLP ? p.hidden / RB_C : 0;
+    const int P3 = p.out3 != nullptr ? p.N3 / RB_C : 0;
+    RbStream st;
+    st.w = p.W + wave * (RB_CT * 64) + lane;
+    st.Gt = G1 + 2 * RB_KS * Pm + RB_KS * P3;
+
+    // ---- prologue: everything the first k-steps and the epilogues need, issued back to back
+    // phase-1 activations: LDS-DMA into fragment order; wave w stages k-steps w and w + 8 (3 row tiles each)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int ks = wave + RB_NW * j;
+        if (ks < G1) {
+#pragma unroll
+            for (int rt = 0; rt < 3; ++rt)
+                rb_dma16(p.A + (long long)(m0 + 16 * rt + l15) * p.lda + ks * 32 + 8 * lq, &R1[(ks * 3 + rt) * 64]);
+        }
+    }
+    bf16x8 wf[D][RB_CT];
+#pragma unroll
+    for (int b = 0; b < D; ++b) {
+        const uint4* s0 = st.at(b);
+#pragma unroll
+        for (int ct = 0; ct < RB_CT; ++ct) wf[b][ct] = rb_ldw(s0 + ct * 64);
+    }
+    const int colw = wave * 64 + 4 * lq;        // this lane's first column inside column tile 0
+    float* xr[3];                                // this lane's three rows of the stream, at its first column
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt) xr[rt] = p.x + (long long)m0 * RB_C + (16 * rt + l15) * RB_C + colw;
+    f32x4 rs[3][RB_CT];                              // residual tile of x
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < RB_CT; ++ct) rs[rt][ct] = *reinterpret_cast<const f32x4*>(xr[rt] + 16 * ct);
+    {
+        // per-column vectors -> LDS.  Unconditional loads (a null vector reads the stream instead and is discarded): no branch + wait
+        // per vector
+        const int grp = p.rpg > 0 ? m0 / p.rpg : 0;
+        {
+            const int c = tid;
+            const long long mo = (long long)grp * p.mod_ld + c;
+            const float* dflt = p.x + c;
+            const float vb = *(p.b1 ? p.b1 + c : dflt), vg = *(p.gate1 ? p.gate1 + mo : dflt), vw = *(p.ln1.ln_w ? p.ln1.ln_w + c : dflt);
+            const float vlb = *(p.ln1.ln_b ? p.ln1.ln_b + c : dflt), vsc = *(p.ln1.scale ? p.ln1.scale + mo : dflt);
+            const float vsh = *(p.ln1.shift ? p.ln1.shift + mo : dflt);
+            const float sc = p.ln1.scale ? 1.0f + vsc : 1.0f;
+            sPar[c] = p.b1 ? vb : 0.f;
+            sPar[RB_C + c] = p.gate1 ? vg : 1.0f;
+            sPar[2 * RB_C + c] = (p.ln1.ln_w ? vw : 1.0f) * sc;
+            sPar[3 * RB_C + c] = (p.ln1.ln_b ? vlb * sc : 0.f) + (p.ln1.scale ? vsh : 0.f);
+            if (MLP) {
+                const float ub = *(p.b_fc2 ? p.b_fc2 + c : dflt), ug = *(p.gate_m ? p.gate_m + mo : dflt), uw = *(p.ln2.ln_w ? p.ln2.ln_w + c : dflt);
+                const float ulb = *(p.ln2.ln_b ? p.ln2.ln_b + c : dflt), usc = *(p.ln2.scale ? p.ln2.scale + mo : dflt);
+                const float ush = *(p.ln2.shift ? p.ln2.shift + mo : dflt);
+                const float sc2 = p.ln2.scale ? 1.0f + usc : 1.0f;
+                sPar[4 * RB_C + c] = p.b_fc2 ? ub : 0.f;
+                sPar[5 * RB_C + c] = p.gate_m ? ug : 1.0f;
+                sPar[6 * RB_C + c] = (p.ln2.ln_w ? uw : 1.0f) * sc2;
+                sPar[7 * RB_C + c] = (p.ln2.ln_b ? ulb * sc2 : 0.f) + (p.ln2.scale ? ush : 0.f);
+            }
+        }
+        // (a global load in an epilogue would be waited for IN ORDER behind the whole weight prefetch: every bias sits in LDS)
+        float vf1[RB_MAX_HIDDEN / RB_THREADS], vb3[RB_MAX_N3 / RB_THREADS];
+#pragma unroll
+        for (int j = 0; j < RB_MAX_HIDDEN / RB_THREADS; ++j) {
+            const int c = tid + RB_THREADS * j;
+            vf1[j] = *((MLP && p.b_fc1 && c < p.hidden) ? p.b_fc1 + c : p.x + tid);
+        }
+#pragma unroll
+        for (int j = 0; j < RB_MAX_N3 / RB_THREADS; ++j) {
+            const int c = tid + RB_THREADS * j;
+            vb3[j] = *((p.b3 && c < P3 * RB_C) ? p.b3 + c : p.x + tid);
+        }
+#pragma unroll
+        for (int j = 0; j < RB_MAX_HIDDEN / RB_THREADS; ++j)
+            if (MLP) sPar[8 * RB_C + tid + RB_THREADS * j] = (p.b_fc1 && tid + RB_THREADS * j < p.hidden) ? vf1[j] : 0.f;
+#pragma unroll
+        for (int j = 0; j < RB_MAX_N3 / RB_THREADS; ++j)
+            sPar[8 * RB_C + RB_MAX_HIDDEN + tid + RB_THREADS * j] = (p.b3 && tid + RB_THREADS * j < P3 * RB_C) ? vb3[j] : 0.f;
+    }
+    f32x4 acc[3][RB_CT];
+    rb_zero(acc);
+    // pin the residual tile here: left alone, the compiler sinks these loads to their first use -- the epilogue, after the k-loop
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < RB_CT; ++ct) asm volatile("" : "+v"(rs[rt][ct]));
+    __syncthreads();                             // activations landed (own DMA drained before the barrier), parameters visible
+
+    // ---- phase 1: x = x + gate1 * (A W1^T + b1), LayerNorm ln1 -> R0
+    int g = 0;
+    rb_gemm<D>(acc, wf, R1 + lane, G1, g, st);
+#pragma unroll
+    for (int ct = 0; ct < RB_CT; ++ct) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(sPar + colw + 16 * ct);
+        const f32x4 g4 = *reinterpret_cast<const f32x4*>(sPar + RB_C + colw + 16 * ct);
+#pragma unroll
+        for (int rt = 0; rt < 3; ++rt) {
+            f32x4 v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = rs[rt][ct][i] + g4[i] * (acc[rt][ct][i] + b4[i]);
+            acc[rt][ct] = v;                     // LayerNorm works on (and overwrites) this copy;
+            rs[rt][ct] = v;                      // the store reads this one: overwriting a register a store in flight still has to read
+            if (!MLP) *reinterpret_cast<f32x4*>(xr[rt] + 16 * ct) = rs[rt][ct];      // means waiting for it, in order, behind the weight prefetch.
+                                                 // (MLP: the stream is written once, after the MLP)
+        }
+    }
+    unsigned short* hb_rows = p.hb_out != nullptr ? p.hb_out + (long long)m0 * RB_C : nullptr;
+    rb_layernorm(acc, sRed, sPar + 2 * RB_C, sPar + 3 * RB_C, p.eps, R0, MLP ? nullptr : hb_rows, wave, lane, lq, l15, colw);
+
+    if (MLP) {
+        // ---- MLP: per 512 hidden units  h = gelu(R0 Wfc1[slice]^T + b) -> R1 (bf16 fragments);  acc2 += R1 Wfc2[:, slice]^T
+        f32x4 acc2[3][RB_CT];
+        rb_zero(acc2);
+        uint2* fb1 = rb_frag_base(R1, wave, lq, l15);
+        for (int s = 0; s < Pm; ++s) {
+            rb_lds_barrier();                     // R0 complete (s = 0) / every wave done reading R1 (s > 0)
+            rb_zero(acc);
+            rb_gemm<D>(acc, wf, R0 + lane, RB_KS, g, st);
+#pragma unroll
+            for (int ct = 0; ct < RB_CT; ++ct) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(sPar + 8 * RB_C + s * RB_C + colw + 16 * ct);
+#pragma unroll
+                for (int rt = 0; rt < 3; ++rt) {
+                    float y[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) y[i] = rb_gelu_tanh(acc[rt][ct][i] + b4[i]);
+                    uint2 o;
+                    o.x = rb_pack_bf16(y[0], y[1]);
+                    o.y = rb_pack_bf16(y[2], y[3]);
+                    rb_put_frag(fb1, ct, rt, o);
+                }
+            }
+            rb_lds_barrier();                     // the slice is complete in R1
+            rb_gemm<D>(acc2, wf, R1 + lane, RB_KS, g, st);
+        }
+#pragma unroll
+        for (int ct = 0; ct < RB_CT; ++ct) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(sPar + 4 * RB_C + colw + 16 * ct);
+            const f32x4 g4 = *reinterpret_cast<const f32x4*>(sPar + 5 * RB_C + colw + 16 * ct);
+#pragma unroll
+            for (int rt = 0; rt < 3; ++rt) {
+                f32x4 v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = rs[rt][ct][i] + g4[i] * (acc2[rt][ct][i] + b4[i]);
+                acc2[rt][ct] = v;
+                rs[rt][ct] = v;
+                *reinterpret_cast<f32x4*>(xr[rt] + 16 * ct) = rs[rt][ct];
+            }
+        }
+        rb_layernorm(acc2, sRed, sPar + 6 * RB_C, sPar + 7 * RB_C, p.eps, R0, hb_rows, wave, lane, lq, l15, colw);
+    }
+    if (P3 == 0) return;
+    rb_lds_barrier();                             // the normalised rows are complete in R0
+
+    // ---- last projection: out[:, 512 pass .. + 512] = R0 W3[pass]^T + b3.  A lane holds 4 columns of a row: written straight out that is
+    // 8-byte pieces, 32 contiguous bytes per row per instruction (measured: 20 us per 12.6 MB pass).  So the tile goes through R1 (free by
+    // now) as rows of 64 16-byte chunks, chunk c of row r at slot c ^ (r & 15) (conflict-free both ways), and leaves as whole 1 KiB rows.
+    const float* b3p = sPar + 8 * RB_C + RB_MAX_HIDDEN;
+    uint2* stg_w = reinterpret_cast<uint2*>(R1);
+    for (int pass = 0; pass < P3; ++pass) {
+        rb_zero(acc);
+        rb_gemm<D>(acc, wf, R0 + lane, RB_KS, g, st);
+        const int col0 = pass * RB_C + colw;
+        if (pass > 0) rb_lds_barrier();          // every wave has drained the previous tile
+#pragma unroll
+        for (int ct = 0; ct < RB_CT; ++ct) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(b3p + col0 + 16 * ct);
+            const int chunk = 8 * wave + 2 * ct + (lq >> 1);
+#pragma unroll
+            for (int rt = 0; rt < 3; ++rt) {
+                uint2 o;
+                o.x = rb_pack_bf16(acc[rt][ct][0] + b4[0], acc[rt][ct][1] + b4[1]);
+                o.y = rb_pack_bf16(acc[rt][ct][2] + b4[2], acc[rt][ct][3] + b4[3]);
+                stg_w[((16 * rt + l15) * 64 + (chunk ^ l15)) * 2 + (lq & 1)] = o;
+            }
+        }
+        rb_lds_barrier();
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int r = wave * 6 + j;
+            const uint4 v = R1[r * 64 + (lane ^ (r & 15))];
+#ifdef RB_ABL_NOSTORE3
+            if (p.M < 0)
+#endif
+            *reinterpret_cast<uint4*>(p.out3 + (long long)(m0 + r) * p.N3 + pass * RB_C + 8 * lane) = v;
+        }
+    }
+}
+
+// W bf16 [N][ldw] (nn.Linear layout) -> fragment order.  One 16-byte chunk per thread.
+__global__ __launch_bounds__(256) void rowblock_pack_kernel(const unsigned short* __restrict__ W, int ldw, int N, int K, int Kp,
+                                                            uint4* __restrict__ out, long long total) {
+    const long long i = blockIdx.x * 256LL + threadIdx.x;
+    if (i >= total) return;
+    const int lane = (int)(i & 63), ct = (int)((i >> 6) & 7), wv = (int)((i >> 9) & 3);
+    const long long s = i >> 11;                 // pass * (Kp / 32) + k-step
+    const int G = Kp >> 5;
+    const int pass = (int)(s / G), ks = (int)(s % G);
+    const int n = pass * RB_C + wv * 128 + ct * 16 + (lane & 15), k = ks * 32 + 8 * (lane >> 4);
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (n < N) {
+        const unsigned short* src = W + (long long)n * ldw + k;
+        if (k + 8 <= K && (ldw % 8) == 0) {
+            v = *reinterpret_cast<const uint4*>(src);
+        } else {
+            unsigned short e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e[j] = k + j < K ? src[j] : (unsigned short)0;
+            v.x = e[0] | ((unsigned)e[1] << 16); v.y = e[2] | ((unsigned)e[3] << 16);
+            v.z = e[4] | ((unsigned)e[5] << 16); v.w = e[6] | ((unsigned)e[7] << 16);
+        }
+    }
+    out[i] = v;
+}
+
+// mlp.0 weight [hidden][512] and mlp.2 weight [512][hidden] -> the interleaved stream of the MLP section: per 512 hidden units, the 16
+// k-steps of that slice of mlp.0 (a 512 x 512 pass), then the 16 k-steps of mlp.2 that consume it.
+__global__ __launch_bounds__(256) void rowblock_pack_mlp_kernel(const unsigned short* __restrict__ W0, const unsigned short* __restrict__ W2,
+                                                                int hidden, uint4* __restrict__ out, long long total) {
+    const long long i = blockIdx.x * 256LL + threadIdx.x;
+    if (i >= total) return;
+    const int lane = (int)(i & 63), ct = (int)((i >> 6) & 7), wv = (int)((i >> 9) & 3);
+    const int s = (int)(i >> 11);                // 32 steps per slice
+    const int slice = s >> 5, ks = s & 15;
+    const int nl = wv * 128 + ct * 16 + (lane & 15), kl = ks * 32 + 8 * (lane >> 4);
+    const unsigned short* src = (s & 16) ? W2 + (long long)nl * hidden + slice * RB_C + kl           // mlp.2: output nl, hidden units of the slice
+                                         : W0 + (long long)(slice * RB_C + nl) * RB_C + kl;           // mlp.0: hidden unit of the slice, input kl
+    out[i] = *reinterpret_cast<const uint4*>(src);
+}
+
+}  // namespace
+
+extern "C" int64_t gvf_rowblock_packed_bytes(int N, int K) {
+    if (N <= 0 || K <= 0 || N % RB_C != 0) return GVF_EINVAL;
+    const int Kp = (K + RB_KPAD - 1) / RB_KPAD * RB_KPAD;
+    return (int64_t)N * Kp * 2;
+}
+
+extern "C" int gvf_rowblock_pack_weight(const void* w_bf16, int ldw, int N, int K, void* packed, void* stream_) {
+    if (!w_bf16 || !packed || N <= 0 || K <= 0 || N % RB_C != 0 || ldw < K) return GVF_EINVAL;
+    if ((((uintptr_t)w_bf16) & 15) || (((uintptr_t)packed) & 15)) return GVF_EINVAL;
+    const int Kp = (K + RB_KPAD - 1) / RB_KPAD * RB_KPAD;
+    const long long total = (long long)N * Kp / 8;
+    (void)hipGetLastError();
+    rowblock_pack_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_>>>(
+        (const unsigned short*)w_bf16, ldw, N, K, Kp, (uint4*)packed, total);
+    GVF_CHECK_LAUNCH();
+    return GVF_OK;
+}
+
+extern "C" int gvf_rowblock_pack_mlp(const void* w_fc1_bf16, const void* w_fc2_bf16, int hidden, void* packed, void* stream_) {
+    if (!w_fc1_bf16 || !w_fc2_bf16 || !packed || hidden <= 0 || hidden % RB_C != 0 || hidden > RB_MAX_HIDDEN) return GVF_EINVAL;
+    if ((((uintptr_t)w_fc1_bf16) & 15) || (((uintptr_t)w_fc2_bf16) & 15) || (((uintptr_t)packed) & 15)) return GVF_EINVAL;
+    const long long total = 2LL * hidden * RB_C / 8;
+    (void)hipGetLastError();
+    rowblock_pack_mlp_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_>>>(
+        (const unsigned short*)w_fc1_bf16, (const unsigned short*)w_fc2_bf16, hidden, (uint4*)packed, total);
+    GVF_CHECK_LAUNCH();
+    return GVF_OK;
+}
+
+extern "C" int gvf_rowblock_fused_bf16(const gvf_rowblock_args* a, void* stream_) {
+    if (!a) return GVF_EINVAL;
+    if (a->M < 0 || a->M % RB_BM != 0 || a->C != RB_C || a->K1 <= 0 || a->K1 % (32 * RB_DEPTH) != 0 || a->K1 > 512 || a->lda < a->K1 || a->lda % 8 != 0)
+        return GVF_EINVAL;
+    if (a->M == 0) return GVF_OK;
+    if (!a->a || !a->w || !a->x) return GVF_EINVAL;
+    const gvf_rowblock_ln* lns[2] = {&a->ln1, &a->ln2};
+    bool grouped = a->gate1 != nullptr || a->gate_m != nullptr;
+    for (int i = 0; i < 2; ++i) {
+        if (((lns[i]->ln_w == nullptr) != (lns[i]->ln_b == nullptr)) || ((lns[i]->shift == nullptr) != (lns[i]->scale == nullptr))) return GVF_EINVAL;
+        grouped = grouped || lns[i]->scale != nullptr;
+    }
+    if (grouped && (a->rows_per_group <= 0 || a->rows_per_group % RB_BM != 0 || a->mod_ld < RB_C)) return GVF_EINVAL;
+    const bool mlp = a->hidden != 0;
+    if (mlp && (a->hidden < 0 || a->hidden % RB_C != 0 || a->hidden > RB_MAX_HIDDEN)) return GVF_EINVAL;
+    if (a->N3 != 0 && (!a->out3 || a->N3 < 0 || a->N3 % RB_C != 0 || a->N3 > RB_MAX_N3 || a->epi3 != GVF_EPI_STORE_BF16))
+        return GVF_EINVAL;
+    if (a->N3 == 0 && a->hb_out == nullptr) return GVF_EINVAL;       // nothing would consume the last LayerNorm
+    if ((((uintptr_t)a->a) & 15) || (((uintptr_t)a->w) & 15) || (((uintptr_t)a->x) & 15) || (((uintptr_t)a->out3) & 7) ||
+        (((uintptr_t)a->hb_out) & 7) || (((uintptr_t)a->b3) & 15))
+        return GVF_EINVAL;
+    RbParams p;
+    p.A = (const unsigned short*)a->a; p.lda = a->lda; p.K1 = a->K1;
+    p.W = (const uint4*)a->w; p.b1 = a->b1;
+    p.x = a->x; p.M = a->M;
+    p.gate1 = a->gate1;
+    p.ln1 = RbLn{a->ln1.ln_w, a->ln1.ln_b, a->ln1.shift, a->ln1.scale};
+    p.mod_ld = a->mod_ld; p.rpg = grouped ? a->rows_per_group : 0; p.eps = a->eps;
+    p.b_fc1 = a->b_fc1; p.b_fc2 = a->b_fc2; p.hidden = a->hidden; p.gate_m = a->gate_m;
+    p.ln2 = RbLn{a->ln2.ln_w, a->ln2.ln_b, a->ln2.shift, a->ln2.scale};
+    p.b3 = a->b3; p.out3 = a->N3 != 0 ? (unsigned short*)a->out3 : nullptr; p.N3 = a->N3;
+    p.hb_out = (unsigned short*)a->hb_out;
+    (void)hipGetLastError();
+    const dim3 grid((unsigned)(a->M / RB_BM)), block(RB_THREADS);
+    if (mlp) rowblock_kernel<true, RB_DEPTH_MLP><<<grid, block, 0, (hipStream_t)stream_>>>(p);
+    else rowblock_kernel<false, RB_DEPTH><<<grid, block, 0, (hipStream_t)stream_>>>(p);
+    GVF_CHECK_LAUNCH();
+    return GVF_OK;
+}

@@ -181,6 +181,8 @@ class DiT(nn.Module):
         # removes (to_qkv 36.6 + 9.1 -> 50.7 us, mlp.0 50 + 9.1 -> 64.4 us; to_q 15.8 + 9.1 -> 20.7 us), and the statistics
         # add 2.4 us to every residual GEMM.
         self.fuse_layernorm = int(os.environ.get("GVF_DIT_FUSE_LN", "0"))
+        # one launch per sub-layer boundary (csrc/rowblock.hip) where the shapes allow it: 0 = the unfused GEMM / LayerNorm launches
+        self.use_rowblock = int(os.environ.get("GVF_DIT_ROWBLOCK", "1")) != 0
         self._graph = None
 
     @property
@@ -258,6 +260,32 @@ class DiT(nn.Module):
         self._wcache = W
         self._ctx_cache = {}
         return W
+
+    def _rowblock_streams(self, W):
+        """Packed weight streams of the row-block launches (csrc/rowblock.hip), built once per weight version: every launch reads ONE
+        stream -- the projection that closes a sub-layer, [the MLP,] the projection that opens the next one -- in the order it consumes
+        it.  Same bf16 values as W's plain copies."""
+        if "rb" in W:
+            return W["rb"]
+        P = dit_ops.rowblock_pack_stream
+        kin = dit_ops.ROWBLOCK_KPAD * ((self.input_layer.in_features + dit_ops.ROWBLOCK_KPAD - 1) // dit_ops.ROWBLOCK_KPAD)
+        w_in = dit_ops.cast_pad_bf16(self.input_layer.weight.detach().float().contiguous(), kin)
+        blocks = W["blocks"]
+        first = "spatial_self_attn"
+        rb = {"kin": kin, "in": P(w_in, w3=blocks[0][first]["qkv"][0]), "blocks": []}
+        for i, b in enumerate(blocks):
+            nxt = blocks[i + 1][first]["qkv"][0] if i + 1 < len(blocks) else None
+            d = {}
+            if self.no_temporal_attn:
+                d["s2"] = P(b["spatial_self_attn"]["out"][0], w3=b["image_cross_attn"]["q"][0])
+            else:
+                d["s2"] = P(b["spatial_self_attn"]["out"][0], w3=b["temporal_self_attn"]["qkv"][0])
+                d["s3"] = P(b["temporal_self_attn"]["out"][0], w3=b["image_cross_attn"]["q"][0])
+            d["s4"] = P(b["image_cross_attn"]["out"][0], w3=b["static_cross_attn"]["q"][0])
+            d["s5"] = P(b["static_cross_attn"]["out"][0], mlp=(b["fc1"][0], b["fc2"][0]), w3=nxt)
+            rb["blocks"].append(d)
+        W["rb"] = rb
+        return rb
 
     # ---- step-invariant condition products ------------------------------------------------------------
     @staticmethod
@@ -396,6 +424,8 @@ class DiT(nn.Module):
             h = ctx["pos"][:, None].expand(B, T, N, C).reshape(M, C).contiguous()
         else:
             h = torch.zeros((M, C), dtype=f32, device=dev)
+        if self.use_rowblock and dit_ops.rowblock_supported(C, T * N, int(C * self.mlp_ratio)):
+            return self._blocks_rowblock(x, h, mod, mod_ld, W, ctx, B, T, N)
         xb = dit_ops.cast_pad_bf16(x.reshape(M, Cin).float().contiguous(), dit_ops.pad64(Cin))
         hb = torch.empty((M, C), dtype=bf, device=dev)          # attention-output scratch of the cross attentions
         qkv = torch.empty((M, 3 * C), dtype=bf, device=dev)
@@ -470,4 +500,74 @@ class DiT(nn.Module):
         o = W["mod_offs"][-1]
         y = torch.empty((M, self.out_channels), dtype=f32, device=dev)
         ln_gemm(W["final"], y, dit_ops.EPI_STORE_F32, shift=mview(o), scale=mview(o + C))
+        return y.reshape(B, T, N, self.out_channels).to(x.dtype if x.dtype.is_floating_point else f32)
+
+    def _blocks_rowblock(self, x, h, mod, mod_ld, W, ctx, B, T, N):
+        """The blocks with one launch per sub-layer boundary (csrc/rowblock.hip): per block  pack + spatial attention | to_out + adaLN +
+        to_qkv | temporal attention | to_out + norm3 + to_q | image attention | to_out + norm4 + to_q | static attention | to_out +
+        adaLN + MLP + adaLN + the NEXT block's to_qkv -- 9 launches instead of 20, the fp32 stream through HBM 5 times instead of 15,
+        the normalised rows and the MLP's hidden units never.  Same rounding points as the unfused path (and as oracle/dit_ref.py)."""
+        C, H = self.model_channels, self.num_heads
+        M, TN = B * T * N, T * N
+        dev = x.device
+        bf, f32 = torch.bfloat16, torch.float32
+        rb = self._rowblock_streams(W)
+        Li, Ls = ctx["Li"], ctx["Ls"]
+        Cin = x.shape[-1]
+        xb = dit_ops.cast_pad_bf16(x.reshape(M, Cin).float().contiguous(), rb["kin"])
+        qkv = torch.empty((M, 3 * C), dtype=bf, device=dev)
+        ab = torch.empty((M, C), dtype=bf, device=dev)            # self-attention output
+        hb = torch.empty((M, C), dtype=bf, device=dev)            # cross-attention output
+        qb = torch.empty((M, C), dtype=bf, device=dev)            # q projection of the cross attentions
+        nb_self = B * T * H * ((N + 63) // 64) * 4096
+        kv_self = (torch.empty(nb_self, dtype=torch.uint8, device=dev), torch.empty(nb_self, dtype=torch.uint8, device=dev))
+        hidden_units = int(C * self.mlp_ratio)
+        blocks = W["blocks"]
+        offs = W["mod_offs"]
+
+        def mview(off):
+            return mod[:, off:]
+
+        def fused(a_, stream, **kw):
+            dit_ops.rowblock_fused(a_, stream, h, mod_ld=mod_ld, rows_per_group=TN, eps=1e-6, **kw)
+
+        o = offs[0]
+        # h = pos + input_layer(x); adaLN of block 0; its to_qkv
+        fused(xb, rb["in"], b1=W["input"][1], ln1=dict(shift=mview(o), scale=mview(o + C)), out3=qkv,
+              b3=blocks[0]["spatial_self_attn"]["qkv"][1])
+        hbn = None
+        for i, b in enumerate(blocks):
+            o, s = offs[i], rb["blocks"][i]
+            g_s, sh_m, sc_m, g_m = mview(o + 2 * C), mview(o + 3 * C), mview(o + 4 * C), mview(o + 5 * C)
+            n3, n4 = dict(ln_w=b["n3"][0], ln_b=b["n3"][1]), dict(ln_w=b["n4"][0], ln_b=b["n4"][1])
+            a = b["spatial_self_attn"]
+            dit_ops.attention_pack_kv(qkv, B * T, N, H, C, 2 * C, gamma_k=a["gk"], out=kv_self)
+            dit_ops.attention_tiled_bf16(qkv, kv_self[0], kv_self[1], ab, B * T, 1, N, N, H, (N * 3 * C, 0, 3 * C), (N * C, 0, C), 1, 0,
+                                         gamma_q=a["gq"])
+            ai = b["image_cross_attn"]
+            if self.no_temporal_attn:
+                fused(ab, s["s2"], b1=a["out"][1], gate1=g_s, ln1=n3, out3=qb, b3=ai["q"][1])
+            else:
+                sh_t, sc_t, g_t = (mview(o + (6 + k) * C) for k in range(3))
+                at = b["temporal_self_attn"]
+                fused(ab, s["s2"], b1=a["out"][1], gate1=g_s, ln1=dict(shift=sh_t, scale=sc_t), out3=qkv, b3=at["qkv"][1])
+                st = (TN * 3 * C, 3 * C, N * 3 * C)           # outer = sample, inner = token, seq = frame
+                dit_ops.attention_bf16(qkv, qkv[:, C:], qkv[:, 2 * C:], ab, B, N, T, T, H, st, st, st, (TN * C, C, N * C), at["gq"], at["gk"])
+                fused(ab, s["s3"], b1=at["out"][1], gate1=g_t, ln1=n3, out3=qb, b3=ai["q"][1])
+            kt, vt = ctx["kv_img"][i]
+            dit_ops.attention_tiled_bf16(qb, kt, vt, hb, B * T, 1, N, Li, H, (N * C, 0, C), (N * C, 0, C), 1, 0, gamma_q=ai["gq"])
+            ast = b["static_cross_attn"]
+            fused(hb, s["s4"], b1=ai["out"][1], ln1=n4, out3=qb, b3=ast["q"][1])
+            kt, vt = ctx["kv_st"][i]
+            dit_ops.attention_tiled_bf16(qb, kt, vt, hb, B, T, N, Ls, H, (TN * C, N * C, C), (TN * C, N * C, C), 1, 0, gamma_q=ast["gq"])
+            kw = dict(b1=ast["out"][1], ln1=dict(shift=sh_m, scale=sc_m), mlp_bias=(b["fc1"][1], b["fc2"][1]), hidden=hidden_units, gate_m=g_m)
+            if i + 1 < len(blocks):
+                on = offs[i + 1]
+                fused(hb, s["s5"], ln2=dict(shift=mview(on), scale=mview(on + C)), out3=qkv, b3=blocks[i + 1]["spatial_self_attn"]["qkv"][1], **kw)
+            else:
+                on = offs[-1]
+                hbn = torch.empty((M, C), dtype=bf, device=dev)
+                fused(hb, s["s5"], ln2=dict(shift=mview(on), scale=mview(on + C)), hb_out=hbn, **kw)
+        y = torch.empty((M, self.out_channels), dtype=f32, device=dev)
+        dit_ops.gemm_bf16(hbn, W["final"][0], W["final"][1], y, dit_ops.EPI_STORE_F32)
         return y.reshape(B, T, N, self.out_channels).to(x.dtype if x.dtype.is_floating_point else f32)

@@ -9,7 +9,29 @@ _vp, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_floa
 
 EPI_STORE_BF16, EPI_GELU_BF16, EPI_STORE_F32, EPI_RESID_F32 = 0, 1, 2, 3
 
+
+
+class RowblockLn(ctypes.Structure):
+    """gvf_rowblock_ln of include/gvf_dit.h"""
+    _fields_ = [("ln_w", _vp), ("ln_b", _vp), ("shift", _vp), ("scale", _vp)]
+
+
+class RowblockArgs(ctypes.Structure):
+    """gvf_rowblock_args of include/gvf_dit.h (same field order; native alignment)"""
+    _fields_ = [("a", _vp), ("lda", ctypes.c_int32), ("K1", ctypes.c_int32), ("w", _vp), ("b1", _vp),
+                ("x", _vp), ("M", ctypes.c_int32), ("C", ctypes.c_int32),
+                ("gate1", _vp), ("ln1", RowblockLn),
+                ("mod_ld", ctypes.c_int32), ("rows_per_group", ctypes.c_int32), ("eps", _f),
+                ("b_fc1", _vp), ("b_fc2", _vp), ("hidden", ctypes.c_int32), ("gate_m", _vp), ("ln2", RowblockLn),
+                ("b3", _vp), ("out3", _vp), ("N3", ctypes.c_int32), ("epi3", ctypes.c_int32),
+                ("hb_out", _vp)]
+
+
 _lib.register({
+    "gvf_rowblock_packed_bytes": (_i64, [_i, _i]),
+    "gvf_rowblock_pack_weight": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "gvf_rowblock_pack_mlp": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "gvf_rowblock_fused_bf16": (_i, [ctypes.POINTER(RowblockArgs), _vp]),
     "gvf_gemm_bf16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "gvf_gemm_stats_parts": (_i, [_i]),
     "gvf_gemm_bf16_resid_stats": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
@@ -90,6 +112,72 @@ def gemm_ln_bf16(x, stats, n_part, w, bias, out, epilogue, eps=1e-6, ln_w=None, 
                                            int(mod_ld), int(rows_per_group), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), M, N, K,
                                            int(epilogue), _stream(x)), "gvf_gemm_ln_bf16")
     return out
+
+
+ROWBLOCK_C, ROWBLOCK_ROWS, ROWBLOCK_KPAD, ROWBLOCK_MAX_HIDDEN, ROWBLOCK_MAX_N3 = 512, 48, 128, 2048, 1536
+
+
+def rowblock_supported(C: int, rows_per_group: int, hidden: int) -> bool:
+    """The row-block kernel covers model_channels 512, 48-row blocks that do not straddle samples, an MLP of <= 2048 hidden units."""
+    return C == ROWBLOCK_C and rows_per_group % ROWBLOCK_ROWS == 0 and hidden % ROWBLOCK_C == 0 and 0 < hidden <= ROWBLOCK_MAX_HIDDEN
+
+
+def rowblock_pack_stream(w1, mlp=None, w3=None):
+    """One weight stream for gvf_rowblock_fused_bf16: w1 = nn.Linear weight bf16 [512][K1 padded to 128] (see cast_pad_bf16), mlp =
+    (mlp.0 weight bf16 [hidden][512], mlp.2 weight bf16 [512][hidden]) or None, w3 = bf16 [N3][512] or None.  Returns a uint8 tensor."""
+    _lib.require_cuda(w1)
+    L = _lib.lib()
+    assert w1.dtype == torch.bfloat16 and w1.shape[0] == ROWBLOCK_C and w1.shape[1] % ROWBLOCK_KPAD == 0 and w1.is_contiguous()
+    sizes = [int(L.gvf_rowblock_packed_bytes(ROWBLOCK_C, w1.shape[1]))]
+    sizes.append(0 if mlp is None else 2 * mlp[0].shape[0] * ROWBLOCK_C * 2)
+    sizes.append(0 if w3 is None else int(L.gvf_rowblock_packed_bytes(w3.shape[0], ROWBLOCK_C)))
+    out = torch.empty(sum(sizes), dtype=torch.uint8, device=w1.device)
+    st = _stream(w1)
+    _lib.check(L.gvf_rowblock_pack_weight(_p(w1), w1.stride(0), ROWBLOCK_C, w1.shape[1], _p(out), st), "gvf_rowblock_pack_weight")
+    if mlp is not None:
+        f1, f2 = mlp
+        assert f1.dtype == f2.dtype == torch.bfloat16 and f1.is_contiguous() and f2.is_contiguous()
+        assert f1.shape == (f2.shape[1], ROWBLOCK_C) and f2.shape[0] == ROWBLOCK_C
+        _lib.check(L.gvf_rowblock_pack_mlp(_p(f1), _p(f2), f1.shape[0], _p(out[sizes[0]:]), st), "gvf_rowblock_pack_mlp")
+    if w3 is not None:
+        assert w3.dtype == torch.bfloat16 and w3.shape[1] == ROWBLOCK_C and w3.is_contiguous() and w3.shape[0] % ROWBLOCK_C == 0
+        _lib.check(L.gvf_rowblock_pack_weight(_p(w3), w3.stride(0), w3.shape[0], ROWBLOCK_C, _p(out[sizes[0] + sizes[1]:]), st),
+                   "gvf_rowblock_pack_weight")
+    return out
+
+
+def _pi(t):
+    return None if t is None else int(t.data_ptr())       # ctypes.Structure pointer fields take ints
+
+
+def _ln_struct(ln):
+    ln = ln or {}
+    return RowblockLn(_pi(ln.get("ln_w")), _pi(ln.get("ln_b")), _pi(ln.get("shift")), _pi(ln.get("scale")))
+
+
+def rowblock_fused(a, stream_w, x, b1=None, gate1=None, ln1=None, mod_ld=0, rows_per_group=0, eps=1e-6,
+                   mlp_bias=None, hidden=0, gate_m=None, ln2=None, b3=None, out3=None, hb_out=None):
+    """x += gate1 * (a W1^T + b1); hb = LN1(x); [x += gate_m * MLP(hb); hb = LN2(x)]; out3 = hb W3^T + b3 or hb_out = hb -- ONE launch
+    (csrc/rowblock.hip; include/gvf_dit.h).  ln1 / ln2: dict with ln_w, ln_b and / or shift, scale.  mlp_bias = (b_fc1, b_fc2)."""
+    _lib.require_cuda(a, stream_w, x)
+    assert a.dtype == torch.bfloat16 and x.dtype == torch.float32 and a.stride(1) == 1 and x.is_contiguous()
+    M, C = x.shape
+    args = RowblockArgs()
+    args.a, args.lda, args.K1, args.w, args.b1 = _pi(a), a.stride(0), a.shape[1], _pi(stream_w), _pi(b1)
+    args.x, args.M, args.C = _pi(x), M, C
+    args.gate1, args.ln1 = _pi(gate1), _ln_struct(ln1)
+    args.mod_ld, args.rows_per_group, args.eps = int(mod_ld), int(rows_per_group), float(eps)
+    if hidden:
+        args.b_fc1, args.b_fc2 = _pi(mlp_bias[0]), _pi(mlp_bias[1])
+        args.hidden, args.gate_m, args.ln2 = int(hidden), _pi(gate_m), _ln_struct(ln2)
+    if out3 is not None:
+        assert out3.dtype == torch.bfloat16 and out3.is_contiguous() and out3.shape[0] == M
+        args.b3, args.out3, args.N3, args.epi3 = _pi(b3), _pi(out3), out3.shape[1], EPI_STORE_BF16
+    if hb_out is not None:
+        assert hb_out.dtype == torch.bfloat16 and hb_out.is_contiguous() and tuple(hb_out.shape) == (M, C)
+        args.hb_out = _pi(hb_out)
+    _lib.check(_lib.lib().gvf_rowblock_fused_bf16(ctypes.byref(args), _stream(x)), "gvf_rowblock_fused_bf16")
+    return x
 
 
 def _s4(st, head_dim=32):

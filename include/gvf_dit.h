@@ -51,6 +51,43 @@ int gvf_gemm_ln_bf16(const float* X, int ldx, const float* row_stats, int n_part
                      const void* W, int ldw, const float* bias, void* C, int ldc, int M, int N, int K, int epilogue,
                      void* stream);
 
+/* ---- row-block kernel: one launch per sub-layer boundary of the DiT block (model_channels C = 512 only) -------------------------
+ * Replaces, in ONE launch over 48-row blocks of the fp32 stream x [M][512] (M a multiple of 48), this run of the reference's
+ * ModulatedSparseTransformerCrossBlock._forward (model/dit.py:236-277) and DiT._forward (model/dit.py:449-480):
+ *     x   += gate1 * (A W1^T + b1)                  the projection closing a sub-layer (to_out, or input_layer for A = the input)
+ *     hb   = bf16(LN(x) * mul1 + add1)              the LayerNorm opening the next one (ln1: affine and / or adaLN modulate)
+ *   [ x   += gate_m * (gelu(hb Wfc1^T + b_fc1) Wfc2^T + b_fc2);  hb = bf16(LN(x) * mul2 + add2) ]      when hidden != 0: the whole MLP
+ *     out3 = epi3(hb W3^T + b3)                     the first projection of the next sub-layer (to_qkv / to_q), N3 a multiple of 512
+ * or, with N3 == 0, hb_out = hb (rows of the last LayerNorm, bf16 [M][512]) for a projection the kernel does not cover
+ * (final_layer.linear).  The normalised rows and the MLP's hidden units never leave the CU.
+ * `w` is ONE weight stream in MFMA-fragment order, the segments back to back in the order the kernel consumes them:
+ *   W1:  gvf_rowblock_pack_weight (nn.Linear weight bf16 [N][K], N a multiple of 512, K padded to a multiple of 128 ->
+ *        gvf_rowblock_packed_bytes(N, K) bytes),
+ *   MLP: gvf_rowblock_pack_mlp (mlp.0 weight [hidden][512] and mlp.2 weight [512][hidden] -> 2 * hidden * 512 * 2 bytes, interleaved
+ *        per 512 hidden units; hidden a multiple of 512, <= 2048)           -- only when hidden != 0,
+ *   W3:  gvf_rowblock_pack_weight                                            -- only when N3 != 0.
+ * K1 (<= 512, multiple of 128) is the PADDED depth of W1; A is bf16 [M][lda] with lda >= K1.  gate / shift / scale: f32, row g =
+ * row / rows_per_group of leading dimension mod_ld (rows_per_group a multiple of 48); NULL = no gate / no modulate.
+ * Rounding points are those of the unfused launches: bf16 operands, fp32 accumulation, fp32 stream, LayerNorm in fp32,
+ * bf16 hidden units. */
+typedef struct gvf_rowblock_ln {
+    const float* ln_w; const float* ln_b;      /* [512] or both NULL */
+    const float* shift; const float* scale;    /* or both NULL */
+} gvf_rowblock_ln;
+typedef struct gvf_rowblock_args {
+    const void* a; int32_t lda; int32_t K1; const void* w; const float* b1;
+    float* x; int32_t M; int32_t C;
+    const float* gate1; gvf_rowblock_ln ln1;
+    int32_t mod_ld; int32_t rows_per_group; float eps;
+    const float* b_fc1; const float* b_fc2; int32_t hidden; const float* gate_m; gvf_rowblock_ln ln2;
+    const float* b3; void* out3; int32_t N3; int32_t epi3;
+    void* hb_out;
+} gvf_rowblock_args;
+int64_t gvf_rowblock_packed_bytes(int N, int K);
+int gvf_rowblock_pack_weight(const void* w_bf16, int ldw, int N, int K, void* packed, void* stream);
+int gvf_rowblock_pack_mlp(const void* w_fc1_bf16, const void* w_fc2_bf16, int hidden, void* packed, void* stream);
+int gvf_rowblock_fused_bf16(const gvf_rowblock_args* args, void* stream);
+
 /* softmax(q k^T * scale) v, head_dim 32 or 64, no mask, scale > 0.  Batch index = (outer, inner); every tensor
  * takes 4 strides in elements {outer, inner, seq, head}: element (o,i,l,h,c) sits at
  * o*s[0] + i*s[1] + l*s[2] + h*s[3] + c, so the q/k/v slices of a packed qkv / kv projection, a K/V set
