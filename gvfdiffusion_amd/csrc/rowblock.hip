@@ -78,6 +78,7 @@ struct RbParams {
     const float* b3;                             // bias [N3] or null
     unsigned short* out3; int N3;          // bf16 [M][N3], or null: no last projection
     unsigned short* hb_out;                      // optional: the rows of the last LayerNorm, bf16 [M][512]
+    long long* dbg;                              // RB_TIMING builds only: [workgroup][16] s_memtime stamps
 };
 
 __device__ __forceinline__ unsigned rb_pack_bf16(float lo, float hi) {
@@ -88,11 +89,14 @@ __device__ __forceinline__ unsigned rb_pack_bf16(float lo, float hi) {
     return __builtin_bit_cast(unsigned, v);
 }
 
-// same expression as gemm.hip's GELU epilogue
+// GELU (tanh form) = x * sigmoid(2u), u = sqrt(2/pi) (x + 0.044715 x^3), as gemm.hip's epilogue -- with the hardware reciprocal (1 ulp)
+// in place of the IEEE division (~10 instructions per element; 48 elements per lane per 512 hidden units, on the critical path
+// between the two GEMMs of a slice)
 __device__ __forceinline__ float rb_gelu_tanh(float x) {
-    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    const float u = k0 * (x + k1 * x * x * x);
-    return x / (1.0f + __expf(-2.0f * u));
+    const float c0 = -2.0f * 0.7978845608028654f * 1.4426950408889634f, c1 = 0.044715f;
+    const float x2 = x * x;
+    const float e = __builtin_amdgcn_exp2f(c0 * (x + c1 * x2 * x));
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
 __device__ __forceinline__ void rb_dma16(const unsigned short* g, uint4* l) {
@@ -105,7 +109,11 @@ __device__ __forceinline__ bf16x8 rb_ldw(const uint4* p) { return __builtin_bit_
 // Past the end it repeats its last step (the refills behind the last MFMAs are redundant, never out of bounds).
 struct RbStream {
     const uint4* w; int Gt;
+#if defined(RB_ABL_WSMALL)        // timing experiment: every step reads the same 32 KiB (L1 / L2 hits only)
+    __device__ __forceinline__ const uint4* at(int s) const { return w + (long long)(s & 1) * RB_STEP; }
+#else
     __device__ __forceinline__ const uint4* at(int s) const { return w + (long long)(s < Gt ? s : Gt - 1) * RB_STEP; }
+#endif
 };
 
 // `steps` k-steps (a multiple of D) of acc += act * W: 3 activation fragments per step from LDS (act = block base + lane), 24 MFMAs,
@@ -114,21 +122,35 @@ struct RbStream {
 // asks and a wait on that miss for the others: ~1 us, i.e. 4+ k-steps of MFMA work.
 template <int D>
 __device__ __forceinline__ void rb_gemm(f32x4 (&acc)[3][RB_CT], bf16x8 (&wf)[D][RB_CT], const uint4* act, int steps, int& g, const RbStream& st) {
+    static_assert(D % 2 == 0, "the activation fragments are double-buffered by step parity");
+    // the activation fragments of step s + 1 are read from LDS while the MFMAs of step s run (the read past the last step stays
+    // inside the LDS block and is never used)
+    bf16x8 af[2][3];
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt) af[0][rt] = __builtin_bit_cast(bf16x8, act[rt * 64]);
     // (not unrolled: in straight-line code the scheduler sinks every refill to just before its use and the prefetch is gone)
 #pragma clang loop unroll(disable)
     for (int ksl = 0; ksl < steps; ksl += D, g += D) {
 #pragma unroll
         for (int b = 0; b < D; ++b) {
-            bf16x8 af[3];
 #pragma unroll
-            for (int rt = 0; rt < 3; ++rt) af[rt] = __builtin_bit_cast(bf16x8, act[((ksl + b) * 3 + rt) * 64]);
+            for (int rt = 0; rt < 3; ++rt) {
+#ifdef RB_ABL_NOLDS                // timing experiment: activation fragments as opaque register values
+                asm volatile("" : "+v"(af[(b + 1) & 1][rt]));
+#else
+                af[(b + 1) & 1][rt] = __builtin_bit_cast(bf16x8, act[((ksl + b + 1) * 3 + rt) * 64]);
+#endif
+            }
+            __builtin_amdgcn_sched_barrier(0);   // ... issued BEFORE this step's MFMAs (the scheduler would sink them behind)
             const uint4* sn = st.at(g + b + D);
 #pragma unroll
             for (int ct = 0; ct < RB_CT; ++ct) {
 #pragma unroll
                 for (int rt = 0; rt < 3; ++rt)
-                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b][ct], af[rt], acc[rt][ct], 0, 0, 0);
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b][ct], af[b & 1][rt], acc[rt][ct], 0, 0, 0);
+#ifndef RB_ABL_NOW                 // timing experiment: no weight refills at all
                 wf[b][ct] = rb_ldw(sn + ct * 64);
+#endif
             }
             __builtin_amdgcn_sched_barrier(0);   // the refills stay in the step that frees their registers
         }
@@ -228,6 +250,13 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
     __shared__ uint4 smem[RB_SMEM];              // the ONE LDS object (a second one makes hipcc drain vmcnt before every ds_read)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, lq = lane >> 4;
     const int m0 = blockIdx.x * RB_BM;           // M % 48 == 0: no row guards anywhere
+#ifdef RB_TIMING
+    int stamp_i = 0;
+#define RB_STAMP() do { if (tid == 0 && p.dbg) p.dbg[blockIdx.x * 16 + stamp_i] = (long long)__builtin_amdgcn_s_memrealtime(); ++stamp_i; } while (0)
+#else
+#define RB_STAMP() do { } while (0)
+#endif
+    RB_STAMP();
     uint4* R0 = &smem[0];                        // normalised rows (operand of mlp.0 / of the last projection)
     uint4* R1 = &smem[RB_BUF];                   // phase-1 activations, then the GELU'd hidden units of one 512-wide slice
     float* sPar = reinterpret_cast<float*>(&smem[RB_PAR]);
@@ -315,16 +344,20 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
     }
     f32x4 acc[3][RB_CT];
     rb_zero(acc);
-    // pin the residual tile here: left alone, the compiler sinks these loads to their first use -- the epilogue, after the k-loop
+    // pin the residual tile here: left alone, the compiler sinks these loads to their first use -- the epilogue, after the k-loop.
+    // (Requesting it later, piece by piece under the k-loop, measured 0.7 us better per launch and cost 9 spilled registers: VMEM results
+    // are counted back in order, so the pieces have to ride in front of refills that are waited for 4 steps later.)
 #pragma unroll
     for (int rt = 0; rt < 3; ++rt)
 #pragma unroll
         for (int ct = 0; ct < RB_CT; ++ct) asm volatile("" : "+v"(rs[rt][ct]));
     __syncthreads();                             // activations landed (own DMA drained before the barrier), parameters visible
+    RB_STAMP();
 
     // ---- phase 1: x = x + gate1 * (A W1^T + b1), LayerNorm ln1 -> R0
     int g = 0;
     rb_gemm<D>(acc, wf, R1 + lane, G1, g, st);
+    RB_STAMP();
 #pragma unroll
     for (int ct = 0; ct < RB_CT; ++ct) {
         const f32x4 b4 = *reinterpret_cast<const f32x4*>(sPar + colw + 16 * ct);
@@ -340,9 +373,11 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
                                                  // (MLP: the stream is written once, after the MLP)
         }
     }
+    RB_STAMP();
     unsigned short* hb_rows = p.hb_out != nullptr ? p.hb_out + (long long)m0 * RB_C : nullptr;
     rb_layernorm(acc, sRed, sPar + 2 * RB_C, sPar + 3 * RB_C, p.eps, R0, MLP ? nullptr : hb_rows, wave, lane, lq, l15, colw);
 
+    RB_STAMP();
     if (MLP) {
         // ---- MLP: per 512 hidden units  h = gelu(R0 Wfc1[slice]^T + b) -> R1 (bf16 fragments);  acc2 += R1 Wfc2[:, slice]^T
         f32x4 acc2[3][RB_CT];
@@ -383,10 +418,13 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
                 *reinterpret_cast<f32x4*>(xr[rt] + 16 * ct) = rs[rt][ct];
             }
         }
+        RB_STAMP();
         rb_layernorm(acc2, sRed, sPar + 6 * RB_C, sPar + 7 * RB_C, p.eps, R0, hb_rows, wave, lane, lq, l15, colw);
+        RB_STAMP();
     }
     if (P3 == 0) return;
     rb_lds_barrier();                             // the normalised rows are complete in R0
+    RB_STAMP();
 
     // ---- last projection: out[:, 512 pass .. + 512] = R0 W3[pass]^T + b3.  A lane holds 4 columns of a row: written straight out that is
     // 8-byte pieces, 32 contiguous bytes per row per instruction (measured: 20 us per 12.6 MB pass).  So the tile goes through R1 (free by
@@ -420,7 +458,9 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
 #endif
             *reinterpret_cast<uint4*>(p.out3 + (long long)(m0 + r) * p.N3 + pass * RB_C + 8 * lane) = v;
         }
+        RB_STAMP();
     }
+#undef RB_STAMP
 }
 
 // W bf16 [N][ldw] (nn.Linear layout) -> fragment order.  One 16-byte chunk per thread.
@@ -465,6 +505,8 @@ __global__ __launch_bounds__(256) void rowblock_pack_mlp_kernel(const unsigned s
 }
 
 }  // namespace
+
+static long long* g_rb_dbg = nullptr;        // RB_TIMING builds of scripts/ubench/rowblock_bench.hip set it
 
 extern "C" int64_t gvf_rowblock_packed_bytes(int N, int K) {
     if (N <= 0 || K <= 0 || N % RB_C != 0) return GVF_EINVAL;
@@ -527,6 +569,7 @@ extern "C" int gvf_rowblock_fused_bf16(const gvf_rowblock_args* a, void* stream_
     p.ln2 = RbLn{a->ln2.ln_w, a->ln2.ln_b, a->ln2.shift, a->ln2.scale};
     p.b3 = a->b3; p.out3 = a->N3 != 0 ? (unsigned short*)a->out3 : nullptr; p.N3 = a->N3;
     p.hb_out = (unsigned short*)a->hb_out;
+    p.dbg = g_rb_dbg;
     (void)hipGetLastError();
     const dim3 grid((unsigned)(a->M / RB_BM)), block(RB_THREADS);
     if (mlp) rowblock_kernel<true, RB_DEPTH_MLP><<<grid, block, 0, (hipStream_t)stream_>>>(p);

@@ -122,6 +122,28 @@ static int run_case(const char* name, int B, int TN, int K1, int hidden, int N3,
     }
     const double rx = sqrt(ex / nx), ro = sqrt(eo / no);
 
+#ifdef RB_TIMING
+    {   // phase stamps (100 MHz s_memrealtime) of one launch, averaged over the workgroups
+        const int nwg = M / 48;
+        long long* dd; CK(hipMalloc(&dd, (size_t)nwg * 16 * 8)); CK(hipMemset(dd, 0, (size_t)nwg * 16 * 8));
+        g_rb_dbg = dd;
+        (void)gvf_rowblock_fused_bf16(&a, nullptr);
+        CK(hipDeviceSynchronize());
+        g_rb_dbg = nullptr;
+        std::vector<long long> hd((size_t)nwg * 16);
+        CK(hipMemcpy(hd.data(), dd, hd.size() * 8, hipMemcpyDeviceToHost));
+        long long t0 = hd[0], tend = 0;
+        for (int w = 0; w < nwg; ++w) t0 = hd[w * 16] < t0 ? hd[w * 16] : t0;
+        printf("    phase ends, us after the first workgroup's entry (mean over %d workgroups):", nwg);
+        for (int i = 0; i < 16; ++i) {
+            double sum = 0; int cnt = 0;
+            for (int w = 0; w < nwg; ++w) if (hd[w * 16 + i]) { sum += (hd[w * 16 + i] - t0) * 0.01; ++cnt; tend = hd[w * 16 + i] > tend ? hd[w * 16 + i] : tend; }
+            if (cnt) printf(" %.1f", sum / cnt);
+        }
+        printf("  | last stamp %.1f\n", (tend - t0) * 0.01);
+        (void)hipFree(dd);
+    }
+#endif
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 3; ++i) (void)gvf_rowblock_fused_bf16(&a, nullptr);
     CK(hipEventRecord(e0));
@@ -140,14 +162,15 @@ static int run_case(const char* name, int B, int TN, int K1, int hidden, int N3,
 
 int main(int argc, char** argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 20;
+    const int only = argc > 2 ? atoi(argv[2]) : -1;      // run one case (PMC passes)
     int bad = 0;
-    bad |= run_case("to_out + adaLN + to_qkv (N3 1536)", 1, 12288, 512, 0, 1536, true, iters);
-    bad |= run_case("to_out + affine LN + to_q (N3 512)", 1, 12288, 512, 0, 512, false, iters);
-    bad |= run_case("input_layer (K 128) + adaLN + to_qkv", 1, 12288, 128, 0, 1536, true, iters);
-    bad |= run_case("to_out + LN + MLP 2048 + adaLN + to_qkv", 1, 12288, 512, 2048, 1536, false, iters);
-    bad |= run_case("to_out + LN + MLP 2048 + adaLN -> hb_out", 1, 12288, 512, 2048, 0, false, iters);
-    bad |= run_case("B=3: to_out + LN + MLP + adaLN + to_qkv", 3, 12288, 512, 2048, 1536, false, iters);
-    bad |= run_case("small: M 96, MLP 512, N3 512", 2, 48, 128, 512, 512, true, 3);
+    if (only < 0 || only == 0) bad |= run_case("to_out + adaLN + to_qkv (N3 1536)", 1, 12288, 512, 0, 1536, true, iters);
+    if (only < 0 || only == 1) bad |= run_case("to_out + affine LN + to_q (N3 512)", 1, 12288, 512, 0, 512, false, iters);
+    if (only < 0 || only == 2) bad |= run_case("input_layer (K 128) + adaLN + to_qkv", 1, 12288, 128, 0, 1536, true, iters);
+    if (only < 0 || only == 3) bad |= run_case("to_out + LN + MLP 2048 + adaLN + to_qkv", 1, 12288, 512, 2048, 1536, false, iters);
+    if (only < 0 || only == 4) bad |= run_case("to_out + LN + MLP 2048 + adaLN -> hb_out", 1, 12288, 512, 2048, 0, false, iters);
+    if (only < 0 || only == 5) bad |= run_case("B=3: to_out + LN + MLP + adaLN + to_qkv", 3, 12288, 512, 2048, 1536, false, iters);
+    if (only < 0 || only == 6) bad |= run_case("small: M 96, MLP 512, N3 512", 2, 48, 128, 512, 512, true, 3);
     printf(bad ? "FAILED\n" : "ALL OK\n");
     return bad;
 }
