@@ -5,6 +5,7 @@
 // h * (1 + scale) + shift), model/dit.py:217-225,240-242 (SiLU in front of the adaLN Linear).
 // One wave per row (C <= 1024): the row is read once with 16-byte loads and kept in registers for the
 // mean / variance / normalise passes (two-pass variance, as torch's LayerNorm computes it).
+#include <cmath>
 #include "gvf_common.h"
 #include "../../include/gvf_rast.h"
 #include "../../include/gvf_dit.h"
@@ -112,6 +113,49 @@ __global__ __launch_bounds__(256) void cast_pad_kernel(const float* __restrict__
     }
 }
 
+
+// TimestepEmbedder + the SiLU in front of the adaLN projections in ONE launch (model/dit.py:59-100: sinusoid -> Linear -> SiLU ->
+// Linear; model/dit.py:217-225: SiLU -> Linear): out[b] = bf16(silu(W2 bf16(silu(W0 bf16([cos | sin](t_b f)) + b0)) + b2)), the operand of
+// the one GEMM that produces every block's modulation vectors.  One workgroup per sample; a wave computes one output at a time
+// (the 64 lanes read a contiguous piece of the weight row, wave reduction): 0.4 MFLOP, launch-latency sized.  Rounding points as the
+// launches it replaces (torch sin / cos, gvf_cast_pad_bf16, gvf_gemm_bf16 x 2): bf16 operands, fp32 accumulation.
+__device__ __forceinline__ float bf2f_(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+
+__global__ __launch_bounds__(256) void timestep_embed_kernel(const float* __restrict__ t, int F, float neg_log_period,
+                                                             const unsigned short* __restrict__ W0, int ldw0, const float* __restrict__ b0,
+                                                             const unsigned short* __restrict__ W2, int ldw2, const float* __restrict__ b2, int C,
+                                                             unsigned short* __restrict__ out, int ld_out, float* __restrict__ t_emb) {
+    __shared__ float sA[1024], sB[1024];          // F <= 1024, C <= 1024
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+    const int half = F / 2;
+    const float tv = t[b];
+    for (int i = tid; i < F; i += 256) {
+        const int j = i < half ? i : i - half;
+        const float f = expf(neg_log_period * (float)j / (float)half);     // torch: exp(-log(max_period) * arange(half) / half), the scalar in fp32
+        const float a = tv * f;
+        sA[i] = bf2f_(f2bf(i < half ? cosf(a) : sinf(a)));
+    }
+    __syncthreads();
+    for (int o = wave; o < C; o += 4) {
+        float acc = 0.f;
+        for (int k = lane; k < F; k += 64) acc += bf2f_(W0[(size_t)o * ldw0 + k]) * sA[k];
+        acc = wave_sum(acc);
+        if (lane == 0) { const float v = acc + (b0 ? b0[o] : 0.f); sB[o] = bf2f_(f2bf(v / (1.0f + __expf(-v)))); }
+    }
+    __syncthreads();
+    for (int o = wave; o < C; o += 4) {
+        float acc = 0.f;
+        for (int k = lane; k < C; k += 64) acc += bf2f_(W2[(size_t)o * ldw2 + k]) * sB[k];
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            const float v = acc + (b2 ? b2[o] : 0.f);
+            if (t_emb != nullptr) t_emb[(size_t)b * C + o] = v;
+            out[(size_t)b * ld_out + o] = f2bf(v / (1.0f + __expf(-v)));
+        }
+    }
+    for (int o = C + tid; o < ld_out; o += 256) out[(size_t)b * ld_out + o] = 0;
+}
+
 }  // namespace
 
 extern "C" int gvf_layernorm_modulate_bf16(const float* x, void* out_bf16, int rows, int C, float eps, const float* ln_w,
@@ -154,6 +198,20 @@ extern "C" int gvf_cast_pad_bf16(const float* src, int ld_src, void* dst, int ld
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(cast_pad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, src, ld_src,
                        (unsigned short*)dst, ld_dst, (long long)rows, cols, act);
+    GVF_CHECK_LAUNCH();
+    return GVF_OK;
+}
+
+extern "C" int gvf_dit_timestep_embed_bf16(const float* t, int B, int freq_dim, float max_period, const void* w0_bf16, int ldw0, const float* b0,
+                                           const void* w2_bf16, int ldw2, const float* b2, int C, void* out_bf16, int ld_out, float* t_emb,
+                                           void* stream_) {
+    if (B < 0 || freq_dim <= 0 || (freq_dim & 1) || freq_dim > 1024 || C <= 0 || C > 1024 || ldw0 < freq_dim || ldw2 < C || ld_out < C || !(max_period > 1.0f))
+        return GVF_EINVAL;
+    if (B == 0) return GVF_OK;
+    if (!t || !w0_bf16 || !w2_bf16 || !out_bf16) return GVF_EINVAL;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(timestep_embed_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream_, t, freq_dim, (float)(-log((double)max_period)), (const unsigned short*)w0_bf16, ldw0,
+                       b0, (const unsigned short*)w2_bf16, ldw2, b2, C, (unsigned short*)out_bf16, ld_out, t_emb);
     GVF_CHECK_LAUNCH();
     return GVF_OK;
 }

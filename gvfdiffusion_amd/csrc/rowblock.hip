@@ -67,6 +67,7 @@ struct RbParams {
     const unsigned short* A; int lda, K1;        // phase-1 activations, bf16 [M][lda], K1 <= 512
     const uint4* W; const float* b1;             // the packed weight stream: W1 [K1/32 steps] | MLP [2 * 16 * hidden/512] | W3 [16 * N3/512]; bias [512] or null
     float* x; int M;                             // fp32 stream [M][512], updated in place
+    const float* x_in; int x_in_period;          // optional: the residual is read from x_in[(row / rpg) * period + (row % rpg) % period] instead
     const float* gate1;                          // row g of leading dimension mod_ld, or null (-> 1)
     RbLn ln1;
     int mod_ld, rpg; float eps;
@@ -291,11 +292,18 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
     float* xr[3];                                // this lane's three rows of the stream, at its first column
 #pragma unroll
     for (int rt = 0; rt < 3; ++rt) xr[rt] = p.x + (long long)m0 * RB_C + (16 * rt + l15) * RB_C + colw;
-    f32x4 rs[3][RB_CT];                              // residual tile of x
+    f32x4 rs[3][RB_CT];                              // residual tile of x (or of x_in: input_layer adds to the position embedding,
+                                                     // [sample][N][512] broadcast over the frames -- no 25 MB copy to initialise the stream)
 #pragma unroll
-    for (int rt = 0; rt < 3; ++rt)
+    for (int rt = 0; rt < 3; ++rt) {
+        const float* src = xr[rt];
+        if (p.x_in != nullptr) {
+            const int grp = p.rpg > 0 ? m0 / p.rpg : 0, in_grp = p.rpg > 0 ? m0 % p.rpg : m0;
+            src = p.x_in + ((long long)grp * p.x_in_period + (in_grp + 16 * rt + l15) % p.x_in_period) * RB_C + colw;
+        }
 #pragma unroll
-        for (int ct = 0; ct < RB_CT; ++ct) rs[rt][ct] = *reinterpret_cast<const f32x4*>(xr[rt] + 16 * ct);
+        for (int ct = 0; ct < RB_CT; ++ct) rs[rt][ct] = *reinterpret_cast<const f32x4*>(src + 16 * ct);
+    }
     {
         // per-column vectors -> LDS.  Unconditional loads (a null vector reads the stream instead and is discarded): no branch + wait
         // per vector
@@ -543,6 +551,8 @@ extern "C" int gvf_rowblock_fused_bf16(const gvf_rowblock_args* a, void* stream_
         return GVF_EINVAL;
     if (a->M == 0) return GVF_OK;
     if (!a->a || !a->w || !a->x) return GVF_EINVAL;
+    if (a->x_in != nullptr && (a->x_in_period <= 0 || a->rows_per_group <= 0 || a->rows_per_group % a->x_in_period != 0 || (((uintptr_t)a->x_in) & 15)))
+        return GVF_EINVAL;
     const gvf_rowblock_ln* lns[2] = {&a->ln1, &a->ln2};
     bool grouped = a->gate1 != nullptr || a->gate_m != nullptr;
     for (int i = 0; i < 2; ++i) {
@@ -562,9 +572,10 @@ extern "C" int gvf_rowblock_fused_bf16(const gvf_rowblock_args* a, void* stream_
     p.A = (const unsigned short*)a->a; p.lda = a->lda; p.K1 = a->K1;
     p.W = (const uint4*)a->w; p.b1 = a->b1;
     p.x = a->x; p.M = a->M;
+    p.x_in = a->x_in; p.x_in_period = a->x_in_period;
     p.gate1 = a->gate1;
     p.ln1 = RbLn{a->ln1.ln_w, a->ln1.ln_b, a->ln1.shift, a->ln1.scale};
-    p.mod_ld = a->mod_ld; p.rpg = grouped ? a->rows_per_group : 0; p.eps = a->eps;
+    p.mod_ld = a->mod_ld; p.rpg = (grouped || a->x_in != nullptr) ? a->rows_per_group : 0; p.eps = a->eps;
     p.b_fc1 = a->b_fc1; p.b_fc2 = a->b_fc2; p.hidden = a->hidden; p.gate_m = a->gate_m;
     p.ln2 = RbLn{a->ln2.ln_w, a->ln2.ln_b, a->ln2.shift, a->ln2.scale};
     p.b3 = a->b3; p.out3 = a->N3 != 0 ? (unsigned short*)a->out3 : nullptr; p.N3 = a->N3;

@@ -408,24 +408,32 @@ class DiT(nn.Module):
         Li, Ls = ctx["Li"], ctx["Ls"]
         bf, f32 = torch.bfloat16, torch.float32
 
-        # timestep embedding -> t_emb (B,C) -> SiLU -> every adaLN projection of the step in one GEMM
-        tf = dit_ops.cast_pad_bf16(TimestepEmbedder.timestep_embedding(t.to(dev), self.t_embedder.frequency_embedding_size).contiguous(),
-                                   dit_ops.pad64(self.t_embedder.frequency_embedding_size))
-        h1 = torch.empty((B, C), dtype=f32, device=dev)
-        dit_ops.gemm_bf16(tf, *W["t0"], h1, dit_ops.EPI_STORE_F32)
-        t_emb = torch.empty((B, C), dtype=f32, device=dev)
-        dit_ops.gemm_bf16(dit_ops.cast_pad_bf16(h1, dit_ops.pad64(C), act=1), *W["t2"], t_emb, dit_ops.EPI_STORE_F32)
+        # timestep embedding -> t_emb (B,C) -> SiLU (one launch) -> every adaLN projection of the step in one GEMM
         mod = torch.empty((B, W["mod_total"]), dtype=f32, device=dev)
-        dit_ops.gemm_bf16(dit_ops.cast_pad_bf16(t_emb, dit_ops.pad64(C), act=1), W["mod_w"], W["mod_b"], mod, dit_ops.EPI_STORE_F32)
+        if self.t_embedder.frequency_embedding_size % 2 == 0 and self.t_embedder.frequency_embedding_size <= 1024 and C <= 1024:
+            s2 = torch.empty((B, dit_ops.pad64(C)), dtype=bf, device=dev)
+            dit_ops.timestep_embed_bf16(t.to(dev).float().contiguous(), W["t0"][0], W["t0"][1], W["t2"][0], W["t2"][1], s2,
+                                        freq_dim=self.t_embedder.frequency_embedding_size)
+        else:
+            tf = dit_ops.cast_pad_bf16(TimestepEmbedder.timestep_embedding(t.to(dev), self.t_embedder.frequency_embedding_size).contiguous(),
+                                       dit_ops.pad64(self.t_embedder.frequency_embedding_size))
+            h1 = torch.empty((B, C), dtype=f32, device=dev)
+            dit_ops.gemm_bf16(tf, *W["t0"], h1, dit_ops.EPI_STORE_F32)
+            t_emb = torch.empty((B, C), dtype=f32, device=dev)
+            dit_ops.gemm_bf16(dit_ops.cast_pad_bf16(h1, dit_ops.pad64(C), act=1), *W["t2"], t_emb, dit_ops.EPI_STORE_F32)
+            s2 = dit_ops.cast_pad_bf16(t_emb, dit_ops.pad64(C), act=1)
+        dit_ops.gemm_bf16(s2, W["mod_w"], W["mod_b"], mod, dit_ops.EPI_STORE_F32)
         mod_ld = W["mod_total"]
 
         # residual stream h (fp32): position embedding broadcast over T, plus input_layer(x)
+        if self.use_rowblock and dit_ops.rowblock_supported(C, T * N, int(C * self.mlp_ratio)):
+            if ctx["pos"] is not None:      # the first row-block launch reads the (B, N, C) embedding with the broadcast and only writes h
+                return self._blocks_rowblock(x, torch.empty((M, C), dtype=f32, device=dev), mod, mod_ld, W, ctx, B, T, N, pos=ctx["pos"])
+            return self._blocks_rowblock(x, torch.zeros((M, C), dtype=f32, device=dev), mod, mod_ld, W, ctx, B, T, N)
         if ctx["pos"] is not None:
             h = ctx["pos"][:, None].expand(B, T, N, C).reshape(M, C).contiguous()
         else:
             h = torch.zeros((M, C), dtype=f32, device=dev)
-        if self.use_rowblock and dit_ops.rowblock_supported(C, T * N, int(C * self.mlp_ratio)):
-            return self._blocks_rowblock(x, h, mod, mod_ld, W, ctx, B, T, N)
         xb = dit_ops.cast_pad_bf16(x.reshape(M, Cin).float().contiguous(), dit_ops.pad64(Cin))
         hb = torch.empty((M, C), dtype=bf, device=dev)          # attention-output scratch of the cross attentions
         qkv = torch.empty((M, 3 * C), dtype=bf, device=dev)
@@ -502,7 +510,7 @@ class DiT(nn.Module):
         ln_gemm(W["final"], y, dit_ops.EPI_STORE_F32, shift=mview(o), scale=mview(o + C))
         return y.reshape(B, T, N, self.out_channels).to(x.dtype if x.dtype.is_floating_point else f32)
 
-    def _blocks_rowblock(self, x, h, mod, mod_ld, W, ctx, B, T, N):
+    def _blocks_rowblock(self, x, h, mod, mod_ld, W, ctx, B, T, N, pos=None):
         """The blocks with one launch per sub-layer boundary (csrc/rowblock.hip): per block  pack + spatial attention | to_out + adaLN +
         to_qkv | temporal attention | to_out + norm3 + to_q | image attention | to_out + norm4 + to_q | static attention | to_out +
         adaLN + MLP + adaLN + the NEXT block's to_qkv -- 9 launches instead of 20, the fp32 stream through HBM 5 times instead of 15,
@@ -534,7 +542,7 @@ class DiT(nn.Module):
         o = offs[0]
         # h = pos + input_layer(x); adaLN of block 0; its to_qkv
         fused(xb, rb["in"], b1=W["input"][1], ln1=dict(shift=mview(o), scale=mview(o + C)), out3=qkv,
-              b3=blocks[0]["spatial_self_attn"]["qkv"][1])
+              b3=blocks[0]["spatial_self_attn"]["qkv"][1], x_in=None if pos is None else pos.reshape(B * N, C), x_in_period=N)
         hbn = None
         for i, b in enumerate(blocks):
             o, s = offs[i], rb["blocks"][i]

@@ -20,6 +20,7 @@ class RowblockArgs(ctypes.Structure):
     """gvf_rowblock_args of include/gvf_dit.h (same field order; native alignment)"""
     _fields_ = [("a", _vp), ("lda", ctypes.c_int32), ("K1", ctypes.c_int32), ("w", _vp), ("b1", _vp),
                 ("x", _vp), ("M", ctypes.c_int32), ("C", ctypes.c_int32),
+                ("x_in", _vp), ("x_in_period", ctypes.c_int32),
                 ("gate1", _vp), ("ln1", RowblockLn),
                 ("mod_ld", ctypes.c_int32), ("rows_per_group", ctypes.c_int32), ("eps", _f),
                 ("b_fc1", _vp), ("b_fc2", _vp), ("hidden", ctypes.c_int32), ("gate_m", _vp), ("ln2", RowblockLn),
@@ -28,6 +29,7 @@ class RowblockArgs(ctypes.Structure):
 
 
 _lib.register({
+    "gvf_dit_timestep_embed_bf16": (_i, [_vp, _i, _i, _f, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp]),
     "gvf_rowblock_packed_bytes": (_i64, [_i, _i]),
     "gvf_rowblock_pack_weight": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "gvf_rowblock_pack_mlp": (_i, [_vp, _vp, _i, _vp, _vp]),
@@ -114,6 +116,18 @@ def gemm_ln_bf16(x, stats, n_part, w, bias, out, epilogue, eps=1e-6, ln_w=None, 
     return out
 
 
+def timestep_embed_bf16(t, w0, b0, w2, b2, out, freq_dim=256, max_period=10000.0, t_emb=None):
+    """out <- bf16(silu(TimestepEmbedder(t))) (rows padded with zeros to out.shape[1]): the sinusoid, both Linears and both SiLUs of
+    model/dit.py:59-100,217-225 in one launch.  w0 / w2: bf16 nn.Linear weights (K padded), b0 / b2 f32 or None."""
+    _lib.require_cuda(t, w0, w2, out)
+    assert t.dtype == torch.float32 and t.dim() == 1 and w0.dtype == w2.dtype == out.dtype == torch.bfloat16
+    C = w2.shape[0]
+    _lib.check(_lib.lib().gvf_dit_timestep_embed_bf16(_p(t), t.numel(), int(freq_dim), float(max_period), _p(w0), w0.stride(0), _p(b0), _p(w2),
+                                                      w2.stride(0), _p(b2), C, _p(out), out.stride(0), _p(t_emb), _stream(t)),
+               "gvf_dit_timestep_embed_bf16")
+    return out
+
+
 ROWBLOCK_C, ROWBLOCK_ROWS, ROWBLOCK_KPAD, ROWBLOCK_MAX_HIDDEN, ROWBLOCK_MAX_N3 = 512, 48, 128, 2048, 1536
 
 
@@ -156,15 +170,19 @@ def _ln_struct(ln):
 
 
 def rowblock_fused(a, stream_w, x, b1=None, gate1=None, ln1=None, mod_ld=0, rows_per_group=0, eps=1e-6,
-                   mlp_bias=None, hidden=0, gate_m=None, ln2=None, b3=None, out3=None, hb_out=None):
+                   mlp_bias=None, hidden=0, gate_m=None, ln2=None, b3=None, out3=None, hb_out=None, x_in=None, x_in_period=0):
     """x += gate1 * (a W1^T + b1); hb = LN1(x); [x += gate_m * MLP(hb); hb = LN2(x)]; out3 = hb W3^T + b3 or hb_out = hb -- ONE launch
-    (csrc/rowblock.hip; include/gvf_dit.h).  ln1 / ln2: dict with ln_w, ln_b and / or shift, scale.  mlp_bias = (b_fc1, b_fc2)."""
+    (csrc/rowblock.hip; include/gvf_dit.h).  ln1 / ln2: dict with ln_w, ln_b and / or shift, scale.  mlp_bias = (b_fc1, b_fc2).
+    x_in (f32 [groups * x_in_period][C]): the residual is read from it, broadcast with period x_in_period inside a row group, and x is only written."""
     _lib.require_cuda(a, stream_w, x)
     assert a.dtype == torch.bfloat16 and x.dtype == torch.float32 and a.stride(1) == 1 and x.is_contiguous()
     M, C = x.shape
     args = RowblockArgs()
     args.a, args.lda, args.K1, args.w, args.b1 = _pi(a), a.stride(0), a.shape[1], _pi(stream_w), _pi(b1)
     args.x, args.M, args.C = _pi(x), M, C
+    if x_in is not None:
+        assert x_in.dtype == torch.float32 and x_in.is_contiguous() and x_in.shape[-1] == C
+        args.x_in, args.x_in_period = _pi(x_in), int(x_in_period)
     args.gate1, args.ln1 = _pi(gate1), _ln_struct(ln1)
     args.mod_ld, args.rows_per_group, args.eps = int(mod_ld), int(rows_per_group), float(eps)
     if hidden:

@@ -77,6 +77,8 @@ typedef struct gvf_rowblock_ln {
 typedef struct gvf_rowblock_args {
     const void* a; int32_t lda; int32_t K1; const void* w; const float* b1;
     float* x; int32_t M; int32_t C;
+    const float* x_in; int32_t x_in_period;    /* optional: residual read from x_in[(row / rows_per_group) * period + (row % rows_per_group) % period]
+                                                   (f32 [groups * period][512]) instead of x: input_layer on top of the position embedding */
     const float* gate1; gvf_rowblock_ln ln1;
     int32_t mod_ld; int32_t rows_per_group; float eps;
     const float* b_fc1; const float* b_fc2; int32_t hidden; const float* gate_m; gvf_rowblock_ln ln2;
@@ -149,6 +151,16 @@ int gvf_layernorm_modulate_bf16(const float* x, void* out_bf16, int rows, int C,
  * act: 0 = identity, 1 = SiLU. */
 int gvf_cast_pad_bf16(const float* src, int ld_src, void* dst, int ld_dst, int64_t rows, int cols, int act,
                       void* stream);
+
+/* TimestepEmbedder and the SiLU in front of the adaLN projections in one launch (model/dit.py:59-100, 217-225):
+ *   t_freq = [cos(t f_i) | sin(t f_i)], f_i = max_period^(-i / (freq_dim/2));  t_emb = W2 silu(W0 t_freq + b0) + b2;
+ *   out[b][0..C) = bf16(silu(t_emb[b])), zero-padded to ld_out columns -- the A operand of the GEMM that computes every block's
+ * modulation vectors.  t: f32 [B]; w0: bf16 [C][ldw0 >= freq_dim], w2: bf16 [C][ldw2 >= C] (nn.Linear layout); t_emb: optional f32
+ * [B][C] copy of the embedding.  freq_dim even, <= 1024; C <= 1024.  Operands are rounded to bf16 where the unfused launches
+ * (gvf_cast_pad_bf16 + gvf_gemm_bf16) round them. */
+int gvf_dit_timestep_embed_bf16(const float* t, int B, int freq_dim, float max_period, const void* w0_bf16, int ldw0, const float* b0,
+                                const void* w2_bf16, int ldw2, const float* b2, int C, void* out_bf16, int ld_out, float* t_emb,
+                                void* stream);
 
 #ifdef __cplusplus
 }

@@ -164,8 +164,47 @@ def test_rowblock_launch_equals_the_unfused_launches(cuda, M, rpg, K1, hidden, N
     print(f"rowblock M{M} K{K1} hidden{hidden} N3 {N3}: stream rel_l2 {rx:.2e}, projection rel_l2 {ro:.2e}")
     assert rx < (2e-4 if hidden else 2e-6)      # MLP: a hidden unit on a bf16 rounding boundary moves a stream element by ~1e-4
     assert ro < 2e-3
+    if not hidden and N3:                       # residual read from a broadcast source (input_layer on the position embedding)
+        period = rpg // 3 if rpg % 3 == 0 and (rpg // 3) % 16 == 0 else rpg
+        src = (torch.randn((groups * period, C), generator=g) * 2).to(cuda)
+        x_b = src.reshape(groups, 1, period, C).expand(groups, rpg // period, period, C).reshape(M, C).contiguous()
+        x_exp = x_b.clone()
+        dit_ops.gemm_bf16(a0, w1, b1, x_exp, dit_ops.EPI_RESID_F32, **kw)
+        x_out = torch.full((M, C), float("nan"), device=cuda)
+        dit_ops.rowblock_fused(a0, stream, x_out, b1=b1, gate1=gate1, ln1=ln1, mod_ld=ld, rows_per_group=rpg, b3=b3, out3=out, x_in=src, x_in_period=period)
+        assert rel_l2(x_out, x_exp) < 2e-6
     with pytest.raises(_lib.GvfError):           # 48-row blocks only
         dit_ops.rowblock_fused(a0[:40], stream, x_new[:40].contiguous(), b1=b1, ln1=dict(ln_w=lw, ln_b=lb), out3=torch.empty((40, max(N3, 512)), dtype=torch.bfloat16, device=cuda))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,F", [(512, 256), (64, 256), (192, 64)])
+def test_timestep_embedder_launch_equals_the_unfused_chain(cuda, C, F):
+    """gvf_dit_timestep_embed_bf16 == torch sinusoid -> gvf_cast_pad_bf16 -> gvf_gemm_bf16 -> SiLU cast -> gvf_gemm_bf16 -> SiLU cast, and the
+    fp32 embedding it can also return == oracle/dit_ref.py (bf16 operands)."""
+    from gvfdiffusion_amd.model.dit import TimestepEmbedder
+    g = torch.Generator().manual_seed(C + F)
+    t = torch.tensor([999.0, 500.25, 1.0, 37.5], device=cuda)
+    w0 = bf(torch.randn((C, F), generator=g) / math.sqrt(F)).to(cuda)
+    w2 = bf(torch.randn((C, C), generator=g) / math.sqrt(C)).to(cuda)
+    b0, b2 = (0.1 * torch.randn((C,), generator=g)).to(cuda), (0.1 * torch.randn((C,), generator=g)).to(cuda)
+    Cp = dit_ops.pad64(C)
+    w0p, w2p = dit_ops.cast_pad_bf16(w0.float(), dit_ops.pad64(F)), dit_ops.cast_pad_bf16(w2.float(), Cp)
+    tf = dit_ops.cast_pad_bf16(TimestepEmbedder.timestep_embedding(t, F).contiguous(), dit_ops.pad64(F))
+    h1 = torch.empty((4, C), device=cuda)
+    dit_ops.gemm_bf16(tf, w0p, b0, h1, dit_ops.EPI_STORE_F32)
+    te = torch.empty((4, C), device=cuda)
+    dit_ops.gemm_bf16(dit_ops.cast_pad_bf16(h1, Cp, act=1), w2p, b2, te, dit_ops.EPI_STORE_F32)
+    ref = dit_ops.cast_pad_bf16(te, Cp, act=1)
+    out = torch.full((4, Cp), float("nan"), dtype=torch.bfloat16, device=cuda)
+    te2 = torch.empty((4, C), device=cuda)
+    dit_ops.timestep_embed_bf16(t, w0p, b0, w2p, b2, out, freq_dim=F, t_emb=te2)
+    r1, r2 = rel_l2(te2, te), rel_l2(out, ref)
+    print(f"timestep embedder C{C} F{F}: t_emb rel_l2 {r1:.2e}, silu(t_emb) bf16 rel_l2 {r2:.2e}")
+    assert r1 < 2e-3 and r2 < 3e-3 and bool((out[:, C:] == 0).all())       # bf16 roundings of silu(h1) may flip: 1 ulp of one of C operands
+    sd = {"a.weight": w0.float(), "a.bias": b0, "b.weight": w2.float(), "b.bias": b2}
+    te_ref = dit_ref.linear(torch.nn.functional.silu(dit_ref.linear(dit_ref.timestep_embedding(t, F), sd, "a", "bf16")), sd, "b", "bf16")
+    assert rel_l2(te2, te_ref) < 2e-3
 
 
 @pytest.mark.gpu
