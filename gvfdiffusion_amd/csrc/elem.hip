@@ -116,44 +116,76 @@ __global__ __launch_bounds__(256) void cast_pad_kernel(const float* __restrict__
 
 // TimestepEmbedder + the SiLU in front of the adaLN projections in ONE launch (model/dit.py:59-100: sinusoid -> Linear -> SiLU ->
 // Linear; model/dit.py:217-225: SiLU -> Linear): out[b] = bf16(silu(W2 bf16(silu(W0 bf16([cos | sin](t_b f)) + b0)) + b2)), the operand of
-// the one GEMM that produces every block's modulation vectors.  One workgroup per sample; a wave computes one output at a time
+// the one GEMM that produces every block's modulation vectors.  One workgroup (16 waves) per sample; a wave computes 8 outputs at a time
 // (the 64 lanes read a contiguous piece of the weight row, wave reduction): 0.4 MFLOP, launch-latency sized.  Rounding points as the
 // launches it replaces (torch sin / cos, gvf_cast_pad_bf16, gvf_gemm_bf16 x 2): bf16 operands, fp32 accumulation.
 __device__ __forceinline__ float bf2f_(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
 
-__global__ __launch_bounds__(256) void timestep_embed_kernel(const float* __restrict__ t, int F, float neg_log_period,
-                                                             const unsigned short* __restrict__ W0, int ldw0, const float* __restrict__ b0,
-                                                             const unsigned short* __restrict__ W2, int ldw2, const float* __restrict__ b2, int C,
-                                                             unsigned short* __restrict__ out, int ld_out, float* __restrict__ t_emb) {
-    __shared__ float sA[1024], sB[1024];          // F <= 1024, C <= 1024
+// dot products of 8 weight rows (o0 + 16 u) with the LDS vector v[0, K): all 8 rows' loads in flight together (one output at a time
+// the kernel is a chain of ~2 us memory latencies: 0.5 ms)
+__device__ __forceinline__ void te_dot8(const unsigned short* __restrict__ W, int ldw, int o0, int n_out, int K, const float* v, int lane, float (&acc)[8]) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+    for (int k = 4 * lane; k < K; k += 256) {
+        uint2 w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int o = o0 + 16 * u;
+            w[u] = o < n_out ? *reinterpret_cast<const uint2*>(W + (size_t)o * ldw + k) : make_uint2(0u, 0u);
+        }
+        const float4 x = *reinterpret_cast<const float4*>(v + k);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            acc[u] += (__uint_as_float(w[u].x << 16) * x.x + __uint_as_float(w[u].x & 0xffff0000u) * x.y) +
+                      (__uint_as_float(w[u].y << 16) * x.z + __uint_as_float(w[u].y & 0xffff0000u) * x.w);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = wave_sum(acc[u]);
+}
+
+__global__ __launch_bounds__(1024) void timestep_embed_kernel(const float* __restrict__ t, int F, float neg_log_period,
+                                                              const unsigned short* __restrict__ W0, int ldw0, const float* __restrict__ b0,
+                                                              const unsigned short* __restrict__ W2, int ldw2, const float* __restrict__ b2, int C,
+                                                              unsigned short* __restrict__ out, int ld_out, float* __restrict__ t_emb) {
+    __shared__ __attribute__((aligned(16))) float sA[1024], sB[1024];          // F <= 1024, C <= 1024 (zero padded to a multiple of 4)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
     const int half = F / 2;
     const float tv = t[b];
-    for (int i = tid; i < F; i += 256) {
-        const int j = i < half ? i : i - half;
-        const float f = expf(neg_log_period * (float)j / (float)half);     // torch: exp(-log(max_period) * arange(half) / half), the scalar in fp32
-        const float a = tv * f;
-        sA[i] = bf2f_(f2bf(i < half ? cosf(a) : sinf(a)));
+    for (int i = tid; i < 1024; i += 1024) {
+        float v = 0.f;
+        if (i < F) {
+            const int j = i < half ? i : i - half;
+            const float f = expf(neg_log_period * (float)j / (float)half);     // torch: exp(-log(max_period) * arange(half) / half), the scalar in fp32
+            const float a = tv * f;
+            v = bf2f_(f2bf(i < half ? cosf(a) : sinf(a)));
+        }
+        sA[i] = v;
+        sB[i] = 0.f;
     }
     __syncthreads();
-    for (int o = wave; o < C; o += 4) {
-        float acc = 0.f;
-        for (int k = lane; k < F; k += 64) acc += bf2f_(W0[(size_t)o * ldw0 + k]) * sA[k];
-        acc = wave_sum(acc);
-        if (lane == 0) { const float v = acc + (b0 ? b0[o] : 0.f); sB[o] = bf2f_(f2bf(v / (1.0f + __expf(-v)))); }
-    }
-    __syncthreads();
-    for (int o = wave; o < C; o += 4) {
-        float acc = 0.f;
-        for (int k = lane; k < C; k += 64) acc += bf2f_(W2[(size_t)o * ldw2 + k]) * sB[k];
-        acc = wave_sum(acc);
-        if (lane == 0) {
-            const float v = acc + (b2 ? b2[o] : 0.f);
-            if (t_emb != nullptr) t_emb[(size_t)b * C + o] = v;
-            out[(size_t)b * ld_out + o] = f2bf(v / (1.0f + __expf(-v)));
+    float acc[8];
+    for (int o0 = wave; o0 < C; o0 += 128) {                 // 16 waves x 8 rows per round
+        te_dot8(W0, ldw0, o0, C, (F + 3) & ~3, sA, lane, acc);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int o = o0 + 16 * u;
+            if (lane == 0 && o < C) { const float v = acc[u] + (b0 ? b0[o] : 0.f); sB[o] = bf2f_(f2bf(v / (1.0f + __expf(-v)))); }
         }
     }
-    for (int o = C + tid; o < ld_out; o += 256) out[(size_t)b * ld_out + o] = 0;
+    __syncthreads();
+    for (int o0 = wave; o0 < C; o0 += 128) {
+        te_dot8(W2, ldw2, o0, C, (C + 3) & ~3, sB, lane, acc);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int o = o0 + 16 * u;
+            if (lane == 0 && o < C) {
+                const float v = acc[u] + (b2 ? b2[o] : 0.f);
+                if (t_emb != nullptr) t_emb[(size_t)b * C + o] = v;
+                out[(size_t)b * ld_out + o] = f2bf(v / (1.0f + __expf(-v)));
+            }
+        }
+    }
+    for (int o = C + tid; o < ld_out; o += 1024) out[(size_t)b * ld_out + o] = 0;
 }
 
 }  // namespace
@@ -205,12 +237,12 @@ extern "C" int gvf_cast_pad_bf16(const float* src, int ld_src, void* dst, int ld
 extern "C" int gvf_dit_timestep_embed_bf16(const float* t, int B, int freq_dim, float max_period, const void* w0_bf16, int ldw0, const float* b0,
                                            const void* w2_bf16, int ldw2, const float* b2, int C, void* out_bf16, int ld_out, float* t_emb,
                                            void* stream_) {
-    if (B < 0 || freq_dim <= 0 || (freq_dim & 1) || freq_dim > 1024 || C <= 0 || C > 1024 || ldw0 < freq_dim || ldw2 < C || ld_out < C || !(max_period > 1.0f))
+    if (B < 0 || freq_dim <= 0 || (freq_dim & 1) || freq_dim > 1024 || C <= 0 || C > 1024 || ldw0 < ((freq_dim + 3) & ~3) || ldw2 < ((C + 3) & ~3) || (ldw0 & 3) || (ldw2 & 3) || ld_out < C || !(max_period > 1.0f))
         return GVF_EINVAL;
     if (B == 0) return GVF_OK;
-    if (!t || !w0_bf16 || !w2_bf16 || !out_bf16) return GVF_EINVAL;
+    if (!t || !w0_bf16 || !w2_bf16 || !out_bf16 || (((uintptr_t)w0_bf16) & 7) || (((uintptr_t)w2_bf16) & 7)) return GVF_EINVAL;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(timestep_embed_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream_, t, freq_dim, (float)(-log((double)max_period)), (const unsigned short*)w0_bf16, ldw0,
+    hipLaunchKernelGGL(timestep_embed_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream_, t, freq_dim, (float)(-log((double)max_period)), (const unsigned short*)w0_bf16, ldw0,
                        b0, (const unsigned short*)w2_bf16, ldw2, b2, C, (unsigned short*)out_bf16, ld_out, t_emb);
     GVF_CHECK_LAUNCH();
     return GVF_OK;

@@ -50,9 +50,9 @@ constexpr int RB_NW = 8, RB_CT = 4;              // waves, 16-column tiles per w
 constexpr int RB_KS = 16;                        // k-steps (32 deep) of a 512-deep GEMM
 constexpr int RB_BUF = RB_KS * 3 * 64;           // uint4 per 48 x 512 bf16 activation block in fragment order (48 KiB)
 constexpr int RB_MAX_HIDDEN = 2048;
-constexpr int RB_PAR = 2 * RB_BUF;               // floats: [b1 | gate1 | mul1 | add1 | b_fc2 | gate_m | mul2 | add2] x 512, b_fc1 x 2048, b3 x 1536
+constexpr int RB_PAR = 2 * RB_BUF;               // floats: [b1 | gate1 | mul1 | add1 | b_fc2 | gate_m | mul2 | add2] x 512, b_fc1 x 2048, b3 x 1536, gamma_k x 512
 constexpr int RB_MAX_N3 = 1536;
-constexpr int RB_PAR_FLOATS = 8 * RB_C + RB_MAX_HIDDEN + RB_MAX_N3;
+constexpr int RB_PAR_FLOATS = 8 * RB_C + RB_MAX_HIDDEN + RB_MAX_N3 + RB_C;     // ... and gamma_k x 512
 constexpr int RB_RED = RB_PAR + RB_PAR_FLOATS / 4;       // [2][8 waves][48 rows] floats
 constexpr int RB_SMEM = RB_RED + 2 * RB_NW * RB_BM / 4;
 constexpr int RB_KPAD = 128;                      // K of a packed weight is padded to this (k-steps come in groups of RB_DEPTH)
@@ -79,6 +79,9 @@ struct RbParams {
     const float* b3;                             // bias [N3] or null
     unsigned short* out3; int N3;          // bf16 [M][N3], or null: no last projection
     unsigned short* hb_out;                      // optional: the rows of the last LayerNorm, bf16 [M][512]
+    // optional (N3 = 1536 = to_qkv of the spatial self attention): pass 0 (q) goes to out3 as [M][512]; pass 1 (k) and pass 2 (v) go
+    // straight into the tiled K / V^T images of csrc/attn_xt.hip (what gvf_attn_pack_kv_bf16 would build from the row-major copy)
+    uint4* kt; uint4* vt; int kv_L, kv_tiles; float k_scale; const float* gamma_k;
     long long* dbg;                              // RB_TIMING builds only: [workgroup][16] s_memtime stamps
 };
 
@@ -349,6 +352,7 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
 #pragma unroll
         for (int j = 0; j < RB_MAX_N3 / RB_THREADS; ++j)
             sPar[8 * RB_C + RB_MAX_HIDDEN + tid + RB_THREADS * j] = (p.b3 && tid + RB_THREADS * j < P3 * RB_C) ? vb3[j] : 0.f;
+        if (p.kt != nullptr) sPar[8 * RB_C + RB_MAX_HIDDEN + RB_MAX_N3 + tid] = p.gamma_k ? p.gamma_k[tid] : 1.0f;
     }
     f32x4 acc[3][RB_CT];
     rb_zero(acc);
@@ -457,14 +461,70 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
             }
         }
         rb_lds_barrier();
+        if (p.kt != nullptr && pass == 1) {
+            // K rows -> tile images: lane = 16-byte chunk of the row = (head lane / 4, dims 8 (lane & 3) ..): MultiHeadRMSNorm over the 4
+            // lanes of a head in fp32, gain, softmax scale * log2 e, ONE rounding; chunk c of key slot s at s * 4 + (c ^ ((s >> 2) & 3)).
+            // Exactly gvf_attn_pack_kv_bf16's arithmetic on the same bf16 values: the tiles are bit-identical.
+            const float* gk = sPar + 8 * RB_C + RB_MAX_HIDDEN + RB_MAX_N3 + 8 * lane;
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(gk), g1 = *reinterpret_cast<const f32x4*>(gk + 4);
+            const float gg[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+            const int h = lane >> 2, c = lane & 3;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const int r = wave * 6 + j;
-            const uint4 v = R1[r * 64 + (lane ^ (r & 15))];
+            for (int j = 0; j < 6; ++j) {
+                const int r = wave * 6 + j;
+                const uint4 v = R1[r * 64 + (lane ^ (r & 15))];
+                const unsigned w[4] = {v.x, v.y, v.z, v.w};
+                float k8[8], ss = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    k8[2 * i] = __uint_as_float(w[i] << 16); k8[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ss += k8[e] * k8[e];
+                ss += __shfl_xor(ss, 1, 64);
+                ss += __shfl_xor(ss, 2, 64);
+                const float mul = p.gamma_k != nullptr ? p.k_scale * 5.656854249492381f / fmaxf(sqrtf(ss), 1e-12f) : p.k_scale;
+                uint4 o;
+                o.x = rb_pack_bf16(k8[0] * mul * gg[0], k8[1] * mul * gg[1]); o.y = rb_pack_bf16(k8[2] * mul * gg[2], k8[3] * mul * gg[3]);
+                o.z = rb_pack_bf16(k8[4] * mul * gg[4], k8[5] * mul * gg[5]); o.w = rb_pack_bf16(k8[6] * mul * gg[6], k8[7] * mul * gg[7]);
+                const int row = m0 + r, set = row / p.kv_L, key = row - set * p.kv_L, key_l = key & 63;
+                p.kt[((long long)(set * (RB_C / 32) + h) * p.kv_tiles + (key >> 6)) * 256 + key_l * 4 + (c ^ ((key_l >> 2) & 3))] = o;
+            }
+        } else if (p.kt != nullptr && pass == 2) {
+            // V rows -> V^T tile images: thread = one (head, d) column; per 16-row group g' and half hf one 16-byte chunk = the 8 keys
+            // 16 g' + 4 hf + {0,1,2,3,8,9,10,11} (the order the score accumulator of attn_xt holds them), chunk j = 2 g + hf of row d at
+            // d * 8 + (j ^ ((d >> 1) & 7)).  A 16-row group never straddles a frame or a 64-key tile (kv_L % 64 == 0, m0 % 16 == 0).
+            const int h = tid >> 5, d = tid & 31, cch = tid >> 3, ce = tid & 7;
+            const unsigned short* stg = reinterpret_cast<const unsigned short*>(R1);
+#pragma unroll
+            for (int gq = 0; gq < 3; ++gq) {
+                const int row0 = m0 + 16 * gq, set = row0 / p.kv_L, key0 = row0 - set * p.kv_L;
+                uint4* dst = p.vt + ((long long)(set * (RB_C / 32) + h) * p.kv_tiles + (key0 >> 6)) * 256 + d * 8;
+                const int g = (key0 & 63) >> 4;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    unsigned vw[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int e0 = 2 * i, e1 = 2 * i + 1;
+                        const int r0 = 16 * gq + 4 * hf + (e0 & 3) + 8 * (e0 >> 2), r1 = 16 * gq + 4 * hf + (e1 & 3) + 8 * (e1 >> 2);
+                        const unsigned lo = stg[(r0 * 64 + (cch ^ (r0 & 15))) * 8 + ce], hi = stg[(r1 * 64 + (cch ^ (r1 & 15))) * 8 + ce];
+                        vw[i] = lo | (hi << 16);
+                    }
+                    dst[(2 * g + hf) ^ ((d >> 1) & 7)] = make_uint4(vw[0], vw[1], vw[2], vw[3]);
+                }
+            }
+        } else {
+            const int ldo = p.kt != nullptr ? RB_C : p.N3;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int r = wave * 6 + j;
+                const uint4 v = R1[r * 64 + (lane ^ (r & 15))];
 #ifdef RB_ABL_NOSTORE3
-            if (p.M < 0)
+                if (p.M < 0)
 #endif
-            *reinterpret_cast<uint4*>(p.out3 + (long long)(m0 + r) * p.N3 + pass * RB_C + 8 * lane) = v;
+                *reinterpret_cast<uint4*>(p.out3 + (long long)(m0 + r) * ldo + pass * RB_C + 8 * lane) = v;
+            }
         }
         RB_STAMP();
     }
@@ -565,6 +625,10 @@ extern "C" int gvf_rowblock_fused_bf16(const gvf_rowblock_args* a, void* stream_
     if (a->N3 != 0 && (!a->out3 || a->N3 < 0 || a->N3 % RB_C != 0 || a->N3 > RB_MAX_N3 || a->epi3 != GVF_EPI_STORE_BF16))
         return GVF_EINVAL;
     if (a->N3 == 0 && a->hb_out == nullptr) return GVF_EINVAL;       // nothing would consume the last LayerNorm
+    if ((a->k_tiles == nullptr) != (a->v_tiles == nullptr)) return GVF_EINVAL;
+    if (a->k_tiles != nullptr && (a->N3 != 3 * RB_C || a->kv_L <= 0 || a->kv_L % 64 != 0 || a->M % a->kv_L != 0 || !(a->k_scale > 0.f) ||
+                                  (((uintptr_t)a->k_tiles) & 15) || (((uintptr_t)a->v_tiles) & 15)))
+        return GVF_EINVAL;
     if ((((uintptr_t)a->a) & 15) || (((uintptr_t)a->w) & 15) || (((uintptr_t)a->x) & 15) || (((uintptr_t)a->out3) & 7) ||
         (((uintptr_t)a->hb_out) & 7) || (((uintptr_t)a->b3) & 15))
         return GVF_EINVAL;
@@ -580,6 +644,7 @@ extern "C" int gvf_rowblock_fused_bf16(const gvf_rowblock_args* a, void* stream_
     p.ln2 = RbLn{a->ln2.ln_w, a->ln2.ln_b, a->ln2.shift, a->ln2.scale};
     p.b3 = a->b3; p.out3 = a->N3 != 0 ? (unsigned short*)a->out3 : nullptr; p.N3 = a->N3;
     p.hb_out = (unsigned short*)a->hb_out;
+    p.kt = (uint4*)a->k_tiles; p.vt = (uint4*)a->v_tiles; p.kv_L = a->kv_L; p.kv_tiles = a->kv_L / 64; p.k_scale = a->k_scale; p.gamma_k = a->gamma_k;
     p.dbg = g_rb_dbg;
     (void)hipGetLastError();
     const dim3 grid((unsigned)(a->M / RB_BM)), block(RB_THREADS);

@@ -183,6 +183,7 @@ class DiT(nn.Module):
         self.fuse_layernorm = int(os.environ.get("GVF_DIT_FUSE_LN", "0"))
         # one launch per sub-layer boundary (csrc/rowblock.hip) where the shapes allow it: 0 = the unfused GEMM / LayerNorm launches
         self.use_rowblock = int(os.environ.get("GVF_DIT_ROWBLOCK", "1")) != 0
+        self.rowblock_tiled_kv = int(os.environ.get("GVF_DIT_TILED_KV", "1")) != 0    # to_qkv's launch writes the attention's K / V^T tiles itself
         self._graph = None
 
     @property
@@ -511,9 +512,9 @@ class DiT(nn.Module):
         return y.reshape(B, T, N, self.out_channels).to(x.dtype if x.dtype.is_floating_point else f32)
 
     def _blocks_rowblock(self, x, h, mod, mod_ld, W, ctx, B, T, N, pos=None):
-        """The blocks with one launch per sub-layer boundary (csrc/rowblock.hip): per block  pack + spatial attention | to_out + adaLN +
+        """The blocks with one launch per sub-layer boundary (csrc/rowblock.hip): per block  spatial attention | to_out + adaLN +
         to_qkv | temporal attention | to_out + norm3 + to_q | image attention | to_out + norm4 + to_q | static attention | to_out +
-        adaLN + MLP + adaLN + the NEXT block's to_qkv -- 9 launches instead of 20, the fp32 stream through HBM 5 times instead of 15,
+        adaLN + MLP + adaLN + the NEXT block's to_qkv (q row-major, K / V^T as the attention's tile images) -- 8 launches instead of 20, the fp32 stream through HBM 5 times instead of 15,
         the normalised rows and the MLP's hidden units never.  Same rounding points as the unfused path (and as oracle/dit_ref.py)."""
         C, H = self.model_channels, self.num_heads
         M, TN = B * T * N, T * N
@@ -541,17 +542,31 @@ class DiT(nn.Module):
 
         o = offs[0]
         # h = pos + input_layer(x); adaLN of block 0; its to_qkv
-        fused(xb, rb["in"], b1=W["input"][1], ln1=dict(shift=mview(o), scale=mview(o + C)), out3=qkv,
-              b3=blocks[0]["spatial_self_attn"]["qkv"][1], x_in=None if pos is None else pos.reshape(B * N, C), x_in_period=N)
+        # to_qkv of the spatial self attention: with whole 64-key tiles per frame its launch writes q row-major and K / V^T directly as the
+        # tiled images the attention kernel stages (no row-major k, v; no pack launch)
+        tiled_kv = N % 64 == 0 and self.rowblock_tiled_kv
+        qs = torch.empty((M, C), dtype=bf, device=dev) if tiled_kv else None
+
+        def qkv_out(blk):
+            a_ = blk["spatial_self_attn"]
+            if tiled_kv:
+                return dict(out3=qs, b3=a_["qkv"][1], kv_tiles=kv_self, kv_L=N, gamma_k=a_["gk"])
+            return dict(out3=qkv, b3=a_["qkv"][1])
+
+        fused(xb, rb["in"], b1=W["input"][1], ln1=dict(shift=mview(o), scale=mview(o + C)),
+              x_in=None if pos is None else pos.reshape(B * N, C), x_in_period=N, **qkv_out(blocks[0]))
         hbn = None
         for i, b in enumerate(blocks):
             o, s = offs[i], rb["blocks"][i]
             g_s, sh_m, sc_m, g_m = mview(o + 2 * C), mview(o + 3 * C), mview(o + 4 * C), mview(o + 5 * C)
             n3, n4 = dict(ln_w=b["n3"][0], ln_b=b["n3"][1]), dict(ln_w=b["n4"][0], ln_b=b["n4"][1])
             a = b["spatial_self_attn"]
-            dit_ops.attention_pack_kv(qkv, B * T, N, H, C, 2 * C, gamma_k=a["gk"], out=kv_self)
-            dit_ops.attention_tiled_bf16(qkv, kv_self[0], kv_self[1], ab, B * T, 1, N, N, H, (N * 3 * C, 0, 3 * C), (N * C, 0, C), 1, 0,
-                                         gamma_q=a["gq"])
+            if tiled_kv:
+                dit_ops.attention_tiled_bf16(qs, kv_self[0], kv_self[1], ab, B * T, 1, N, N, H, (N * C, 0, C), (N * C, 0, C), 1, 0, gamma_q=a["gq"])
+            else:
+                dit_ops.attention_pack_kv(qkv, B * T, N, H, C, 2 * C, gamma_k=a["gk"], out=kv_self)
+                dit_ops.attention_tiled_bf16(qkv, kv_self[0], kv_self[1], ab, B * T, 1, N, N, H, (N * 3 * C, 0, 3 * C), (N * C, 0, C), 1, 0,
+                                             gamma_q=a["gq"])
             ai = b["image_cross_attn"]
             if self.no_temporal_attn:
                 fused(ab, s["s2"], b1=a["out"][1], gate1=g_s, ln1=n3, out3=qb, b3=ai["q"][1])
@@ -571,7 +586,7 @@ class DiT(nn.Module):
             kw = dict(b1=ast["out"][1], ln1=dict(shift=sh_m, scale=sc_m), mlp_bias=(b["fc1"][1], b["fc2"][1]), hidden=hidden_units, gate_m=g_m)
             if i + 1 < len(blocks):
                 on = offs[i + 1]
-                fused(hb, s["s5"], ln2=dict(shift=mview(on), scale=mview(on + C)), out3=qkv, b3=blocks[i + 1]["spatial_self_attn"]["qkv"][1], **kw)
+                fused(hb, s["s5"], ln2=dict(shift=mview(on), scale=mview(on + C)), **qkv_out(blocks[i + 1]), **kw)
             else:
                 on = offs[-1]
                 hbn = torch.empty((M, C), dtype=bf, device=dev)

@@ -25,7 +25,8 @@ class RowblockArgs(ctypes.Structure):
                 ("mod_ld", ctypes.c_int32), ("rows_per_group", ctypes.c_int32), ("eps", _f),
                 ("b_fc1", _vp), ("b_fc2", _vp), ("hidden", ctypes.c_int32), ("gate_m", _vp), ("ln2", RowblockLn),
                 ("b3", _vp), ("out3", _vp), ("N3", ctypes.c_int32), ("epi3", ctypes.c_int32),
-                ("hb_out", _vp)]
+                ("hb_out", _vp),
+                ("k_tiles", _vp), ("v_tiles", _vp), ("kv_L", ctypes.c_int32), ("k_scale", _f), ("gamma_k", _vp)]
 
 
 _lib.register({
@@ -170,7 +171,7 @@ def _ln_struct(ln):
 
 
 def rowblock_fused(a, stream_w, x, b1=None, gate1=None, ln1=None, mod_ld=0, rows_per_group=0, eps=1e-6,
-                   mlp_bias=None, hidden=0, gate_m=None, ln2=None, b3=None, out3=None, hb_out=None, x_in=None, x_in_period=0):
+                   mlp_bias=None, hidden=0, gate_m=None, ln2=None, b3=None, out3=None, hb_out=None, x_in=None, x_in_period=0, kv_tiles=None, kv_L=0, gamma_k=None, kv_scale=None):
     """x += gate1 * (a W1^T + b1); hb = LN1(x); [x += gate_m * MLP(hb); hb = LN2(x)]; out3 = hb W3^T + b3 or hb_out = hb -- ONE launch
     (csrc/rowblock.hip; include/gvf_dit.h).  ln1 / ln2: dict with ln_w, ln_b and / or shift, scale.  mlp_bias = (b_fc1, b_fc2).
     x_in (f32 [groups * x_in_period][C]): the residual is read from it, broadcast with period x_in_period inside a row group, and x is only written."""
@@ -191,6 +192,13 @@ def rowblock_fused(a, stream_w, x, b1=None, gate1=None, ln1=None, mod_ld=0, rows
     if out3 is not None:
         assert out3.dtype == torch.bfloat16 and out3.is_contiguous() and out3.shape[0] == M
         args.b3, args.out3, args.N3, args.epi3 = _pi(b3), _pi(out3), out3.shape[1], EPI_STORE_BF16
+    if kv_tiles is not None:        # to_qkv of the spatial self attention: out3 = q [M][C]; k, v -> tiled images (see attention_pack_kv)
+        assert out3 is not None and out3.shape[1] == C and kv_L % 64 == 0 and M % kv_L == 0
+        nbytes = (M // kv_L) * (C // 32) * (kv_L // 64) * 4096
+        assert kv_tiles[0].numel() >= nbytes and kv_tiles[1].numel() >= nbytes
+        args.N3 = 3 * C
+        args.k_tiles, args.v_tiles, args.kv_L = _pi(kv_tiles[0]), _pi(kv_tiles[1]), int(kv_L)
+        args.k_scale, args.gamma_k = float((32 ** -0.5 if kv_scale is None else kv_scale) * LOG2E), _pi(gamma_k)
     if hb_out is not None:
         assert hb_out.dtype == torch.bfloat16 and hb_out.is_contiguous() and tuple(hb_out.shape) == (M, C)
         args.hb_out = _pi(hb_out)

@@ -84,6 +84,10 @@ typedef struct gvf_rowblock_args {
     const float* b_fc1; const float* b_fc2; int32_t hidden; const float* gate_m; gvf_rowblock_ln ln2;
     const float* b3; void* out3; int32_t N3; int32_t epi3;
     void* hb_out;
+    /* optional, N3 = 1536 (to_qkv of the spatial self attention, head_dim 32): q (pass 0) goes to out3 as bf16 [M][512]; k and v go straight
+       into the tiled K / V^T images of gvf_attn_tiled_fwd_bf16 -- bit-identical to gvf_attn_pack_kv_bf16(k_scale, gamma_k) on the row-major
+       projection, which is then never written.  Key sets = runs of kv_L rows (kv_L a multiple of 64, M a multiple of kv_L). */
+    void* k_tiles; void* v_tiles; int32_t kv_L; float k_scale; const float* gamma_k;
 } gvf_rowblock_args;
 int64_t gvf_rowblock_packed_bytes(int N, int K);
 int gvf_rowblock_pack_weight(const void* w_bf16, int ldw, int N, int K, void* packed, void* stream);

@@ -178,6 +178,40 @@ def test_rowblock_launch_equals_the_unfused_launches(cuda, M, rpg, K1, hidden, N
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_sets,L,rms,mlp", [(3, 64, True, False), (6, 128, False, False), (24, 512, True, True)])
+def test_rowblock_tiled_kv_epilogue_is_bitwise_the_pack_kernel(cuda, n_sets, L, rms, mlp):
+    """to_qkv inside the row-block launch with k_tiles / v_tiles: q == the row-major projection's first 512 columns, and the K / V^T tile
+    images == gvf_attn_pack_kv_bf16 applied to its k and v columns -- bit for bit (same bf16 values, same fp32 expression)."""
+    g = torch.Generator().manual_seed(n_sets * L)
+    C, H, M = 512, 16, n_sets * L
+    if M % 48:
+        pytest.skip("rows not a multiple of 48")
+    a0 = bf(torch.randn((M, 512), generator=g)).to(cuda)
+    w1 = bf(torch.randn((C, 512), generator=g) / math.sqrt(512)).to(cuda)
+    w3 = bf(torch.randn((3 * C, C), generator=g) / math.sqrt(C)).to(cuda)
+    b3 = (0.1 * torch.randn((3 * C,), generator=g)).to(cuda)
+    f1 = bf(torch.randn((512, C), generator=g) / math.sqrt(C)).to(cuda)
+    f2 = bf(torch.randn((C, 512), generator=g) / math.sqrt(512)).to(cuda)
+    gk = (1 + 0.2 * torch.randn((H, 32), generator=g)).to(cuda) if rms else None
+    lw, lb = (1 + 0.1 * torch.randn((C,), generator=g)).to(cuda), (0.1 * torch.randn((C,), generator=g)).to(cuda)
+    x0 = (torch.randn((M, C), generator=g) * 2).to(cuda)
+    stream = dit_ops.rowblock_pack_stream(w1, mlp=(f1, f2) if mlp else None, w3=w3)
+    kw = dict(ln1=dict(ln_w=lw, ln_b=lb), b3=b3)
+    if mlp:
+        kw.update(mlp_bias=(None, None), hidden=512, ln2=dict(ln_w=lw, ln_b=lb))
+    qkv = torch.empty((M, 3 * C), dtype=torch.bfloat16, device=cuda)
+    dit_ops.rowblock_fused(a0, stream, x0.clone(), out3=qkv, **kw)
+    kt_ref, vt_ref = dit_ops.attention_pack_kv(qkv, n_sets, L, H, C, 2 * C, gamma_k=gk)
+    nbytes = kt_ref.numel()
+    kt, vt = torch.full((nbytes,), 0xAB, dtype=torch.uint8, device=cuda), torch.full((nbytes,), 0xAB, dtype=torch.uint8, device=cuda)
+    q = torch.empty((M, C), dtype=torch.bfloat16, device=cuda)
+    dit_ops.rowblock_fused(a0, stream, x0.clone(), out3=q, kv_tiles=(kt, vt), kv_L=L, gamma_k=gk, **kw)
+    assert torch.equal(q, qkv[:, :C])
+    assert torch.equal(kt, kt_ref), f"K tiles differ in {(kt != kt_ref).sum().item()} bytes"
+    assert torch.equal(vt, vt_ref), f"V^T tiles differ in {(vt != vt_ref).sum().item()} bytes"
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("C,F", [(512, 256), (64, 256), (192, 64)])
 def test_timestep_embedder_launch_equals_the_unfused_chain(cuda, C, F):
     """gvf_dit_timestep_embed_bf16 == torch sinusoid -> gvf_cast_pad_bf16 -> gvf_gemm_bf16 -> SiLU cast -> gvf_gemm_bf16 -> SiLU cast, and the
