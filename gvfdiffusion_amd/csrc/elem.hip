@@ -173,19 +173,23 @@ __global__ __launch_bounds__(1024) void timestep_embed_kernel(const float* __res
         }
     }
     __syncthreads();
-    for (int o0 = wave; o0 < C; o0 += 128) {
-        te_dot8(W2, ldw2, o0, C, (C + 3) & ~3, sB, lane, acc);
+    // second Linear: this workgroup's slice of the outputs only (gridDim.y workgroups per sample; the first Linear is recomputed by each:
+    // one CU pulls ~70 GB/s, so one workgroup alone would spend 13 us on the 0.75 MB of weights)
+    const int per = (C + gridDim.y - 1) / gridDim.y, lo = blockIdx.y * per, hi = lo + per < C ? lo + per : C;
+    for (int o0 = lo + wave; o0 < hi; o0 += 128) {
+        te_dot8(W2, ldw2, o0, hi, (C + 3) & ~3, sB, lane, acc);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int o = o0 + 16 * u;
-            if (lane == 0 && o < C) {
+            if (lane == 0 && o < hi) {
                 const float v = acc[u] + (b2 ? b2[o] : 0.f);
                 if (t_emb != nullptr) t_emb[(size_t)b * C + o] = v;
                 out[(size_t)b * ld_out + o] = f2bf(v / (1.0f + __expf(-v)));
             }
         }
     }
-    for (int o = C + tid; o < ld_out; o += 1024) out[(size_t)b * ld_out + o] = 0;
+    if (blockIdx.y == 0)
+        for (int o = C + tid; o < ld_out; o += 1024) out[(size_t)b * ld_out + o] = 0;
 }
 
 }  // namespace
@@ -242,7 +246,7 @@ extern "C" int gvf_dit_timestep_embed_bf16(const float* t, int B, int freq_dim, 
     if (B == 0) return GVF_OK;
     if (!t || !w0_bf16 || !w2_bf16 || !out_bf16 || (((uintptr_t)w0_bf16) & 7) || (((uintptr_t)w2_bf16) & 7)) return GVF_EINVAL;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(timestep_embed_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream_, t, freq_dim, (float)(-log((double)max_period)), (const unsigned short*)w0_bf16, ldw0,
+    hipLaunchKernelGGL(timestep_embed_kernel, dim3(B, 16), dim3(1024), 0, (hipStream_t)stream_, t, freq_dim, (float)(-log((double)max_period)), (const unsigned short*)w0_bf16, ldw0,
                        b0, (const unsigned short*)w2_bf16, ldw2, b2, C, (unsigned short*)out_bf16, ld_out, t_emb);
     GVF_CHECK_LAUNCH();
     return GVF_OK;

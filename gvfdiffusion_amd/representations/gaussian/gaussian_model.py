@@ -39,6 +39,8 @@ def _inv_softplus(x: float) -> float:
 
 
 class GaussianModel:
+    _TRELLIS_TWIN = False
+
     def __init__(self, sh_degree: int = 0, aabb=(-0.5, -0.5, -0.5, 1.0, 1.0, 1.0), mininum_kernel_size: float = 0.0,
                  scaling_bias: float = 0.01, opacity_bias: float = 0.1, scaling_activation: str = "exp",
                  device="cuda"):
@@ -49,9 +51,10 @@ class GaussianModel:
                                 scaling_activation=scaling_activation)
         self.sh_degree = sh_degree
         self.max_sh_degree = sh_degree
-        # trellis twin: active_sh_degree = sh_degree (trellis/.../gaussian_model.py:30); every use in
-        # the reference has sh_degree 0, where the two classes agree.
-        self.active_sh_degree = sh_degree
+        # representations/gaussian/gaussian_model.py:54 starts at 0 and relies on oneupSHdegree(); the TRELLIS twin
+        # (trellis/representations/gaussian/gaussian_model.py:29, class `Gaussian` below) starts at sh_degree.  Every use in the
+        # reference has sh_degree 0, where the two agree.
+        self.active_sh_degree = sh_degree if self._TRELLIS_TWIN else 0
         self.mininum_kernel_size = mininum_kernel_size
         self.scaling_bias = scaling_bias
         self.scaling_activation_type = scaling_activation
@@ -99,7 +102,8 @@ class GaussianModel:
 
     @property
     def get_features(self):
-        if self._features_rest is not None:
+        # representations/gaussian/gaussian_model.py:117-121 returns the DC term only; the TRELLIS twin (:87-88) appends the rest on dim 2
+        if self._TRELLIS_TWIN and self._features_rest is not None:
             return torch.cat((self._features_dc, self._features_rest), dim=2)
         return self._features_dc
 
@@ -166,4 +170,7 @@ class GaussianModel:
         return a
 
 
-Gaussian = GaussianModel  # the TRELLIS twin's class name
+class Gaussian(GaussianModel):
+    """trellis/representations/gaussian/gaussian_model.py: the same class with active_sh_degree = sh_degree from the start and
+    get_features = DC | rest (the structured-latent decoder's output type)."""
+    _TRELLIS_TWIN = True

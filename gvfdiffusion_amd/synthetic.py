@@ -7,7 +7,7 @@ import math
 import torch
 
 from .renderers.sh_utils import RGB2SH
-from .representations.gaussian import GaussianModel
+from .representations.gaussian import Gaussian, GaussianModel
 
 FOV_X_DEG = 49.1  # dataset/dataset_latent_inference.py:182
 NEAR, FAR = 0.8, 1.6  # model/sparse_voxel_diffusion/sparse_vae.py:197-199
@@ -55,7 +55,8 @@ def random_gaussians(P: int, sh_degree: int = 2, seed: int = 0, scale_lo: float 
 
 def gaussian_model_from(attrs, sh_degree: int, device, scaling_activation="softplus") -> GaussianModel:
     """GaussianModel whose activated accessors reproduce `attrs` (inverse activations applied)."""
-    gm = GaussianModel(sh_degree=sh_degree, aabb=[-0.5, -0.5, -0.5, 1.0, 1.0, 1.0], mininum_kernel_size=KERNEL_3D,
+    # the TRELLIS twin: all SH bands active from the start (the mirror of representations/gaussian starts at degree 0)
+    gm = Gaussian(sh_degree=sh_degree, aabb=[-0.5, -0.5, -0.5, 1.0, 1.0, 1.0], mininum_kernel_size=KERNEL_3D,
                        scaling_bias=SCALING_BIAS, opacity_bias=OPACITY_BIAS, scaling_activation=scaling_activation,
                        device=device)
     d = {k: v.to(device) for k, v in attrs.items()}

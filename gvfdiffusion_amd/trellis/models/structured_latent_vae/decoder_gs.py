@@ -10,7 +10,7 @@ import torch.nn as nn
 from .... import sparse as sp
 from ....model.sparse_voxel_diffusion.sparse_vae import hammersley_sequence
 from ....ops import dit_ops
-from ....representations.gaussian import GaussianModel as Gaussian
+from ....representations.gaussian import Gaussian
 from ....representations.gaussian.voxel_rows import gaussian_row_layout, rows_to_gaussian
 from .base import SparseTransformerBase
 
