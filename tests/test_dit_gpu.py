@@ -257,6 +257,10 @@ def test_rowblock_path_of_the_dit_equals_the_unfused_path(cuda):
     y0 = net(**inp)
     net.use_rowblock = True
     r = rel_l2(y1, y0)
+    net.enable_graph(True)                  # the ~110 launches of the row-block forward as one hipGraph: same kernels, same bits
+    yg = [net(**dict(inp, t=inp["t"] * s)) for s in (1.0, 0.5)]
+    net.enable_graph(False)
+    assert torch.equal(yg[0], y1) and torch.equal(yg[1], net(**dict(inp, t=inp["t"] * 0.5)))
     print(f"DiT row-block path vs unfused path: rel_l2 {r:.2e}")
     assert r < TOL_DIT_VS_BF16_ORACLE      # two bf16 pipelines with the same rounding points and different summation orders: measured 3.4e-3,
                                            # the same distance as either has to the bf16-emulating oracle
