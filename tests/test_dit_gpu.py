@@ -242,6 +242,28 @@ def test_timestep_embedder_launch_equals_the_unfused_chain(cuda, C, F):
 
 
 @pytest.mark.gpu
+def test_rowblock_path_batch_of_three_equals_three_single_samples(cuda):
+    """The guided sampler's batch-3 forward (different conditions, timesteps and positions per sample) == each sample on its own: row groups of
+    the row-block launches (gate / shift / scale rows, the broadcast position embedding), per-sample K / V sets of the attentions."""
+    from gvfdiffusion_amd.model.dit import DiT
+    man = json.load(open(os.path.join(GOLD, "dit_manifest.json")))
+    net = DiT(**man["config"])
+    net.load_state_dict(synthetic.dit_state_dict(man["state_dict"], seed=0), strict=True)
+    net = net.to(cuda).eval()
+    ones = [{k: v.to(cuda) for k, v in synthetic.dit_inputs(B=1, T=24, seed=10 + i).items()} for i in range(3)]
+    keys = ("x", "t", "cond_images", "static_latent", "deformation_position_xyz")
+    for i, o in enumerate(ones):
+        o["t"] = o["t"] * (0.3 + 0.3 * i)
+    batch = {k: torch.cat([o[k] for o in ones]) for k in keys}
+    yb = net(**batch)
+    for i, o in enumerate(ones):
+        yi = net(**{k: o[k] for k in keys})
+        r = rel_l2(yb[i:i + 1], yi)
+        print(f"sample {i} of the batch vs alone: rel_l2 {r:.2e}")
+        assert r < 1e-6
+
+
+@pytest.mark.gpu
 def test_rowblock_path_of_the_dit_equals_the_unfused_path(cuda):
     """Full-size config (C = 512, 24 x 512 tokens): DiT._blocks_rowblock against the per-sub-layer launches of DiT._forward."""
     from gvfdiffusion_amd.model.dit import DiT
