@@ -27,6 +27,7 @@
 //     4 lanes + 4 waves wide.
 //   * the residual tile of x (96 VGPRs) is fetched before the k-loop; the per-column vectors (bias, gate, LayerNorm gain / shift)
 //     sit in LDS.
+#include <cstddef>
 #include <cstdlib>
 #include "gvf_common.h"
 #include "../../include/gvf_rast.h"
@@ -575,6 +576,17 @@ __global__ __launch_bounds__(256) void rowblock_pack_mlp_kernel(const unsigned s
 }  // namespace
 
 static long long* g_rb_dbg = nullptr;        // RB_TIMING builds of scripts/ubench/rowblock_bench.hip set it
+
+// sizeof / field offsets of the argument struct, for bindings to check their own layout against (tests/test_capi_symbols.py)
+extern "C" int gvf_rowblock_args_layout(int32_t* out, int n) {
+    const int v[] = {(int)sizeof(gvf_rowblock_args), (int)offsetof(gvf_rowblock_args, x), (int)offsetof(gvf_rowblock_args, gate1),
+                     (int)offsetof(gvf_rowblock_args, mod_ld), (int)offsetof(gvf_rowblock_args, b_fc1), (int)offsetof(gvf_rowblock_args, ln2),
+                     (int)offsetof(gvf_rowblock_args, b3), (int)offsetof(gvf_rowblock_args, hb_out), (int)offsetof(gvf_rowblock_args, k_tiles),
+                     (int)offsetof(gvf_rowblock_args, gamma_k)};
+    const int m = (int)(sizeof(v) / sizeof(v[0]));
+    for (int i = 0; i < n && i < m; ++i) out[i] = v[i];
+    return m;
+}
 
 extern "C" int64_t gvf_rowblock_packed_bytes(int N, int K) {
     if (N <= 0 || K <= 0 || N % RB_C != 0) return GVF_EINVAL;

@@ -31,6 +31,7 @@ class RowblockArgs(ctypes.Structure):
 
 _lib.register({
     "gvf_dit_timestep_embed_bf16": (_i, [_vp, _i, _i, _f, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp]),
+    "gvf_rowblock_args_layout": (_i, [ctypes.POINTER(ctypes.c_int32), _i]),
     "gvf_rowblock_packed_bytes": (_i64, [_i, _i]),
     "gvf_rowblock_pack_weight": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "gvf_rowblock_pack_mlp": (_i, [_vp, _vp, _i, _vp, _vp]),

@@ -89,6 +89,8 @@ typedef struct gvf_rowblock_args {
        projection, which is then never written.  Key sets = runs of kv_L rows (kv_L a multiple of 64, M a multiple of kv_L). */
     void* k_tiles; void* v_tiles; int32_t kv_L; float k_scale; const float* gamma_k;
 } gvf_rowblock_args;
+/* layout of gvf_rowblock_args as compiled: {sizeof, offsetof x, gate1, mod_ld, b_fc1, ln2, b3, hb_out, k_tiles, gamma_k}; returns the count */
+int gvf_rowblock_args_layout(int32_t* out, int n);
 int64_t gvf_rowblock_packed_bytes(int N, int K);
 int gvf_rowblock_pack_weight(const void* w_bf16, int ldw, int N, int K, void* packed, void* stream);
 int gvf_rowblock_pack_mlp(const void* w_fc1_bf16, const void* w_fc2_bf16, int hidden, void* packed, void* stream);

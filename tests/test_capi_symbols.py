@@ -45,6 +45,26 @@ def test_host_side_argument_errors_need_no_gpu():
     assert l.gvf_sort_tmp_bytes(1 << 20) >= 256 * 256 * 4
 
 
+def test_rowblock_argument_struct_layout_matches_the_library():
+    """The ctypes mirror of gvf_rowblock_args has the size and field offsets the compiled library reports, and a null / malformed argument
+    block is refused on the host (no GPU needed)."""
+    from gvfdiffusion_amd import _lib
+    from gvfdiffusion_amd.ops import dit_ops
+    l = _lib.lib()
+    buf = (ctypes.c_int32 * 16)()
+    n = l.gvf_rowblock_args_layout(buf, 16)
+    A = dit_ops.RowblockArgs
+    mine = [ctypes.sizeof(A)] + [getattr(A, f).offset for f in ("x", "gate1", "mod_ld", "b_fc1", "ln2", "b3", "hb_out", "k_tiles", "gamma_k")]
+    assert n == len(mine) and list(buf[:n]) == mine
+    assert l.gvf_rowblock_fused_bf16(None, None) == _lib.GVF_EINVAL
+    a = A()
+    a.M, a.C, a.K1, a.lda = 96, 256, 128, 128                   # C != 512
+    assert l.gvf_rowblock_fused_bf16(ctypes.byref(a), None) == _lib.GVF_EINVAL
+    a.C, a.M = 512, 100                                          # rows not a multiple of 48
+    assert l.gvf_rowblock_fused_bf16(ctypes.byref(a), None) == _lib.GVF_EINVAL
+    assert l.gvf_rowblock_packed_bytes(512, 64) == 512 * 128 * 2 and l.gvf_rowblock_packed_bytes(500, 64) == _lib.GVF_EINVAL
+
+
 def test_operators_refuse_cpu_tensors():
     import torch
     from gvfdiffusion_amd import _lib, rasterizer as R
