@@ -55,6 +55,11 @@ def test_driver_matches_per_frame_renders(cuda):
         # torch activations (facade) vs fused activations (driver): sub-ulp colour differences can flip a uint8 step
         assert d.max() <= 1 and (d > 0).mean() < 0.02, (k, d.max(), (d > 0).mean())
     assert (got[0].float() - got[V].float()).abs().max() > 0          # the deltas move the object between timesteps
+    # chunks in flight on 1, 2 or 3 streams (and a too-small first-chunk estimate: dense views later force the re-render path): same frames
+    for n_streams in (1, 3):
+        again = torch.cat([f for _, f in render_sample_frames(rend, gm, delta, K, extrinsics=cams, chunk_frames=4, streams=n_streams)])
+        assert torch.equal(again, got), n_streams
+    rend.pipe.use_mip_gaussian = False
 
 
 @pytest.mark.gpu
