@@ -631,3 +631,39 @@ def test_adaptive_solver_on_the_hip_dit_matches_fp32_oracle(cuda):
           + ("" if nh == no else "  <- step acceptance diverged: a trial sat within bf16 noise of the error threshold"))
     assert torch.isfinite(xh).all() and r < 5e-2
     assert nh == no, f"NFE {nh} != {no}: the bf16 denoiser changed an accept / reject decision of the adaptive solver"
+
+
+def test_two_samplers_in_flight_equal_serial_sampling(cuda):
+    """gvfdiffusion_amd.utils.run_in_flight: two independent samples (own DiT instance, stream and thread each; hipGraph replay) denoised
+    concurrently == the same samples one after the other, bit for bit; an exception in a job reaches the caller."""
+    from gvfdiffusion_amd.model.dpmsolver import NoiseScheduleVP, model_wrapper, DPM_Solver
+    from gvfdiffusion_amd.model.gaussian_diffusion import create_gaussian_diffusion
+    from gvfdiffusion_amd.utils import run_in_flight
+    g, cfg, sd, model = _load_small(cuda)
+    model2 = type(model)(**cfg).to(cuda).eval()
+    model2.load_state_dict(sd, strict=True)
+    ns = NoiseScheduleVP("discrete", betas=torch.from_numpy(create_gaussian_diffusion(noise_schedule="cosine", predict_type="v").betas))
+    base = {k: torch.from_numpy(g[k]).to(cuda) for k in ("x", "cond_images", "static_latent", "xyz")}
+
+    def make(m, scale):
+        m.enable_graph(True)
+        kw = dict(cond_images=base["cond_images"] * scale, static_latent=base["static_latent"] * scale, deformation_position_xyz=base["xyz"])
+        fn = model_wrapper(lambda x, t, **k: m(x, t, **k), ns, model_type="v", model_kwargs=kw)
+        solver = DPM_Solver(fn, ns, algorithm_type="dpmsolver++")
+        x0 = base["x"] * scale
+        return lambda slot=0: solver.sample(x0, steps=6, t_start=1.0, t_end=1 / 1000, order=2, skip_type="time_uniform", method="multistep")
+
+    jobs = [make(model, 1.0), make(model2, 0.5)]
+    serial = [j() for j in jobs]
+    torch.cuda.synchronize()
+    for _ in range(2):
+        both = run_in_flight(jobs, cuda, 2)
+        assert torch.equal(both[0], serial[0]) and torch.equal(both[1], serial[1])
+    assert not torch.equal(serial[0], serial[1])
+    three = run_in_flight(jobs + [jobs[0]], cuda, 2)          # more jobs than slots: the third reuses a slot
+    assert torch.equal(three[2], serial[0])
+
+    def boom(slot):
+        raise RuntimeError("job failed")
+    with pytest.raises(RuntimeError, match="job failed"):
+        run_in_flight([jobs[0], boom], cuda, 2)
