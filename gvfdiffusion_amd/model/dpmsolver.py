@@ -235,11 +235,21 @@ class DPM_Solver:
 
     # ---- scalar schedule helpers (host) -------------------------------------------------------
     def _sched(self, t):
-        """t: (1,) CPU tensor -> python floats (log_alpha, sigma, lambda, alpha)."""
+        """t: (1,) CPU tensor -> python floats (log_alpha, sigma, lambda, alpha).  Memoised on the fp32 bits of t: a step asks for the same
+        few times several times over (each evaluation is a table interpolation in ~30 host tensor ops)."""
+        key = float(t.reshape(-1)[0])
+        cache = self.__dict__.setdefault("_sched_cache", {})
+        hit = cache.get(key)
+        if hit is not None:
+            return hit
         ns = self.noise_schedule
         la = ns.marginal_log_mean_coeff(t)
         sig = torch.sqrt(1.0 - torch.exp(2.0 * la))
-        return float(la), float(sig), float(la - torch.log(sig)), float(torch.exp(la))
+        out = (float(la), float(sig), float(la - torch.log(sig)), float(torch.exp(la)))
+        if len(cache) > 4096:
+            cache.clear()
+        cache[key] = out
+        return out
 
     @staticmethod
     def _host(t):
