@@ -140,21 +140,24 @@ def modulate(h, shift, scale):
     return h * (1 + scale[:, None, None]) + shift[:, None, None]
 
 
-def block_forward(x, mod, image_emb, static_emb, sd, p, heads, precision):
-    """One ModulatedSparseTransformerCrossBlock; x (B,T,N,C) fp32, mod (B,C), contexts (B,T,L,C)."""
+def block_forward(x, mod, image_emb, static_emb, sd, p, heads, precision, no_temporal_attn=False):
+    """One ModulatedSparseTransformerCrossBlock; x (B,T,N,C) fp32, mod (B,C), contexts (B,T,L,C).  no_temporal_attn: the block has no
+    temporal sub-layer (model/dit.py:241-242, 253-260)."""
     B, T, N, C = x.shape
     silu = F.silu(mod)
     m6 = linear(silu, sd, p + ".adaLN_modulation.1", precision)
     sh_s, sc_s, g_s, sh_m, sc_m, g_m = m6.chunk(6, dim=1)
-    sh_t, sc_t, g_t = linear(silu, sd, p + ".adaLN_modulation_temporal.1", precision).chunk(3, dim=1)
+    if not no_temporal_attn:
+        sh_t, sc_t, g_t = linear(silu, sd, p + ".adaLN_modulation_temporal.1", precision).chunk(3, dim=1)
     # spatial self attention over the N tokens of each frame
     h = modulate(layer_norm(x), sh_s, sc_s)
     h = self_attention(h.reshape(B * T, N, C), sd, p + ".spatial_self_attn", heads, precision, tiled=True).reshape(B, T, N, C)
     x = x + h * g_s[:, None, None]
     # temporal self attention over the T frames of each token
-    h = modulate(layer_norm(x), sh_t, sc_t).transpose(1, 2).reshape(B * N, T, C)
-    h = self_attention(h, sd, p + ".temporal_self_attn", heads, precision).reshape(B, N, T, C).transpose(1, 2)
-    x = x + h * g_t[:, None, None]
+    if not no_temporal_attn:
+        h = modulate(layer_norm(x), sh_t, sc_t).transpose(1, 2).reshape(B * N, T, C)
+        h = self_attention(h, sd, p + ".temporal_self_attn", heads, precision).reshape(B, N, T, C).transpose(1, 2)
+        x = x + h * g_t[:, None, None]
     # image cross attention (affine LayerNorm, no gate)
     h = F.layer_norm(x, (C,), sd[p + ".norm3.weight"], sd[p + ".norm3.bias"], 1e-6)
     h = cross_attention(h.reshape(B * T, N, C), image_emb.reshape(B * T, -1, C), sd, p + ".image_cross_attn", heads, precision)
@@ -185,7 +188,7 @@ def dit_forward(sd, cfg, x, t, cond_images, static_latent, deformation_position_
     h = h + absolute_position_embedding(deformation_position_xyz, C)[:, None]
     inter = {"h0": h, "t_emb": t_emb}
     for i in range(nblocks):
-        h = block_forward(h, t_emb, image_emb, static_emb, sd, f"blocks.{i}", heads, precision)
+        h = block_forward(h, t_emb, image_emb, static_emb, sd, f"blocks.{i}", heads, precision, no_temporal_attn=cfg.get("no_temporal_attn", False))
         if i == 0:
             inter["block0"] = h
     shift, scale = linear(F.silu(t_emb), sd, "final_layer.adaLN_modulation.1", precision).chunk(2, dim=1)
