@@ -196,6 +196,32 @@ def gen_dit():
     np.savez_compressed(os.path.join(OUT, "dit_full_golden.npz"), y=y.numpy(), t=inp["t"].numpy())
 
 
+def gen_dit_notemporal():
+    """model/dit.py with no_temporal_attn=True (the block's temporal sub-layer and its adaLN projection removed, :241-260, :358): the
+    reduced model of gen_dit() in that variant, so that the oracle's branch for it is pinned by the reference too."""
+    import json
+    from model.dit import DiT
+    cfg = dict(DIT_SMALL, no_temporal_attn=True)
+    torch.manual_seed(0)
+    model = DiT(**cfg).eval()
+    _randomise(model, 11)
+    g = torch.Generator().manual_seed(12)
+    B, T, N, Li, Ls = 2, 3, 24, 19, 30
+    x = torch.randn((B, T, N, 16), generator=g)
+    t = torch.tensor([700.5, 40.25])
+    cond = torch.randn((B, T, Li, 32), generator=g)
+    static = torch.randn((B, Ls, 14), generator=g)
+    xyz = torch.rand((B, N, 3), generator=g) - 0.5
+    with torch.no_grad():
+        y = model(x, t, cond_images=cond, static_latent=static, deformation_position_xyz=xyz)
+    out = {"cfg_json": np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8), "x": x.numpy(), "t": t.numpy(), "cond_images": cond.numpy(),
+           "static_latent": static.numpy(), "xyz": xyz.numpy(), "y": y.numpy()}
+    for k, v in model.state_dict().items():
+        out["sd." + k] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "dit_small_notemporal_golden.npz"), **out)
+    print("dit_small_notemporal_golden.npz", len(out), "arrays,", y.shape, float(y.abs().mean()))
+
+
 def gen_dit_autocast():
     """The reference's OWN reduced-precision behaviour: model/dit.py under torch.autocast (the reference runs fp16 autocast,
     inference_dpm_latent.py:171; bf16 is what the MI355X path computes in) on the inputs of dit_small_golden.npz and
@@ -686,7 +712,7 @@ def gen_sparse_layers():
     print("sparse_layers_golden.npz", {k: v.shape for k, v in out.items()})
 
 
-SECTIONS = {"sparse_layers": gen_sparse_layers, "slat_decoder": gen_slat_decoder, "sparse_vae": gen_sparse_vae, "vae_encode": gen_vae_encode, "vae": gen_vae, "raster": gen_raster, "vox2seq": gen_vox2seq, "dit": gen_dit, "dit_autocast": gen_dit_autocast, "align": gen_align, "sampler": gen_sampler, "sparse": gen_sparse}
+SECTIONS = {"sparse_layers": gen_sparse_layers, "slat_decoder": gen_slat_decoder, "sparse_vae": gen_sparse_vae, "vae_encode": gen_vae_encode, "vae": gen_vae, "raster": gen_raster, "vox2seq": gen_vox2seq, "dit": gen_dit, "dit_notemporal": gen_dit_notemporal, "dit_autocast": gen_dit_autocast, "align": gen_align, "sampler": gen_sampler, "sparse": gen_sparse}
 
 if __name__ == "__main__":
     install_stubs()

@@ -536,6 +536,24 @@ def test_small_dit_forward_matches_reference_golden(cuda):
     assert rel_l2(ca(x, ctxt), dit_ref.cross_attention(x, ctxt, sdc, "blocks.1.image_cross_attn", 2, "bf16")) < 1e-2
 
 
+def test_small_dit_without_temporal_attention_matches_reference_golden(cuda):
+    """no_temporal_attn=True: HIP forward vs the reference's own forward of that variant (dit_small_notemporal_golden.npz)."""
+    from gvfdiffusion_amd.model.dit import DiT
+    g = np.load(os.path.join(GOLD, "dit_small_notemporal_golden.npz"))
+    cfg = json.loads(bytes(g["cfg_json"]).decode())
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")}
+    model = DiT(**cfg)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(cuda).eval()
+    args = [torch.from_numpy(g[k]).to(cuda) for k in ("x", "t", "cond_images", "static_latent", "xyz")]
+    y = model(*args)
+    gold = torch.from_numpy(g["y"]).to(cuda)
+    yb = dit_ref.dit_forward({k: v.to(cuda) for k, v in sd.items()}, cfg, *args, precision="bf16")
+    r_ref, r_b = rel_l2(y, gold), rel_l2(y, yb)
+    print(f"small DiT, no temporal attention: rel_l2 vs fp32 reference golden {r_ref:.2e}; vs bf16-emulating oracle {r_b:.2e}")
+    assert r_ref < TOL_DIT_VS_FP32_REF and r_b < TOL_DIT_VS_BF16_ORACLE
+
+
 def test_condition_cache_is_keyed_on_tensor_identity(cuda):
     g, cfg, sd, model = _load_small(cuda)
     args = [torch.from_numpy(g[k]).to(cuda) for k in ("x", "t", "cond_images", "static_latent", "xyz")]

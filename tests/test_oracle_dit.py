@@ -55,6 +55,21 @@ def test_small_model_forward_matches_reference():
     assert 0.3 * ref_bf16 < rel <= 1.1 * ref_bf16, (rel, ref_bf16)
 
 
+def test_small_model_without_temporal_attention_matches_reference():
+    """no_temporal_attn=True (model/dit.py:241-260, 358): the reference's own forward of that variant, make_golden.py::gen_dit_notemporal."""
+    import json
+    g = np.load(os.path.join(GOLD, "dit_small_notemporal_golden.npz"))
+    cfg = json.loads(bytes(g["cfg_json"]).decode())
+    assert cfg["no_temporal_attn"] is True
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")}
+    assert not any("temporal" in k and "weight" in k and v.numel() > 0 for k, v in sd.items() if "adaLN_modulation_temporal" in k)
+    args = [torch.from_numpy(g[k]) for k in ("x", "t", "cond_images", "static_latent", "xyz")]
+    with torch.no_grad():
+        y = dit_ref.dit_forward(sd, cfg, *args, precision="fp32")
+    err = np.abs(y.numpy() - g["y"]).max()
+    assert err < 5e-5, err
+
+
 def test_full_config_forward_matches_reference():
     """configs/diffusion.yml, B=1, T=24, 1370 image tokens, 4096 static tokens (5.04 TFLOP on the CPU)."""
     man = json.load(open(os.path.join(GOLD, "dit_manifest.json")))
