@@ -69,4 +69,19 @@ def run_in_flight(jobs: Sequence[Callable[[int], object]], device, in_flight: in
         cur.wait_stream(s)
     if errors:
         raise errors[0]
+    _record_stream(results, cur)
     return results
+
+
+def _record_stream(obj, stream):
+    """Tensors a job allocated on its side stream and handed back are used on the caller's stream from now on: tell the caching allocator,
+    so that the block is not recycled on the side stream while the caller's stream still reads it."""
+    if torch.is_tensor(obj):
+        if obj.is_cuda:
+            obj.record_stream(stream)
+    elif isinstance(obj, (list, tuple)):
+        for o in obj:
+            _record_stream(o, stream)
+    elif isinstance(obj, dict):
+        for o in obj.values():
+            _record_stream(o, stream)
