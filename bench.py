@@ -567,8 +567,8 @@ def main():
     calls = ctypes.c_int(0)
     _lib.check(_lib.lib().gvf_rast_profile_read(ms, ctypes.byref(calls)), "profile_read")
     _lib.lib().gvf_rast_profile_enable(0)
-    # ---- pass 2: the timed K steps, n_slots samples in flight
-    for i in range(a.warmup):
+    # ---- pass 2: the timed K steps, n_slots samples in flight (every slot warmed at least twice, whatever W is)
+    for i in range(max(a.warmup, 2 * n_slots)):
         step(i, n_slots)
     barrier()
     t0 = time.perf_counter()
