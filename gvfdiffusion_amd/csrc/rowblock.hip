@@ -432,6 +432,7 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
             }
         }
         RB_STAMP();
+        if (P3 == 0 && hb_rows == nullptr) return;       // last block: final_layer reads the stream itself (gvf_dit_final_layer_f32)
         rb_layernorm(acc2, sRed, sPar + 6 * RB_C, sPar + 7 * RB_C, p.eps, R0, hb_rows, wave, lane, lq, l15, colw);
         RB_STAMP();
     }
@@ -619,10 +620,12 @@ extern "C" int gvf_rowblock_pack_mlp(const void* w_fc1_bf16, const void* w_fc2_b
 
 extern "C" int gvf_rowblock_fused_bf16(const gvf_rowblock_args* a, void* stream_) {
     if (!a) return GVF_EINVAL;
-    if (a->M < 0 || a->M % RB_BM != 0 || a->C != RB_C || a->K1 <= 0 || a->K1 % (32 * RB_DEPTH) != 0 || a->K1 > 512 || a->lda < a->K1 || a->lda % 8 != 0)
-        return GVF_EINVAL;
+    // K1 == 0: no closing projection (the stream already holds the sub-layer's result, e.g. input_layer in fp32): LayerNorm + projection only
+    if (a->M < 0 || a->M % RB_BM != 0 || a->C != RB_C || a->K1 < 0 || a->K1 % (32 * RB_DEPTH) != 0 || a->K1 > 512) return GVF_EINVAL;
+    if (a->K1 > 0 && (a->lda < a->K1 || a->lda % 8 != 0)) return GVF_EINVAL;
     if (a->M == 0) return GVF_OK;
-    if (!a->a || !a->w || !a->x) return GVF_EINVAL;
+    if ((a->K1 > 0 && !a->a) || !a->w || !a->x) return GVF_EINVAL;
+    if (a->K1 == 0 && (a->gate1 != nullptr || a->b1 != nullptr)) return GVF_EINVAL;
     if (a->x_in != nullptr && (a->x_in_period <= 0 || a->rows_per_group <= 0 || a->rows_per_group % a->x_in_period != 0 || (((uintptr_t)a->x_in) & 15)))
         return GVF_EINVAL;
     const gvf_rowblock_ln* lns[2] = {&a->ln1, &a->ln2};
@@ -636,7 +639,8 @@ extern "C" int gvf_rowblock_fused_bf16(const gvf_rowblock_args* a, void* stream_
     if (mlp && (a->hidden < 0 || a->hidden % RB_C != 0 || a->hidden > RB_MAX_HIDDEN)) return GVF_EINVAL;
     if (a->N3 != 0 && (!a->out3 || a->N3 < 0 || a->N3 % RB_C != 0 || a->N3 > RB_MAX_N3 || a->epi3 != GVF_EPI_STORE_BF16))
         return GVF_EINVAL;
-    if (a->N3 == 0 && a->hb_out == nullptr) return GVF_EINVAL;       // nothing would consume the last LayerNorm
+    if (a->N3 == 0 && a->hb_out == nullptr && a->hidden == 0) return GVF_EINVAL;       // nothing would consume the LayerNorm (with the MLP: the
+                                                                                        // stream update alone is a result; LayerNorm ln2 is skipped)
     if ((a->k_tiles == nullptr) != (a->v_tiles == nullptr)) return GVF_EINVAL;
     if (a->k_tiles != nullptr && (a->N3 != 3 * RB_C || a->kv_L <= 0 || a->kv_L % 64 != 0 || a->M % a->kv_L != 0 || !(a->k_scale > 0.f) ||
                                   (((uintptr_t)a->k_tiles) & 15) || (((uintptr_t)a->v_tiles) & 15)))

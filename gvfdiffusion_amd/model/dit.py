@@ -224,7 +224,14 @@ class DiT(nn.Module):
             return dit_ops.cast_pad_bf16(w, dit_ops.pad64(w.shape[1])), \
                 (None if lin.bias is None else lin.bias.detach().float().contiguous())
 
+        def prep32(lin):
+            return lin.weight.detach().float().contiguous(), (None if lin.bias is None else lin.bias.detach().float().contiguous())
+
         W = {"ver": ver}
+        # the small projections (0.3 % of the FLOPs, a third of the bf16 error: csrc/elem.hip) stay in fp32
+        W["input_f32"], W["final_f32"] = prep32(self.input_layer), prep32(self.final_layer.linear)
+        W["t0_f32"], W["t2_f32"] = prep32(self.t_embedder.mlp[0]), prep32(self.t_embedder.mlp[2])
+        W["img_f32"], W["static_f32"] = prep32(self.image_cond_proj), prep32(self.static_cond_proj)
         W["input"] = prep(self.input_layer)
         W["t0"], W["t2"] = prep(self.t_embedder.mlp[0]), prep(self.t_embedder.mlp[2])
         W["img"], W["static"] = prep(self.image_cond_proj), prep(self.static_cond_proj)
@@ -241,7 +248,8 @@ class DiT(nn.Module):
         offs.append(o)
         mods_w.append(self.final_layer.adaLN_modulation[-1].weight.detach().float())
         mods_b.append(self.final_layer.adaLN_modulation[-1].bias.detach().float())
-        W["mod_w"] = dit_ops.cast_pad_bf16(torch.cat(mods_w).contiguous(), dit_ops.pad64(self.model_channels))
+        W["mod_w_f32"] = torch.cat(mods_w).contiguous()
+        W["mod_w"] = dit_ops.cast_pad_bf16(W["mod_w_f32"], dit_ops.pad64(self.model_channels))
         W["mod_b"] = torch.cat(mods_b).contiguous()
         W["mod_offs"], W["mod_total"] = offs, W["mod_b"].numel()
         W["blocks"] = []
@@ -253,7 +261,7 @@ class DiT(nn.Module):
                     b[name] = dict(qkv=prep(m.to_qkv), out=prep(m.to_out), gq=m._gammas()[0], gk=m._gammas()[1])
             for name in ("image_cross_attn", "static_cross_attn"):
                 m = getattr(blk, name)
-                b[name] = dict(q=prep(m.to_q), kv=prep(m.to_kv), out=prep(m.to_out), gq=m._gammas()[0], gk=m._gammas()[1])
+                b[name] = dict(q=prep(m.to_q), kv=prep(m.to_kv), kv_f32=prep32(m.to_kv), out=prep(m.to_out), gq=m._gammas()[0], gk=m._gammas()[1])
             b["fc1"], b["fc2"] = prep(blk.mlp.mlp[0]), prep(blk.mlp.mlp[2])
             b["n3"] = (blk.norm3.weight.detach().float().contiguous(), blk.norm3.bias.detach().float().contiguous())
             b["n4"] = (blk.norm4.weight.detach().float().contiguous(), blk.norm4.bias.detach().float().contiguous())
@@ -269,11 +277,9 @@ class DiT(nn.Module):
         if "rb" in W:
             return W["rb"]
         P = dit_ops.rowblock_pack_stream
-        kin = dit_ops.ROWBLOCK_KPAD * ((self.input_layer.in_features + dit_ops.ROWBLOCK_KPAD - 1) // dit_ops.ROWBLOCK_KPAD)
-        w_in = dit_ops.cast_pad_bf16(self.input_layer.weight.detach().float().contiguous(), kin)
         blocks = W["blocks"]
         first = "spatial_self_attn"
-        rb = {"kin": kin, "in": P(w_in, w3=blocks[0][first]["qkv"][0]), "blocks": []}
+        rb = {"in": P(None, w3=blocks[0][first]["qkv"][0]), "blocks": []}        # input_layer itself runs in fp32 (csrc/elem.hip)
         for i, b in enumerate(blocks):
             nxt = blocks[i + 1][first]["qkv"][0] if i + 1 < len(blocks) else None
             d = {}
@@ -329,22 +335,32 @@ class DiT(nn.Module):
         B, Tc, Li, Ci = cond_images.shape
         Ls = static_latent.shape[1]
         ctx = {"T": T, "held": (conds, tuple(self._key(t) for t in conds)), "Li": Li, "Ls": Ls}
-        ci = dit_ops.cast_pad_bf16(cond_images.reshape(B * Tc * Li, Ci).float().contiguous(), dit_ops.pad64(Ci))
-        img_emb = torch.empty((B * Tc * Li, C), dtype=torch.bfloat16, device=dev)
-        dit_ops.gemm_bf16(ci, W["img"][0], W["img"][1], img_emb, dit_ops.EPI_STORE_BF16)
-        cs = dit_ops.cast_pad_bf16(static_latent.reshape(B * Ls, -1).float().contiguous(), dit_ops.pad64(static_latent.shape[-1]))
-        st_emb = torch.empty((B * Ls, C), dtype=torch.bfloat16, device=dev)
-        dit_ops.gemm_bf16(cs, W["static"][0], W["static"][1], st_emb, dit_ops.EPI_STORE_BF16)
+        # Step-invariant, so precision here is free: condition projections and every block's to_kv(context) as plain fp32 library GEMMs
+        # (rocBLAS through torch, ~5 ms per sample), ONE rounding to bf16 when the cache builder folds the softmax scale in and stores the
+        # tiled image the attention workgroups stage into LDS (csrc/attn_xt.hip); static K/V once per sample, not per frame.
         H = self.num_heads
-        # every block's to_kv(context), kept in fp32 until the cache builder has folded the softmax scale in, then stored
-        # in the tiled image the attention workgroups stage into LDS (csrc/attn_xt.hip); static K/V once per sample
         ctx["kv_img"], ctx["kv_st"] = [], []
+        img_emb = torch.empty((B * Tc * Li, C), dtype=torch.float32, device=dev)
+        st_emb = torch.empty((B * Ls, C), dtype=torch.float32, device=dev)
         kv_i = torch.empty((B * Tc * Li, 2 * C), dtype=torch.float32, device=dev)
         kv_s = torch.empty((B * Ls, 2 * C), dtype=torch.float32, device=dev)
+
+        def lin_out(x_, wb, out):
+            # one library call per SAMPLE: the GEMM then has the shape (and the summation order) of a batch-1 call, so a sample's result
+            # does not depend on what it is batched with (tests: batch of three == three single samples, bit for bit)
+            rows = x_.shape[0] // B
+            for s_ in range(B):
+                xs, os_ = x_[s_ * rows:(s_ + 1) * rows], out[s_ * rows:(s_ + 1) * rows]
+                if wb[1] is None:
+                    torch.mm(xs, wb[0].t(), out=os_)
+                else:
+                    torch.addmm(wb[1], xs, wb[0].t(), out=os_)
+        lin_out(cond_images.reshape(B * Tc * Li, Ci).float(), W["img_f32"], img_emb)
+        lin_out(static_latent.reshape(B * Ls, -1).float(), W["static_f32"], st_emb)
         for b in W["blocks"]:
-            dit_ops.gemm_bf16(img_emb, *b["image_cross_attn"]["kv"], kv_i, dit_ops.EPI_STORE_F32)
+            lin_out(img_emb, b["image_cross_attn"]["kv_f32"], kv_i)
             ctx["kv_img"].append(dit_ops.attention_pack_kv(kv_i, B * Tc, Li, H, 0, C, gamma_k=b["image_cross_attn"]["gk"]))
-            dit_ops.gemm_bf16(st_emb, *b["static_cross_attn"]["kv"], kv_s, dit_ops.EPI_STORE_F32)   # once per sample, not per frame
+            lin_out(st_emb, b["static_cross_attn"]["kv_f32"], kv_s)
             ctx["kv_st"].append(dit_ops.attention_pack_kv(kv_s, B, Ls, H, 0, C, gamma_k=b["static_cross_attn"]["gk"]))
         if self.pe_mode == "ape":
             assert deformation_position_xyz is not None, "Deformation position xyz is required for APE mode"
@@ -409,33 +425,35 @@ class DiT(nn.Module):
         Li, Ls = ctx["Li"], ctx["Ls"]
         bf, f32 = torch.bfloat16, torch.float32
 
-        # timestep embedding -> t_emb (B,C) -> SiLU (one launch) -> every adaLN projection of the step in one GEMM
-        mod = torch.empty((B, W["mod_total"]), dtype=f32, device=dev)
-        if self.t_embedder.frequency_embedding_size % 2 == 0 and self.t_embedder.frequency_embedding_size <= 1024 and C <= 1024:
-            s2 = torch.empty((B, dit_ops.pad64(C)), dtype=bf, device=dev)
-            dit_ops.timestep_embed_bf16(t.to(dev).float().contiguous(), W["t0"][0], W["t0"][1], W["t2"][0], W["t2"][1], s2,
-                                        freq_dim=self.t_embedder.frequency_embedding_size)
+        # timestep embedder (sinusoid, two Linears, two SiLUs: one launch) and every adaLN projection of the step (one GEMV), both in fp32
+        fdim = self.t_embedder.frequency_embedding_size
+        if fdim % 4 == 0 and fdim <= 1024 and C % 4 == 0 and C <= 1024:
+            s2 = dit_ops.timestep_embed_f32(t.to(dev).float().contiguous(), *W["t0_f32"], *W["t2_f32"], freq_dim=fdim)
+            mod = dit_ops.modulation_f32(s2, W["mod_w_f32"], W["mod_b"])
         else:
-            tf = dit_ops.cast_pad_bf16(TimestepEmbedder.timestep_embedding(t.to(dev), self.t_embedder.frequency_embedding_size).contiguous(),
-                                       dit_ops.pad64(self.t_embedder.frequency_embedding_size))
+            mod = torch.empty((B, W["mod_total"]), dtype=f32, device=dev)
+            tf = dit_ops.cast_pad_bf16(TimestepEmbedder.timestep_embedding(t.to(dev), fdim).contiguous(), dit_ops.pad64(fdim))
             h1 = torch.empty((B, C), dtype=f32, device=dev)
             dit_ops.gemm_bf16(tf, *W["t0"], h1, dit_ops.EPI_STORE_F32)
             t_emb = torch.empty((B, C), dtype=f32, device=dev)
             dit_ops.gemm_bf16(dit_ops.cast_pad_bf16(h1, dit_ops.pad64(C), act=1), *W["t2"], t_emb, dit_ops.EPI_STORE_F32)
-            s2 = dit_ops.cast_pad_bf16(t_emb, dit_ops.pad64(C), act=1)
-        dit_ops.gemm_bf16(s2, W["mod_w"], W["mod_b"], mod, dit_ops.EPI_STORE_F32)
+            dit_ops.gemm_bf16(dit_ops.cast_pad_bf16(t_emb, dit_ops.pad64(C), act=1), W["mod_w"], W["mod_b"], mod, dit_ops.EPI_STORE_F32)
         mod_ld = W["mod_total"]
 
-        # residual stream h (fp32): position embedding broadcast over T, plus input_layer(x)
-        if self.use_rowblock and dit_ops.rowblock_supported(C, T * N, int(C * self.mlp_ratio)):
-            if ctx["pos"] is not None:      # the first row-block launch reads the (B, N, C) embedding with the broadcast and only writes h
-                return self._blocks_rowblock(x, torch.empty((M, C), dtype=f32, device=dev), mod, mod_ld, W, ctx, B, T, N, pos=ctx["pos"])
-            return self._blocks_rowblock(x, torch.zeros((M, C), dtype=f32, device=dev), mod, mod_ld, W, ctx, B, T, N)
-        if ctx["pos"] is not None:
-            h = ctx["pos"][:, None].expand(B, T, N, C).reshape(M, C).contiguous()
+        # residual stream h (fp32) = position embedding broadcast over T + input_layer(x), in fp32 (csrc/elem.hip)
+        small_f32 = C <= 512 and C % 4 == 0 and Cin <= 24 and self.out_channels <= 32
+        h = torch.empty((M, C), dtype=f32, device=dev)
+        if small_f32:
+            pos = ctx["pos"]
+            dit_ops.input_layer_f32(x.reshape(M, Cin).float().contiguous(), W["input_f32"][0], W["input_f32"][1], h,
+                                    pos=None if pos is None else pos.reshape(B * N, C), pos_period=N, rows_per_group=T * N)
+        elif ctx["pos"] is not None:
+            h.copy_(ctx["pos"][:, None].expand(B, T, N, C).reshape(M, C))
         else:
-            h = torch.zeros((M, C), dtype=f32, device=dev)
-        xb = dit_ops.cast_pad_bf16(x.reshape(M, Cin).float().contiguous(), dit_ops.pad64(Cin))
+            h.zero_()
+        if self.use_rowblock and small_f32 and dit_ops.rowblock_supported(C, T * N, int(C * self.mlp_ratio)):
+            return self._blocks_rowblock(x, h, mod, mod_ld, W, ctx, B, T, N)
+        xb = None if small_f32 else dit_ops.cast_pad_bf16(x.reshape(M, Cin).float().contiguous(), dit_ops.pad64(Cin))
         hb = torch.empty((M, C), dtype=bf, device=dev)          # attention-output scratch of the cross attentions
         qkv = torch.empty((M, 3 * C), dtype=bf, device=dev)
         ab = torch.empty((M, C), dtype=bf, device=dev)          # attention output / q projection
@@ -466,7 +484,8 @@ class DiT(nn.Module):
                 dit_ops.layernorm_modulate_bf16(h, hb, 1e-6, ln_w, ln_b, shift, scale, mod_ld, TN)
                 dit_ops.gemm_bf16(hb, wb[0], wb[1], out, epi)
 
-        resid(xb, W["input"])           # h = pos + input_layer(x)
+        if not small_f32:
+            resid(xb, W["input"])           # h = pos + input_layer(x)
 
         def mview(off):                                       # (B,) rows of `mod`, columns [off, off+C)
             return mod[:, off:]
@@ -508,10 +527,13 @@ class DiT(nn.Module):
 
         o = W["mod_offs"][-1]
         y = torch.empty((M, self.out_channels), dtype=f32, device=dev)
-        ln_gemm(W["final"], y, dit_ops.EPI_STORE_F32, shift=mview(o), scale=mview(o + C))
+        if small_f32:
+            dit_ops.final_layer_f32(h, W["final_f32"][0], W["final_f32"][1], y, shift=mview(o), scale=mview(o + C), mod_ld=mod_ld, rows_per_group=TN)
+        else:
+            ln_gemm(W["final"], y, dit_ops.EPI_STORE_F32, shift=mview(o), scale=mview(o + C))
         return y.reshape(B, T, N, self.out_channels).to(x.dtype if x.dtype.is_floating_point else f32)
 
-    def _blocks_rowblock(self, x, h, mod, mod_ld, W, ctx, B, T, N, pos=None):
+    def _blocks_rowblock(self, x, h, mod, mod_ld, W, ctx, B, T, N):
         """The blocks with one launch per sub-layer boundary (csrc/rowblock.hip): per block  spatial attention | to_out + adaLN +
         to_qkv | temporal attention | to_out + norm3 + to_q | image attention | to_out + norm4 + to_q | static attention | to_out +
         adaLN + MLP + adaLN + the NEXT block's to_qkv (q row-major, K / V^T as the attention's tile images) -- 8 launches instead of 20, the fp32 stream through HBM 5 times instead of 15,
@@ -522,8 +544,6 @@ class DiT(nn.Module):
         bf, f32 = torch.bfloat16, torch.float32
         rb = self._rowblock_streams(W)
         Li, Ls = ctx["Li"], ctx["Ls"]
-        Cin = x.shape[-1]
-        xb = dit_ops.cast_pad_bf16(x.reshape(M, Cin).float().contiguous(), rb["kin"])
         qkv = torch.empty((M, 3 * C), dtype=bf, device=dev)
         ab = torch.empty((M, C), dtype=bf, device=dev)            # self-attention output
         hb = torch.empty((M, C), dtype=bf, device=dev)            # cross-attention output
@@ -553,9 +573,8 @@ class DiT(nn.Module):
                 return dict(out3=qs, b3=a_["qkv"][1], kv_tiles=kv_self, kv_L=N, gamma_k=a_["gk"])
             return dict(out3=qkv, b3=a_["qkv"][1])
 
-        fused(xb, rb["in"], b1=W["input"][1], ln1=dict(shift=mview(o), scale=mview(o + C)),
-              x_in=None if pos is None else pos.reshape(B * N, C), x_in_period=N, **qkv_out(blocks[0]))
-        hbn = None
+        # h already holds pos + input_layer(x): adaLN of block 0 and its to_qkv
+        fused(None, rb["in"], ln1=dict(shift=mview(o), scale=mview(o + C)), **qkv_out(blocks[0]))
         for i, b in enumerate(blocks):
             o, s = offs[i], rb["blocks"][i]
             g_s, sh_m, sc_m, g_m = mview(o + 2 * C), mview(o + 3 * C), mview(o + 4 * C), mview(o + 5 * C)
@@ -588,9 +607,8 @@ class DiT(nn.Module):
                 on = offs[i + 1]
                 fused(hb, s["s5"], ln2=dict(shift=mview(on), scale=mview(on + C)), **qkv_out(blocks[i + 1]), **kw)
             else:
-                on = offs[-1]
-                hbn = torch.empty((M, C), dtype=bf, device=dev)
-                fused(hb, s["s5"], ln2=dict(shift=mview(on), scale=mview(on + C)), hb_out=hbn, **kw)
+                fused(hb, s["s5"], **kw)                       # the last MLP; final_layer reads the stream itself
+        on = offs[-1]
         y = torch.empty((M, self.out_channels), dtype=f32, device=dev)
-        dit_ops.gemm_bf16(hbn, W["final"][0], W["final"][1], y, dit_ops.EPI_STORE_F32)
+        dit_ops.final_layer_f32(h, W["final_f32"][0], W["final_f32"][1], y, shift=mview(on), scale=mview(on + C), mod_ld=mod_ld, rows_per_group=TN)
         return y.reshape(B, T, N, self.out_channels).to(x.dtype if x.dtype.is_floating_point else f32)

@@ -30,6 +30,10 @@ class RowblockArgs(ctypes.Structure):
 
 
 _lib.register({
+    "gvf_dit_timestep_embed_f32": (_i, [_vp, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "gvf_dit_modulation_f32": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp]),
+    "gvf_dit_input_layer_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "gvf_dit_final_layer_f32": (_i, [_vp, _i, _i, _f, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "gvf_dit_timestep_embed_bf16": (_i, [_vp, _i, _i, _f, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp]),
     "gvf_rowblock_args_layout": (_i, [ctypes.POINTER(ctypes.c_int32), _i]),
     "gvf_rowblock_packed_bytes": (_i64, [_i, _i]),
@@ -130,6 +134,47 @@ def timestep_embed_bf16(t, w0, b0, w2, b2, out, freq_dim=256, max_period=10000.0
     return out
 
 
+def timestep_embed_f32(t, w0, b0, w2, b2, freq_dim=256, max_period=10000.0, t_emb=None):
+    """-> silu(TimestepEmbedder(t)) f32 (B, C), all in fp32 (w0 (C, freq_dim), w2 (C, C) fp32 nn.Linear weights)."""
+    _lib.require_cuda(t, w0, w2)
+    assert t.dtype == w0.dtype == w2.dtype == torch.float32 and w0.is_contiguous() and w2.is_contiguous()
+    C = w2.shape[0]
+    out = torch.empty((t.numel(), C), dtype=torch.float32, device=t.device)
+    _lib.check(_lib.lib().gvf_dit_timestep_embed_f32(_p(t), t.numel(), int(freq_dim), float(max_period), _p(w0), _p(b0), _p(w2), _p(b2), C, _p(out),
+                                                     _p(t_emb), _stream(t)), "gvf_dit_timestep_embed_f32")
+    return out
+
+
+def modulation_f32(s, w, bias, out=None):
+    """out (B, N) = s (B, C) @ w (N, C)^T + bias, fp32 GEMV per sample (every adaLN projection of the step)."""
+    _lib.require_cuda(s, w)
+    assert s.dtype == w.dtype == torch.float32 and s.is_contiguous() and w.is_contiguous()
+    B, C = s.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty((B, N), dtype=torch.float32, device=s.device)
+    _lib.check(_lib.lib().gvf_dit_modulation_f32(_p(s), B, C, _p(w), _p(bias), N, _p(out), _stream(s)), "gvf_dit_modulation_f32")
+    return out
+
+
+def input_layer_f32(x, w, bias, out, pos=None, pos_period=0, rows_per_group=0):
+    """out (M, 512) = pos (broadcast) + x (M, Cin) @ w (512, Cin)^T + bias, fp32."""
+    _lib.require_cuda(x, w, out)
+    assert x.dtype == w.dtype == out.dtype == torch.float32 and x.is_contiguous() and w.is_contiguous() and out.is_contiguous()
+    _lib.check(_lib.lib().gvf_dit_input_layer_f32(_p(x), x.shape[0], x.shape[1], _p(w), _p(bias), _p(pos), int(pos_period), int(rows_per_group),
+                                                  out.shape[1], _p(out), _stream(x)), "gvf_dit_input_layer_f32")
+    return out
+
+
+def final_layer_f32(x, w, bias, out, shift=None, scale=None, mod_ld=0, rows_per_group=0, eps=1e-6):
+    """out (M, Cout) = (LayerNorm(x) * (1 + scale) + shift) @ w (Cout, 512)^T + bias, fp32, straight from the stream."""
+    _lib.require_cuda(x, w, out)
+    assert x.dtype == w.dtype == out.dtype == torch.float32 and x.is_contiguous() and w.is_contiguous() and out.is_contiguous()
+    _lib.check(_lib.lib().gvf_dit_final_layer_f32(_p(x), x.shape[0], x.shape[1], float(eps), _p(shift), _p(scale), int(mod_ld), int(rows_per_group),
+                                                  _p(w), _p(bias), w.shape[0], _p(out), _stream(x)), "gvf_dit_final_layer_f32")
+    return out
+
+
 ROWBLOCK_C, ROWBLOCK_ROWS, ROWBLOCK_KPAD, ROWBLOCK_MAX_HIDDEN, ROWBLOCK_MAX_N3 = 512, 48, 128, 2048, 1536
 
 
@@ -141,15 +186,18 @@ def rowblock_supported(C: int, rows_per_group: int, hidden: int) -> bool:
 def rowblock_pack_stream(w1, mlp=None, w3=None):
     """One weight stream for gvf_rowblock_fused_bf16: w1 = nn.Linear weight bf16 [512][K1 padded to 128] (see cast_pad_bf16), mlp =
     (mlp.0 weight bf16 [hidden][512], mlp.2 weight bf16 [512][hidden]) or None, w3 = bf16 [N3][512] or None.  Returns a uint8 tensor."""
-    _lib.require_cuda(w1)
     L = _lib.lib()
-    assert w1.dtype == torch.bfloat16 and w1.shape[0] == ROWBLOCK_C and w1.shape[1] % ROWBLOCK_KPAD == 0 and w1.is_contiguous()
-    sizes = [int(L.gvf_rowblock_packed_bytes(ROWBLOCK_C, w1.shape[1]))]
+    ref = w1 if w1 is not None else (w3 if w3 is not None else mlp[0])
+    _lib.require_cuda(ref)
+    if w1 is not None:
+        assert w1.dtype == torch.bfloat16 and w1.shape[0] == ROWBLOCK_C and w1.shape[1] % ROWBLOCK_KPAD == 0 and w1.is_contiguous()
+    sizes = [0 if w1 is None else int(L.gvf_rowblock_packed_bytes(ROWBLOCK_C, w1.shape[1]))]
     sizes.append(0 if mlp is None else 2 * mlp[0].shape[0] * ROWBLOCK_C * 2)
     sizes.append(0 if w3 is None else int(L.gvf_rowblock_packed_bytes(w3.shape[0], ROWBLOCK_C)))
-    out = torch.empty(sum(sizes), dtype=torch.uint8, device=w1.device)
-    st = _stream(w1)
-    _lib.check(L.gvf_rowblock_pack_weight(_p(w1), w1.stride(0), ROWBLOCK_C, w1.shape[1], _p(out), st), "gvf_rowblock_pack_weight")
+    out = torch.empty(sum(sizes), dtype=torch.uint8, device=ref.device)
+    st = _stream(ref)
+    if w1 is not None:
+        _lib.check(L.gvf_rowblock_pack_weight(_p(w1), w1.stride(0), ROWBLOCK_C, w1.shape[1], _p(out), st), "gvf_rowblock_pack_weight")
     if mlp is not None:
         f1, f2 = mlp
         assert f1.dtype == f2.dtype == torch.bfloat16 and f1.is_contiguous() and f2.is_contiguous()
@@ -175,12 +223,17 @@ def rowblock_fused(a, stream_w, x, b1=None, gate1=None, ln1=None, mod_ld=0, rows
                    mlp_bias=None, hidden=0, gate_m=None, ln2=None, b3=None, out3=None, hb_out=None, x_in=None, x_in_period=0, kv_tiles=None, kv_L=0, gamma_k=None, kv_scale=None):
     """x += gate1 * (a W1^T + b1); hb = LN1(x); [x += gate_m * MLP(hb); hb = LN2(x)]; out3 = hb W3^T + b3 or hb_out = hb -- ONE launch
     (csrc/rowblock.hip; include/gvf_dit.h).  ln1 / ln2: dict with ln_w, ln_b and / or shift, scale.  mlp_bias = (b_fc1, b_fc2).
+    a = None: no closing projection (x already holds the sub-layer's result; the stream has no W1 segment).
     x_in (f32 [groups * x_in_period][C]): the residual is read from it, broadcast with period x_in_period inside a row group, and x is only written."""
-    _lib.require_cuda(a, stream_w, x)
-    assert a.dtype == torch.bfloat16 and x.dtype == torch.float32 and a.stride(1) == 1 and x.is_contiguous()
+    _lib.require_cuda(stream_w, x)
+    assert x.dtype == torch.float32 and x.is_contiguous()
     M, C = x.shape
     args = RowblockArgs()
-    args.a, args.lda, args.K1, args.w, args.b1 = _pi(a), a.stride(0), a.shape[1], _pi(stream_w), _pi(b1)
+    if a is not None:
+        _lib.require_cuda(a)
+        assert a.dtype == torch.bfloat16 and a.stride(1) == 1
+        args.a, args.lda, args.K1 = _pi(a), a.stride(0), a.shape[1]
+    args.w, args.b1 = _pi(stream_w), _pi(b1)
     args.x, args.M, args.C = _pi(x), M, C
     if x_in is not None:
         assert x_in.dtype == torch.float32 and x_in.is_contiguous() and x_in.shape[-1] == C

@@ -66,6 +66,8 @@ int gvf_gemm_ln_bf16(const float* X, int ldx, const float* row_stats, int n_part
  *   MLP: gvf_rowblock_pack_mlp (mlp.0 weight [hidden][512] and mlp.2 weight [512][hidden] -> 2 * hidden * 512 * 2 bytes, interleaved
  *        per 512 hidden units; hidden a multiple of 512, <= 2048)           -- only when hidden != 0,
  *   W3:  gvf_rowblock_pack_weight                                            -- only when N3 != 0.
+ * K1 = 0 skips the closing projection (x already holds the sub-layer's result; `a`, b1, gate1 NULL, no W1 segment in `w`).  With the MLP and
+ * neither N3 nor hb_out the launch ends after the MLP's update of x (LayerNorm ln2 is skipped: final_layer reads the stream itself).
  * K1 (<= 512, multiple of 128) is the PADDED depth of W1; A is bf16 [M][lda] with lda >= K1.  gate / shift / scale: f32, row g =
  * row / rows_per_group of leading dimension mod_ld (rows_per_group a multiple of 48); NULL = no gate / no modulate.
  * Rounding points are those of the unfused launches: bf16 operands, fp32 accumulation, fp32 stream, LayerNorm in fp32,
@@ -157,6 +159,23 @@ int gvf_layernorm_modulate_bf16(const float* x, void* out_bf16, int rows, int C,
  * act: 0 = identity, 1 = SiLU. */
 int gvf_cast_pad_bf16(const float* src, int ld_src, void* dst, int ld_dst, int64_t rows, int cols, int act,
                       void* stream);
+
+/* ---- the small projections of the denoise step in FP32 (csrc/elem.hip) ----------------------------------------------------------------
+ * 0.3 % of the step's FLOPs and more than a third of its bf16 error (their results multiply or feed everything else), so they do not go
+ * through the bf16 matrix pipe:
+ *   gvf_dit_timestep_embed_f32: out_silu[b] = silu(W2 silu(W0 [cos | sin](t_b f) + b0) + b2), f32 [B][C]   (model/dit.py:59-100, 217-225)
+ *   gvf_dit_modulation_f32:     out[b][n] = w[n] . s[b] + bias[n]: every block's adaLN vectors in one GEMV   (model/dit.py:217-225, 298-303)
+ *   gvf_dit_input_layer_f32:    out[row] = pos[(row / rows_per_group) * pos_period + (row % rows_per_group) % pos_period] + w x[row] + bias
+ *                               (model/dit.py:455-460: input_layer(x) + the position embedding broadcast over the frames; pos may be NULL)
+ *   gvf_dit_final_layer_f32:    out[row] = w (LayerNorm(x[row]) * (1 + scale[g]) + shift[g]) + bias              (model/dit.py:298-303)
+ * Weights are the nn.Linear fp32 weights as stored ([out][in], contiguous).  C <= 512 (a multiple of 4) for the last two; Cin <= 24; Cout <= 32. */
+int gvf_dit_timestep_embed_f32(const float* t, int B, int freq_dim, float max_period, const float* w0, const float* b0, const float* w2,
+                               const float* b2, int C, float* out_silu, float* t_emb, void* stream);
+int gvf_dit_modulation_f32(const float* s, int B, int C, const float* w, const float* bias, int N, float* out, void* stream);
+int gvf_dit_input_layer_f32(const float* x, int M, int Cin, const float* w, const float* bias, const float* pos, int pos_period,
+                            int rows_per_group, int C, float* out, void* stream);
+int gvf_dit_final_layer_f32(const float* x, int M, int C, float eps, const float* shift, const float* scale, int mod_ld, int rows_per_group,
+                            const float* w, const float* bias, int Cout, float* out, void* stream);
 
 /* TimestepEmbedder and the SiLU in front of the adaLN projections in one launch (model/dit.py:59-100, 217-225):
  *   t_freq = [cos(t f_i) | sin(t f_i)], f_i = max_period^(-i / (freq_dim/2));  t_emb = W2 silu(W0 t_freq + b0) + b2;

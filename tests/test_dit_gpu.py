@@ -212,6 +212,44 @@ def test_rowblock_tiled_kv_epilogue_is_bitwise_the_pack_kernel(cuda, n_sets, L, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("C,Cin,Cout,B,T,N", [(512, 16, 16, 2, 3, 48), (64, 16, 16, 2, 3, 40), (192, 7, 5, 1, 2, 33)])
+def test_small_projections_in_fp32_match_torch(cuda, C, Cin, Cout, B, T, N):
+    """csrc/elem.hip's fp32 kernels (timestep embedder, adaLN GEMV, input_layer + broadcast position embedding, final_layer from the stream)
+    against torch fp32 expressions of model/dit.py:59-100, 217-225, 298-303, 455-460."""
+    Fnn = torch.nn.functional
+    g = torch.Generator().manual_seed(C + N)
+    rn = lambda *s, sc=1.0: (torch.randn(s, generator=g) * sc).to(cuda)
+    M, TN, Nmod = B * T * N, T * N, 7 * C + 3
+    # timestep embedder + modulation
+    t = torch.tensor([999.0, 12.5, 431.25][:B], device=cuda)
+    w0, b0, w2, b2 = rn(C, 256, sc=1 / 16), rn(C, sc=0.1), rn(C, C, sc=1 / math.sqrt(C)), rn(C, sc=0.1)
+    te = torch.empty((B, C), device=cuda)
+    s2 = dit_ops.timestep_embed_f32(t, w0, b0, w2, b2, freq_dim=256, t_emb=te)
+    te_ref = Fnn.linear(Fnn.silu(Fnn.linear(dit_ref.timestep_embedding(t, 256), w0, b0)), w2, b2)
+    assert rel_l2(te, te_ref) < 2e-6 and rel_l2(s2, Fnn.silu(te_ref)) < 2e-6
+    wm, bm = rn(Nmod, C, sc=1 / math.sqrt(C)), rn(Nmod, sc=0.1)
+    mod = dit_ops.modulation_f32(s2, wm, bm)
+    assert rel_l2(mod, Fnn.linear(s2, wm, bm)) < 2e-6
+    # input layer on the broadcast position embedding
+    x, wi, bi, pos = rn(M, Cin), rn(C, Cin, sc=0.3), rn(C, sc=0.1), rn(B * N, C)
+    h = torch.full((M, C), float("nan"), device=cuda)
+    dit_ops.input_layer_f32(x, wi, bi, h, pos=pos, pos_period=N, rows_per_group=TN)
+    h_ref = Fnn.linear(x, wi, bi).reshape(B, T, N, C) + pos.reshape(B, 1, N, C)
+    assert rel_l2(h, h_ref.reshape(M, C)) < 2e-6
+    h2 = torch.empty((M, C), device=cuda)
+    dit_ops.input_layer_f32(x, wi, None, h2)
+    assert rel_l2(h2, Fnn.linear(x, wi)) < 2e-6
+    # final layer from the stream
+    wf, bfin = rn(Cout, C, sc=1 / math.sqrt(C)), rn(Cout, sc=0.1)
+    md = rn(B, 4 * C, sc=0.3)
+    y = torch.full((M, Cout), float("nan"), device=cuda)
+    dit_ops.final_layer_f32(h, wf, bfin, y, shift=md[:, :C], scale=md[:, C:], mod_ld=4 * C, rows_per_group=TN)
+    ln = Fnn.layer_norm(h.reshape(B, TN, C), (C,), None, None, 1e-6)
+    y_ref = Fnn.linear(ln * (1 + md[:, None, C:2 * C]) + md[:, None, :C], wf, bfin).reshape(M, Cout)
+    assert rel_l2(y, y_ref) < 5e-6
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("C,F", [(512, 256), (64, 256), (192, 64)])
 def test_timestep_embedder_launch_equals_the_unfused_chain(cuda, C, F):
     """gvf_dit_timestep_embed_bf16 == torch sinusoid -> gvf_cast_pad_bf16 -> gvf_gemm_bf16 -> SiLU cast -> gvf_gemm_bf16 -> SiLU cast, and the
