@@ -237,13 +237,15 @@ __global__ __launch_bounds__(1024) void timestep_embed_f32_kernel(const float* _
         sB[tid] = 0.f;
     }
     __syncthreads();
-    float acc[8];
-    for (int o0 = wave; o0 < C; o0 += 128) {
+    float acc[8], acc2[8];
+    for (int o0 = wave; o0 < C; o0 += 256) {               // two independent groups of 8 rows per trip: 16 rows' loads in flight per wave
         dot8_f32(W0, F, o0, 16, C, F, sA, lane, acc);
+        dot8_f32(W0, F, o0 + 128, 16, C, F, sA, lane, acc2);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int o = o0 + 16 * u;
+            const int o = o0 + 16 * u, o2 = o + 128;
             if (lane == 0 && o < C) { const float v = acc[u] + (b0 ? b0[o] : 0.f); sB[o] = v / (1.0f + __expf(-v)); }
+            if (lane == 0 && o2 < C) { const float v = acc2[u] + (b0 ? b0[o2] : 0.f); sB[o2] = v / (1.0f + __expf(-v)); }
         }
     }
     __syncthreads();
@@ -286,83 +288,120 @@ __global__ __launch_bounds__(256) void modulation_f32_kernel(const float* __rest
 }
 
 // input_layer in fp32 on top of the (broadcast) position embedding: out[row] = pos[(row / rpg) * period + (row % rpg) % period] + W x[row] + b.
-// 16 rows per workgroup, thread = output columns tid and tid + 256; W^T and the 16 input rows in LDS.  Cin <= 24, C <= 512.
-__global__ __launch_bounds__(256) void input_layer_f32_kernel(const float* __restrict__ x, int M, int Cin, const float* __restrict__ W, const float* __restrict__ bias,
+// 16 rows per workgroup, thread = output columns tid and tid + 256 with their weights in registers (W^T [Cin][C], transposed once by the
+// caller: coalesced loads); the input rows in LDS.  Cin <= 24, C <= 512.
+constexpr int IN_ROWS = 16;
+__global__ __launch_bounds__(256) void input_layer_f32_kernel(const float* __restrict__ x, int M, int Cin, const float* __restrict__ Wt, const float* __restrict__ bias,
                                                               const float* __restrict__ pos, int period, int rpg, int C, float* __restrict__ out) {
-    __shared__ float sW[24 * 512];                        // [k][c]
-    __shared__ float sX[16 * 24];
+    __shared__ __attribute__((aligned(16))) float sX[IN_ROWS * 24];
     const int tid = threadIdx.x;
-    for (int i = tid; i < Cin * C; i += 256) { const int c = i / Cin, k = i - c * Cin; sW[k * C + c] = W[i]; }
-    const int r0 = blockIdx.x * 16;
-    for (int i = tid; i < 16 * Cin; i += 256) { const int r = i / Cin, k = i - r * Cin; sX[r * 24 + k] = r0 + r < M ? x[(size_t)(r0 + r) * Cin + k] : 0.f; }
-    __syncthreads();
+    const int r0 = blockIdx.x * IN_ROWS;
+    for (int i = tid; i < IN_ROWS * 24; i += 256) {
+        const int r = i / 24, k = i - r * 24;
+        sX[i] = (k < Cin && r0 + r < M) ? x[(size_t)(r0 + r) * Cin + k] : 0.f;
+    }
     const int c0 = tid, c1 = tid + 256;
     const bool ok0 = c0 < C, ok1 = c1 < C;
-    float a0[16], a1[16];
+    float w0[24], w1[24];                                  // this thread's two weight columns (coalesced across the threads: W^T rows)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
-    for (int k = 0; k < Cin; ++k) {
-        const float w0 = ok0 ? sW[k * C + c0] : 0.f, w1 = ok1 ? sW[k * C + c1] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { const float xv = sX[r * 24 + k]; a0[r] = fmaf(xv, w0, a0[r]); a1[r] = fmaf(xv, w1, a1[r]); }
+    for (int k = 0; k < 24; ++k) {
+        w0[k] = (k < Cin && ok0) ? Wt[k * C + c0] : 0.f;
+        w1[k] = (k < Cin && ok1) ? Wt[k * C + c1] : 0.f;
     }
     const float b0 = (bias && ok0) ? bias[c0] : 0.f, b1 = (bias && ok1) ? bias[c1] : 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    __syncthreads();
+#pragma unroll 4
+    for (int r = 0; r < IN_ROWS; ++r) {
         const int row = r0 + r;
-        if (row < M) {
-            const size_t pr = pos != nullptr ? (size_t)(row / rpg) * period + (row % rpg) % period : 0;
-            if (ok0) out[(size_t)row * C + c0] = (pos != nullptr ? pos[pr * C + c0] : 0.f) + (a0[r] + b0);
-            if (ok1) out[(size_t)row * C + c1] = (pos != nullptr ? pos[pr * C + c1] : 0.f) + (a1[r] + b1);
+        if (row >= M) break;
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int k4 = 0; k4 < 6; ++k4) {
+            const float4 xv = *reinterpret_cast<const float4*>(&sX[r * 24 + 4 * k4]);     // broadcast read
+            a0 = fmaf(xv.x, w0[4 * k4], a0); a0 = fmaf(xv.y, w0[4 * k4 + 1], a0); a0 = fmaf(xv.z, w0[4 * k4 + 2], a0); a0 = fmaf(xv.w, w0[4 * k4 + 3], a0);
+            a1 = fmaf(xv.x, w1[4 * k4], a1); a1 = fmaf(xv.y, w1[4 * k4 + 1], a1); a1 = fmaf(xv.z, w1[4 * k4 + 2], a1); a1 = fmaf(xv.w, w1[4 * k4 + 3], a1);
         }
+        const size_t pr = pos != nullptr ? (size_t)(row / rpg) * period + (row % rpg) % period : 0;
+        if (ok0) out[(size_t)row * C + c0] = (pos != nullptr ? pos[pr * C + c0] : 0.f) + (a0 + b0);
+        if (ok1) out[(size_t)row * C + c1] = (pos != nullptr ? pos[pr * C + c1] : 0.f) + (a1 + b1);
     }
 }
 
 // FinalLayer in fp32 straight from the stream: out[row] = W (LayerNorm(x[row]) * (1 + scale[g]) + shift[g]) + b.  One wave per row (C <= 512, a
-// multiple of 4: up to two float4 per lane), Cout <= 32 output columns, W [Cout][C] in LDS.
+// multiple of 4: up to two float4 per lane), NP = 16 or 32 output columns (W rows beyond Cout are zero in LDS: no branches in the row loop).
+template <int NP>
 __global__ __launch_bounds__(256) void final_layer_f32_kernel(const float* __restrict__ x, int M, int C, float eps, const float* __restrict__ shift,
                                                               const float* __restrict__ scale, int mod_ld, int rpg, const float* __restrict__ W,
                                                               const float* __restrict__ bias, int Cout, float* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) float sW[32 * 512];
+    extern __shared__ __attribute__((aligned(16))) float sW[];        // NP * C floats (32 KiB at 16 x 512: 4-5 workgroups per CU)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < Cout * C; i += 256) sW[i] = W[i];
+    {   // W -> LDS, all of a thread's loads in flight together (one element per trip is a chain of memory latencies)
+        const int n4 = Cout * C / 4, n4p = NP * C / 4;
+        const float4* W4 = reinterpret_cast<const float4*>(W);
+        float4* s4 = reinterpret_cast<float4*>(sW);
+        for (int base = 0; base < n4p; base += 256 * 8) {
+            float4 tmp[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = base + u * 256 + tid; tmp[u] = i < n4 ? W4[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = base + u * 256 + tid; if (i < n4p) s4[i] = tmp[u]; }
+        }
+    }
     __syncthreads();
-    const bool ok[2] = {lane * 4 < C, (64 + lane) * 4 < C};
+    const bool ok0 = lane * 4 < C, ok1 = (64 + lane) * 4 < C;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
-        const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * C);
-        float4 v[2] = {ok[0] ? xr[lane] : z4, ok[1] ? xr[64 + lane] : z4};
-        const float sum = (v[0].x + v[0].y) + (v[0].z + v[0].w) + (v[1].x + v[1].y) + (v[1].z + v[1].w);
-        const float mean = wave_sum(sum) / (float)C;
-        float q = 0.f;
+    const int stride = gridDim.x * 4;
+    const float4* sW4 = reinterpret_cast<const float4*>(sW);
+    const int i0 = ok0 ? lane : 0, i1 = ok1 ? 64 + lane : 0;           // LDS / global chunk indices (a masked chunk reads chunk 0 and is zeroed)
+    float4 nxt0 = z4, nxt1 = z4;
+    {
+        const int row = blockIdx.x * 4 + wave;
+        if (row < M) { const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * C); nxt0 = xr[i0]; nxt1 = xr[i1]; }
+    }
+    for (int row = blockIdx.x * 4 + wave; row < M; row += stride) {
+        float4 v0 = ok0 ? nxt0 : z4, v1 = ok1 ? nxt1 : z4;
+        if (row + stride < M) {                              // the next row of this wave is requested before this one is reduced
+            const float4* xn = reinterpret_cast<const float4*>(x + (size_t)(row + stride) * C);
+            nxt0 = xn[i0]; nxt1 = xn[i1];
+        }
+        const float mean = wave_sum((v0.x + v0.y) + (v0.z + v0.w) + (v1.x + v1.y) + (v1.z + v1.w)) / (float)C;
+        if (ok0) { v0.x -= mean; v0.y -= mean; v0.z -= mean; v0.w -= mean; }
+        if (ok1) { v1.x -= mean; v1.y -= mean; v1.z -= mean; v1.w -= mean; }
+        const float rstd = rsqrtf(wave_sum((v0.x * v0.x + v0.y * v0.y) + (v0.z * v0.z + v0.w * v0.w) + (v1.x * v1.x + v1.y * v1.y) + (v1.z * v1.z + v1.w * v1.w)) / (float)C + eps);
+        float4 sc0 = z4, sh0 = z4, sc1 = z4, sh1 = z4;
+        if (scale != nullptr) {
+            const size_t mo = (size_t)(rpg > 0 ? row / rpg : 0) * mod_ld;
+            sc0 = *reinterpret_cast<const float4*>(scale + mo + i0 * 4); sh0 = *reinterpret_cast<const float4*>(shift + mo + i0 * 4);
+            sc1 = *reinterpret_cast<const float4*>(scale + mo + i1 * 4); sh1 = *reinterpret_cast<const float4*>(shift + mo + i1 * 4);
+        }
+        float y[8] = {v0.x * rstd * (1.0f + sc0.x) + sh0.x, v0.y * rstd * (1.0f + sc0.y) + sh0.y, v0.z * rstd * (1.0f + sc0.z) + sh0.z, v0.w * rstd * (1.0f + sc0.w) + sh0.w,
+                      v1.x * rstd * (1.0f + sc1.x) + sh1.x, v1.y * rstd * (1.0f + sc1.y) + sh1.y, v1.z * rstd * (1.0f + sc1.z) + sh1.z, v1.w * rstd * (1.0f + sc1.w) + sh1.w};
+        if (!ok0) { y[0] = y[1] = y[2] = y[3] = 0.f; }
+        if (!ok1) { y[4] = y[5] = y[6] = y[7] = 0.f; }
+        // NP dot products: per-lane partials, then ONE butterfly over all of them: after step d a lane keeps the half of the remaining
+        // outputs selected by its bit d, so the partials shrink NP -> NP/2 -> ... -> 1 while the lanes fold: lane l ends with the complete
+        // sum of output (l & (NP - 1)) -- NP - 1 exchanges per lane instead of 6 per output
+        float part[NP];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (ok[i]) {
-                v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
-                q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+        for (int o = 0; o < NP; ++o) {
+            const float4 w0 = sW4[o * (C / 4) + i0], w1 = sW4[o * (C / 4) + i1];
+            part[o] = (y[0] * w0.x + y[1] * w0.y) + (y[2] * w0.z + y[3] * w0.w) + (y[4] * w1.x + y[5] * w1.y) + (y[6] * w1.z + y[7] * w1.w);
+        }
+        constexpr int STEPS = NP == 32 ? 5 : 4;
+#pragma unroll
+        for (int d = 0; d < STEPS; ++d) {
+            const bool up = (lane >> d) & 1;
+#pragma unroll
+            for (int i = 0; i < (NP >> (d + 1)); ++i) {
+                const float keep = up ? part[2 * i + 1] : part[2 * i], give = up ? part[2 * i] : part[2 * i + 1];
+                part[i] = keep + __shfl_xor(give, 1 << d, 64);
             }
         }
-        const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
-        const int g = rpg > 0 ? row / rpg : 0;
-        float y[8];
+        float tot = part[0];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int c0 = (lane + 64 * i) * 4;
-            float4 sc = z4, sh = z4;
-            if (scale != nullptr && ok[i]) {
-                sc = *reinterpret_cast<const float4*>(scale + (size_t)g * mod_ld + c0);
-                sh = *reinterpret_cast<const float4*>(shift + (size_t)g * mod_ld + c0);
-            }
-            y[4 * i + 0] = ok[i] ? v[i].x * rstd * (1.0f + sc.x) + sh.x : 0.f; y[4 * i + 1] = ok[i] ? v[i].y * rstd * (1.0f + sc.y) + sh.y : 0.f;
-            y[4 * i + 2] = ok[i] ? v[i].z * rstd * (1.0f + sc.z) + sh.z : 0.f; y[4 * i + 3] = ok[i] ? v[i].w * rstd * (1.0f + sc.w) + sh.w : 0.f;
-        }
-        for (int o = 0; o < Cout; ++o) {
-            const float4 w0 = ok[0] ? *reinterpret_cast<const float4*>(sW + o * C + lane * 4) : z4;
-            const float4 w1 = ok[1] ? *reinterpret_cast<const float4*>(sW + o * C + (64 + lane) * 4) : z4;
-            float acc = (y[0] * w0.x + y[1] * w0.y) + (y[2] * w0.z + y[3] * w0.w) + (y[4] * w1.x + y[5] * w1.y) + (y[6] * w1.z + y[7] * w1.w);
-            acc = wave_sum(acc);
-            if (lane == 0) out[(size_t)row * Cout + o] = acc + (bias ? bias[o] : 0.f);
-        }
+        for (int d = STEPS; d < 6; ++d) tot += __shfl_xor(tot, 1 << d, 64);
+        const int o = lane & (NP - 1);
+        if (lane < NP && o < Cout) out[(size_t)row * Cout + o] = tot + (bias ? bias[o] : 0.f);
     }
 }
 
@@ -432,7 +471,7 @@ extern "C" int gvf_dit_timestep_embed_f32(const float* t, int B, int freq_dim, f
     if (B == 0) return GVF_OK;
     if (!t || !w0 || !w2 || !out_silu || (((uintptr_t)w0) & 15) || (((uintptr_t)w2) & 15)) return GVF_EINVAL;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(timestep_embed_f32_kernel, dim3(B, 16), dim3(1024), 0, (hipStream_t)stream_, t, freq_dim, (float)(-log((double)max_period)), w0, b0, w2, b2,
+    hipLaunchKernelGGL(timestep_embed_f32_kernel, dim3(B, 32), dim3(1024), 0, (hipStream_t)stream_, t, freq_dim, (float)(-log((double)max_period)), w0, b0, w2, b2,
                        C, out_silu, t_emb);
     GVF_CHECK_LAUNCH();
     return GVF_OK;
@@ -457,7 +496,7 @@ extern "C" int gvf_dit_input_layer_f32(const float* x, int M, int Cin, const flo
     if (!x || !w || !out) return GVF_EINVAL;
     if (pos != nullptr && (pos_period <= 0 || rows_per_group <= 0 || rows_per_group % pos_period != 0)) return GVF_EINVAL;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(input_layer_f32_kernel, dim3((M + 15) / 16), dim3(256), 0, (hipStream_t)stream_, x, M, Cin, w, bias, pos, pos_period,
+    hipLaunchKernelGGL(input_layer_f32_kernel, dim3((M + IN_ROWS - 1) / IN_ROWS), dim3(256), 0, (hipStream_t)stream_, x, M, Cin, w, bias, pos, pos_period,
                        rows_per_group > 0 ? rows_per_group : 1, C, out);
     GVF_CHECK_LAUNCH();
     return GVF_OK;
@@ -467,13 +506,17 @@ extern "C" int gvf_dit_final_layer_f32(const float* x, int M, int C, float eps, 
                                        const float* w, const float* bias, int Cout, float* out, void* stream_) {
     if (M < 0 || C <= 0 || C > 512 || (C & 3) || Cout <= 0 || Cout > 32) return GVF_EINVAL;
     if (M == 0) return GVF_OK;
-    if (!x || !w || !out || ((shift == nullptr) != (scale == nullptr)) || (((uintptr_t)x) & 15)) return GVF_EINVAL;
+    if (!x || !w || !out || ((shift == nullptr) != (scale == nullptr)) || (((uintptr_t)x) & 15) || (((uintptr_t)w) & 15)) return GVF_EINVAL;
     if (scale != nullptr && (rows_per_group <= 0 || (mod_ld & 3) || (((uintptr_t)scale) & 15) || (((uintptr_t)shift) & 15))) return GVF_EINVAL;
     (void)hipGetLastError();
     int blocks = (M + 3) / 4;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(final_layer_f32_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, x, M, C, eps, shift, scale, mod_ld, rows_per_group, w, bias, Cout,
-                       out);
+    if (blocks > 1024) blocks = 1024;                  // each workgroup copies W into LDS once: 4 resident workgroups per CU, 3 rows per wave
+    if (Cout <= 16)
+        hipLaunchKernelGGL(final_layer_f32_kernel<16>, dim3(blocks), dim3(256), (size_t)16 * C * sizeof(float), (hipStream_t)stream_, x, M, C, eps, shift, scale,
+                           mod_ld, rows_per_group, w, bias, Cout, out);
+    else
+        hipLaunchKernelGGL(final_layer_f32_kernel<32>, dim3(blocks), dim3(256), (size_t)32 * C * sizeof(float), (hipStream_t)stream_, x, M, C, eps, shift, scale,
+                           mod_ld, rows_per_group, w, bias, Cout, out);
     GVF_CHECK_LAUNCH();
     return GVF_OK;
 }

@@ -69,6 +69,7 @@ struct RbParams {
     const uint4* W; const float* b1;             // the packed weight stream: W1 [K1/32 steps] | MLP [2 * 16 * hidden/512] | W3 [16 * N3/512]; bias [512] or null
     float* x; int M;                             // fp32 stream [M][512], updated in place
     const float* x_in; int x_in_period;          // optional: the residual is read from x_in[(row / rpg) * period + (row % rpg) % period] instead
+    const float* in_x; const float* in_wt; const float* in_b; int in_cin;     // optional (K1 == 0): + in_x[row] W_in^T + b in fp32 (input_layer)
     const float* gate1;                          // row g of leading dimension mod_ld, or null (-> 1)
     RbLn ln1;
     int mod_ld, rpg; float eps;
@@ -355,6 +356,18 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
             sPar[8 * RB_C + RB_MAX_HIDDEN + tid + RB_THREADS * j] = (p.b3 && tid + RB_THREADS * j < P3 * RB_C) ? vb3[j] : 0.f;
         if (p.kt != nullptr) sPar[8 * RB_C + RB_MAX_HIDDEN + RB_MAX_N3 + tid] = p.gamma_k ? p.gamma_k[tid] : 1.0f;
     }
+    if (p.in_x != nullptr) {
+        // input_layer in fp32 on the plain ALUs (16 input channels: 0.4 MFLOP per workgroup): W_in^T [Cin][512] and the block's 48 input rows
+        // go to R1 (free: there is no phase-1 operand)
+        float* sWt = reinterpret_cast<float*>(R1);
+        float* sXin = sWt + 16 * RB_C;
+        for (int i = tid; i < p.in_cin * RB_C / 4; i += RB_THREADS)
+            reinterpret_cast<f32x4*>(sWt)[i] = reinterpret_cast<const f32x4*>(p.in_wt)[i];
+        for (int i = tid; i < RB_BM * 16; i += RB_THREADS) {
+            const int r = i >> 4, k = i & 15;
+            sXin[i] = k < p.in_cin ? p.in_x[(long long)(m0 + r) * p.in_cin + k] : 0.f;
+        }
+    }
     f32x4 acc[3][RB_CT];
     rb_zero(acc);
     // pin the residual tile here: left alone, the compiler sinks these loads to their first use -- the epilogue, after the k-loop.
@@ -367,6 +380,32 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
     __syncthreads();                             // activations landed (own DMA drained before the barrier), parameters visible
     RB_STAMP();
 
+    if (p.in_x != nullptr) {                     // rs (= position embedding or x) += b_in + in_x W_in^T, column by column in fp32
+        const float* sWt = reinterpret_cast<const float*>(R1);
+        const float* sXin = sWt + 16 * RB_C;
+#pragma unroll
+        for (int ct = 0; ct < RB_CT; ++ct) {
+            if (p.in_b != nullptr) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.in_b + colw + 16 * ct);
+#pragma unroll
+                for (int rt = 0; rt < 3; ++rt) rs[rt][ct] += b4;
+            }
+        }
+        for (int k4 = 0; k4 < p.in_cin; k4 += 4) {
+            f32x4 xv[3];
+#pragma unroll
+            for (int rt = 0; rt < 3; ++rt) xv[rt] = *reinterpret_cast<const f32x4*>(sXin + (16 * rt + l15) * 16 + k4);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                for (int ct = 0; ct < RB_CT; ++ct) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(sWt + (k4 + kk) * RB_C + colw + 16 * ct);
+#pragma unroll
+                    for (int rt = 0; rt < 3; ++rt) rs[rt][ct] += xv[rt][kk] * w4;
+                }
+            }
+        }
+    }
     // ---- phase 1: x = x + gate1 * (A W1^T + b1), LayerNorm ln1 -> R0
     int g = 0;
     rb_gemm<D>(acc, wf, R1 + lane, G1, g, st);
@@ -580,7 +619,7 @@ static long long* g_rb_dbg = nullptr;        // RB_TIMING builds of scripts/uben
 
 // sizeof / field offsets of the argument struct, for bindings to check their own layout against (tests/test_capi_symbols.py)
 extern "C" int gvf_rowblock_args_layout(int32_t* out, int n) {
-    const int v[] = {(int)sizeof(gvf_rowblock_args), (int)offsetof(gvf_rowblock_args, x), (int)offsetof(gvf_rowblock_args, gate1),
+    const int v[] = {(int)sizeof(gvf_rowblock_args), (int)offsetof(gvf_rowblock_args, x), (int)offsetof(gvf_rowblock_args, in_x), (int)offsetof(gvf_rowblock_args, gate1),
                      (int)offsetof(gvf_rowblock_args, mod_ld), (int)offsetof(gvf_rowblock_args, b_fc1), (int)offsetof(gvf_rowblock_args, ln2),
                      (int)offsetof(gvf_rowblock_args, b3), (int)offsetof(gvf_rowblock_args, hb_out), (int)offsetof(gvf_rowblock_args, k_tiles),
                      (int)offsetof(gvf_rowblock_args, gamma_k)};
@@ -626,6 +665,9 @@ extern "C" int gvf_rowblock_fused_bf16(const gvf_rowblock_args* a, void* stream_
     if (a->M == 0) return GVF_OK;
     if ((a->K1 > 0 && !a->a) || !a->w || !a->x) return GVF_EINVAL;
     if (a->K1 == 0 && (a->gate1 != nullptr || a->b1 != nullptr)) return GVF_EINVAL;
+    if (a->in_x != nullptr && (a->K1 != 0 || !a->in_wt || a->in_cin <= 0 || a->in_cin > 16 || (a->in_cin & 3) || (((uintptr_t)a->in_wt) & 15) ||
+                               (((uintptr_t)a->in_b) & 15)))
+        return GVF_EINVAL;
     if (a->x_in != nullptr && (a->x_in_period <= 0 || a->rows_per_group <= 0 || a->rows_per_group % a->x_in_period != 0 || (((uintptr_t)a->x_in) & 15)))
         return GVF_EINVAL;
     const gvf_rowblock_ln* lns[2] = {&a->ln1, &a->ln2};
@@ -653,6 +695,7 @@ extern "C" int gvf_rowblock_fused_bf16(const gvf_rowblock_args* a, void* stream_
     p.W = (const uint4*)a->w; p.b1 = a->b1;
     p.x = a->x; p.M = a->M;
     p.x_in = a->x_in; p.x_in_period = a->x_in_period;
+    p.in_x = a->in_x; p.in_wt = a->in_wt; p.in_b = a->in_b; p.in_cin = a->in_cin;
     p.gate1 = a->gate1;
     p.ln1 = RbLn{a->ln1.ln_w, a->ln1.ln_b, a->ln1.shift, a->ln1.scale};
     p.mod_ld = a->mod_ld; p.rpg = (grouped || a->x_in != nullptr) ? a->rows_per_group : 0; p.eps = a->eps;

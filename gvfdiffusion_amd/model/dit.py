@@ -230,6 +230,7 @@ class DiT(nn.Module):
         W = {"ver": ver}
         # the small projections (0.3 % of the FLOPs, a third of the bf16 error: csrc/elem.hip) stay in fp32
         W["input_f32"], W["final_f32"] = prep32(self.input_layer), prep32(self.final_layer.linear)
+        W["input_f32"] = (W["input_f32"][0].t().contiguous(), W["input_f32"][1])          # (Cin, C): the kernel copies it straight into LDS
         W["t0_f32"], W["t2_f32"] = prep32(self.t_embedder.mlp[0]), prep32(self.t_embedder.mlp[2])
         W["img_f32"], W["static_f32"] = prep32(self.image_cond_proj), prep32(self.static_cond_proj)
         W["input"] = prep(self.input_layer)
@@ -443,16 +444,17 @@ class DiT(nn.Module):
         # residual stream h (fp32) = position embedding broadcast over T + input_layer(x), in fp32 (csrc/elem.hip)
         small_f32 = C <= 512 and C % 4 == 0 and Cin <= 24 and self.out_channels <= 32
         h = torch.empty((M, C), dtype=f32, device=dev)
+        x2d = x.reshape(M, Cin).float().contiguous()
+        pos = None if ctx["pos"] is None else ctx["pos"].reshape(B * N, C)
+        if self.use_rowblock and small_f32 and Cin % 4 == 0 and Cin <= 16 and dit_ops.rowblock_supported(C, T * N, int(C * self.mlp_ratio)):
+            y = self._blocks_rowblock(x2d, h, mod, mod_ld, W, ctx, B, T, N, pos)          # its first launch also does input_layer
+            return y.to(x.dtype if x.dtype.is_floating_point else f32)
         if small_f32:
-            pos = ctx["pos"]
-            dit_ops.input_layer_f32(x.reshape(M, Cin).float().contiguous(), W["input_f32"][0], W["input_f32"][1], h,
-                                    pos=None if pos is None else pos.reshape(B * N, C), pos_period=N, rows_per_group=T * N)
+            dit_ops.input_layer_f32(x2d, W["input_f32"][0], W["input_f32"][1], h, pos=pos, pos_period=N, rows_per_group=T * N)
         elif ctx["pos"] is not None:
             h.copy_(ctx["pos"][:, None].expand(B, T, N, C).reshape(M, C))
         else:
             h.zero_()
-        if self.use_rowblock and small_f32 and dit_ops.rowblock_supported(C, T * N, int(C * self.mlp_ratio)):
-            return self._blocks_rowblock(x, h, mod, mod_ld, W, ctx, B, T, N)
         xb = None if small_f32 else dit_ops.cast_pad_bf16(x.reshape(M, Cin).float().contiguous(), dit_ops.pad64(Cin))
         hb = torch.empty((M, C), dtype=bf, device=dev)          # attention-output scratch of the cross attentions
         qkv = torch.empty((M, 3 * C), dtype=bf, device=dev)
@@ -533,14 +535,14 @@ class DiT(nn.Module):
             ln_gemm(W["final"], y, dit_ops.EPI_STORE_F32, shift=mview(o), scale=mview(o + C))
         return y.reshape(B, T, N, self.out_channels).to(x.dtype if x.dtype.is_floating_point else f32)
 
-    def _blocks_rowblock(self, x, h, mod, mod_ld, W, ctx, B, T, N):
+    def _blocks_rowblock(self, x2d, h, mod, mod_ld, W, ctx, B, T, N, pos):
         """The blocks with one launch per sub-layer boundary (csrc/rowblock.hip): per block  spatial attention | to_out + adaLN +
         to_qkv | temporal attention | to_out + norm3 + to_q | image attention | to_out + norm4 + to_q | static attention | to_out +
         adaLN + MLP + adaLN + the NEXT block's to_qkv (q row-major, K / V^T as the attention's tile images) -- 8 launches instead of 20, the fp32 stream through HBM 5 times instead of 15,
         the normalised rows and the MLP's hidden units never.  Same rounding points as the unfused path (and as oracle/dit_ref.py)."""
         C, H = self.model_channels, self.num_heads
         M, TN = B * T * N, T * N
-        dev = x.device
+        dev = x2d.device
         bf, f32 = torch.bfloat16, torch.float32
         rb = self._rowblock_streams(W)
         Li, Ls = ctx["Li"], ctx["Ls"]
@@ -573,8 +575,11 @@ class DiT(nn.Module):
                 return dict(out3=qs, b3=a_["qkv"][1], kv_tiles=kv_self, kv_L=N, gamma_k=a_["gk"])
             return dict(out3=qkv, b3=a_["qkv"][1])
 
-        # h already holds pos + input_layer(x): adaLN of block 0 and its to_qkv
-        fused(None, rb["in"], ln1=dict(shift=mview(o), scale=mview(o + C)), **qkv_out(blocks[0]))
+        # h = pos (broadcast over the frames) + input_layer(x) in fp32, adaLN of block 0 and its to_qkv: one launch
+        if pos is None:
+            h.zero_()
+        fused(None, rb["in"], ln1=dict(shift=mview(o), scale=mview(o + C)), in_x=x2d, in_wt=W["input_f32"][0], in_b=W["input_f32"][1],
+              x_in=pos, x_in_period=N, **qkv_out(blocks[0]))
         for i, b in enumerate(blocks):
             o, s = offs[i], rb["blocks"][i]
             g_s, sh_m, sc_m, g_m = mview(o + 2 * C), mview(o + 3 * C), mview(o + 4 * C), mview(o + 5 * C)
@@ -611,4 +616,4 @@ class DiT(nn.Module):
         on = offs[-1]
         y = torch.empty((M, self.out_channels), dtype=f32, device=dev)
         dit_ops.final_layer_f32(h, W["final_f32"][0], W["final_f32"][1], y, shift=mview(on), scale=mview(on + C), mod_ld=mod_ld, rows_per_group=TN)
-        return y.reshape(B, T, N, self.out_channels).to(x.dtype if x.dtype.is_floating_point else f32)
+        return y.reshape(B, T, N, self.out_channels)

@@ -21,6 +21,7 @@ class RowblockArgs(ctypes.Structure):
     _fields_ = [("a", _vp), ("lda", ctypes.c_int32), ("K1", ctypes.c_int32), ("w", _vp), ("b1", _vp),
                 ("x", _vp), ("M", ctypes.c_int32), ("C", ctypes.c_int32),
                 ("x_in", _vp), ("x_in_period", ctypes.c_int32),
+                ("in_x", _vp), ("in_wt", _vp), ("in_b", _vp), ("in_cin", ctypes.c_int32),
                 ("gate1", _vp), ("ln1", RowblockLn),
                 ("mod_ld", ctypes.c_int32), ("rows_per_group", ctypes.c_int32), ("eps", _f),
                 ("b_fc1", _vp), ("b_fc2", _vp), ("hidden", ctypes.c_int32), ("gate_m", _vp), ("ln2", RowblockLn),
@@ -157,10 +158,12 @@ def modulation_f32(s, w, bias, out=None):
     return out
 
 
-def input_layer_f32(x, w, bias, out, pos=None, pos_period=0, rows_per_group=0):
-    """out (M, 512) = pos (broadcast) + x (M, Cin) @ w (512, Cin)^T + bias, fp32."""
+def input_layer_f32(x, w_t, bias, out, pos=None, pos_period=0, rows_per_group=0):
+    """out (M, C) = pos (broadcast) + x (M, Cin) @ w_t (Cin, C) + bias, fp32; w_t = the nn.Linear weight transposed."""
+    w = w_t
     _lib.require_cuda(x, w, out)
     assert x.dtype == w.dtype == out.dtype == torch.float32 and x.is_contiguous() and w.is_contiguous() and out.is_contiguous()
+    assert tuple(w.shape) == (x.shape[1], out.shape[1])
     _lib.check(_lib.lib().gvf_dit_input_layer_f32(_p(x), x.shape[0], x.shape[1], _p(w), _p(bias), _p(pos), int(pos_period), int(rows_per_group),
                                                   out.shape[1], _p(out), _stream(x)), "gvf_dit_input_layer_f32")
     return out
@@ -220,7 +223,7 @@ def _ln_struct(ln):
 
 
 def rowblock_fused(a, stream_w, x, b1=None, gate1=None, ln1=None, mod_ld=0, rows_per_group=0, eps=1e-6,
-                   mlp_bias=None, hidden=0, gate_m=None, ln2=None, b3=None, out3=None, hb_out=None, x_in=None, x_in_period=0, kv_tiles=None, kv_L=0, gamma_k=None, kv_scale=None):
+                   mlp_bias=None, hidden=0, gate_m=None, ln2=None, b3=None, out3=None, hb_out=None, x_in=None, x_in_period=0, kv_tiles=None, kv_L=0, gamma_k=None, kv_scale=None, in_x=None, in_wt=None, in_b=None):
     """x += gate1 * (a W1^T + b1); hb = LN1(x); [x += gate_m * MLP(hb); hb = LN2(x)]; out3 = hb W3^T + b3 or hb_out = hb -- ONE launch
     (csrc/rowblock.hip; include/gvf_dit.h).  ln1 / ln2: dict with ln_w, ln_b and / or shift, scale.  mlp_bias = (b_fc1, b_fc2).
     a = None: no closing projection (x already holds the sub-layer's result; the stream has no W1 segment).
@@ -238,6 +241,10 @@ def rowblock_fused(a, stream_w, x, b1=None, gate1=None, ln1=None, mod_ld=0, rows
     if x_in is not None:
         assert x_in.dtype == torch.float32 and x_in.is_contiguous() and x_in.shape[-1] == C
         args.x_in, args.x_in_period = _pi(x_in), int(x_in_period)
+    if in_x is not None:            # input_layer in fp32 inside the launch (a must be None)
+        assert a is None and in_x.dtype == in_wt.dtype == torch.float32 and in_x.is_contiguous() and in_wt.is_contiguous()
+        assert in_x.shape[0] == M and tuple(in_wt.shape) == (in_x.shape[1], C)
+        args.in_x, args.in_wt, args.in_b, args.in_cin = _pi(in_x), _pi(in_wt), _pi(in_b), in_x.shape[1]
     args.gate1, args.ln1 = _pi(gate1), _ln_struct(ln1)
     args.mod_ld, args.rows_per_group, args.eps = int(mod_ld), int(rows_per_group), float(eps)
     if hidden:

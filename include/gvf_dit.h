@@ -81,6 +81,9 @@ typedef struct gvf_rowblock_args {
     float* x; int32_t M; int32_t C;
     const float* x_in; int32_t x_in_period;    /* optional: residual read from x_in[(row / rows_per_group) * period + (row % rows_per_group) % period]
                                                    (f32 [groups * period][512]) instead of x: input_layer on top of the position embedding */
+    /* optional, K1 == 0: x (or x_in) += in_x[row] w_in^T + in_b in fp32 before the LayerNorm -- input_layer (model/dit.py:455-460);
+       in_x f32 [M][in_cin], in_wt = the weight TRANSPOSED f32 [in_cin][512], in_cin a multiple of 4, <= 16 */
+    const float* in_x; const float* in_wt; const float* in_b; int32_t in_cin;
     const float* gate1; gvf_rowblock_ln ln1;
     int32_t mod_ld; int32_t rows_per_group; float eps;
     const float* b_fc1; const float* b_fc2; int32_t hidden; const float* gate_m; gvf_rowblock_ln ln2;
@@ -91,7 +94,7 @@ typedef struct gvf_rowblock_args {
        projection, which is then never written.  Key sets = runs of kv_L rows (kv_L a multiple of 64, M a multiple of kv_L). */
     void* k_tiles; void* v_tiles; int32_t kv_L; float k_scale; const float* gamma_k;
 } gvf_rowblock_args;
-/* layout of gvf_rowblock_args as compiled: {sizeof, offsetof x, gate1, mod_ld, b_fc1, ln2, b3, hb_out, k_tiles, gamma_k}; returns the count */
+/* layout of gvf_rowblock_args as compiled: {sizeof, offsetof x, in_x, gate1, mod_ld, b_fc1, ln2, b3, hb_out, k_tiles, gamma_k}; returns the count */
 int gvf_rowblock_args_layout(int32_t* out, int n);
 int64_t gvf_rowblock_packed_bytes(int N, int K);
 int gvf_rowblock_pack_weight(const void* w_bf16, int ldw, int N, int K, void* packed, void* stream);
@@ -165,14 +168,15 @@ int gvf_cast_pad_bf16(const float* src, int ld_src, void* dst, int ld_dst, int64
  * through the bf16 matrix pipe:
  *   gvf_dit_timestep_embed_f32: out_silu[b] = silu(W2 silu(W0 [cos | sin](t_b f) + b0) + b2), f32 [B][C]   (model/dit.py:59-100, 217-225)
  *   gvf_dit_modulation_f32:     out[b][n] = w[n] . s[b] + bias[n]: every block's adaLN vectors in one GEMV   (model/dit.py:217-225, 298-303)
- *   gvf_dit_input_layer_f32:    out[row] = pos[(row / rows_per_group) * pos_period + (row % rows_per_group) % pos_period] + w x[row] + bias
+ *   gvf_dit_input_layer_f32:    out[row] = pos[(row / rows_per_group) * pos_period + (row % rows_per_group) % pos_period] + w_t^T x[row] + bias
+ *                               (w_t = the weight TRANSPOSED, f32 [Cin][C])
  *                               (model/dit.py:455-460: input_layer(x) + the position embedding broadcast over the frames; pos may be NULL)
  *   gvf_dit_final_layer_f32:    out[row] = w (LayerNorm(x[row]) * (1 + scale[g]) + shift[g]) + bias              (model/dit.py:298-303)
  * Weights are the nn.Linear fp32 weights as stored ([out][in], contiguous).  C <= 512 (a multiple of 4) for the last two; Cin <= 24; Cout <= 32. */
 int gvf_dit_timestep_embed_f32(const float* t, int B, int freq_dim, float max_period, const float* w0, const float* b0, const float* w2,
                                const float* b2, int C, float* out_silu, float* t_emb, void* stream);
 int gvf_dit_modulation_f32(const float* s, int B, int C, const float* w, const float* bias, int N, float* out, void* stream);
-int gvf_dit_input_layer_f32(const float* x, int M, int Cin, const float* w, const float* bias, const float* pos, int pos_period,
+int gvf_dit_input_layer_f32(const float* x, int M, int Cin, const float* w_t, const float* bias, const float* pos, int pos_period,
                             int rows_per_group, int C, float* out, void* stream);
 int gvf_dit_final_layer_f32(const float* x, int M, int C, float eps, const float* shift, const float* scale, int mod_ld, int rows_per_group,
                             const float* w, const float* bias, int Cout, float* out, void* stream);

@@ -233,11 +233,11 @@ def test_small_projections_in_fp32_match_torch(cuda, C, Cin, Cout, B, T, N):
     # input layer on the broadcast position embedding
     x, wi, bi, pos = rn(M, Cin), rn(C, Cin, sc=0.3), rn(C, sc=0.1), rn(B * N, C)
     h = torch.full((M, C), float("nan"), device=cuda)
-    dit_ops.input_layer_f32(x, wi, bi, h, pos=pos, pos_period=N, rows_per_group=TN)
+    dit_ops.input_layer_f32(x, wi.t().contiguous(), bi, h, pos=pos, pos_period=N, rows_per_group=TN)
     h_ref = Fnn.linear(x, wi, bi).reshape(B, T, N, C) + pos.reshape(B, 1, N, C)
     assert rel_l2(h, h_ref.reshape(M, C)) < 2e-6
     h2 = torch.empty((M, C), device=cuda)
-    dit_ops.input_layer_f32(x, wi, None, h2)
+    dit_ops.input_layer_f32(x, wi.t().contiguous(), None, h2)
     assert rel_l2(h2, Fnn.linear(x, wi)) < 2e-6
     # final layer from the stream
     wf, bfin = rn(Cout, C, sc=1 / math.sqrt(C)), rn(Cout, sc=0.1)
