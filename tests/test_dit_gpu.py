@@ -31,7 +31,8 @@ TOL_DIT_VS_BF16_ORACLE = 6e-3   # full denoiser vs oracle with the same rounding
 #   at the full config / 2.7e-4 at the small one.  Single kernels agree with the oracle to 1e-5 .. 2e-4 (tests above); what is
 #   left after 12 blocks is decorrelated rounding noise (a probability or an activation that rounds the other way), not bias.
 TOL_DIT_VS_FP32_REF = 3e-2      # loose sanity bound vs the fp32 reference output (golden); the REAL bar is REF_AUTOCAST_SLACK:
-REF_AUTOCAST_SLACK = 1.1        # err(HIP vs fp32 golden) <= 1.1 x err(the reference's own bf16 autocast run vs fp32 golden),
+REF_AUTOCAST_SLACK = 0.6        # err(HIP vs fp32 golden) <= 0.6 x err(the reference's own bf16 autocast run vs fp32 golden)
+#   (measured 0.47 x at the full config, 0.06 x at the small one, with the small projections in fp32),
 #   tests/golden/dit_autocast_golden.npz (tests/golden/make_golden.py::gen_dit_autocast, model/dit.py under torch.autocast)
 
 

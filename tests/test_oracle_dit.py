@@ -47,12 +47,22 @@ def test_small_model_forward_matches_reference():
         yb = dit_ref.dit_forward(sd, cfg, *args, precision="bf16")
     rel = float((yb - y).norm() / y.norm())
     assert rel < 3e-2, rel
-    # ... and is not less accurate than the reference's OWN bf16 autocast run of model/dit.py on the same inputs
-    # (tests/golden/dit_autocast_golden.npz, make_golden.py::gen_dit_autocast): the rounding model is not optimistic either
+    # ... and is more accurate than the reference's OWN bf16 autocast run of model/dit.py on the same inputs
+    # (tests/golden/dit_autocast_golden.npz, make_golden.py::gen_dit_autocast).  With the small projections in fp32 (dit_ref.FP32_SITES,
+    # the HIP pipeline's placement) this two-block model loses almost all of its bf16 error: 2.4e-4 against the reference's 4.2e-3, and
+    # less than the reference's fp16 autocast (5.2e-4); with every site in bf16 the same oracle gives 3.1e-3 (not optimistic either)
     ac = np.load(os.path.join(GOLD, "dit_autocast_golden.npz"))
-    ref_bf16 = float(ac["small_rel_l2_bf16"])
+    ref_bf16, ref_fp16 = float(ac["small_rel_l2_bf16"]), float(ac["small_rel_l2_fp16"])
     assert abs(float((torch.from_numpy(ac["small_y_bf16"]) - torch.from_numpy(g["y"])).norm() / torch.from_numpy(g["y"]).norm()) - ref_bf16) < 1e-6
-    assert 0.3 * ref_bf16 < rel <= 1.1 * ref_bf16, (rel, ref_bf16)
+    assert 0.02 * ref_bf16 < rel <= ref_fp16, (rel, ref_bf16, ref_fp16)
+    saved = dit_ref.FP32_SITES
+    try:
+        dit_ref.FP32_SITES = ()
+        with torch.no_grad():
+            rel_all = float((dit_ref.dit_forward(sd, cfg, *args, precision="bf16") - y).norm() / y.norm())
+    finally:
+        dit_ref.FP32_SITES = saved
+    assert 0.3 * ref_bf16 < rel_all <= 1.1 * ref_bf16, (rel_all, ref_bf16)
 
 
 def test_small_model_without_temporal_attention_matches_reference():
