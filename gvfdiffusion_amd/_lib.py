@@ -61,6 +61,7 @@ SIGNATURES = {
     "gvf_rast_profile_read": (_i, [ctypes.POINTER(_f), ctypes.POINTER(_i)]),
     "gvf_sort_tmp_bytes": (_sz, [_i64]),
     "gvf_sort_pairs_u64": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _vp, _sz, _vp]),
+    "gvf_tile_sort_u64": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
 }
 
 _LIB = None

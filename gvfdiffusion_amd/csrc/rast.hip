@@ -869,6 +869,9 @@ __global__ __launch_bounds__(256) void ranges_kernel(const uint64_t* __restrict_
 // workgroup whose segment is not in its class exits at once.
 // ---------------------------------------------------------------------------------------------
 constexpr int SORT_SMALL_N = 2048;
+#ifndef SORT_BUCKETS
+#define SORT_BUCKETS 1            // 0: every small segment through the sorting network (the round-1 path)
+#endif
 constexpr int SORT_LARGE_N = 16384;
 
 // Bitonic sorting network in its "all comparators ascending" form (the first step of every merge compares
@@ -992,6 +995,106 @@ __device__ __forceinline__ void tile_sort_regs(const uint64_t* __restrict__ k, c
     }
 }
 
+// Distribution sort of one small segment (the common path since round 2; the network above is the fallback).
+// The keys of a (frame, tile) segment are (depth bits << 32 | id) with depths spread over [z_lo, z_hi] of the tile, so
+//   bucket(key) = min(NB - 1, int((depth - z_lo) * NB / (z_hi - z_lo)))          NB = 256 E >= n buckets
+// is a monotone function of the key (float subtract, multiply by a positive constant, truncate and clamp all are), i.e. every
+// key of bucket b sorts before every key of bucket b + 1, and a bucket holds ~1 key on average: a histogram (one LDS
+// atomic per key, which also hands out the key's slot inside its bucket), an exclusive scan of NB counters, a scatter into
+// bucket order, and -- exactness -- each key's rank inside its own bucket by counting the smaller 64-bit keys there.
+// ~60 instructions per key instead of the ~300 of the 55-round network at 1024 keys.  Keys are unique (they end in the id), so
+// the ranks are a permutation.  A bucket longer than BKT_MAX_RUN (many splats at one depth: a wall facing the camera) makes
+// the counting quadratic: the workgroup then returns false and its segment goes through the network (exact for any input).
+constexpr int BKT_MAX_RUN = 40;
+constexpr int BKT_AUX = 16;            // 4 wave minima, 4 wave maxima, 4 wave totals, 4 wave run maxima
+
+template <int E>
+__device__ __forceinline__ bool tile_sort_buckets(const uint64_t* __restrict__ k, const uint32_t* __restrict__ v,
+                                                  uint32_t* __restrict__ ids, int n, uint64_t* __restrict__ s_keys /*[256 E]*/,
+                                                  uint32_t* __restrict__ s_hist /*[256 E + 1 + BKT_AUX]*/) {
+    constexpr int NB = 256 * E;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t* s_aux = s_hist + NB + 1;
+    uint64_t key[E];
+    uint32_t dmin = ~0u, dmax = 0u;
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const int e = tid + 256 * r;
+        key[r] = e < n ? (v != nullptr ? ((k[e] << 32) | v[e]) : k[e]) : 0ull;
+        if (e < n) {
+            const uint32_t d = (uint32_t)(key[r] >> 32);
+            dmin = min(dmin, d);
+            dmax = max(dmax, d);
+        }
+        s_hist[e] = 0u;
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+        dmin = min(dmin, (uint32_t)__shfl_xor((int)dmin, m, 64));
+        dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, m, 64));
+    }
+    if (lane == 0) { s_aux[wave] = dmin; s_aux[4 + wave] = dmax; }
+    __syncthreads();
+    dmin = min(min(s_aux[0], s_aux[1]), min(s_aux[2], s_aux[3]));
+    dmax = max(max(s_aux[4], s_aux[5]), max(s_aux[6], s_aux[7]));
+    // depths are positive floats (the near cull is 0.2), so the bit patterns order like the values
+    const float z_lo = __uint_as_float(dmin), range = __uint_as_float(dmax) - z_lo;
+    const float scale = range > 1e-30f ? (float)NB / range : 0.0f;       // one depth (or a denormal range): everything in bucket 0
+    uint32_t bkt[E], slot[E];
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        if (tid + 256 * r < n) {
+            bkt[r] = (uint32_t)min(NB - 1, (int)((__uint_as_float((uint32_t)(key[r] >> 32)) - z_lo) * scale));
+            slot[r] = atomicAdd(&s_hist[bkt[r]], 1u);
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the NB counters: thread t owns counters [t E, (t + 1) E)
+    uint32_t cnt[E], tot = 0u, run = 0u;
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        cnt[i] = s_hist[tid * E + i];
+        tot += cnt[i];
+        run = max(run, cnt[i]);
+    }
+    const uint32_t incl = gvf_wave_incl_scan(tot, (unsigned)lane);
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) run = max(run, (uint32_t)__shfl_xor((int)run, m, 64));
+    if (lane == 63) s_aux[8 + wave] = incl;
+    if (lane == 0) s_aux[12 + wave] = run;
+    __syncthreads();
+    if (max(max(s_aux[12], s_aux[13]), max(s_aux[14], s_aux[15])) > (uint32_t)BKT_MAX_RUN) return false;   // workgroup-uniform
+    uint32_t base = incl - tot;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) base += w < wave ? s_aux[8 + w] : 0u;
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        s_hist[tid * E + i] = base;
+        base += cnt[i];
+    }
+    if (tid == 255) s_hist[NB] = (uint32_t)n;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < E; ++r)
+        if (tid + 256 * r < n) s_keys[s_hist[bkt[r]] + slot[r]] = key[r];
+    __syncthreads();
+    // position p of the bucket-ordered array: neighbouring lanes sit in the same or the next bucket (broadcast LDS reads, and ids
+    // written next to each other)
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const int p = tid + 256 * r;
+        if (p < n) {
+            const uint64_t mine = s_keys[p];
+            const int b = min(NB - 1, (int)((__uint_as_float((uint32_t)(mine >> 32)) - z_lo) * scale));
+            const uint32_t lo = s_hist[b], hi = s_hist[b + 1];
+            uint32_t rank = lo;
+            for (uint32_t j = lo; j < hi; ++j) rank += s_keys[j] < mine ? 1u : 0u;
+            ids[rank] = (uint32_t)mine;
+        }
+    }
+    return true;
+}
+
 // number of keys < x in the sorted run a[0, n)
 __device__ __forceinline__ int lower_bound_u64(const uint64_t* a, int n, uint64_t x) {
     int lo = 0, hi = n;
@@ -1018,6 +1121,7 @@ __global__ void tile_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __r
                                  const uint32_t* __restrict__ vals, uint32_t* __restrict__ ids,
                                  const uint32_t* __restrict__ cls, uint32_t nseg) {
     __shared__ uint64_t s_small[MODE == 0 ? SORT_SMALL_N : 1];
+    __shared__ uint32_t s_hist[MODE == 0 ? SORT_SMALL_N + 1 + BKT_AUX : 1];
     extern __shared__ __attribute__((aligned(16))) uint64_t s_large[];
     if (MODE == 0) {
         const uint2 rng = ranges[blockIdx.x];
@@ -1026,6 +1130,15 @@ __global__ void tile_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __r
         const uint64_t* k = keys + rng.x;
         const uint32_t* v = vals != nullptr ? vals + rng.x : nullptr;
         uint32_t* o = ids + rng.x;
+        if (SORT_BUCKETS && n > 128) {               // distribution sort; false = a long run of near-equal depths, take the network
+            bool done;
+            if (n <= 256) done = tile_sort_buckets<1>(k, v, o, n, s_small, s_hist);
+            else if (n <= 512) done = tile_sort_buckets<2>(k, v, o, n, s_small, s_hist);
+            else if (n <= 1024) done = tile_sort_buckets<4>(k, v, o, n, s_small, s_hist);
+            else done = tile_sort_buckets<8>(k, v, o, n, s_small, s_hist);
+            if (done) return;
+            __syncthreads();
+        }
         if (n <= 64) tile_sort_regs<1, 64>(k, v, o, n, s_small);
         else if (n <= 128) tile_sort_regs<1, 128>(k, v, o, n, s_small);
         else if (n <= 256) tile_sort_regs<1, 256>(k, v, o, n, s_small);
@@ -1078,6 +1191,25 @@ __global__ void tile_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __r
         }
         __syncthreads();
     }
+}
+
+// classify + the three size classes of the per-tile sort over nseg segments (cls: 2 + 2 nseg words of scratch)
+static int launch_tile_sort(hipStream_t stream, const uint2* ranges, uint64_t* keys, const uint32_t* vals, uint32_t* ids,
+                            uint32_t* cls, uint32_t nseg) {
+    if (hipMemsetAsync(cls, 0, 2 * sizeof(uint32_t), stream) != hipSuccess) return GVF_ELAUNCH;
+    hipLaunchKernelGGL(classify_kernel, dim3((nseg + 255) / 256), dim3(256), 0, stream, ranges, nseg, cls);
+    hipLaunchKernelGGL(tile_sort_kernel<0>, dim3(nseg), dim3(256), 0, stream, ranges, keys, vals, ids, cls, nseg);
+    static bool large_attr_set = false;
+    if (!large_attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_sort_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                SORT_LARGE_N * 8) != hipSuccess)
+            return GVF_ELAUNCH;
+        large_attr_set = true;
+    }
+    hipLaunchKernelGGL(tile_sort_kernel<1>, dim3(64), dim3(1024), SORT_LARGE_N * 8, stream, ranges, keys, vals, ids, cls, nseg);
+    hipLaunchKernelGGL(tile_sort_kernel<2>, dim3(64), dim3(1024), 0, stream, ranges, keys, vals, ids, cls, nseg);
+    GVF_CHECK_LAUNCH();
+    return GVF_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1475,19 +1607,8 @@ int run_pipeline(const GvfRastSettings& st, const GvfRastFrame* frames_host, int
             }
             prof_mark(stream, slot, 5);
             // per-tile on-chip sort by (depth, id)
-            if (hipMemsetAsync(w.cls, 0, 2 * sizeof(uint32_t), stream) != hipSuccess) return GVF_ELAUNCH;
-            hipLaunchKernelGGL(classify_kernel, dim3((nseg + 255) / 256), dim3(256), 0, stream, w.ranges, nseg, w.cls);
-            hipLaunchKernelGGL(tile_sort_kernel<0>, dim3(nseg), dim3(256), 0, stream, w.ranges, keys_sorted, vals_by_tile, w.ids, w.cls, nseg);
-            static bool large_attr_set = false;
-            if (!large_attr_set) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_sort_kernel<1>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LARGE_N * 8) != hipSuccess)
-                    return GVF_ELAUNCH;
-                large_attr_set = true;
-            }
-            hipLaunchKernelGGL(tile_sort_kernel<1>, dim3(64), dim3(1024), SORT_LARGE_N * 8, stream, w.ranges, keys_sorted, vals_by_tile, w.ids, w.cls, nseg);
-            hipLaunchKernelGGL(tile_sort_kernel<2>, dim3(64), dim3(1024), 0, stream, w.ranges, keys_sorted, vals_by_tile, w.ids, w.cls, nseg);
-            GVF_CHECK_LAUNCH();
+            const int rc = launch_tile_sort(stream, w.ranges, keys_sorted, vals_by_tile, w.ids, w.cls, nseg);
+            if (rc != GVF_OK) return rc;
         } else {
             prof_mark(stream, slot, 5);
         }
@@ -2069,6 +2190,14 @@ extern "C" int gvf_gaussian_activate(const GvfGaussianActivation* act, int P, in
                        opacities);
     GVF_CHECK_LAUNCH();
     return GVF_OK;
+}
+
+extern "C" int gvf_tile_sort_u64(uint64_t* keys, const uint32_t* ranges, int nseg, uint32_t* ids, uint32_t* scratch, void* stream) {
+    if (nseg < 0) return GVF_EINVAL;
+    if (nseg == 0) return GVF_OK;
+    if (!keys || !ranges || !ids || !scratch) return GVF_EINVAL;
+    (void)hipGetLastError();
+    return launch_tile_sort((hipStream_t)stream, reinterpret_cast<const uint2*>(ranges), keys, nullptr, ids, scratch, (uint32_t)nseg);
 }
 
 extern "C" int gvf_rgb_to_u8(const float* rgb, uint8_t* out, int64_t n, void* stream) {

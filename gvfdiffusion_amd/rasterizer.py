@@ -323,6 +323,19 @@ def sort_pairs_u64(keys: torch.Tensor, values: torch.Tensor, end_bit: int = 64):
     return k, v
 
 
+def tile_sort_u64(keys: torch.Tensor, ranges: torch.Tensor) -> torch.Tensor:
+    """Per-segment sort of (depth bits << 32 | id) keys, the per-tile half of the rasteriser's sort stage (gvf_tile_sort_u64):
+    ranges is (nseg, 2) int32 [begin, end); returns the ids (low key words) in sorted order at the same positions."""
+    _lib.require_cuda(keys, ranges)
+    assert keys.dtype == torch.int64 and ranges.dtype == torch.int32 and ranges.dim() == 2 and ranges.shape[1] == 2
+    k, r = keys.clone().contiguous(), ranges.contiguous()
+    ids = torch.full((k.numel(),), -1, dtype=torch.int32, device=k.device)
+    scratch = torch.empty((2 + 2 * r.shape[0],), dtype=torch.int32, device=k.device)
+    _lib.check(_lib.lib().gvf_tile_sort_u64(_lib.ptr(k), _lib.ptr(r), r.shape[0], _lib.ptr(ids), _lib.ptr(scratch),
+                                            _lib.current_stream(k.device)), "gvf_tile_sort_u64")
+    return ids
+
+
 def frames_to_uint8(rgb: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
     """(.., H, W) float frames -> uint8 on the device: clamp(0,1) * 255 truncated, as the reference's
     render_and_save_images does on the host (utils/inference_utils.py:280-286)."""

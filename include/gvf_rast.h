@@ -171,6 +171,13 @@ size_t gvf_sort_tmp_bytes(int64_t n);
 int gvf_sort_pairs_u64(uint64_t* keys, uint64_t* keys_alt, uint32_t* values, uint32_t* values_alt,
                        int64_t n, int end_bit, void* tmp, size_t tmp_bytes, void* stream);
 
+/* The second half of R4, exported for testing: every segment [ranges[2 s], ranges[2 s + 1]) of keys -- (depth bits << 32 | id),
+ * ids unique inside a segment, as the binning stage leaves them per (frame, tile) -- is sorted ascending and the low words (the
+ * ids) are written to the same positions of `ids`: upstream's stable (tile, depth) order.  Segments up to 2048 keys take a
+ * distribution sort on depth (sorting network when one depth bucket gets crowded), up to 16384 a network in LDS, larger ones a
+ * network in global memory (keys of those segments are permuted in place).  scratch: 2 + 2 nseg uint32. */
+int gvf_tile_sort_u64(uint64_t* keys, const uint32_t* ranges, int nseg, uint32_t* ids, uint32_t* scratch, void* stream);
+
 /* Frame post-process of the render loop (utils/inference_utils.py:280-286: image.clamp(0,1) -> * 255 ->
  * astype('uint8')) on the device: out[i] = (uint8)(clamp(rgb[i], 0, 1) * 255), n elements. */
 int gvf_rgb_to_u8(const float* rgb, uint8_t* out, int64_t n, void* stream);
