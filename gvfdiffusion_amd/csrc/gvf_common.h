@@ -50,6 +50,33 @@ __device__ __forceinline__ unsigned gvf_wave_incl_scan(unsigned v, unsigned lane
     return v;
 }
 
+// The same scan / the wave-wide unsigned min, max on the DPP network (no LDS round trips: ~10 VALU instructions instead of six
+// dependent ds_bpermute latencies).  ALL 64 lanes must be active.  Within a row of 16 lanes: shifts by 1, 2, 4, 8 (a lane whose
+// source falls outside the row keeps `old`: 0 for the sum, its own value for min / max); across rows: row_bcast:15 into rows 1 and 3,
+// row_bcast:31 into rows 2 and 3 -- lane 63 then holds the reduction, every lane its inclusive prefix.
+#define GVF_DPP_ROW_SHR(n) (0x110 + (n))
+#define GVF_DPP_ROW_BCAST15 0x142
+#define GVF_DPP_ROW_BCAST31 0x143
+__device__ __forceinline__ unsigned gvf_wave_incl_scan_dpp(unsigned v) {
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, GVF_DPP_ROW_SHR(1), 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, GVF_DPP_ROW_SHR(2), 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, GVF_DPP_ROW_SHR(4), 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, GVF_DPP_ROW_SHR(8), 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, GVF_DPP_ROW_BCAST15, 0xa, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, GVF_DPP_ROW_BCAST31, 0xc, 0xf, false);
+    return v;
+}
+#define GVF_WAVE_REDUCE_DPP(OP)                                                                                         \
+    v = OP(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, GVF_DPP_ROW_SHR(1), 0xf, 0xf, false));            \
+    v = OP(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, GVF_DPP_ROW_SHR(2), 0xf, 0xf, false));            \
+    v = OP(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, GVF_DPP_ROW_SHR(4), 0xf, 0xf, false));            \
+    v = OP(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, GVF_DPP_ROW_SHR(8), 0xf, 0xf, false));            \
+    v = OP(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, GVF_DPP_ROW_BCAST15, 0xa, 0xf, false));           \
+    v = OP(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, GVF_DPP_ROW_BCAST31, 0xc, 0xf, false));           \
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63)
+__device__ __forceinline__ unsigned gvf_wave_umin(unsigned v) { GVF_WAVE_REDUCE_DPP(min); }
+__device__ __forceinline__ unsigned gvf_wave_umax(unsigned v) { GVF_WAVE_REDUCE_DPP(max); }
+
 // XCD-aware workgroup remap (MI355X: 8 XCDs, each with a private 4 MiB L2; the dispatcher is observed to
 // place workgroup b on XCD b % 8).  Returns the logical work index of physical workgroup `bid` such that
 // each XCD owns ONE contiguous range of logical indices: neighbours in logical order (which share operand

@@ -290,6 +290,7 @@ __global__ __launch_bounds__(PRE_THREADS) void preprocess_kernel(
     const float* __restrict__ cov3D_precomp, const float* __restrict__ delta, float4* __restrict__ splats,
     uint32_t* __restrict__ tiles_touched,
     int32_t* __restrict__ radii, uint32_t* __restrict__ block_sums, uint4* __restrict__ binrec,
+    const uint32_t* __restrict__ bin_slot /* Gaussian -> position of its bin record inside a frame; null = identity */,
     const float2* __restrict__ zrange /* per frame {z_lo, slabs per unit depth}; null = one slab */) {
     extern __shared__ __attribute__((aligned(16))) float sh_lds[];  // [PRE_THREADS][M*3] + 4 wave sums
     const int t = threadIdx.x;
@@ -311,6 +312,7 @@ __global__ __launch_bounds__(PRE_THREADS) void preprocess_kernel(
     }
     __syncthreads();
 
+  const uint32_t my_slot = (bin_slot != nullptr && i < P) ? bin_slot[i] : (uint32_t)i;
   for (int ff = 0; ff < PRE_FB; ++ff) {
     const int f = blockIdx.y * PRE_FB + ff;
     if (f >= pp.F) break;
@@ -450,8 +452,8 @@ __global__ __launch_bounds__(PRE_THREADS) void preprocess_kernel(
                 const float2 zr = zrange[f];
                 slab = (uint32_t)fminf(fmaxf((gC.y - zr.x) * zr.y, 0.0f), (float)(NSLAB - 1));
             }
-            binrec[o] = make_uint4((uint32_t)rect.x0 | ((uint32_t)rect.y0 << 16), (uint32_t)rect.x1 | ((uint32_t)rect.y1 << 16),
-                                   __float_as_uint(gC.y), slab);
+            binrec[(size_t)f * P + my_slot] = make_uint4((uint32_t)rect.x0 | ((uint32_t)rect.y0 << 16),
+                                                         (uint32_t)rect.x1 | ((uint32_t)rect.y1 << 16), __float_as_uint(gC.y), slab);
         }
     }
 
@@ -658,7 +660,7 @@ __global__ void frame_zrange_kernel(const GvfRastFrame* __restrict__ frames, int
 }
 
 // Count / scatter passes over the compact bin records, BIN_SPT slots per thread, slots taken in Morton order
-// (`order`, may be null = identity): the rects of one block then fall into a small window of tiles, instances are
+// (`order` = the Gaussian of each slot, may be null = identity; the records themselves are stored by slot): the rects of one block then fall into a small window of tiles, instances are
 // counted in an LDS table and every touched tile costs ONE global atomic per block (count pass: += tile_count;
 // scatter pass: cursor allocation, the base is left in the table and an LDS counter hands out the slots).  A block
 // whose window exceeds WIN_MAX tiles (incoherent order) pays one global atomic per instance instead.
@@ -688,7 +690,7 @@ __global__ __launch_bounds__(PRE_THREADS) void bin_kernel(int P, int gx, int gy,
         x0[k] = y0[k] = x1[k] = y1[k] = 0; sl[k] = 0; key[k] = 0;
         if (s < P) {
             const uint32_t id = order != nullptr ? order[s] : (uint32_t)s;
-            const uint4 br = binrec[(size_t)f * P + id];
+            const uint4 br = binrec[(size_t)f * P + s];                // records sit at their slots (preprocess_kernel, bin_slot)
             x0[k] = (int)(br.x & 0xffffu); y0[k] = (int)(br.x >> 16);
             x1[k] = (int)(br.y & 0xffffu); y1[k] = (int)(br.y >> 16);
             sl[k] = (int)br.w;
@@ -832,11 +834,15 @@ __global__ __launch_bounds__(1024) void morton_scan_kernel(uint32_t* __restrict_
     for (int k = 0; k < PER; ++k) { hist[t * PER + k] = run; run += v[k]; }
 }
 
-__global__ __launch_bounds__(256) void morton_scatter_kernel(int P, const uint32_t* __restrict__ codes,
-                                                             uint32_t* __restrict__ hist, uint32_t* __restrict__ order) {
+// codes_rank: in = the Gaussian's Morton code, out = its slot in the order (the inverse permutation: preprocess writes the bin
+// records at their slots, so the bin passes read them as one contiguous stream instead of gathering a 64-byte line per 16-byte record)
+__global__ __launch_bounds__(256) void morton_scatter_kernel(int P, uint32_t* codes_rank, uint32_t* __restrict__ hist,
+                                                             uint32_t* __restrict__ order) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
-    order[atomicAdd(&hist[codes[i]], 1u)] = (uint32_t)i;
+    const uint32_t slot = atomicAdd(&hist[codes_rank[i]], 1u);
+    order[slot] = (uint32_t)i;
+    codes_rank[i] = slot;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1028,11 +1034,8 @@ __device__ __forceinline__ bool tile_sort_buckets(const uint64_t* __restrict__ k
         }
         s_hist[e] = 0u;
     }
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) {
-        dmin = min(dmin, (uint32_t)__shfl_xor((int)dmin, m, 64));
-        dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, m, 64));
-    }
+    dmin = gvf_wave_umin(dmin);
+    dmax = gvf_wave_umax(dmax);
     if (lane == 0) { s_aux[wave] = dmin; s_aux[4 + wave] = dmax; }
     __syncthreads();
     dmin = min(min(s_aux[0], s_aux[1]), min(s_aux[2], s_aux[3]));
@@ -1057,9 +1060,8 @@ __device__ __forceinline__ bool tile_sort_buckets(const uint64_t* __restrict__ k
         tot += cnt[i];
         run = max(run, cnt[i]);
     }
-    const uint32_t incl = gvf_wave_incl_scan(tot, (unsigned)lane);
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) run = max(run, (uint32_t)__shfl_xor((int)run, m, 64));
+    const uint32_t incl = gvf_wave_incl_scan_dpp(tot);
+    run = gvf_wave_umax(run);
     if (lane == 63) s_aux[8 + wave] = incl;
     if (lane == 0) s_aux[12 + wave] = run;
     __syncthreads();
@@ -1088,7 +1090,10 @@ __device__ __forceinline__ bool tile_sort_buckets(const uint64_t* __restrict__ k
             const int b = min(NB - 1, (int)((__uint_as_float((uint32_t)(mine >> 32)) - z_lo) * scale));
             const uint32_t lo = s_hist[b], hi = s_hist[b + 1];
             uint32_t rank = lo;
-            for (uint32_t j = lo; j < hi; ++j) rank += s_keys[j] < mine ? 1u : 0u;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j)         // a bucket holds ~1 key: four independent reads (clamped into the array), then the rest
+                rank += (lo + j < hi && s_keys[min(lo + j, (uint32_t)NB - 1u)] < mine) ? 1u : 0u;
+            for (uint32_t j = lo + 4; j < hi; ++j) rank += s_keys[j] < mine ? 1u : 0u;
             ids[rank] = (uint32_t)mine;
         }
     }
@@ -1134,7 +1139,10 @@ __global__ void tile_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __r
             bool done;
             if (n <= 256) done = tile_sort_buckets<1>(k, v, o, n, s_small, s_hist);
             else if (n <= 512) done = tile_sort_buckets<2>(k, v, o, n, s_small, s_hist);
+            else if (n <= 768) done = tile_sort_buckets<3>(k, v, o, n, s_small, s_hist);
             else if (n <= 1024) done = tile_sort_buckets<4>(k, v, o, n, s_small, s_hist);
+            else if (n <= 1280) done = tile_sort_buckets<5>(k, v, o, n, s_small, s_hist);
+            else if (n <= 1536) done = tile_sort_buckets<6>(k, v, o, n, s_small, s_hist);
             else done = tile_sort_buckets<8>(k, v, o, n, s_small, s_hist);
             if (done) return;
             __syncthreads();
@@ -1551,7 +1559,7 @@ int run_pipeline(const GvfRastSettings& st, const GvfRastFrame* frames_host, int
         hipLaunchKernelGGL(preprocess_kernel, dim3(nb, (F + PRE_FB - 1) / PRE_FB), dim3(PRE_THREADS), sh_lds_bytes, stream, pp,
                            w.frames, a0, a1, a2, a3, colors_precomp ? nullptr : sh, colors_precomp, cov3D_precomp, delta,
                            w.splats, bucket ? nullptr : w.tiles_touched, (bucket && out_radii == nullptr) ? nullptr : w.radii,
-                           bucket ? nullptr : w.block_sums, bucket ? w.binrec : nullptr,
+                           bucket ? nullptr : w.block_sums, bucket ? w.binrec : nullptr, order != nullptr ? w.order_alt : nullptr,
                            (bucket && nslab > 1) ? w.zrange : nullptr);
         const int bnb = (P + BIN_SLOTS - 1) / BIN_SLOTS;
         if (bucket)
