@@ -565,6 +565,8 @@ __device__ __forceinline__ float float_unordered(uint32_t o) {
 // launches: block sums of 4096 counters, then every block adds up the sums in front of it (at most a few hundred
 // values) and rescans its own chunk.  Writes segment ranges + cursors, per-frame D, the grand total.
 constexpr int SCAN_CHUNK = 4096;
+constexpr int SORT_SMALL_N = 2048;     // size classes of the per-tile sort (R4, below)
+constexpr int SORT_LARGE_N = 16384;
 __global__ __launch_bounds__(1024) void seg_sums_kernel(const uint32_t* __restrict__ cnt, int n, uint32_t* __restrict__ partial) {
     __shared__ uint32_t wsum[16];
     const int t = threadIdx.x, j0 = blockIdx.x * SCAN_CHUNK + 4 * t;
@@ -583,7 +585,8 @@ __global__ __launch_bounds__(1024) void seg_scan_kernel(const uint32_t* __restri
                                                         uint2* __restrict__ ranges, uint32_t* __restrict__ cursor,
                                                         uint32_t* __restrict__ frame_base /*[F+1]*/,
                                                         uint32_t* __restrict__ num_rendered /*[F]*/,
-                                                        uint32_t* __restrict__ total_out, uint32_t max_rendered) {
+                                                        uint32_t* __restrict__ total_out, uint32_t max_rendered,
+                                                        uint32_t* __restrict__ cls /* sort size classes, as classify_kernel */) {
     __shared__ uint32_t wsum[16], wtot[16];
     __shared__ uint32_t s_base, s_total;
     const int t = threadIdx.x;
@@ -620,6 +623,10 @@ __global__ __launch_bounds__(1024) void seg_scan_kernel(const uint32_t* __restri
             // Overflow (D > workspace capacity): render nothing, but the true counts let the caller retry.
             ranges[j] = overflow ? make_uint2(0u, 0u) : make_uint2(run, run + c[k]);
             cursor[j] = run;
+            if (!overflow && c[k] > (uint32_t)SORT_SMALL_N) {           // rare: a segment for the LDS / global sort classes
+                if (c[k] > (uint32_t)SORT_LARGE_N) cls[2 + n + atomicAdd(&cls[1], 1u)] = (uint32_t)j;
+                else cls[2 + atomicAdd(&cls[0], 1u)] = (uint32_t)j;
+            }
             if (j % per_frame == 0) frame_base[j / per_frame] = run;
         }
         run += c[k];
@@ -674,10 +681,14 @@ __global__ __launch_bounds__(PRE_THREADS) void bin_kernel(int P, int gx, int gy,
                                                           uint32_t* __restrict__ tile_count /* count pass */,
                                                           uint32_t* __restrict__ cursor /* scatter pass */,
                                                           const uint32_t* __restrict__ total,
-                                                          uint64_t* __restrict__ payload, int nslab) {
+                                                          uint64_t* __restrict__ payload, int nslab,
+                                                          const uint32_t* __restrict__ frame_base, uint32_t* __restrict__ num_rendered) {
     __shared__ uint32_t s_tab[WIN_MAX];
     __shared__ uint32_t s_run[SCATTER ? WIN_MAX : 1];
     __shared__ int s_box[4];
+    // scatter pass: the per-frame instance counts from the frame bases the scan left (saves a launch of its own)
+    if (SCATTER && num_rendered != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
+        num_rendered[blockIdx.y] = frame_base[blockIdx.y + 1] - frame_base[blockIdx.y];
     if (SCATTER && *total == 0u) return;            // nothing visible, or capacity overflow (uniform)
     const int t = threadIdx.x, lane = t & 63, f = blockIdx.y;
     if (t == 0) { s_box[0] = 0x7fffffff; s_box[1] = 0x7fffffff; s_box[2] = 0; s_box[3] = 0; }
@@ -874,11 +885,9 @@ __global__ __launch_bounds__(256) void ranges_kernel(const uint64_t* __restrict_
 // (slow, correct: a whole scene projected onto one tile).  All three are launched over all tiles; a
 // workgroup whose segment is not in its class exits at once.
 // ---------------------------------------------------------------------------------------------
-constexpr int SORT_SMALL_N = 2048;
 #ifndef SORT_BUCKETS
 #define SORT_BUCKETS 1            // 0: every small segment through the sorting network (the round-1 path)
 #endif
-constexpr int SORT_LARGE_N = 16384;
 
 // Bitonic sorting network in its "all comparators ascending" form (the first step of every merge compares
 // mirrored partners i <-> block_end - i, the remaining steps are the usual half-cleaners).  Because every
@@ -1176,16 +1185,19 @@ __global__ void tile_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __r
         }
         return;
     }
-    // rare classes: a small fixed grid walks the list built by classify_kernel
-    const uint32_t count = cls[MODE == 1 ? 0 : 1];
-    const uint32_t* list = cls + 2 + (MODE == 1 ? 0u : nseg);
+    // rare classes: a small fixed grid walks the lists built by classify_kernel / seg_scan_kernel.  MODE 1 is launched with 128
+    // blocks: [0, 64) take the LDS class, [64, 128) the global class (one launch for both: they are almost always empty)
+    const bool huge = MODE == 2 || blockIdx.x >= 64u;
+    const uint32_t bid = MODE == 1 ? (blockIdx.x & 63u) : blockIdx.x, stride = MODE == 1 ? 64u : gridDim.x;
+    const uint32_t count = cls[huge ? 1 : 0];
+    const uint32_t* list = cls + 2 + (huge ? nseg : 0u);
     const int tid = threadIdx.x, nt = blockDim.x;
-    for (uint32_t li = blockIdx.x; li < count; li += gridDim.x) {
+    for (uint32_t li = bid; li < count; li += stride) {
         const uint2 rng = ranges[list[li]];
         const int n = (int)(rng.y - rng.x);
         uint64_t* k = keys + rng.x;
         const uint32_t* v = vals != nullptr ? vals + rng.x : nullptr;
-        if (MODE == 2) {
+        if (huge) {
             if (v != nullptr)
                 for (int i = tid; i < n; i += nt) k[i] = (k[i] << 32) | v[i];   // in place in global memory
             __syncthreads();
@@ -1202,10 +1214,12 @@ __global__ void tile_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __r
 }
 
 // classify + the three size classes of the per-tile sort over nseg segments (cls: 2 + 2 nseg words of scratch)
+// cls_state: 0 = cls holds nothing (clear + classify here), 1 = the two counters are cleared (classify here), 2 = classified
 static int launch_tile_sort(hipStream_t stream, const uint2* ranges, uint64_t* keys, const uint32_t* vals, uint32_t* ids,
-                            uint32_t* cls, uint32_t nseg) {
-    if (hipMemsetAsync(cls, 0, 2 * sizeof(uint32_t), stream) != hipSuccess) return GVF_ELAUNCH;
-    hipLaunchKernelGGL(classify_kernel, dim3((nseg + 255) / 256), dim3(256), 0, stream, ranges, nseg, cls);
+                            uint32_t* cls, uint32_t nseg, int cls_state) {
+    if (cls_state == 0 && hipMemsetAsync(cls, 0, 2 * sizeof(uint32_t), stream) != hipSuccess) return GVF_ELAUNCH;
+    if (cls_state < 2)
+        hipLaunchKernelGGL(classify_kernel, dim3((nseg + 255) / 256), dim3(256), 0, stream, ranges, nseg, cls);
     hipLaunchKernelGGL(tile_sort_kernel<0>, dim3(nseg), dim3(256), 0, stream, ranges, keys, vals, ids, cls, nseg);
     static bool large_attr_set = false;
     if (!large_attr_set) {
@@ -1214,8 +1228,8 @@ static int launch_tile_sort(hipStream_t stream, const uint2* ranges, uint64_t* k
             return GVF_ELAUNCH;
         large_attr_set = true;
     }
-    hipLaunchKernelGGL(tile_sort_kernel<1>, dim3(64), dim3(1024), SORT_LARGE_N * 8, stream, ranges, keys, vals, ids, cls, nseg);
-    hipLaunchKernelGGL(tile_sort_kernel<2>, dim3(64), dim3(1024), 0, stream, ranges, keys, vals, ids, cls, nseg);
+    // the two rare classes in one launch: blocks [0, 64) walk the LDS-class list, [64, 128) the global-class list
+    hipLaunchKernelGGL(tile_sort_kernel<1>, dim3(128), dim3(1024), SORT_LARGE_N * 8, stream, ranges, keys, vals, ids, cls, nseg);
     GVF_CHECK_LAUNCH();
     return GVF_OK;
 }
@@ -1400,10 +1414,29 @@ __global__ __launch_bounds__(256) void rgb_to_u8_kernel(const float4* __restrict
 // Camera blocks travel as kernel arguments (16 per launch): no host buffer has to outlive the call
 // and the upload is capturable in a hipGraph.
 struct FrameChunk { GvfRastFrame f[16]; };
-__global__ void upload_frames_kernel(FrameChunk c, int count, GvfRastFrame* __restrict__ dst) {
-    const int words = (int)(sizeof(GvfRastFrame) / 4) * count;
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(&c);
-    for (int k = threadIdx.x; k < words; k += blockDim.x) reinterpret_cast<uint32_t*>(dst)[k] = src[k];
+// The first upload launch of a call also clears the call's tables (one launch instead of six memsets, each a ~4 us bubble in a
+// 1.5 ms step): blocks >= 1 zero the tile ranges, the tile counters, the Morton histogram and the sort-class counters, and
+// set the bounding-box accumulators (min slots to all-ones, max slots to zero).
+struct CallTables {
+    uint32_t* ranges; uint32_t n_ranges;             // words
+    uint32_t* tile_count; uint32_t n_tile_count;
+    uint32_t* mhist; uint32_t n_mhist;
+    uint32_t* cls;                                    // 2 words
+    uint32_t* mm;                                     // 6 words
+};
+__global__ void upload_frames_kernel(FrameChunk c, int count, GvfRastFrame* __restrict__ dst, CallTables tab) {
+    if (blockIdx.x == 0) {
+        const int words = (int)(sizeof(GvfRastFrame) / 4) * count;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&c);
+        for (int k = threadIdx.x; k < words; k += blockDim.x) reinterpret_cast<uint32_t*>(dst)[k] = src[k];
+        if (tab.cls != nullptr && threadIdx.x < 2) tab.cls[threadIdx.x] = 0u;
+        if (tab.mm != nullptr && threadIdx.x < 6) tab.mm[threadIdx.x] = threadIdx.x < 3 ? 0xffffffffu : 0u;
+        return;
+    }
+    const uint32_t t = (blockIdx.x - 1) * blockDim.x + threadIdx.x, nt = (gridDim.x - 1) * blockDim.x;
+    for (uint32_t k = t; k < tab.n_ranges; k += nt) tab.ranges[k] = 0u;
+    for (uint32_t k = t; k < tab.n_tile_count; k += nt) tab.tile_count[k] = 0u;
+    for (uint32_t k = t; k < tab.n_mhist; k += nt) tab.mhist[k] = 0u;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1508,14 +1541,24 @@ int run_pipeline(const GvfRastSettings& st, const GvfRastFrame* frames_host, int
     const int nb = (P + PRE_THREADS - 1) / PRE_THREADS;
     const int slot = (g_prof.on && g_prof.calls < PROF_MAX_CALLS) ? g_prof.calls++ : -1;
 
+    const bool morton = st.bin_algo != GVF_RAST_BIN_RADIX && F >= 4 && P >= 4096;     // spatial order of the Gaussians (see below)
     for (int f0 = 0; f0 < F; f0 += 16) {
         FrameChunk ch;
         const int cnt = F - f0 < 16 ? F - f0 : 16;
         for (int k = 0; k < cnt; ++k) ch.f[k] = frames_host[f0 + k];
-        hipLaunchKernelGGL(upload_frames_kernel, dim3(1), dim3(256), 0, stream, ch, cnt, w.frames + f0);
+        CallTables tab = {};
+        if (f0 == 0) {
+            const size_t nseg_all = (size_t)F * ntiles * NSLAB;
+            tab.ranges = reinterpret_cast<uint32_t*>(w.ranges); tab.n_ranges = (uint32_t)(2 * nseg_all);
+            tab.tile_count = w.tile_count; tab.n_tile_count = (uint32_t)nseg_all;
+            tab.mhist = w.mhist; tab.n_mhist = morton ? (uint32_t)MORTON_BINS : 0u;
+            tab.cls = w.cls; tab.mm = w.mm;
+        }
+        const size_t clear_words = (size_t)tab.n_ranges + tab.n_tile_count + tab.n_mhist;
+        const int zb = f0 == 0 ? (int)((clear_words + 4095) / 4096 < 256 ? (clear_words + 4095) / 4096 : 256) : 0;
+        hipLaunchKernelGGL(upload_frames_kernel, dim3(1 + zb), dim3(256), 0, stream, ch, cnt, w.frames + f0, tab);
     }
     GVF_CHECK_LAUNCH();
-    if (hipMemsetAsync(w.ranges, 0, sizeof(uint2) * (size_t)F * ntiles * NSLAB, stream) != hipSuccess) return GVF_ELAUNCH;
 
     int nslab_blend = 1;
     if (P == 0 || nb == 0) {
@@ -1526,10 +1569,7 @@ int run_pipeline(const GvfRastSettings& st, const GvfRastFrame* frames_host, int
         prof_mark(stream, slot, 0);
         // ---- spatial order of the Gaussians (bucket binning, several frames to amortise it over) ----
         const uint32_t* order = nullptr;
-        if (bucket && F >= 4 && P >= 4096) {
-            if (hipMemsetAsync(w.mm, 0xff, 3 * sizeof(uint32_t), stream) != hipSuccess) return GVF_ELAUNCH;
-            if (hipMemsetAsync(w.mm + 3, 0, 3 * sizeof(uint32_t), stream) != hipSuccess) return GVF_ELAUNCH;
-            if (hipMemsetAsync(w.mhist, 0, MORTON_BINS * sizeof(uint32_t), stream) != hipSuccess) return GVF_ELAUNCH;
+        if (morton) {                                  // (bounding box accumulators and histogram: cleared by the upload launch)
             int bb = (P + 255) / 256; if (bb > 128) bb = 128;
             const int pb = (P + 255) / 256;
             hipLaunchKernelGGL(bbox_kernel, dim3(bb), dim3(256), 0, stream, P, a0, w.mm);
@@ -1554,7 +1594,6 @@ int run_pipeline(const GvfRastSettings& st, const GvfRastFrame* frames_host, int
         // per-pixel sub-pixel offsets move the sample positions: no box culling then (as in the blend)
         pp.upstream_binning = (st.upstream_binning != 0 || subpixel_offset != nullptr) ? 1 : 0;
         if (fused) pp.act = *act; else pp.act = GvfGaussianActivation{};
-        if (bucket && hipMemsetAsync(w.tile_count, 0, sizeof(uint32_t) * nseg, stream) != hipSuccess) return GVF_ELAUNCH;
         const size_t sh_lds_bytes = gvf_align_up((size_t)PRE_THREADS * pp.M * 3 * sizeof(float), 16) + 16;
         hipLaunchKernelGGL(preprocess_kernel, dim3(nb, (F + PRE_FB - 1) / PRE_FB), dim3(PRE_THREADS), sh_lds_bytes, stream, pp,
                            w.frames, a0, a1, a2, a3, colors_precomp ? nullptr : sh, colors_precomp, cov3D_precomp, delta,
@@ -1564,7 +1603,7 @@ int run_pipeline(const GvfRastSettings& st, const GvfRastFrame* frames_host, int
         const int bnb = (P + BIN_SLOTS - 1) / BIN_SLOTS;
         if (bucket)
             hipLaunchKernelGGL(bin_kernel<false>, dim3(bnb, F), dim3(PRE_THREADS), 0, stream, P, gx, gy, w.binrec, order,
-                               w.tile_count, w.cursor, w.total, w.keys, nslab);
+                               w.tile_count, w.cursor, w.total, w.keys, nslab, nullptr, nullptr);
         GVF_CHECK_LAUNCH();
         prof_mark(stream, slot, 2);
         if (bucket)
@@ -1573,8 +1612,9 @@ int run_pipeline(const GvfRastSettings& st, const GvfRastFrame* frames_host, int
             hipLaunchKernelGGL(seg_sums_kernel, dim3(sblocks), dim3(1024), 0, stream, w.tile_count, (int)nseg, w.partial);
             hipLaunchKernelGGL(seg_scan_kernel, dim3(sblocks), dim3(1024), 0, stream, w.tile_count, (int)nseg, ntiles * nslab, F,
                                w.partial, sblocks, w.ranges, w.cursor, w.frame_base, out_num_rendered, w.total,
-                               (uint32_t)max_rendered);
-            hipLaunchKernelGGL(frame_counts_kernel, dim3((F + 63) / 64), dim3(64), 0, stream, w.frame_base, F, out_num_rendered);
+                               (uint32_t)max_rendered, w.cls);
+            if (max_rendered <= 0)                   // otherwise the scatter pass writes the per-frame counts on its way
+                hipLaunchKernelGGL(frame_counts_kernel, dim3((F + 63) / 64), dim3(64), 0, stream, w.frame_base, F, out_num_rendered);
         }
         else
             hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, stream, w.block_sums, nb, F, w.frame_base,
@@ -1584,7 +1624,7 @@ int run_pipeline(const GvfRastSettings& st, const GvfRastFrame* frames_host, int
         if (max_rendered > 0) {
             if (bucket)
                 hipLaunchKernelGGL(bin_kernel<true>, dim3(bnb, F), dim3(PRE_THREADS), 0, stream, P, gx, gy, w.binrec, order,
-                                   w.tile_count, w.cursor, w.total, w.keys, nslab);
+                                   w.tile_count, w.cursor, w.total, w.keys, nslab, w.frame_base, out_num_rendered);
             else
                 hipLaunchKernelGGL(duplicate_kernel, dim3(nb, F), dim3(PRE_THREADS), 0, stream, P, gx, gy, w.splats,
                                    w.tiles_touched, w.radii, w.block_sums, w.keys, w.vals, (uint32_t)max_rendered,
@@ -1615,7 +1655,7 @@ int run_pipeline(const GvfRastSettings& st, const GvfRastFrame* frames_host, int
             }
             prof_mark(stream, slot, 5);
             // per-tile on-chip sort by (depth, id)
-            const int rc = launch_tile_sort(stream, w.ranges, keys_sorted, vals_by_tile, w.ids, w.cls, nseg);
+            const int rc = launch_tile_sort(stream, w.ranges, keys_sorted, vals_by_tile, w.ids, w.cls, nseg, bucket ? 2 : 1);
             if (rc != GVF_OK) return rc;
         } else {
             prof_mark(stream, slot, 5);
@@ -2205,7 +2245,7 @@ extern "C" int gvf_tile_sort_u64(uint64_t* keys, const uint32_t* ranges, int nse
     if (nseg == 0) return GVF_OK;
     if (!keys || !ranges || !ids || !scratch) return GVF_EINVAL;
     (void)hipGetLastError();
-    return launch_tile_sort((hipStream_t)stream, reinterpret_cast<const uint2*>(ranges), keys, nullptr, ids, scratch, (uint32_t)nseg);
+    return launch_tile_sort((hipStream_t)stream, reinterpret_cast<const uint2*>(ranges), keys, nullptr, ids, scratch, (uint32_t)nseg, 0);
 }
 
 extern "C" int gvf_rgb_to_u8(const float* rgb, uint8_t* out, int64_t n, void* stream) {
