@@ -567,6 +567,7 @@ __device__ __forceinline__ float float_unordered(uint32_t o) {
 constexpr int SCAN_CHUNK = 4096;
 constexpr int SORT_SMALL_N = 2048;     // size classes of the per-tile sort (R4, below)
 constexpr int SORT_LARGE_N = 16384;
+constexpr int SORT_LARGE_BLOCKS = 256, SORT_HUGE_BLOCKS = 64;   // grid of the launch that walks the two rare classes
 __global__ __launch_bounds__(1024) void seg_sums_kernel(const uint32_t* __restrict__ cnt, int n, uint32_t* __restrict__ partial) {
     __shared__ uint32_t wsum[16];
     const int t = threadIdx.x, j0 = blockIdx.x * SCAN_CHUNK + 4 * t;
@@ -1021,79 +1022,85 @@ __device__ __forceinline__ void tile_sort_regs(const uint64_t* __restrict__ k, c
 // the ranks are a permutation.  A bucket longer than BKT_MAX_RUN (many splats at one depth: a wall facing the camera) makes
 // the counting quadratic: the workgroup then returns false and its segment goes through the network (exact for any input).
 constexpr int BKT_MAX_RUN = 40;
-constexpr int BKT_AUX = 16;            // 4 wave minima, 4 wave maxima, 4 wave totals, 4 wave run maxima
+constexpr int BKT_AUX = 64;            // per wave: minimum, maximum, total, longest run (4 x up to 16 waves)
+constexpr int BKT_LARGE_NB = 4096;     // buckets of the 1024-thread class (2049 .. 16384 keys: 0.5 .. 4 keys per bucket)
 
-template <int E>
+// E keys per thread, T threads, C counters per thread: n <= T E keys into NB = T C buckets
+template <int E, int T, int C>
 __device__ __forceinline__ bool tile_sort_buckets(const uint64_t* __restrict__ k, const uint32_t* __restrict__ v,
-                                                  uint32_t* __restrict__ ids, int n, uint64_t* __restrict__ s_keys /*[256 E]*/,
-                                                  uint32_t* __restrict__ s_hist /*[256 E + 1 + BKT_AUX]*/) {
-    constexpr int NB = 256 * E;
+                                                  uint32_t* __restrict__ ids, int n, uint64_t* __restrict__ s_keys /*[T E]*/,
+                                                  uint32_t* __restrict__ s_hist /*[NB + 1 + BKT_AUX]*/) {
+    constexpr int NB = T * C, NW = T / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t* s_aux = s_hist + NB + 1;
     uint64_t key[E];
     uint32_t dmin = ~0u, dmax = 0u;
 #pragma unroll
     for (int r = 0; r < E; ++r) {
-        const int e = tid + 256 * r;
+        const int e = tid + T * r;
         key[r] = e < n ? (v != nullptr ? ((k[e] << 32) | v[e]) : k[e]) : 0ull;
         if (e < n) {
             const uint32_t d = (uint32_t)(key[r] >> 32);
             dmin = min(dmin, d);
             dmax = max(dmax, d);
         }
-        s_hist[e] = 0u;
     }
+#pragma unroll
+    for (int i = 0; i < C; ++i) s_hist[tid + T * i] = 0u;
     dmin = gvf_wave_umin(dmin);
     dmax = gvf_wave_umax(dmax);
-    if (lane == 0) { s_aux[wave] = dmin; s_aux[4 + wave] = dmax; }
+    if (lane == 0) { s_aux[wave] = dmin; s_aux[NW + wave] = dmax; }
     __syncthreads();
-    dmin = min(min(s_aux[0], s_aux[1]), min(s_aux[2], s_aux[3]));
-    dmax = max(max(s_aux[4], s_aux[5]), max(s_aux[6], s_aux[7]));
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { dmin = min(dmin, s_aux[w]); dmax = max(dmax, s_aux[NW + w]); }
     // depths are positive floats (the near cull is 0.2), so the bit patterns order like the values
     const float z_lo = __uint_as_float(dmin), range = __uint_as_float(dmax) - z_lo;
     const float scale = range > 1e-30f ? (float)NB / range : 0.0f;       // one depth (or a denormal range): everything in bucket 0
     uint32_t bkt[E], slot[E];
 #pragma unroll
     for (int r = 0; r < E; ++r) {
-        if (tid + 256 * r < n) {
+        if (tid + T * r < n) {
             bkt[r] = (uint32_t)min(NB - 1, (int)((__uint_as_float((uint32_t)(key[r] >> 32)) - z_lo) * scale));
             slot[r] = atomicAdd(&s_hist[bkt[r]], 1u);
         }
     }
     __syncthreads();
-    // exclusive scan of the NB counters: thread t owns counters [t E, (t + 1) E)
-    uint32_t cnt[E], tot = 0u, run = 0u;
+    // exclusive scan of the NB counters: thread t owns counters [t C, (t + 1) C)
+    uint32_t cnt[C], tot = 0u, run = 0u;
 #pragma unroll
-    for (int i = 0; i < E; ++i) {
-        cnt[i] = s_hist[tid * E + i];
+    for (int i = 0; i < C; ++i) {
+        cnt[i] = s_hist[tid * C + i];
         tot += cnt[i];
         run = max(run, cnt[i]);
     }
     const uint32_t incl = gvf_wave_incl_scan_dpp(tot);
     run = gvf_wave_umax(run);
-    if (lane == 63) s_aux[8 + wave] = incl;
-    if (lane == 0) s_aux[12 + wave] = run;
+    if (lane == 63) s_aux[2 * NW + wave] = incl;
+    if (lane == 0) s_aux[3 * NW + wave] = run;
     __syncthreads();
-    if (max(max(s_aux[12], s_aux[13]), max(s_aux[14], s_aux[15])) > (uint32_t)BKT_MAX_RUN) return false;   // workgroup-uniform
-    uint32_t base = incl - tot;
+    uint32_t base = incl - tot, longest = 0u;
 #pragma unroll
-    for (int w = 0; w < 3; ++w) base += w < wave ? s_aux[8 + w] : 0u;
+    for (int w = 0; w < NW; ++w) {
+        base += w < wave ? s_aux[2 * NW + w] : 0u;
+        longest = max(longest, s_aux[3 * NW + w]);
+    }
+    if (longest > (uint32_t)BKT_MAX_RUN) return false;                  // workgroup-uniform
 #pragma unroll
-    for (int i = 0; i < E; ++i) {
-        s_hist[tid * E + i] = base;
+    for (int i = 0; i < C; ++i) {
+        s_hist[tid * C + i] = base;
         base += cnt[i];
     }
-    if (tid == 255) s_hist[NB] = (uint32_t)n;
+    if (tid == T - 1) s_hist[NB] = (uint32_t)n;
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < E; ++r)
-        if (tid + 256 * r < n) s_keys[s_hist[bkt[r]] + slot[r]] = key[r];
+        if (tid + T * r < n) s_keys[s_hist[bkt[r]] + slot[r]] = key[r];
     __syncthreads();
     // position p of the bucket-ordered array: neighbouring lanes sit in the same or the next bucket (broadcast LDS reads, and ids
     // written next to each other)
 #pragma unroll
     for (int r = 0; r < E; ++r) {
-        const int p = tid + 256 * r;
+        const int p = tid + T * r;
         if (p < n) {
             const uint64_t mine = s_keys[p];
             const int b = min(NB - 1, (int)((__uint_as_float((uint32_t)(mine >> 32)) - z_lo) * scale));
@@ -1101,7 +1108,7 @@ __device__ __forceinline__ bool tile_sort_buckets(const uint64_t* __restrict__ k
             uint32_t rank = lo;
 #pragma unroll
             for (uint32_t j = 0; j < 4; ++j)         // a bucket holds ~1 key: four independent reads (clamped into the array), then the rest
-                rank += (lo + j < hi && s_keys[min(lo + j, (uint32_t)NB - 1u)] < mine) ? 1u : 0u;
+                rank += (lo + j < hi && s_keys[min(lo + j, (uint32_t)(T * E) - 1u)] < mine) ? 1u : 0u;
             for (uint32_t j = lo + 4; j < hi; ++j) rank += s_keys[j] < mine ? 1u : 0u;
             ids[rank] = (uint32_t)mine;
         }
@@ -1135,7 +1142,7 @@ __global__ void tile_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __r
                                  const uint32_t* __restrict__ vals, uint32_t* __restrict__ ids,
                                  const uint32_t* __restrict__ cls, uint32_t nseg) {
     __shared__ uint64_t s_small[MODE == 0 ? SORT_SMALL_N : 1];
-    __shared__ uint32_t s_hist[MODE == 0 ? SORT_SMALL_N + 1 + BKT_AUX : 1];
+    __shared__ uint32_t s_hist[MODE == 0 ? SORT_SMALL_N + 1 + BKT_AUX : (MODE == 1 ? BKT_LARGE_NB + 1 + BKT_AUX : 1)];
     extern __shared__ __attribute__((aligned(16))) uint64_t s_large[];
     if (MODE == 0) {
         const uint2 rng = ranges[blockIdx.x];
@@ -1146,13 +1153,13 @@ __global__ void tile_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __r
         uint32_t* o = ids + rng.x;
         if (SORT_BUCKETS && n > 128) {               // distribution sort; false = a long run of near-equal depths, take the network
             bool done;
-            if (n <= 256) done = tile_sort_buckets<1>(k, v, o, n, s_small, s_hist);
-            else if (n <= 512) done = tile_sort_buckets<2>(k, v, o, n, s_small, s_hist);
-            else if (n <= 768) done = tile_sort_buckets<3>(k, v, o, n, s_small, s_hist);
-            else if (n <= 1024) done = tile_sort_buckets<4>(k, v, o, n, s_small, s_hist);
-            else if (n <= 1280) done = tile_sort_buckets<5>(k, v, o, n, s_small, s_hist);
-            else if (n <= 1536) done = tile_sort_buckets<6>(k, v, o, n, s_small, s_hist);
-            else done = tile_sort_buckets<8>(k, v, o, n, s_small, s_hist);
+            if (n <= 256) done = tile_sort_buckets<1, 256, 1>(k, v, o, n, s_small, s_hist);
+            else if (n <= 512) done = tile_sort_buckets<2, 256, 2>(k, v, o, n, s_small, s_hist);
+            else if (n <= 768) done = tile_sort_buckets<3, 256, 3>(k, v, o, n, s_small, s_hist);
+            else if (n <= 1024) done = tile_sort_buckets<4, 256, 4>(k, v, o, n, s_small, s_hist);
+            else if (n <= 1280) done = tile_sort_buckets<5, 256, 5>(k, v, o, n, s_small, s_hist);
+            else if (n <= 1536) done = tile_sort_buckets<6, 256, 6>(k, v, o, n, s_small, s_hist);
+            else done = tile_sort_buckets<8, 256, 8>(k, v, o, n, s_small, s_hist);
             if (done) return;
             __syncthreads();
         }
@@ -1185,10 +1192,12 @@ __global__ void tile_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __r
         }
         return;
     }
-    // rare classes: a small fixed grid walks the lists built by classify_kernel / seg_scan_kernel.  MODE 1 is launched with 128
-    // blocks: [0, 64) take the LDS class, [64, 128) the global class (one launch for both: they are almost always empty)
-    const bool huge = MODE == 2 || blockIdx.x >= 64u;
-    const uint32_t bid = MODE == 1 ? (blockIdx.x & 63u) : blockIdx.x, stride = MODE == 1 ? 64u : gridDim.x;
+    // rare classes: a small fixed grid walks the lists built by classify_kernel / seg_scan_kernel.  MODE 1 is launched with
+    // SORT_LARGE_BLOCKS + SORT_HUGE_BLOCKS blocks: the first take the LDS class (one workgroup per CU: 145 KB of LDS), the rest the
+    // global class (one launch for both: at the bench shape they are empty)
+    const bool huge = MODE == 2 || blockIdx.x >= (uint32_t)SORT_LARGE_BLOCKS;
+    const uint32_t bid = (MODE == 1 && huge) ? blockIdx.x - SORT_LARGE_BLOCKS : blockIdx.x;
+    const uint32_t stride = MODE == 1 ? (huge ? (uint32_t)SORT_HUGE_BLOCKS : (uint32_t)SORT_LARGE_BLOCKS) : gridDim.x;
     const uint32_t count = cls[huge ? 1 : 0];
     const uint32_t* list = cls + 2 + (huge ? nseg : 0u);
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -1204,6 +1213,14 @@ __global__ void tile_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __r
             bitonic_sort_asc(k, n, tid, nt);
             for (int i = tid; i < n; i += nt) ids[rng.x + i] = (uint32_t)k[i];
         } else {
+            if (MODE == 1 && SORT_BUCKETS) {             // the distribution sort on 1024 threads; false = crowded bucket, take the network
+                bool sorted;
+                if (n <= 4096) sorted = tile_sort_buckets<4, 1024, BKT_LARGE_NB / 1024>(k, v, ids + rng.x, n, s_large, s_hist);
+                else if (n <= 8192) sorted = tile_sort_buckets<8, 1024, BKT_LARGE_NB / 1024>(k, v, ids + rng.x, n, s_large, s_hist);
+                else sorted = tile_sort_buckets<16, 1024, BKT_LARGE_NB / 1024>(k, v, ids + rng.x, n, s_large, s_hist);
+                __syncthreads();
+                if (sorted) continue;
+            }
             for (int i = tid; i < n; i += nt) s_large[i] = v != nullptr ? ((k[i] << 32) | v[i]) : k[i];
             __syncthreads();
             bitonic_sort_asc(s_large, n, tid, nt);
@@ -1228,8 +1245,9 @@ static int launch_tile_sort(hipStream_t stream, const uint2* ranges, uint64_t* k
             return GVF_ELAUNCH;
         large_attr_set = true;
     }
-    // the two rare classes in one launch: blocks [0, 64) walk the LDS-class list, [64, 128) the global-class list
-    hipLaunchKernelGGL(tile_sort_kernel<1>, dim3(128), dim3(1024), SORT_LARGE_N * 8, stream, ranges, keys, vals, ids, cls, nseg);
+    // the two rare classes in one launch
+    hipLaunchKernelGGL(tile_sort_kernel<1>, dim3(SORT_LARGE_BLOCKS + SORT_HUGE_BLOCKS), dim3(1024), SORT_LARGE_N * 8, stream, ranges, keys,
+                       vals, ids, cls, nseg);
     GVF_CHECK_LAUNCH();
     return GVF_OK;
 }
