@@ -1013,8 +1013,10 @@ __device__ __forceinline__ void tile_sort_regs(const uint64_t* __restrict__ k, c
 
 // Distribution sort of one small segment (the common path since round 2; the network above is the fallback).
 // The keys of a (frame, tile) segment are (depth bits << 32 | id) with depths spread over [z_lo, z_hi] of the tile, so
-//   bucket(key) = min(NB - 1, int((depth - z_lo) * NB / (z_hi - z_lo)))          NB = 256 E >= n buckets
-// is a monotone function of the key (float subtract, multiply by a positive constant, truncate and clamp all are), i.e. every
+//   bucket(key) = min(NB - 1, int(float(bits - bits_lo) * (NB / float(bits_hi - bits_lo))))      NB = 256 E >= n buckets,
+// bits = the depth's bit pattern as an unsigned integer (the high word of the key),
+// is a monotone function of the key (unsigned subtract, int -> float, multiply by a positive constant, truncate and clamp all are)
+// for ANY key values -- no assumption on sign or finiteness of the depth --, i.e. every
 // key of bucket b sorts before every key of bucket b + 1, and a bucket holds ~1 key on average: a histogram (one LDS
 // atomic per key, which also hands out the key's slot inside its bucket), an exclusive scan of NB counters, a scatter into
 // bucket order, and -- exactness -- each key's rank inside its own bucket by counting the smaller 64-bit keys there.
@@ -1053,14 +1055,14 @@ __device__ __forceinline__ bool tile_sort_buckets(const uint64_t* __restrict__ k
     __syncthreads();
 #pragma unroll
     for (int w = 0; w < NW; ++w) { dmin = min(dmin, s_aux[w]); dmax = max(dmax, s_aux[NW + w]); }
-    // depths are positive floats (the near cull is 0.2), so the bit patterns order like the values
-    const float z_lo = __uint_as_float(dmin), range = __uint_as_float(dmax) - z_lo;
-    const float scale = range > 1e-30f ? (float)NB / range : 0.0f;       // one depth (or a denormal range): everything in bucket 0
+    // buckets are linear in the BIT PATTERN of the depth (as an unsigned integer, the way the key itself orders): monotone for any
+    // key whatsoever, and for the positive depths of a frame (near cull 0.2) piecewise linear in the depth itself
+    const float scale = dmax > dmin ? (float)NB / (float)(dmax - dmin) : 0.0f;     // one depth: everything in bucket 0
     uint32_t bkt[E], slot[E];
 #pragma unroll
     for (int r = 0; r < E; ++r) {
         if (tid + T * r < n) {
-            bkt[r] = (uint32_t)min(NB - 1, (int)((__uint_as_float((uint32_t)(key[r] >> 32)) - z_lo) * scale));
+            bkt[r] = (uint32_t)min(NB - 1, (int)((float)((uint32_t)(key[r] >> 32) - dmin) * scale));
             slot[r] = atomicAdd(&s_hist[bkt[r]], 1u);
         }
     }
@@ -1103,7 +1105,7 @@ __device__ __forceinline__ bool tile_sort_buckets(const uint64_t* __restrict__ k
         const int p = tid + T * r;
         if (p < n) {
             const uint64_t mine = s_keys[p];
-            const int b = min(NB - 1, (int)((__uint_as_float((uint32_t)(mine >> 32)) - z_lo) * scale));
+            const int b = min(NB - 1, (int)((float)((uint32_t)(mine >> 32) - dmin) * scale));
             const uint32_t lo = s_hist[b], hi = s_hist[b + 1];
             uint32_t rank = lo;
 #pragma unroll

@@ -28,10 +28,12 @@ def _depths(kind, n, rng):
     if kind == "tiny_range":                    # neighbouring floats only
         base = np.float32(1.3).view(np.uint32)
         return (base + rng.integers(0, 3, n).astype(np.uint32)).view(np.float32)
+    if kind == "any_bits":                      # not depths at all: arbitrary high words (negative floats, NaNs, infinities)
+        return rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32)
     raise KeyError(kind)
 
 
-@pytest.mark.parametrize("kind", ["uniform", "clusters", "one_depth", "few_depths", "outlier", "tiny_range"])
+@pytest.mark.parametrize("kind", ["uniform", "clusters", "one_depth", "few_depths", "outlier", "tiny_range", "any_bits"])
 def test_every_segment_is_sorted_by_depth_then_id(cuda, kind):
     from gvfdiffusion_amd.rasterizer import tile_sort_u64
     rng = np.random.default_rng(abs(hash(kind)) % (1 << 31))
