@@ -25,6 +25,26 @@ def test_orbit_cameras_are_rigid_and_look_at_origin():
     assert not torch.allclose(eye[0], eye[1])
 
 
+def test_camera_blocks_are_cached_by_tensor_identity_and_version():
+    """GaussianRenderer.make_frames keeps the camera blocks of the last few (extrinsics, intrinsics) pairs: the same tensors give
+    the same list back, an in-place change of the cameras (or another delta mapping) rebuilds it.  Host logic only (no GPU)."""
+    from gvfdiffusion_amd.renderers import GaussianRenderer
+    rend = GaussianRenderer({"resolution": 64, "near": 0.8, "far": 1.6, "ssaa": 1, "bg_color": (1, 1, 1)})
+    from gvfdiffusion_amd.utils import orbit_cameras
+    ext = orbit_cameras(3).clone()
+    K = torch.tensor([[1.2, 0.0, 0.5], [0.0, 1.2, 0.5], [0.0, 0.0, 1.0]])
+    a = rend.make_frames(ext, K, [0, 1, 2])
+    assert rend.make_frames(ext, K, [0, 1, 2]) is a
+    assert rend.make_frames(ext, K, [0, 0, 0]) is not a and rend.make_frames(ext, K, [0, 0, 0])[2].delta_index == 0
+    before = [a[1].viewmatrix[k] for k in range(16)]
+    ext[1, 0, 3] += 0.25                                              # in place: same storage, new version
+    b = rend.make_frames(ext, K, [0, 1, 2])
+    assert b is not a and [b[1].viewmatrix[k] for k in range(16)] != before
+    assert [b[0].viewmatrix[k] for k in range(16)] == [a[0].viewmatrix[k] for k in range(16)]
+    fresh = GaussianRenderer({"resolution": 64, "near": 0.8, "far": 1.6, "ssaa": 1, "bg_color": (1, 1, 1)}).make_frames(ext, K, [0, 1, 2])
+    assert all([b[f].projmatrix[k] for k in range(16)] == [fresh[f].projmatrix[k] for k in range(16)] for f in range(3))
+
+
 @pytest.mark.gpu
 def test_driver_matches_per_frame_renders(cuda):
     from gvfdiffusion_amd.renderers import GaussianRenderer
