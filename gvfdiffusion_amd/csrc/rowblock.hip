@@ -84,6 +84,7 @@ struct RbParams {
     // optional (N3 = 1536 = to_qkv of the spatial self attention): pass 0 (q) goes to out3 as [M][512]; pass 1 (k) and pass 2 (v) go
     // straight into the tiled K / V^T images of csrc/attn_xt.hip (what gvf_attn_pack_kv_bf16 would build from the row-major copy)
     uint4* kt; uint4* vt; int kv_L, kv_tiles; float k_scale; const float* gamma_k;
+    int kv_group_rows;                  // > 0: only the first kv_group_rows rows of every rows_per_group group hold keys (padded groups)
     long long* dbg;                              // RB_TIMING builds only: [workgroup][16] s_memtime stamps
 };
 
@@ -528,7 +529,13 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
                 uint4 o;
                 o.x = rb_pack_bf16(k8[0] * mul * gg[0], k8[1] * mul * gg[1]); o.y = rb_pack_bf16(k8[2] * mul * gg[2], k8[3] * mul * gg[3]);
                 o.z = rb_pack_bf16(k8[4] * mul * gg[4], k8[5] * mul * gg[5]); o.w = rb_pack_bf16(k8[6] * mul * gg[6], k8[7] * mul * gg[7]);
-                const int row = m0 + r, set = row / p.kv_L, key = row - set * p.kv_L, key_l = key & 63;
+                int row = m0 + r;
+                if (p.kv_group_rows > 0) {               // padded groups: rows behind a group's keys write nothing, key sets count keys only
+                    const int grp = m0 / p.rpg, local = row - grp * p.rpg;
+                    if (local >= p.kv_group_rows) continue;
+                    row = grp * p.kv_group_rows + local;
+                }
+                const int set = row / p.kv_L, key = row - set * p.kv_L, key_l = key & 63;
                 p.kt[((long long)(set * (RB_C / 32) + h) * p.kv_tiles + (key >> 6)) * 256 + key_l * 4 + (c ^ ((key_l >> 2) & 3))] = o;
             }
         } else if (p.kt != nullptr && pass == 2) {
@@ -539,7 +546,13 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
             const unsigned short* stg = reinterpret_cast<const unsigned short*>(R1);
 #pragma unroll
             for (int gq = 0; gq < 3; ++gq) {
-                const int row0 = m0 + 16 * gq, set = row0 / p.kv_L, key0 = row0 - set * p.kv_L;
+                int row0 = m0 + 16 * gq;
+                if (p.kv_group_rows > 0) {               // (a 16-row group is all keys or all padding: kv_group_rows % 64 == 0)
+                    const int grp = m0 / p.rpg, local = row0 - grp * p.rpg;
+                    if (local >= p.kv_group_rows) continue;
+                    row0 = grp * p.kv_group_rows + local;
+                }
+                const int set = row0 / p.kv_L, key0 = row0 - set * p.kv_L;
                 uint4* dst = p.vt + ((long long)(set * (RB_C / 32) + h) * p.kv_tiles + (key0 >> 6)) * 256 + d * 8;
                 const int g = (key0 & 63) >> 4;
 #pragma unroll
@@ -622,7 +635,7 @@ extern "C" int gvf_rowblock_args_layout(int32_t* out, int n) {
     const int v[] = {(int)sizeof(gvf_rowblock_args), (int)offsetof(gvf_rowblock_args, x), (int)offsetof(gvf_rowblock_args, in_x), (int)offsetof(gvf_rowblock_args, gate1),
                      (int)offsetof(gvf_rowblock_args, mod_ld), (int)offsetof(gvf_rowblock_args, b_fc1), (int)offsetof(gvf_rowblock_args, ln2),
                      (int)offsetof(gvf_rowblock_args, b3), (int)offsetof(gvf_rowblock_args, hb_out), (int)offsetof(gvf_rowblock_args, k_tiles),
-                     (int)offsetof(gvf_rowblock_args, gamma_k)};
+                     (int)offsetof(gvf_rowblock_args, gamma_k), (int)offsetof(gvf_rowblock_args, kv_group_rows)};
     const int m = (int)(sizeof(v) / sizeof(v[0]));
     for (int i = 0; i < n && i < m; ++i) out[i] = v[i];
     return m;
@@ -668,7 +681,7 @@ extern "C" int gvf_rowblock_fused_bf16(const gvf_rowblock_args* a, void* stream_
     if (a->in_x != nullptr && (a->K1 != 0 || !a->in_wt || a->in_cin <= 0 || a->in_cin > 16 || (a->in_cin & 3) || (((uintptr_t)a->in_wt) & 15) ||
                                (((uintptr_t)a->in_b) & 15)))
         return GVF_EINVAL;
-    if (a->x_in != nullptr && (a->x_in_period <= 0 || a->rows_per_group <= 0 || a->rows_per_group % a->x_in_period != 0 || (((uintptr_t)a->x_in) & 15)))
+    if (a->x_in != nullptr && (a->x_in_period <= 0 || a->rows_per_group <= 0 || a->rows_per_group % RB_BM != 0 || (((uintptr_t)a->x_in) & 15)))
         return GVF_EINVAL;
     const gvf_rowblock_ln* lns[2] = {&a->ln1, &a->ln2};
     bool grouped = a->gate1 != nullptr || a->gate_m != nullptr;
@@ -684,8 +697,12 @@ extern "C" int gvf_rowblock_fused_bf16(const gvf_rowblock_args* a, void* stream_
     if (a->N3 == 0 && a->hb_out == nullptr && a->hidden == 0) return GVF_EINVAL;       // nothing would consume the LayerNorm (with the MLP: the
                                                                                         // stream update alone is a result; LayerNorm ln2 is skipped)
     if ((a->k_tiles == nullptr) != (a->v_tiles == nullptr)) return GVF_EINVAL;
-    if (a->k_tiles != nullptr && (a->N3 != 3 * RB_C || a->kv_L <= 0 || a->kv_L % 64 != 0 || a->M % a->kv_L != 0 || !(a->k_scale > 0.f) ||
+    if (a->k_tiles != nullptr && (a->N3 != 3 * RB_C || a->kv_L <= 0 || a->kv_L % 64 != 0 || !(a->k_scale > 0.f) ||
                                   (((uintptr_t)a->k_tiles) & 15) || (((uintptr_t)a->v_tiles) & 15)))
+        return GVF_EINVAL;
+    if (a->k_tiles != nullptr && a->kv_group_rows == 0 && a->M % a->kv_L != 0) return GVF_EINVAL;
+    if (a->kv_group_rows != 0 && (a->k_tiles == nullptr || a->kv_group_rows < 0 || a->kv_group_rows % a->kv_L != 0 || a->rows_per_group <= 0 ||
+                                  a->rows_per_group % RB_BM != 0 || a->kv_group_rows > a->rows_per_group || a->M % a->rows_per_group != 0))
         return GVF_EINVAL;
     if ((((uintptr_t)a->a) & 15) || (((uintptr_t)a->w) & 15) || (((uintptr_t)a->x) & 15) || (((uintptr_t)a->out3) & 7) ||
         (((uintptr_t)a->hb_out) & 7) || (((uintptr_t)a->b3) & 15))
@@ -698,12 +715,13 @@ extern "C" int gvf_rowblock_fused_bf16(const gvf_rowblock_args* a, void* stream_
     p.in_x = a->in_x; p.in_wt = a->in_wt; p.in_b = a->in_b; p.in_cin = a->in_cin;
     p.gate1 = a->gate1;
     p.ln1 = RbLn{a->ln1.ln_w, a->ln1.ln_b, a->ln1.shift, a->ln1.scale};
-    p.mod_ld = a->mod_ld; p.rpg = (grouped || a->x_in != nullptr) ? a->rows_per_group : 0; p.eps = a->eps;
+    p.mod_ld = a->mod_ld; p.rpg = (grouped || a->x_in != nullptr || a->kv_group_rows > 0) ? a->rows_per_group : 0; p.eps = a->eps;
     p.b_fc1 = a->b_fc1; p.b_fc2 = a->b_fc2; p.hidden = a->hidden; p.gate_m = a->gate_m;
     p.ln2 = RbLn{a->ln2.ln_w, a->ln2.ln_b, a->ln2.shift, a->ln2.scale};
     p.b3 = a->b3; p.out3 = a->N3 != 0 ? (unsigned short*)a->out3 : nullptr; p.N3 = a->N3;
     p.hb_out = (unsigned short*)a->hb_out;
     p.kt = (uint4*)a->k_tiles; p.vt = (uint4*)a->v_tiles; p.kv_L = a->kv_L; p.kv_tiles = a->kv_L / 64; p.k_scale = a->k_scale; p.gamma_k = a->gamma_k;
+    p.kv_group_rows = a->kv_group_rows;
     p.dbg = g_rb_dbg;
     (void)hipGetLastError();
     const dim3 grid((unsigned)(a->M / RB_BM)), block(RB_THREADS);

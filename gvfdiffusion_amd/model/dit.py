@@ -443,12 +443,16 @@ class DiT(nn.Module):
 
         # residual stream h (fp32) = position embedding broadcast over T + input_layer(x), in fp32 (csrc/elem.hip)
         small_f32 = C <= 512 and C % 4 == 0 and Cin <= 24 and self.out_channels <= 32
-        h = torch.empty((M, C), dtype=f32, device=dev)
         x2d = x.reshape(M, Cin).float().contiguous()
         pos = None if ctx["pos"] is None else ctx["pos"].reshape(B * N, C)
-        if self.use_rowblock and small_f32 and Cin % 4 == 0 and Cin <= 16 and dit_ops.rowblock_supported(C, T * N, int(C * self.mlp_ratio)):
-            y = self._blocks_rowblock(x2d, h, mod, mod_ld, W, ctx, B, T, N, pos)          # its first launch also does input_layer
+        # the row-block launches work on whole 48-row blocks of one sample: a sample whose T * N is not a multiple of 48 (T = 16, 32 at
+        # N = 512) gets its rows padded (needs whole 64-key tiles per frame for the attention's strided views: N % 64 == 0)
+        TNp = dit_ops.rowblock_padded_rows(T * N)
+        if self.use_rowblock and small_f32 and Cin % 4 == 0 and Cin <= 16 and dit_ops.rowblock_supported(C, TNp, int(C * self.mlp_ratio)) \
+                and (TNp == T * N or (N % 64 == 0 and self.rowblock_tiled_kv)):
+            y = self._blocks_rowblock(x2d, mod, mod_ld, W, ctx, B, T, N, pos)          # its first launch also does input_layer
             return y.to(x.dtype if x.dtype.is_floating_point else f32)
+        h = torch.empty((M, C), dtype=f32, device=dev)
         if small_f32:
             dit_ops.input_layer_f32(x2d, W["input_f32"][0], W["input_f32"][1], h, pos=pos, pos_period=N, rows_per_group=T * N)
         elif ctx["pos"] is not None:
@@ -535,21 +539,33 @@ class DiT(nn.Module):
             ln_gemm(W["final"], y, dit_ops.EPI_STORE_F32, shift=mview(o), scale=mview(o + C))
         return y.reshape(B, T, N, self.out_channels).to(x.dtype if x.dtype.is_floating_point else f32)
 
-    def _blocks_rowblock(self, x2d, h, mod, mod_ld, W, ctx, B, T, N, pos):
+    def _blocks_rowblock(self, x2d, mod, mod_ld, W, ctx, B, T, N, pos):
         """The blocks with one launch per sub-layer boundary (csrc/rowblock.hip): per block  spatial attention | to_out + adaLN +
         to_qkv | temporal attention | to_out + norm3 + to_q | image attention | to_out + norm4 + to_q | static attention | to_out +
         adaLN + MLP + adaLN + the NEXT block's to_qkv (q row-major, K / V^T as the attention's tile images) -- 8 launches instead of 20, the fp32 stream through HBM 5 times instead of 15,
-        the normalised rows and the MLP's hidden units never.  Same rounding points as the unfused path (and as oracle/dit_ref.py)."""
+        the normalised rows and the MLP's hidden units never.  Same rounding points as the unfused path (and as oracle/dit_ref.py).
+        Row layout: sample b owns rows [b TNp, b TNp + T N), TNp = T N rounded up to whole 48-row blocks; the padding rows (T N not a
+        multiple of 48) are computed like any other row by the row-block launches and never read by an attention."""
         C, H = self.model_channels, self.num_heads
-        M, TN = B * T * N, T * N
+        TN = T * N
+        TNp = dit_ops.rowblock_padded_rows(TN)
+        padded = TNp != TN
+        M = B * TNp
         dev = x2d.device
         bf, f32 = torch.bfloat16, torch.float32
         rb = self._rowblock_streams(W)
         Li, Ls = ctx["Li"], ctx["Ls"]
+        # buffers an attention writes and a row-block launch reads whole: their padding rows must stay finite
+        alloc = torch.zeros if padded else torch.empty
+        h = torch.empty((M, C), dtype=f32, device=dev)            # the residual stream
         qkv = torch.empty((M, 3 * C), dtype=bf, device=dev)
-        ab = torch.empty((M, C), dtype=bf, device=dev)            # self-attention output
-        hb = torch.empty((M, C), dtype=bf, device=dev)            # cross-attention output
+        ab = alloc((M, C), dtype=bf, device=dev)                  # self-attention output
+        hb = alloc((M, C), dtype=bf, device=dev)                  # cross-attention output
         qb = torch.empty((M, C), dtype=bf, device=dev)            # q projection of the cross attentions
+        if padded:
+            xp = torch.zeros((B, TNp, x2d.shape[1]), dtype=f32, device=dev)
+            xp[:, :TN] = x2d.view(B, TN, -1)
+            x2d = xp.view(M, -1)
         nb_self = B * T * H * ((N + 63) // 64) * 4096
         kv_self = (torch.empty(nb_self, dtype=torch.uint8, device=dev), torch.empty(nb_self, dtype=torch.uint8, device=dev))
         hidden_units = int(C * self.mlp_ratio)
@@ -560,7 +576,7 @@ class DiT(nn.Module):
             return mod[:, off:]
 
         def fused(a_, stream, **kw):
-            dit_ops.rowblock_fused(a_, stream, h, mod_ld=mod_ld, rows_per_group=TN, eps=1e-6, **kw)
+            dit_ops.rowblock_fused(a_, stream, h, mod_ld=mod_ld, rows_per_group=TNp, eps=1e-6, **kw)
 
         o = offs[0]
         # h = pos + input_layer(x); adaLN of block 0; its to_qkv
@@ -572,8 +588,16 @@ class DiT(nn.Module):
         def qkv_out(blk):
             a_ = blk["spatial_self_attn"]
             if tiled_kv:
-                return dict(out3=qs, b3=a_["qkv"][1], kv_tiles=kv_self, kv_L=N, gamma_k=a_["gk"])
+                return dict(out3=qs, b3=a_["qkv"][1], kv_tiles=kv_self, kv_L=N, gamma_k=a_["gk"], kv_group_rows=TN if padded else 0)
             return dict(out3=qkv, b3=a_["qkv"][1])
+
+        # per-frame views of the row buffers.  Padded: outer = sample (stride TNp rows), inner = frame (N rows), key set of (b, f) = b T + f;
+        # otherwise the frames of all samples are one uniform run (the launch geometry the kernels were tuned on)
+        if padded:
+            fr = dict(n=(B, T), c=(TNp * C, N * C, C), c3=(TNp * 3 * C, N * 3 * C, 3 * C), kv=(T, 1))
+        else:
+            fr = dict(n=(B * T, 1), c=(N * C, 0, C), c3=(N * 3 * C, 0, 3 * C), kv=(1, 0))
+        fr_c = (TNp * C, N * C, C)                                 # (sample, frame) view for the per-sample key set of the static attention
 
         # h = pos (broadcast over the frames) + input_layer(x) in fp32, adaLN of block 0 and its to_qkv: one launch
         if pos is None:
@@ -586,11 +610,10 @@ class DiT(nn.Module):
             n3, n4 = dict(ln_w=b["n3"][0], ln_b=b["n3"][1]), dict(ln_w=b["n4"][0], ln_b=b["n4"][1])
             a = b["spatial_self_attn"]
             if tiled_kv:
-                dit_ops.attention_tiled_bf16(qs, kv_self[0], kv_self[1], ab, B * T, 1, N, N, H, (N * C, 0, C), (N * C, 0, C), 1, 0, gamma_q=a["gq"])
-            else:
+                dit_ops.attention_tiled_bf16(qs, kv_self[0], kv_self[1], ab, *fr["n"], N, N, H, fr["c"], fr["c"], *fr["kv"], gamma_q=a["gq"])
+            else:                                              # (never padded: see _forward)
                 dit_ops.attention_pack_kv(qkv, B * T, N, H, C, 2 * C, gamma_k=a["gk"], out=kv_self)
-                dit_ops.attention_tiled_bf16(qkv, kv_self[0], kv_self[1], ab, B * T, 1, N, N, H, (N * 3 * C, 0, 3 * C), (N * C, 0, C), 1, 0,
-                                             gamma_q=a["gq"])
+                dit_ops.attention_tiled_bf16(qkv, kv_self[0], kv_self[1], ab, *fr["n"], N, N, H, fr["c3"], fr["c"], *fr["kv"], gamma_q=a["gq"])
             ai = b["image_cross_attn"]
             if self.no_temporal_attn:
                 fused(ab, s["s2"], b1=a["out"][1], gate1=g_s, ln1=n3, out3=qb, b3=ai["q"][1])
@@ -598,15 +621,15 @@ class DiT(nn.Module):
                 sh_t, sc_t, g_t = (mview(o + (6 + k) * C) for k in range(3))
                 at = b["temporal_self_attn"]
                 fused(ab, s["s2"], b1=a["out"][1], gate1=g_s, ln1=dict(shift=sh_t, scale=sc_t), out3=qkv, b3=at["qkv"][1])
-                st = (TN * 3 * C, 3 * C, N * 3 * C)           # outer = sample, inner = token, seq = frame
-                dit_ops.attention_bf16(qkv, qkv[:, C:], qkv[:, 2 * C:], ab, B, N, T, T, H, st, st, st, (TN * C, C, N * C), at["gq"], at["gk"])
+                st = (TNp * 3 * C, 3 * C, N * 3 * C)          # outer = sample, inner = token, seq = frame
+                dit_ops.attention_bf16(qkv, qkv[:, C:], qkv[:, 2 * C:], ab, B, N, T, T, H, st, st, st, (TNp * C, C, N * C), at["gq"], at["gk"])
                 fused(ab, s["s3"], b1=at["out"][1], gate1=g_t, ln1=n3, out3=qb, b3=ai["q"][1])
             kt, vt = ctx["kv_img"][i]
-            dit_ops.attention_tiled_bf16(qb, kt, vt, hb, B * T, 1, N, Li, H, (N * C, 0, C), (N * C, 0, C), 1, 0, gamma_q=ai["gq"])
+            dit_ops.attention_tiled_bf16(qb, kt, vt, hb, *fr["n"], N, Li, H, fr["c"], fr["c"], *fr["kv"], gamma_q=ai["gq"])
             ast = b["static_cross_attn"]
             fused(hb, s["s4"], b1=ai["out"][1], ln1=n4, out3=qb, b3=ast["q"][1])
             kt, vt = ctx["kv_st"][i]
-            dit_ops.attention_tiled_bf16(qb, kt, vt, hb, B, T, N, Ls, H, (TN * C, N * C, C), (TN * C, N * C, C), 1, 0, gamma_q=ast["gq"])
+            dit_ops.attention_tiled_bf16(qb, kt, vt, hb, B, T, N, Ls, H, fr_c, fr_c, 1, 0, gamma_q=ast["gq"])
             kw = dict(b1=ast["out"][1], ln1=dict(shift=sh_m, scale=sc_m), mlp_bias=(b["fc1"][1], b["fc2"][1]), hidden=hidden_units, gate_m=g_m)
             if i + 1 < len(blocks):
                 on = offs[i + 1]
@@ -615,5 +638,5 @@ class DiT(nn.Module):
                 fused(hb, s["s5"], **kw)                       # the last MLP; final_layer reads the stream itself
         on = offs[-1]
         y = torch.empty((M, self.out_channels), dtype=f32, device=dev)
-        dit_ops.final_layer_f32(h, W["final_f32"][0], W["final_f32"][1], y, shift=mview(on), scale=mview(on + C), mod_ld=mod_ld, rows_per_group=TN)
-        return y.reshape(B, T, N, self.out_channels)
+        dit_ops.final_layer_f32(h, W["final_f32"][0], W["final_f32"][1], y, shift=mview(on), scale=mview(on + C), mod_ld=mod_ld, rows_per_group=TNp)
+        return y.view(B, TNp, self.out_channels)[:, :TN].reshape(B, T, N, self.out_channels)

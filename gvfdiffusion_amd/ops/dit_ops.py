@@ -27,7 +27,8 @@ class RowblockArgs(ctypes.Structure):
                 ("b_fc1", _vp), ("b_fc2", _vp), ("hidden", ctypes.c_int32), ("gate_m", _vp), ("ln2", RowblockLn),
                 ("b3", _vp), ("out3", _vp), ("N3", ctypes.c_int32), ("epi3", ctypes.c_int32),
                 ("hb_out", _vp),
-                ("k_tiles", _vp), ("v_tiles", _vp), ("kv_L", ctypes.c_int32), ("k_scale", _f), ("gamma_k", _vp)]
+                ("k_tiles", _vp), ("v_tiles", _vp), ("kv_L", ctypes.c_int32), ("k_scale", _f), ("gamma_k", _vp),
+                ("kv_group_rows", ctypes.c_int32)]
 
 
 _lib.register({
@@ -182,8 +183,14 @@ ROWBLOCK_C, ROWBLOCK_ROWS, ROWBLOCK_KPAD, ROWBLOCK_MAX_HIDDEN, ROWBLOCK_MAX_N3 =
 
 
 def rowblock_supported(C: int, rows_per_group: int, hidden: int) -> bool:
-    """The row-block kernel covers model_channels 512, 48-row blocks that do not straddle samples, an MLP of <= 2048 hidden units."""
+    """The row-block kernel covers model_channels 512, 48-row blocks that do not straddle samples (callers pad a sample's rows to a
+    multiple of 48: rowblock_padded_rows), an MLP of <= 2048 hidden units."""
     return C == ROWBLOCK_C and rows_per_group % ROWBLOCK_ROWS == 0 and hidden % ROWBLOCK_C == 0 and 0 < hidden <= ROWBLOCK_MAX_HIDDEN
+
+
+def rowblock_padded_rows(rows: int) -> int:
+    """Rows of a sample rounded up to whole 48-row blocks."""
+    return (rows + ROWBLOCK_ROWS - 1) // ROWBLOCK_ROWS * ROWBLOCK_ROWS
 
 
 def rowblock_pack_stream(w1, mlp=None, w3=None):
@@ -223,7 +230,7 @@ def _ln_struct(ln):
 
 
 def rowblock_fused(a, stream_w, x, b1=None, gate1=None, ln1=None, mod_ld=0, rows_per_group=0, eps=1e-6,
-                   mlp_bias=None, hidden=0, gate_m=None, ln2=None, b3=None, out3=None, hb_out=None, x_in=None, x_in_period=0, kv_tiles=None, kv_L=0, gamma_k=None, kv_scale=None, in_x=None, in_wt=None, in_b=None):
+                   mlp_bias=None, hidden=0, gate_m=None, ln2=None, b3=None, out3=None, hb_out=None, x_in=None, x_in_period=0, kv_tiles=None, kv_L=0, gamma_k=None, kv_scale=None, in_x=None, in_wt=None, in_b=None, kv_group_rows=0):
     """x += gate1 * (a W1^T + b1); hb = LN1(x); [x += gate_m * MLP(hb); hb = LN2(x)]; out3 = hb W3^T + b3 or hb_out = hb -- ONE launch
     (csrc/rowblock.hip; include/gvf_dit.h).  ln1 / ln2: dict with ln_w, ln_b and / or shift, scale.  mlp_bias = (b_fc1, b_fc2).
     a = None: no closing projection (x already holds the sub-layer's result; the stream has no W1 segment).
@@ -254,8 +261,15 @@ def rowblock_fused(a, stream_w, x, b1=None, gate1=None, ln1=None, mod_ld=0, rows
         assert out3.dtype == torch.bfloat16 and out3.is_contiguous() and out3.shape[0] == M
         args.b3, args.out3, args.N3, args.epi3 = _pi(b3), _pi(out3), out3.shape[1], EPI_STORE_BF16
     if kv_tiles is not None:        # to_qkv of the spatial self attention: out3 = q [M][C]; k, v -> tiled images (see attention_pack_kv)
-        assert out3 is not None and out3.shape[1] == C and kv_L % 64 == 0 and M % kv_L == 0
-        nbytes = (M // kv_L) * (C // 32) * (kv_L // 64) * 4096
+        assert out3 is not None and out3.shape[1] == C and kv_L % 64 == 0
+        if kv_group_rows:               # padded groups (see include/gvf_dit.h): rows_per_group rows each, the first kv_group_rows are tokens
+            assert rows_per_group > 0 and M % rows_per_group == 0 and kv_group_rows % kv_L == 0 and kv_group_rows <= rows_per_group
+            n_sets = (M // rows_per_group) * (kv_group_rows // kv_L)
+            args.kv_group_rows = int(kv_group_rows)
+        else:
+            assert M % kv_L == 0
+            n_sets = M // kv_L
+        nbytes = n_sets * (C // 32) * (kv_L // 64) * 4096
         assert kv_tiles[0].numel() >= nbytes and kv_tiles[1].numel() >= nbytes
         args.N3 = 3 * C
         args.k_tiles, args.v_tiles, args.kv_L = _pi(kv_tiles[0]), _pi(kv_tiles[1]), int(kv_L)

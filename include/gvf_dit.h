@@ -91,10 +91,15 @@ typedef struct gvf_rowblock_args {
     void* hb_out;
     /* optional, N3 = 1536 (to_qkv of the spatial self attention, head_dim 32): q (pass 0) goes to out3 as bf16 [M][512]; k and v go straight
        into the tiled K / V^T images of gvf_attn_tiled_fwd_bf16 -- bit-identical to gvf_attn_pack_kv_bf16(k_scale, gamma_k) on the row-major
-       projection, which is then never written.  Key sets = runs of kv_L rows (kv_L a multiple of 64, M a multiple of kv_L). */
+       projection, which is then never written.  Key sets = runs of kv_L rows (kv_L a multiple of 64, M a multiple of kv_L).
+       kv_group_rows > 0: the stream is laid out in groups of rows_per_group rows (a multiple of 48) of which only the first
+       kv_group_rows (a multiple of kv_L) are tokens -- a sample whose T*N is not a multiple of 48, padded; the padding rows are
+       computed like any other row but write no keys, and key sets count tokens only (set = group * kv_group_rows / kv_L + ...). */
     void* k_tiles; void* v_tiles; int32_t kv_L; float k_scale; const float* gamma_k;
+    int32_t kv_group_rows;
 } gvf_rowblock_args;
-/* layout of gvf_rowblock_args as compiled: {sizeof, offsetof x, in_x, gate1, mod_ld, b_fc1, ln2, b3, hb_out, k_tiles, gamma_k}; returns the count */
+/* layout of gvf_rowblock_args as compiled: {sizeof, offsetof x, in_x, gate1, mod_ld, b_fc1, ln2, b3, hb_out, k_tiles, gamma_k, kv_group_rows};
+   returns the count */
 int gvf_rowblock_args_layout(int32_t* out, int n);
 int64_t gvf_rowblock_packed_bytes(int N, int K);
 int gvf_rowblock_pack_weight(const void* w_bf16, int ldw, int N, int K, void* packed, void* stream);

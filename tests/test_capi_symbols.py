@@ -54,7 +54,7 @@ def test_rowblock_argument_struct_layout_matches_the_library():
     buf = (ctypes.c_int32 * 16)()
     n = l.gvf_rowblock_args_layout(buf, 16)
     A = dit_ops.RowblockArgs
-    mine = [ctypes.sizeof(A)] + [getattr(A, f).offset for f in ("x", "in_x", "gate1", "mod_ld", "b_fc1", "ln2", "b3", "hb_out", "k_tiles", "gamma_k")]
+    mine = [ctypes.sizeof(A)] + [getattr(A, f).offset for f in ("x", "in_x", "gate1", "mod_ld", "b_fc1", "ln2", "b3", "hb_out", "k_tiles", "gamma_k", "kv_group_rows")]
     assert n == len(mine) and list(buf[:n]) == mine
     assert l.gvf_rowblock_fused_bf16(None, None) == _lib.GVF_EINVAL
     a = A()

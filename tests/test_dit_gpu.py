@@ -360,6 +360,41 @@ def test_rowblock_path_of_the_dit_equals_the_unfused_path(cuda):
                                            # the same distance as either has to the bf16-emulating oracle
 
 
+@pytest.mark.parametrize("B,T", [(1, 16), (2, 5), (3, 8)])
+def test_rowblock_path_pads_samples_whose_rows_are_not_whole_blocks(cuda, B, T):
+    """T * 512 tokens that are not a multiple of the kernel's 48-row blocks (T = 16, 32, ...): the row-block path lays every sample out
+    in whole blocks (padding rows computed, never read by an attention, their keys never written) and must agree with the per-sub-layer
+    launches exactly as it does at T = 24; also batch entries must not see each other (sample b of the batch == the sample alone)."""
+    from gvfdiffusion_amd.model.dit import DiT
+    from gvfdiffusion_amd.ops import dit_ops
+    man = json.load(open(os.path.join(GOLD, "dit_manifest.json")))
+    cfg = dict(man["config"], num_blocks=2)
+    net = DiT(**cfg)
+    sd = {k: v for k, v in synthetic.dit_state_dict(man["state_dict"], seed=0).items() if not k.startswith("blocks.") or int(k.split(".")[1]) < 2}
+    net.load_state_dict(sd, strict=True)
+    net = net.to(cuda).eval()
+    assert (T * 512) % dit_ops.ROWBLOCK_ROWS != 0 and dit_ops.rowblock_padded_rows(T * 512) % dit_ops.ROWBLOCK_ROWS == 0
+    i = {k: v.to(cuda) for k, v in synthetic.dit_inputs(B=B, T=T, seed=3).items()}
+    inp = dict(x=i["x"], t=i["t"], cond_images=i["cond_images"], static_latent=i["static_latent"], deformation_position_xyz=i["deformation_position_xyz"])
+    launches = []
+    orig = dit_ops.rowblock_fused
+    dit_ops.rowblock_fused = lambda *a, **k: (launches.append(k.get("kv_group_rows", 0)), orig(*a, **k))[1]
+    try:
+        y1 = net(**inp)
+    finally:
+        dit_ops.rowblock_fused = orig
+    assert len(launches) == 1 + 4 * 2 and max(launches) == T * 512          # the padded row-block path ran
+    net.use_rowblock = False
+    y0 = net(**inp)
+    net.use_rowblock = True
+    r = rel_l2(y1, y0)
+    print(f"B={B} T={T}: padded row-block path vs unfused path rel_l2 {r:.2e}")
+    assert y1.shape == (B, T, 512, cfg["out_channels"]) and torch.isfinite(y1).all() and r < TOL_DIT_VS_BF16_ORACLE
+    if B > 1:
+        one = {k: (v[1:2] if v.shape[0] == B else v) for k, v in inp.items()}
+        assert torch.equal(net(**one)[0], y1[1])
+
+
 def _attn_ref(q, k, v, gq, gk):
     if gq is not None:
         q = dit_ref.rms_norm_heads(q.float(), gq, "bf16")
