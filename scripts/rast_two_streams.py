@@ -16,7 +16,8 @@ for i in range(1, n_streams):
     w.color = torch.empty_like(works[0].color); w.nr = torch.zeros_like(works[0].nr)
     w.ws = torch.empty(w.ws_bytes + 256, dtype=torch.uint8, device=dev); w.ws_base = (w.ws.data_ptr() + 255) // 256 * 256
     works.append(w)
-streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
+prio = [int(p) for p in os.environ.get("GVF_PRIO", "").split(",") if p] or [0] * n_streams
+streams = [torch.cuda.Stream(device=dev, priority=prio[i % len(prio)]) for i in range(n_streams)]
 
 
 def run(ns):
