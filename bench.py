@@ -621,6 +621,12 @@ def main():
                          # the same launch priced on the instances the kernel actually touches (alpha-box culled binning), 36 B each
                          "frac_on_binned_instances": round((work.D_binned * 36 + F * S * S * 12) / blend_s / 1e9 / HBM_PEAK_GBS, 5) if blend_s > 0 else 0,
                          "valu_issue": valu_issue,
+                         # BASELINE's north star prices "tile-sort + blend" together: the per-tile sort moves 8 B in + 4 B out per binned
+                         # instance (PMC: 0.25 GB per launch = exactly that), priced like the blend on upstream's instance count
+                         "tile_sort_plus_blend": (lambda b_, t_: {"alg_bytes": int(b_), "ms": round(t_ * 1e3, 4), "achieved_GBs": round(b_ / t_ / 1e9, 2),
+                                                                  "frac": round(b_ / t_ / 1e9 / HBM_PEAK_GBS, 5)})(
+                             work.alg_bytes_blend_launch() + 12.0 * work.D, (stage_ms["blend"] + stage_ms["tile_sort"]) * 1e-3)
+                         if stage_ms["blend"] + stage_ms["tile_sort"] > 0 else None,
                          "alg_bytes_per_launch": int(work.alg_bytes_blend_launch()),
                          "avg_launch_ms": round(stage_ms["blend"], 4)},
             "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
