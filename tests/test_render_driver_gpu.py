@@ -195,3 +195,35 @@ def test_align_gaussian_to_canonical_recovers_a_known_azimuth(cuda):
     a = np.radians(90.0)
     R2 = torch.tensor([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], dtype=torch.float32, device=cuda)
     assert (gm2.get_xyz - xyz2 @ R2.T).abs().max() < 1e-5
+
+
+@pytest.mark.gpu
+def test_batched_rasteriser_call_is_capturable_in_a_graph(cuda):
+    """include/gvf_rast.h: gvf_rast_forward_batched enqueues kernels only (camera blocks travel as kernel arguments, the per-call tables
+    are cleared by the first launch, no host synchronisation), so a render loop can capture it once and replay it: frames of the replays
+    equal the eager call's, also after the inputs changed in place."""
+    import bench
+    w = bench.RasterWorkload(cuda, 20_000, 256, 6, 2, seed=5)
+    w.step()
+    torch.cuda.synchronize()
+    eager, eager_nr = w.color.clone(), w.nr.clone()
+    assert int(eager_nr.sum()) > 0 and float(eager.std()) > 0
+    s = torch.cuda.Stream(device=cuda)
+    s.wait_stream(torch.cuda.current_stream(cuda))
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        w.color.zero_()
+        with torch.cuda.graph(g, stream=s):
+            w.step()
+    for _ in range(2):
+        w.color.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(w.color, eager) and torch.equal(w.nr, eager_nr)
+    w.delta.mul_(0.5)                                   # same buffers, new contents: the replay renders the new sample
+    g.replay()
+    torch.cuda.synchronize()
+    replayed = w.color.clone()
+    w.step()
+    torch.cuda.synchronize()
+    assert torch.equal(w.color, replayed) and not torch.equal(replayed, eager)
