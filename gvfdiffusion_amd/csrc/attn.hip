@@ -174,6 +174,67 @@ __device__ __forceinline__ void tile64(const uint4* __restrict__ sKb, const unsi
         }
 }
 
+// The same step without the running maximum, for keys that were staged PRE-MULTIPLIED by softmax_scale * log2(e) (the K/V-resident
+// kernel does that in fp32 before the one rounding to bf16, as the tiled cache of attn_xt.hip does): the MFMA result is the exp2
+// argument, P = exp2(s), l += sum P.  No maximum tree, no subtraction, no rescale of O: 16 max3 + 32 fma fewer per 64 keys, and the
+// exponentials of one half-tile can issue while the matrix pipe still works on the other.  Valid while no exp2 overflows or all of
+// them vanish; the caller checks the denominators and falls back to tile64 (exact for any input).
+template <int D, bool MASKED>
+__device__ __forceinline__ void tile64_nomax(const uint4* __restrict__ sKb, const unsigned short* __restrict__ sVTb, int key0, int Lk,
+                                             const bf16x8 (&qf)[Cfg<D>::NS], int l31, int half, f32x16 (&o_acc)[Cfg<D>::ND], float& l_run) {
+    using C = Cfg<D>;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 s_acc[2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+        const int krow_l = sub * 32 + l31;
+        const int sw = C::swz(krow_l);
+        s_acc[sub] = zero;
+#pragma unroll
+        for (int st = 0; st < C::NS; ++st) {
+            const bf16x8 kf = __builtin_bit_cast(bf16x8, sKb[krow_l * C::KC + ((2 * st + half) ^ sw)]);
+            s_acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], s_acc[sub], 0, 0, 0);
+        }
+    }
+    float psum = 0.f;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+        unsigned pw[8];
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            float p0 = __builtin_amdgcn_exp2f(s_acc[sub][r]), p1 = __builtin_amdgcn_exp2f(s_acc[sub][r + 1]);
+            if (MASKED) {
+                if ((key0 + 32 * sub + (r & 3) + 8 * (r >> 2) + 4 * half) >= Lk) p0 = 0.f;
+                if ((key0 + 32 * sub + ((r + 1) & 3) + 8 * ((r + 1) >> 2) + 4 * half) >= Lk) p1 = 0.f;
+            }
+            psum += p0 + p1;
+            pw[r >> 1] = cvt_pk_bf16(p0, p1);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, make_uint4(pw[4 * u], pw[4 * u + 1], pw[4 * u + 2], pw[4 * u + 3]));
+#pragma unroll
+            for (int dt = 0; dt < C::ND; ++dt) {
+                const unsigned short* vrow = sVTb + (dt * 32 + l31) * VT_LD + sub * 32 + 16 * u + 4 * half;
+                const uint2 va = *reinterpret_cast<const uint2*>(vrow);        // keys +0..3
+                const uint2 vb = *reinterpret_cast<const uint2*>(vrow + 8);    // keys +8..11
+                const bf16x8 vf = __builtin_bit_cast(bf16x8, make_uint4(va.x, va.y, vb.x, vb.y));
+                o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o_acc[dt], 0, 0, 0);
+            }
+        }
+    }
+    l_run += psum;
+}
+
+// 8 bf16 times a scalar, in fp32, one rounding
+__device__ __forceinline__ uint4 scale8(uint4 raw, float sc) {
+    unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        w[i] = (unsigned)f2bf(bf2f((unsigned short)(w[i] & 0xffffu)) * sc) | ((unsigned)f2bf(bf2f((unsigned short)(w[i] >> 16)) * sc) << 16);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 // D: head dim (32: the DiT; 64: the VAEs).  VT: V is given transposed ([d][key], keys contiguous; v_sl = d
 // stride) -- the layout the DiT's step-invariant cross-attention cache is stored in, so staging is a straight copy.
 template <int D, bool VT>
@@ -353,6 +414,9 @@ constexpr int RES_THREADS = 512;
 constexpr int RES_MAX_TILES = 8;
 constexpr int RES_ROUND = 4;                 // staging chunks per thread in flight per round
 
+#ifndef RES_NOMAX
+#define RES_NOMAX 1            // K/V-resident kernel: softmax without the running maximum (exact fallback per wave); 0 = always exact
+#endif
 template <int D>
 constexpr int res_vt_tile() { return D * VT_LD + 8; }          // ushorts per V^T tile (16-byte multiple)
 
@@ -420,6 +484,7 @@ __global__ __launch_bounds__(RES_THREADS) void attn_kvres_kernel(AttnParams p, i
                 if (C::KC == 8) ss += __shfl_xor(ss, 4, 64);
                 kw = rms_apply<D>(kw, ss, gk8);
             }
+            if (RES_NOMAX) kw = scale8(kw, p.scale_log2e);   // the scores then ARE the exp2 arguments (tile64_nomax)
             if (c < total) {
                 sK[(size_t)kt * CPT + kin * C::KC + (st_c ^ C::swz(kin))] = kw;
                 unsigned short* vt = sVT + (size_t)kt * res_vt_tile<D>();
@@ -472,11 +537,35 @@ __global__ __launch_bounds__(RES_THREADS) void attn_kvres_kernel(AttnParams p, i
 #pragma unroll
             for (int r = 0; r < 16; ++r) o_acc[dt][r] = 0.f;
         float m_run = -INFINITY, l_run = 0.f;
-        for (int kt = 0; kt < n_tiles; ++kt) {
-            const uint4* kb = sK + (size_t)kt * CPT;
-            const unsigned short* vb = sVT + (size_t)kt * res_vt_tile<D>();
-            if (kt < last_full) tile64<D, false>(kb, vb, kt * KT, Lk, p.scale_log2e, qf, l31, half, o_acc, m_run, l_run);
-            else tile64<D, true>(kb, vb, kt * KT, Lk, p.scale_log2e, qf, l31, half, o_acc, m_run, l_run);
+        bool exact = !RES_NOMAX;
+        if (RES_NOMAX) {
+            for (int kt = 0; kt < n_tiles; ++kt) {
+                const uint4* kb = sK + (size_t)kt * CPT;
+                const unsigned short* vb = sVT + (size_t)kt * res_vt_tile<D>();
+                if (kt < last_full) tile64_nomax<D, false>(kb, vb, kt * KT, Lk, qf, l31, half, o_acc, l_run);
+                else tile64_nomax<D, true>(kb, vb, kt * KT, Lk, qf, l31, half, o_acc, l_run);
+            }
+            // every query's denominator must be finite and in range (2^-100 .. 2^100: no exp2 overflowed, not all of them vanished);
+            // otherwise the WAVE redoes its 32 queries with the running-maximum softmax (keys are pre-scaled: scale 1)
+            const float l_chk = l_run + __shfl_xor(l_run, 32, 64);
+            const bool bad = qvalid && !(l_chk > 7.888609e-31f && l_chk < 1.2676506e30f);
+            if (__any(bad)) {
+                exact = true;
+                l_run = 0.f;
+#pragma unroll
+                for (int dt = 0; dt < C::ND; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o_acc[dt][r] = 0.f;
+            }
+        }
+        if (exact) {
+            const float sc = RES_NOMAX ? 1.0f : p.scale_log2e;
+            for (int kt = 0; kt < n_tiles; ++kt) {
+                const uint4* kb = sK + (size_t)kt * CPT;
+                const unsigned short* vb = sVT + (size_t)kt * res_vt_tile<D>();
+                if (kt < last_full) tile64<D, false>(kb, vb, kt * KT, Lk, sc, qf, l31, half, o_acc, m_run, l_run);
+                else tile64<D, true>(kb, vb, kt * KT, Lk, sc, qf, l31, half, o_acc, m_run, l_run);
+            }
         }
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
         if (qvalid) {
