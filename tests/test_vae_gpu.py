@@ -195,3 +195,27 @@ def test_kv_resident_attention_variant_forced_everywhere(cuda):
                         "tests/test_vae_gpu.py::test_encode_head_dim_64", "tests/test_sparse.py", "tests/test_sparse_vae_gpu.py::test_released_width_ragged_batch"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_kv_resident_attention_survives_scores_that_overflow_exp2(cuda):
+    """The K/V-resident kernel (decoder cross attention: head_dim 64, transposed V, 512 keys, >= 1024 queries) computes P = exp2(s)
+    without a running maximum and checks every denominator: a query whose scores exceed the exponent range must come out of the exact
+    running-maximum pass, its neighbours in other waves unaffected."""
+    from gvfdiffusion_amd.ops import dit_ops
+    g = torch.Generator().manual_seed(11)
+    Lq, Lk, H, D = 2048, 512, 2, 64
+    q = torch.randn((1, Lq, H, D), generator=g)
+    k = torch.randn((1, Lk, H, D), generator=g)
+    v = torch.randn((1, Lk, H, D), generator=g)
+    q[0, 5] *= 400.0                                           # |s| ~ 400 * 8 / sqrt(64) * log2 e: exp2 overflows
+    q[0, 1500, 1] *= -300.0
+    qb, kb, vb = (t.to(torch.bfloat16).to(cuda) for t in (q, k, v))
+    vt = vb.permute(0, 2, 3, 1).contiguous()                   # [1][H][D][Lk]: keys contiguous
+    out = torch.empty_like(qb)
+    sq, sk = (Lq * H * D, 0, H * D, D), (Lk * H * D, 0, H * D, D)
+    dit_ops.attention_bf16(qb, kb, vt, out, 1, 1, Lq, Lk, H, sq, sk, (H * D * Lk, 0, Lk, D * Lk), sq, v_transposed=True, head_dim=D)
+    s = torch.einsum("blhd,bmhd->bhlm", qb.float(), kb.float()) * D ** -0.5
+    ref = torch.einsum("bhlm,bmhd->blhd", torch.softmax(s, dim=-1), vb.float())
+    assert torch.isfinite(out).all()
+    err = (out.float() - ref).norm(dim=-1) / ref.norm(dim=-1).clamp_min(1e-6)
+    assert float(err[0, 5].max()) < 2e-2 and float(err[0, 1500].max()) < 2e-2 and float(err.max()) < 3e-2, (err[0, 5], err.max())
