@@ -179,51 +179,72 @@ __device__ __forceinline__ void tile64(const uint4* __restrict__ sKb, const unsi
 // argument, P = exp2(s), l += sum P.  No maximum tree, no subtraction, no rescale of O: 16 max3 + 32 fma fewer per 64 keys, and the
 // exponentials of one half-tile can issue while the matrix pipe still works on the other.  Valid while no exp2 overflows or all of
 // them vanish; the caller checks the denominators and falls back to tile64 (exact for any input).
-template <int D, bool MASKED>
+template <int D, bool MASKED, int NQ>
 __device__ __forceinline__ void tile64_nomax(const uint4* __restrict__ sKb, const unsigned short* __restrict__ sVTb, int key0, int Lk,
-                                             const bf16x8 (&qf)[Cfg<D>::NS], int l31, int half, f32x16 (&o_acc)[Cfg<D>::ND], float& l_run) {
+                                             const bf16x8 (&qf)[NQ][Cfg<D>::NS], int l31, int half, f32x16 (&o_acc)[NQ][Cfg<D>::ND],
+                                             float (&l_run)[NQ]) {
+    // NQ 32-query tiles of the wave against the same 64 keys: every K / V^T fragment read from LDS feeds NQ MFMAs (the LDS port, not
+    // the matrix pipe, bounds this kernel: 16 KiB of fragments per tile per wave with one query tile)
     using C = Cfg<D>;
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    f32x16 s_acc[2];
+    f32x16 s_acc[NQ][2];
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
         const int krow_l = sub * 32 + l31;
         const int sw = C::swz(krow_l);
-        s_acc[sub] = zero;
+#pragma unroll
+        for (int t = 0; t < NQ; ++t) s_acc[t][sub] = zero;
 #pragma unroll
         for (int st = 0; st < C::NS; ++st) {
             const bf16x8 kf = __builtin_bit_cast(bf16x8, sKb[krow_l * C::KC + ((2 * st + half) ^ sw)]);
-            s_acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], s_acc[sub], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NQ; ++t) s_acc[t][sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[t][st], s_acc[t][sub], 0, 0, 0);
         }
     }
-    float psum = 0.f;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
-        unsigned pw[8];
+        unsigned pw[NQ][8];
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-            float p0 = __builtin_amdgcn_exp2f(s_acc[sub][r]), p1 = __builtin_amdgcn_exp2f(s_acc[sub][r + 1]);
-            if (MASKED) {
-                if ((key0 + 32 * sub + (r & 3) + 8 * (r >> 2) + 4 * half) >= Lk) p0 = 0.f;
-                if ((key0 + 32 * sub + ((r + 1) & 3) + 8 * ((r + 1) >> 2) + 4 * half) >= Lk) p1 = 0.f;
+        for (int t = 0; t < NQ; ++t) {
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                float p0 = __builtin_amdgcn_exp2f(s_acc[t][sub][r]), p1 = __builtin_amdgcn_exp2f(s_acc[t][sub][r + 1]);
+                if (MASKED) {
+                    if ((key0 + 32 * sub + (r & 3) + 8 * (r >> 2) + 4 * half) >= Lk) p0 = 0.f;
+                    if ((key0 + 32 * sub + ((r + 1) & 3) + 8 * ((r + 1) >> 2) + 4 * half) >= Lk) p1 = 0.f;
+                }
+                psum += p0 + p1;
+                pw[t][r >> 1] = cvt_pk_bf16(p0, p1);
             }
-            psum += p0 + p1;
-            pw[r >> 1] = cvt_pk_bf16(p0, p1);
+            l_run[t] += psum;
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const bf16x8 pf = __builtin_bit_cast(bf16x8, make_uint4(pw[4 * u], pw[4 * u + 1], pw[4 * u + 2], pw[4 * u + 3]));
 #pragma unroll
             for (int dt = 0; dt < C::ND; ++dt) {
                 const unsigned short* vrow = sVTb + (dt * 32 + l31) * VT_LD + sub * 32 + 16 * u + 4 * half;
                 const uint2 va = *reinterpret_cast<const uint2*>(vrow);        // keys +0..3
                 const uint2 vb = *reinterpret_cast<const uint2*>(vrow + 8);    // keys +8..11
                 const bf16x8 vf = __builtin_bit_cast(bf16x8, make_uint4(va.x, va.y, vb.x, vb.y));
-                o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o_acc[dt], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NQ; ++t) {
+                    const bf16x8 pf = __builtin_bit_cast(bf16x8, make_uint4(pw[t][4 * u], pw[t][4 * u + 1], pw[t][4 * u + 2], pw[t][4 * u + 3]));
+                    o_acc[t][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o_acc[t][dt], 0, 0, 0);
+                }
             }
         }
     }
-    l_run += psum;
+#if RES_SCHED
+    // ask the scheduler for an MFMA : VALU interleave over the whole tile (the QK^T MFMAs of one query tile are independent of the
+    // exponentials of the other): one matrix instruction, then a handful of vector ones, repeated
+#pragma unroll
+    for (int i = 0; i < 16 * NQ; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, RES_SCHED, 0);
+    }
+#endif
 }
 
 // 8 bf16 times a scalar, in fp32, one rounding
@@ -417,6 +438,12 @@ constexpr int RES_ROUND = 4;                 // staging chunks per thread in fli
 #ifndef RES_NOMAX
 #define RES_NOMAX 1            // K/V-resident kernel: softmax without the running maximum (exact fallback per wave); 0 = always exact
 #endif
+#ifndef RES_SCHED
+#define RES_SCHED 6            // VALU instructions asked for behind every MFMA of a max-free tile step (0: scheduler's own order)
+#endif
+#ifndef RES_NQ
+#define RES_NQ 2               // 32-query tiles a wave runs against each staged key tile at once (shared fragment reads)
+#endif
 template <int D>
 constexpr int res_vt_tile() { return D * VT_LD + 8; }          // ushorts per V^T tile (16-byte multiple)
 
@@ -507,79 +534,98 @@ __global__ __launch_bounds__(RES_THREADS) void attn_kvres_kernel(AttnParams p, i
     }
     __syncthreads();
 
-    // ---- every wave: its 32-query tiles over all key tiles, straight from LDS
-    for (int qt = 0; qt < qt_per_wg; ++qt) {
-        const int q0 = (qb * qt_per_wg + qt) * (RES_THREADS / 2) + wave * 32;
-        if (q0 >= Lq) break;                                  // wave-uniform
-        const int qrow = q0 + l31;
-        const bool qvalid = qrow < Lq;
-        uint4 qraw[C::NS];
+    // ---- every wave: its 32-query tiles over all key tiles, straight from LDS; RES_NQ tiles at a time (passes qt, qt + 1, ...)
+    constexpr int NQ = RES_NOMAX ? RES_NQ : 1;
+    for (int qt = 0; qt < qt_per_wg; qt += NQ) {
+        int qrow[NQ];
+        bool qvalid[NQ];
 #pragma unroll
-        for (int s2 = 0; s2 < C::NS; ++s2) {
-            const uint4 v4 = *reinterpret_cast<const uint4*>(qp + (long long)(qvalid ? qrow : 0) * p.q_sl + 16 * s2 + 8 * half);
-            const unsigned m = qvalid ? 0xffffffffu : 0u;
-            qraw[s2] = make_uint4(v4.x & m, v4.y & m, v4.z & m, v4.w & m);
+        for (int t = 0; t < NQ; ++t) {
+            const int q0 = (qb * qt_per_wg + qt + t) * (RES_THREADS / 2) + wave * 32;
+            qrow[t] = q0 + l31;
+            qvalid[t] = qt + t < qt_per_wg && qrow[t] < Lq;
         }
-        if (p.gamma_q != nullptr) {
-            float ss = 0.f;
+        if ((qb * qt_per_wg + qt) * (RES_THREADS / 2) + wave * 32 >= Lq) break;      // wave-uniform
+        bf16x8 qf[NQ][C::NS];
 #pragma unroll
-            for (int s2 = 0; s2 < C::NS; ++s2) ss += sumsq8(qraw[s2]);
-            ss += __shfl_xor(ss, 32, 64);
+        for (int t = 0; t < NQ; ++t) {
+            uint4 qraw[C::NS];
 #pragma unroll
-            for (int s2 = 0; s2 < C::NS; ++s2) qraw[s2] = rms_apply<D>(qraw[s2], ss, p.gamma_q + head * D + 16 * s2 + 8 * half);
+            for (int s2 = 0; s2 < C::NS; ++s2) {
+                const uint4 v4 = *reinterpret_cast<const uint4*>(qp + (long long)(qvalid[t] ? qrow[t] : 0) * p.q_sl + 16 * s2 + 8 * half);
+                const unsigned m = qvalid[t] ? 0xffffffffu : 0u;
+                qraw[s2] = make_uint4(v4.x & m, v4.y & m, v4.z & m, v4.w & m);
+            }
+            if (p.gamma_q != nullptr) {
+                float ss = 0.f;
+#pragma unroll
+                for (int s2 = 0; s2 < C::NS; ++s2) ss += sumsq8(qraw[s2]);
+                ss += __shfl_xor(ss, 32, 64);
+#pragma unroll
+                for (int s2 = 0; s2 < C::NS; ++s2) qraw[s2] = rms_apply<D>(qraw[s2], ss, p.gamma_q + head * D + 16 * s2 + 8 * half);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < C::NS; ++s2) qf[t][s2] = __builtin_bit_cast(bf16x8, qraw[s2]);
         }
-        bf16x8 qf[C::NS];
+        f32x16 o_acc[NQ][C::ND];
+        float l_run[NQ], m_run[NQ];
+        bool exact[NQ];
 #pragma unroll
-        for (int s2 = 0; s2 < C::NS; ++s2) qf[s2] = __builtin_bit_cast(bf16x8, qraw[s2]);
-        f32x16 o_acc[C::ND];
+        for (int t = 0; t < NQ; ++t) {
+            l_run[t] = 0.f; m_run[t] = -INFINITY; exact[t] = !RES_NOMAX;
 #pragma unroll
-        for (int dt = 0; dt < C::ND; ++dt)
+            for (int dt = 0; dt < C::ND; ++dt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o_acc[dt][r] = 0.f;
-        float m_run = -INFINITY, l_run = 0.f;
-        bool exact = !RES_NOMAX;
+                for (int r = 0; r < 16; ++r) o_acc[t][dt][r] = 0.f;
+        }
         if (RES_NOMAX) {
             for (int kt = 0; kt < n_tiles; ++kt) {
                 const uint4* kb = sK + (size_t)kt * CPT;
                 const unsigned short* vb = sVT + (size_t)kt * res_vt_tile<D>();
-                if (kt < last_full) tile64_nomax<D, false>(kb, vb, kt * KT, Lk, qf, l31, half, o_acc, l_run);
-                else tile64_nomax<D, true>(kb, vb, kt * KT, Lk, qf, l31, half, o_acc, l_run);
+                if (kt < last_full) tile64_nomax<D, false, NQ>(kb, vb, kt * KT, Lk, qf, l31, half, o_acc, l_run);
+                else tile64_nomax<D, true, NQ>(kb, vb, kt * KT, Lk, qf, l31, half, o_acc, l_run);
             }
             // every query's denominator must be finite and in range (2^-100 .. 2^100: no exp2 overflowed, not all of them vanished);
-            // otherwise the WAVE redoes its 32 queries with the running-maximum softmax (keys are pre-scaled: scale 1)
-            const float l_chk = l_run + __shfl_xor(l_run, 32, 64);
-            const bool bad = qvalid && !(l_chk > 7.888609e-31f && l_chk < 1.2676506e30f);
-            if (__any(bad)) {
-                exact = true;
-                l_run = 0.f;
+            // otherwise the WAVE redoes that 32-query tile with the running-maximum softmax (keys are pre-scaled: scale 1)
+#pragma unroll
+            for (int t = 0; t < NQ; ++t) {
+                const float l_chk = l_run[t] + __shfl_xor(l_run[t], 32, 64);
+                const bool bad = qvalid[t] && !(l_chk > 7.888609e-31f && l_chk < 1.2676506e30f);
+                if (__any(bad)) {
+                    exact[t] = true;
+                    l_run[t] = 0.f;
+#pragma unroll
+                    for (int dt = 0; dt < C::ND; ++dt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o_acc[t][dt][r] = 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NQ; ++t) {
+            if (exact[t]) {
+                const float sc = RES_NOMAX ? 1.0f : p.scale_log2e;
+                for (int kt = 0; kt < n_tiles; ++kt) {
+                    const uint4* kb = sK + (size_t)kt * CPT;
+                    const unsigned short* vb = sVT + (size_t)kt * res_vt_tile<D>();
+                    if (kt < last_full) tile64<D, false>(kb, vb, kt * KT, Lk, sc, qf[t], l31, half, o_acc[t], m_run[t], l_run[t]);
+                    else tile64<D, true>(kb, vb, kt * KT, Lk, sc, qf[t], l31, half, o_acc[t], m_run[t], l_run[t]);
+                }
+            }
+            const float l_tot = l_run[t] + __shfl_xor(l_run[t], 32, 64);
+            if (qvalid[t]) {
+                const float inv = 1.0f / l_tot;
+                unsigned short* orow = op + (long long)qrow[t] * p.o_sl;
 #pragma unroll
                 for (int dt = 0; dt < C::ND; ++dt)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) o_acc[dt][r] = 0.f;
+                    for (int g = 0; g < 4; ++g) {
+                        uint2 w2;
+                        w2.x = cvt_pk_bf16(o_acc[t][dt][4 * g] * inv, o_acc[t][dt][4 * g + 1] * inv);
+                        w2.y = cvt_pk_bf16(o_acc[t][dt][4 * g + 2] * inv, o_acc[t][dt][4 * g + 3] * inv);
+                        *reinterpret_cast<uint2*>(orow + dt * 32 + 8 * g + 4 * half) = w2;
+                    }
             }
-        }
-        if (exact) {
-            const float sc = RES_NOMAX ? 1.0f : p.scale_log2e;
-            for (int kt = 0; kt < n_tiles; ++kt) {
-                const uint4* kb = sK + (size_t)kt * CPT;
-                const unsigned short* vb = sVT + (size_t)kt * res_vt_tile<D>();
-                if (kt < last_full) tile64<D, false>(kb, vb, kt * KT, Lk, sc, qf, l31, half, o_acc, m_run, l_run);
-                else tile64<D, true>(kb, vb, kt * KT, Lk, sc, qf, l31, half, o_acc, m_run, l_run);
-            }
-        }
-        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-        if (qvalid) {
-            const float inv = 1.0f / l_tot;
-            unsigned short* orow = op + (long long)qrow * p.o_sl;
-#pragma unroll
-            for (int dt = 0; dt < C::ND; ++dt)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    uint2 w2;
-                    w2.x = cvt_pk_bf16(o_acc[dt][4 * g] * inv, o_acc[dt][4 * g + 1] * inv);
-                    w2.y = cvt_pk_bf16(o_acc[dt][4 * g + 2] * inv, o_acc[dt][4 * g + 3] * inv);
-                    *reinterpret_cast<uint2*>(orow + dt * 32 + 8 * g + 4 * half) = w2;
-                }
         }
     }
 }
