@@ -143,7 +143,10 @@ int gvf_rast_backward(const GvfRastSettings* settings_host, const GvfRastFrame* 
  *   frames_host[F].
  * Outputs: out_color[F][3][H][W]; out_alpha/out_depth [F][H][W] or null; out_radii[F][P] or null;
  *   out_num_rendered[F] device uint32 (per-frame instance counts; their sum must be
- *   <= max_rendered, else frames past the overflow point are not rendered correctly). */
+ *   <= max_rendered, else frames past the overflow point are not rendered correctly).
+ * The call only enqueues kernels on `stream` (camera blocks travel as kernel arguments, per-call tables are cleared by the first
+ * launch, nothing is read back): it can be captured in a hipGraph and replayed -- after ONE ordinary call in the process, which
+ * sets a function attribute of the large-segment sort kernel (not allowed inside a capture). */
 int gvf_rast_forward_batched(const GvfRastSettings* settings_host, const GvfRastFrame* frames_host, int F,
                              const GvfGaussianActivation* act_host,
                              int P, int M,
