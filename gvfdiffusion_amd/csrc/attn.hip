@@ -16,13 +16,13 @@
 // fp32 online softmax (running max / sum per query, exp2 with log2e folded into the scale).
 #include <cstdlib>
 #include "gvf_common.h"
+#include "gvf_lp.h"
 #include "../../include/gvf_rast.h"
 #include "../../include/gvf_dit.h"
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef gvf_f32x16 f32x16;
 
 constexpr int QB = 128;          // queries per workgroup
 constexpr int KT = 64;           // keys per staged tile
@@ -30,27 +30,13 @@ constexpr int THREADS = 256;
 constexpr int VT_LD = KT + 4;    // row stride (bf16) of the transposed V tile: 34 dwords -> the 32 rows a wave reads with
                                  // ds_read_b64 start on 32 distinct even banks (conflict-free); rows stay 8-byte aligned
 
-__device__ __forceinline__ unsigned short f2bf(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
-// two f32 -> packed bf16x2 (lo in bits 0-15), round-to-nearest-even.  Written as plain conversions: hipcc
-// selects v_cvt_pk_bf16_f32 itself, and (unlike an asm statement) pads the VALU -> MFMA operand hazard.
-__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-    bf16x2 v;
-    v[0] = (__bf16)lo;
-    v[1] = (__bf16)hi;
-    return __builtin_bit_cast(unsigned, v);
-}
+// (two f32 -> packed 16-bit pair: GvfLp<DT>::pack, plain conversions -- hipcc selects v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32 itself and,
+// unlike an asm statement, pads the VALU -> MFMA operand hazard)
 // fmaxf on MFMA results: compiled with -fno-honor-nans (see _build.py), otherwise hipcc puts a canonicalising
 // v_max_f32 x,x (IEEE-mode sNaN quieting) in front of every operand -- 3x the instructions.  No inline asm
 // here on purpose: an asm statement reading an MFMA result is not covered by the compiler's hazard padding.
 __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 __device__ __forceinline__ float max2f(float a, float b) { return fmaxf(a, b); }
-__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
 
 struct AttnParams {
     const unsigned short *q, *k, *v;
@@ -63,24 +49,23 @@ struct AttnParams {
 };
 
 // 8 bf16 (one 16-byte chunk of a head row) -> RMS-normalised * gamma * sqrt(D), given the row's sum of squares
-template <int D>
+template <int D, int DT>
 __device__ __forceinline__ uint4 rms_apply(uint4 raw, float sumsq, const float* g8) {
     const float inv = (D == 32 ? 5.656854249492381f : 8.0f) / fmaxf(sqrtf(sumsq), 1e-12f);   // sqrt(D) / max(||x||, eps)
     unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        float lo = bf2f((unsigned short)(w[i] & 0xffffu)) * inv * g8[2 * i];
-        float hi = bf2f((unsigned short)(w[i] >> 16)) * inv * g8[2 * i + 1];
-        w[i] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+        w[i] = GvfLp<DT>::pack(GvfLp<DT>::lo(w[i]) * inv * g8[2 * i], GvfLp<DT>::hi(w[i]) * inv * g8[2 * i + 1]);
     }
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
+template <int DT>
 __device__ __forceinline__ float sumsq8(uint4 raw) {
     unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        float lo = bf2f((unsigned short)(w[i] & 0xffffu)), hi = bf2f((unsigned short)(w[i] >> 16));
+        float lo = GvfLp<DT>::lo(w[i]), hi = GvfLp<DT>::hi(w[i]);
         s += lo * lo + hi * hi;
     }
     return s;
@@ -99,11 +84,13 @@ struct Cfg {
 // One staged 64-key tile for the 32 queries of a wave: S^T = K Q^T (both 32-key halves issued back to back),
 // ONE online-softmax update for the 64 keys, O^T += V^T P^T.  Issuing all QK^T MFMAs first and all P V MFMAs
 // last leaves long straight-line stretches in which the matrix pipe works while the VALU does the softmax.
-template <int D, bool MASKED>
+template <int D, bool MASKED, int DT>
 __device__ __forceinline__ void tile64(const uint4* __restrict__ sKb, const unsigned short* __restrict__ sVTb, int key0,
-                                       int Lk, float scale_log2e, const bf16x8 (&qf)[Cfg<D>::NS], int l31, int half,
+                                       int Lk, float scale_log2e, const typename GvfLp<DT>::x8 (&qf)[Cfg<D>::NS], int l31, int half,
                                        f32x16 (&o_acc)[Cfg<D>::ND], float& m_run, float& l_run) {
     using C = Cfg<D>;
+    typedef GvfLp<DT> LP;
+    typedef typename LP::x8 x8;
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x16 s_acc[2];
 #pragma unroll
@@ -113,8 +100,8 @@ __device__ __forceinline__ void tile64(const uint4* __restrict__ sKb, const unsi
         s_acc[sub] = zero;
 #pragma unroll
         for (int st = 0; st < C::NS; ++st) {
-            const bf16x8 kf = __builtin_bit_cast(bf16x8, sKb[krow_l * C::KC + ((2 * st + half) ^ sw)]);
-            s_acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], s_acc[sub], 0, 0, 0);
+            const x8 kf = __builtin_bit_cast(x8, sKb[krow_l * C::KC + ((2 * st + half) ^ sw)]);
+            s_acc[sub] = LP::mfma32(kf, qf[st], s_acc[sub]);
         }
     }
     // accumulator row r of half-tile `sub` is key  key0 + 32*sub + (r&3) + 8*(r>>2) + 4*half
@@ -154,7 +141,7 @@ __device__ __forceinline__ void tile64(const uint4* __restrict__ sKb, const unsi
             const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[sub][r], scale_log2e, -m_run));
             const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[sub][r + 1], scale_log2e, -m_run));
             psum += p0 + p1;
-            pw[sub][r >> 1] = cvt_pk_bf16(p0, p1);
+            pw[sub][r >> 1] = LP::pack(p0, p1);
         }
     l_run += psum;
     // O^T[d][q] += sum_slots V^T[d][key(slot)] P^T[key(slot)][q]; slot (u, half, e) = accumulator row 8u+e
@@ -162,14 +149,14 @@ __device__ __forceinline__ void tile64(const uint4* __restrict__ sKb, const unsi
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const bf16x8 pf = __builtin_bit_cast(bf16x8, make_uint4(pw[sub][4 * u], pw[sub][4 * u + 1], pw[sub][4 * u + 2], pw[sub][4 * u + 3]));
+            const x8 pf = __builtin_bit_cast(x8, make_uint4(pw[sub][4 * u], pw[sub][4 * u + 1], pw[sub][4 * u + 2], pw[sub][4 * u + 3]));
 #pragma unroll
             for (int dt = 0; dt < C::ND; ++dt) {
                 const unsigned short* vrow = sVTb + (dt * 32 + l31) * VT_LD + sub * 32 + 16 * u + 4 * half;
                 const uint2 va = *reinterpret_cast<const uint2*>(vrow);        // keys +0..3
                 const uint2 vb = *reinterpret_cast<const uint2*>(vrow + 8);    // keys +8..11
-                const bf16x8 vf = __builtin_bit_cast(bf16x8, make_uint4(va.x, va.y, vb.x, vb.y));
-                o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o_acc[dt], 0, 0, 0);
+                const x8 vf = __builtin_bit_cast(x8, make_uint4(va.x, va.y, vb.x, vb.y));
+                o_acc[dt] = LP::mfma32(vf, pf, o_acc[dt]);
             }
         }
 }
@@ -179,10 +166,12 @@ __device__ __forceinline__ void tile64(const uint4* __restrict__ sKb, const unsi
 // argument, P = exp2(s), l += sum P.  No maximum tree, no subtraction, no rescale of O: 16 max3 + 32 fma fewer per 64 keys, and the
 // exponentials of one half-tile can issue while the matrix pipe still works on the other.  Valid while no exp2 overflows or all of
 // them vanish; the caller checks the denominators and falls back to tile64 (exact for any input).
-template <int D, bool MASKED, int NQ>
+template <int D, bool MASKED, int NQ, int DT>
 __device__ __forceinline__ void tile64_nomax(const uint4* __restrict__ sKb, const unsigned short* __restrict__ sVTb, int key0, int Lk,
-                                             const bf16x8 (&qf)[NQ][Cfg<D>::NS], int l31, int half, f32x16 (&o_acc)[NQ][Cfg<D>::ND],
+                                             const typename GvfLp<DT>::x8 (&qf)[NQ][Cfg<D>::NS], int l31, int half, f32x16 (&o_acc)[NQ][Cfg<D>::ND],
                                              float (&l_run)[NQ]) {
+    typedef GvfLp<DT> LP;
+    typedef typename LP::x8 x8;
     // NQ 32-query tiles of the wave against the same 64 keys: every K / V^T fragment read from LDS feeds NQ MFMAs (the LDS port, not
     // the matrix pipe, bounds this kernel: 16 KiB of fragments per tile per wave with one query tile)
     using C = Cfg<D>;
@@ -196,9 +185,9 @@ __device__ __forceinline__ void tile64_nomax(const uint4* __restrict__ sKb, cons
         for (int t = 0; t < NQ; ++t) s_acc[t][sub] = zero;
 #pragma unroll
         for (int st = 0; st < C::NS; ++st) {
-            const bf16x8 kf = __builtin_bit_cast(bf16x8, sKb[krow_l * C::KC + ((2 * st + half) ^ sw)]);
+            const x8 kf = __builtin_bit_cast(x8, sKb[krow_l * C::KC + ((2 * st + half) ^ sw)]);
 #pragma unroll
-            for (int t = 0; t < NQ; ++t) s_acc[t][sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[t][st], s_acc[t][sub], 0, 0, 0);
+            for (int t = 0; t < NQ; ++t) s_acc[t][sub] = LP::mfma32(kf, qf[t][st], s_acc[t][sub]);
         }
     }
 #pragma unroll
@@ -215,7 +204,7 @@ __device__ __forceinline__ void tile64_nomax(const uint4* __restrict__ sKb, cons
                     if ((key0 + 32 * sub + ((r + 1) & 3) + 8 * ((r + 1) >> 2) + 4 * half) >= Lk) p1 = 0.f;
                 }
                 psum += p0 + p1;
-                pw[t][r >> 1] = cvt_pk_bf16(p0, p1);
+                pw[t][r >> 1] = LP::pack(p0, p1);
             }
             l_run[t] += psum;
         }
@@ -226,11 +215,11 @@ __device__ __forceinline__ void tile64_nomax(const uint4* __restrict__ sKb, cons
                 const unsigned short* vrow = sVTb + (dt * 32 + l31) * VT_LD + sub * 32 + 16 * u + 4 * half;
                 const uint2 va = *reinterpret_cast<const uint2*>(vrow);        // keys +0..3
                 const uint2 vb = *reinterpret_cast<const uint2*>(vrow + 8);    // keys +8..11
-                const bf16x8 vf = __builtin_bit_cast(bf16x8, make_uint4(va.x, va.y, vb.x, vb.y));
+                const x8 vf = __builtin_bit_cast(x8, make_uint4(va.x, va.y, vb.x, vb.y));
 #pragma unroll
                 for (int t = 0; t < NQ; ++t) {
-                    const bf16x8 pf = __builtin_bit_cast(bf16x8, make_uint4(pw[t][4 * u], pw[t][4 * u + 1], pw[t][4 * u + 2], pw[t][4 * u + 3]));
-                    o_acc[t][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o_acc[t][dt], 0, 0, 0);
+                    const x8 pf = __builtin_bit_cast(x8, make_uint4(pw[t][4 * u], pw[t][4 * u + 1], pw[t][4 * u + 2], pw[t][4 * u + 3]));
+                    o_acc[t][dt] = LP::mfma32(vf, pf, o_acc[t][dt]);
                 }
             }
         }
@@ -247,20 +236,22 @@ __device__ __forceinline__ void tile64_nomax(const uint4* __restrict__ sKb, cons
 #endif
 }
 
-// 8 bf16 times a scalar, in fp32, one rounding
+// 8 operand-type values times a scalar, in fp32, one rounding
+template <int DT>
 __device__ __forceinline__ uint4 scale8(uint4 raw, float sc) {
     unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-        w[i] = (unsigned)f2bf(bf2f((unsigned short)(w[i] & 0xffffu)) * sc) | ((unsigned)f2bf(bf2f((unsigned short)(w[i] >> 16)) * sc) << 16);
+    for (int i = 0; i < 4; ++i) w[i] = GvfLp<DT>::pack(GvfLp<DT>::lo(w[i]) * sc, GvfLp<DT>::hi(w[i]) * sc);
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 // D: head dim (32: the DiT; 64: the VAEs).  VT: V is given transposed ([d][key], keys contiguous; v_sl = d
 // stride) -- the layout the DiT's step-invariant cross-attention cache is stored in, so staging is a straight copy.
-template <int D, bool VT>
+template <int D, bool VT, int DT>
 __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(AttnParams p) {
     using C = Cfg<D>;
+    typedef GvfLp<DT> LP;
+    typedef typename LP::x8 x8;
     __shared__ uint4 sK[2][KT * C::KC];               // [key][KC chunks of 8 bf16], chunk ^= swz(key)
     __shared__ __attribute__((aligned(16))) unsigned short sVT[2][D * VT_LD + 8];   // [d][key]
 
@@ -301,14 +292,14 @@ __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(AttnParams p) {
     if (p.gamma_q != nullptr) {
         float ss = 0.f;
 #pragma unroll
-        for (int s = 0; s < C::NS; ++s) ss += sumsq8(qraw[s]);
+        for (int s = 0; s < C::NS; ++s) ss += sumsq8<DT>(qraw[s]);
         ss += __shfl_xor(ss, 32, 64);
 #pragma unroll
-        for (int s = 0; s < C::NS; ++s) qraw[s] = rms_apply<D>(qraw[s], ss, p.gamma_q + head * D + 16 * s + 8 * half);
+        for (int s = 0; s < C::NS; ++s) qraw[s] = rms_apply<D, DT>(qraw[s], ss, p.gamma_q + head * D + 16 * s + 8 * half);
     }
-    bf16x8 qf[C::NS];
+    x8 qf[C::NS];
 #pragma unroll
-    for (int s = 0; s < C::NS; ++s) qf[s] = __builtin_bit_cast(bf16x8, qraw[s]);
+    for (int s = 0; s < C::NS; ++s) qf[s] = __builtin_bit_cast(x8, qraw[s]);
 
     f32x16 o_acc[C::ND];
 #pragma unroll
@@ -369,11 +360,11 @@ __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(AttnParams p) {
             if (!VT) vw = make_uint4(vw.x & m, vw.y & m, vw.z & m, vw.w & m);                           \
         }                                                                                               \
         if (has_gk) {                                                                                   \
-            float ss = sumsq8(kw);                                                                      \
+            float ss = sumsq8<DT>(kw);                                                                      \
             ss += __shfl_xor(ss, 1, 64);                                                                \
             ss += __shfl_xor(ss, 2, 64);                                                                \
             if (C::KC == 8) ss += __shfl_xor(ss, 4, 64);                                                \
-            kw = rms_apply<D>(kw, ss, gk8);                                                             \
+            kw = rms_apply<D, DT>(kw, ss, gk8);                                                             \
         }                                                                                               \
         sK[buf_][k_slot[i]] = kw;                                                                       \
         if (VT) {                                                                                       \
@@ -397,9 +388,9 @@ __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(AttnParams p) {
         if (kt + 1 < n_tiles) { GVF_ATTN_LOAD(kt + 1) }      // in flight while this tile is consumed
 
         if (kt < last_full)                // full tile: no key masking
-            tile64<D, false>(sK[buf], sVT[buf], kt * KT, Lk, p.scale_log2e, qf, l31, half, o_acc, m_run, l_run);
+            tile64<D, false, DT>(sK[buf], sVT[buf], kt * KT, Lk, p.scale_log2e, qf, l31, half, o_acc, m_run, l_run);
         else                               // last, partial tile: keys >= Lk get -inf scores (their staged K/V rows are zero)
-            tile64<D, true>(sK[buf], sVT[buf], kt * KT, Lk, p.scale_log2e, qf, l31, half, o_acc, m_run, l_run);
+            tile64<D, true, DT>(sK[buf], sVT[buf], kt * KT, Lk, p.scale_log2e, qf, l31, half, o_acc, m_run, l_run);
         // the other buffer was last read in iteration kt-1; every wave has passed that iteration's barrier
         if (kt + 1 < n_tiles) { GVF_ATTN_STORE(buf ^ 1, kt + 1) }
         __syncthreads();
@@ -417,8 +408,8 @@ __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 uint2 w;
-                w.x = cvt_pk_bf16(o_acc[dt][4 * g] * inv, o_acc[dt][4 * g + 1] * inv);
-                w.y = cvt_pk_bf16(o_acc[dt][4 * g + 2] * inv, o_acc[dt][4 * g + 3] * inv);
+                w.x = LP::pack(o_acc[dt][4 * g] * inv, o_acc[dt][4 * g + 1] * inv);
+                w.y = LP::pack(o_acc[dt][4 * g + 2] * inv, o_acc[dt][4 * g + 3] * inv);
                 *reinterpret_cast<uint2*>(orow + dt * 32 + 8 * g + 4 * half) = w;
             }
     }
@@ -447,9 +438,13 @@ constexpr int RES_ROUND = 4;                 // staging chunks per thread in fli
 template <int D>
 constexpr int res_vt_tile() { return D * VT_LD + 8; }          // ushorts per V^T tile (16-byte multiple)
 
-template <int D, bool VT>
+template <int D, bool VT, int DT>
 __global__ __launch_bounds__(RES_THREADS) void attn_kvres_kernel(AttnParams p, int qt_per_wg, int tiles_max) {
     using C = Cfg<D>;
+    typedef GvfLp<DT> LP;
+    typedef typename LP::x8 x8;
+    // fp16 probabilities of raw scores would overflow (see attn_xt.hip for the shifted max-free form): fp16 takes the running-maximum softmax here
+    constexpr bool NOMAX = RES_NOMAX && !LP::kNeedsShift;
     constexpr int CPT = KT * C::KC;                            // 16-byte chunks per K tile (= per V tile)
     extern __shared__ __attribute__((aligned(16))) unsigned char res_smem[];
     uint4* sK = reinterpret_cast<uint4*>(res_smem);                                            // [tiles][CPT]
@@ -505,13 +500,13 @@ __global__ __launch_bounds__(RES_THREADS) void attn_kvres_kernel(AttnParams p, i
             const int kt = c / CPT, w = c % CPT, kin = w / C::KC;
             uint4 kw = kreg[i];
             if (has_gk) {                                   // uniform branch; the KC lanes of a key row are neighbours
-                float ss = sumsq8(kw);
+                float ss = sumsq8<DT>(kw);
                 ss += __shfl_xor(ss, 1, 64);
                 ss += __shfl_xor(ss, 2, 64);
                 if (C::KC == 8) ss += __shfl_xor(ss, 4, 64);
-                kw = rms_apply<D>(kw, ss, gk8);
+                kw = rms_apply<D, DT>(kw, ss, gk8);
             }
-            if (RES_NOMAX) kw = scale8(kw, p.scale_log2e);   // the scores then ARE the exp2 arguments (tile64_nomax)
+            if (NOMAX) kw = scale8<DT>(kw, p.scale_log2e);   // the scores then ARE the exp2 arguments (tile64_nomax)
             if (c < total) {
                 sK[(size_t)kt * CPT + kin * C::KC + (st_c ^ C::swz(kin))] = kw;
                 unsigned short* vt = sVT + (size_t)kt * res_vt_tile<D>();
@@ -535,7 +530,7 @@ __global__ __launch_bounds__(RES_THREADS) void attn_kvres_kernel(AttnParams p, i
     __syncthreads();
 
     // ---- every wave: its 32-query tiles over all key tiles, straight from LDS; RES_NQ tiles at a time (passes qt, qt + 1, ...)
-    constexpr int NQ = RES_NOMAX ? RES_NQ : 1;
+    constexpr int NQ = NOMAX ? RES_NQ : 1;
     for (int qt = 0; qt < qt_per_wg; qt += NQ) {
         int qrow[NQ];
         bool qvalid[NQ];
@@ -546,7 +541,7 @@ __global__ __launch_bounds__(RES_THREADS) void attn_kvres_kernel(AttnParams p, i
             qvalid[t] = qt + t < qt_per_wg && qrow[t] < Lq;
         }
         if ((qb * qt_per_wg + qt) * (RES_THREADS / 2) + wave * 32 >= Lq) break;      // wave-uniform
-        bf16x8 qf[NQ][C::NS];
+        x8 qf[NQ][C::NS];
 #pragma unroll
         for (int t = 0; t < NQ; ++t) {
             uint4 qraw[C::NS];
@@ -559,31 +554,31 @@ __global__ __launch_bounds__(RES_THREADS) void attn_kvres_kernel(AttnParams p, i
             if (p.gamma_q != nullptr) {
                 float ss = 0.f;
 #pragma unroll
-                for (int s2 = 0; s2 < C::NS; ++s2) ss += sumsq8(qraw[s2]);
+                for (int s2 = 0; s2 < C::NS; ++s2) ss += sumsq8<DT>(qraw[s2]);
                 ss += __shfl_xor(ss, 32, 64);
 #pragma unroll
-                for (int s2 = 0; s2 < C::NS; ++s2) qraw[s2] = rms_apply<D>(qraw[s2], ss, p.gamma_q + head * D + 16 * s2 + 8 * half);
+                for (int s2 = 0; s2 < C::NS; ++s2) qraw[s2] = rms_apply<D, DT>(qraw[s2], ss, p.gamma_q + head * D + 16 * s2 + 8 * half);
             }
 #pragma unroll
-            for (int s2 = 0; s2 < C::NS; ++s2) qf[t][s2] = __builtin_bit_cast(bf16x8, qraw[s2]);
+            for (int s2 = 0; s2 < C::NS; ++s2) qf[t][s2] = __builtin_bit_cast(x8, qraw[s2]);
         }
         f32x16 o_acc[NQ][C::ND];
         float l_run[NQ], m_run[NQ];
         bool exact[NQ];
 #pragma unroll
         for (int t = 0; t < NQ; ++t) {
-            l_run[t] = 0.f; m_run[t] = -INFINITY; exact[t] = !RES_NOMAX;
+            l_run[t] = 0.f; m_run[t] = -INFINITY; exact[t] = !NOMAX;
 #pragma unroll
             for (int dt = 0; dt < C::ND; ++dt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o_acc[t][dt][r] = 0.f;
         }
-        if (RES_NOMAX) {
+        if (NOMAX) {
             for (int kt = 0; kt < n_tiles; ++kt) {
                 const uint4* kb = sK + (size_t)kt * CPT;
                 const unsigned short* vb = sVT + (size_t)kt * res_vt_tile<D>();
-                if (kt < last_full) tile64_nomax<D, false, NQ>(kb, vb, kt * KT, Lk, qf, l31, half, o_acc, l_run);
-                else tile64_nomax<D, true, NQ>(kb, vb, kt * KT, Lk, qf, l31, half, o_acc, l_run);
+                if (kt < last_full) tile64_nomax<D, false, NQ, DT>(kb, vb, kt * KT, Lk, qf, l31, half, o_acc, l_run);
+                else tile64_nomax<D, true, NQ, DT>(kb, vb, kt * KT, Lk, qf, l31, half, o_acc, l_run);
             }
             // every query's denominator must be finite and in range (2^-100 .. 2^100: no exp2 overflowed, not all of them vanished);
             // otherwise the WAVE redoes that 32-query tile with the running-maximum softmax (keys are pre-scaled: scale 1)
@@ -604,12 +599,12 @@ __global__ __launch_bounds__(RES_THREADS) void attn_kvres_kernel(AttnParams p, i
 #pragma unroll
         for (int t = 0; t < NQ; ++t) {
             if (exact[t]) {
-                const float sc = RES_NOMAX ? 1.0f : p.scale_log2e;
+                const float sc = NOMAX ? 1.0f : p.scale_log2e;
                 for (int kt = 0; kt < n_tiles; ++kt) {
                     const uint4* kb = sK + (size_t)kt * CPT;
                     const unsigned short* vb = sVT + (size_t)kt * res_vt_tile<D>();
-                    if (kt < last_full) tile64<D, false>(kb, vb, kt * KT, Lk, sc, qf[t], l31, half, o_acc[t], m_run[t], l_run[t]);
-                    else tile64<D, true>(kb, vb, kt * KT, Lk, sc, qf[t], l31, half, o_acc[t], m_run[t], l_run[t]);
+                    if (kt < last_full) tile64<D, false, DT>(kb, vb, kt * KT, Lk, sc, qf[t], l31, half, o_acc[t], m_run[t], l_run[t]);
+                    else tile64<D, true, DT>(kb, vb, kt * KT, Lk, sc, qf[t], l31, half, o_acc[t], m_run[t], l_run[t]);
                 }
             }
             const float l_tot = l_run[t] + __shfl_xor(l_run[t], 32, 64);
@@ -621,8 +616,8 @@ __global__ __launch_bounds__(RES_THREADS) void attn_kvres_kernel(AttnParams p, i
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         uint2 w2;
-                        w2.x = cvt_pk_bf16(o_acc[t][dt][4 * g] * inv, o_acc[t][dt][4 * g + 1] * inv);
-                        w2.y = cvt_pk_bf16(o_acc[t][dt][4 * g + 2] * inv, o_acc[t][dt][4 * g + 3] * inv);
+                        w2.x = LP::pack(o_acc[t][dt][4 * g] * inv, o_acc[t][dt][4 * g + 1] * inv);
+                        w2.y = LP::pack(o_acc[t][dt][4 * g + 2] * inv, o_acc[t][dt][4 * g + 3] * inv);
                         *reinterpret_cast<uint2*>(orow + dt * 32 + 8 * g + 4 * half) = w2;
                     }
             }
@@ -630,7 +625,7 @@ __global__ __launch_bounds__(RES_THREADS) void attn_kvres_kernel(AttnParams p, i
     }
 }
 
-template <int D, bool VT>
+template <int D, bool VT, int DT>
 int launch_kvres(AttnParams p, int H, int n_inner, int n_outer, int max_Lq, int max_Lk, hipStream_t stream) {
     const int tiles_max = (max_Lk + KT - 1) / KT;
     const size_t lds = (size_t)tiles_max * (KT * Cfg<D>::KC * 16 + res_vt_tile<D>() * 2);
@@ -642,12 +637,12 @@ int launch_kvres(AttnParams p, int H, int n_inner, int n_outer, int max_Lq, int 
     if (blocks > 0x7fffffffLL) return GVF_EINVAL;
     static bool attr_set = false;                                          // per instantiation
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kvres_kernel<D, VT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kvres_kernel<D, VT, DT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)((size_t)RES_MAX_TILES * (KT * Cfg<D>::KC * 16 + res_vt_tile<D>() * 2))) != hipSuccess)
             return GVF_ELAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL((attn_kvres_kernel<D, VT>), dim3((unsigned)blocks), dim3(RES_THREADS), lds, stream, p, qt, tiles_max);
+    hipLaunchKernelGGL((attn_kvres_kernel<D, VT, DT>), dim3((unsigned)blocks), dim3(RES_THREADS), lds, stream, p, qt, tiles_max);
     GVF_CHECK_LAUNCH();
     return GVF_OK;
 }
@@ -662,7 +657,10 @@ int launch_kvres(AttnParams p, int H, int n_inner, int n_outer, int max_Lq, int 
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int SM_VLD = 36;                       // bf16 pitch of the staged V rows (72 B: conflict-free column reads)
 
+template <int DT>
 __global__ __launch_bounds__(THREADS) void attn_small_kernel(AttnParams p, long long n_problems) {
+    typedef GvfLp<DT> LP;
+    typedef typename LP::x8 x8;
     __shared__ unsigned short sV[THREADS / 64][32 * SM_VLD];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long prob = (long long)blockIdx.x * (THREADS / 64) + wave;
@@ -700,25 +698,25 @@ __global__ __launch_bounds__(THREADS) void attn_small_kernel(AttnParams p, long 
     }
     // fused MultiHeadRMSNorm: a row's 32 elements live in this lane's two chunks and in lane ^ 32's
     if (p.gamma_q != nullptr) {
-        float ss = sumsq8(qc[0]) + sumsq8(qc[1]);
+        float ss = sumsq8<DT>(qc[0]) + sumsq8<DT>(qc[1]);
         ss += __shfl_xor(ss, 32, 64);
         const float* g = p.gamma_q + h * 32;
-        qc[0] = rms_apply<32>(qc[0], ss, g + 8 * half);
-        qc[1] = rms_apply<32>(qc[1], ss, g + 8 * (2 + half));
+        qc[0] = rms_apply<32, DT>(qc[0], ss, g + 8 * half);
+        qc[1] = rms_apply<32, DT>(qc[1], ss, g + 8 * (2 + half));
     }
     if (p.gamma_k != nullptr) {
-        float ss = sumsq8(kc[0]) + sumsq8(kc[1]);
+        float ss = sumsq8<DT>(kc[0]) + sumsq8<DT>(kc[1]);
         ss += __shfl_xor(ss, 32, 64);
         const float* g = p.gamma_k + h * 32;
-        kc[0] = rms_apply<32>(kc[0], ss, g + 8 * half);
-        kc[1] = rms_apply<32>(kc[1], ss, g + 8 * (2 + half));
+        kc[0] = rms_apply<32, DT>(kc[0], ss, g + 8 * half);
+        kc[1] = rms_apply<32, DT>(kc[1], ss, g + 8 * (2 + half));
     }
     // S^T = K Q^T : accumulator column = query l31, row r = key (r & 3) + 8 (r >> 2) + 4 half
     f32x16 s_acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int st = 0; st < 2; ++st)
-        s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kc[st]), __builtin_bit_cast(bf16x8, qc[st]),
-                                                        s_acc, 0, 0, 0);
+        s_acc = LP::mfma32(__builtin_bit_cast(x8, kc[st]), __builtin_bit_cast(x8, qc[st]),
+                                                        s_acc);
     float m = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -738,14 +736,14 @@ __global__ __launch_bounds__(THREADS) void attn_small_kernel(AttnParams p, long 
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         uint4 pf, vf;
-        pf.x = cvt_pk_bf16(pr[8 * t + 0], pr[8 * t + 1]); pf.y = cvt_pk_bf16(pr[8 * t + 2], pr[8 * t + 3]);
-        pf.z = cvt_pk_bf16(pr[8 * t + 4], pr[8 * t + 5]); pf.w = cvt_pk_bf16(pr[8 * t + 6], pr[8 * t + 7]);
+        pf.x = LP::pack(pr[8 * t + 0], pr[8 * t + 1]); pf.y = LP::pack(pr[8 * t + 2], pr[8 * t + 3]);
+        pf.z = LP::pack(pr[8 * t + 4], pr[8 * t + 5]); pf.w = LP::pack(pr[8 * t + 6], pr[8 * t + 7]);
         const unsigned short* col = &sV[wave][(16 * t + 4 * half) * SM_VLD + l31];      // V[key][d = l31]
         vf.x = (unsigned)col[0 * SM_VLD] | ((unsigned)col[1 * SM_VLD] << 16);
         vf.y = (unsigned)col[2 * SM_VLD] | ((unsigned)col[3 * SM_VLD] << 16);
         vf.z = (unsigned)col[8 * SM_VLD] | ((unsigned)col[9 * SM_VLD] << 16);
         vf.w = (unsigned)col[10 * SM_VLD] | ((unsigned)col[11 * SM_VLD] << 16);
-        o_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), __builtin_bit_cast(bf16x8, pf), o_acc, 0, 0, 0);
+        o_acc = LP::mfma32(__builtin_bit_cast(x8, vf), __builtin_bit_cast(x8, pf), o_acc);
     }
     // accumulator column = query l31, row r = d (r & 3) + 8 (r >> 2) + 4 half : four 8-byte stores per lane
     if (l31 < p.Lq) {
@@ -754,13 +752,14 @@ __global__ __launch_bounds__(THREADS) void attn_small_kernel(AttnParams p, long 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             uint2 w2;
-            w2.x = cvt_pk_bf16(o_acc[4 * i + 0] * inv, o_acc[4 * i + 1] * inv);
-            w2.y = cvt_pk_bf16(o_acc[4 * i + 2] * inv, o_acc[4 * i + 3] * inv);
+            w2.x = LP::pack(o_acc[4 * i + 0] * inv, o_acc[4 * i + 1] * inv);
+            w2.y = LP::pack(o_acc[4 * i + 2] * inv, o_acc[4 * i + 3] * inv);
             *reinterpret_cast<uint2*>(orow + 8 * i + 4 * half) = w2;
         }
     }
 }
 
+template <int DT>
 int launch_attn(const void* q, const void* k, const void* v, void* out, int n_outer, int n_inner, int Lq, int Lk, int H,
                 int D, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                 const int64_t* o_strides, int v_transposed, const int32_t* cu_q, const int32_t* cu_k,
@@ -792,7 +791,7 @@ int launch_attn(const void* q, const void* k, const void* v, void* out, int n_ou
     const dim3 grid((unsigned)blocks), block(THREADS);
     if (D == 32 && !v_transposed && cu_q == nullptr && Lq <= 32 && Lk <= 32) {
         const long long n_problems = (long long)H * n_inner * n_outer;
-        hipLaunchKernelGGL(attn_small_kernel, dim3((unsigned)((n_problems + 3) / 4)), block, 0, stream, p, n_problems);
+        hipLaunchKernelGGL(attn_small_kernel<DT>, dim3((unsigned)((n_problems + 3) / 4)), block, 0, stream, p, n_problems);
         GVF_CHECK_LAUNCH();
         return GVF_OK;
     }
@@ -803,17 +802,17 @@ int launch_attn(const void* q, const void* k, const void* v, void* out, int n_ou
     // this path by default; GVF_ATTN_KVRES=2 forces it wherever it applies (tests run both).
     static const int kvres_mode = [] { const char* e = getenv("GVF_ATTN_KVRES"); return e == nullptr ? 1 : atoi(e); }();
     if (kvres_mode != 0 && Lk <= RES_MAX_TILES * KT && Lq >= 128 && (kvres_mode == 2 || (D == 64 && v_transposed && Lq >= 1024))) {
-        if (D == 32) return v_transposed ? launch_kvres<32, true>(p, H, n_inner, n_outer, Lq, Lk, stream)
-                                         : launch_kvres<32, false>(p, H, n_inner, n_outer, Lq, Lk, stream);
-        return v_transposed ? launch_kvres<64, true>(p, H, n_inner, n_outer, Lq, Lk, stream)
-                            : launch_kvres<64, false>(p, H, n_inner, n_outer, Lq, Lk, stream);
+        if (D == 32) return v_transposed ? launch_kvres<32, true, DT>(p, H, n_inner, n_outer, Lq, Lk, stream)
+                                         : launch_kvres<32, false, DT>(p, H, n_inner, n_outer, Lq, Lk, stream);
+        return v_transposed ? launch_kvres<64, true, DT>(p, H, n_inner, n_outer, Lq, Lk, stream)
+                            : launch_kvres<64, false, DT>(p, H, n_inner, n_outer, Lq, Lk, stream);
     }
     if (D == 32) {
-        if (v_transposed) hipLaunchKernelGGL((attn_fwd_kernel<32, true>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((attn_fwd_kernel<32, false>), grid, block, 0, stream, p);
+        if (v_transposed) hipLaunchKernelGGL((attn_fwd_kernel<32, true, DT>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((attn_fwd_kernel<32, false, DT>), grid, block, 0, stream, p);
     } else {
-        if (v_transposed) hipLaunchKernelGGL((attn_fwd_kernel<64, true>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((attn_fwd_kernel<64, false>), grid, block, 0, stream, p);
+        if (v_transposed) hipLaunchKernelGGL((attn_fwd_kernel<64, true, DT>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((attn_fwd_kernel<64, false, DT>), grid, block, 0, stream, p);
     }
     GVF_CHECK_LAUNCH();
     return GVF_OK;
@@ -821,13 +820,24 @@ int launch_attn(const void* q, const void* k, const void* v, void* out, int n_ou
 
 }  // namespace
 
+#define GVF_ATTN_DT(dtype_, ...) ((dtype_) == GVF_DT_BF16 ? launch_attn<0>(__VA_ARGS__) : (dtype_) == GVF_DT_F16 ? launch_attn<1>(__VA_ARGS__) : GVF_EINVAL)
+
+extern "C" int gvf_attn_fwd(int dtype, const void* q, const void* k, const void* v, void* out, int n_outer, int n_inner,
+                            int Lq, int Lk, int H, int head_dim, const int64_t* q_strides,
+                            const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides,
+                            int v_transposed, const float* gamma_q, const float* gamma_k, float scale,
+                            void* stream) {
+    return GVF_ATTN_DT(dtype, q, k, v, out, n_outer, n_inner, Lq, Lk, H, head_dim, q_strides, k_strides, v_strides, o_strides,
+                       v_transposed, nullptr, nullptr, gamma_q, gamma_k, scale, (hipStream_t)stream);
+}
+
 extern "C" int gvf_attn_fwd_bf16(const void* q, const void* k, const void* v, void* out, int n_outer, int n_inner,
                                  int Lq, int Lk, int H, int head_dim, const int64_t* q_strides,
                                  const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides,
                                  int v_transposed, const float* gamma_q, const float* gamma_k, float scale,
                                  void* stream) {
-    return launch_attn(q, k, v, out, n_outer, n_inner, Lq, Lk, H, head_dim, q_strides, k_strides, v_strides, o_strides,
-                       v_transposed, nullptr, nullptr, gamma_q, gamma_k, scale, (hipStream_t)stream);
+    return gvf_attn_fwd(GVF_DT_BF16, q, k, v, out, n_outer, n_inner, Lq, Lk, H, head_dim, q_strides, k_strides, v_strides, o_strides,
+                        v_transposed, gamma_q, gamma_k, scale, stream);
 }
 
 extern "C" int gvf_attn_varlen_fwd_bf16(const void* q, const void* k, const void* v, void* out, int n_seqs,
@@ -835,7 +845,16 @@ extern "C" int gvf_attn_varlen_fwd_bf16(const void* q, const void* k, const void
                                         int H, int head_dim, const int64_t* q_strides, const int64_t* k_strides,
                                         const int64_t* v_strides, const int64_t* o_strides, const float* gamma_q,
                                         const float* gamma_k, float scale, void* stream) {
+    return gvf_attn_varlen_fwd(GVF_DT_BF16, q, k, v, out, n_seqs, cu_seqlens_q, cu_seqlens_k, max_Lq, max_Lk, H, head_dim, q_strides, k_strides,
+                               v_strides, o_strides, gamma_q, gamma_k, scale, stream);
+}
+
+extern "C" int gvf_attn_varlen_fwd(int dtype, const void* q, const void* k, const void* v, void* out, int n_seqs,
+                                   const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k, int max_Lq, int max_Lk,
+                                   int H, int head_dim, const int64_t* q_strides, const int64_t* k_strides,
+                                   const int64_t* v_strides, const int64_t* o_strides, const float* gamma_q,
+                                   const float* gamma_k, float scale, void* stream) {
     if (!cu_seqlens_q || !cu_seqlens_k) return GVF_EINVAL;
-    return launch_attn(q, k, v, out, n_seqs, 1, max_Lq, max_Lk > 0 ? max_Lk : 1, H, head_dim, q_strides, k_strides,
+    return GVF_ATTN_DT(dtype, q, k, v, out, n_seqs, 1, max_Lq, max_Lk > 0 ? max_Lk : 1, H, head_dim, q_strides, k_strides,
                        v_strides, o_strides, 0, cu_seqlens_q, cu_seqlens_k, gamma_q, gamma_k, scale, (hipStream_t)stream);
 }

@@ -36,6 +36,7 @@
 // always correct, the guard only decides the speed.
 #include <cstdlib>
 #include "gvf_common.h"
+#include "gvf_lp.h"
 #include "../../include/gvf_rast.h"
 #include "../../include/gvf_dit.h"
 
@@ -85,10 +86,8 @@
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef gvf_f32x16 f32x16;
+typedef gvf_f32x4 f32x4;
 
 constexpr int XT_THREADS = 256;
 constexpr int XT_QB = 256;             // queries per workgroup (4 waves x 2 sub-tiles x 32)
@@ -110,32 +109,25 @@ struct XtParams {
     int out_f32;                       // out is float (same element strides): the kernel's arithmetic without the output rounding
 };
 
-__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-    bf16x2 v;
-    v[0] = (__bf16)lo;
-    v[1] = (__bf16)hi;
-    return __builtin_bit_cast(unsigned, v);
-}
-
-__device__ __forceinline__ float xt_bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+template <int DT>
 __device__ __forceinline__ float xt_sumsq8(uint4 raw) {
     const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const float lo = xt_bf2f((unsigned short)(w[i] & 0xffffu)), hi = xt_bf2f((unsigned short)(w[i] >> 16));
+        const float lo = GvfLp<DT>::lo(w[i]), hi = GvfLp<DT>::hi(w[i]);
         s += lo * lo + hi * hi;
     }
     return s;
 }
-// 8 bf16 of a 32-wide head row -> normalize(x) * gamma * sqrt(32) * extra, given the row's sum of squares
+// 8 operand-type values of a 32-wide head row -> normalize(x) * gamma * sqrt(32) * extra, given the row's sum of squares
+template <int DT>
 __device__ __forceinline__ uint4 xt_rms_apply(uint4 raw, float sumsq, const float* g8, float extra) {
     const float inv = extra * 5.656854249492381f / fmaxf(sqrtf(sumsq), 1e-12f);
     unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-        w[i] = cvt_pk_bf16(xt_bf2f((unsigned short)(w[i] & 0xffffu)) * inv * g8[2 * i], xt_bf2f((unsigned short)(w[i] >> 16)) * inv * g8[2 * i + 1]);
+        w[i] = GvfLp<DT>::pack(GvfLp<DT>::lo(w[i]) * inv * g8[2 * i], GvfLp<DT>::hi(w[i]) * inv * g8[2 * i + 1]);
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
@@ -158,24 +150,32 @@ __device__ __forceinline__ void xt_dma16(const uint4* g, uint4* l) {
 // E = 8 v_exp_f32 of chunk g, P = its 4 v_cvt_pk + 8 row-sum adds, Q = one QK^T MFMA, V = one PV MFMA: every MFMA is
 // followed by 8-12 independent VALU / transcendental instructions that issue in its shadow.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bf16x8 xt_ld_k(const uint4* sK, int sub, int st, int l31, int half) {
+template <int DT>
+__device__ __forceinline__ typename GvfLp<DT>::x8 xt_ld_k(const uint4* sK, int sub, int st, int l31, int half) {
     const int key = sub * 32 + l31;
-    return __builtin_bit_cast(bf16x8, sK[key * 4 + ((2 * st + half) ^ ((key >> 2) & 3))]);
+    return __builtin_bit_cast(typename GvfLp<DT>::x8, sK[key * 4 + ((2 * st + half) ^ ((key >> 2) & 3))]);
 }
-__device__ __forceinline__ bf16x8 xt_ld_v(const uint4* sV, int g, int l31, int half) {
-    return __builtin_bit_cast(bf16x8, sV[l31 * 8 + ((2 * g + half) ^ ((l31 >> 1) & 7))]);
+template <int DT>
+__device__ __forceinline__ typename GvfLp<DT>::x8 xt_ld_v(const uint4* sV, int g, int l31, int half) {
+    return __builtin_bit_cast(typename GvfLp<DT>::x8, sV[l31 * 8 + ((2 * g + half) ^ ((l31 >> 1) & 7))]);
 }
 
-template <bool DO_QK, bool DO_SM, bool MASK, int PF>
-__device__ __forceinline__ void xt_phase(bf16x8 (&kf)[2][2], bf16x8 (&vf)[4], const uint4* __restrict__ sNext, const bf16x8 (&qf_in)[2],
-                                         const uint4* __restrict__ sQ,
+// c0: initial value of the score accumulators.  bf16: zero (the compiler folds it into the MFMA's inline constant).  fp16: the splat of
+// minus the query's shift (see attn_xt_kernel) -- exp2 of a raw score would leave fp16's range.
+template <int DT, bool DO_QK, bool DO_SM, bool MASK, int PF>
+__device__ __forceinline__ void xt_phase(typename GvfLp<DT>::x8 (&kf)[2][2], typename GvfLp<DT>::x8 (&vf)[4], const uint4* __restrict__ sNext,
+                                         const typename GvfLp<DT>::x8 (&qf_in)[2], const uint4* __restrict__ sQ,
                                          f32x16 (&s_out)[2], const f32x16 (&s_in)[2], f32x16& o_acc, float (&l_acc)[4], f32x4& l4, f32x4& l4b,
-                                         int l31, int half, int n_valid) {
-    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                                         int l31, int half, int n_valid, const f32x16& c0) {
+    typedef GvfLp<DT> LP;
+    typedef typename LP::x8 x8;
+    typedef typename LP::x4 x4;
+    const f32x16 zero_ = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const f32x16 zero = LP::kNeedsShift ? c0 : zero_;
     float pe[8];
     unsigned pw[4][4];
-    bf16x8 qf[2];
-    if (XT_Q_LDS && DO_QK) { qf[0] = __builtin_bit_cast(bf16x8, sQ[0]); qf[1] = __builtin_bit_cast(bf16x8, sQ[64]); }
+    x8 qf[2];
+    if (XT_Q_LDS && DO_QK) { qf[0] = __builtin_bit_cast(x8, sQ[0]); qf[1] = __builtin_bit_cast(x8, sQ[64]); }
     else { qf[0] = qf_in[0]; qf[1] = qf_in[1]; }
 #if XT_PIPELINE
 #define XT_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -193,10 +193,10 @@ __device__ __forceinline__ void xt_phase(bf16x8 (&kf)[2][2], bf16x8 (&vf)[4], co
 #if XT_SUM_MFMA
 #define XT_SUM(g_)                                                                                          \
     {                                                                                                       \
-        const bf16x4 ones = __builtin_bit_cast(bf16x4, make_uint2(0x3f803f80u, 0x3f803f80u));              \
-        l4 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones, __builtin_bit_cast(bf16x4, make_uint2(pw[g_][0], pw[g_][1])), l4, 0, 0, 0); \
-        if (XT_SUM2) l4b = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones, __builtin_bit_cast(bf16x4, make_uint2(pw[g_][2], pw[g_][3])), l4b, 0, 0, 0); \
-        else l4 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones, __builtin_bit_cast(bf16x4, make_uint2(pw[g_][2], pw[g_][3])), l4, 0, 0, 0); \
+        const x4 ones = __builtin_bit_cast(x4, make_uint2(LP::ONE2, LP::ONE2));                             \
+        l4 = LP::mfma4(ones, __builtin_bit_cast(x4, make_uint2(pw[g_][0], pw[g_][1])), l4);                 \
+        if (XT_SUM2) l4b = LP::mfma4(ones, __builtin_bit_cast(x4, make_uint2(pw[g_][2], pw[g_][3])), l4b);  \
+        else l4 = LP::mfma4(ones, __builtin_bit_cast(x4, make_uint2(pw[g_][2], pw[g_][3])), l4);            \
     }
 #else
 #define XT_SUM(g_)                                                                                          \
@@ -204,27 +204,27 @@ __device__ __forceinline__ void xt_phase(bf16x8 (&kf)[2][2], bf16x8 (&vf)[4], co
 #endif
 #define XT_P(g_)                                                                                            \
     if (DO_SM) {                                                                                            \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) pw[g_][i] = cvt_pk_bf16(pe[2 * i], pe[2 * i + 1]);    \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) pw[g_][i] = LP::pack(pe[2 * i], pe[2 * i + 1]);    \
         XT_SUM(g_)                                                                                          \
         XT_FENCE();                                                                                         \
     }
 #define XT_V(g_)                                                                                            \
     if (DO_SM && !XT_ABL_NOPV) {                                                                            \
         if (XT_SETPRIO) __builtin_amdgcn_s_setprio(1);                                                      \
-        o_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[g_], __builtin_bit_cast(bf16x8, make_uint4(pw[g_][0], pw[g_][1], pw[g_][2], pw[g_][3])), o_acc, 0, 0, 0); \
+        o_acc = LP::mfma32(vf[g_], __builtin_bit_cast(x8, make_uint4(pw[g_][0], pw[g_][1], pw[g_][2], pw[g_][3])), o_acc); \
         if (XT_SETPRIO) __builtin_amdgcn_s_setprio(0);                                                      \
-        if (PF == 1 && !XT_ABL_NOLDS) vf[g_] = xt_ld_v(sNext, g_, l31, half);                              \
+        if (PF == 1 && !XT_ABL_NOLDS) vf[g_] = xt_ld_v<DT>(sNext, g_, l31, half);                              \
         if (PF == 2 && !XT_ABL_NOLDS && ((g_) == 0 || (g_) == 3)) {   /* K fragments of the next tile: sub 0 behind V0 */ \
-            kf[(g_) == 3][0] = xt_ld_k(sNext, (g_) == 3, 0, l31, half);   /* (Q1 is done), sub 1 behind V3 (end of phase) */ \
-            kf[(g_) == 3][1] = xt_ld_k(sNext, (g_) == 3, 1, l31, half);                                    \
+            kf[(g_) == 3][0] = xt_ld_k<DT>(sNext, (g_) == 3, 0, l31, half);   /* (Q1 is done), sub 1 behind V3 (end of phase) */ \
+            kf[(g_) == 3][1] = xt_ld_k<DT>(sNext, (g_) == 3, 1, l31, half);                                   \
         }                                                                                                   \
         XT_FENCE();                                                                                         \
     }
 #define XT_Q(i_)                                                                                            \
     if (DO_QK && !XT_ABL_NOQK) {                                                                            \
-        if (((i_) & 1) == 0) s_out[(i_) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[(i_) >> 1][0], qf[0], zero, 0, 0, 0);          \
+        if (((i_) & 1) == 0) s_out[(i_) >> 1] = LP::mfma32(kf[(i_) >> 1][0], qf[0], zero);                  \
         else {                                                                                              \
-            s_out[(i_) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[(i_) >> 1][1], qf[1], s_out[(i_) >> 1], 0, 0, 0);               \
+            s_out[(i_) >> 1] = LP::mfma32(kf[(i_) >> 1][1], qf[1], s_out[(i_) >> 1]);                       \
         }                                                                                                   \
         XT_FENCE();                                                                                         \
     }
@@ -232,7 +232,7 @@ __device__ __forceinline__ void xt_phase(bf16x8 (&kf)[2][2], bf16x8 (&vf)[4], co
     XT_E(0) XT_Q(0) XT_P(0) XT_Q(1) XT_E(1) XT_V(0) XT_P(1) XT_Q(2) XT_E(2) XT_V(1) XT_P(2) XT_Q(3) XT_E(3) XT_V(2) XT_P(3) XT_V(3)
     if (PF == 1 && !DO_SM && !XT_ABL_NOLDS) {      // first phase of a workgroup: nothing to chase, load the V^T fragments now
 #pragma unroll
-        for (int g = 0; g < 4; ++g) vf[g] = xt_ld_v(sNext, g, l31, half);
+        for (int g = 0; g < 4; ++g) vf[g] = xt_ld_v<DT>(sNext, g, l31, half);
     }
 #undef XT_E
 #undef XT_P
@@ -243,16 +243,19 @@ __device__ __forceinline__ void xt_phase(bf16x8 (&kf)[2][2], bf16x8 (&vf)[4], co
 }
 
 // classic online softmax over one staged tile for ONE 32-query sub-tile (exact fallback; not pipelined)
-__device__ __forceinline__ void xt_safe_tile(const uint4* __restrict__ sK, const uint4* __restrict__ sV, const bf16x8 (&qf)[2],
+template <int DT>
+__device__ __forceinline__ void xt_safe_tile(const uint4* __restrict__ sK, const uint4* __restrict__ sV, const typename GvfLp<DT>::x8 (&qf)[2],
                                              f32x16& o_acc, float& m_run, float& l_run, int l31, int half, int n_valid) {
+    typedef GvfLp<DT> LP;
+    typedef typename LP::x8 x8;
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x16 s[2];
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
         const int key = sub * 32 + l31;
         const int sw = (key >> 2) & 3;
-        s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, sK[key * 4 + (half ^ sw)]), qf[0], zero, 0, 0, 0);
-        s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, sK[key * 4 + ((2 + half) ^ sw)]), qf[1], s[sub], 0, 0, 0);
+        s[sub] = LP::mfma32(__builtin_bit_cast(x8, sK[key * 4 + (half ^ sw)]), qf[0], zero);
+        s[sub] = LP::mfma32(__builtin_bit_cast(x8, sK[key * 4 + ((2 + half) ^ sw)]), qf[1], s[sub]);
     }
     float mloc = -INFINITY;
 #pragma unroll
@@ -279,15 +282,35 @@ __device__ __forceinline__ void xt_safe_tile(const uint4* __restrict__ sK, const
             const float p0 = __builtin_amdgcn_exp2f(s[g >> 1][8 * (g & 1) + e] - m_run);
             const float p1 = __builtin_amdgcn_exp2f(s[g >> 1][8 * (g & 1) + e + 1] - m_run);
             l_run += p0 + p1;
-            pw[e >> 1] = cvt_pk_bf16(p0, p1);
+            pw[e >> 1] = LP::pack(p0, p1);
         }
-        const bf16x8 pf = __builtin_bit_cast(bf16x8, make_uint4(pw[0], pw[1], pw[2], pw[3]));
-        const bf16x8 vf = __builtin_bit_cast(bf16x8, sV[l31 * 8 + ((2 * g + half) ^ sw)]);
-        o_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o_acc, 0, 0, 0);
+        const x8 pf = __builtin_bit_cast(x8, make_uint4(pw[0], pw[1], pw[2], pw[3]));
+        const x8 vf = __builtin_bit_cast(x8, sV[l31 * 8 + ((2 * g + half) ^ sw)]);
+        o_acc = LP::mfma32(vf, pf, o_acc);
     }
 }
 
+// fp16 operands (DT = GVF_DT_F16): P = exp2(s) of a raw score overflows at s = 16, so every query gets a SHIFT -- the maximum of its scores
+// against the first key tile (one 32-element in-lane max + one lane exchange per sub-tile per workgroup, not per tile) -- that enters every
+// later QK^T MFMA as the accumulator's initial value (a 16-register splat of -shift per sub-tile): the MFMA result is again the exp2 argument,
+// no per-score subtraction.  softmax is shift invariant; the true maximum is >= the shift, so the largest probability is >= 1 (full fp16
+// precision where it matters) and overflows only if some later key beats the first tile's best by 2^16: P = inf -> l = inf -> the same range
+// guard -> exact fallback.  bf16 needs none of this (kNeedsShift = false: the code below compiles to the round-2 kernel).
+template <int DT>
+__device__ __forceinline__ void xt_take_shift(f32x16 (&s)[2], f32x16& c) {
+    float m = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) m = fmaxf(fmaxf(m, s[0][r]), s[1][r]);
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    if (!(m > -3.0e38f && m < 3.0e38f)) m = 0.f;          // NaN / inf scores: no shift; the range guard sends the workgroup to the exact path
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[0][r] -= m; s[1][r] -= m; c[r] = -m; }
+}
+
+template <int DT>
 __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(XtParams p, int force_safe) {
+    typedef GvfLp<DT> LP;
+    typedef typename LP::x8 x8;
     // ring of XT_NBUF stages x XT_TPS tiles x (256 K chunks + 256 V^T chunks) + one chunk for the guard flag.  ONE LDS object on purpose:
     // with a second __shared__ variable hipcc drains the LDS-DMA queue (vmcnt(0)) in front of every ds_read.
     __shared__ uint4 smem[XT_NBUF * XT_TPS * XT_TILE_CHUNKS + 1 + XT_ABL_LDSPAD + (XT_Q_LDS ? XT_THREADS * 4 : 0)];
@@ -313,7 +336,7 @@ __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(
     // ---- Q fragments (B operand of S^T = K' Q^T): lane (q = l31, half): Q[q][16 st + 8 half .. +7]
     int qrow[2];
     bool qvalid[2];
-    bf16x8 qf[2][2];
+    x8 qf[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
         qrow[a] = qb * XT_QB + wave * 64 + a * 32 + l31;
@@ -326,13 +349,13 @@ __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(
             qraw[st] = make_uint4(v4.x & m, v4.y & m, v4.z & m, v4.w & m);
         }
         if (p.gamma_q != nullptr) {     // fused MultiHeadRMSNorm (model/attention/modules.py:8-15): the row lives in this lane and lane ^ 32
-            float ss = xt_sumsq8(qraw[0]) + xt_sumsq8(qraw[1]);
+            float ss = xt_sumsq8<DT>(qraw[0]) + xt_sumsq8<DT>(qraw[1]);
             ss += __shfl_xor(ss, 32, 64);
 #pragma unroll
-            for (int st = 0; st < 2; ++st) qraw[st] = xt_rms_apply(qraw[st], ss, p.gamma_q + head * 32 + 16 * st + 8 * half, 1.0f);
+            for (int st = 0; st < 2; ++st) qraw[st] = xt_rms_apply<DT>(qraw[st], ss, p.gamma_q + head * 32 + 16 * st + 8 * half, 1.0f);
         }
 #pragma unroll
-        for (int st = 0; st < 2; ++st) qf[a][st] = __builtin_bit_cast(bf16x8, qraw[st]);
+        for (int st = 0; st < 2; ++st) qf[a][st] = __builtin_bit_cast(x8, qraw[st]);
     }
     // XT_Q_LDS: the wave's four Q fragments live in its own 4 KiB of LDS ([sub-tile][k-step][lane]); no barrier needed (wave-private)
     uint4* sQw = &smem[XT_NBUF * XT_TPS * XT_TILE_CHUNKS + 1 + XT_ABL_LDSPAD] + wave * 256 + lane;
@@ -368,7 +391,8 @@ __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(
 
     if (!bad) {
         f32x16 sA[2], sB[2];
-        bf16x8 kf[2][2], vf[4];
+        f32x16 cA = zero, cB = zero;        // fp16: -shift of the lane's query in sub-tile A / B (see xt_take_shift); bf16: unused
+        x8 kf[2][2], vf[4];
         if (XT_ABL_NOLDS) {       // timing experiment: fragments as opaque register values, no LDS traffic
             for (int i = 0; i < 4; ++i) { asm volatile("" : "=v"(kf[i >> 1][i & 1])); asm volatile("" : "=v"(vf[i])); }
         }
@@ -385,11 +409,13 @@ __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(
         if (n_stages > 2) { XT_STAGE(2) }
         if (!XT_ABL_NOLDS) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) kf[i >> 1][i & 1] = xt_ld_k(XT_K(0), i >> 1, i & 1, l31, half);
+            for (int i = 0; i < 4; ++i) kf[i >> 1][i & 1] = xt_ld_k<DT>(XT_K(0), i >> 1, i & 1, l31, half);
         }
-        xt_phase<true, false, false, 1>(kf, vf, XT_V(0), qf[0], sQw, sA, sB, oB, lB4, l4B, l4Bb, l31, half, XT_KT);
+        xt_phase<DT, true, false, false, 1>(kf, vf, XT_V(0), qf[0], sQw, sA, sB, oB, lB4, l4B, l4Bb, l31, half, XT_KT, cA);
+        if (LP::kNeedsShift) xt_take_shift<DT>(sA, cA);
         if (T > 1) {
-            xt_phase<true, true, false, 2>(kf, vf, XT_K(1), qf[1], sQw + 128, sB, sA, oA, lA4, l4A, l4Ab, l31, half, XT_KT);
+            xt_phase<DT, true, true, false, 2>(kf, vf, XT_K(1), qf[1], sQw + 128, sB, sA, oA, lA4, l4A, l4Ab, l31, half, XT_KT, cB);
+            if (LP::kNeedsShift) xt_take_shift<DT>(sB, cB);
             // steady state, iterations t = 1 .. T-2.  Entering stage s = t / TPS: one barrier -- stage s+1 has landed
             // (iteration t may prefetch K(t+1) from it) and every wave is done with stage s-1, whose ring slot takes the
             // DMA of stage s+2.
@@ -399,14 +425,15 @@ __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(
                     const int s2 = t / XT_TPS + 2;
                     if (s2 < n_stages) { XT_STAGE(s2) }
                 }
-                xt_phase<true, true, false, 1>(kf, vf, XT_V(t), qf[0], sQw, sA, sB, oB, lB4, l4B, l4Bb, l31, half, XT_KT);
-                xt_phase<true, true, false, 2>(kf, vf, XT_K(t + 1), qf[1], sQw + 128, sB, sA, oA, lA4, l4A, l4Ab, l31, half, XT_KT);
+                xt_phase<DT, true, true, false, 1>(kf, vf, XT_V(t), qf[0], sQw, sA, sB, oB, lB4, l4B, l4Bb, l31, half, XT_KT, cA);
+                xt_phase<DT, true, true, false, 2>(kf, vf, XT_K(t + 1), qf[1], sQw + 128, sB, sA, oA, lA4, l4A, l4Ab, l31, half, XT_KT, cB);
             }
             if ((T - 1) % XT_TPS == 0) __syncthreads();      // the last tile opens a stage: it must have landed
-            xt_phase<true, true, false, 1>(kf, vf, XT_V(T - 1), qf[0], sQw, sA, sB, oB, lB4, l4B, l4Bb, l31, half, XT_KT);
+            xt_phase<DT, true, true, false, 1>(kf, vf, XT_V(T - 1), qf[0], sQw, sA, sB, oB, lB4, l4B, l4Bb, l31, half, XT_KT, cA);
         }
-        xt_phase<true, true, true, 0>(kf, vf, XT_K(0), qf[1], sQw + 128, sB, sA, oA, lA4, l4A, l4Ab, l31, half, last_valid);
-        xt_phase<false, true, true, 0>(kf, vf, XT_K(0), qf[1], sQw, sA, sB, oB, lB4, l4B, l4Bb, l31, half, last_valid);
+        xt_phase<DT, true, true, true, 0>(kf, vf, XT_K(0), qf[1], sQw + 128, sB, sA, oA, lA4, l4A, l4Ab, l31, half, last_valid, cB);
+        if (LP::kNeedsShift && T == 1) xt_take_shift<DT>(sB, cB);      // a single key tile: sub-tile B's first scores come out of this phase
+        xt_phase<DT, false, true, true, 0>(kf, vf, XT_K(0), qf[1], sQw, sA, sB, oB, lB4, l4B, l4Bb, l31, half, last_valid, cB);
 #if XT_SUM_MFMA
         lA = l4A[0] + l4Ab[0]; lB = l4B[0] + l4Bb[0];
 #else
@@ -415,8 +442,10 @@ __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(
 #endif
         lA += __shfl_xor(lA, 32, 64);
         lB += __shfl_xor(lB, 32, 64);
-        // range guard (NaN fails both comparisons)
-        const bool okA = lA > 7.8886e-31f && lA < 1.2676e30f, okB = lB > 7.8886e-31f && lB < 1.2676e30f;
+        // range guard (NaN fails both comparisons).  fp16: with the shift the denominator is >= 1 unless a single, partly padded key tile
+        // pushed every probability under 2^-12 (the padding's zero scores took part in the shift)
+        const float l_min = LP::kNeedsShift ? 0.015625f : 7.8886e-31f;
+        const bool okA = lA > l_min && lA < 1.2676e30f, okB = lB > l_min && lB < 1.2676e30f;
         bad = !(okA && okB);
         if (XT_ABL_NOEXP || XT_ABL_NOQK || XT_ABL_NOPV || XT_ABL_NOSUM || XT_ABL_NOSYNC || XT_ABL_NOLDS) bad = false;   // timing experiments
     }
@@ -438,8 +467,8 @@ __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(
                 if (t / XT_TPS + 1 < n_stages) { XT_STAGE(t / XT_TPS + 1) }
             }
             const int nv = t + 1 < T ? XT_KT : last_valid;
-            xt_safe_tile(XT_K(t), XT_V(t), qf[0], oA, mA, lA, l31, half, nv);
-            xt_safe_tile(XT_K(t), XT_V(t), qf[1], oB, mB, lB, l31, half, nv);
+            xt_safe_tile<DT>(XT_K(t), XT_V(t), qf[0], oA, mA, lA, l31, half, nv);
+            xt_safe_tile<DT>(XT_K(t), XT_V(t), qf[1], oB, mB, lB, l31, half, nv);
         }
         lA += __shfl_xor(lA, 32, 64);
         lB += __shfl_xor(lB, 32, 64);
@@ -466,8 +495,8 @@ __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             uint2 w;
-            w.x = cvt_pk_bf16(o[4 * g] * inv, o[4 * g + 1] * inv);
-            w.y = cvt_pk_bf16(o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+            w.x = LP::pack(o[4 * g] * inv, o[4 * g + 1] * inv);
+            w.y = LP::pack(o[4 * g + 2] * inv, o[4 * g + 3] * inv);
             *reinterpret_cast<uint2*>(orow + 8 * g + 4 * half) = w;
         }
     }
@@ -480,24 +509,22 @@ __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(
 // scale, one rounding), V is transposed through LDS; both 4 KiB images are written as contiguous 16-byte chunks.
 // Cheap enough (~2 x the bytes it moves at HBM speed) to run per denoise step for the self attention's K / V as well.
 // ---------------------------------------------------------------------------------------------------------------
-template <typename TIn>
-__device__ __forceinline__ void xt_ld8(const TIn* p, float (&v)[8]);
-template <>
-__device__ __forceinline__ void xt_ld8<float>(const float* p, float (&v)[8]) {
+template <int DT>
+__device__ __forceinline__ void xt_ld8(const float* p, float (&v)[8]) {
     const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
     v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 }
-template <>
-__device__ __forceinline__ void xt_ld8<unsigned short>(const unsigned short* p, float (&v)[8]) {
+template <int DT>
+__device__ __forceinline__ void xt_ld8(const unsigned short* p, float (&v)[8]) {
     const uint4 r = *reinterpret_cast<const uint4*>(p);
     const unsigned w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { v[2 * i] = xt_bf2f((unsigned short)(w[i] & 0xffffu)); v[2 * i + 1] = xt_bf2f((unsigned short)(w[i] >> 16)); }
+    for (int i = 0; i < 4; ++i) { v[2 * i] = GvfLp<DT>::lo(w[i]); v[2 * i + 1] = GvfLp<DT>::hi(w[i]); }
 }
 
 constexpr int XT_PK_LD = 40;     // bf16 pitch of the staged V rows (80 B): the column gathers of a wave spread over the banks
 
-template <typename TIn>
+template <typename TIn, int DT>
 __global__ __launch_bounds__(256) void attn_pack_kv_kernel(const TIn* __restrict__ kv, long long ld, int k_col0, int v_col0, int L, int H,
                                                            int n_tiles, float k_scale, const float* __restrict__ gamma_k,
                                                            uint4* __restrict__ kt, uint4* __restrict__ vt) {
@@ -511,8 +538,8 @@ __global__ __launch_bounds__(256) void attn_pack_kv_kernel(const TIn* __restrict
     const bool valid = key < L;
     const TIn* row = kv + (set * L + (valid ? key : 0)) * ld + h * 32 + 8 * c;
     float k8[8], v8[8];
-    xt_ld8<TIn>(row + k_col0, k8);
-    xt_ld8<TIn>(row + v_col0, v8);
+    xt_ld8<DT>(row + k_col0, k8);
+    xt_ld8<DT>(row + v_col0, v8);
     float mul = k_scale;
     if (gamma_k != nullptr) {           // MultiHeadRMSNorm of the key row in fp32, then the softmax scale: ONE rounding
         float ss = 0.f;
@@ -526,13 +553,13 @@ __global__ __launch_bounds__(256) void attn_pack_kv_kernel(const TIn* __restrict
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float g0 = gamma_k != nullptr ? gamma_k[h * 32 + 8 * c + 2 * i] : 1.0f, g1 = gamma_k != nullptr ? gamma_k[h * 32 + 8 * c + 2 * i + 1] : 1.0f;
-        kw[i] = valid ? cvt_pk_bf16(k8[2 * i] * mul * g0, k8[2 * i + 1] * mul * g1) : 0u;
+        kw[i] = valid ? GvfLp<DT>::pack(k8[2 * i] * mul * g0, k8[2 * i + 1] * mul * g1) : 0u;
     }
     const long long base = ((set * H + h) * n_tiles + tile) * 256;
     kt[base + key_l * 4 + (c ^ ((key_l >> 2) & 3))] = make_uint4(kw[0], kw[1], kw[2], kw[3]);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-        *reinterpret_cast<unsigned*>(&sV[key_l * XT_PK_LD + 8 * c + 2 * i]) = valid ? cvt_pk_bf16(v8[2 * i], v8[2 * i + 1]) : 0u;
+        *reinterpret_cast<unsigned*>(&sV[key_l * XT_PK_LD + 8 * c + 2 * i]) = valid ? GvfLp<DT>::pack(v8[2 * i], v8[2 * i + 1]) : 0u;
     __syncthreads();
     const int d = tid >> 3, pos = tid & 7, j = pos ^ ((d >> 1) & 7), g = j >> 1, hf = j & 1;
     unsigned vw[4];
@@ -548,8 +575,9 @@ __global__ __launch_bounds__(256) void attn_pack_kv_kernel(const TIn* __restrict
 
 }  // namespace
 
-extern "C" int gvf_attn_pack_kv_bf16(const void* kv, int kv_is_f32, int64_t ld, int k_col0, int v_col0, int n_sets, int L, int H,
-                                     float k_scale, const float* gamma_k, void* k_tiles, void* v_tiles, void* stream_) {
+extern "C" int gvf_attn_pack_kv(int dtype, const void* kv, int kv_is_f32, int64_t ld, int k_col0, int v_col0, int n_sets, int L, int H,
+                                float k_scale, const float* gamma_k, void* k_tiles, void* v_tiles, void* stream_) {
+    if (dtype != GVF_DT_BF16 && dtype != GVF_DT_F16) return GVF_EINVAL;
     if (n_sets < 0 || L <= 0 || H <= 0 || ld <= 0 || k_col0 < 0 || v_col0 < 0) return GVF_EINVAL;
     if (n_sets == 0) return GVF_OK;
     if (!kv || !k_tiles || !v_tiles) return GVF_EINVAL;
@@ -562,21 +590,28 @@ extern "C" int gvf_attn_pack_kv_bf16(const void* kv, int kv_is_f32, int64_t ld, 
     if ((ld % al) || (k_col0 % al) || (v_col0 % al) || (((uintptr_t)kv) & 15)) return GVF_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
     (void)hipGetLastError();
-    if (kv_is_f32)
-        attn_pack_kv_kernel<float><<<dim3((unsigned)blocks), dim3(256), 0, stream>>>((const float*)kv, ld, k_col0, v_col0, L, H, n_tiles, k_scale,
-                                                                                     gamma_k, (uint4*)k_tiles, (uint4*)v_tiles);
-    else
-        attn_pack_kv_kernel<unsigned short><<<dim3((unsigned)blocks), dim3(256), 0, stream>>>((const unsigned short*)kv, ld, k_col0, v_col0, L, H,
-                                                                                              n_tiles, k_scale, gamma_k, (uint4*)k_tiles,
-                                                                                              (uint4*)v_tiles);
+    GVF_LP_DISPATCH(dtype,
+        if (kv_is_f32)
+            attn_pack_kv_kernel<float, DT><<<dim3((unsigned)blocks), dim3(256), 0, stream>>>((const float*)kv, ld, k_col0, v_col0, L, H, n_tiles, k_scale,
+                                                                                             gamma_k, (uint4*)k_tiles, (uint4*)v_tiles);
+        else
+            attn_pack_kv_kernel<unsigned short, DT><<<dim3((unsigned)blocks), dim3(256), 0, stream>>>((const unsigned short*)kv, ld, k_col0, v_col0, L, H,
+                                                                                                      n_tiles, k_scale, gamma_k, (uint4*)k_tiles,
+                                                                                                      (uint4*)v_tiles));
     GVF_CHECK_LAUNCH();
     return GVF_OK;
 }
 
-extern "C" int gvf_attn_tiled_fwd_bf16(const void* q, const void* k_tiles, const void* v_tiles, void* out, int n_outer, int n_inner,
-                                       int Lq, int Lk, int H, const int64_t* q_strides, const int64_t* o_strides,
-                                       int64_t kv_set_stride_outer, int64_t kv_set_stride_inner, const float* gamma_q, int out_is_f32,
-                                       int force_exact, int32_t* fallback_counter, void* stream_) {
+extern "C" int gvf_attn_pack_kv_bf16(const void* kv, int kv_is_f32, int64_t ld, int k_col0, int v_col0, int n_sets, int L, int H,
+                                     float k_scale, const float* gamma_k, void* k_tiles, void* v_tiles, void* stream_) {
+    return gvf_attn_pack_kv(GVF_DT_BF16, kv, kv_is_f32, ld, k_col0, v_col0, n_sets, L, H, k_scale, gamma_k, k_tiles, v_tiles, stream_);
+}
+
+extern "C" int gvf_attn_tiled_fwd(int dtype, const void* q, const void* k_tiles, const void* v_tiles, void* out, int n_outer, int n_inner,
+                                  int Lq, int Lk, int H, const int64_t* q_strides, const int64_t* o_strides,
+                                  int64_t kv_set_stride_outer, int64_t kv_set_stride_inner, const float* gamma_q, int out_is_f32,
+                                  int force_exact, int32_t* fallback_counter, void* stream_) {
+    if (dtype != GVF_DT_BF16 && dtype != GVF_DT_F16) return GVF_EINVAL;
     if (n_outer < 0 || n_inner <= 0 || Lq < 0 || Lk <= 0 || H <= 0) return GVF_EINVAL;
     if (n_outer == 0 || Lq == 0) return GVF_OK;
     if (!q || !k_tiles || !v_tiles || !out || !q_strides || !o_strides) return GVF_EINVAL;
@@ -598,7 +633,15 @@ extern "C" int gvf_attn_tiled_fwd_bf16(const void* q, const void* k_tiles, const
     const long long blocks = (long long)p.q_blocks * H * n_inner * n_outer;
     if (blocks > 0x7fffffffLL) return GVF_EINVAL;
     (void)hipGetLastError();
-    attn_xt_kernel<<<dim3((unsigned)blocks), dim3(XT_THREADS), 0, (hipStream_t)stream_>>>(p, force_exact);
+    GVF_LP_DISPATCH(dtype, attn_xt_kernel<DT><<<dim3((unsigned)blocks), dim3(XT_THREADS), 0, (hipStream_t)stream_>>>(p, force_exact));
     GVF_CHECK_LAUNCH();
     return GVF_OK;
+}
+
+extern "C" int gvf_attn_tiled_fwd_bf16(const void* q, const void* k_tiles, const void* v_tiles, void* out, int n_outer, int n_inner,
+                                       int Lq, int Lk, int H, const int64_t* q_strides, const int64_t* o_strides,
+                                       int64_t kv_set_stride_outer, int64_t kv_set_stride_inner, const float* gamma_q, int out_is_f32,
+                                       int force_exact, int32_t* fallback_counter, void* stream_) {
+    return gvf_attn_tiled_fwd(GVF_DT_BF16, q, k_tiles, v_tiles, out, n_outer, n_inner, Lq, Lk, H, q_strides, o_strides, kv_set_stride_outer,
+                              kv_set_stride_inner, gamma_q, out_is_f32, force_exact, fallback_counter, stream_);
 }

@@ -7,6 +7,7 @@
 // mean / variance / normalise passes (two-pass variance, as torch's LayerNorm computes it).
 #include <cmath>
 #include "gvf_common.h"
+#include "gvf_lp.h"
 #include "../../include/gvf_rast.h"
 #include "../../include/gvf_dit.h"
 
@@ -26,7 +27,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // VPL = float4 loads per lane: C = 64 * 4 * VPL
-template <int VPL>
+template <int VPL, int DT>
 __global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ x, unsigned short* __restrict__ out,
                                                      int rows, int C, float eps, const float* __restrict__ ln_w,
                                                      const float* __restrict__ ln_b, const float* __restrict__ shift,
@@ -67,13 +68,14 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ x
             y[2] = y[2] * (1.0f + sc.z) + sh.z; y[3] = y[3] * (1.0f + sc.w) + sh.w;
         }
         uint2 o;
-        o.x = (unsigned)f2bf(y[0]) | ((unsigned)f2bf(y[1]) << 16);
-        o.y = (unsigned)f2bf(y[2]) | ((unsigned)f2bf(y[3]) << 16);
+        o.x = GvfLp<DT>::pack(y[0], y[1]);
+        o.y = GvfLp<DT>::pack(y[2], y[3]);
         *reinterpret_cast<uint2*>(out + (size_t)row * C + c0) = o;
     }
 }
 
 // any C (multiple of 4): the row is re-read from cache for each pass
+template <int DT>
 __global__ __launch_bounds__(256) void ln_mod_generic_kernel(const float* __restrict__ x, unsigned short* __restrict__ out,
                                                              int rows, int C, float eps, const float* __restrict__ ln_w,
                                                              const float* __restrict__ ln_b, const float* __restrict__ shift,
@@ -93,10 +95,11 @@ __global__ __launch_bounds__(256) void ln_mod_generic_kernel(const float* __rest
         float y = (xr[c] - mean) * rstd;
         if (ln_w != nullptr) y = y * ln_w[c] + ln_b[c];
         if (scale != nullptr) y = y * (1.0f + scale[(size_t)g * mod_ld + c]) + shift[(size_t)g * mod_ld + c];
-        out[(size_t)row * C + c] = f2bf(y);
+        out[(size_t)row * C + c] = GvfLp<DT>::to16(y);
     }
 }
 
+template <int DT>
 __global__ __launch_bounds__(256) void cast_pad_kernel(const float* __restrict__ src, int ld_src,
                                                        unsigned short* __restrict__ dst, int ld_dst, long long rows,
                                                        int cols, int act) {
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(256) void cast_pad_kernel(const float* __restrict__
             v = src[r * ld_src + c];
             if (act == 1) v = v / (1.0f + __expf(-v));
         }
-        dst[i] = f2bf(v);
+        dst[i] = GvfLp<DT>::to16(v);
     }
 }
 
@@ -410,6 +413,13 @@ __global__ __launch_bounds__(256) void final_layer_f32_kernel(const float* __res
 extern "C" int gvf_layernorm_modulate_bf16(const float* x, void* out_bf16, int rows, int C, float eps, const float* ln_w,
                                            const float* ln_b, const float* shift, const float* scale, int mod_ld,
                                            int rows_per_group, void* stream_) {
+    return gvf_layernorm_modulate(GVF_DT_BF16, x, out_bf16, rows, C, eps, ln_w, ln_b, shift, scale, mod_ld, rows_per_group, stream_);
+}
+
+extern "C" int gvf_layernorm_modulate(int dtype, const float* x, void* out_bf16, int rows, int C, float eps, const float* ln_w,
+                                      const float* ln_b, const float* shift, const float* scale, int mod_ld,
+                                      int rows_per_group, void* stream_) {
+    if (dtype != GVF_DT_BF16 && dtype != GVF_DT_F16) return GVF_EINVAL;
     if (rows < 0 || C <= 0) return GVF_EINVAL;
     if (rows == 0) return GVF_OK;
     if (!x || !out_bf16 || ((ln_w == nullptr) != (ln_b == nullptr)) || ((shift == nullptr) != (scale == nullptr)))
@@ -421,23 +431,29 @@ extern "C" int gvf_layernorm_modulate_bf16(const float* x, void* out_bf16, int r
     const int rpg = rows_per_group > 0 ? rows_per_group : 1;
     const dim3 grid((rows + 3) / 4), block(256);
     unsigned short* o = (unsigned short*)out_bf16;
-    if ((C % 256) != 0 || C > 1024) {
-        hipLaunchKernelGGL(ln_mod_generic_kernel, grid, block, 0, stream, x, o, rows, C, eps, ln_w, ln_b, shift, scale, mod_ld, rpg);
-        GVF_CHECK_LAUNCH();
-        return GVF_OK;
-    }
-    switch (C / 256) {
-        case 1: hipLaunchKernelGGL(ln_mod_kernel<1>, grid, block, 0, stream, x, o, rows, C, eps, ln_w, ln_b, shift, scale, mod_ld, rpg); break;
-        case 2: hipLaunchKernelGGL(ln_mod_kernel<2>, grid, block, 0, stream, x, o, rows, C, eps, ln_w, ln_b, shift, scale, mod_ld, rpg); break;
-        case 3: hipLaunchKernelGGL(ln_mod_kernel<3>, grid, block, 0, stream, x, o, rows, C, eps, ln_w, ln_b, shift, scale, mod_ld, rpg); break;
-        default: hipLaunchKernelGGL(ln_mod_kernel<4>, grid, block, 0, stream, x, o, rows, C, eps, ln_w, ln_b, shift, scale, mod_ld, rpg); break;
-    }
+    GVF_LP_DISPATCH(dtype,
+        if ((C % 256) != 0 || C > 1024) {
+            hipLaunchKernelGGL(ln_mod_generic_kernel<DT>, grid, block, 0, stream, x, o, rows, C, eps, ln_w, ln_b, shift, scale, mod_ld, rpg);
+        } else {
+            switch (C / 256) {
+                case 1: hipLaunchKernelGGL((ln_mod_kernel<1, DT>), grid, block, 0, stream, x, o, rows, C, eps, ln_w, ln_b, shift, scale, mod_ld, rpg); break;
+                case 2: hipLaunchKernelGGL((ln_mod_kernel<2, DT>), grid, block, 0, stream, x, o, rows, C, eps, ln_w, ln_b, shift, scale, mod_ld, rpg); break;
+                case 3: hipLaunchKernelGGL((ln_mod_kernel<3, DT>), grid, block, 0, stream, x, o, rows, C, eps, ln_w, ln_b, shift, scale, mod_ld, rpg); break;
+                default: hipLaunchKernelGGL((ln_mod_kernel<4, DT>), grid, block, 0, stream, x, o, rows, C, eps, ln_w, ln_b, shift, scale, mod_ld, rpg); break;
+            }
+        });
     GVF_CHECK_LAUNCH();
     return GVF_OK;
 }
 
 extern "C" int gvf_cast_pad_bf16(const float* src, int ld_src, void* dst, int ld_dst, int64_t rows, int cols, int act,
                                  void* stream_) {
+    return gvf_cast_pad(GVF_DT_BF16, src, ld_src, dst, ld_dst, rows, cols, act, stream_);
+}
+
+extern "C" int gvf_cast_pad(int dtype, const float* src, int ld_src, void* dst, int ld_dst, int64_t rows, int cols, int act,
+                            void* stream_) {
+    if (dtype != GVF_DT_BF16 && dtype != GVF_DT_F16) return GVF_EINVAL;
     if (rows < 0 || cols <= 0 || ld_src < cols || ld_dst < cols || (act != 0 && act != 1)) return GVF_EINVAL;
     if (rows == 0) return GVF_OK;
     if (!src || !dst) return GVF_EINVAL;
@@ -445,8 +461,8 @@ extern "C" int gvf_cast_pad_bf16(const float* src, int ld_src, void* dst, int ld
     long long total = rows * (long long)ld_dst;
     long long blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(cast_pad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, src, ld_src,
-                       (unsigned short*)dst, ld_dst, (long long)rows, cols, act);
+    GVF_LP_DISPATCH(dtype, hipLaunchKernelGGL(cast_pad_kernel<DT>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, src, ld_src,
+                                              (unsigned short*)dst, ld_dst, (long long)rows, cols, act));
     GVF_CHECK_LAUNCH();
     return GVF_OK;
 }

@@ -13,13 +13,13 @@
 // issued before the MFMAs of the current one, one __syncthreads per k-tile, two LDS buffers.
 #include <cstdlib>
 #include "gvf_common.h"
+#include "gvf_lp.h"
 #include "../../include/gvf_rast.h"
 #include "../../include/gvf_dit.h"
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef gvf_f32x4 f32x4;
 
 constexpr int BN_DEFAULT = 128;                     // BM (128 or 64), BK (32 or 64) and BN (128 or 192) are template parameters
 constexpr int THREADS = 256;
@@ -28,21 +28,6 @@ constexpr int THREADS = 256;
 // (BK = 64): row & 7 (the 16 lanes of a group then hit 16 distinct 16-byte slots of the 256-byte bank row).
 template <int CPR>
 __device__ __forceinline__ int swz(int row) { return CPR == 4 ? ((row & 8) ? 3 : 0) : (row & 7); }
-
-__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);  // quiet NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
-
-__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-    bf16x2 v;
-    v[0] = (__bf16)lo;
-    v[1] = (__bf16)hi;
-    return __builtin_bit_cast(unsigned, v);
-}
 
 // GELU (tanh form): 0.5 x (1 + tanh(u)) = x * sigmoid(2u), u = sqrt(2/pi) (x + 0.044715 x^3): one exp, one rcp
 __device__ __forceinline__ float gelu_tanh(float x) {
@@ -79,13 +64,15 @@ constexpr int ALN_MAX_K = 1024;
 
 // BN = 192 (2x2 waves of 64x96): for shapes whose 128-wide tiling leaves a mostly empty last round of workgroups -- the
 // DiT's to_qkv (M = 12288, N = 1536): 1152 tiles of 128x128 on 1024 resident slots against 768 tiles of 128x192 on 768.
-template <int EPI, int BM, int BK, bool ALN = false, int BN = BN_DEFAULT>
-__global__ __launch_bounds__(THREADS, BN == 192 ? 3 : (BK == 32 ? 4 : (BM == 64 ? 3 : 2))) void gemm_bf16_kernel(const unsigned short* __restrict__ A, int lda,
+template <int DT, int EPI, int BM, int BK, bool ALN = false, int BN = BN_DEFAULT>
+__global__ __launch_bounds__(THREADS, BN == 192 ? 3 : (BK == 32 ? 4 : (BM == 64 ? 3 : 2))) void gemm_lp_kernel(const unsigned short* __restrict__ A, int lda,
                                                             const unsigned short* __restrict__ W, int ldw,
                                                             const float* __restrict__ bias, void* __restrict__ Cv,
                                                             int ldc, int M, int N, int K,
                                                             const float* __restrict__ gate, int gate_ld, int rpg,
                                                             int tiles_n, float* __restrict__ stats_out, GemmLnArgs ln) {
+    typedef GvfLp<DT> LP;
+    typedef typename LP::x8 x8;
     constexpr int MI = BM / 32;                          // 16-row fragments per wave along M
     constexpr int NJ = BN / 32;                          // 16-column fragments per wave along N (wave tile = BM/2 x BN/2)
     constexpr int CHUNKS_PER_ROW = BK / 8;               // 16-byte chunks per tile row
@@ -191,10 +178,10 @@ __global__ __launch_bounds__(THREADS, BN == 192 ? 3 : (BK == 32 ? 4 : (BM == 64 
             const float4 x0 = araw[i][0], x1 = araw[i][1];                                                 \
             const float a_ = ln_a[i], b_ = ln_b2[i];                                                       \
             uint4 pk;                                                                                      \
-            pk.x = pack_bf16(__builtin_fmaf(__builtin_fmaf(x0.x, a_, b_), s0.x, t0.x), __builtin_fmaf(__builtin_fmaf(x0.y, a_, b_), s0.y, t0.y)); \
-            pk.y = pack_bf16(__builtin_fmaf(__builtin_fmaf(x0.z, a_, b_), s0.z, t0.z), __builtin_fmaf(__builtin_fmaf(x0.w, a_, b_), s0.w, t0.w)); \
-            pk.z = pack_bf16(__builtin_fmaf(__builtin_fmaf(x1.x, a_, b_), s1.x, t1.x), __builtin_fmaf(__builtin_fmaf(x1.y, a_, b_), s1.y, t1.y)); \
-            pk.w = pack_bf16(__builtin_fmaf(__builtin_fmaf(x1.z, a_, b_), s1.z, t1.z), __builtin_fmaf(__builtin_fmaf(x1.w, a_, b_), s1.w, t1.w)); \
+            pk.x = LP::pack(__builtin_fmaf(__builtin_fmaf(x0.x, a_, b_), s0.x, t0.x), __builtin_fmaf(__builtin_fmaf(x0.y, a_, b_), s0.y, t0.y)); \
+            pk.y = LP::pack(__builtin_fmaf(__builtin_fmaf(x0.z, a_, b_), s0.z, t0.z), __builtin_fmaf(__builtin_fmaf(x0.w, a_, b_), s0.w, t0.w)); \
+            pk.z = LP::pack(__builtin_fmaf(__builtin_fmaf(x1.x, a_, b_), s1.x, t1.x), __builtin_fmaf(__builtin_fmaf(x1.y, a_, b_), s1.y, t1.y)); \
+            pk.w = LP::pack(__builtin_fmaf(__builtin_fmaf(x1.z, a_, b_), s1.z, t1.z), __builtin_fmaf(__builtin_fmaf(x1.w, a_, b_), s1.w, t1.w)); \
             SA(buf_, (i * 4 + wave) * 64 + lane) = pk;                                                     \
         }                                                                                                  \
     }
@@ -229,23 +216,23 @@ __global__ __launch_bounds__(THREADS, BN == 192 ? 3 : (BK == 32 ? 4 : (BM == 64 
         if (kt + 1 < KT) { GVF_GEMM_STAGE(kt + 1, buf ^ 1) GVF_GEMM_LOADA(kt + 1) }   // land while this tile is multiplied
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ++ks) {
-            bf16x8 af[MI], bfr[NJ];
+            x8 af[MI], bfr[NJ];
             const int kc = ks * 4 + (lane >> 4);
 #pragma unroll
             for (int f = 0; f < MI; ++f) {
                 const int ar = wm * (BM / 2) + f * 16 + (lane & 15);
-                af[f] = __builtin_bit_cast(bf16x8, SA(buf, ar * CHUNKS_PER_ROW + (kc ^ swz<CHUNKS_PER_ROW>(ar))));
+                af[f] = __builtin_bit_cast(x8, SA(buf, ar * CHUNKS_PER_ROW + (kc ^ swz<CHUNKS_PER_ROW>(ar))));
             }
 #pragma unroll
             for (int f = 0; f < NJ; ++f) {
                 const int br = wn * (BN / 2) + f * 16 + (lane & 15);
-                bfr[f] = __builtin_bit_cast(bf16x8, SB(buf, br * CHUNKS_PER_ROW + (kc ^ swz<CHUNKS_PER_ROW>(br))));
+                bfr[f] = __builtin_bit_cast(x8, SB(buf, br * CHUNKS_PER_ROW + (kc ^ swz<CHUNKS_PER_ROW>(br))));
             }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = LP::mfma16(af[i], bfr[j], acc[i][j]);
         }
         if (kt + 1 < KT) { GVF_GEMM_STOREA(kt + 1, buf ^ 1) }  // buffer buf ^ 1 was last read in iteration kt - 1 (barrier in between)
         __syncthreads();
@@ -303,7 +290,7 @@ __global__ __launch_bounds__(THREADS, BN == 192 ? 3 : (BK == 32 ? 4 : (BM == 64 
             if (vec_ok && col0 + 3 < N) {
                 if (EPI == GVF_EPI_STORE_BF16 || EPI == GVF_EPI_GELU_BF16) {
                     uint2 w2;
-                    w2.x = pack_bf16(v.x, v.y); w2.y = pack_bf16(v.z, v.w);
+                    w2.x = LP::pack(v.x, v.y); w2.y = LP::pack(v.z, v.w);
                     *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(Cv) + o) = w2;
                 } else if (EPI == GVF_EPI_STORE_F32) {
                     *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + o) = v;
@@ -330,7 +317,7 @@ __global__ __launch_bounds__(THREADS, BN == 192 ? 3 : (BK == 32 ? 4 : (BM == 64 
                 for (int e = 0; e < 4; ++e) {
                     if (col0 + e >= N) break;
                     if (EPI == GVF_EPI_STORE_BF16 || EPI == GVF_EPI_GELU_BF16) {
-                        reinterpret_cast<unsigned short*>(Cv)[o + e] = f32_to_bf16(vv[e]);
+                        reinterpret_cast<unsigned short*>(Cv)[o + e] = LP::to16(vv[e]);
                     } else if (EPI == GVF_EPI_STORE_F32) {
                         reinterpret_cast<float*>(Cv)[o + e] = vv[e];
                     } else {
@@ -349,6 +336,7 @@ __global__ __launch_bounds__(THREADS, BN == 192 ? 3 : (BK == 32 ? 4 : (BM == 64 
 
 namespace {
 
+template <int DT>
 int launch_gemm(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M, int N, int K, int epilogue,
                 const float* gate, int gate_ld, int rows_per_group, float* stats_out, const GemmLnArgs* ln, hipStream_t stream) {
     const bool aln = ln != nullptr;
@@ -397,16 +385,16 @@ int launch_gemm(const void* A, int lda, const void* W, int ldw, const float* bia
     const int tiles_n_w = N / 192;
 #define GVF_GEMM_LAUNCH(EPI_)                                                                                     \
     if (wide) {                                                                                                    \
-        gemm_bf16_kernel<EPI_, 128, 32, false, 192><<<grid_w, block, 0, stream>>>(a, lda, w, ldw, bias, C, ldc, M, N, K, gate, gate_ld, rpg, tiles_n_w, stats_out, lnv); \
+        gemm_lp_kernel<DT, EPI_, 128, 32, false, 192><<<grid_w, block, 0, stream>>>(a, lda, w, ldw, bias, C, ldc, M, N, K, gate, gate_ld, rpg, tiles_n_w, stats_out, lnv); \
     } else if (aln) {                                                                                                     \
-        if (small) gemm_bf16_kernel<EPI_, 64, 32, true><<<grid, block, 0, stream>>>(GVF_GEMM_ARGS);               \
-        else gemm_bf16_kernel<EPI_, 128, 32, true><<<grid, block, 0, stream>>>(GVF_GEMM_ARGS);                    \
+        if (small) gemm_lp_kernel<DT, EPI_, 64, 32, true><<<grid, block, 0, stream>>>(GVF_GEMM_ARGS);               \
+        else gemm_lp_kernel<DT, EPI_, 128, 32, true><<<grid, block, 0, stream>>>(GVF_GEMM_ARGS);                    \
     } else if (bk64 && (K % 64) == 0) {                                                                            \
-        if (small) gemm_bf16_kernel<EPI_, 64, 64><<<grid, block, 0, stream>>>(GVF_GEMM_ARGS);                     \
-        else gemm_bf16_kernel<EPI_, 128, 64><<<grid, block, 0, stream>>>(GVF_GEMM_ARGS);                          \
+        if (small) gemm_lp_kernel<DT, EPI_, 64, 64><<<grid, block, 0, stream>>>(GVF_GEMM_ARGS);                     \
+        else gemm_lp_kernel<DT, EPI_, 128, 64><<<grid, block, 0, stream>>>(GVF_GEMM_ARGS);                          \
     } else {                                                                                                       \
-        if (small) gemm_bf16_kernel<EPI_, 64, 32><<<grid, block, 0, stream>>>(GVF_GEMM_ARGS);                     \
-        else gemm_bf16_kernel<EPI_, 128, 32><<<grid, block, 0, stream>>>(GVF_GEMM_ARGS);                          \
+        if (small) gemm_lp_kernel<DT, EPI_, 64, 32><<<grid, block, 0, stream>>>(GVF_GEMM_ARGS);                     \
+        else gemm_lp_kernel<DT, EPI_, 128, 32><<<grid, block, 0, stream>>>(GVF_GEMM_ARGS);                          \
     }
     switch (epilogue) {
         case GVF_EPI_STORE_BF16: GVF_GEMM_LAUNCH(GVF_EPI_STORE_BF16) break;
@@ -423,29 +411,48 @@ int launch_gemm(const void* A, int lda, const void* W, int ldw, const float* bia
 
 }  // namespace
 
+#define GVF_GEMM_DT(dtype_, ...) ((dtype_) == GVF_DT_BF16 ? launch_gemm<0>(__VA_ARGS__) : (dtype_) == GVF_DT_F16 ? launch_gemm<1>(__VA_ARGS__) : GVF_EINVAL)
+
+extern "C" int gvf_gemm(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc,
+                        int M, int N, int K, int epilogue, const float* gate, int gate_ld, int rows_per_group, void* stream_) {
+    return GVF_GEMM_DT(dtype, A, lda, W, ldw, bias, C, ldc, M, N, K, epilogue, gate, gate_ld, rows_per_group, nullptr, nullptr, (hipStream_t)stream_);
+}
+
 extern "C" int gvf_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc,
                              int M, int N, int K, int epilogue, const float* gate, int gate_ld, int rows_per_group,
                              void* stream_) {
-    return launch_gemm(A, lda, W, ldw, bias, C, ldc, M, N, K, epilogue, gate, gate_ld, rows_per_group, nullptr, nullptr, (hipStream_t)stream_);
+    return gvf_gemm(GVF_DT_BF16, A, lda, W, ldw, bias, C, ldc, M, N, K, epilogue, gate, gate_ld, rows_per_group, stream_);
 }
 
 extern "C" int gvf_gemm_stats_parts(int N) { return 2 * ((N + BN_DEFAULT - 1) / BN_DEFAULT); }
 
-extern "C" int gvf_gemm_bf16_resid_stats(const void* A, int lda, const void* W, int ldw, const float* bias, float* C, int ldc, int M, int N,
-                                         int K, const float* gate, int gate_ld, int rows_per_group, float* row_stats, void* stream_) {
+extern "C" int gvf_gemm_resid_stats(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, float* C, int ldc, int M, int N,
+                                    int K, const float* gate, int gate_ld, int rows_per_group, float* row_stats, void* stream_) {
     if (!row_stats) return GVF_EINVAL;
-    return launch_gemm(A, lda, W, ldw, bias, C, ldc, M, N, K, GVF_EPI_RESID_F32, gate, gate_ld, rows_per_group, row_stats, nullptr,
+    return GVF_GEMM_DT(dtype, A, lda, W, ldw, bias, C, ldc, M, N, K, GVF_EPI_RESID_F32, gate, gate_ld, rows_per_group, row_stats, nullptr,
                        (hipStream_t)stream_);
 }
 
-extern "C" int gvf_gemm_ln_bf16(const float* X, int ldx, const float* row_stats, int n_part, float eps, const float* ln_w, const float* ln_b,
-                                const float* shift, const float* scale, int mod_ld, int rows_per_group, const void* W, int ldw,
-                                const float* bias, void* C, int ldc, int M, int N, int K, int epilogue, void* stream_) {
+extern "C" int gvf_gemm_bf16_resid_stats(const void* A, int lda, const void* W, int ldw, const float* bias, float* C, int ldc, int M, int N,
+                                         int K, const float* gate, int gate_ld, int rows_per_group, float* row_stats, void* stream_) {
+    return gvf_gemm_resid_stats(GVF_DT_BF16, A, lda, W, ldw, bias, C, ldc, M, N, K, gate, gate_ld, rows_per_group, row_stats, stream_);
+}
+
+extern "C" int gvf_gemm_ln(int dtype, const float* X, int ldx, const float* row_stats, int n_part, float eps, const float* ln_w, const float* ln_b,
+                           const float* shift, const float* scale, int mod_ld, int rows_per_group, const void* W, int ldw,
+                           const float* bias, void* C, int ldc, int M, int N, int K, int epilogue, void* stream_) {
     if (epilogue == GVF_EPI_RESID_F32) return GVF_EINVAL;
     GemmLnArgs ln;
     ln.stats = row_stats; ln.n_part = n_part; ln.eps = eps; ln.ln_w = ln_w; ln.ln_b = ln_b; ln.shift = shift; ln.scale = scale;
     ln.mod_ld = mod_ld; ln.rpg = rows_per_group;
     if ((ldx % 4) != 0) return GVF_EINVAL;
     // launch_gemm's operand checks are written for bf16 rows (lda % 8): the fp32 rows need 16-byte alignment only
-    return launch_gemm(X, (ldx % 8) == 0 ? ldx : -1, W, ldw, bias, C, ldc, M, N, K, epilogue, nullptr, 0, 0, nullptr, &ln, (hipStream_t)stream_);
+    return GVF_GEMM_DT(dtype, X, (ldx % 8) == 0 ? ldx : -1, W, ldw, bias, C, ldc, M, N, K, epilogue, nullptr, 0, 0, nullptr, &ln, (hipStream_t)stream_);
+}
+
+extern "C" int gvf_gemm_ln_bf16(const float* X, int ldx, const float* row_stats, int n_part, float eps, const float* ln_w, const float* ln_b,
+                                const float* shift, const float* scale, int mod_ld, int rows_per_group, const void* W, int ldw,
+                                const float* bias, void* C, int ldc, int M, int N, int K, int epilogue, void* stream_) {
+    return gvf_gemm_ln(GVF_DT_BF16, X, ldx, row_stats, n_part, eps, ln_w, ln_b, shift, scale, mod_ld, rows_per_group, W, ldw, bias, C, ldc, M, N, K,
+                       epilogue, stream_);
 }

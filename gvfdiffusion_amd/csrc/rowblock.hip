@@ -30,13 +30,13 @@
 #include <cstddef>
 #include <cstdlib>
 #include "gvf_common.h"
+#include "gvf_lp.h"
 #include "../../include/gvf_rast.h"
 #include "../../include/gvf_dit.h"
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef gvf_f32x4 f32x4;
 
 #ifndef RB_DEPTH
 #define RB_DEPTH 4                               // k-steps of weight fragments in flight per wave (16 VGPRs each)
@@ -88,14 +88,6 @@ struct RbParams {
     long long* dbg;                              // RB_TIMING builds only: [workgroup][16] s_memtime stamps
 };
 
-__device__ __forceinline__ unsigned rb_pack_bf16(float lo, float hi) {
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-    bf16x2 v;
-    v[0] = (__bf16)lo;
-    v[1] = (__bf16)hi;
-    return __builtin_bit_cast(unsigned, v);
-}
-
 // GELU (tanh form) = x * sigmoid(2u), u = sqrt(2/pi) (x + 0.044715 x^3), as gemm.hip's epilogue -- with the hardware reciprocal (1 ulp)
 // in place of the IEEE division (~10 instructions per element; 48 elements per lane per 512 hidden units, on the critical path
 // between the two GEMMs of a slice)
@@ -110,7 +102,8 @@ __device__ __forceinline__ void rb_dma16(const unsigned short* g, uint4* l) {
     __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-__device__ __forceinline__ bf16x8 rb_ldw(const uint4* p) { return __builtin_bit_cast(bf16x8, *p); }
+template <int DT>
+__device__ __forceinline__ typename GvfLp<DT>::x8 rb_ldw(const uint4* p) { return __builtin_bit_cast(typename GvfLp<DT>::x8, *p); }
 
 // The weight stream of one wave: the k-steps of W1, then of the MLP section, then of W3, packed back to back (32 KiB per step).
 // Past the end it repeats its last step (the refills behind the last MFMAs are redundant, never out of bounds).
@@ -127,14 +120,15 @@ struct RbStream {
 // the weight fragments refilled in place D steps ahead.  g = index of the first step in the stream.  D: the stream is new to the L2 in
 // every launch (the DiT's weights are 100+ MB), so a refill is a miss to the Infinity Cache / HBM for the first workgroup of an XCD that
 // asks and a wait on that miss for the others: ~1 us, i.e. 4+ k-steps of MFMA work.
-template <int D>
-__device__ __forceinline__ void rb_gemm(f32x4 (&acc)[3][RB_CT], bf16x8 (&wf)[D][RB_CT], const uint4* act, int steps, int& g, const RbStream& st) {
+template <int D, int DT>
+__device__ __forceinline__ void rb_gemm(f32x4 (&acc)[3][RB_CT], typename GvfLp<DT>::x8 (&wf)[D][RB_CT], const uint4* act, int steps, int& g, const RbStream& st) {
+    typedef typename GvfLp<DT>::x8 x8;
     static_assert(D % 2 == 0, "the activation fragments are double-buffered by step parity");
     // the activation fragments of step s + 1 are read from LDS while the MFMAs of step s run (the read past the last step stays
     // inside the LDS block and is never used)
-    bf16x8 af[2][3];
+    x8 af[2][3];
 #pragma unroll
-    for (int rt = 0; rt < 3; ++rt) af[0][rt] = __builtin_bit_cast(bf16x8, act[rt * 64]);
+    for (int rt = 0; rt < 3; ++rt) af[0][rt] = __builtin_bit_cast(x8, act[rt * 64]);
     // (not unrolled: in straight-line code the scheduler sinks every refill to just before its use and the prefetch is gone)
 #pragma clang loop unroll(disable)
     for (int ksl = 0; ksl < steps; ksl += D, g += D) {
@@ -145,7 +139,7 @@ __device__ __forceinline__ void rb_gemm(f32x4 (&acc)[3][RB_CT], bf16x8 (&wf)[D][
 #ifdef RB_ABL_NOLDS                // timing experiment: activation fragments as opaque register values
                 asm volatile("" : "+v"(af[(b + 1) & 1][rt]));
 #else
-                af[(b + 1) & 1][rt] = __builtin_bit_cast(bf16x8, act[((ksl + b + 1) * 3 + rt) * 64]);
+                af[(b + 1) & 1][rt] = __builtin_bit_cast(x8, act[((ksl + b + 1) * 3 + rt) * 64]);
 #endif
             }
             __builtin_amdgcn_sched_barrier(0);   // ... issued BEFORE this step's MFMAs (the scheduler would sink them behind)
@@ -154,9 +148,9 @@ __device__ __forceinline__ void rb_gemm(f32x4 (&acc)[3][RB_CT], bf16x8 (&wf)[D][
             for (int ct = 0; ct < RB_CT; ++ct) {
 #pragma unroll
                 for (int rt = 0; rt < 3; ++rt)
-                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b][ct], af[b & 1][rt], acc[rt][ct], 0, 0, 0);
+                    acc[rt][ct] = GvfLp<DT>::mfma16(wf[b][ct], af[b & 1][rt], acc[rt][ct]);
 #ifndef RB_ABL_NOW                 // timing experiment: no weight refills at all
-                wf[b][ct] = rb_ldw(sn + ct * 64);
+                wf[b][ct] = rb_ldw<DT>(sn + ct * 64);
 #endif
             }
             __builtin_amdgcn_sched_barrier(0);   // the refills stay in the step that frees their registers
@@ -190,6 +184,7 @@ __device__ __forceinline__ void rb_put_frag(uint2* base, int ct, int rt, uint2 o
 
 // LayerNorm of the 48 rows held in v (row 16 rt + l15, columns colw + 16 ct + i), times mul plus add, as bf16 fragments into
 // `block` (and to hb_out).  v is left centred.  Two barriers; the caller adds the one that publishes `block`.
+template <int DT>
 __device__ __forceinline__ void rb_layernorm(f32x4 (&v)[3][RB_CT], float* sRed, const float* mul, const float* add, float eps, uint4* block,
                                              unsigned short* hb_out_row0, int wave, int lane, int lq, int l15, int colw) {
     float rsum[3];
@@ -244,16 +239,18 @@ __device__ __forceinline__ void rb_layernorm(f32x4 (&v)[3][RB_CT], float* sRed, 
 #pragma unroll
             for (int i = 0; i < 4; ++i) y[i] = (v[rt][ct][i] * rstd[rt]) * mu[i] + ad[i];
             uint2 o;
-            o.x = rb_pack_bf16(y[0], y[1]);
-            o.y = rb_pack_bf16(y[2], y[3]);
+            o.x = GvfLp<DT>::pack(y[0], y[1]);
+            o.y = GvfLp<DT>::pack(y[2], y[3]);
             rb_put_frag(fb, ct, rt, o);
             if (hb_out_row0 != nullptr) *reinterpret_cast<uint2*>(hbr[rt] + 16 * ct) = o;
         }
     }
 }
 
-template <bool MLP, int D>
+template <bool MLP, int D, int DT>
 __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
+    typedef GvfLp<DT> LP;
+    typedef typename LP::x8 x8;
     __shared__ uint4 smem[RB_SMEM];              // the ONE LDS object (a second one makes hipcc drain vmcnt before every ds_read)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, lq = lane >> 4;
     const int m0 = blockIdx.x * RB_BM;           // M % 48 == 0: no row guards anywhere
@@ -287,12 +284,12 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
                 rb_dma16(p.A + (long long)(m0 + 16 * rt + l15) * p.lda + ks * 32 + 8 * lq, &R1[(ks * 3 + rt) * 64]);
         }
     }
-    bf16x8 wf[D][RB_CT];
+    x8 wf[D][RB_CT];
 #pragma unroll
     for (int b = 0; b < D; ++b) {
         const uint4* s0 = st.at(b);
 #pragma unroll
-        for (int ct = 0; ct < RB_CT; ++ct) wf[b][ct] = rb_ldw(s0 + ct * 64);
+        for (int ct = 0; ct < RB_CT; ++ct) wf[b][ct] = rb_ldw<DT>(s0 + ct * 64);
     }
     const int colw = wave * 64 + 4 * lq;        // this lane's first column inside column tile 0
     float* xr[3];                                // this lane's three rows of the stream, at its first column
@@ -409,7 +406,7 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
     }
     // ---- phase 1: x = x + gate1 * (A W1^T + b1), LayerNorm ln1 -> R0
     int g = 0;
-    rb_gemm<D>(acc, wf, R1 + lane, G1, g, st);
+    rb_gemm<D, DT>(acc, wf, R1 + lane, G1, g, st);
     RB_STAMP();
 #pragma unroll
     for (int ct = 0; ct < RB_CT; ++ct) {
@@ -428,7 +425,7 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
     }
     RB_STAMP();
     unsigned short* hb_rows = p.hb_out != nullptr ? p.hb_out + (long long)m0 * RB_C : nullptr;
-    rb_layernorm(acc, sRed, sPar + 2 * RB_C, sPar + 3 * RB_C, p.eps, R0, MLP ? nullptr : hb_rows, wave, lane, lq, l15, colw);
+    rb_layernorm<DT>(acc, sRed, sPar + 2 * RB_C, sPar + 3 * RB_C, p.eps, R0, MLP ? nullptr : hb_rows, wave, lane, lq, l15, colw);
 
     RB_STAMP();
     if (MLP) {
@@ -439,7 +436,7 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
         for (int s = 0; s < Pm; ++s) {
             rb_lds_barrier();                     // R0 complete (s = 0) / every wave done reading R1 (s > 0)
             rb_zero(acc);
-            rb_gemm<D>(acc, wf, R0 + lane, RB_KS, g, st);
+            rb_gemm<D, DT>(acc, wf, R0 + lane, RB_KS, g, st);
 #pragma unroll
             for (int ct = 0; ct < RB_CT; ++ct) {
                 const f32x4 b4 = *reinterpret_cast<const f32x4*>(sPar + 8 * RB_C + s * RB_C + colw + 16 * ct);
@@ -449,13 +446,13 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) y[i] = rb_gelu_tanh(acc[rt][ct][i] + b4[i]);
                     uint2 o;
-                    o.x = rb_pack_bf16(y[0], y[1]);
-                    o.y = rb_pack_bf16(y[2], y[3]);
+                    o.x = LP::pack(y[0], y[1]);
+                    o.y = LP::pack(y[2], y[3]);
                     rb_put_frag(fb1, ct, rt, o);
                 }
             }
             rb_lds_barrier();                     // the slice is complete in R1
-            rb_gemm<D>(acc2, wf, R1 + lane, RB_KS, g, st);
+            rb_gemm<D, DT>(acc2, wf, R1 + lane, RB_KS, g, st);
         }
 #pragma unroll
         for (int ct = 0; ct < RB_CT; ++ct) {
@@ -473,7 +470,7 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
         }
         RB_STAMP();
         if (P3 == 0 && hb_rows == nullptr) return;       // last block: final_layer reads the stream itself (gvf_dit_final_layer_f32)
-        rb_layernorm(acc2, sRed, sPar + 6 * RB_C, sPar + 7 * RB_C, p.eps, R0, hb_rows, wave, lane, lq, l15, colw);
+        rb_layernorm<DT>(acc2, sRed, sPar + 6 * RB_C, sPar + 7 * RB_C, p.eps, R0, hb_rows, wave, lane, lq, l15, colw);
         RB_STAMP();
     }
     if (P3 == 0) return;
@@ -487,7 +484,7 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
     uint2* stg_w = reinterpret_cast<uint2*>(R1);
     for (int pass = 0; pass < P3; ++pass) {
         rb_zero(acc);
-        rb_gemm<D>(acc, wf, R0 + lane, RB_KS, g, st);
+        rb_gemm<D, DT>(acc, wf, R0 + lane, RB_KS, g, st);
         const int col0 = pass * RB_C + colw;
         if (pass > 0) rb_lds_barrier();          // every wave has drained the previous tile
 #pragma unroll
@@ -497,8 +494,8 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
 #pragma unroll
             for (int rt = 0; rt < 3; ++rt) {
                 uint2 o;
-                o.x = rb_pack_bf16(acc[rt][ct][0] + b4[0], acc[rt][ct][1] + b4[1]);
-                o.y = rb_pack_bf16(acc[rt][ct][2] + b4[2], acc[rt][ct][3] + b4[3]);
+                o.x = LP::pack(acc[rt][ct][0] + b4[0], acc[rt][ct][1] + b4[1]);
+                o.y = LP::pack(acc[rt][ct][2] + b4[2], acc[rt][ct][3] + b4[3]);
                 stg_w[((16 * rt + l15) * 64 + (chunk ^ l15)) * 2 + (lq & 1)] = o;
             }
         }
@@ -519,7 +516,7 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
                 float k8[8], ss = 0.f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    k8[2 * i] = __uint_as_float(w[i] << 16); k8[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+                    k8[2 * i] = LP::lo(w[i]); k8[2 * i + 1] = LP::hi(w[i]);
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) ss += k8[e] * k8[e];
@@ -527,8 +524,8 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
                 ss += __shfl_xor(ss, 2, 64);
                 const float mul = p.gamma_k != nullptr ? p.k_scale * 5.656854249492381f / fmaxf(sqrtf(ss), 1e-12f) : p.k_scale;
                 uint4 o;
-                o.x = rb_pack_bf16(k8[0] * mul * gg[0], k8[1] * mul * gg[1]); o.y = rb_pack_bf16(k8[2] * mul * gg[2], k8[3] * mul * gg[3]);
-                o.z = rb_pack_bf16(k8[4] * mul * gg[4], k8[5] * mul * gg[5]); o.w = rb_pack_bf16(k8[6] * mul * gg[6], k8[7] * mul * gg[7]);
+                o.x = LP::pack(k8[0] * mul * gg[0], k8[1] * mul * gg[1]); o.y = LP::pack(k8[2] * mul * gg[2], k8[3] * mul * gg[3]);
+                o.z = LP::pack(k8[4] * mul * gg[4], k8[5] * mul * gg[5]); o.w = LP::pack(k8[6] * mul * gg[6], k8[7] * mul * gg[7]);
                 int row = m0 + r;
                 if (p.kv_group_rows > 0) {               // padded groups: rows behind a group's keys write nothing, key sets count keys only
                     const int grp = m0 / p.rpg, local = row - grp * p.rpg;
@@ -635,7 +632,7 @@ extern "C" int gvf_rowblock_args_layout(int32_t* out, int n) {
     const int v[] = {(int)sizeof(gvf_rowblock_args), (int)offsetof(gvf_rowblock_args, x), (int)offsetof(gvf_rowblock_args, in_x), (int)offsetof(gvf_rowblock_args, gate1),
                      (int)offsetof(gvf_rowblock_args, mod_ld), (int)offsetof(gvf_rowblock_args, b_fc1), (int)offsetof(gvf_rowblock_args, ln2),
                      (int)offsetof(gvf_rowblock_args, b3), (int)offsetof(gvf_rowblock_args, hb_out), (int)offsetof(gvf_rowblock_args, k_tiles),
-                     (int)offsetof(gvf_rowblock_args, gamma_k), (int)offsetof(gvf_rowblock_args, kv_group_rows)};
+                     (int)offsetof(gvf_rowblock_args, gamma_k), (int)offsetof(gvf_rowblock_args, kv_group_rows), (int)offsetof(gvf_rowblock_args, dtype)};
     const int m = (int)(sizeof(v) / sizeof(v[0]));
     for (int i = 0; i < n && i < m; ++i) out[i] = v[i];
     return m;
@@ -670,8 +667,8 @@ extern "C" int gvf_rowblock_pack_mlp(const void* w_fc1_bf16, const void* w_fc2_b
     return GVF_OK;
 }
 
-extern "C" int gvf_rowblock_fused_bf16(const gvf_rowblock_args* a, void* stream_) {
-    if (!a) return GVF_EINVAL;
+static int rowblock_launch(const gvf_rowblock_args* a, int dtype, void* stream_) {
+    if (!a || (dtype != GVF_DT_BF16 && dtype != GVF_DT_F16)) return GVF_EINVAL;
     // K1 == 0: no closing projection (the stream already holds the sub-layer's result, e.g. input_layer in fp32): LayerNorm + projection only
     if (a->M < 0 || a->M % RB_BM != 0 || a->C != RB_C || a->K1 < 0 || a->K1 % (32 * RB_DEPTH) != 0 || a->K1 > 512) return GVF_EINVAL;
     if (a->K1 > 0 && (a->lda < a->K1 || a->lda % 8 != 0)) return GVF_EINVAL;
@@ -725,8 +722,12 @@ extern "C" int gvf_rowblock_fused_bf16(const gvf_rowblock_args* a, void* stream_
     p.dbg = g_rb_dbg;
     (void)hipGetLastError();
     const dim3 grid((unsigned)(a->M / RB_BM)), block(RB_THREADS);
-    if (mlp) rowblock_kernel<true, RB_DEPTH_MLP><<<grid, block, 0, (hipStream_t)stream_>>>(p);
-    else rowblock_kernel<false, RB_DEPTH><<<grid, block, 0, (hipStream_t)stream_>>>(p);
+    GVF_LP_DISPATCH(dtype,
+        if (mlp) rowblock_kernel<true, RB_DEPTH_MLP, DT><<<grid, block, 0, (hipStream_t)stream_>>>(p);
+        else rowblock_kernel<false, RB_DEPTH, DT><<<grid, block, 0, (hipStream_t)stream_>>>(p));
     GVF_CHECK_LAUNCH();
     return GVF_OK;
 }
+
+extern "C" int gvf_rowblock_fused(const gvf_rowblock_args* a, void* stream_) { return rowblock_launch(a, a ? a->dtype : -1, stream_); }
+extern "C" int gvf_rowblock_fused_bf16(const gvf_rowblock_args* a, void* stream_) { return rowblock_launch(a, GVF_DT_BF16, stream_); }

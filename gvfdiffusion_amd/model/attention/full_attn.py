@@ -1,9 +1,11 @@
 """scaled_dot_product_attention with the reference's three calling conventions
 (model/attention/full_attn.py:38-140): (qkv [N,L,3,H,C]) | (q [N,L,H,C], kv [N,L,2,H,C]) |
-(q, k, v [N,L,H,C]); no mask, no dropout, scale 1/sqrt(C); returns [N,L,H,C] in the input dtype."""
+(q, k, v [N,L,H,C]); no mask, no dropout, scale 1/sqrt(C); returns [N,L,H,C] in the input dtype.
+fp16 / bf16 tensors are contracted in their own type (fp16 MFMA / bf16 MFMA, fp32 softmax and accumulation) -- flash-attn's contract; fp32
+tensors are rounded to the type ops/precision.py resolves (an active autocast region's dtype, else bf16)."""
 import torch
 
-from ...ops import dit_ops
+from ...ops import dit_ops, precision
 
 __all__ = ["scaled_dot_product_attention"]
 
@@ -43,9 +45,9 @@ def scaled_dot_product_attention(*args, **kwargs):
     if C not in (32, 64):
         raise NotImplementedError(f"hip attention backend: head_dim {C} (32 and 64 are built)")
     dt = q.dtype
-    q, k, v = (t if t.dtype == torch.bfloat16 else t.to(torch.bfloat16) for t in (q, k, v))
+    lp = precision.resolve(tensors=(q, k, v))
+    q, k, v = (t if t.dtype == lp else t.to(lp) for t in (q, k, v))
     q, k, v = (t if (t.stride(3) == 1 and t.stride(2) == C) else t.contiguous() for t in (q, k, v))
-    out = torch.empty((N, Lq, H, C), dtype=torch.bfloat16, device=q.device)
-    dit_ops.attention_bf16(q, k, v, out, N, 1, Lq, k.shape[1], H, _strides(q), _strides(k), _strides(v), _strides(out),
-                           head_dim=C)
-    return out if dt == torch.bfloat16 else out.to(dt)
+    out = torch.empty((N, Lq, H, C), dtype=lp, device=q.device)
+    dit_ops.attention(q, k, v, out, N, 1, Lq, k.shape[1], H, _strides(q), _strides(k), _strides(v), _strides(out), head_dim=C)
+    return out if dt == lp else out.to(dt)

@@ -1,6 +1,6 @@
 """MultiHeadRMSNorm / MultiHeadAttention with the reference's constructor, parameter names and
 forward contract (model/attention/modules.py:8-15,63-146), computed by the gfx950 kernels:
-bf16 MFMA projections (csrc/gemm.hip) and flash attention with the QK-RMSNorm fused into its operand
+fp16 / bf16 MFMA projections (csrc/gemm.hip; the type: ops/precision.py) and flash attention with the QK-RMSNorm fused into its operand
 loads (csrc/attn.hip).  RoPE is not built: DiT passes use_rope=False to every block (model/dit.py:357-366) and the reference's
 RotaryPositionEmbedder does not broadcast against the dense (B, L, H, d) tensors this module would hand it (dead code upstream)."""
 from typing import *
@@ -8,7 +8,7 @@ from typing import *
 import torch
 import torch.nn as nn
 
-from ...ops import dit_ops
+from ...ops import dit_ops, precision
 
 __all__ = ["MultiHeadRMSNorm", "MultiHeadAttention"]
 
@@ -27,19 +27,19 @@ class MultiHeadRMSNorm(nn.Module):
 
 
 class _WeightCache:
-    """bf16 (K padded to a multiple of 64) copies of nn.Linear weights, refreshed when the parameter changes."""
+    """16-bit (K padded to a multiple of 64) copies of nn.Linear weights, refreshed when the parameter changes."""
 
     def __init__(self):
         self._c = {}
 
-    def get(self, lin: nn.Linear):
+    def get(self, lin: nn.Linear, lp=torch.bfloat16):
         w = lin.weight
-        key = id(lin)
+        key = (id(lin), lp)
         ver = (w._version, w.data_ptr(), w.device)
         hit = self._c.get(key)
         if hit is None or hit[0] != ver:
             k = w.shape[1]
-            wb = dit_ops.cast_pad_bf16(w.detach().float().contiguous(), dit_ops.pad64(k))
+            wb = dit_ops.cast_pad(w.detach().float().contiguous(), dit_ops.pad64(k), dtype=lp)
             b = None if lin.bias is None else lin.bias.detach().float().contiguous()
             hit = (ver, wb, b)
             self._c[key] = hit
@@ -80,34 +80,41 @@ class MultiHeadAttention(nn.Module):
             self.k_rms_norm = MultiHeadRMSNorm(self.head_dim, num_heads)
         self.to_out = nn.Linear(channels, channels)
         self._wc = _WeightCache()
+        self.compute_dtype = None          # None: ops/precision.py decides per call (input type, autocast, bf16)
+
+    def set_compute_dtype(self, dtype):
+        self.compute_dtype = precision.parse(dtype)
+        return self
 
     def _gammas(self):
         if not self.qk_rms_norm:
             return None, None
         return self.q_rms_norm.gamma.detach().float().contiguous(), self.k_rms_norm.gamma.detach().float().contiguous()
 
-    def _proj(self, x2d_bf16, lin, out_dtype=torch.bfloat16):
-        w, b = self._wc.get(lin)
-        out = torch.empty((x2d_bf16.shape[0], lin.out_features), dtype=out_dtype, device=x2d_bf16.device)
-        epi = dit_ops.EPI_STORE_BF16 if out_dtype == torch.bfloat16 else dit_ops.EPI_STORE_F32
-        return dit_ops.gemm_bf16(x2d_bf16, w, b, out, epi)
+    def _proj(self, x2d, lin, out_dtype=None):
+        w, b = self._wc.get(lin, x2d.dtype)
+        out_dtype = x2d.dtype if out_dtype is None else out_dtype
+        out = torch.empty((x2d.shape[0], lin.out_features), dtype=out_dtype, device=x2d.device)
+        epi = dit_ops.EPI_STORE_F32 if out_dtype == torch.float32 else dit_ops.EPI_STORE_16
+        return dit_ops.gemm(x2d, w, b, out, epi)
 
     def forward(self, x: torch.Tensor, context: Optional[torch.Tensor] = None, indices: Optional[torch.Tensor] = None) -> torch.Tensor:
         B, L, C = x.shape
         H, d = self.num_heads, self.head_dim
-        xb = dit_ops.cast_pad_bf16(x.reshape(B * L, C).float().contiguous(), dit_ops.pad64(C))
+        lp = precision.resolve(self.compute_dtype, (x, context))
+        xb = dit_ops.cast_pad(x.reshape(B * L, C).float().contiguous(), dit_ops.pad64(C), dtype=lp)
         gq, gk = self._gammas()
-        attn = torch.empty((B * L, C), dtype=torch.bfloat16, device=x.device)
+        attn = torch.empty((B * L, C), dtype=lp, device=x.device)
         if self._type == "self":
             qkv = self._proj(xb, self.to_qkv)                      # (B*L, 3C) = [q | k | v] per token
             s = (L * 3 * C, 0, 3 * C)
-            dit_ops.attention_bf16(qkv, qkv[:, C:], qkv[:, 2 * C:], attn, B, 1, L, L, H, s, s, s, (L * C, 0, C), gq, gk, head_dim=d)
+            dit_ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], attn, B, 1, L, L, H, s, s, s, (L * C, 0, C), gq, gk, head_dim=d)
         else:
             Lkv = context.shape[1]
-            cb = dit_ops.cast_pad_bf16(context.reshape(B * Lkv, -1).float().contiguous(), dit_ops.pad64(context.shape[-1]))
+            cb = dit_ops.cast_pad(context.reshape(B * Lkv, -1).float().contiguous(), dit_ops.pad64(context.shape[-1]), dtype=lp)
             q = self._proj(xb, self.to_q)
             kv = self._proj(cb, self.to_kv)                        # (B*Lkv, 2C) = [k | v]
             sk = (Lkv * 2 * C, 0, 2 * C)
-            dit_ops.attention_bf16(q, kv, kv[:, C:], attn, B, 1, L, Lkv, H, (L * C, 0, C), sk, sk, (L * C, 0, C), gq, gk, head_dim=d)
+            dit_ops.attention(q, kv, kv[:, C:], attn, B, 1, L, Lkv, H, (L * C, 0, C), sk, sk, (L * C, 0, C), gq, gk, head_dim=d)
         out = self._proj(attn, self.to_out, out_dtype=torch.float32)
         return out.reshape(B, L, C).to(x.dtype)

@@ -12,8 +12,10 @@ The forward pass does not call the sub-modules one by one: it drives the gfx950 
   * everything that depends only on the conditions -- image_cond_proj, static_cond_proj, every block's
     to_kv(context), the position embedding -- is computed once per condition set and reused for all
     NFEs (static K/V additionally once per sample instead of once per frame: dit.py:465 repeats it over T).
-Numerics follow torch.autocast placement: bf16 contraction operands, fp32 accumulation, fp32 residual
-stream / LayerNorm / softmax / modulation (the reference runs fp16 autocast; bf16 per BASELINE.json).
+Numerics follow torch.autocast placement: 16-bit contraction operands, fp32 accumulation, fp32 residual
+stream / LayerNorm / softmax / modulation.  The operand type is fp16 -- what the reference runs (accelerate
+mixed_precision='fp16', inference_dpm_latent.py:122-125; configs/diffusion.yml use_fp16: true) -- or bf16 (BASELINE.json),
+same MFMA rate: ops/precision.py has the rule, `set_compute_dtype` / GVF_DIT_DTYPE the override.
 There is no CPU path: CPU tensors raise (the fp32 CPU restatement lives in oracle/dit_ref.py, tests only).
 """
 import math
@@ -24,7 +26,7 @@ import torch
 import torch.nn as nn
 
 from .attention import MultiHeadAttention
-from ..ops import dit_ops
+from ..ops import dit_ops, precision
 from .. import _lib
 
 
@@ -170,7 +172,8 @@ class DiT(nn.Module):
         self.static_cond_proj = nn.Linear(static_cond_channels, model_channels)
         self.image_cond_proj = nn.Linear(image_cond_channels, model_channels)
         self.initialize_weights()
-        self._wcache = None       # bf16 weights, rebuilt when any parameter changes
+        self._wcache = None       # 16-bit weights, rebuilt when any parameter (or the compute dtype) changes
+        self.compute_dtype = None # None: ops/precision.py decides per forward (GVF_DIT_DTYPE, autocast, use_fp16 -> fp16 else bf16)
         self._ctx_cache = {}      # step-invariant condition products
         self.use_graph = False    # replay the whole forward as one hipGraph (set by enable_graph)
         import os
@@ -185,10 +188,21 @@ class DiT(nn.Module):
         self.use_rowblock = int(os.environ.get("GVF_DIT_ROWBLOCK", "1")) != 0
         self.rowblock_tiled_kv = int(os.environ.get("GVF_DIT_TILED_KV", "1")) != 0    # to_qkv's launch writes the attention's K / V^T tiles itself
         self._graph = None
+        self.capture_blocks = None     # diagnostics: a list -> _blocks_rowblock appends a copy of the fp32 stream after every block
 
     @property
     def device(self) -> torch.device:
         return next(self.parameters()).device
+
+    def set_compute_dtype(self, dtype):
+        """torch.float16 / torch.bfloat16 (or "fp16" / "bf16"); None hands the choice back to ops/precision.py."""
+        self.compute_dtype = precision.parse(dtype)
+        return self
+
+    def _lp(self):
+        """The matrix pipe's operand type for this forward (see ops/precision.py).  The inputs are fp32 in the reference's
+        pipeline; a 16-bit x does not change the choice (the stream is fp32 either way)."""
+        return precision.resolve(self.compute_dtype, (), torch.float16 if self.use_fp16 else torch.bfloat16)
 
     def initialize_weights(self) -> None:
         """Same scheme as model/dit.py:401-427 (xavier Linear, zero bias, N(0,0.02) embedders, zero adaLN / head)."""
@@ -214,20 +228,21 @@ class DiT(nn.Module):
     def _param_version(self):
         return tuple((p._version, p.data_ptr()) for p in self.parameters())
 
-    def _weights(self):
-        ver = self._param_version()
+    def _weights(self, lp=None):
+        lp = self._lp() if lp is None else lp
+        ver = (self._param_version(), lp)
         if self._wcache is not None and self._wcache["ver"] == ver:
             return self._wcache
 
         def prep(lin):
             w = lin.weight.detach().float().contiguous()
-            return dit_ops.cast_pad_bf16(w, dit_ops.pad64(w.shape[1])), \
+            return dit_ops.cast_pad(w, dit_ops.pad64(w.shape[1]), dtype=lp), \
                 (None if lin.bias is None else lin.bias.detach().float().contiguous())
 
         def prep32(lin):
             return lin.weight.detach().float().contiguous(), (None if lin.bias is None else lin.bias.detach().float().contiguous())
 
-        W = {"ver": ver}
+        W = {"ver": ver, "lp": lp}
         # the small projections (0.3 % of the FLOPs, a third of the bf16 error: csrc/elem.hip) stay in fp32
         W["input_f32"], W["final_f32"] = prep32(self.input_layer), prep32(self.final_layer.linear)
         W["input_f32"] = (W["input_f32"][0].t().contiguous(), W["input_f32"][1])          # (Cin, C): the kernel copies it straight into LDS
@@ -250,7 +265,7 @@ class DiT(nn.Module):
         mods_w.append(self.final_layer.adaLN_modulation[-1].weight.detach().float())
         mods_b.append(self.final_layer.adaLN_modulation[-1].bias.detach().float())
         W["mod_w_f32"] = torch.cat(mods_w).contiguous()
-        W["mod_w"] = dit_ops.cast_pad_bf16(W["mod_w_f32"], dit_ops.pad64(self.model_channels))
+        W["mod_w"] = dit_ops.cast_pad(W["mod_w_f32"], dit_ops.pad64(self.model_channels), dtype=lp)
         W["mod_b"] = torch.cat(mods_b).contiguous()
         W["mod_offs"], W["mod_total"] = offs, W["mod_b"].numel()
         W["blocks"] = []
@@ -274,7 +289,7 @@ class DiT(nn.Module):
     def _rowblock_streams(self, W):
         """Packed weight streams of the row-block launches (csrc/rowblock.hip), built once per weight version: every launch reads ONE
         stream -- the projection that closes a sub-layer, [the MLP,] the projection that opens the next one -- in the order it consumes
-        it.  Same bf16 values as W's plain copies."""
+        it.  Same 16-bit values as W's plain copies."""
         if "rb" in W:
             return W["rb"]
         P = dit_ops.rowblock_pack_stream
@@ -323,21 +338,22 @@ class DiT(nn.Module):
         self._graph = None
 
     def prepare_conditions(self, cond_images, static_latent, deformation_position_xyz, T: int):
-        """image_emb / static_emb -> per-block cross-attention K,V (bf16), and the APE.  Cached on the identity of the
+        """image_emb / static_emb -> per-block cross-attention K,V (tile images in the compute dtype), and the APE.  Cached on the identity of the
         three condition tensors; the entry HOLDS them (see _same_tensors), so a hit is a proof of equal contents.
         gvfdiffusion_amd's model_wrapper hands the same (concatenated) condition tensors to every step; a wrapper
         that rebuilds them per call still gets correct results, only without the reuse."""
         W = self._weights()
+        lp = W["lp"]
         conds = (cond_images, static_latent, deformation_position_xyz)
-        if self._ctx_cache.get("T") == T and self._same_tensors(self._ctx_cache.get("held"), conds):
+        if self._ctx_cache.get("T") == T and self._ctx_cache.get("lp") == lp and self._same_tensors(self._ctx_cache.get("held"), conds):
             return self._ctx_cache
         C = self.model_channels
         dev = cond_images.device
         B, Tc, Li, Ci = cond_images.shape
         Ls = static_latent.shape[1]
-        ctx = {"T": T, "held": (conds, tuple(self._key(t) for t in conds)), "Li": Li, "Ls": Ls}
+        ctx = {"T": T, "lp": lp, "held": (conds, tuple(self._key(t) for t in conds)), "Li": Li, "Ls": Ls}
         # Step-invariant, so precision here is free: condition projections and every block's to_kv(context) as plain fp32 library GEMMs
-        # (rocBLAS through torch, ~5 ms per sample), ONE rounding to bf16 when the cache builder folds the softmax scale in and stores the
+        # (rocBLAS through torch, ~5 ms per sample), ONE rounding to 16 bits when the cache builder folds the softmax scale in and stores the
         # tiled image the attention workgroups stage into LDS (csrc/attn_xt.hip); static K/V once per sample, not per frame.
         H = self.num_heads
         ctx["kv_img"], ctx["kv_st"] = [], []
@@ -360,9 +376,9 @@ class DiT(nn.Module):
         lin_out(static_latent.reshape(B * Ls, -1).float(), W["static_f32"], st_emb)
         for b in W["blocks"]:
             lin_out(img_emb, b["image_cross_attn"]["kv_f32"], kv_i)
-            ctx["kv_img"].append(dit_ops.attention_pack_kv(kv_i, B * Tc, Li, H, 0, C, gamma_k=b["image_cross_attn"]["gk"]))
+            ctx["kv_img"].append(dit_ops.attention_pack_kv(kv_i, B * Tc, Li, H, 0, C, gamma_k=b["image_cross_attn"]["gk"], dtype=lp))
             lin_out(st_emb, b["static_cross_attn"]["kv_f32"], kv_s)
-            ctx["kv_st"].append(dit_ops.attention_pack_kv(kv_s, B, Ls, H, 0, C, gamma_k=b["static_cross_attn"]["gk"]))
+            ctx["kv_st"].append(dit_ops.attention_pack_kv(kv_s, B, Ls, H, 0, C, gamma_k=b["static_cross_attn"]["gk"], dtype=lp))
         if self.pe_mode == "ape":
             assert deformation_position_xyz is not None, "Deformation position xyz is required for APE mode"
             ctx["pos"] = self.pos_embedder(deformation_position_xyz).float().contiguous()      # (B, N, C)
@@ -392,7 +408,7 @@ class DiT(nn.Module):
     def _forward_graphed(self, x, t, cond_images, static_latent, deformation_position_xyz=None):
         _lib.require_cuda(x, t, cond_images, static_latent, deformation_position_xyz)
         t = t.to(x.device)
-        key = (tuple(x.shape), x.dtype, tuple(t.shape), t.dtype, self._param_version())
+        key = (tuple(x.shape), x.dtype, tuple(t.shape), t.dtype, self._param_version(), self._lp())
         conds = (cond_images, static_latent, deformation_position_xyz)
         g = self._graph
         if g is None or g["key"] != key or not self._same_tensors(g["held"], conds):
@@ -424,7 +440,7 @@ class DiT(nn.Module):
         W = self._weights()
         ctx = self.prepare_conditions(cond_images, static_latent, deformation_position_xyz, T)
         Li, Ls = ctx["Li"], ctx["Ls"]
-        bf, f32 = torch.bfloat16, torch.float32
+        bf, f32 = W["lp"], torch.float32              # bf: the 16-bit operand type of this forward (bf16 or fp16)
 
         # timestep embedder (sinusoid, two Linears, two SiLUs: one launch) and every adaLN projection of the step (one GEMV), both in fp32
         fdim = self.t_embedder.frequency_embedding_size
@@ -433,12 +449,12 @@ class DiT(nn.Module):
             mod = dit_ops.modulation_f32(s2, W["mod_w_f32"], W["mod_b"])
         else:
             mod = torch.empty((B, W["mod_total"]), dtype=f32, device=dev)
-            tf = dit_ops.cast_pad_bf16(TimestepEmbedder.timestep_embedding(t.to(dev), fdim).contiguous(), dit_ops.pad64(fdim))
+            tf = dit_ops.cast_pad(TimestepEmbedder.timestep_embedding(t.to(dev), fdim).contiguous(), dit_ops.pad64(fdim), dtype=bf)
             h1 = torch.empty((B, C), dtype=f32, device=dev)
-            dit_ops.gemm_bf16(tf, *W["t0"], h1, dit_ops.EPI_STORE_F32)
+            dit_ops.gemm(tf, *W["t0"], h1, dit_ops.EPI_STORE_F32)
             t_emb = torch.empty((B, C), dtype=f32, device=dev)
-            dit_ops.gemm_bf16(dit_ops.cast_pad_bf16(h1, dit_ops.pad64(C), act=1), *W["t2"], t_emb, dit_ops.EPI_STORE_F32)
-            dit_ops.gemm_bf16(dit_ops.cast_pad_bf16(t_emb, dit_ops.pad64(C), act=1), W["mod_w"], W["mod_b"], mod, dit_ops.EPI_STORE_F32)
+            dit_ops.gemm(dit_ops.cast_pad(h1, dit_ops.pad64(C), act=1, dtype=bf), *W["t2"], t_emb, dit_ops.EPI_STORE_F32)
+            dit_ops.gemm(dit_ops.cast_pad(t_emb, dit_ops.pad64(C), act=1, dtype=bf), W["mod_w"], W["mod_b"], mod, dit_ops.EPI_STORE_F32)
         mod_ld = W["mod_total"]
 
         # residual stream h (fp32) = position embedding broadcast over T + input_layer(x), in fp32 (csrc/elem.hip)
@@ -459,7 +475,7 @@ class DiT(nn.Module):
             h.copy_(ctx["pos"][:, None].expand(B, T, N, C).reshape(M, C))
         else:
             h.zero_()
-        xb = None if small_f32 else dit_ops.cast_pad_bf16(x.reshape(M, Cin).float().contiguous(), dit_ops.pad64(Cin))
+        xb = None if small_f32 else dit_ops.cast_pad(x.reshape(M, Cin).float().contiguous(), dit_ops.pad64(Cin), dtype=bf)
         hb = torch.empty((M, C), dtype=bf, device=dev)          # attention-output scratch of the cross attentions
         qkv = torch.empty((M, 3 * C), dtype=bf, device=dev)
         ab = torch.empty((M, C), dtype=bf, device=dev)          # attention output / q projection
@@ -473,22 +489,25 @@ class DiT(nn.Module):
         fuse_max_n = 1 << 30 if self.fuse_layernorm == 1 else 512
         n_part = dit_ops.gemm_stats_parts(C)
         stats = torch.empty((M, n_part, 2), dtype=f32, device=dev) if fuse_ln else None
+        have_stats = [False]       # the row statistics exist once a residual GEMM has written them: the fp32 input layer (csrc/elem.hip) does
+                                   # not, so block 0's first projection normalises with the LayerNorm launch
 
         def resid(a_, wb, gate=None):
             """h += gate * (a_ @ W^T + b)  (+ statistics of the new h)"""
             kw = dict(gate=gate, gate_ld=mod_ld, rows_per_group=TN) if gate is not None else {}
             if fuse_ln:
                 dit_ops.gemm_resid_stats(a_, wb[0], wb[1], h, stats, **kw)
+                have_stats[0] = True
             else:
-                dit_ops.gemm_bf16(a_, wb[0], wb[1], h, dit_ops.EPI_RESID_F32, **kw)
+                dit_ops.gemm(a_, wb[0], wb[1], h, dit_ops.EPI_RESID_F32, **kw)
 
         def ln_gemm(wb, out, epi, ln_w=None, ln_b=None, shift=None, scale=None):
             """out = epi((LN(h) * s + t) @ W^T + b)"""
-            if fuse_ln and wb[0].shape[0] <= fuse_max_n:
+            if fuse_ln and have_stats[0] and wb[0].shape[0] <= fuse_max_n:
                 dit_ops.gemm_ln_bf16(h, stats, n_part, wb[0], wb[1], out, epi, 1e-6, ln_w, ln_b, shift, scale, mod_ld, TN)
             else:
-                dit_ops.layernorm_modulate_bf16(h, hb, 1e-6, ln_w, ln_b, shift, scale, mod_ld, TN)
-                dit_ops.gemm_bf16(hb, wb[0], wb[1], out, epi)
+                dit_ops.layernorm_modulate(h, hb, 1e-6, ln_w, ln_b, shift, scale, mod_ld, TN)
+                dit_ops.gemm(hb, wb[0], wb[1], out, epi)
 
         if not small_f32:
             resid(xb, W["input"])           # h = pos + input_layer(x)
@@ -501,34 +520,34 @@ class DiT(nn.Module):
             sh_s, sc_s, g_s, sh_m, sc_m, g_m = (mview(o + k * C) for k in range(6))
             # -- spatial self attention over N
             a = b["spatial_self_attn"]
-            ln_gemm(a["qkv"], qkv, dit_ops.EPI_STORE_BF16, shift=sh_s, scale=sc_s)
+            ln_gemm(a["qkv"], qkv, dit_ops.EPI_STORE_16, shift=sh_s, scale=sc_s)
             # K (RMS-normed, pre-scaled) and V^T of this step's projection into the tiled image, then the tiled-cache kernel
             dit_ops.attention_pack_kv(qkv, B * T, N, H, C, 2 * C, gamma_k=a["gk"], out=kv_self)
-            dit_ops.attention_tiled_bf16(qkv, kv_self[0], kv_self[1], ab, B * T, 1, N, N, H, (N * 3 * C, 0, 3 * C), (N * C, 0, C), 1, 0,
-                                         gamma_q=a["gq"])
+            dit_ops.attention_tiled(qkv, kv_self[0], kv_self[1], ab, B * T, 1, N, N, H, (N * 3 * C, 0, 3 * C), (N * C, 0, C), 1, 0,
+                                    gamma_q=a["gq"])
             resid(ab, a["out"], g_s)
             # -- temporal self attention over T (strided views, no transposes)
             if not self.no_temporal_attn:
                 sh_t, sc_t, g_t = (mview(o + (6 + k) * C) for k in range(3))
                 a = b["temporal_self_attn"]
-                ln_gemm(a["qkv"], qkv, dit_ops.EPI_STORE_BF16, shift=sh_t, scale=sc_t)
+                ln_gemm(a["qkv"], qkv, dit_ops.EPI_STORE_16, shift=sh_t, scale=sc_t)
                 st = (TN * 3 * C, 3 * C, N * 3 * C)           # outer = sample, inner = token, seq = frame
-                dit_ops.attention_bf16(qkv, qkv[:, C:], qkv[:, 2 * C:], ab, B, N, T, T, H, st, st, st, (TN * C, C, N * C), a["gq"], a["gk"])
+                dit_ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], ab, B, N, T, T, H, st, st, st, (TN * C, C, N * C), a["gq"], a["gk"])
                 resid(ab, a["out"], g_t)
             # -- image cross attention (affine LayerNorm, cached K/V)
             a = b["image_cross_attn"]
-            ln_gemm(a["q"], ab, dit_ops.EPI_STORE_BF16, ln_w=b["n3"][0], ln_b=b["n3"][1])
+            ln_gemm(a["q"], ab, dit_ops.EPI_STORE_16, ln_w=b["n3"][0], ln_b=b["n3"][1])
             kt, vt = ctx["kv_img"][i]
-            dit_ops.attention_tiled_bf16(ab, kt, vt, hb, B * T, 1, N, Li, H, (N * C, 0, C), (N * C, 0, C), 1, 0, gamma_q=a["gq"])
+            dit_ops.attention_tiled(ab, kt, vt, hb, B * T, 1, N, Li, H, (N * C, 0, C), (N * C, 0, C), 1, 0, gamma_q=a["gq"])
             resid(hb, a["out"])
             # -- static cross attention: K/V shared by the T frames of a sample (inner stride 0)
             a = b["static_cross_attn"]
-            ln_gemm(a["q"], ab, dit_ops.EPI_STORE_BF16, ln_w=b["n4"][0], ln_b=b["n4"][1])
+            ln_gemm(a["q"], ab, dit_ops.EPI_STORE_16, ln_w=b["n4"][0], ln_b=b["n4"][1])
             kt, vt = ctx["kv_st"][i]
-            dit_ops.attention_tiled_bf16(ab, kt, vt, hb, B, T, N, Ls, H, (TN * C, N * C, C), (TN * C, N * C, C), 1, 0, gamma_q=a["gq"])
+            dit_ops.attention_tiled(ab, kt, vt, hb, B, T, N, Ls, H, (TN * C, N * C, C), (TN * C, N * C, C), 1, 0, gamma_q=a["gq"])
             resid(hb, a["out"])
             # -- MLP
-            ln_gemm(b["fc1"], hidden, dit_ops.EPI_GELU_BF16, shift=sh_m, scale=sc_m)
+            ln_gemm(b["fc1"], hidden, dit_ops.EPI_GELU_16, shift=sh_m, scale=sc_m)
             resid(hidden, b["fc2"], g_m)
 
         o = W["mod_offs"][-1]
@@ -552,7 +571,7 @@ class DiT(nn.Module):
         padded = TNp != TN
         M = B * TNp
         dev = x2d.device
-        bf, f32 = torch.bfloat16, torch.float32
+        bf, f32 = W["lp"], torch.float32              # bf: the 16-bit operand type (bf16 or fp16); the packed streams are of that type
         rb = self._rowblock_streams(W)
         Li, Ls = ctx["Li"], ctx["Ls"]
         # buffers an attention writes and a row-block launch reads whole: their padding rows must stay finite
@@ -576,7 +595,7 @@ class DiT(nn.Module):
             return mod[:, off:]
 
         def fused(a_, stream, **kw):
-            dit_ops.rowblock_fused(a_, stream, h, mod_ld=mod_ld, rows_per_group=TNp, eps=1e-6, **kw)
+            dit_ops.rowblock_fused(a_, stream, h, mod_ld=mod_ld, rows_per_group=TNp, eps=1e-6, dtype=bf, **kw)
 
         o = offs[0]
         # h = pos + input_layer(x); adaLN of block 0; its to_qkv
@@ -610,10 +629,10 @@ class DiT(nn.Module):
             n3, n4 = dict(ln_w=b["n3"][0], ln_b=b["n3"][1]), dict(ln_w=b["n4"][0], ln_b=b["n4"][1])
             a = b["spatial_self_attn"]
             if tiled_kv:
-                dit_ops.attention_tiled_bf16(qs, kv_self[0], kv_self[1], ab, *fr["n"], N, N, H, fr["c"], fr["c"], *fr["kv"], gamma_q=a["gq"])
+                dit_ops.attention_tiled(qs, kv_self[0], kv_self[1], ab, *fr["n"], N, N, H, fr["c"], fr["c"], *fr["kv"], gamma_q=a["gq"])
             else:                                              # (never padded: see _forward)
                 dit_ops.attention_pack_kv(qkv, B * T, N, H, C, 2 * C, gamma_k=a["gk"], out=kv_self)
-                dit_ops.attention_tiled_bf16(qkv, kv_self[0], kv_self[1], ab, *fr["n"], N, N, H, fr["c3"], fr["c"], *fr["kv"], gamma_q=a["gq"])
+                dit_ops.attention_tiled(qkv, kv_self[0], kv_self[1], ab, *fr["n"], N, N, H, fr["c3"], fr["c"], *fr["kv"], gamma_q=a["gq"])
             ai = b["image_cross_attn"]
             if self.no_temporal_attn:
                 fused(ab, s["s2"], b1=a["out"][1], gate1=g_s, ln1=n3, out3=qb, b3=ai["q"][1])
@@ -622,20 +641,22 @@ class DiT(nn.Module):
                 at = b["temporal_self_attn"]
                 fused(ab, s["s2"], b1=a["out"][1], gate1=g_s, ln1=dict(shift=sh_t, scale=sc_t), out3=qkv, b3=at["qkv"][1])
                 st = (TNp * 3 * C, 3 * C, N * 3 * C)          # outer = sample, inner = token, seq = frame
-                dit_ops.attention_bf16(qkv, qkv[:, C:], qkv[:, 2 * C:], ab, B, N, T, T, H, st, st, st, (TNp * C, C, N * C), at["gq"], at["gk"])
+                dit_ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], ab, B, N, T, T, H, st, st, st, (TNp * C, C, N * C), at["gq"], at["gk"])
                 fused(ab, s["s3"], b1=at["out"][1], gate1=g_t, ln1=n3, out3=qb, b3=ai["q"][1])
             kt, vt = ctx["kv_img"][i]
-            dit_ops.attention_tiled_bf16(qb, kt, vt, hb, *fr["n"], N, Li, H, fr["c"], fr["c"], *fr["kv"], gamma_q=ai["gq"])
+            dit_ops.attention_tiled(qb, kt, vt, hb, *fr["n"], N, Li, H, fr["c"], fr["c"], *fr["kv"], gamma_q=ai["gq"])
             ast = b["static_cross_attn"]
             fused(hb, s["s4"], b1=ai["out"][1], ln1=n4, out3=qb, b3=ast["q"][1])
             kt, vt = ctx["kv_st"][i]
-            dit_ops.attention_tiled_bf16(qb, kt, vt, hb, B, T, N, Ls, H, fr_c, fr_c, 1, 0, gamma_q=ast["gq"])
+            dit_ops.attention_tiled(qb, kt, vt, hb, B, T, N, Ls, H, fr_c, fr_c, 1, 0, gamma_q=ast["gq"])
             kw = dict(b1=ast["out"][1], ln1=dict(shift=sh_m, scale=sc_m), mlp_bias=(b["fc1"][1], b["fc2"][1]), hidden=hidden_units, gate_m=g_m)
             if i + 1 < len(blocks):
                 on = offs[i + 1]
                 fused(hb, s["s5"], ln2=dict(shift=mview(on), scale=mview(on + C)), **qkv_out(blocks[i + 1]), **kw)
             else:
                 fused(hb, s["s5"], **kw)                       # the last MLP; final_layer reads the stream itself
+            if self.capture_blocks is not None:
+                self.capture_blocks.append(h.view(B, TNp, C)[:, :TN].reshape(B, T, N, C).clone())
         on = offs[-1]
         y = torch.empty((M, self.out_channels), dtype=f32, device=dev)
         dit_ops.final_layer_f32(h, W["final_f32"][0], W["final_f32"][1], y, shift=mview(on), scale=mview(on + C), mod_ld=mod_ld, rows_per_group=TNp)

@@ -1,4 +1,7 @@
-"""ctypes bindings of include/gvf_dit.h (csrc/gemm.hip, attn.hip, elem.hip) on torch device tensors."""
+"""ctypes bindings of include/gvf_dit.h (csrc/gemm.hip, attn.hip, attn_xt.hip, rowblock.hip, elem.hip) on torch device tensors.
+
+The 16-bit operand type of a call (GVF_DT_BF16 / GVF_DT_F16 of the C ABI) is the torch dtype of its operand tensors: torch.bfloat16 or
+torch.float16; buffers without a dtype of their own (the uint8 K / V^T tile images, packed weight streams) take it as an argument."""
 import ctypes
 
 import torch
@@ -8,6 +11,25 @@ from .. import _lib
 _vp, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 
 EPI_STORE_BF16, EPI_GELU_BF16, EPI_STORE_F32, EPI_RESID_F32 = 0, 1, 2, 3
+EPI_STORE_16, EPI_GELU_16 = EPI_STORE_BF16, EPI_GELU_BF16        # (the 16-bit output takes the call's operand type)
+DT_BF16, DT_F16 = 0, 1
+LP_DTYPES = (torch.bfloat16, torch.float16)
+
+
+def dt_code(dtype) -> int:
+    """torch.bfloat16 / torch.float16 -> GVF_DT_BF16 / GVF_DT_F16 (include/gvf_dit.h)."""
+    if dtype == torch.bfloat16:
+        return DT_BF16
+    if dtype == torch.float16:
+        return DT_F16
+    raise _lib.GvfError(f"the matrix-pipe operand type must be torch.bfloat16 or torch.float16, got {dtype}")
+
+
+def _same_lp(*tensors) -> int:
+    dts = {t.dtype for t in tensors if t is not None and t.dtype in LP_DTYPES}
+    if len(dts) != 1:
+        raise _lib.GvfError(f"operands must share one 16-bit type (bf16 or fp16), got {[t.dtype for t in tensors if t is not None]}")
+    return dt_code(dts.pop())
 
 
 
@@ -28,7 +50,7 @@ class RowblockArgs(ctypes.Structure):
                 ("b3", _vp), ("out3", _vp), ("N3", ctypes.c_int32), ("epi3", ctypes.c_int32),
                 ("hb_out", _vp),
                 ("k_tiles", _vp), ("v_tiles", _vp), ("kv_L", ctypes.c_int32), ("k_scale", _f), ("gamma_k", _vp),
-                ("kv_group_rows", ctypes.c_int32)]
+                ("kv_group_rows", ctypes.c_int32), ("dtype", ctypes.c_int32)]
 
 
 _lib.register({
@@ -41,19 +63,26 @@ _lib.register({
     "gvf_rowblock_packed_bytes": (_i64, [_i, _i]),
     "gvf_rowblock_pack_weight": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "gvf_rowblock_pack_mlp": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "gvf_rowblock_fused": (_i, [ctypes.POINTER(RowblockArgs), _vp]),
     "gvf_rowblock_fused_bf16": (_i, [ctypes.POINTER(RowblockArgs), _vp]),
-    "gvf_gemm_bf16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "gvf_gemm_stats_parts": (_i, [_i]),
-    "gvf_gemm_bf16_resid_stats": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
-    "gvf_gemm_ln_bf16": (_i, [_vp, _i, _vp, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    "gvf_attn_fwd_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i] + [ctypes.POINTER(_i64)] * 4 + [_i, _vp, _vp, _f, _vp]),
-    "gvf_attn_varlen_fwd_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i] + [ctypes.POINTER(_i64)] * 4 + [_vp, _vp, _f, _vp]),
-    "gvf_attn_pack_kv_bf16": (_i, [_vp, _i, _i64, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
-    "gvf_attn_tiled_fwd_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, ctypes.POINTER(_i64), ctypes.POINTER(_i64), _i64, _i64,
-                                    _vp, _i, _i, _vp, _vp]),
-    "gvf_layernorm_modulate_bf16": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _vp]),
-    "gvf_cast_pad_bf16": (_i, [_vp, _i, _vp, _i, _i64, _i, _i, _vp]),
 })
+# every entry point that contracts 16-bit operands exists as NAME(dtype, ...) and as the round-1/2 wrapper NAME_bf16(...)
+_GEMM_ARGS = [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]
+_PAIRS = {
+    ("gvf_gemm", "gvf_gemm_bf16"): _GEMM_ARGS,
+    ("gvf_gemm_resid_stats", "gvf_gemm_bf16_resid_stats"): [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp],
+    ("gvf_gemm_ln", "gvf_gemm_ln_bf16"): [_vp, _i, _vp, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    ("gvf_attn_fwd", "gvf_attn_fwd_bf16"): [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i] + [ctypes.POINTER(_i64)] * 4 + [_i, _vp, _vp, _f, _vp],
+    ("gvf_attn_varlen_fwd", "gvf_attn_varlen_fwd_bf16"): [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i] + [ctypes.POINTER(_i64)] * 4 + [_vp, _vp, _f, _vp],
+    ("gvf_attn_pack_kv", "gvf_attn_pack_kv_bf16"): [_vp, _i, _i64, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp],
+    ("gvf_attn_tiled_fwd", "gvf_attn_tiled_fwd_bf16"): [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, ctypes.POINTER(_i64), ctypes.POINTER(_i64), _i64, _i64,
+                                                        _vp, _i, _i, _vp, _vp],
+    ("gvf_layernorm_modulate", "gvf_layernorm_modulate_bf16"): [_vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    ("gvf_cast_pad", "gvf_cast_pad_bf16"): [_vp, _i, _vp, _i, _i64, _i, _i, _vp],
+}
+_lib.register({new: (_i, [_i] + args) for (new, _old), args in _PAIRS.items()})
+_lib.register({old: (_i, args) for (_new, old), args in _PAIRS.items()})
 
 
 def _p(t):
@@ -68,29 +97,34 @@ def pad64(k: int) -> int:
     return (k + 63) // 64 * 64
 
 
-def cast_pad_bf16(src: torch.Tensor, ld_dst: int = None, act: int = 0, out: torch.Tensor = None) -> torch.Tensor:
-    """fp32 (rows, cols) -> bf16 (rows, ld_dst) zero-padded; act 1 = SiLU."""
+def cast_pad(src: torch.Tensor, ld_dst: int = None, act: int = 0, out: torch.Tensor = None, dtype=torch.bfloat16) -> torch.Tensor:
+    """fp32 (rows, cols) -> bf16 / fp16 (rows, ld_dst) zero-padded; act 1 = SiLU.  The type is out's, else `dtype`."""
     _lib.require_cuda(src)
     assert src.dtype == torch.float32 and src.dim() == 2 and src.stride(1) == 1
     rows, cols = src.shape
     ld_dst = cols if ld_dst is None else ld_dst
     if out is None:
-        out = torch.empty((rows, ld_dst), dtype=torch.bfloat16, device=src.device)
-    _lib.check(_lib.lib().gvf_cast_pad_bf16(_p(src), src.stride(0), _p(out), ld_dst, rows, cols, act, _stream(src)),
-               "gvf_cast_pad_bf16")
+        out = torch.empty((rows, ld_dst), dtype=dtype, device=src.device)
+    _lib.check(_lib.lib().gvf_cast_pad(dt_code(out.dtype), _p(src), src.stride(0), _p(out), ld_dst, rows, cols, act, _stream(src)),
+               "gvf_cast_pad")
     return out
 
 
-def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, epilogue: int, gate: torch.Tensor = None,
+def cast_pad_bf16(src, ld_dst=None, act=0, out=None):
+    return cast_pad(src, ld_dst, act, out, torch.bfloat16)
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, epilogue: int, gate: torch.Tensor = None,
               gate_ld: int = 0, rows_per_group: int = 0, n: int = None):
-    """out (M, >=N) <- epilogue(a (M,K) @ w (N,K)^T + bias).  a, w bf16 with K % 64 == 0."""
+    """out (M, >=N) <- epilogue(a (M,K) @ w (N,K)^T + bias).  a, w bf16 or fp16 (the same) with K % 64 == 0; a 16-bit `out` has their type."""
     _lib.require_cuda(a, w, out)
-    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a.stride(1) == 1 and w.stride(1) == 1
+    dt = _same_lp(a, w, out)
+    assert a.stride(1) == 1 and w.stride(1) == 1
     M, K = a.shape
     N = w.shape[0] if n is None else n
     assert w.shape[1] == K and out.stride(-1) == 1
-    _lib.check(_lib.lib().gvf_gemm_bf16(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), M, N, K,
-                                        epilogue, _p(gate), gate_ld, rows_per_group, _stream(a)), "gvf_gemm_bf16")
+    _lib.check(_lib.lib().gvf_gemm(dt, _p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), M, N, K,
+                                   epilogue, _p(gate), gate_ld, rows_per_group, _stream(a)), "gvf_gemm")
     return out
 
 
@@ -102,12 +136,13 @@ def gemm_resid_stats(a, w, bias, x, stats, gate=None, gate_ld=0, rows_per_group=
     """x (M, N) fp32 += gate * (a @ w^T + bias), and stats (M, parts(N), 2) <- per-row partial (sum, sum of squares) of the
     UPDATED x (input of gemm_ln_bf16)."""
     _lib.require_cuda(a, w, x, stats)
-    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.dtype == torch.float32 and stats.dtype == torch.float32
+    dt = _same_lp(a, w)
+    assert x.dtype == torch.float32 and stats.dtype == torch.float32
     M, K = a.shape
     N = w.shape[0]
     assert stats.is_contiguous() and stats.numel() >= M * gemm_stats_parts(N) * 2
-    _lib.check(_lib.lib().gvf_gemm_bf16_resid_stats(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(x), x.stride(0), M, N, K,
-                                                    _p(gate), gate_ld, rows_per_group, _p(stats), _stream(a)), "gvf_gemm_bf16_resid_stats")
+    _lib.check(_lib.lib().gvf_gemm_resid_stats(dt, _p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(x), x.stride(0), M, N, K,
+                                               _p(gate), gate_ld, rows_per_group, _p(stats), _stream(a)), "gvf_gemm_resid_stats")
     return x
 
 
@@ -115,12 +150,13 @@ def gemm_ln_bf16(x, stats, n_part, w, bias, out, epilogue, eps=1e-6, ln_w=None, 
                  rows_per_group=0):
     """out <- epilogue((LayerNorm(x) * s + t) @ w^T + bias) with LN statistics from gemm_resid_stats; see include/gvf_dit.h."""
     _lib.require_cuda(x, stats, w, out)
-    assert x.dtype == torch.float32 and w.dtype == torch.bfloat16 and x.stride(1) == 1
+    dt = _same_lp(w, out)
+    assert x.dtype == torch.float32 and x.stride(1) == 1
     M, K = x.shape
     N = w.shape[0]
-    _lib.check(_lib.lib().gvf_gemm_ln_bf16(_p(x), x.stride(0), _p(stats), int(n_part), float(eps), _p(ln_w), _p(ln_b), _p(shift), _p(scale),
-                                           int(mod_ld), int(rows_per_group), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), M, N, K,
-                                           int(epilogue), _stream(x)), "gvf_gemm_ln_bf16")
+    _lib.check(_lib.lib().gvf_gemm_ln(dt, _p(x), x.stride(0), _p(stats), int(n_part), float(eps), _p(ln_w), _p(ln_b), _p(shift), _p(scale),
+                                      int(mod_ld), int(rows_per_group), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), M, N, K,
+                                      int(epilogue), _stream(x)), "gvf_gemm_ln")
     return out
 
 
@@ -194,13 +230,14 @@ def rowblock_padded_rows(rows: int) -> int:
 
 
 def rowblock_pack_stream(w1, mlp=None, w3=None):
-    """One weight stream for gvf_rowblock_fused_bf16: w1 = nn.Linear weight bf16 [512][K1 padded to 128] (see cast_pad_bf16), mlp =
-    (mlp.0 weight bf16 [hidden][512], mlp.2 weight bf16 [512][hidden]) or None, w3 = bf16 [N3][512] or None.  Returns a uint8 tensor."""
+    """One weight stream for gvf_rowblock_fused: w1 = nn.Linear weight bf16 / fp16 [512][K1 padded to 128] (see cast_pad), mlp =
+    (mlp.0 weight [hidden][512], mlp.2 weight [512][hidden]) or None, w3 = [N3][512] or None, all of ONE 16-bit type (the packers move 16-bit
+    words: the stream has the type of its sources, which the launch must be told: rowblock_fused(dtype=...)).  Returns a uint8 tensor."""
     L = _lib.lib()
     ref = w1 if w1 is not None else (w3 if w3 is not None else mlp[0])
     _lib.require_cuda(ref)
     if w1 is not None:
-        assert w1.dtype == torch.bfloat16 and w1.shape[0] == ROWBLOCK_C and w1.shape[1] % ROWBLOCK_KPAD == 0 and w1.is_contiguous()
+        assert w1.dtype in LP_DTYPES and w1.shape[0] == ROWBLOCK_C and w1.shape[1] % ROWBLOCK_KPAD == 0 and w1.is_contiguous()
     sizes = [0 if w1 is None else int(L.gvf_rowblock_packed_bytes(ROWBLOCK_C, w1.shape[1]))]
     sizes.append(0 if mlp is None else 2 * mlp[0].shape[0] * ROWBLOCK_C * 2)
     sizes.append(0 if w3 is None else int(L.gvf_rowblock_packed_bytes(w3.shape[0], ROWBLOCK_C)))
@@ -210,11 +247,11 @@ def rowblock_pack_stream(w1, mlp=None, w3=None):
         _lib.check(L.gvf_rowblock_pack_weight(_p(w1), w1.stride(0), ROWBLOCK_C, w1.shape[1], _p(out), st), "gvf_rowblock_pack_weight")
     if mlp is not None:
         f1, f2 = mlp
-        assert f1.dtype == f2.dtype == torch.bfloat16 and f1.is_contiguous() and f2.is_contiguous()
+        assert f1.dtype == f2.dtype and f1.dtype in LP_DTYPES and f1.is_contiguous() and f2.is_contiguous()
         assert f1.shape == (f2.shape[1], ROWBLOCK_C) and f2.shape[0] == ROWBLOCK_C
         _lib.check(L.gvf_rowblock_pack_mlp(_p(f1), _p(f2), f1.shape[0], _p(out[sizes[0]:]), st), "gvf_rowblock_pack_mlp")
     if w3 is not None:
-        assert w3.dtype == torch.bfloat16 and w3.shape[1] == ROWBLOCK_C and w3.is_contiguous() and w3.shape[0] % ROWBLOCK_C == 0
+        assert w3.dtype in LP_DTYPES and w3.shape[1] == ROWBLOCK_C and w3.is_contiguous() and w3.shape[0] % ROWBLOCK_C == 0
         _lib.check(L.gvf_rowblock_pack_weight(_p(w3), w3.stride(0), w3.shape[0], ROWBLOCK_C, _p(out[sizes[0] + sizes[1]:]), st),
                    "gvf_rowblock_pack_weight")
     return out
@@ -230,7 +267,8 @@ def _ln_struct(ln):
 
 
 def rowblock_fused(a, stream_w, x, b1=None, gate1=None, ln1=None, mod_ld=0, rows_per_group=0, eps=1e-6,
-                   mlp_bias=None, hidden=0, gate_m=None, ln2=None, b3=None, out3=None, hb_out=None, x_in=None, x_in_period=0, kv_tiles=None, kv_L=0, gamma_k=None, kv_scale=None, in_x=None, in_wt=None, in_b=None, kv_group_rows=0):
+                   mlp_bias=None, hidden=0, gate_m=None, ln2=None, b3=None, out3=None, hb_out=None, x_in=None, x_in_period=0, kv_tiles=None, kv_L=0, gamma_k=None, kv_scale=None, in_x=None, in_wt=None, in_b=None, kv_group_rows=0,
+                   dtype=None):
     """x += gate1 * (a W1^T + b1); hb = LN1(x); [x += gate_m * MLP(hb); hb = LN2(x)]; out3 = hb W3^T + b3 or hb_out = hb -- ONE launch
     (csrc/rowblock.hip; include/gvf_dit.h).  ln1 / ln2: dict with ln_w, ln_b and / or shift, scale.  mlp_bias = (b_fc1, b_fc2).
     a = None: no closing projection (x already holds the sub-layer's result; the stream has no W1 segment).
@@ -239,9 +277,13 @@ def rowblock_fused(a, stream_w, x, b1=None, gate1=None, ln1=None, mod_ld=0, rows
     assert x.dtype == torch.float32 and x.is_contiguous()
     M, C = x.shape
     args = RowblockArgs()
+    lp = [t for t in (a, out3, hb_out) if t is not None]
+    dt = _same_lp(*lp) if lp else dt_code(dtype)          # the packed stream and the K / V^T tiles are of the same type (the caller's contract)
+    assert dtype is None or dt_code(dtype) == dt
+    args.dtype = dt
     if a is not None:
         _lib.require_cuda(a)
-        assert a.dtype == torch.bfloat16 and a.stride(1) == 1
+        assert a.stride(1) == 1
         args.a, args.lda, args.K1 = _pi(a), a.stride(0), a.shape[1]
     args.w, args.b1 = _pi(stream_w), _pi(b1)
     args.x, args.M, args.C = _pi(x), M, C
@@ -258,7 +300,7 @@ def rowblock_fused(a, stream_w, x, b1=None, gate1=None, ln1=None, mod_ld=0, rows
         args.b_fc1, args.b_fc2 = _pi(mlp_bias[0]), _pi(mlp_bias[1])
         args.hidden, args.gate_m, args.ln2 = int(hidden), _pi(gate_m), _ln_struct(ln2)
     if out3 is not None:
-        assert out3.dtype == torch.bfloat16 and out3.is_contiguous() and out3.shape[0] == M
+        assert out3.is_contiguous() and out3.shape[0] == M
         args.b3, args.out3, args.N3, args.epi3 = _pi(b3), _pi(out3), out3.shape[1], EPI_STORE_BF16
     if kv_tiles is not None:        # to_qkv of the spatial self attention: out3 = q [M][C]; k, v -> tiled images (see attention_pack_kv)
         assert out3 is not None and out3.shape[1] == C and kv_L % 64 == 0
@@ -275,9 +317,9 @@ def rowblock_fused(a, stream_w, x, b1=None, gate1=None, ln1=None, mod_ld=0, rows
         args.k_tiles, args.v_tiles, args.kv_L = _pi(kv_tiles[0]), _pi(kv_tiles[1]), int(kv_L)
         args.k_scale, args.gamma_k = float((32 ** -0.5 if kv_scale is None else kv_scale) * LOG2E), _pi(gamma_k)
     if hb_out is not None:
-        assert hb_out.dtype == torch.bfloat16 and hb_out.is_contiguous() and tuple(hb_out.shape) == (M, C)
+        assert hb_out.is_contiguous() and tuple(hb_out.shape) == (M, C)
         args.hb_out = _pi(hb_out)
-    _lib.check(_lib.lib().gvf_rowblock_fused_bf16(ctypes.byref(args), _stream(x)), "gvf_rowblock_fused_bf16")
+    _lib.check(_lib.lib().gvf_rowblock_fused(ctypes.byref(args), _stream(x)), "gvf_rowblock_fused")
     return x
 
 
@@ -288,32 +330,34 @@ def _s4(st, head_dim=32):
     return (_i64 * 4)(*st)
 
 
-def attention_bf16(q, k, v, out, n_outer, n_inner, Lq, Lk, H, q_strides, k_strides, v_strides, o_strides, gamma_q=None,
+def attention(q, k, v, out, n_outer, n_inner, Lq, Lk, H, q_strides, k_strides, v_strides, o_strides, gamma_q=None,
                    gamma_k=None, scale=None, v_transposed=False, head_dim=32):
     """Strided flash attention (head_dim 32 or 64).  *_strides = (outer, inner, seq[, head = head_dim]) in
     elements; v_transposed: v stored [..][head][d][key] with v_strides[2] the d stride (see include/gvf_dit.h)."""
     _lib.require_cuda(q, k, v, out)
-    assert q.dtype == k.dtype == v.dtype == out.dtype == torch.bfloat16
+    dt = _same_lp(q, k, v, out)
+    assert q.dtype == k.dtype == v.dtype == out.dtype
     scale = head_dim ** -0.5 if scale is None else scale
-    _lib.check(_lib.lib().gvf_attn_fwd_bf16(_p(q), _p(k), _p(v), _p(out), n_outer, n_inner, Lq, Lk, H, head_dim,
-                                            _s4(q_strides, head_dim), _s4(k_strides, head_dim), _s4(v_strides, head_dim),
-                                            _s4(o_strides, head_dim), int(bool(v_transposed)), _p(gamma_q), _p(gamma_k),
-                                            float(scale), _stream(q)), "gvf_attn_fwd_bf16")
+    _lib.check(_lib.lib().gvf_attn_fwd(dt, _p(q), _p(k), _p(v), _p(out), n_outer, n_inner, Lq, Lk, H, head_dim,
+                                       _s4(q_strides, head_dim), _s4(k_strides, head_dim), _s4(v_strides, head_dim),
+                                       _s4(o_strides, head_dim), int(bool(v_transposed)), _p(gamma_q), _p(gamma_k),
+                                       float(scale), _stream(q)), "gvf_attn_fwd")
     return out
 
 
-def attention_varlen_bf16(q, k, v, out, cu_q, cu_k, max_Lq, max_Lk, H, q_strides, k_strides, v_strides, o_strides,
+def attention_varlen(q, k, v, out, cu_q, cu_k, max_Lq, max_Lk, H, q_strides, k_strides, v_strides, o_strides,
                           gamma_q=None, gamma_k=None, scale=None, head_dim=32):
     """Packed variable-length attention: cu_q / cu_k int32 device tensors [n_seqs + 1]."""
     _lib.require_cuda(q, k, v, out, cu_q, cu_k)
-    assert q.dtype == k.dtype == v.dtype == out.dtype == torch.bfloat16
+    dt = _same_lp(q, k, v, out)
+    assert q.dtype == k.dtype == v.dtype == out.dtype
     assert cu_q.dtype == torch.int32 and cu_k.dtype == torch.int32 and cu_q.numel() == cu_k.numel()
     scale = head_dim ** -0.5 if scale is None else scale
-    _lib.check(_lib.lib().gvf_attn_varlen_fwd_bf16(_p(q), _p(k), _p(v), _p(out), cu_q.numel() - 1, _p(cu_q), _p(cu_k),
-                                                   int(max_Lq), int(max_Lk), H, head_dim, _s4(q_strides, head_dim),
-                                                   _s4(k_strides, head_dim), _s4(v_strides, head_dim),
-                                                   _s4(o_strides, head_dim), _p(gamma_q), _p(gamma_k), float(scale),
-                                                   _stream(q)), "gvf_attn_varlen_fwd_bf16")
+    _lib.check(_lib.lib().gvf_attn_varlen_fwd(dt, _p(q), _p(k), _p(v), _p(out), cu_q.numel() - 1, _p(cu_q), _p(cu_k),
+                                              int(max_Lq), int(max_Lk), H, head_dim, _s4(q_strides, head_dim),
+                                              _s4(k_strides, head_dim), _s4(v_strides, head_dim),
+                                              _s4(o_strides, head_dim), _p(gamma_q), _p(gamma_k), float(scale),
+                                              _stream(q)), "gvf_attn_varlen_fwd")
     return out
 
 
@@ -321,11 +365,14 @@ LOG2E = 1.4426950408889634
 
 
 def attention_pack_kv(kv: torch.Tensor, n_sets: int, L: int, H: int, k_col0: int, v_col0: int, scale: float = None,
-                      gamma_k: torch.Tensor = None, out=None):
-    """kv rows (n_sets * L, ld) fp32 or bf16 -> (k_tiles, v_tiles) uint8 device buffers in the tiled cache image of
-    csrc/attn_xt.hip (K pre-multiplied by scale * log2 e, optional RMSNorm gain)."""
+                      gamma_k: torch.Tensor = None, out=None, dtype=None):
+    """kv rows (n_sets * L, ld) fp32, bf16 or fp16 -> (k_tiles, v_tiles) uint8 device buffers in the tiled cache image of
+    csrc/attn_xt.hip (K pre-multiplied by scale * log2 e, optional RMSNorm gain).  The tiles' 16-bit type is that of a 16-bit
+    `kv`, else `dtype` (fp32 rows; default bf16)."""
     _lib.require_cuda(kv)
-    assert kv.dim() == 2 and kv.stride(1) == 1 and kv.dtype in (torch.float32, torch.bfloat16)
+    assert kv.dim() == 2 and kv.stride(1) == 1 and kv.dtype in (torch.float32,) + LP_DTYPES
+    dt = dt_code(kv.dtype) if kv.dtype in LP_DTYPES else dt_code(dtype or torch.bfloat16)
+    assert dtype is None or dt_code(dtype) == dt
     n_tiles = (L + 63) // 64
     nbytes = n_sets * H * n_tiles * 4096
     if out is None:
@@ -333,31 +380,36 @@ def attention_pack_kv(kv: torch.Tensor, n_sets: int, L: int, H: int, k_col0: int
     kt, vt = out
     assert kt.numel() >= nbytes and vt.numel() >= nbytes
     scale = 32 ** -0.5 if scale is None else scale
-    _lib.check(_lib.lib().gvf_attn_pack_kv_bf16(_p(kv), int(kv.dtype == torch.float32), kv.stride(0), k_col0, v_col0, n_sets, L, H,
-                                                float(scale * LOG2E), _p(gamma_k), _p(kt), _p(vt), _stream(kv)),
-               "gvf_attn_pack_kv_bf16")
+    _lib.check(_lib.lib().gvf_attn_pack_kv(dt, _p(kv), int(kv.dtype == torch.float32), kv.stride(0), k_col0, v_col0, n_sets, L, H,
+                                           float(scale * LOG2E), _p(gamma_k), _p(kt), _p(vt), _stream(kv)),
+               "gvf_attn_pack_kv")
     return kt, vt
 
 
-def attention_tiled_bf16(q, k_tiles, v_tiles, out, n_outer, n_inner, Lq, Lk, H, q_strides, o_strides, kv_stride_outer,
+def attention_tiled(q, k_tiles, v_tiles, out, n_outer, n_inner, Lq, Lk, H, q_strides, o_strides, kv_stride_outer,
                          kv_stride_inner, gamma_q=None, force_exact=False, fallback_counter=None):
-    """Cross attention against a tiled K/V cache (head_dim 32); see include/gvf_dit.h."""
+    """Cross attention against a tiled K/V cache (head_dim 32) of q's 16-bit type; see include/gvf_dit.h."""
     _lib.require_cuda(q, k_tiles, v_tiles, out)
-    assert q.dtype == torch.bfloat16 and out.dtype in (torch.bfloat16, torch.float32)
-    _lib.check(_lib.lib().gvf_attn_tiled_fwd_bf16(_p(q), _p(k_tiles), _p(v_tiles), _p(out), n_outer, n_inner, Lq, Lk, H,
-                                                  _s4(q_strides), _s4(o_strides), int(kv_stride_outer), int(kv_stride_inner),
-                                                  _p(gamma_q), int(out.dtype == torch.float32), int(bool(force_exact)),
-                                                  _p(fallback_counter), _stream(q)),
-               "gvf_attn_tiled_fwd_bf16")
+    assert q.dtype in LP_DTYPES and out.dtype in (q.dtype, torch.float32)
+    _lib.check(_lib.lib().gvf_attn_tiled_fwd(dt_code(q.dtype), _p(q), _p(k_tiles), _p(v_tiles), _p(out), n_outer, n_inner, Lq, Lk, H,
+                                             _s4(q_strides), _s4(o_strides), int(kv_stride_outer), int(kv_stride_inner),
+                                             _p(gamma_q), int(out.dtype == torch.float32), int(bool(force_exact)),
+                                             _p(fallback_counter), _stream(q)),
+               "gvf_attn_tiled_fwd")
     return out
 
 
-def layernorm_modulate_bf16(x, out, eps=1e-6, ln_w=None, ln_b=None, shift=None, scale=None, mod_ld=0, rows_per_group=0):
-    """x fp32 (rows, C) -> out bf16 (rows, C): LN then affine (ln_w, ln_b) and/or adaLN (shift, scale views)."""
+def layernorm_modulate(x, out, eps=1e-6, ln_w=None, ln_b=None, shift=None, scale=None, mod_ld=0, rows_per_group=0):
+    """x fp32 (rows, C) -> out bf16 / fp16 (rows, C): LN then affine (ln_w, ln_b) and/or adaLN (shift, scale views)."""
     _lib.require_cuda(x, out)
-    assert x.dtype == torch.float32 and out.dtype == torch.bfloat16 and x.is_contiguous() and out.is_contiguous()
+    assert x.dtype == torch.float32 and x.is_contiguous() and out.is_contiguous()
     rows, C = x.shape
-    _lib.check(_lib.lib().gvf_layernorm_modulate_bf16(_p(x), _p(out), rows, C, float(eps), _p(ln_w), _p(ln_b), _p(shift),
-                                                      _p(scale), mod_ld, rows_per_group, _stream(x)),
-               "gvf_layernorm_modulate_bf16")
+    _lib.check(_lib.lib().gvf_layernorm_modulate(dt_code(out.dtype), _p(x), _p(out), rows, C, float(eps), _p(ln_w), _p(ln_b), _p(shift),
+                                                 _p(scale), mod_ld, rows_per_group, _stream(x)),
+               "gvf_layernorm_modulate")
     return out
+
+
+# round-1/2 names (the functions take either 16-bit type)
+gemm_bf16, attention_bf16, attention_varlen_bf16, attention_tiled_bf16 = gemm, attention, attention_varlen, attention_tiled
+layernorm_modulate_bf16 = layernorm_modulate

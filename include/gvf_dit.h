@@ -7,8 +7,12 @@
  *   model/attention/modules.py:112-146    the nn.Linear projections around it                 -> gvf_gemm_bf16
  *   model/dit.py:128-138, 246-277         FeedForwardNet, adaLN modulate / gate / residual     -> gvf_gemm_bf16 epilogues,
  *                                                                                               gvf_layernorm_modulate_bf16
- * Numerics: operands bf16, accumulation fp32 (MFMA 16x16x32 / 32x32x16 bf16), softmax / LayerNorm /
+ * Numerics: 16-bit contraction operands, accumulation fp32 (MFMA 16x16x32 / 32x32x16), softmax / LayerNorm /
  * RMSNorm / residual stream in fp32 -- the placement the reference gets from torch.autocast.
+ * The operand type is a run-time argument `dtype` of every entry point below: GVF_DT_F16 (what the reference
+ * runs: accelerate mixed_precision='fp16', inference_dpm_latent.py:122-125) or GVF_DT_BF16 (what BASELINE.json
+ * names); same MFMA rate, same layouts.  The `*_bf16` names are the round-1/2 entry points, kept as wrappers
+ * with dtype = GVF_DT_BF16.  "16-bit" below means the type `dtype` selects.
  * Conventions as in gvf_rast.h: device pointers, caller-owned buffers, explicit stream, int status.
  */
 #ifndef GVF_DIT_H
@@ -21,7 +25,10 @@
 extern "C" {
 #endif
 
-/* gvf_gemm_bf16 epilogues:  acc[m][n] = sum_k A[m][k] * W[n][k]  (+ bias[n]) */
+#define GVF_DT_BF16 0
+#define GVF_DT_F16  1
+
+/* gvf_gemm epilogues:  acc[m][n] = sum_k A[m][k] * W[n][k]  (+ bias[n]) */
 #define GVF_EPI_STORE_BF16   0   /* C bf16 [M][ldc]  = acc                                  */
 #define GVF_EPI_GELU_BF16    1   /* C bf16           = gelu_tanh(acc)      (mlp.0)          */
 #define GVF_EPI_STORE_F32    2   /* C f32  [M][ldc]  = acc                                  */
@@ -30,6 +37,8 @@ extern "C" {
 /* C = A W^T (+bias): A bf16 [M][lda] row-major, W bf16 [N][ldw] row-major (nn.Linear layout),
  * K a multiple of 64 (pad activations and weights), lda/ldw multiples of 8, bias f32 [N] or null.
  * gate f32: row g of `gate` (leading dimension gate_ld) applies to rows [g*rows_per_group, ...). */
+int gvf_gemm(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc,
+             int M, int N, int K, int epilogue, const float* gate, int gate_ld, int rows_per_group, void* stream);
 int gvf_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc,
                   int M, int N, int K, int epilogue, const float* gate, int gate_ld, int rows_per_group,
                   void* stream);
@@ -43,6 +52,13 @@ int gvf_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* b
  * The bf16 operand is the rounded normalised value -- exactly what gvf_layernorm_modulate_bf16 would have written --
  * but the 37.7 MB LayerNorm pass and its launch are gone.  epilogue: STORE_BF16, GELU_BF16 or STORE_F32. */
 int gvf_gemm_stats_parts(int N);
+int gvf_gemm_resid_stats(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, float* C, int ldc,
+                         int M, int N, int K, const float* gate, int gate_ld, int rows_per_group, float* row_stats,
+                         void* stream);
+int gvf_gemm_ln(int dtype, const float* X, int ldx, const float* row_stats, int n_part, float eps, const float* ln_w,
+                const float* ln_b, const float* shift, const float* scale, int mod_ld, int rows_per_group,
+                const void* W, int ldw, const float* bias, void* C, int ldc, int M, int N, int K, int epilogue,
+                void* stream);
 int gvf_gemm_bf16_resid_stats(const void* A, int lda, const void* W, int ldw, const float* bias, float* C, int ldc,
                               int M, int N, int K, const float* gate, int gate_ld, int rows_per_group, float* row_stats,
                               void* stream);
@@ -97,14 +113,16 @@ typedef struct gvf_rowblock_args {
        computed like any other row but write no keys, and key sets count tokens only (set = group * kv_group_rows / kv_L + ...). */
     void* k_tiles; void* v_tiles; int32_t kv_L; float k_scale; const float* gamma_k;
     int32_t kv_group_rows;
+    int32_t dtype;                             /* GVF_DT_BF16 / GVF_DT_F16: type of a, the packed weights, out3, hb_out and the K / V^T tiles */
 } gvf_rowblock_args;
-/* layout of gvf_rowblock_args as compiled: {sizeof, offsetof x, in_x, gate1, mod_ld, b_fc1, ln2, b3, hb_out, k_tiles, gamma_k, kv_group_rows};
-   returns the count */
+/* layout of gvf_rowblock_args as compiled: {sizeof, offsetof x, in_x, gate1, mod_ld, b_fc1, ln2, b3, hb_out, k_tiles, gamma_k, kv_group_rows,
+   dtype}; returns the count */
 int gvf_rowblock_args_layout(int32_t* out, int n);
 int64_t gvf_rowblock_packed_bytes(int N, int K);
 int gvf_rowblock_pack_weight(const void* w_bf16, int ldw, int N, int K, void* packed, void* stream);
 int gvf_rowblock_pack_mlp(const void* w_fc1_bf16, const void* w_fc2_bf16, int hidden, void* packed, void* stream);
-int gvf_rowblock_fused_bf16(const gvf_rowblock_args* args, void* stream);
+int gvf_rowblock_fused(const gvf_rowblock_args* args, void* stream);            /* operand type = args->dtype */
+int gvf_rowblock_fused_bf16(const gvf_rowblock_args* args, void* stream);       /* args->dtype ignored: bf16 */
 
 /* softmax(q k^T * scale) v, head_dim 32 or 64, no mask, scale > 0.  Batch index = (outer, inner); every tensor
  * takes 4 strides in elements {outer, inner, seq, head}: element (o,i,l,h,c) sits at
@@ -114,6 +132,11 @@ int gvf_rowblock_fused_bf16(const gvf_rowblock_args* args, void* stream);
  * stride, rows padded with finite values to a multiple of 64 keys) -- the layout of the DiT's
  * step-invariant cross-attention cache.
  * gamma_q / gamma_k: f32 [H][head_dim] MultiHeadRMSNorm gains (x <- normalize(x) * gamma * sqrt(head_dim)) or null. */
+int gvf_attn_fwd(int dtype, const void* q, const void* k, const void* v, void* out,
+                 int n_outer, int n_inner, int Lq, int Lk, int H, int head_dim,
+                 const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                 const int64_t* o_strides, int v_transposed,
+                 const float* gamma_q, const float* gamma_k, float scale, void* stream);
 int gvf_attn_fwd_bf16(const void* q, const void* k, const void* v, void* out,
                       int n_outer, int n_inner, int Lq, int Lk, int H, int head_dim,
                       const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
@@ -124,6 +147,12 @@ int gvf_attn_fwd_bf16(const void* q, const void* k, const void* v, void* out,
  * model/sparse_attention/full_attn.py:189-210: flash_attn_varlen_* / xformers BlockDiagonalMask): sequence s
  * owns query rows [cu_seqlens_q[s], cu_seqlens_q[s+1]) and key rows [cu_seqlens_k[s], cu_seqlens_k[s+1]) of
  * the packed tensors; strides as above with strides[0] (outer) normally 0.  cu_seqlens: device int32 [n_seqs+1]. */
+int gvf_attn_varlen_fwd(int dtype, const void* q, const void* k, const void* v, void* out, int n_seqs,
+                        const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k, int max_Lq, int max_Lk,
+                        int H, int head_dim,
+                        const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                        const int64_t* o_strides, const float* gamma_q, const float* gamma_k, float scale,
+                        void* stream);
 int gvf_attn_varlen_fwd_bf16(const void* q, const void* k, const void* v, void* out, int n_seqs,
                              const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k, int max_Lq, int max_Lk,
                              int H, int head_dim,
@@ -139,6 +168,8 @@ int gvf_attn_varlen_fwd_bf16(const void* q, const void* k, const void* v, void* 
  * f32 [H][32]) and 4 KiB of V^T each.  kv: f32 (kv_is_f32 != 0) or bf16 rows, row (set * L + key), leading dimension ld
  * (elements); K of head h at columns [k_col0 + 32 h, +32), V at [v_col0 + 32 h, +32).
  * k_tiles / v_tiles: n_sets * H * ceil(L / 64) * 4096 bytes each, 16-byte aligned. */
+int gvf_attn_pack_kv(int dtype, const void* kv, int kv_is_f32, int64_t ld, int k_col0, int v_col0, int n_sets, int L, int H,
+                     float k_scale, const float* gamma_k, void* k_tiles, void* v_tiles, void* stream);
 int gvf_attn_pack_kv_bf16(const void* kv, int kv_is_f32, int64_t ld, int k_col0, int v_col0, int n_sets, int L, int H,
                           float k_scale, const float* gamma_k, void* k_tiles, void* v_tiles, void* stream);
 
@@ -149,7 +180,13 @@ int gvf_attn_pack_kv_bf16(const void* kv, int kv_is_f32, int64_t ld, int k_col0,
  * (the kernel's arithmetic without the final rounding to bf16; used by the parity tests).
  * Numerics: P = exp2(s) without the running maximum while every query's denominator stays inside [2^-100, 2^100];
  * a workgroup with a query outside recomputes its 256 queries with the exact online softmax (force_exact != 0: always).
+ * GVF_DT_F16: every query's scores are shifted by its maximum over the first key tile (through the MFMA accumulator's
+ * initial value), so that exp2 stays inside fp16's range; an overflow (a later score 2^16 above that) fails the same guard.
  * fallback_counter (optional, device int32): += 1 per workgroup that took the exact path. */
+int gvf_attn_tiled_fwd(int dtype, const void* q, const void* k_tiles, const void* v_tiles, void* out, int n_outer, int n_inner,
+                       int Lq, int Lk, int H, const int64_t* q_strides, const int64_t* o_strides,
+                       int64_t kv_set_stride_outer, int64_t kv_set_stride_inner, const float* gamma_q,
+                       int out_is_f32, int force_exact, int32_t* fallback_counter, void* stream);
 int gvf_attn_tiled_fwd_bf16(const void* q, const void* k_tiles, const void* v_tiles, void* out, int n_outer, int n_inner,
                             int Lq, int Lk, int H, const int64_t* q_strides, const int64_t* o_strides,
                             int64_t kv_set_stride_outer, int64_t kv_set_stride_inner, const float* gamma_q,
@@ -158,6 +195,10 @@ int gvf_attn_tiled_fwd_bf16(const void* q, const void* k_tiles, const void* v_ti
 /* out_bf16[r][:] = LN(x[r][:]) (eps, no affine) then either  * ln_w + ln_b  (affine LayerNorm, norm3/4)
  * or  * (1 + scale[g]) + shift[g]  (adaLN, g = r / rows_per_group; shift/scale rows have stride mod_ld),
  * x f32 [rows][C]; C a multiple of 256 (<= 1024) takes the register-resident fast path. */
+int gvf_layernorm_modulate(int dtype, const float* x, void* out16, int rows, int C, float eps,
+                           const float* ln_w, const float* ln_b,
+                           const float* shift, const float* scale, int mod_ld, int rows_per_group,
+                           void* stream);
 int gvf_layernorm_modulate_bf16(const float* x, void* out_bf16, int rows, int C, float eps,
                                 const float* ln_w, const float* ln_b,
                                 const float* shift, const float* scale, int mod_ld, int rows_per_group,
@@ -165,6 +206,8 @@ int gvf_layernorm_modulate_bf16(const float* x, void* out_bf16, int rows, int C,
 
 /* dst bf16 [rows][ld_dst] = act(src f32 [rows][cols]) with zero padding of columns cols..ld_dst-1.
  * act: 0 = identity, 1 = SiLU. */
+int gvf_cast_pad(int dtype, const float* src, int ld_src, void* dst, int ld_dst, int64_t rows, int cols, int act,
+                 void* stream);
 int gvf_cast_pad_bf16(const float* src, int ld_src, void* dst, int ld_dst, int64_t rows, int cols, int act,
                       void* stream);
 

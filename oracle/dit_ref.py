@@ -29,8 +29,19 @@ import torch
 import torch.nn.functional as F
 
 
-def _r(x, precision):
-    return x.to(torch.bfloat16).to(torch.float32) if precision == "bf16" else x
+_DT = {"bf16": torch.bfloat16, "fp16": torch.float16}
+
+
+def _r(x, precision, site="gemm"):
+    """Storage rounding of a tensor at a rounding point of the HIP pipeline.  precision: "fp32" (none), "bf16", "fp16", or a
+    dict {"gemm": .., "attn": ..} giving the operand type of the projections' matrix products ("gemm": activations, weights, MLP
+    hidden units, attention outputs) and of the attention's own operands ("attn": q, k, v, P) separately."""
+    p = precision.get(site, "fp32") if isinstance(precision, dict) else precision
+    return x if p == "fp32" else x.to(_DT[p]).to(torch.float32)
+
+
+def _reduced(precision):
+    return precision != "fp32"
 
 
 # The HIP pipeline keeps the small projections in fp32 (csrc/elem.hip, and plain fp32 library GEMMs for the hoisted ones): 0.3 % of the FLOPs,
@@ -40,13 +51,13 @@ FP32_SITES = ("input_layer", "t_embedder.", "image_cond_proj", "static_cond_proj
 
 def linear(x, sd, prefix, precision, round_out=False):
     w, b = sd[prefix + ".weight"], sd.get(prefix + ".bias")
-    if precision == "bf16" and any(s in prefix or prefix.startswith(s) for s in FP32_SITES):
+    if _reduced(precision) and any(s in prefix or prefix.startswith(s) for s in FP32_SITES):
         y = F.linear(x, w, None)
         return y if b is None else y + b
     y = F.linear(_r(x, precision), _r(w, precision), None)
     if b is not None:
         y = y + b
-    return _r(y, precision) if round_out else y
+    return _r(y, precision, "attn") if round_out else y          # the projections whose outputs are stored: q / qkv
 
 
 def layer_norm(x, eps=1e-6):
@@ -56,7 +67,7 @@ def layer_norm(x, eps=1e-6):
 def rms_norm_heads(x, gamma, precision):
     """MultiHeadRMSNorm: normalize(x.float(), dim=-1) * gamma[H,d] * sqrt(d), cast back to x's dtype."""
     y = F.normalize(x.float(), dim=-1) * gamma * (x.shape[-1] ** 0.5)
-    return _r(y, precision)
+    return _r(y, precision, "attn")
 
 
 def sdpa(q, k, v, precision):
@@ -64,14 +75,14 @@ def sdpa(q, k, v, precision):
     q, k, v = (t.permute(0, 2, 1, 3) for t in (q, k, v))
     s = (q @ k.transpose(-2, -1)) * (1.0 / math.sqrt(q.shape[-1]))
     p = torch.softmax(s, dim=-1)
-    if precision == "bf16":
-        # the kernel rounds the un-normalised probabilities to bf16 and divides by the fp32 row sum afterwards
+    if _reduced(precision):
+        # the kernel rounds the un-normalised probabilities to the operand type and divides by the fp32 row sum afterwards
         m = s.amax(dim=-1, keepdim=True)
         e = torch.exp(s - m)
-        o = (_r(e, precision) @ v) / e.sum(dim=-1, keepdim=True)
+        o = (_r(e, precision, "attn") @ v) / e.sum(dim=-1, keepdim=True)
     else:
         o = p @ v
-    return _r(o.permute(0, 2, 1, 3), precision)
+    return _r(o.permute(0, 2, 1, 3), precision, "gemm")
 
 
 LOG2E = 1.4426950408889634
@@ -86,13 +97,18 @@ def sdpa_tiled(q, k, v, precision, gamma_k=None):
     d = q.shape[-1]
     if gamma_k is not None:
         k = F.normalize(k.float(), dim=-1) * gamma_k * (d ** 0.5)
-    if precision != "bf16":
+    if not _reduced(precision):
         return sdpa(q, k, v, precision)
     q, k, v = (t.permute(0, 2, 1, 3) for t in (q, k, v))
-    k2 = _r(k * (LOG2E / math.sqrt(d)), precision)
-    p = _r(torch.exp2(q @ k2.transpose(-2, -1)), precision)
-    o = (p @ _r(v, precision)) / p.sum(dim=-1, keepdim=True)
-    return _r(o.permute(0, 2, 1, 3), precision)
+    k2 = _r(k * (LOG2E / math.sqrt(d)), precision, "attn")
+    s = q @ k2.transpose(-2, -1)
+    if (precision.get("attn") if isinstance(precision, dict) else precision) == "fp16":
+        # fp16 probabilities need a per-query shift (exp2 of a raw score overflows at 16): the kernel subtracts a shift through the
+        # score accumulator's initial value; softmax is shift invariant, only the rounding grid of P moves with it
+        s = s - s.amax(dim=-1, keepdim=True)
+    p = _r(torch.exp2(s), precision, "attn")
+    o = (p @ _r(v, precision, "attn")) / p.sum(dim=-1, keepdim=True)
+    return _r(o.permute(0, 2, 1, 3), precision, "gemm")
 
 
 def self_attention(x, sd, prefix, heads, precision, tiled=False):
@@ -179,7 +195,7 @@ def block_forward(x, mod, image_emb, static_emb, sd, p, heads, precision, no_tem
     # MLP
     h = modulate(layer_norm(x), sh_m, sc_m)
     h = linear(h, sd, p + ".mlp.mlp.0", precision)
-    h = _r(F.gelu(h, approximate="tanh"), precision)
+    h = _r(F.gelu(h, approximate="tanh"), precision, "gemm")
     h = linear(h, sd, p + ".mlp.mlp.2", precision)
     return x + h * g_m[:, None, None]
 
@@ -187,7 +203,7 @@ def block_forward(x, mod, image_emb, static_emb, sd, p, heads, precision, no_tem
 def dit_forward(sd, cfg, x, t, cond_images, static_latent, deformation_position_xyz, precision="fp32",
                 return_intermediates=False):
     """sd: state_dict (reference key names); cfg: configs/diffusion.yml `model:` dict."""
-    assert precision in ("fp32", "bf16")
+    assert isinstance(precision, dict) or precision in ("fp32", "bf16", "fp16")
     C, heads, nblocks = cfg["model_channels"], cfg["num_heads"], cfg["num_blocks"]
     B, T, N, _ = x.shape
     h = linear(x, sd, "input_layer", precision)
@@ -196,11 +212,13 @@ def dit_forward(sd, cfg, x, t, cond_images, static_latent, deformation_position_
     static_emb = linear(static_latent, sd, "static_cond_proj", precision, round_out=True)[:, None].expand(B, T, -1, C)
     assert cfg.get("pe_mode", "learnable") == "ape"
     h = h + absolute_position_embedding(deformation_position_xyz, C)[:, None]
-    inter = {"h0": h, "t_emb": t_emb}
+    inter = {"h0": h, "t_emb": t_emb, "blocks": []}
     for i in range(nblocks):
         h = block_forward(h, t_emb, image_emb, static_emb, sd, f"blocks.{i}", heads, precision, no_temporal_attn=cfg.get("no_temporal_attn", False))
         if i == 0:
             inter["block0"] = h
+        if return_intermediates:
+            inter["blocks"].append(h)
     shift, scale = linear(F.silu(t_emb), sd, "final_layer.adaLN_modulation.1", precision).chunk(2, dim=1)
     h = modulate(layer_norm(h), shift, scale)
     y = linear(h, sd, "final_layer.linear", precision)

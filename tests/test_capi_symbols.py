@@ -54,7 +54,7 @@ def test_rowblock_argument_struct_layout_matches_the_library():
     buf = (ctypes.c_int32 * 16)()
     n = l.gvf_rowblock_args_layout(buf, 16)
     A = dit_ops.RowblockArgs
-    mine = [ctypes.sizeof(A)] + [getattr(A, f).offset for f in ("x", "in_x", "gate1", "mod_ld", "b_fc1", "ln2", "b3", "hb_out", "k_tiles", "gamma_k", "kv_group_rows")]
+    mine = [ctypes.sizeof(A)] + [getattr(A, f).offset for f in ("x", "in_x", "gate1", "mod_ld", "b_fc1", "ln2", "b3", "hb_out", "k_tiles", "gamma_k", "kv_group_rows", "dtype")]
     assert n == len(mine) and list(buf[:n]) == mine
     assert l.gvf_rowblock_fused_bf16(None, None) == _lib.GVF_EINVAL
     a = A()
@@ -62,6 +62,8 @@ def test_rowblock_argument_struct_layout_matches_the_library():
     assert l.gvf_rowblock_fused_bf16(ctypes.byref(a), None) == _lib.GVF_EINVAL
     a.C, a.M = 512, 100                                          # rows not a multiple of 48
     assert l.gvf_rowblock_fused_bf16(ctypes.byref(a), None) == _lib.GVF_EINVAL
+    a.M, a.dtype = 96, 7                                         # not a 16-bit operand type
+    assert l.gvf_rowblock_fused(ctypes.byref(a), None) == _lib.GVF_EINVAL
     assert l.gvf_rowblock_packed_bytes(512, 64) == 512 * 128 * 2 and l.gvf_rowblock_packed_bytes(500, 64) == _lib.GVF_EINVAL
 
 

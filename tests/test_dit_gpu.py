@@ -15,6 +15,14 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
+@pytest.fixture(autouse=True)
+def _bf16_pipeline(monkeypatch):
+    """This module pins the BF16 pipeline (BASELINE.json's compute type): kernels are called with bf16 tensors and every DiT resolves to
+    bf16 whatever its use_fp16 flag says (ops/precision.py).  tests/test_dit_fp16_gpu.py is the fp16 twin and holds the dtype-parametrised
+    full-config bars."""
+    monkeypatch.setenv("GVF_DIT_DTYPE", "bf16")
+
+
 def bf(x):
     return x.to(torch.bfloat16)
 
