@@ -125,7 +125,7 @@ class DiTWorkload:
     """BASELINE configs[2]: configs/diffusion.yml DiT, batch 1, T=24, 32-step DPM-Solver++(2M) sampling on
     synthetic latents + random DINOv2-shaped conditions; weights seed-generated (no checkpoint here)."""
 
-    def __init__(self, dev, T=24, seed=0, guidance=(1.0, 1.0), input_seed=None):
+    def __init__(self, dev, T=24, seed=0, guidance=(1.0, 1.0), input_seed=None, dtype=None):
         import json
         from gvfdiffusion_amd import synthetic
         from gvfdiffusion_amd.model.dit import DiT
@@ -135,7 +135,11 @@ class DiTWorkload:
         self.cfg = man["config"]
         model = DiT(**self.cfg)
         model.load_state_dict(synthetic.dit_state_dict(man["state_dict"], seed=seed), strict=True)
+        # operand type of the matrix pipe: None = the module's own rule (configs/diffusion.yml use_fp16: true -> fp16, the reference's
+        # accelerate precision; GVF_DIT_DTYPE overrides), "bf16" / "fp16" = explicit
+        model.set_compute_dtype(dtype)
         self.model = model.to(dev).eval().enable_graph(os.environ.get("GVF_DIT_GRAPH", "1") == "1")
+        self.dtype_name = {torch.float16: "fp16", torch.bfloat16: "bf16"}[self.model._lp()]
         inp = {k: v.to(dev) for k, v in synthetic.dit_inputs(B=1, T=T, seed=seed + 1 if input_seed is None else input_seed).items()}
         self.x = inp.pop("x"); inp.pop("t")
         self.cond = inp
@@ -169,15 +173,28 @@ class DiTWorkload:
 
 def bench_dit(dev, nfe=32):
     nfe = int(os.environ.get("GVF_BENCH_DIT_NFE", nfe))
+
+    def timed(w_):
+        w_.sample(steps=4)                  # warm-up: weight conversion, condition cache, allocator
+        torch.cuda.synchronize()
+        t0_ = time.perf_counter()
+        w_.sample(steps=nfe)                # exactly nfe network evaluations
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0_
     w = DiTWorkload(dev)
-    w.sample(steps=4)                       # warm-up: weight conversion, condition cache, allocator
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    w.sample(steps=nfe)                     # exactly nfe network evaluations
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt = timed(w)
     per = dt / nfe
     fh, fa = w.flops_per_nfe(True), w.flops_per_nfe(False)
+    dtype_name = w.dtype_name
+    # the same step with the other 16-bit operand type (same kernels, same MFMA rate): BASELINE.json names bf16, the reference runs fp16
+    other = None
+    if os.environ.get("GVF_BENCH_DIT_OTHER_DTYPE", "1") == "1":
+        wo = DiTWorkload(dev, dtype="bf16" if dtype_name == "fp16" else "fp16")
+        do = timed(wo)
+        other = {"dtype": wo.dtype_name, "value": round(nfe / do, 3), "unit": "steps/s", "ms_per_nfe": round(do / nfe * 1e3, 3),
+                 "frac": round(fh / (do / nfe) / 1e12 / MFMA_PEAK_TFLOPS, 5)}
+        del wo
+        torch.cuda.empty_cache()
     # two independent samples in flight (own DiT instance, stream and Python thread each; gvfdiffusion_amd.utils.run_in_flight): the
     # serving-style throughput of the same B = 1 step.  Secondary figure: `value` / `ms_per_nfe` / `roofline` stay those of ONE sample.
     flight = None
@@ -219,7 +236,11 @@ def bench_dit(dev, nfe=32):
                 "note": "guidance_scale 3.0 / 1.5: batch-3 forward per step; fixed per-launch costs amortised over 3 samples"}
     return {"metric": "DiT denoise steps/sec (B=1, T=24, configs/diffusion.yml, 32-step DPM-Solver++ multistep)",
             "cfg3": cfg3, "in_flight": flight,
-            "value": round(nfe / dt, 3), "unit": "steps/s", "ms_per_nfe": round(per * 1e3, 3), "nfe": nfe, "dtype": "bf16",
+            "value": round(nfe / dt, 3), "unit": "steps/s", "ms_per_nfe": round(per * 1e3, 3), "nfe": nfe, "dtype": dtype_name,
+            "dtype_note": "operand type of the MFMA contractions (fp32 accumulation, stream, LayerNorm, softmax): fp16 = what the reference "
+                          "runs (accelerate mixed_precision='fp16'; configs/diffusion.yml use_fp16: true), 3.4e-4 of the fp32 reference output "
+                          "against 2.8e-3 for bf16 (tests/test_dit_fp16_gpu.py); `other_dtype` = the same step with BASELINE.json's bf16",
+            "other_dtype": other,
             "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_PEAK_TFLOPS,
                          "achieved": round(fh / per / 1e12, 2), "frac": round(fh / per / 1e12 / MFMA_PEAK_TFLOPS, 5),
                          "flops_per_nfe_hoisted": fh, "flops_per_nfe_as_written": fa,
