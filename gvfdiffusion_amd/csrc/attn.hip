@@ -15,6 +15,7 @@
 // LDS once per workgroup (K: 16-byte chunks XOR-swizzled over 4-row groups; V: written transposed).
 // fp32 online softmax (running max / sum per query, exp2 with log2e folded into the scale).
 #include <cstdlib>
+#include <mutex>
 #include "gvf_common.h"
 #include "gvf_lp.h"
 #include "../../include/gvf_rast.h"
@@ -635,12 +636,16 @@ int launch_kvres(AttnParams p, int H, int n_inner, int n_outer, int max_Lq, int 
     p.q_blocks = (max_Lq + qt * per_pass - 1) / (qt * per_pass);
     const long long blocks = (long long)p.q_blocks * H * n_inner * n_outer;
     if (blocks > 0x7fffffffLL) return GVF_EINVAL;
-    static bool attr_set = false;                                          // per instantiation
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kvres_kernel<D, VT, DT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)((size_t)RES_MAX_TILES * (KT * Cfg<D>::KC * 16 + res_vt_tile<D>() * 2))) != hipSuccess)
-            return GVF_ELAUNCH;
-        attr_set = true;
+    {
+        static std::mutex m;                                                // per instantiation; callers may be on several host threads
+        static bool attr_set = false;
+        std::lock_guard<std::mutex> g(m);
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kvres_kernel<D, VT, DT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)((size_t)RES_MAX_TILES * (KT * Cfg<D>::KC * 16 + res_vt_tile<D>() * 2))) != hipSuccess)
+                return GVF_ELAUNCH;
+            attr_set = true;
+        }
     }
     hipLaunchKernelGGL((attn_kvres_kernel<D, VT, DT>), dim3((unsigned)blocks), dim3(RES_THREADS), lds, stream, p, qt, tiles_max);
     GVF_CHECK_LAUNCH();

@@ -33,7 +33,9 @@
 // computed once per visible Gaussian.  A 16-byte bin record {x0|y0<<16, x1|y1<<16, depth bits, slab}; per
 // (frame, tile) a range, a counter and a cursor; per instance one u64 key and one u32 ordered id (radix path:
 // u64 key + u32 id, double buffered).
+#include <atomic>
 #include <cstdlib>
+#include <mutex>
 #include "gvf_common.h"
 #include "gvf_sort.h"
 #include "../../include/gvf_rast.h"
@@ -1233,6 +1235,23 @@ __global__ void tile_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __r
 }
 
 // classify + the three size classes of the per-tile sort over nseg segments (cls: 2 + 2 nseg words of scratch)
+// The large-segment sort class needs more dynamic LDS than the default limit: raise it ONCE per process, under a lock (the rasteriser is
+// called from several host threads: utils/in_flight.py), and from gvf_rast_workspace_bytes too -- every caller sizes its workspace before
+// its first forward, i.e. outside any hipGraph capture, where hipFuncSetAttribute would be illegal.
+static int tile_sort_set_lds_limit() {
+    static std::mutex m;
+    static bool done = false;
+    std::lock_guard<std::mutex> g(m);
+    if (done) return GVF_OK;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_sort_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LARGE_N * 8) !=
+        hipSuccess) {
+        (void)hipGetLastError();
+        return GVF_ELAUNCH;
+    }
+    done = true;
+    return GVF_OK;
+}
+
 // cls_state: 0 = cls holds nothing (clear + classify here), 1 = the two counters are cleared (classify here), 2 = classified
 static int launch_tile_sort(hipStream_t stream, const uint2* ranges, uint64_t* keys, const uint32_t* vals, uint32_t* ids,
                             uint32_t* cls, uint32_t nseg, int cls_state) {
@@ -1240,13 +1259,7 @@ static int launch_tile_sort(hipStream_t stream, const uint2* ranges, uint64_t* k
     if (cls_state < 2)
         hipLaunchKernelGGL(classify_kernel, dim3((nseg + 255) / 256), dim3(256), 0, stream, ranges, nseg, cls);
     hipLaunchKernelGGL(tile_sort_kernel<0>, dim3(nseg), dim3(256), 0, stream, ranges, keys, vals, ids, cls, nseg);
-    static bool large_attr_set = false;
-    if (!large_attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_sort_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                SORT_LARGE_N * 8) != hipSuccess)
-            return GVF_ELAUNCH;
-        large_attr_set = true;
-    }
+    if (tile_sort_set_lds_limit() != GVF_OK) return GVF_ELAUNCH;
     // the two rare classes in one launch
     hipLaunchKernelGGL(tile_sort_kernel<1>, dim3(SORT_LARGE_BLOCKS + SORT_HUGE_BLOCKS), dim3(1024), SORT_LARGE_N * 8, stream, ranges, keys,
                        vals, ids, cls, nseg);
@@ -1468,7 +1481,7 @@ constexpr int PROF_MAX_CALLS = 256;
 constexpr int PROF_EVENTS = GVF_RAST_NSTAGES + 1;
 struct Profiler {
     bool on = false;
-    int calls = 0;
+    std::atomic<int> calls{0};          // slots are handed out to concurrent callers (one host thread per sample in flight)
     hipEvent_t ev[PROF_MAX_CALLS][PROF_EVENTS];
 };
 Profiler g_prof;
@@ -1559,7 +1572,8 @@ int run_pipeline(const GvfRastSettings& st, const GvfRastFrame* frames_host, int
 
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE, ntiles = gx * gy;
     const int nb = (P + PRE_THREADS - 1) / PRE_THREADS;
-    const int slot = (g_prof.on && g_prof.calls < PROF_MAX_CALLS) ? g_prof.calls++ : -1;
+    int slot = g_prof.on ? g_prof.calls.fetch_add(1) : -1;
+    if (slot >= PROF_MAX_CALLS) slot = -1;
 
     const bool morton = st.bin_algo != GVF_RAST_BIN_RADIX && F >= 4 && P >= 4096;     // spatial order of the Gaussians (see below)
     for (int f0 = 0; f0 < F; f0 += 16) {
@@ -2133,6 +2147,7 @@ extern "C" int gvf_rast_workspace_bytes(int P, int F, int H, int W, int64_t max_
     if (!bytes || P < 0 || F <= 0 || H <= 0 || W <= 0 || max_rendered < 0) return GVF_EINVAL;
     Workspace w = carve(nullptr, (size_t)-1, P, F, H, W, max_rendered);
     *bytes = w.bytes + 256;
+    (void)tile_sort_set_lds_limit();        // best effort here (no device in a CPU-only process); launch_tile_sort insists
     return GVF_OK;
 }
 
@@ -2305,7 +2320,8 @@ extern "C" int gvf_rast_profile_read(float* ms_sum, int* calls) {
     for (int k = 0; k < GVF_RAST_NSTAGES; ++k) ms_sum[k] = 0.f;
     *calls = 0;
     if (!g_prof.on) return GVF_OK;
-    for (int c = 0; c < g_prof.calls; ++c) {
+    const int n_calls = g_prof.calls.load() < PROF_MAX_CALLS ? g_prof.calls.load() : PROF_MAX_CALLS;
+    for (int c = 0; c < n_calls; ++c) {
         if (hipEventSynchronize(g_prof.ev[c][PROF_EVENTS - 1]) != hipSuccess) return GVF_ELAUNCH;
         for (int k = 0; k < GVF_RAST_NSTAGES; ++k) {
             float ms = 0.f;
@@ -2313,7 +2329,7 @@ extern "C" int gvf_rast_profile_read(float* ms_sum, int* calls) {
             ms_sum[k] += ms;
         }
     }
-    *calls = g_prof.calls;
+    *calls = n_calls;
     g_prof.calls = 0;
     return GVF_OK;
 }

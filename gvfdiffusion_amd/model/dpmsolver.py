@@ -179,24 +179,6 @@ def model_wrapper(model, noise_schedule, model_type="noise", model_kwargs={}, gu
         _cfg_cache["key"], _cfg_cache["c_in"] = key, c_in
         return c_in
 
-    def raw_output_fn(x, t_continuous, cond=None):
-        t_input = get_model_input_time(t_continuous).to(x.device)
-        output = model(x, t_input, **model_kwargs) if cond is None else model(x, t_input, **cond, **model_kwargs)
-        if output.shape[1] != x.shape[1]:
-            output, _ = torch.split(output, x.shape[1], dim=1)
-        return output
-
-    def v_fn(x, t_continuous):
-        """The network's (guided) v-prediction itself.  The guidance combination is affine with weights summing to 1, so combining the
-        v outputs and converting once equals combining the converted noise predictions; DPM_Solver.data_prediction_fn then gets
-        x0 = alpha x - sigma v in two launches instead of the six of v -> noise -> x0 (alpha^2 + sigma^2 = 1 on a VP schedule)."""
-        if guidance_type == "uncond":
-            return raw_output_fn(x, t_continuous)
-        if (guidance_scale == 1.0 and guidance_scale2 == 1.0) or unconditional_condition is None:
-            return raw_output_fn(x, t_continuous, cond=condition)
-        v_full, v_unc, v_cond = raw_output_fn(torch.cat([x] * 3), torch.cat([t_continuous] * 3), cond=_cfg_condition()).chunk(3)
-        return v_full + guidance_scale * (v_unc - v_full) + guidance_scale2 * (v_cond - v_unc)
-
     def model_fn(x, t_continuous):
         if guidance_type == "uncond":
             return noise_pred_fn(x, t_continuous)
@@ -215,8 +197,6 @@ def model_wrapper(model, noise_schedule, model_type="noise", model_kwargs={}, gu
         e_full, e_unc, e_cond = noise_pred_fn(x_in, t_in, cond=c_in).chunk(3)
         return e_full + guidance_scale * (e_unc - e_full) + guidance_scale2 * (e_cond - e_unc)
 
-    if model_type == "v" and guidance_type in ("uncond", "classifier-free"):
-        model_fn.gvf_v_fn = v_fn          # fast path of DPM_Solver.data_prediction_fn (same numbers to fp32 rounding)
     return model_fn
 
 
@@ -267,10 +247,6 @@ class DPM_Solver:
         return self.model(x, t)
 
     def data_prediction_fn(self, x, t):
-        v_fn = getattr(self.model, "gvf_v_fn", None)
-        if v_fn is not None and self.correcting_x0_fn is None and torch.is_tensor(t) and t.numel() == 1:
-            _, sigma_t, _, alpha_t = self._sched(self._host(t))
-            return torch.add(x * alpha_t, v_fn(x, t), alpha=-sigma_t)        # x0 = alpha x - sigma v
         noise = self.noise_prediction_fn(x, t)
         _, sigma_t, _, alpha_t = self._sched(self._host(t))
         x0 = (x - sigma_t * noise) / alpha_t

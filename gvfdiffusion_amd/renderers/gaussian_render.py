@@ -11,6 +11,7 @@ MI355X addition: all (frame, camera) pairs of a sample in ONE launch sequence wi
 delta activations fused into the rasteriser preprocess (utils/inference_utils.py:256-269 loop).
 """
 import math
+import threading as _threading
 
 import numpy as np
 import torch
@@ -163,27 +164,39 @@ class GaussianRenderer:
         Fn = extrinsics.shape[0]
         # The render loops call this with the SAME camera tensors for every sample / chunk (the fixed orbit of
         # inference_dpm_latent.py:262-269): building 24 blocks costs ~2 ms of host time (one device read, then an inverse, a matmul
-        # and three .tolist() per frame) against ~1.5 ms of GPU work for the frames themselves.  Keep the last few sets, keyed on the
-        # tensors' identity and version (the entry holds the tensors, so an address cannot be recycled while it is cached).
+        # and three .tolist() per frame) against ~1.5 ms of GPU work for the frames themselves.  Keep the last few sets, keyed (1) on
+        # the tensors' identity and version (the entry holds the tensors, so an address cannot be recycled while it is cached) -- a hit
+        # costs nothing -- and (2) on the CONTENT of the host copies: the chunked driver (utils/inference_utils.render_sample_frames)
+        # slices a fresh `ext[idx]` per chunk, so identity never repeats there, but every sample walks the same orbit.  One renderer may
+        # be shared by the threads of utils/in_flight.py: the list is read and written under a lock.
         di = None if delta_index is None else tuple(int(d) for d in delta_index)
+        common = (float(opts["near"]), float(opts["far"]), size, di)
         key = (extrinsics.data_ptr(), extrinsics._version, tuple(extrinsics.shape), intrinsics.data_ptr(), intrinsics._version,
-               tuple(intrinsics.shape), float(opts["near"]), float(opts["far"]), size, di)
+               tuple(intrinsics.shape)) + common
+        lock = self.__dict__.setdefault("_frame_cache_lock", _threading.Lock())
         cache = self.__dict__.setdefault("_frame_cache", [])
-        for k, _, frames in cache:
-            if k == key:
-                return frames
+        with lock:
+            for k, _, _, frames in cache:
+                if k == key:
+                    return frames
         held = (extrinsics, intrinsics)
         if intrinsics.dim() == 2:
             intrinsics = intrinsics[None].expand(Fn, 3, 3)
         ext_c, int_c = extrinsics.detach().float().cpu(), intrinsics.detach().float().cpu()
+        ckey = (ext_c.numpy().tobytes(), int_c.contiguous().numpy().tobytes()) + common
+        with lock:
+            for _, ck, _, frames in cache:
+                if ck == ckey:
+                    return frames
         frames = []
         for f in range(Fn):
             cam = _camera(ext_c[f], int_c[f], opts["near"], opts["far"], size)
             frames.append(_r.make_frame(cam.world_view_transform, cam.full_proj_transform, cam.camera_center,
                                         math.tan(float(cam.FoVx) * 0.5), math.tan(float(cam.FoVy) * 0.5),
                                         -1 if di is None else di[f]))
-        cache.append((key, held, frames))
-        del cache[:-4]
+        with lock:
+            cache.append((key, ckey, held, frames))
+            del cache[:-8]
         return frames
 
     def render_frames(self, gaussian, extrinsics, intrinsics, delta_pc=None, delta_index=None,

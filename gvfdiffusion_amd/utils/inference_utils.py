@@ -225,25 +225,28 @@ def render_sample_frames(renderer, gaussian, pred_delta: torch.Tensor, intrinsic
             for part in chunks:
                 yield part, render(part)[0]
             return
-        cur = torch.cuda.current_stream(dev)
         pool = _side_streams(dev, streams)
         frames, nr = render(chunks[0])                    # synchronous: measures the instance count
-        per_frame = int(nr.to(torch.int64).max()) + 1
+
+        def counts(nr_):                                  # per-frame instance counts (device uint32 viewed as int32) as int64
+            return nr_.to(torch.int64).bitwise_and(0xFFFFFFFF)
+        per_frame = int(counts(nr).max()) + 1
         yield chunks[0], frames
         inflight = []
 
         def hand_out():
             part, fr, nr_, ev, cap = inflight.pop(0)
             ev.synchronize()
-            if int(nr_.to(torch.int64).bitwise_and(0xFFFFFFFF).sum()) > cap:      # rare: a denser view than the estimate
+            if int(counts(nr_).sum()) > cap:              # rare: a denser view than the estimate
                 return part, render(part)[0]
+            cur = torch.cuda.current_stream(dev)          # the consumer's stream NOW (it may have changed between next() calls)
             cur.wait_event(ev)
             fr.record_stream(cur)
             return part, fr
 
         for i, part in enumerate(chunks[1:]):
             s = pool[i % streams]
-            s.wait_stream(cur)                            # the sample's tensors were produced on the caller's stream
+            s.wait_stream(torch.cuda.current_stream(dev))   # the sample's tensors were produced on the caller's stream
             cap = int(per_frame * len(part) * 1.5) + 4096
             with torch.cuda.stream(s):
                 fr, nr_ = render(part, cap)
@@ -255,6 +258,13 @@ def render_sample_frames(renderer, gaussian, pred_delta: torch.Tensor, intrinsic
         while inflight:
             yield hand_out()
     finally:
+        # a consumer that stops early (break / exception) leaves chunks queued on the side streams that still read pred_delta, the
+        # Gaussians and the camera tensors -- all allocated on the caller's stream: order the caller's stream behind them, so that
+        # the caching allocator cannot hand that memory out while they run
+        if dev.type == "cuda" and streams > 1:
+            cur = torch.cuda.current_stream(dev)
+            for s in _side_streams(dev, streams):
+                cur.wait_stream(s)
         renderer.pipe.use_mip_gaussian = old_mip
 
 

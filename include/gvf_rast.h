@@ -145,8 +145,10 @@ int gvf_rast_backward(const GvfRastSettings* settings_host, const GvfRastFrame* 
  *   out_num_rendered[F] device uint32 (per-frame instance counts; their sum must be
  *   <= max_rendered, else frames past the overflow point are not rendered correctly).
  * The call only enqueues kernels on `stream` (camera blocks travel as kernel arguments, per-call tables are cleared by the first
- * launch, nothing is read back): it can be captured in a hipGraph and replayed -- after ONE ordinary call in the process, which
- * sets a function attribute of the large-segment sort kernel (not allowed inside a capture). */
+ * launch, nothing is read back): it can be captured in a hipGraph and replayed.  One function attribute of the large-segment sort
+ * kernel has to be set outside any capture: gvf_rast_workspace_bytes -- which every caller runs, on the device's thread, to size
+ * the workspace before its first forward -- does that once per process (under a lock; the entry points are re-entrant per
+ * (device, stream) and may be called from several host threads). */
 int gvf_rast_forward_batched(const GvfRastSettings* settings_host, const GvfRastFrame* frames_host, int F,
                              const GvfGaussianActivation* act_host,
                              int P, int M,
