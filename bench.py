@@ -53,7 +53,7 @@ class RasterWorkload:
 
     def __init__(self, dev, P, S, F, deg, seed):
         from gvfdiffusion_amd import synthetic, _lib, rasterizer as R
-        from rast_util import camera_block
+        camera_block = synthetic.camera_block
         self._lib, self.R, self.dev = _lib, R, dev
         self.P, self.S, self.F, self.deg, self.M = P, S, F, deg, (deg + 1) ** 2
         self.attrs = synthetic.random_gaussians(P, sh_degree=deg, seed=seed, scale_lo=0.002, scale_hi=0.01)
@@ -88,16 +88,6 @@ class RasterWorkload:
         self.ws = torch.empty(self.ws_bytes + 256, dtype=torch.uint8, device=dev)
         self.ws_base = (self.ws.data_ptr() + 255) // 256 * 256
 
-    def clone_buffers(self):
-        """Another slot of the same resident sample: its own workspace, frame buffer and counters (for a second stream)."""
-        w = RasterWorkload.__new__(RasterWorkload)
-        w.__dict__.update(self.__dict__)
-        w.color = torch.empty_like(self.color)
-        w.nr = torch.zeros_like(self.nr)
-        w.ws = torch.empty(self.ws_bytes + 256, dtype=torch.uint8, device=self.dev)
-        w.ws_base = (w.ws.data_ptr() + 255) // 256 * 256
-        return w
-
     def step(self):
         L, p = self._lib, self._lib.ptr
         rc = L.lib().gvf_rast_forward_batched(
@@ -114,8 +104,9 @@ class RasterWorkload:
         return self.P * p_in + d * 24 + d * 36 + self.S * self.S * 4 * 3
 
     def alg_bytes_blend_launch(self):
-        # the blend launch covers all F frames: per instance 36 B of splat record + its 4 B id, plus the image
-        return self.D * (36 + 4) + self.F * self.S * self.S * 4 * 3
+        # the blend launch covers all F frames.  SURVEY.md section 8d: 36 B fetched per (splat, tile) instance (xy 8 + conic / opacity 16 +
+        # rgb 12) + the image (12 B per pixel).  (The 4-byte id the kernel also reads per instance is implementation traffic: not credited.)
+        return self.D * 36 + self.F * self.S * self.S * 4 * 3
 
 
 MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
@@ -329,50 +320,51 @@ def bench_sharded_sampling(dev, dist, rank, world, P, S, T, total_batch=8, steps
     frames (RCCL over xGMI).  Reported: whole-job samples / frames / denoise steps per second from the max-over-ranks wall
     time, the slowest rank's per-NFE time, and the gather on its own."""
     import contextlib
-    from gvfdiffusion_amd import rasterizer as R
-    from gvfdiffusion_amd.utils import run_in_flight
-    b_loc = max(1, total_batch // world)
+    from gvfdiffusion_amd import distributed as D, rasterizer as R
+    total = max(total_batch, world)                     # every rank owns at least one sample
+    mine = D.shard_indices(total, rank, world)
+    b_loc = len(mine)
     # a rank with several samples keeps two of them in flight (own models, stream and thread each: gvfdiffusion_amd.utils.run_in_flight)
     n_fl = 2 if b_loc >= 2 and os.environ.get("GVF_BENCH_DIT_INFLIGHT", "1") == "1" else 1
     es = [E2EWorkload(dev, P, S, T, sample_seed=rank + 1000 * k) for k in range(n_fl)]
-    e = es[0]
-    u8 = torch.empty((b_loc, T, 3, S, S), dtype=torch.uint8, device=dev)
-    gathered = torch.empty((world * b_loc, T, 3, S, S), dtype=torch.uint8, device=dev)
+    timings = []
+
+    def chain(slot, i):
+        """sample i: 32-step sampling -> decode -> render -> uint8 frames (the chain of inference_dpm_latent.py:225-272)"""
+        with torch.no_grad():
+            res = es[slot].chain(method="multistep", steps=steps)
+            timings.append((res[0], res[1]))
+            return R.frames_to_uint8(res[2].rgb)
+
     with torch.no_grad(), contextlib.redirect_stdout(sys.stderr):
         for e_ in es:
             e_.chain(method="multistep", steps=4)         # warm-up, serially (graph capture)
         dist.barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        ms_sample = ms_decode = ms_render = 0.0
-        nfe = 0
-
-        def one(slot, i):
-            with torch.no_grad():
-                res = es[slot].chain(method="multistep", steps=steps)
-                R.frames_to_uint8(res[2].rgb, out=u8[i])
-            return res[0], res[1]
-        for (a_, b_, c_), n in run_in_flight([lambda slot, i=i: one(slot, i) for i in range(b_loc)], dev, n_fl):
-            ms_sample += a_; ms_decode += b_; ms_render += c_; nfe += n
+        local, _ = D.sample_decode_render_sharded(chain, total, device=dev, in_flight=n_fl, gather=False)
         g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         g0.record()
-        dist.all_gather_into_tensor(gathered, u8)
+        gathered = D.gather_frames(local, total)            # the path's one collective (RCCL over xGMI)
         g1.record()
         dist.barrier(); torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+    assert gathered.shape == (total, T, 3, S, S) and torch.equal(gathered[rank::world], local)
+    ms_sample = sum(t_[0][0] for t_ in timings); ms_decode = sum(t_[0][1] for t_ in timings); ms_render = sum(t_[0][2] for t_ in timings)
+    nfe = sum(t_[1] for t_ in timings)
     t = torch.tensor([dt, ms_sample / max(nfe, 1), g0.elapsed_time(g1)], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt, ms_nfe, ms_gather = (float(v) for v in t.tolist())
-    n_samples = world * b_loc
+    n_samples = total
     return {"metric": "batch-sharded sampling (BASELINE configs[4]): 32-step DPM-Solver++ on the DiT -> VAE decode -> 24-frame "
                       "800x800 render per sample, one frame all-gather at the end",
             "samples": n_samples, "samples_per_rank": b_loc, "samples_in_flight_per_rank": n_fl, "wall_ms": round(dt * 1e3, 2),
             "samples_per_s": round(n_samples / dt, 3), "frames_per_s": round(n_samples * T / dt, 2),
             "denoise_steps_per_s": round(n_samples * steps / dt, 2), "ms_per_nfe_slowest_rank": round(ms_nfe, 3),
-            "gather_ms": round(ms_gather, 3), "gather_bytes_per_rank": int(u8.numel()),
+            "gather_ms": round(ms_gather, 3), "gather_bytes_per_rank": int(local.numel()),
             "rank0_stage_ms_per_sample": {"sample": round(ms_sample / b_loc, 2), "vae_decode": round(ms_decode / b_loc, 2),
                                           "render": round(ms_render / b_loc, 2)},
             # per GPU, from the wall time of the whole chain (decode, render and gather included): a lower bound on the DiT's own fraction
-            "dit_roofline_frac": round(e.w.flops_per_nfe(True) * b_loc * steps / dt / 1e12 / MFMA_PEAK_TFLOPS, 5),
+            "dit_roofline_frac": round(es[0].w.flops_per_nfe(True) * b_loc * steps / dt / 1e12 / MFMA_PEAK_TFLOPS, 5),
             "ms_per_nfe_per_gpu_throughput": round(dt * 1e3 / (b_loc * steps), 3),
             "scaling": "weak" if world <= total_batch else "replicas"}
 
@@ -382,7 +374,7 @@ def bench_backward(dev, attrs, S, deg, iters=8):
     backward, same Gaussians / resolution as the headline workload.  Secondary figure, not part of `value`."""
     from gvfdiffusion_amd import synthetic
     from gvfdiffusion_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
-    from rast_util import camera_block
+    from gvfdiffusion_amd.synthetic import camera_block
     leaves = {k: v.to(dev).requires_grad_(True) for k, v in attrs.items()}
     P = leaves["means3D"].shape[0]
     w = torch.randn((3, S, S), device=dev)
@@ -540,23 +532,38 @@ def main():
     # its own workspace and frame buffer (what gvfdiffusion_amd.utils.render_sample_frames does with consecutive frame chunks): the
     # HBM-bound front of one sample (projection, binning) runs under the VALU-bound compositing of the other.  Stage times and the
     # roofline object come from a strictly serial, instrumented pass over the same K steps first.
+    # Every slot in flight holds its OWN sample (different Gaussians and deltas: seed + 1000 slot), as consecutive samples of a job do.
+    from gvfdiffusion_amd import distributed as D
     n_slots = max(1, a.streams)
-    slots = [work] + [work.clone_buffers() for _ in range(n_slots - 1)]
+    slots = [work] + [RasterWorkload(dev, a.gaussians, a.res, a.frames, a.sh_degree, seed=rank + 1000 * k) for k in range(1, n_slots)]
     rstreams = [torch.cuda.Stream(device=dev) for _ in range(n_slots)]
 
-    # frame exchange (N > 1): uint8 frames, one all-gather per step on a side stream
-    side = torch.cuda.Stream(device=dev) if multi else None
+    # Frame exchange (N > 1), BASELINE's "all-gather over xGMI only for the final frame collection": the job this loop measures is a batch
+    # of `world` samples, one per rank per step; its ONE collective -- gvfdiffusion_amd.distributed.gather_frames of every rank's finished
+    # uint8 frames (46 MB per sample) -- runs once, at the end of the timed region, inside it.  GVF_BENCH_GATHER_EVERY_STEP=1 restores
+    # the round-2 variant (a gather of every step's frames on a side stream, overlapped with the next step's rendering).
+    every_step = multi and os.environ.get("GVF_BENCH_GATHER_EVERY_STEP", "0") == "1"
+    side = torch.cuda.Stream(device=dev) if every_step else None
     nbuf = max(2, n_slots)
     u8 = [torch.empty((F, 3, S, S), dtype=torch.uint8, device=dev) for _ in range(nbuf)] if multi else None
-    gathered = [torch.empty((world * F, 3, S, S), dtype=torch.uint8, device=dev) for _ in range(nbuf)] if multi else None
-    ready = [torch.cuda.Event() for _ in range(nbuf)] if multi else None
-    consumed = [torch.cuda.Event() for _ in range(nbuf)] if multi else None
+    gathered = [torch.empty((world * F, 3, S, S), dtype=torch.uint8, device=dev) for _ in range(nbuf)] if every_step else None
+    ready = [torch.cuda.Event() for _ in range(nbuf)] if every_step else None
+    consumed = [torch.cuda.Event() for _ in range(nbuf)] if every_step else None
+
+    def final_gather(n_active, n_steps):
+        """The job's one collective: every rank's last finished sample, (world, F, 3, S, S) uint8 on every rank."""
+        if not multi or every_step:
+            return None
+        k = (n_steps - 1) % n_active
+        torch.cuda.current_stream().wait_stream(rstreams[k])
+        work.R.frames_to_uint8(slots[k].color, out=u8[0])
+        return D.gather_frames(u8[0][None], total=world)
 
     def step(i, n_active):
         k = i % n_active
         with torch.cuda.stream(rstreams[k]):
             slots[k].step()
-            if multi:
+            if every_step:
                 b = i % nbuf
                 rstreams[k].wait_event(consumed[b])                            # buffer b free again
                 work.R.frames_to_uint8(slots[k].color, out=u8[b])
@@ -571,7 +578,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if multi:
+    if every_step:
         for e in consumed:
             e.record()
     # ---- pass 1: serial and instrumented (per-stage HIP events inside the library): stage times, roofline, single-stream step time
@@ -582,6 +589,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(i, 1)
+    final_gather(1, a.steps)
     barrier()
     dt_serial = time.perf_counter() - t0
     ms = (ctypes.c_float * len(STAGES))()
@@ -589,16 +597,29 @@ def main():
     _lib.check(_lib.lib().gvf_rast_profile_read(ms, ctypes.byref(calls)), "profile_read")
     _lib.lib().gvf_rast_profile_enable(0)
     # ---- pass 2: the timed K steps, n_slots samples in flight (every slot warmed at least twice, whatever W is)
+    serial_frames = []
+    for k in range(n_slots):                    # what each slot's sample looks like rendered alone, on one stream
+        with torch.cuda.stream(rstreams[k]):
+            slots[k].step()
+        rstreams[k].synchronize()
+        serial_frames.append(slots[k].color.clone())
+        slots[k].color.zero_()
     for i in range(max(a.warmup, 2 * n_slots)):
         step(i, n_slots)
+    final_gather(n_slots, max(a.warmup, 2 * n_slots))      # (warms the communicator's all-gather path too)
     barrier()
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(i, n_slots)
+    got = final_gather(n_slots, a.steps)
     barrier()
     dt = time.perf_counter() - t0
-    for w_ in slots[1:]:
-        assert torch.equal(w_.color, work.color), "the slots render the same sample: their frames must be identical"
+    for k in range(n_slots):
+        assert torch.equal(slots[k].color, serial_frames[k]), f"slot {k}: frames rendered with {n_slots} samples in flight differ from the serial render"
+    assert n_slots < 2 or not torch.equal(serial_frames[0], serial_frames[1]), "the slots must hold different samples"
+    if got is not None:
+        k = (a.steps - 1) % n_slots
+        assert got.shape == (world, F, 3, S, S) and torch.equal(got[rank], work.R.frames_to_uint8(slots[k].color))
 
     t = torch.tensor([dt, dt_serial], dtype=torch.float64, device=dev)
     if multi:
@@ -606,7 +627,7 @@ def main():
     dt, dt_serial = float(t[0].item()), float(t[1].item())
 
     # overflow check after the timed region (no sync inside it)
-    assert all(int(w_.nr.to(torch.int64).sum()) <= work.cap for w_ in slots), "workspace overflow during the timed region"
+    assert all(int(w_.nr.to(torch.int64).sum()) <= w_.cap for w_ in slots), "workspace overflow during the timed region"
 
     if rank == 0:
         traffic, traffic_note = pmc_traffic("blend_kernel", a, S, F)
@@ -631,8 +652,12 @@ def main():
                        "gaussians": a.gaussians, "resolution": S, "frames_per_step": F, "sh_degree": a.sh_degree,
                        "instances_per_frame": round(work.D / F, 1), "instances_binned_per_frame": round(work.D_binned / F, 1), "parallelism": f"sample-sharded x{world}",
                        "samples_in_flight": n_slots,
-                       "pipelining": f"{n_slots} independent samples in flight per GPU, one HIP stream + workspace + frame buffer each; "
-                                     "stage_ms_per_step, roofline and ms_per_step_serial are from a serial instrumented pass over the same steps"},
+                       "pipelining": f"{n_slots} DIFFERENT samples in flight per GPU (own Gaussians, deltas, HIP stream, workspace and frame buffer "
+                                     "each; every slot's frames are asserted bit-identical to its serial render); stage_ms_per_step, roofline and "
+                                     "ms_per_step_serial are from a serial instrumented pass over the same steps",
+                       "collective": None if not multi else ("one all_gather_into_tensor per step on a side stream" if every_step else
+                                                             "ONE gather of every rank's finished uint8 frames at the end of the timed region "
+                                                             "(gvfdiffusion_amd.distributed.gather_frames)")},
             "roofline": {"bound": "hbm", "kernel": "blend_kernel (R6, one launch = all frames of the step)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,

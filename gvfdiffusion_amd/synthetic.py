@@ -40,6 +40,19 @@ def intrinsics(fov_x_deg: float = FOV_X_DEG) -> torch.Tensor:
     return torch.tensor([[f, 0, 0.5], [0, f, 0.5], [0, 0, 1]], dtype=torch.float32)
 
 
+def camera_block(azi=0.0, elev=0.0, radius=2.0, fov=FOV_X_DEG, near=NEAR, far=FAR):
+    """One orbit camera in every form the rasteriser's callers use (renderers/gaussian_render.py:285-321): extrinsics (w2c), normalised
+    intrinsics, and the derived GaussianRasterizationSettings fields (viewmatrix = V^T, projmatrix = (P V)^T, campos, tan fov)."""
+    from .renderers.gaussian_render import intrinsics_to_projection
+    view = orbit_w2c(azi, elev, radius)
+    K = intrinsics(fov)
+    persp = intrinsics_to_projection(K, near, far)
+    tan = math.tan(float(2 * torch.atan(0.5 / K[0, 0])) * 0.5)
+    return dict(extrinsics=view, intrinsics=K, viewmatrix=view.T.contiguous(),
+                projmatrix=(persp @ view).T.contiguous(), campos=torch.inverse(view)[:3, 3].contiguous(),
+                tanfovx=tan, tanfovy=tan)
+
+
 def random_gaussians(P: int, sh_degree: int = 2, seed: int = 0, scale_lo: float = 0.003, scale_hi: float = 0.02):
     """Activated attributes (dict of CPU fp32 tensors): means3D, scales, rotations, opacities (P,1), shs (P,M,3)."""
     g = torch.Generator().manual_seed(seed)

@@ -1,22 +1,12 @@
 """Shared helpers of the rasteriser tests: camera blocks as the reference builds them
 (renderers/gaussian_render.py:285-321), oracle invocation, flagged-pixel comparison."""
-import math
-
 import numpy as np
 import torch
 
 from gvfdiffusion_amd import synthetic
-from gvfdiffusion_amd.renderers.gaussian_render import intrinsics_to_projection
 
 
-def camera_block(azi=0.0, elev=0.0, radius=2.0, fov=synthetic.FOV_X_DEG, near=synthetic.NEAR, far=synthetic.FAR):
-    view = synthetic.orbit_w2c(azi, elev, radius)
-    K = synthetic.intrinsics(fov)
-    persp = intrinsics_to_projection(K, near, far)
-    tan = math.tan(float(2 * torch.atan(0.5 / K[0, 0])) * 0.5)
-    return dict(extrinsics=view, intrinsics=K, viewmatrix=view.T.contiguous(),
-                projmatrix=(persp @ view).T.contiguous(), campos=torch.inverse(view)[:3, 3].contiguous(),
-                tanfovx=tan, tanfovy=tan)
+camera_block = synthetic.camera_block        # (moved into the package: bench.py and the smoke test use it too)
 
 
 def oracle_render(oracle, attrs, cam, H, W, sh_degree, mode=0, kernel_size=synthetic.KERNEL_2D, bg=synthetic.BG,

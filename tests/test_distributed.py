@@ -1,11 +1,12 @@
-"""N > 1 path of bench.py on CPU: two gloo ranks shard the samples (rank r owns samples r::world) and
-exchange finished uint8 frames with one all_gather_into_tensor per step, exactly the calls bench.py makes on
-RCCL.  The renderer itself needs a GPU, so the per-rank frames here come from the CPU oracle at a tiny size."""
+"""The N > 1 path (gvfdiffusion_amd/distributed.py, which bench.py --gpus N drives over RCCL) on CPU: two gloo ranks shard the samples
+(rank r owns samples r::world), compute them with no exchange, and collect the finished uint8 frames with the path's ONE collective.
+The HIP renderer needs a GPU, so the per-sample frames here come from the CPU oracle at a tiny size."""
 import os
 import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -17,36 +18,67 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, total):
+    """One rank of the product path: gvfdiffusion_amd.distributed.sample_decode_render_sharded over a chain whose renderer is the CPU oracle
+    (the HIP renderer needs a GPU); `total` samples that do not divide evenly over the ranks."""
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    import oracle
-    from gvfdiffusion_amd import synthetic
-    from rast_util import camera_block, oracle_render
-    F, S = 2, 48
-    attrs = synthetic.random_gaussians(400, sh_degree=1, seed=rank, scale_lo=0.01, scale_hi=0.05)   # sample `rank`
-    frames = np.stack([oracle_render(oracle, attrs, camera_block(azi=30.0 * f), S, S, 1)["color"] for f in range(F)])
-    u8 = (torch.from_numpy(frames).clamp(0, 1) * 255).to(torch.uint8)                               # as bench.py
-    gathered = torch.empty((world * F, 3, S, S), dtype=torch.uint8)          # concatenated along dim 0, as bench.py
-    dist.all_gather_into_tensor(gathered, u8)
-    gathered = gathered.reshape(world, F, 3, S, S)
+    from gvfdiffusion_amd import distributed as D
+    assert D.rank_world() == (0, 1)                                   # before the group exists: single-process defaults
+    assert D.init_from_env() == (rank, world) and D.rank_world() == (rank, world)
+    rendered = []
+
+    def chain(slot, i):
+        rendered.append(i)
+        return _oracle_frames(i)
+
+    frames, mine = D.sample_decode_render_sharded(chain, total)
+    assert mine == D.shard_indices(total) == list(range(rank, total, world)) == rendered
+    local, _ = D.sample_decode_render_sharded(chain, total, gather=False)
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)                                                       # max-over-ranks timing
-    np.save(os.path.join(out_dir, f"g{rank}.npy"), gathered.numpy())
-    np.save(os.path.join(out_dir, f"own{rank}.npy"), u8.numpy())
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)                          # max-over-ranks timing, as bench.py
+    np.save(os.path.join(out_dir, f"g{rank}.npy"), frames.numpy())
+    np.save(os.path.join(out_dir, f"own{rank}.npy"), local.numpy())
     assert float(t) == world
+    with pytest.raises(ValueError):                                   # a block that is not this rank's shard is refused
+        D.gather_frames(torch.zeros((len(mine) + 1, 2)), total)
     dist.barrier()
     dist.destroy_process_group()
 
 
+def _oracle_frames(i, F=2, S=48):
+    """uint8 frames (F, 3, S, S) of sample i: per-sample seed, so what a sample looks like does not depend on who renders it."""
+    import oracle
+    from gvfdiffusion_amd import synthetic
+    from rast_util import oracle_render
+    attrs = synthetic.random_gaussians(400, sh_degree=1, seed=i, scale_lo=0.01, scale_hi=0.05)
+    frames = np.stack([oracle_render(oracle, attrs, synthetic.camera_block(azi=30.0 * f), S, S, 1)["color"] for f in range(F)])
+    return (torch.from_numpy(frames).clamp(0, 1) * 255).to(torch.uint8)
+
+
+def test_shard_indices_and_single_process_defaults():
+    from gvfdiffusion_amd import distributed as D
+    assert D.shard_indices(8, 1, 4) == [1, 5] and D.shard_indices(3, 2, 4) == [2] and D.shard_indices(3, 3, 4) == []
+    assert sorted(sum((D.shard_indices(11, r, 4) for r in range(4)), [])) == list(range(11))
+    assert D.shard_size(11, 4) == 3 and D.shard_size(8, 8) == 1
+    with pytest.raises(ValueError):
+        D.shard_indices(4, 4, 4)
+    x = torch.arange(6).reshape(3, 2)
+    assert D.gather_frames(x) is x                                     # no process group: the local block is the whole job
+    frames, mine = D.sample_decode_render_sharded(lambda slot, i: torch.full((2,), i), 3)
+    assert mine == [0, 1, 2] and frames.tolist() == [[0, 0], [1, 1], [2, 2]]
+
+
 def test_two_rank_sample_sharding_and_frame_gather(tmp_path):
-    world, port = 2, _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    world, total, port = 2, 3, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path), total), nprocs=world, join=True)
     g0, g1 = np.load(tmp_path / "g0.npy"), np.load(tmp_path / "g1.npy")
-    assert np.array_equal(g0, g1)                                   # every rank holds every sample's frames
+    assert g0.shape[0] == total and np.array_equal(g0, g1)          # every rank holds every sample's frames, in global order
+    for i in range(total):
+        assert np.array_equal(g0[i], _oracle_frames(i).numpy())     # == the same samples rendered in this one process
     for r in range(world):
-        assert np.array_equal(g0[r], np.load(tmp_path / f"own{r}.npy"))
+        assert np.array_equal(np.load(tmp_path / f"own{r}.npy"), g0[r::world])
     assert not np.array_equal(g0[0], g0[1])                         # different samples per rank (sharded, not replicated)
 
 
@@ -82,26 +114,26 @@ def _sample_batch(indices, method):
 def _sampler_worker(rank, world, port, out_dir, total):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    mine = list(range(rank, total, world))              # rank r owns samples r::world, as bench.py / DESIGN section 4
-    x0 = _sample_batch(mine, "multistep")
-    gathered = torch.empty((world * len(mine),) + tuple(x0.shape[1:]))
-    dist.all_gather_into_tensor(gathered, x0.contiguous())       # the path's one collective (frames in bench.py; latents here)
+    from gvfdiffusion_amd import distributed as D
+    D.init_from_env()
+    # every owned sample on its own (batch 1 with three-way guidance inside), as the product path runs them
+    res = D.run_sharded(lambda slot, i: _sample_batch([i], "multistep")[0], total)
+    gathered = D.gather_frames(torch.stack(res), total)          # the path's one collective (frames in the product; latents here)
     if rank == 0:
-        np.save(os.path.join(out_dir, "sharded.npy"), gathered.reshape(world, len(mine), *x0.shape[1:]).numpy())
+        np.save(os.path.join(out_dir, "sharded.npy"), gathered.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_two_rank_sharded_sampling_equals_single_process(tmp_path):
-    """Rank-sharded DPM_Solver.sample (with three-way classifier-free guidance) == the same samples drawn in one process:
-    sharding over the batch changes nothing but where a sample is computed."""
-    world, total, port = 2, 4, _free_port()
+    """Rank-sharded DPM_Solver.sample (with three-way classifier-free guidance) == the same samples drawn in one process as one batch:
+    sharding over the batch changes nothing but where a sample is computed (5 samples over 2 ranks: uneven shards)."""
+    world, total, port = 2, 5, _free_port()
     mp.spawn(_sampler_worker, args=(world, port, str(tmp_path), total), nprocs=world, join=True)
-    sharded = np.load(tmp_path / "sharded.npy")                    # [rank][local index]
+    sharded = np.load(tmp_path / "sharded.npy")                    # global sample order
     sys.path.insert(0, ROOT)
     single = _sample_batch(list(range(total)), "multistep").numpy()
-    for r in range(world):
-        for j, i in enumerate(range(r, total, world)):
-            assert np.allclose(sharded[r, j], single[i], rtol=0, atol=1e-6), (r, j, i)
+    assert sharded.shape == single.shape
+    for i in range(total):
+        assert np.allclose(sharded[i], single[i], rtol=0, atol=1e-6), i
     assert not np.allclose(single[0], single[1])
