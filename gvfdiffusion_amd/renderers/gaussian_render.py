@@ -207,9 +207,8 @@ class GaussianRenderer:
         or None; delta_index: F ints selecting the delta slice per frame (default: frame f -> min(f,T-1),
         -1 = static).  Returns edict(rgb (F,3,H,W) [, alpha, depth (F,H,W)], num_rendered (F,))."""
         opts = self.rendering_options
-        if opts["ssaa"] != 1:
-            raise NotImplementedError("render_frames: ssaa > 1 is handled by render() only")
-        size = int(opts["resolution"])
+        ssaa = int(opts["ssaa"])
+        size = int(opts["resolution"]) * ssaa          # supersampled render, down-sampled below as render() does (gaussian_render.py:355-360)
         dev = extrinsics.device
         bg = self._background(dev)
         T = 0 if delta_pc is None else (1 if delta_pc.dim() == 2 else delta_pc.shape[0])
@@ -223,7 +222,10 @@ class GaussianRenderer:
                                    gaussian._scaling, gaussian._rotation, gaussian._opacity, delta=delta_pc,
                                    want_alpha_depth=want_alpha_depth or not self.pipe.use_mip_gaussian,
                                    max_rendered=max_rendered, sync=sync)
-        ret = edict({"rgb": out["color"], "num_rendered": out["num_rendered"]})
-        if out["alpha"] is not None:
+        rgb = out["color"]
+        if ssaa > 1:                                   # all F frames in one bicubic antialiased resize
+            rgb = F.interpolate(rgb, size=(int(opts["resolution"]),) * 2, mode="bicubic", align_corners=False, antialias=True)
+        ret = edict({"rgb": rgb, "num_rendered": out["num_rendered"]})
+        if out["alpha"] is not None:                   # (depth / alpha stay at the supersampled size, as in render())
             ret["alpha"], ret["depth"] = out["alpha"], out["depth"]
         return ret

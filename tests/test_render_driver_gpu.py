@@ -83,6 +83,31 @@ def test_driver_matches_per_frame_renders(cuda):
 
 
 @pytest.mark.gpu
+def test_render_frames_supersamples_like_the_per_frame_render(cuda):
+    """rendering_options.ssaa > 1 (renderers/gaussian_render.py:355-360: render at resolution x ssaa, bicubic antialiased down-sampling):
+    the batched call == the reference's per-frame render() with the same option."""
+    from gvfdiffusion_amd.renderers import GaussianRenderer
+    from gvfdiffusion_amd.utils import orbit_cameras
+    P, T, S = 10_000, 3, 96
+    attrs = synthetic.random_gaussians(P, sh_degree=1, seed=3, scale_lo=0.004, scale_hi=0.02)
+    gm = synthetic.gaussian_model_from(attrs, 1, cuda)
+    delta = synthetic.random_deltas(T, P, seed=4, std=0.02).to(cuda)
+    K = synthetic.intrinsics().to(cuda)
+    rend = GaussianRenderer({"resolution": S, "near": synthetic.NEAR, "far": synthetic.FAR, "bg_color": (1, 1, 1), "ssaa": 2})
+    rend.pipe.use_mip_gaussian = True
+    cams = orbit_cameras(T).to(cuda)
+    with torch.no_grad():
+        out = rend.render_frames(gm, cams, K, delta_pc=delta)
+        assert out.rgb.shape == (T, 3, S, S)
+        for t in range(T):
+            one = rend.render(gm, cams[t], K, delta_pc=delta[t])["rgb"]
+            assert one.shape == (3, S, S) and float((out.rgb[t] - one).abs().max()) < 2e-5
+    rend.rendering_options.ssaa = 1
+    with torch.no_grad():
+        assert float((rend.render_frames(gm, cams, K, delta_pc=delta).rgb - out.rgb).abs().max()) > 1e-3     # the option does something
+
+
+@pytest.mark.gpu
 def test_all_delta_module_is_the_rgb_only_facade(cuda):
     """renderers/gaussian_render_all_delta.py (named by BASELINE.json's north_star): same frames as gaussian_render, rgb only."""
     from gvfdiffusion_amd.renderers import GaussianRenderer
