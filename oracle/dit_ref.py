@@ -36,7 +36,7 @@ def _r(x, precision, site="gemm"):
     """Storage rounding of a tensor at a rounding point of the HIP pipeline.  precision: "fp32" (none), "bf16", "fp16", or a
     dict {"gemm": .., "attn": ..} giving the operand type of the projections' matrix products ("gemm": activations, weights, MLP
     hidden units, attention outputs) and of the attention's own operands ("attn": q, k, v, P) separately."""
-    p = precision.get(site, "fp32") if isinstance(precision, dict) else precision
+    p = precision.get(site, precision.get("attn", "fp32") if site == "attn_pv" else "fp32") if isinstance(precision, dict) else precision
     return x if p == "fp32" else x.to(_DT[p]).to(torch.float32)
 
 
@@ -79,7 +79,7 @@ def sdpa(q, k, v, precision):
         # the kernel rounds the un-normalised probabilities to the operand type and divides by the fp32 row sum afterwards
         m = s.amax(dim=-1, keepdim=True)
         e = torch.exp(s - m)
-        o = (_r(e, precision, "attn") @ v) / e.sum(dim=-1, keepdim=True)
+        o = (_r(e, precision, "attn_pv") @ _r(v, precision, "attn_pv")) / e.sum(dim=-1, keepdim=True)
     else:
         o = p @ v
     return _r(o.permute(0, 2, 1, 3), precision, "gemm")
@@ -102,12 +102,12 @@ def sdpa_tiled(q, k, v, precision, gamma_k=None):
     q, k, v = (t.permute(0, 2, 1, 3) for t in (q, k, v))
     k2 = _r(k * (LOG2E / math.sqrt(d)), precision, "attn")
     s = q @ k2.transpose(-2, -1)
-    if (precision.get("attn") if isinstance(precision, dict) else precision) == "fp16":
+    if (precision.get("attn_pv", precision.get("attn")) if isinstance(precision, dict) else precision) == "fp16":
         # fp16 probabilities need a per-query shift (exp2 of a raw score overflows at 16): the kernel subtracts a shift through the
         # score accumulator's initial value; softmax is shift invariant, only the rounding grid of P moves with it
         s = s - s.amax(dim=-1, keepdim=True)
-    p = _r(torch.exp2(s), precision, "attn")
-    o = (p @ _r(v, precision, "attn")) / p.sum(dim=-1, keepdim=True)
+    p = _r(torch.exp2(s), precision, "attn_pv")
+    o = (p @ _r(v, precision, "attn_pv")) / p.sum(dim=-1, keepdim=True)
     return _r(o.permute(0, 2, 1, 3), precision, "gemm")
 
 

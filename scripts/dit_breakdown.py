@@ -5,9 +5,9 @@ nfe = float(sys.argv[2]) if len(sys.argv) > 2 else 36.0
 
 
 def short_name(n):
-    if 'gemm_bf16_kernel' in n:
-        return 'gemm<' + n.split('gemm_bf16_kernel<')[1].split('>')[0] + '>'
-    for key in ('rowblock_kernel<true', 'rowblock_kernel<false', 'rowblock_pack', 'attn_xt_kernel', 'attn_pack_kv', 'attn_fwd_kernel', 'attn_small', 'attn_kvres', 'ln_mod', 'cast_pad', 'gemm_ln'):
+    if 'gemm_lp_kernel' in n:
+        return 'gemm<' + n.split('gemm_lp_kernel<')[1].split('>')[0] + '>'
+    for key in ('rowblock_kernel<true', 'rowblock_kernel<false', 'rowblock_pack', 'attn_xt_kernel<0', 'attn_xt_kernel<1', 'attn_xt_kernel', 'attn_pack_kv', 'attn_fwd_kernel', 'attn_small', 'attn_kvres', 'ln_mod', 'cast_pad', 'gemm_ln'):
         if key in n:
             return key + ('<T>' if key == 'attn_fwd_kernel' and 'true' in n else '')
     return n.split('(')[0][-40:]
