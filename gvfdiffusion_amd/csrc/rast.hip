@@ -1289,9 +1289,13 @@ static int launch_tile_sort(hipStream_t stream, const uint2* ranges, uint64_t* k
 // corners of the box of a rotated, elongated ellipse.)  The test only decides which (splat, quadrant) pairs are
 // evaluated; a kept splat is evaluated with the usual arithmetic and a culled one would have failed alpha >= 1/255 at
 // every pixel of the quadrant (margin: 0.02 octaves on the threshold against ~1e-5 of rounding), so images do not change.
-__device__ __forceinline__ float edge_max(float qa, float qb, float qc, float fixed, float lo, float hi) {
-    // max over t in [lo, hi] of  qa fixed^2 + qb fixed t + qc t^2   (qc < 0)
-    const float t = fminf(fmaxf(-0.5f * qb * fixed / qc, lo), hi);
+// max over t in [lo, hi] of  qa fixed^2 + qb fixed t + qc t^2   (qc < 0), the vertex slope kv = -qb / (2 qc) handed in: one hardware
+// reciprocal per splat and orientation instead of an IEEE division per edge (round 3: the staging loop spent 8 divisions = ~100 of its 265
+// vector instructions per instance on them; blend 0.87 -> 0.82 ms).  An inexact vertex only LOWERS the value (any t of the interval is a
+// lower bound of a concave function's maximum) by ~qc dt^2 ~ 1e-13 -- against the 0.02-octave margin of the test, i.e. never visibly; the
+// forward and the backward kernel share this function, so they evaluate the same splats.
+__device__ __forceinline__ float edge_max(float qa, float qb, float qc, float kv, float fixed, float lo, float hi) {
+    const float t = fminf(fmaxf(kv * fixed, lo), hi);
     return qa * fixed * fixed + (qb * fixed + qc * t) * t;
 }
 __device__ __forceinline__ unsigned quadrant_mask(float x, float y, float ap, float bp, float cp, float op, float hx,
@@ -1299,16 +1303,17 @@ __device__ __forceinline__ unsigned quadrant_mask(float x, float y, float ap, fl
     if (hx < 0.0f) return 0u;                            // opacity < 1/255: alpha < 1/255 at every pixel
     if (no_cull || !(hx < __builtin_inff())) return 0xFu; // sub-pixel offsets / degenerate conic: keep everywhere
     const float lim = -(__log2f(255.0f * op) + 0.02f);
+    const float kx = -0.5f * bp * __builtin_amdgcn_rcpf(cp), ky = -0.5f * bp * __builtin_amdgcn_rcpf(ap);   // vertex slopes: dy* = kx dx, dx* = ky dy
     unsigned m = 0u;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const float x0 = tile_x0 + (float)((q & 1) * 8), y0 = tile_y0 + (float)((q >> 1) * 8);
         const float dxl = x - (x0 + 7.0f), dxh = x - x0, dyl = y - (y0 + 7.0f), dyh = y - y0;   // offset ranges over the quadrant
         const bool inside = dxl <= 0.0f && dxh >= 0.0f && dyl <= 0.0f && dyh >= 0.0f;
-        float e = edge_max(ap, bp, cp, dxl, dyl, dyh);
-        e = fmaxf(e, edge_max(ap, bp, cp, dxh, dyl, dyh));
-        e = fmaxf(e, edge_max(cp, bp, ap, dyl, dxl, dxh));
-        e = fmaxf(e, edge_max(cp, bp, ap, dyh, dxl, dxh));
+        float e = edge_max(ap, bp, cp, kx, dxl, dyl, dyh);
+        e = fmaxf(e, edge_max(ap, bp, cp, kx, dxh, dyl, dyh));
+        e = fmaxf(e, edge_max(cp, bp, ap, ky, dyl, dxl, dxh));
+        e = fmaxf(e, edge_max(cp, bp, ap, ky, dyh, dxl, dxh));
         m |= (inside || e >= lim) ? (1u << q) : 0u;
     }
     return m;
@@ -1391,7 +1396,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
             const float test_T = T - w_raw;        /* = T (1 - alpha) up to one rounding; one op less */ \
             const bool stop = ok && test_T < 0.0001f;                                                  \
             done = done || stop;                                                                       \
-            const bool acc = ok && !stop;                                                              \
+            const bool acc = ok != stop;           /* = ok && !stop (stop implies ok): a scalar xor of the two lane masks instead of a second compare */ \
             const float wgt = acc ? w_raw : 0.0f;                                                      \
             C0 = __builtin_fmaf(b.z, wgt, C0);                                                         \
             C1 = __builtin_fmaf(b.w, wgt, C1);                                                         \
