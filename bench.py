@@ -266,7 +266,7 @@ class E2EWorkload:
             for p in vae.parameters():
                 p.copy_(torch.randn_like(p) * (1.0 / p.shape[1] ** 0.5 if p.dim() == 2 else 0.05))
             vae.to_outputs.weight.mul_(0.02)            # deltas of a few per cent of the object size, as a trained decoder gives
-        self.vae = vae.to(dev)
+        self.vae = vae.to(dev).set_compute_dtype(self.w.model._lp())      # the chain runs in ONE 16-bit operand type (the reference: fp16 autocast)
         attrs = synthetic.random_gaussians(P, sh_degree=0, seed=sample_seed)
         self.gm = synthetic.gaussian_model_from(attrs, 0, dev)
         gm = self.gm
@@ -310,7 +310,7 @@ def bench_e2e(dev, P=262_144, S=800, T=24):
             "value": round(T / wall, 2), "unit": "frames/s", "wall_ms": round(wall * 1e3, 2), "nfe": nfe,
             "stage_ms": {"sample": round(ms_sample, 2), "vae_decode": round(ms_decode, 2), "render": round(ms_render, 2)},
             "config": {"gaussians": P, "resolution": S, "frames": T, "sampler": "dpmsolver++ adaptive, steps=100, order 2",
-                       "dtype": "bf16 models, f32 rasteriser"}}
+                       "dtype": f"{e.w.dtype_name} models (DiT and motion VAE), f32 rasteriser"}}
 
 
 def bench_sharded_sampling(dev, dist, rank, world, P, S, T, total_batch=8, steps=32):
@@ -366,7 +366,7 @@ def bench_sharded_sampling(dev, dist, rank, world, P, S, T, total_batch=8, steps
             # per GPU, from the wall time of the whole chain (decode, render and gather included): a lower bound on the DiT's own fraction
             "dit_roofline_frac": round(es[0].w.flops_per_nfe(True) * b_loc * steps / dt / 1e12 / MFMA_PEAK_TFLOPS, 5),
             "ms_per_nfe_per_gpu_throughput": round(dt * 1e3 / (b_loc * steps), 3),
-            "scaling": "weak" if world <= total_batch else "replicas"}
+            "dtype": es[0].w.dtype_name, "scaling": "weak" if world <= total_batch else "replicas"}
 
 
 def bench_backward(dev, attrs, S, deg, iters=8):
@@ -707,7 +707,7 @@ def main():
             out["dit"] = {"metric": "DiT denoise steps/sec, whole job (sample-sharded, 32-step DPM-Solver++ multistep per sample)",
                           "value": shard["denoise_steps_per_s"], "unit": "steps/s", "ms_per_nfe": shard["ms_per_nfe_per_gpu_throughput"],
                           "ms_per_nfe_one_sample_latency": shard["ms_per_nfe_slowest_rank"], "samples_in_flight_per_rank": shard["samples_in_flight_per_rank"],
-                          "dtype": "bf16", "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_PEAK_TFLOPS,
+                          "dtype": shard["dtype"], "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_PEAK_TFLOPS,
                                                         "frac": shard["dit_roofline_frac"]}}
             out["end_to_end"] = shard
     if rank == 0:

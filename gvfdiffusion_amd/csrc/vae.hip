@@ -7,18 +7,12 @@
 // each lane owning channels lane, lane+64, ...; three wave-level LayerNorms; the result is the bf16 operand
 // of the to_q GEMM.  It depends on the static Gaussians only, so the host runs it once for all T frames.
 #include "gvf_common.h"
+#include "gvf_lp.h"
 #include "../../include/gvf_rast.h"
 #include "../../include/gvf_vae.h"
+#include "../../include/gvf_dit.h"
 
 namespace {
-
-__device__ __forceinline__ unsigned short f2bf(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
-__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -28,6 +22,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+template <int DT>
 __global__ __launch_bounds__(256) void geglu_kernel(const unsigned short* __restrict__ in, int ld_in,
                                                     unsigned short* __restrict__ out, int ld_out, long long rows, int F) {
     const int f8 = F >> 3;
@@ -41,9 +36,9 @@ __global__ __launch_bounds__(256) void geglu_kernel(const unsigned short* __rest
         unsigned ow[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float lo = bf2f((unsigned short)(aw[k] & 0xffffu)) * gelu_erf(bf2f((unsigned short)(gw[k] & 0xffffu)));
-            const float hi = bf2f((unsigned short)(aw[k] >> 16)) * gelu_erf(bf2f((unsigned short)(gw[k] >> 16)));
-            ow[k] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+            const float lo = GvfLp<DT>::lo(aw[k]) * gelu_erf(GvfLp<DT>::lo(gw[k]));
+            const float hi = GvfLp<DT>::hi(aw[k]) * gelu_erf(GvfLp<DT>::hi(gw[k]));
+            ow[k] = GvfLp<DT>::pack(lo, hi);
         }
         *reinterpret_cast<uint4*>(out + r * ld_out + c) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
     }
@@ -67,6 +62,7 @@ __device__ __forceinline__ void wave_layernorm(float (&v)[QE_MAXI], int ni, int 
     for (int i = 0; i < QE_MAXI; ++i) v[i] = (v[i] - mean) * rstd;
 }
 
+template <int DT>
 __global__ __launch_bounds__(256) void query_embed_kernel(const float* __restrict__ queries, int qdim,
                                                           const float* __restrict__ W, const float* __restrict__ bias,
                                                           const float* __restrict__ omega, unsigned short* __restrict__ out,
@@ -121,7 +117,7 @@ __global__ __launch_bounds__(256) void query_embed_kernel(const float* __restric
 #pragma unroll
         for (int i = 0; i < QE_MAXI; ++i) {
             const int c = lane + 64 * i;
-            if (i < ni && c < C) out[row * C + c] = f2bf(e1[i]);
+            if (i < ni && c < C) out[row * C + c] = GvfLp<DT>::to16(e1[i]);
         }
     }
 }
@@ -129,6 +125,11 @@ __global__ __launch_bounds__(256) void query_embed_kernel(const float* __restric
 }  // namespace
 
 extern "C" int gvf_geglu_bf16(const void* in_bf16, int ld_in, void* out_bf16, int ld_out, int64_t rows, int F, void* stream_) {
+    return gvf_geglu(GVF_DT_BF16, in_bf16, ld_in, out_bf16, ld_out, rows, F, stream_);
+}
+
+extern "C" int gvf_geglu(int dtype, const void* in_bf16, int ld_in, void* out_bf16, int ld_out, int64_t rows, int F, void* stream_) {
+    if (dtype != GVF_DT_BF16 && dtype != GVF_DT_F16) return GVF_EINVAL;
     if (rows < 0 || F <= 0 || (F & 7) || (ld_in & 7) || (ld_out & 7) || ld_in < 2 * F || ld_out < F) return GVF_EINVAL;
     if (rows == 0) return GVF_OK;
     if (!in_bf16 || !out_bf16 || (((uintptr_t)in_bf16) & 15) || (((uintptr_t)out_bf16) & 15)) return GVF_EINVAL;
@@ -136,20 +137,27 @@ extern "C" int gvf_geglu_bf16(const void* in_bf16, int ld_in, void* out_bf16, in
     long long total = rows * (long long)(F >> 3);
     long long blocks = (total + 255) / 256;
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(geglu_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_,
-                       (const unsigned short*)in_bf16, ld_in, (unsigned short*)out_bf16, ld_out, (long long)rows, F);
+    GVF_LP_DISPATCH(dtype, hipLaunchKernelGGL(geglu_kernel<DT>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_,
+                                              (const unsigned short*)in_bf16, ld_in, (unsigned short*)out_bf16, ld_out, (long long)rows, F));
     GVF_CHECK_LAUNCH();
     return GVF_OK;
 }
 
 extern "C" int gvf_vae_query_embed_bf16(const float* queries, int qdim, const float* W, const float* bias, const float* omega,
                                         void* out_bf16, int64_t P, int C, float eps_embed, float eps_prenorm, void* stream_) {
-    return gvf_vae_embed_bf16_f32(queries, qdim, W, bias, omega, out_bf16, nullptr, P, C, eps_embed, eps_prenorm, stream_);
+    return gvf_vae_embed(GVF_DT_BF16, queries, qdim, W, bias, omega, out_bf16, nullptr, P, C, eps_embed, eps_prenorm, stream_);
 }
 
 extern "C" int gvf_vae_embed_bf16_f32(const float* queries, int qdim, const float* W, const float* bias, const float* omega,
                                       void* out_bf16, float* out_embed_f32, int64_t P, int C, float eps_embed, float eps_prenorm,
                                       void* stream_) {
+    return gvf_vae_embed(GVF_DT_BF16, queries, qdim, W, bias, omega, out_bf16, out_embed_f32, P, C, eps_embed, eps_prenorm, stream_);
+}
+
+extern "C" int gvf_vae_embed(int dtype, const float* queries, int qdim, const float* W, const float* bias, const float* omega,
+                             void* out_bf16, float* out_embed_f32, int64_t P, int C, float eps_embed, float eps_prenorm,
+                             void* stream_) {
+    if (dtype != GVF_DT_BF16 && dtype != GVF_DT_F16) return GVF_EINVAL;
     if (P < 0 || qdim < 3 || qdim > QE_MAXQ || C <= 0 || C > 64 * QE_MAXI || (C % 6) != 0) return GVF_EINVAL;
     if (P == 0) return GVF_OK;
     if (!queries || !W || !bias || !omega || !out_bf16) return GVF_EINVAL;
@@ -157,8 +165,9 @@ extern "C" int gvf_vae_embed_bf16_f32(const float* queries, int qdim, const floa
     const int rows_per_block = 64;   // amortises the W -> LDS copy (C*qdim floats) over 64 Gaussians
     const size_t smem = ((size_t)C * (qdim | 1) + C + C / 6) * sizeof(float);
     const long long blocks = (P + rows_per_block - 1) / rows_per_block;
-    hipLaunchKernelGGL(query_embed_kernel, dim3((unsigned)blocks), dim3(256), smem, (hipStream_t)stream_, queries, qdim, W, bias,
-                       omega, (unsigned short*)out_bf16, out_embed_f32, (long long)P, C, eps_embed, eps_prenorm, rows_per_block);
+    GVF_LP_DISPATCH(dtype, hipLaunchKernelGGL(query_embed_kernel<DT>, dim3((unsigned)blocks), dim3(256), smem, (hipStream_t)stream_, queries, qdim, W,
+                                              bias, omega, (unsigned short*)out_bf16, out_embed_f32, (long long)P, C, eps_embed, eps_prenorm,
+                                              rows_per_block));
     GVF_CHECK_LAUNCH();
     return GVF_OK;
 }

@@ -25,6 +25,7 @@ import torch.nn as nn
 
 from .. import _lib
 from ..ops import dit_ops, vae_ops
+from ..ops import precision
 
 
 class GEGLU(nn.Module):
@@ -131,7 +132,17 @@ class GSKLTemporalVariationalAutoEncoder(nn.Module):
         nn.init.zeros_(self.to_outputs.weight)       # zero_module(to_outputs), model/autoencoder.py:434
         nn.init.zeros_(self.to_outputs.bias)
         self._wcache = None
-        self.max_chunk_rows = 1 << 20                # rows (B*T*Pc) of the bf16 attention-output chunk: 1.5 GiB at dim 768
+        self.compute_dtype = None                    # None: ops/precision.py decides per call (GVF_DIT_DTYPE, an autocast region -- the
+                                                     # reference decodes under accelerate's fp16 autocast, inference_dpm_latent.py:256 --, else bf16)
+        self.max_chunk_rows = 1 << 20                # rows (B*T*Pc) of the 16-bit attention-output chunk: 1.5 GiB at dim 768
+
+    def set_compute_dtype(self, dtype):
+        """torch.float16 / torch.bfloat16 (or "fp16" / "bf16"): the matrix pipe's operand type; None = ops/precision.py's rule."""
+        self.compute_dtype = precision.parse(dtype)
+        return self
+
+    def _lp(self):
+        return precision.resolve(self.compute_dtype, (), torch.bfloat16)
 
     # ---- encode (encode_latent.py / training; not on the inference path) ---------------------------------------------
     @staticmethod
@@ -166,7 +177,7 @@ class GSKLTemporalVariationalAutoEncoder(nn.Module):
         B, N, _ = static_pc.shape
         T = delta_pc.shape[1]
         C, H, d, L, dev = self.dim, self.heads, self.dim_head, self.num_latents, static_pc.device
-        bf16 = torch.bfloat16
+        bf16 = W["lp"]                                   # the 16-bit operand type of this call (bf16 or fp16)
         sampled_static_gs = sample_gs(static_gs_list, L, random_start=random_start)                  # (B, L, 14)
         input_static_gs = sampled_static_gs[..., :3].float().contiguous()
         static_pc, delta_pc = static_pc.float(), delta_pc.float()
@@ -175,8 +186,8 @@ class GSKLTemporalVariationalAutoEncoder(nn.Module):
         # embeddings: rows [xyz | delta]; the Linear sees only the delta (zero weights on xyz), PointEmbed only the xyz
         qrows = torch.cat([input_static_gs[:, None].expand(B, T, L, 3), est], dim=-1).reshape(B * T * L, 6).contiguous()
         crows = torch.cat([static_pc[:, None].expand(B, T, N, 3), delta_pc], dim=-1).reshape(B * T * N, 6).contiguous()
-        xn, x = vae_ops.vae_embed_bf16_f32(qrows, W["in_w6"], W["in_b"], W["omega"])
-        cn, _ = vae_ops.vae_embed_bf16_f32(crows, W["in_w6"], W["in_b"], W["omega"], want_embed=False)
+        xn, x = vae_ops.vae_embed_bf16_f32(qrows, W["in_w6"], W["in_b"], W["omega"], dtype=bf16)
+        cn, _ = vae_ops.vae_embed_bf16_f32(crows, W["in_w6"], W["in_b"], W["omega"], want_embed=False, dtype=bf16)
         M, Mc = B * T * L, B * T * N
         e = W["enc"]
         q = torch.empty((M, C), dtype=bf16, device=dev)
@@ -194,7 +205,7 @@ class GSKLTemporalVariationalAutoEncoder(nn.Module):
         dit_ops.gemm_bf16(hb, *e["fc1"], hid, dit_ops.EPI_STORE_BF16)
         act = vae_ops.geglu_bf16(hid)
         dit_ops.gemm_bf16(act, *e["fc2"], x, dit_ops.EPI_RESID_F32)
-        xb = dit_ops.cast_pad_bf16(x, C)
+        xb = dit_ops.cast_pad(x, C, dtype=bf16)
         Dl = self.mean_fc.out_features
         mean = torch.empty((M, Dl), dtype=torch.float32, device=dev)
         logvar = torch.empty((M, Dl), dtype=torch.float32, device=dev)
@@ -220,18 +231,19 @@ class GSKLTemporalVariationalAutoEncoder(nn.Module):
         return tuple((p._version, p.data_ptr()) for p in self.parameters())
 
     def _weights(self):
-        ver = self._param_version()
+        lp = self._lp()
+        ver = (self._param_version(), lp)
         if self._wcache is not None and self._wcache["ver"] == ver:
             return self._wcache
 
         def bf(w):
             w = w.detach().float().contiguous()
-            return dit_ops.cast_pad_bf16(w, dit_ops.pad64(w.shape[1]))
+            return dit_ops.cast_pad(w, dit_ops.pad64(w.shape[1]), dtype=lp)
 
         def fb(b):
             return None if b is None else b.detach().float().contiguous()
 
-        W = {"ver": ver, "proj": (bf(self.proj.weight), fb(self.proj.bias)), "layers": []}
+        W = {"ver": ver, "lp": lp, "proj": (bf(self.proj.weight), fb(self.proj.bias)), "layers": []}
         for a, f in self.layers:
             W["layers"].append(dict(
                 qkv=bf(torch.cat([a.fn.to_q.weight, a.fn.to_kv.weight], 0)),
@@ -266,8 +278,8 @@ class GSKLTemporalVariationalAutoEncoder(nn.Module):
         BT, L, Dl = x.shape
         C, H, d, dev = self.dim, self.heads, self.dim_head, x.device
         M = BT * L
-        bf16 = torch.bfloat16
-        xb = dit_ops.cast_pad_bf16(x.reshape(M, Dl).float().contiguous(), dit_ops.pad64(Dl))
+        bf16 = W["lp"]                                   # the 16-bit operand type of this call (bf16 or fp16)
+        xb = dit_ops.cast_pad(x.reshape(M, Dl).float().contiguous(), dit_ops.pad64(Dl), dtype=bf16)
         h = torch.empty((M, C), dtype=torch.float32, device=dev)
         dit_ops.gemm_bf16(xb, *W["proj"], h, dit_ops.EPI_STORE_F32)
         hb = torch.empty((M, C), dtype=bf16, device=dev)
@@ -296,7 +308,7 @@ class GSKLTemporalVariationalAutoEncoder(nn.Module):
         BT, L = x.shape[:2]
         if BT != B * T:
             raise ValueError(f"x has {BT} latent sets, queries imply B*T = {B}*{T}")
-        bf16 = torch.bfloat16
+        bf16 = W["lp"]                                   # the 16-bit operand type of this call (bf16 or fp16)
         h = self.decode_latents(x)
         # context: PreNorm.norm_context -> to_kv, K head-major and V^T zero-padded to 64 keys, per (b, t)
         hb = torch.empty((BT * L, C), dtype=bf16, device=dev)
@@ -308,7 +320,7 @@ class GSKLTemporalVariationalAutoEncoder(nn.Module):
         vt = torch.zeros((BT, H, d, Lp), dtype=bf16, device=dev)
         vt[..., :L] = kv[:, C:].reshape(BT, L, H, d).permute(0, 2, 3, 1)
         # queries: embedding + PreNorm + to_q once per static Gaussian (shared by the T frames)
-        qe = vae_ops.vae_query_embed_bf16(queries.reshape(B * P, -1).float().contiguous(), W["gs_w"], W["gs_b"], W["omega"])
+        qe = vae_ops.vae_query_embed_bf16(queries.reshape(B * P, -1).float().contiguous(), W["gs_w"], W["gs_b"], W["omega"], dtype=bf16)
         qp = torch.empty((B * P, C), dtype=bf16, device=dev)
         dit_ops.gemm_bf16(qe, W["dec_q"], None, qp, dit_ops.EPI_STORE_BF16)
         del qe

@@ -7,6 +7,8 @@
  *   model/autoencoder.py:392-394   gs_embedding = Linear(14, dim) + LayerNorm(no affine),
  *                  :250-301        position_encoding = PointEmbed(dim) + LayerNorm(no affine),
  *                  :561, :80-81    their sum, then the decoder PreNorm LayerNorm              -> gvf_vae_query_embed_bf16
+ * `dtype` = GVF_DT_BF16 / GVF_DT_F16 of gvf_dit.h: the 16-bit type of the GEMM / attention operands these kernels read and write (the
+ * reference decodes under accelerate's fp16 autocast, inference_dpm_latent.py:256-257); the `*_bf16*` names are the round-1/2 entry points.
  * Conventions as in gvf_rast.h: device pointers, caller-owned buffers, explicit stream, int status.
  */
 #ifndef GVF_VAE_H
@@ -21,6 +23,7 @@ extern "C" {
 
 /* out bf16 [rows][ld_out] (first F columns) = in[r][c] * gelu_erf(in[r][F + c]);  in bf16 [rows][ld_in], F % 8 == 0,
  * ld_in / ld_out multiples of 8. */
+int gvf_geglu(int dtype, const void* in16, int ld_in, void* out16, int ld_out, int64_t rows, int F, void* stream);
 int gvf_geglu_bf16(const void* in_bf16, int ld_in, void* out_bf16, int ld_out, int64_t rows, int F, void* stream);
 
 /* out bf16 [P][C] = LN_pre( LN_emb(q W^T + b) + LN_emb(point_embed(q[:, :3])) ), LayerNorms without affine; the two
@@ -35,6 +38,8 @@ int gvf_vae_query_embed_bf16(const float* queries, int qdim, const float* W, con
  * additionally writes the embedding itself, out_embed_f32 [P][C] = LN_emb(q W^T + b) + LN_emb(point_embed(q[:, :3]))
  * (may be null), which the encoder's residual stream starts from; out_bf16 is its PreNorm-normalised GEMM operand.
  * The encoder passes rows [xyz | delta] with zero weights on the xyz columns. */
+int gvf_vae_embed(int dtype, const float* queries, int qdim, const float* W, const float* bias, const float* omega,
+                  void* out16, float* out_embed_f32, int64_t P, int C, float eps_embed, float eps_prenorm, void* stream);
 int gvf_vae_embed_bf16_f32(const float* queries, int qdim, const float* W, const float* bias, const float* omega,
                            void* out_bf16, float* out_embed_f32, int64_t P, int C, float eps_embed, float eps_prenorm,
                            void* stream);

@@ -8,8 +8,12 @@ import torch
 import torch.nn.functional as F
 
 
+_DT = {"bf16": torch.bfloat16, "fp16": torch.float16}
+
+
 def _r(x, precision):
-    return x.to(torch.bfloat16).to(torch.float32) if precision == "bf16" else x
+    """storage rounding at a rounding point of the HIP pipeline: "fp32" (none), "bf16" or "fp16" (the reference's autocast dtype)"""
+    return x if precision == "fp32" else x.to(_DT[precision]).to(torch.float32)
 
 
 def _lin(x, sd, name, precision, round_out=False):
@@ -30,7 +34,7 @@ def attention(xq, ctx, sd, prefix, heads, precision):
     d = q.shape[-1] // heads
     q, k, v = (t.reshape(t.shape[0], t.shape[1], heads, d).permute(0, 2, 1, 3) for t in (q, k, v))
     s = (q @ k.transpose(-1, -2)) * d ** -0.5
-    if precision == "bf16":
+    if precision != "fp32":
         e = torch.exp(s - s.amax(dim=-1, keepdim=True))
         o = (_r(e, precision) @ v) / e.sum(dim=-1, keepdim=True)
     else:

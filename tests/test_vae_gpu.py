@@ -15,6 +15,9 @@ pytestmark = pytest.mark.gpu
 
 TOL_VS_BF16_ORACLE = 1e-2
 TOL_VS_FP32_ORACLE = 3e-2
+# fp16 operands (set_compute_dtype / an fp16 autocast region: what the reference decodes under, inference_dpm_latent.py:256-257)
+TOL_FP16_VS_FP16_ORACLE = 1.5e-3
+TOL_FP16_VS_FP32_ORACLE = 4e-3
 
 
 def _model(cfg, seed=0, gain=1.0):
@@ -42,22 +45,24 @@ def _rel(a, b):
     return float((a - b).norm() / b.norm())
 
 
-def _check(cfg, B, P, L, chunk_rows=None, gain=1.0):
+def _check(cfg, B, P, L, chunk_rows=None, gain=1.0, dtype="bf16"):
     from oracle import vae_ref
     m = _model(cfg, gain=gain)
     x, q = _inputs(cfg, B, P, L)
     sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
     with torch.no_grad():
         ref32 = vae_ref.vae_decode(sd, cfg, x, q, cfg["num_timesteps"], "fp32")
-        ref16 = vae_ref.vae_decode(sd, cfg, x, q, cfg["num_timesteps"], "bf16")
-    m = m.cuda()
+        ref16 = vae_ref.vae_decode(sd, cfg, x, q, cfg["num_timesteps"], dtype)
+    m = m.cuda().set_compute_dtype(dtype)
     if chunk_rows:
         m.max_chunk_rows = chunk_rows
     y = m.decode(x.cuda(), q.cuda()).cpu()
+    assert m._wcache["lp"] == {"bf16": torch.bfloat16, "fp16": torch.float16}[dtype]
     assert y.shape == (B, cfg["num_timesteps"], P, cfg["output_dim"]) and torch.isfinite(y).all()
     e16, e32 = _rel(y, ref16), _rel(y, ref32)
-    print(f"vae decode rel-L2: vs bf16 oracle {e16:.2e}, vs fp32 oracle {e32:.2e}, bf16 oracle vs fp32 oracle {_rel(ref16, ref32):.2e}")
-    assert e16 < TOL_VS_BF16_ORACLE and e32 < TOL_VS_FP32_ORACLE, (e16, e32)
+    print(f"vae decode [{dtype}] rel-L2: vs {dtype} oracle {e16:.2e}, vs fp32 oracle {e32:.2e}, {dtype} oracle vs fp32 oracle {_rel(ref16, ref32):.2e}")
+    t16, t32 = (TOL_VS_BF16_ORACLE, TOL_VS_FP32_ORACLE) if dtype == "bf16" else (TOL_FP16_VS_FP16_ORACLE, TOL_FP16_VS_FP32_ORACLE)
+    assert e16 < t16 and e32 < t32, (e16, e32)
     return e16, e32
 
 
@@ -92,19 +97,33 @@ def test_query_embed_matches_torch(cuda, C):
     assert (y - ref).abs().max() < 2e-2 and _rel(y, ref) < 3e-3     # bf16 output rounding: 2^-9 relative
 
 
-def test_decode_head_dim_64_chunked(cuda):
-    _check(BASE, B=2, P=300, L=40, chunk_rows=6 * 128)     # 3 chunks of 128 Gaussians, the last ragged (44)
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_decode_head_dim_64_chunked(cuda, dtype):
+    _check(BASE, B=2, P=300, L=40, chunk_rows=6 * 128, dtype=dtype)     # 3 chunks of 128 Gaussians, the last ragged (44)
 
 
-def test_decode_head_dim_32(cuda):
-    _check(dict(BASE, heads=6), B=1, P=257, L=64)
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_decode_head_dim_32(cuda, dtype):
+    _check(dict(BASE, heads=6), B=1, P=257, L=64, dtype=dtype)
 
 
-def test_decode_released_config(cuda):
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_decode_released_config(cuda, dtype):
     """depth 12, dim 768, 12 heads of 64, 512 latents, 24 frames (configs/diffusion.yml: autoencoder section)."""
     cfg = dict(depth=12, dim=768, queries_dim=768, output_dim=14, num_inputs=8192, num_latents=512, latent_dim=16, heads=12,
                dim_head=-1, num_timesteps=24, chunk_size=8192)
-    _check(cfg, B=1, P=1500, L=512)
+    _check(cfg, B=1, P=1500, L=512, dtype=dtype)
+
+
+def test_decode_follows_an_autocast_region(cuda):
+    """`with accelerator.autocast(): vae.decode(...)` (inference_dpm_latent.py:256-257, mixed_precision='fp16') selects fp16 operands."""
+    m = _model(BASE).cuda()
+    x, q = _inputs(BASE, 1, 130, 40)
+    y_default = m.decode(x.cuda(), q.cuda())
+    assert m._wcache["lp"] == torch.bfloat16
+    with torch.autocast("cuda", dtype=torch.float16):
+        y16 = m.decode(x.cuda(), q.cuda())
+    assert m._wcache["lp"] == torch.float16 and y16.dtype == torch.float32 and not torch.equal(y16, y_default)
 
 
 def test_strict_load_of_reference_layout_and_loud_failures(cuda):
