@@ -35,8 +35,9 @@ def rel_l2(a, b):
 # cannot meet that element-wise (one bf16 ulp is 3.9e-3 relative and accumulation order moves roundings), so
 # the claims are stated as relative L2 errors, measured values printed by the tests:
 TOL_KERNEL_REL_L2 = 2e-3     # single kernel vs torch on identical bf16 operands (fp32 accumulate)
-TOL_DIT_VS_BF16_ORACLE = 6e-3   # full denoiser vs oracle with the same rounding points (dit_ref precision="bf16"): measured 3.4e-3
-#   at the full config / 2.7e-4 at the small one.  Single kernels agree with the oracle to 1e-5 .. 2e-4 (tests above); what is
+TOL_DIT_VS_BF16_ORACLE = 4.5e-3  # full denoiser vs oracle with the same rounding points (dit_ref precision="bf16"): measured 2.7e-3 at the
+#   full config, 1.4e-5 at the small one; two bf16 pipelines with different summation orders (row-block vs per-sub-layer launches): 3.4e-3;
+#   the bound is the largest of these + 30 %.  (The dtype-parametrised bars of the full config live in tests/test_dit_fp16_gpu.py.)  Single kernels agree with the oracle to 1e-5 .. 2e-4 (tests above); what is
 #   left after 12 blocks is decorrelated rounding noise (a probability or an activation that rounds the other way), not bias.
 TOL_DIT_VS_FP32_REF = 3e-2      # loose sanity bound vs the fp32 reference output (golden); the REAL bar is REF_AUTOCAST_SLACK:
 REF_AUTOCAST_SLACK = 0.6        # err(HIP vs fp32 golden) <= 0.6 x err(the reference's own bf16 autocast run vs fp32 golden)
