@@ -167,10 +167,13 @@ __device__ __forceinline__ void tile64(const uint4* __restrict__ sKb, const unsi
 // argument, P = exp2(s), l += sum P.  No maximum tree, no subtraction, no rescale of O: 16 max3 + 32 fma fewer per 64 keys, and the
 // exponentials of one half-tile can issue while the matrix pipe still works on the other.  Valid while no exp2 overflows or all of
 // them vanish; the caller checks the denominators and falls back to tile64 (exact for any input).
+// fp16 operands: exp2 of a raw score leaves fp16's range at 16, so every query carries a SHIFT (cinit = the splat of minus the maximum of its
+// scores against the first key tile, tile_first_max below) that enters each QK^T MFMA as the accumulator's initial value -- the scheme of
+// attn_xt.hip; bf16: cinit is zero and folds into the MFMA's inline constant.
 template <int D, bool MASKED, int NQ, int DT>
 __device__ __forceinline__ void tile64_nomax(const uint4* __restrict__ sKb, const unsigned short* __restrict__ sVTb, int key0, int Lk,
                                              const typename GvfLp<DT>::x8 (&qf)[NQ][Cfg<D>::NS], int l31, int half, f32x16 (&o_acc)[NQ][Cfg<D>::ND],
-                                             float (&l_run)[NQ]) {
+                                             float (&l_run)[NQ], const f32x16 (&cinit)[NQ]) {
     typedef GvfLp<DT> LP;
     typedef typename LP::x8 x8;
     // NQ 32-query tiles of the wave against the same 64 keys: every K / V^T fragment read from LDS feeds NQ MFMAs (the LDS port, not
@@ -183,7 +186,7 @@ __device__ __forceinline__ void tile64_nomax(const uint4* __restrict__ sKb, cons
         const int krow_l = sub * 32 + l31;
         const int sw = C::swz(krow_l);
 #pragma unroll
-        for (int t = 0; t < NQ; ++t) s_acc[t][sub] = zero;
+        for (int t = 0; t < NQ; ++t) s_acc[t][sub] = LP::kNeedsShift ? cinit[t] : zero;
 #pragma unroll
         for (int st = 0; st < C::NS; ++st) {
             const x8 kf = __builtin_bit_cast(x8, sKb[krow_l * C::KC + ((2 * st + half) ^ sw)]);
@@ -235,6 +238,31 @@ __device__ __forceinline__ void tile64_nomax(const uint4* __restrict__ sKb, cons
         __builtin_amdgcn_sched_group_barrier(0x002, RES_SCHED, 0);
     }
 #endif
+}
+
+// Maximum of one 32-query tile's scores against a staged (pre-scaled) 64-key tile: the fp16 shift of tile64_nomax.  Keys past Lk were
+// staged as zeros (score 0): they take part, which can only raise the shift -- the denominators' lower bound then sends a wave whose
+// probabilities all vanished to the exact path.
+template <int D, int DT>
+__device__ __forceinline__ float tile_first_max(const uint4* __restrict__ sKb, const typename GvfLp<DT>::x8 (&qf)[Cfg<D>::NS], int l31, int half) {
+    using C = Cfg<D>;
+    typedef GvfLp<DT> LP;
+    typedef typename LP::x8 x8;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float m = -INFINITY;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+        const int krow_l = sub * 32 + l31;
+        const int sw = C::swz(krow_l);
+        f32x16 s = zero;
+#pragma unroll
+        for (int st = 0; st < C::NS; ++st)
+            s = LP::mfma32(__builtin_bit_cast(x8, sKb[krow_l * C::KC + ((2 * st + half) ^ sw)]), qf[st], s);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = max2f(m, s[r]);
+    }
+    m = max2f(m, __shfl_xor(m, 32, 64));
+    return (m > -3.0e38f && m < 3.0e38f) ? m : 0.f;
 }
 
 // 8 operand-type values times a scalar, in fp32, one rounding
@@ -444,8 +472,9 @@ __global__ __launch_bounds__(RES_THREADS) void attn_kvres_kernel(AttnParams p, i
     using C = Cfg<D>;
     typedef GvfLp<DT> LP;
     typedef typename LP::x8 x8;
-    // fp16 probabilities of raw scores would overflow (see attn_xt.hip for the shifted max-free form): fp16 takes the running-maximum softmax here
-    constexpr bool NOMAX = RES_NOMAX && !LP::kNeedsShift;
+    // fp16: the max-free softmax with a per-query shift (tile_first_max), ONE query tile per wave at a time (the shift splats of two would
+    // not fit the register budget of head_dim 64)
+    constexpr bool NOMAX = RES_NOMAX != 0;
     constexpr int CPT = KT * C::KC;                            // 16-byte chunks per K tile (= per V tile)
     extern __shared__ __attribute__((aligned(16))) unsigned char res_smem[];
     uint4* sK = reinterpret_cast<uint4*>(res_smem);                                            // [tiles][CPT]
@@ -531,7 +560,7 @@ __global__ __launch_bounds__(RES_THREADS) void attn_kvres_kernel(AttnParams p, i
     __syncthreads();
 
     // ---- every wave: its 32-query tiles over all key tiles, straight from LDS; RES_NQ tiles at a time (passes qt, qt + 1, ...)
-    constexpr int NQ = NOMAX ? RES_NQ : 1;
+    constexpr int NQ = NOMAX ? (LP::kNeedsShift ? 1 : RES_NQ) : 1;
     for (int qt = 0; qt < qt_per_wg; qt += NQ) {
         int qrow[NQ];
         bool qvalid[NQ];
@@ -575,18 +604,27 @@ __global__ __launch_bounds__(RES_THREADS) void attn_kvres_kernel(AttnParams p, i
                 for (int r = 0; r < 16; ++r) o_acc[t][dt][r] = 0.f;
         }
         if (NOMAX) {
+            f32x16 cinit[NQ];
+#pragma unroll
+            for (int t = 0; t < NQ; ++t) {
+                const float m0 = LP::kNeedsShift ? tile_first_max<D, DT>(sK, qf[t], l31, half) : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cinit[t][r] = -m0;
+            }
             for (int kt = 0; kt < n_tiles; ++kt) {
                 const uint4* kb = sK + (size_t)kt * CPT;
                 const unsigned short* vb = sVT + (size_t)kt * res_vt_tile<D>();
-                if (kt < last_full) tile64_nomax<D, false, NQ, DT>(kb, vb, kt * KT, Lk, qf, l31, half, o_acc, l_run);
-                else tile64_nomax<D, true, NQ, DT>(kb, vb, kt * KT, Lk, qf, l31, half, o_acc, l_run);
+                if (kt < last_full) tile64_nomax<D, false, NQ, DT>(kb, vb, kt * KT, Lk, qf, l31, half, o_acc, l_run, cinit);
+                else tile64_nomax<D, true, NQ, DT>(kb, vb, kt * KT, Lk, qf, l31, half, o_acc, l_run, cinit);
             }
             // every query's denominator must be finite and in range (2^-100 .. 2^100: no exp2 overflowed, not all of them vanished);
             // otherwise the WAVE redoes that 32-query tile with the running-maximum softmax (keys are pre-scaled: scale 1)
 #pragma unroll
             for (int t = 0; t < NQ; ++t) {
                 const float l_chk = l_run[t] + __shfl_xor(l_run[t], 32, 64);
-                const bool bad = qvalid[t] && !(l_chk > 7.888609e-31f && l_chk < 1.2676506e30f);
+                // fp16: this kernel sums the UNROUNDED fp32 probabilities, so a probability beyond fp16's 65504 (inf as an MFMA operand) does
+                // not show in l by itself: bound l -- hence every probability -- by 2^15 (l >= 1 with the shift, see tile_first_max)
+                const bool bad = qvalid[t] && !(l_chk > (LP::kNeedsShift ? 0.015625f : 7.888609e-31f) && l_chk < (LP::kNeedsShift ? 32768.0f : 1.2676506e30f));
                 if (__any(bad)) {
                     exact[t] = true;
                     l_run[t] = 0.f;

@@ -216,10 +216,12 @@ def test_kv_resident_attention_variant_forced_everywhere(cuda):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
-def test_kv_resident_attention_survives_scores_that_overflow_exp2(cuda):
+@pytest.mark.parametrize("lp", [torch.bfloat16, torch.float16])
+def test_kv_resident_attention_survives_scores_that_overflow_exp2(cuda, lp):
     """The K/V-resident kernel (decoder cross attention: head_dim 64, transposed V, 512 keys, >= 1024 queries) computes P = exp2(s)
     without a running maximum and checks every denominator: a query whose scores exceed the exponent range must come out of the exact
-    running-maximum pass, its neighbours in other waves unaffected."""
+    running-maximum pass, its neighbours in other waves unaffected.  fp16: the max-free pass shifts every query by its best score against
+    the first key tile; the spiked queries overflow fp16 (or underflow everything else) and take the exact pass the same way."""
     from gvfdiffusion_amd.ops import dit_ops
     g = torch.Generator().manual_seed(11)
     Lq, Lk, H, D = 2048, 512, 2, 64
@@ -228,7 +230,7 @@ def test_kv_resident_attention_survives_scores_that_overflow_exp2(cuda):
     v = torch.randn((1, Lk, H, D), generator=g)
     q[0, 5] *= 400.0                                           # |s| ~ 400 * 8 / sqrt(64) * log2 e: exp2 overflows
     q[0, 1500, 1] *= -300.0
-    qb, kb, vb = (t.to(torch.bfloat16).to(cuda) for t in (q, k, v))
+    qb, kb, vb = (t.to(lp).to(cuda) for t in (q, k, v))
     vt = vb.permute(0, 2, 3, 1).contiguous()                   # [1][H][D][Lk]: keys contiguous
     out = torch.empty_like(qb)
     sq, sk = (Lq * H * D, 0, H * D, D), (Lk * H * D, 0, H * D, D)
@@ -237,4 +239,5 @@ def test_kv_resident_attention_survives_scores_that_overflow_exp2(cuda):
     ref = torch.einsum("bhlm,bmhd->blhd", torch.softmax(s, dim=-1), vb.float())
     assert torch.isfinite(out).all()
     err = (out.float() - ref).norm(dim=-1) / ref.norm(dim=-1).clamp_min(1e-6)
-    assert float(err[0, 5].max()) < 2e-2 and float(err[0, 1500].max()) < 2e-2 and float(err.max()) < 3e-2, (err[0, 5], err.max())
+    tol = 1.0 if lp == torch.bfloat16 else 0.15
+    assert float(err[0, 5].max()) < 2e-2 * tol and float(err[0, 1500].max()) < 2e-2 * tol and float(err.max()) < 3e-2 * tol, (err[0, 5], err.max())
