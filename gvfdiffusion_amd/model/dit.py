@@ -30,6 +30,9 @@ from ..ops import dit_ops, precision
 from .. import _lib
 
 
+_CAPTURE_LOCK = __import__("threading").Lock()      # hipGraph captures of DiT instances are serialised (see DiT._forward_graphed)
+
+
 class AbsolutePositionEmbedder(nn.Module):
     """(B, L, in_channels) positions -> (B, L, channels): per axis [sin(x f_i), cos(x f_i)], zero-padded
     (model/dit.py:16-56).  Step-invariant, evaluated once per condition set with torch device ops."""
@@ -413,12 +416,16 @@ class DiT(nn.Module):
         g = self._graph
         if g is None or g["key"] != key or not self._same_tensors(g["held"], conds):
             sx, st = x.clone(), t.clone()
-            # eager run first: builds the weight / condition caches and warms the allocator outside the capture
-            self._forward(sx, st, cond_images, static_latent, deformation_position_xyz)
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                sy = self._forward(sx, st, cond_images, static_latent, deformation_position_xyz)
+            # One capture at a time per process, and in thread-local capture mode: other host threads (another sample in flight on its own
+            # stream and DiT instance, utils/in_flight.py) keep launching and allocating while this one captures -- a new condition set (a new
+            # sample) means a new capture, so captures do happen inside the in-flight phase, not only in a serial warm-up.
+            with _CAPTURE_LOCK:
+                # eager run first: builds the weight / condition caches and warms the allocator outside the capture
+                self._forward(sx, st, cond_images, static_latent, deformation_position_xyz)
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    sy = self._forward(sx, st, cond_images, static_latent, deformation_position_xyz)
             g = self._graph = {"key": key, "held": (conds, tuple(self._key(c) for c in conds)), "graph": graph, "x": sx,
                                "t": st, "y": sy}
         g["x"].copy_(x)
