@@ -351,7 +351,7 @@ def bench_sharded_sampling(dev, dist, rank, world, P, S, T, total_batch=8, steps
     assert gathered.shape == (total, T, 3, S, S) and torch.equal(gathered[rank::world], local)
     ms_sample = sum(t_[0][0] for t_ in timings); ms_decode = sum(t_[0][1] for t_ in timings); ms_render = sum(t_[0][2] for t_ in timings)
     nfe = sum(t_[1] for t_ in timings)
-    t = torch.tensor([dt, ms_sample / max(nfe, 1), g0.elapsed_time(g1)], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt, ms_sample / max(nfe, 1), g0.elapsed_time(g1)], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt, ms_nfe, ms_gather = (float(v) for v in t.tolist())
     n_samples = total
@@ -491,7 +491,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", local % torch.cuda.device_count())      # (several ranks on one GPU only with GVF_BENCH_BACKEND=gloo: a test aid)
     torch.cuda.set_device(dev)
     dist = None
     # GVF_BENCH_FORCE_DIST=1: take the N > 1 code path (RCCL init, frame all-gather on the side stream, reductions) with a
@@ -508,8 +508,12 @@ def main():
         saved = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", device_id=dev)
-            warm = torch.zeros(1, device=dev)
+            backend = os.environ.get("GVF_BENCH_BACKEND", "nccl")       # "nccl" = RCCL over xGMI; "gloo": the N > 1 code path on a one-GPU box
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(backend)
+            warm = torch.zeros(1, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(warm)                      # forces communicator creation now
             torch.cuda.synchronize()
         finally:
@@ -584,6 +588,7 @@ def main():
     # ---- pass 1: serial and instrumented (per-stage HIP events inside the library): stage times, roofline, single-stream step time
     for i in range(a.warmup):
         step(i, 1)
+    final_gather(1, max(a.warmup, 1))               # first all-gather of the process: RCCL sets its channels up here, outside any timed region
     barrier()
     _lib.check(_lib.lib().gvf_rast_profile_enable(1), "profile_enable")
     t0 = time.perf_counter()
@@ -621,7 +626,7 @@ def main():
         k = (a.steps - 1) % n_slots
         assert got.shape == (world, F, 3, S, S) and torch.equal(got[rank], work.R.frames_to_uint8(slots[k].color))
 
-    t = torch.tensor([dt, dt_serial], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt, dt_serial], dtype=torch.float64, device=dev if (not multi or dist.get_backend() == "nccl") else "cpu")
     if multi:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt, dt_serial = float(t[0].item()), float(t[1].item())

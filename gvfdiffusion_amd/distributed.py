@@ -72,8 +72,14 @@ def gather_frames(local: torch.Tensor, total: Optional[int] = None, group=None, 
     block = local.contiguous()
     if n_local < per:
         block = torch.cat([block, block.new_zeros((per - n_local,) + tuple(local.shape[1:]))])
-    flat = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(flat, block, group=group)
+    if block.is_cuda and dist.get_backend(group) == "gloo":
+        # a gloo group over GPU tensors (two ranks sharing one GPU box in a test: RCCL refuses two ranks on one device): stage through the host
+        flat_h = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype)
+        dist.all_gather_into_tensor(flat_h, block.cpu(), group=group)
+        flat = flat_h.to(local.device)
+    else:
+        flat = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(flat, block, group=group)
     # flat is rank-major: [rank][local index j] holds global sample j * world + rank
     by_rank = flat.view((world, per) + tuple(local.shape[1:]))
     glob = by_rank.transpose(0, 1).reshape((per * world,) + tuple(local.shape[1:]))[:total]
