@@ -1,8 +1,9 @@
 """MultiHeadRMSNorm / MultiHeadAttention with the reference's constructor, parameter names and
 forward contract (model/attention/modules.py:8-15,63-146), computed by the gfx950 kernels:
 fp16 / bf16 MFMA projections (csrc/gemm.hip; the type: ops/precision.py) and flash attention with the QK-RMSNorm fused into its operand
-loads (csrc/attn.hip).  RoPE is not built: DiT passes use_rope=False to every block (model/dit.py:357-366) and the reference's
-RotaryPositionEmbedder does not broadcast against the dense (B, L, H, d) tensors this module would hand it (dead code upstream)."""
+loads (csrc/attn.hip).  RoPE is not built: DiT passes use_rope=(pe_mode == "rope") (model/dit.py:376; configs/diffusion.yml: "ape"), and the
+reference's RotaryPositionEmbedder cannot run on the dense (B, L, H, d) tensors this module would hand it -- its default indices index the
+HEAD axis and its (B, L, H * freq_dim) phases do not broadcast against the (B, L, H, d / 2) complex view (dead code upstream)."""
 from typing import *
 
 import torch
