@@ -85,6 +85,12 @@ struct RbParams {
     // straight into the tiled K / V^T images of csrc/attn_xt.hip (what gvf_attn_pack_kv_bf16 would build from the row-major copy)
     uint4* kt; uint4* vt; int kv_L, kv_tiles; float k_scale; const float* gamma_k;
     int kv_group_rows;                  // > 0: only the first kv_group_rows rows of every rows_per_group group hold keys (padded groups)
+    // temporal section (TEMPORAL kernels): between ln1 and the last projection the launch also runs
+    //     [q | k | v] = hb Wqkv^T + b;  o = softmax over a token's t_T frames (per head of 32);  x += t_gate * (o Wout^T + t_bout);  hb = LN(x) * t_ln
+    // on blocks of 48 / t_T TOKENS x t_T frames: local row r = tok * t_T + frame  <->  stream row  group * rpg + frame * t_N + (block * 48 / t_T + tok)
+    int t_T, t_N;
+    const float* t_bqkv; const float* t_gq; const float* t_gk; float t_kscale;
+    const float* t_bout; const float* t_gate; RbLn t_ln;
     long long* dbg;                              // RB_TIMING builds only: [workgroup][16] s_memtime stamps
 };
 
@@ -120,7 +126,9 @@ struct RbStream {
 // the weight fragments refilled in place D steps ahead.  g = index of the first step in the stream.  D: the stream is new to the L2 in
 // every launch (the DiT's weights are 100+ MB), so a refill is a miss to the Infinity Cache / HBM for the first workgroup of an XCD that
 // asks and a wait on that miss for the others: ~1 us, i.e. 4+ k-steps of MFMA work.
-template <int D, int DT>
+// SWAP: the activation fragment is the A operand -> D[m][n]: a lane ends up with 4 consecutive ROWS of one column (the V^T layout of the
+// temporal section); same fragments, same stream.
+template <int D, int DT, bool SWAP = false>
 __device__ __forceinline__ void rb_gemm(f32x4 (&acc)[3][RB_CT], typename GvfLp<DT>::x8 (&wf)[D][RB_CT], const uint4* act, int steps, int& g, const RbStream& st) {
     typedef typename GvfLp<DT>::x8 x8;
     static_assert(D % 2 == 0, "the activation fragments are double-buffered by step parity");
@@ -148,7 +156,7 @@ __device__ __forceinline__ void rb_gemm(f32x4 (&acc)[3][RB_CT], typename GvfLp<D
             for (int ct = 0; ct < RB_CT; ++ct) {
 #pragma unroll
                 for (int rt = 0; rt < 3; ++rt)
-                    acc[rt][ct] = GvfLp<DT>::mfma16(wf[b][ct], af[b & 1][rt], acc[rt][ct]);
+                    acc[rt][ct] = SWAP ? GvfLp<DT>::mfma16(af[b & 1][rt], wf[b][ct], acc[rt][ct]) : GvfLp<DT>::mfma16(wf[b][ct], af[b & 1][rt], acc[rt][ct]);
 #ifndef RB_ABL_NOW                 // timing experiment: no weight refills at all
                 wf[b][ct] = rb_ldw<DT>(sn + ct * 64);
 #endif
@@ -247,10 +255,11 @@ __device__ __forceinline__ void rb_layernorm(f32x4 (&v)[3][RB_CT], float* sRed, 
     }
 }
 
-template <bool MLP, int D, int DT>
+template <bool MLP, int D, int DT, bool TEMPORAL = false>
 __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
     typedef GvfLp<DT> LP;
     typedef typename LP::x8 x8;
+    static_assert(!(MLP && TEMPORAL), "the temporal section belongs to the launch between the spatial and the image attention");
     __shared__ uint4 smem[RB_SMEM];              // the ONE LDS object (a second one makes hipcc drain vmcnt before every ds_read)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, lq = lane >> 4;
     const int m0 = blockIdx.x * RB_BM;           // M % 48 == 0: no row guards anywhere
@@ -271,7 +280,20 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
     const int P3 = p.out3 != nullptr ? p.N3 / RB_C : 0;
     RbStream st;
     st.w = p.W + wave * (RB_CT * 64) + lane;
-    st.Gt = G1 + 2 * RB_KS * Pm + RB_KS * P3;
+    st.Gt = G1 + 2 * RB_KS * Pm + (TEMPORAL ? 4 * RB_KS : 0) + RB_KS * P3;
+    // local row r of this block <-> row of the stream.  TEMPORAL: the block owns 48 / T tokens x all T frames of its group (sample), local
+    // row = token * T + frame, so that a token's frames are neighbours (the keys of its attention) while the stream stays frame-major
+    const int t_T = TEMPORAL ? p.t_T : 1;
+    long long t_row0 = 0;
+    if (TEMPORAL) {
+        const int bpg = p.rpg / RB_BM, grp = blockIdx.x / bpg;
+        t_row0 = (long long)grp * p.rpg + (blockIdx.x - grp * bpg) * (RB_BM / t_T);
+    }
+    auto srow = [&](int r) -> long long {
+        if (!TEMPORAL) return m0 + r;
+        const int tok = r / t_T;
+        return t_row0 + (long long)(r - tok * t_T) * p.t_N + tok;
+    };
 
     // ---- prologue: everything the first k-steps and the epilogues need, issued back to back
     // phase-1 activations: LDS-DMA into fragment order; wave w stages k-steps w and w + 8 (3 row tiles each)
@@ -281,7 +303,7 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
         if (ks < G1) {
 #pragma unroll
             for (int rt = 0; rt < 3; ++rt)
-                rb_dma16(p.A + (long long)(m0 + 16 * rt + l15) * p.lda + ks * 32 + 8 * lq, &R1[(ks * 3 + rt) * 64]);
+                rb_dma16(p.A + srow(16 * rt + l15) * p.lda + ks * 32 + 8 * lq, &R1[(ks * 3 + rt) * 64]);
         }
     }
     x8 wf[D][RB_CT];
@@ -294,7 +316,7 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
     const int colw = wave * 64 + 4 * lq;        // this lane's first column inside column tile 0
     float* xr[3];                                // this lane's three rows of the stream, at its first column
 #pragma unroll
-    for (int rt = 0; rt < 3; ++rt) xr[rt] = p.x + (long long)m0 * RB_C + (16 * rt + l15) * RB_C + colw;
+    for (int rt = 0; rt < 3; ++rt) xr[rt] = p.x + srow(16 * rt + l15) * RB_C + colw;
     f32x4 rs[3][RB_CT];                              // residual tile of x (or of x_in: input_layer adds to the position embedding,
                                                      // [sample][N][512] broadcast over the frames -- no 25 MB copy to initialise the stream)
 #pragma unroll
@@ -323,15 +345,17 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
             sPar[RB_C + c] = p.gate1 ? vg : 1.0f;
             sPar[2 * RB_C + c] = (p.ln1.ln_w ? vw : 1.0f) * sc;
             sPar[3 * RB_C + c] = (p.ln1.ln_b ? vlb * sc : 0.f) + (p.ln1.scale ? vsh : 0.f);
-            if (MLP) {
-                const float ub = *(p.b_fc2 ? p.b_fc2 + c : dflt), ug = *(p.gate_m ? p.gate_m + mo : dflt), uw = *(p.ln2.ln_w ? p.ln2.ln_w + c : dflt);
-                const float ulb = *(p.ln2.ln_b ? p.ln2.ln_b + c : dflt), usc = *(p.ln2.scale ? p.ln2.scale + mo : dflt);
-                const float ush = *(p.ln2.shift ? p.ln2.shift + mo : dflt);
-                const float sc2 = p.ln2.scale ? 1.0f + usc : 1.0f;
-                sPar[4 * RB_C + c] = p.b_fc2 ? ub : 0.f;
-                sPar[5 * RB_C + c] = p.gate_m ? ug : 1.0f;
-                sPar[6 * RB_C + c] = (p.ln2.ln_w ? uw : 1.0f) * sc2;
-                sPar[7 * RB_C + c] = (p.ln2.ln_b ? ulb * sc2 : 0.f) + (p.ln2.scale ? ush : 0.f);
+            if (MLP || TEMPORAL) {             // the second update of the stream: the MLP's, or the temporal attention's to_out
+                const float* sb = TEMPORAL ? p.t_bout : p.b_fc2; const float* sg = TEMPORAL ? p.t_gate : p.gate_m;
+                const RbLn& ln = TEMPORAL ? p.t_ln : p.ln2;
+                const float ub = *(sb ? sb + c : dflt), ug = *(sg ? sg + mo : dflt), uw = *(ln.ln_w ? ln.ln_w + c : dflt);
+                const float ulb = *(ln.ln_b ? ln.ln_b + c : dflt), usc = *(ln.scale ? ln.scale + mo : dflt);
+                const float ush = *(ln.shift ? ln.shift + mo : dflt);
+                const float sc2 = ln.scale ? 1.0f + usc : 1.0f;
+                sPar[4 * RB_C + c] = sb ? ub : 0.f;
+                sPar[5 * RB_C + c] = sg ? ug : 1.0f;
+                sPar[6 * RB_C + c] = (ln.ln_w ? uw : 1.0f) * sc2;
+                sPar[7 * RB_C + c] = (ln.ln_b ? ulb * sc2 : 0.f) + (ln.scale ? ush : 0.f);
             }
         }
         // (a global load in an epilogue would be waited for IN ORDER behind the whole weight prefetch: every bias sits in LDS)
@@ -339,7 +363,8 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
 #pragma unroll
         for (int j = 0; j < RB_MAX_HIDDEN / RB_THREADS; ++j) {
             const int c = tid + RB_THREADS * j;
-            vf1[j] = *((MLP && p.b_fc1 && c < p.hidden) ? p.b_fc1 + c : p.x + tid);
+            if (TEMPORAL) vf1[j] = *(j < 3 ? (p.t_bqkv ? p.t_bqkv + c : p.x + tid) : (p.t_gq ? p.t_gq + tid : p.x + tid));      // [b_q | b_k | b_v | gamma_q]
+            else vf1[j] = *((MLP && p.b_fc1 && c < p.hidden) ? p.b_fc1 + c : p.x + tid);
         }
 #pragma unroll
         for (int j = 0; j < RB_MAX_N3 / RB_THREADS; ++j) {
@@ -348,11 +373,13 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
         }
 #pragma unroll
         for (int j = 0; j < RB_MAX_HIDDEN / RB_THREADS; ++j)
-            if (MLP) sPar[8 * RB_C + tid + RB_THREADS * j] = (p.b_fc1 && tid + RB_THREADS * j < p.hidden) ? vf1[j] : 0.f;
+            if (TEMPORAL) sPar[8 * RB_C + tid + RB_THREADS * j] = j < 3 ? (p.t_bqkv ? vf1[j] : 0.f) : (p.t_gq ? vf1[j] : 1.0f);
+            else if (MLP) sPar[8 * RB_C + tid + RB_THREADS * j] = (p.b_fc1 && tid + RB_THREADS * j < p.hidden) ? vf1[j] : 0.f;
 #pragma unroll
         for (int j = 0; j < RB_MAX_N3 / RB_THREADS; ++j)
             sPar[8 * RB_C + RB_MAX_HIDDEN + tid + RB_THREADS * j] = (p.b3 && tid + RB_THREADS * j < P3 * RB_C) ? vb3[j] : 0.f;
-        if (p.kt != nullptr) sPar[8 * RB_C + RB_MAX_HIDDEN + RB_MAX_N3 + tid] = p.gamma_k ? p.gamma_k[tid] : 1.0f;
+        if (TEMPORAL) sPar[8 * RB_C + RB_MAX_HIDDEN + RB_MAX_N3 + tid] = p.t_gk ? p.t_gk[tid] : 1.0f;
+        else if (p.kt != nullptr) sPar[8 * RB_C + RB_MAX_HIDDEN + RB_MAX_N3 + tid] = p.gamma_k ? p.gamma_k[tid] : 1.0f;
     }
     if (p.in_x != nullptr) {
         // input_layer in fp32 on the plain ALUs (16 input channels: 0.4 MFLOP per workgroup): W_in^T [Cin][512] and the block's 48 input rows
@@ -419,8 +446,8 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
             for (int i = 0; i < 4; ++i) v[i] = rs[rt][ct][i] + g4[i] * (acc[rt][ct][i] + b4[i]);
             acc[rt][ct] = v;                     // LayerNorm works on (and overwrites) this copy;
             rs[rt][ct] = v;                      // the store reads this one: overwriting a register a store in flight still has to read
-            if (!MLP) *reinterpret_cast<f32x4*>(xr[rt] + 16 * ct) = rs[rt][ct];      // means waiting for it, in order, behind the weight prefetch.
-                                                 // (MLP: the stream is written once, after the MLP)
+            if (!MLP && !TEMPORAL) *reinterpret_cast<f32x4*>(xr[rt] + 16 * ct) = rs[rt][ct];      // means waiting for it, in order, behind the weight prefetch.
+                                                 // (MLP / TEMPORAL: the stream is written once, after the second update)
         }
     }
     RB_STAMP();
@@ -428,6 +455,147 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
     rb_layernorm<DT>(acc, sRed, sPar + 2 * RB_C, sPar + 3 * RB_C, p.eps, R0, MLP ? nullptr : hb_rows, wave, lane, lq, l15, colw);
 
     RB_STAMP();
+    if (TEMPORAL) {
+        // ---- temporal self attention of the block's tokens, in registers.  hb (R0) -> q, k (normal accumulator layout: lane (l15, lq)
+        // holds row 16 rt + l15, columns 4 lq .. + 4 of a column tile) and v (SWAPPED MFMA operands: lane holds rows 16 rt + 4 lq .. + 4
+        // of column l15, i.e. the V^T operand of P V).  Wave w owns columns [64 w, 64 w + 64) = heads 2 w and 2 w + 1, so scores,
+        // softmax and P V need nothing from another wave; only the output goes through LDS (R1), as the A operand of to_out.
+        // Same rounding points as the unfused chain (to_qkv -> 16-bit, csrc/attn.hip's attn_small_kernel): q, k, v rounded to 16 bit,
+        // MultiHeadRMSNorm in fp32 on the rounded values, scores and the row sum in fp32, P rounded for the MFMA.
+        const float* tb = sPar + 8 * RB_C;                    // [b_q | b_k | b_v | gamma_q]
+        const float* tgk = sPar + 8 * RB_C + RB_MAX_HIDDEN + RB_MAX_N3;
+        const bool rms = p.t_gq != nullptr;
+        uint4 qop[3][2], kop[3][2];                           // [row tile][head of the wave]: the 16 x 16 x 32 operand of (rows, head dims)
+        auto qk_pass = [&](uint4 (&op)[3][2], const float* bias, const float* gam) {
+            rb_zero(acc);
+            rb_gemm<D, DT>(acc, wf, R0 + lane, RB_KS, g, st);
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                f32x4 b4[2], g4[2];
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) {
+                    b4[c2] = *reinterpret_cast<const f32x4*>(bias + colw + 16 * (2 * hh + c2));
+                    g4[c2] = *reinterpret_cast<const f32x4*>(gam + colw + 16 * (2 * hh + c2));
+                }
+#pragma unroll
+                for (int rt = 0; rt < 3; ++rt) {
+                    // contraction slot e of the lane <-> head dim 16 (e >> 2) + 4 lq + (e & 3): any bijection, the same for q and k
+                    float f[8], ss = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        f[e] = LP::from16(LP::to16(acc[rt][2 * hh + (e >> 2)][e & 3] + b4[e >> 2][e & 3]));
+                        ss += f[e] * f[e];
+                    }
+                    if (rms) {
+                        ss += __shfl_xor(ss, 16, 64);
+                        ss += __shfl_xor(ss, 32, 64);
+                        const float inv = 5.656854249492381f / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] = f[e] * inv * g4[e >> 2][e & 3];
+                    }
+                    op[rt][hh] = make_uint4(LP::pack(f[0], f[1]), LP::pack(f[2], f[3]), LP::pack(f[4], f[5]), LP::pack(f[6], f[7]));
+                }
+            }
+        };
+        rb_lds_barrier();                                     // the normalised rows are complete in R0
+        qk_pass(qop, tb, tb + 3 * RB_C);
+        qk_pass(kop, tb + RB_C, tgk);
+        // S^T tile (rk, rq) = K_rk Q_rq^T: lane (l15, lq) holds query row 16 rq + l15 against key rows 16 rk + 4 lq .. + 4.  A key counts
+        // iff it is a frame of the query's token.
+        unsigned same_tok[3];                                 // bit 4 rk + i
+        {
+            int tk[3][4];
+#pragma unroll
+            for (int rk = 0; rk < 3; ++rk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) tk[rk][i] = (16 * rk + 4 * lq + i) / t_T;
+#pragma unroll
+            for (int rq = 0; rq < 3; ++rq) {
+                const int tq = (16 * rq + l15) / t_T;
+                unsigned mm = 0;
+#pragma unroll
+                for (int rk = 0; rk < 3; ++rk)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) mm |= (tk[rk][i] == tq ? 1u : 0u) << (4 * rk + i);
+                same_tok[rq] = mm;
+            }
+        }
+        uint2 ppk[2][3][3];                                   // [head][rq][rk]: the probabilities, 16 bit
+        float linv[2][3];
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+            for (int rq = 0; rq < 3; ++rq) {
+                f32x4 sc[3];
+                float m = -INFINITY;
+#pragma unroll
+                for (int rk = 0; rk < 3; ++rk) {
+                    sc[rk] = LP::mfma16(__builtin_bit_cast(x8, kop[rk][hh]), __builtin_bit_cast(x8, qop[rq][hh]), zero4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (!((same_tok[rq] >> (4 * rk + i)) & 1u)) sc[rk][i] = -INFINITY;
+                        m = fmaxf(m, sc[rk][i]);
+                    }
+                }
+                m = fmaxf(m, __shfl_xor(m, 16, 64));
+                m = fmaxf(m, __shfl_xor(m, 32, 64));            // finite: the query's own row is one of its keys
+                const float ms = m * p.t_kscale;
+                float l = 0.f;
+#pragma unroll
+                for (int rk = 0; rk < 3; ++rk) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { sc[rk][i] = exp2f(sc[rk][i] * p.t_kscale - ms); l += sc[rk][i]; }
+                    ppk[hh][rq][rk] = make_uint2(LP::pack(sc[rk][0], sc[rk][1]), LP::pack(sc[rk][2], sc[rk][3]));
+                }
+                l += __shfl_xor(l, 16, 64);
+                l += __shfl_xor(l, 32, 64);
+                linv[hh][rq] = 1.0f / l;
+            }
+        }
+        // v, transposed by the MFMA itself
+        rb_zero(acc);
+        rb_gemm<D, DT, true>(acc, wf, R0 + lane, RB_KS, g, st);
+        uint2* fb1 = rb_frag_base(R1, wave, lq, l15);
+#pragma unroll
+        for (int ct = 0; ct < RB_CT; ++ct) {
+            const float bv = tb[2 * RB_C + wave * 64 + 16 * ct + l15];
+            uint2 vp[3];
+#pragma unroll
+            for (int rt = 0; rt < 3; ++rt)
+                vp[rt] = make_uint2(LP::pack(acc[rt][ct][0] + bv, acc[rt][ct][1] + bv), LP::pack(acc[rt][ct][2] + bv, acc[rt][ct][3] + bv));
+            // O^T = V^T P^T: contraction slots 0..3 <-> keys 4 lq .. + 4 of one 16-row tile, 4..7 of another (the third pairs with zeros)
+            const x8 v01 = __builtin_bit_cast(x8, make_uint4(vp[0].x, vp[0].y, vp[1].x, vp[1].y));
+            const x8 v2z = __builtin_bit_cast(x8, make_uint4(vp[2].x, vp[2].y, 0u, 0u));
+#pragma unroll
+            for (int rq = 0; rq < 3; ++rq) {
+                const uint2 (&pp)[3] = ppk[ct >> 1][rq];
+                f32x4 o = LP::mfma16(v01, __builtin_bit_cast(x8, make_uint4(pp[0].x, pp[0].y, pp[1].x, pp[1].y)), zero4);
+                o = LP::mfma16(v2z, __builtin_bit_cast(x8, make_uint4(pp[2].x, pp[2].y, 0u, 0u)), o);
+                const float li = linv[ct >> 1][rq];
+                rb_put_frag(fb1, ct, rq, make_uint2(LP::pack(o[0] * li, o[1] * li), LP::pack(o[2] * li, o[3] * li)));
+            }
+        }
+        rb_lds_barrier();                                     // the attention output is complete in R1
+        // ---- x += t_gate * (o Wout^T + t_bout), LayerNorm t_ln -> R0
+        rb_zero(acc);
+        rb_gemm<D, DT>(acc, wf, R1 + lane, RB_KS, g, st);
+#pragma unroll
+        for (int ct = 0; ct < RB_CT; ++ct) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(sPar + 4 * RB_C + colw + 16 * ct);
+            const f32x4 g4 = *reinterpret_cast<const f32x4*>(sPar + 5 * RB_C + colw + 16 * ct);
+#pragma unroll
+            for (int rt = 0; rt < 3; ++rt) {
+                f32x4 v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = rs[rt][ct][i] + g4[i] * (acc[rt][ct][i] + b4[i]);
+                acc[rt][ct] = v;
+                rs[rt][ct] = v;
+                *reinterpret_cast<f32x4*>(xr[rt] + 16 * ct) = rs[rt][ct];
+            }
+        }
+        rb_layernorm<DT>(acc, sRed, sPar + 6 * RB_C, sPar + 7 * RB_C, p.eps, R0, nullptr, wave, lane, lq, l15, colw);
+    }
     if (MLP) {
         // ---- MLP: per 512 hidden units  h = gelu(R0 Wfc1[slice]^T + b) -> R1 (bf16 fragments);  acc2 += R1 Wfc2[:, slice]^T
         f32x4 acc2[3][RB_CT];
@@ -574,7 +742,7 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
 #ifdef RB_ABL_NOSTORE3
                 if (p.M < 0)
 #endif
-                *reinterpret_cast<uint4*>(p.out3 + (long long)(m0 + r) * ldo + pass * RB_C + 8 * lane) = v;
+                *reinterpret_cast<uint4*>(p.out3 + srow(r) * ldo + pass * RB_C + 8 * lane) = v;
             }
         }
         RB_STAMP();
@@ -632,7 +800,9 @@ extern "C" int gvf_rowblock_args_layout(int32_t* out, int n) {
     const int v[] = {(int)sizeof(gvf_rowblock_args), (int)offsetof(gvf_rowblock_args, x), (int)offsetof(gvf_rowblock_args, in_x), (int)offsetof(gvf_rowblock_args, gate1),
                      (int)offsetof(gvf_rowblock_args, mod_ld), (int)offsetof(gvf_rowblock_args, b_fc1), (int)offsetof(gvf_rowblock_args, ln2),
                      (int)offsetof(gvf_rowblock_args, b3), (int)offsetof(gvf_rowblock_args, hb_out), (int)offsetof(gvf_rowblock_args, k_tiles),
-                     (int)offsetof(gvf_rowblock_args, gamma_k), (int)offsetof(gvf_rowblock_args, kv_group_rows), (int)offsetof(gvf_rowblock_args, dtype)};
+                     (int)offsetof(gvf_rowblock_args, gamma_k), (int)offsetof(gvf_rowblock_args, kv_group_rows), (int)offsetof(gvf_rowblock_args, dtype),
+                     (int)offsetof(gvf_rowblock_args, t_frames), (int)offsetof(gvf_rowblock_args, t_b_qkv), (int)offsetof(gvf_rowblock_args, t_scale),
+                     (int)offsetof(gvf_rowblock_args, t_ln)};
     const int m = (int)(sizeof(v) / sizeof(v[0]));
     for (int i = 0; i < n && i < m; ++i) out[i] = v[i];
     return m;
@@ -704,6 +874,16 @@ static int rowblock_launch(const gvf_rowblock_args* a, int dtype, void* stream_)
     if ((((uintptr_t)a->a) & 15) || (((uintptr_t)a->w) & 15) || (((uintptr_t)a->x) & 15) || (((uintptr_t)a->out3) & 7) ||
         (((uintptr_t)a->hb_out) & 7) || (((uintptr_t)a->b3) & 15))
         return GVF_EINVAL;
+    const bool temporal = a->t_frames != 0;
+    if (temporal) {
+        // blocks of 48 / T tokens x T frames inside a group of T * t_stride rows; one stream: W1 | to_qkv | to_out | W3
+        if (a->t_frames < 0 || RB_BM % a->t_frames != 0 || a->t_stride <= 0 || a->t_stride % (RB_BM / a->t_frames) != 0) return GVF_EINVAL;
+        if (a->rows_per_group != a->t_frames * a->t_stride || a->M % a->rows_per_group != 0) return GVF_EINVAL;
+        if (mlp || a->K1 == 0 || a->in_x != nullptr || a->x_in != nullptr || a->k_tiles != nullptr || a->hb_out != nullptr || a->N3 == 0) return GVF_EINVAL;
+        if ((a->t_gamma_q == nullptr) != (a->t_gamma_k == nullptr) || !(a->t_scale > 0.f)) return GVF_EINVAL;
+        if (((a->t_ln.ln_w == nullptr) != (a->t_ln.ln_b == nullptr)) || ((a->t_ln.shift == nullptr) != (a->t_ln.scale == nullptr))) return GVF_EINVAL;
+        if ((a->t_gate != nullptr || a->t_ln.scale != nullptr) && a->mod_ld < RB_C) return GVF_EINVAL;
+    }
     RbParams p;
     p.A = (const unsigned short*)a->a; p.lda = a->lda; p.K1 = a->K1;
     p.W = (const uint4*)a->w; p.b1 = a->b1;
@@ -712,18 +892,23 @@ static int rowblock_launch(const gvf_rowblock_args* a, int dtype, void* stream_)
     p.in_x = a->in_x; p.in_wt = a->in_wt; p.in_b = a->in_b; p.in_cin = a->in_cin;
     p.gate1 = a->gate1;
     p.ln1 = RbLn{a->ln1.ln_w, a->ln1.ln_b, a->ln1.shift, a->ln1.scale};
-    p.mod_ld = a->mod_ld; p.rpg = (grouped || a->x_in != nullptr || a->kv_group_rows > 0) ? a->rows_per_group : 0; p.eps = a->eps;
+    p.mod_ld = a->mod_ld; p.rpg = (grouped || temporal || a->x_in != nullptr || a->kv_group_rows > 0) ? a->rows_per_group : 0; p.eps = a->eps;
     p.b_fc1 = a->b_fc1; p.b_fc2 = a->b_fc2; p.hidden = a->hidden; p.gate_m = a->gate_m;
     p.ln2 = RbLn{a->ln2.ln_w, a->ln2.ln_b, a->ln2.shift, a->ln2.scale};
     p.b3 = a->b3; p.out3 = a->N3 != 0 ? (unsigned short*)a->out3 : nullptr; p.N3 = a->N3;
     p.hb_out = (unsigned short*)a->hb_out;
     p.kt = (uint4*)a->k_tiles; p.vt = (uint4*)a->v_tiles; p.kv_L = a->kv_L; p.kv_tiles = a->kv_L / 64; p.k_scale = a->k_scale; p.gamma_k = a->gamma_k;
     p.kv_group_rows = a->kv_group_rows;
+    p.t_T = a->t_frames; p.t_N = a->t_stride;
+    p.t_bqkv = a->t_b_qkv; p.t_gq = a->t_gamma_q; p.t_gk = a->t_gamma_k; p.t_kscale = a->t_scale * 1.4426950408889634f;
+    p.t_bout = a->t_b_out; p.t_gate = a->t_gate;
+    p.t_ln = RbLn{a->t_ln.ln_w, a->t_ln.ln_b, a->t_ln.shift, a->t_ln.scale};
     p.dbg = g_rb_dbg;
     (void)hipGetLastError();
     const dim3 grid((unsigned)(a->M / RB_BM)), block(RB_THREADS);
     GVF_LP_DISPATCH(dtype,
         if (mlp) rowblock_kernel<true, RB_DEPTH_MLP, DT><<<grid, block, 0, (hipStream_t)stream_>>>(p);
+        else if (temporal) rowblock_kernel<false, RB_DEPTH, DT, true><<<grid, block, 0, (hipStream_t)stream_>>>(p);
         else rowblock_kernel<false, RB_DEPTH, DT><<<grid, block, 0, (hipStream_t)stream_>>>(p));
     GVF_CHECK_LAUNCH();
     return GVF_OK;

@@ -190,6 +190,9 @@ class DiT(nn.Module):
         # one launch per sub-layer boundary (csrc/rowblock.hip) where the shapes allow it: 0 = the unfused GEMM / LayerNorm launches
         self.use_rowblock = int(os.environ.get("GVF_DIT_ROWBLOCK", "1")) != 0
         self.rowblock_tiled_kv = int(os.environ.get("GVF_DIT_TILED_KV", "1")) != 0    # to_qkv's launch writes the attention's K / V^T tiles itself
+        # the temporal self attention runs INSIDE the row-block launch between the spatial and the image attention (T | 48): 7 launches per
+        # block instead of 9, the qkv / attention-output buffers of the temporal sub-layer never exist
+        self.rowblock_temporal = int(os.environ.get("GVF_DIT_TEMPORAL_FUSED", "1")) != 0
         self._graph = None
         self.capture_blocks = None     # diagnostics: a list -> _blocks_rowblock appends a copy of the fp32 stream after every block
 
@@ -307,6 +310,8 @@ class DiT(nn.Module):
             else:
                 d["s2"] = P(b["spatial_self_attn"]["out"][0], w3=b["temporal_self_attn"]["qkv"][0])
                 d["s3"] = P(b["temporal_self_attn"]["out"][0], w3=b["image_cross_attn"]["q"][0])
+                d["s23"] = P(b["spatial_self_attn"]["out"][0], temporal=(b["temporal_self_attn"]["qkv"][0], b["temporal_self_attn"]["out"][0]),
+                             w3=b["image_cross_attn"]["q"][0])
             d["s4"] = P(b["image_cross_attn"]["out"][0], w3=b["static_cross_attn"]["q"][0])
             d["s5"] = P(b["static_cross_attn"]["out"][0], mlp=(b["fc1"][0], b["fc2"][0]), w3=nxt)
             rb["blocks"].append(d)
@@ -609,6 +614,8 @@ class DiT(nn.Module):
         # to_qkv of the spatial self attention: with whole 64-key tiles per frame its launch writes q row-major and K / V^T directly as the
         # tiled images the attention kernel stages (no row-major k, v; no pack launch)
         tiled_kv = N % 64 == 0 and self.rowblock_tiled_kv
+        R = dit_ops.ROWBLOCK_ROWS
+        temporal_fused = self.rowblock_temporal and not self.no_temporal_attn and not padded and R % T == 0 and N % (R // T) == 0
         qs = torch.empty((M, C), dtype=bf, device=dev) if tiled_kv else None
 
         def qkv_out(blk):
@@ -646,10 +653,14 @@ class DiT(nn.Module):
             else:
                 sh_t, sc_t, g_t = (mview(o + (6 + k) * C) for k in range(3))
                 at = b["temporal_self_attn"]
-                fused(ab, s["s2"], b1=a["out"][1], gate1=g_s, ln1=dict(shift=sh_t, scale=sc_t), out3=qkv, b3=at["qkv"][1])
-                st = (TNp * 3 * C, 3 * C, N * 3 * C)          # outer = sample, inner = token, seq = frame
-                dit_ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], ab, B, N, T, T, H, st, st, st, (TNp * C, C, N * C), at["gq"], at["gk"])
-                fused(ab, s["s3"], b1=at["out"][1], gate1=g_t, ln1=n3, out3=qb, b3=ai["q"][1])
+                if temporal_fused:
+                    fused(ab, s["s23"], b1=a["out"][1], gate1=g_s, ln1=dict(shift=sh_t, scale=sc_t), out3=qb, b3=ai["q"][1],
+                          temporal=dict(frames=T, stride=N, b_qkv=at["qkv"][1], gamma_q=at["gq"], gamma_k=at["gk"], b_out=at["out"][1], gate=g_t, ln=n3))
+                else:
+                    fused(ab, s["s2"], b1=a["out"][1], gate1=g_s, ln1=dict(shift=sh_t, scale=sc_t), out3=qkv, b3=at["qkv"][1])
+                    st = (TNp * 3 * C, 3 * C, N * 3 * C)          # outer = sample, inner = token, seq = frame
+                    dit_ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], ab, B, N, T, T, H, st, st, st, (TNp * C, C, N * C), at["gq"], at["gk"])
+                    fused(ab, s["s3"], b1=at["out"][1], gate1=g_t, ln1=n3, out3=qb, b3=ai["q"][1])
             kt, vt = ctx["kv_img"][i]
             dit_ops.attention_tiled(qb, kt, vt, hb, *fr["n"], N, Li, H, fr["c"], fr["c"], *fr["kv"], gamma_q=ai["gq"])
             ast = b["static_cross_attn"]

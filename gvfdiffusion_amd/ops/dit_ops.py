@@ -50,7 +50,10 @@ class RowblockArgs(ctypes.Structure):
                 ("b3", _vp), ("out3", _vp), ("N3", ctypes.c_int32), ("epi3", ctypes.c_int32),
                 ("hb_out", _vp),
                 ("k_tiles", _vp), ("v_tiles", _vp), ("kv_L", ctypes.c_int32), ("k_scale", _f), ("gamma_k", _vp),
-                ("kv_group_rows", ctypes.c_int32), ("dtype", ctypes.c_int32)]
+                ("kv_group_rows", ctypes.c_int32), ("dtype", ctypes.c_int32),
+                ("t_frames", ctypes.c_int32), ("t_stride", ctypes.c_int32),
+                ("t_b_qkv", _vp), ("t_gamma_q", _vp), ("t_gamma_k", _vp), ("t_scale", _f),
+                ("t_b_out", _vp), ("t_gate", _vp), ("t_ln", RowblockLn)]
 
 
 _lib.register({
@@ -229,17 +232,23 @@ def rowblock_padded_rows(rows: int) -> int:
     return (rows + ROWBLOCK_ROWS - 1) // ROWBLOCK_ROWS * ROWBLOCK_ROWS
 
 
-def rowblock_pack_stream(w1, mlp=None, w3=None):
+def rowblock_pack_stream(w1, mlp=None, w3=None, temporal=None):
     """One weight stream for gvf_rowblock_fused: w1 = nn.Linear weight bf16 / fp16 [512][K1 padded to 128] (see cast_pad), mlp =
     (mlp.0 weight [hidden][512], mlp.2 weight [512][hidden]) or None, w3 = [N3][512] or None, all of ONE 16-bit type (the packers move 16-bit
-    words: the stream has the type of its sources, which the launch must be told: rowblock_fused(dtype=...)).  Returns a uint8 tensor."""
+    words: the stream has the type of its sources, which the launch must be told: rowblock_fused(dtype=...)).  temporal = (to_qkv weight
+    [1536][512], to_out weight [512][512]) of the temporal section (instead of mlp).  Returns a uint8 tensor."""
     L = _lib.lib()
     ref = w1 if w1 is not None else (w3 if w3 is not None else mlp[0])
     _lib.require_cuda(ref)
     if w1 is not None:
         assert w1.dtype in LP_DTYPES and w1.shape[0] == ROWBLOCK_C and w1.shape[1] % ROWBLOCK_KPAD == 0 and w1.is_contiguous()
     sizes = [0 if w1 is None else int(L.gvf_rowblock_packed_bytes(ROWBLOCK_C, w1.shape[1]))]
-    sizes.append(0 if mlp is None else 2 * mlp[0].shape[0] * ROWBLOCK_C * 2)
+    assert mlp is None or temporal is None
+    if temporal is not None:
+        tq, to = temporal
+        assert tq.dtype == to.dtype and tq.dtype in LP_DTYPES and tq.is_contiguous() and to.is_contiguous()
+        assert tuple(tq.shape) == (3 * ROWBLOCK_C, ROWBLOCK_C) and tuple(to.shape) == (ROWBLOCK_C, ROWBLOCK_C)
+    sizes.append((0 if temporal is None else 4 * ROWBLOCK_C * ROWBLOCK_C * 2) if mlp is None else 2 * mlp[0].shape[0] * ROWBLOCK_C * 2)
     sizes.append(0 if w3 is None else int(L.gvf_rowblock_packed_bytes(w3.shape[0], ROWBLOCK_C)))
     out = torch.empty(sum(sizes), dtype=torch.uint8, device=ref.device)
     st = _stream(ref)
@@ -250,6 +259,10 @@ def rowblock_pack_stream(w1, mlp=None, w3=None):
         assert f1.dtype == f2.dtype and f1.dtype in LP_DTYPES and f1.is_contiguous() and f2.is_contiguous()
         assert f1.shape == (f2.shape[1], ROWBLOCK_C) and f2.shape[0] == ROWBLOCK_C
         _lib.check(L.gvf_rowblock_pack_mlp(_p(f1), _p(f2), f1.shape[0], _p(out[sizes[0]:]), st), "gvf_rowblock_pack_mlp")
+    if temporal is not None:
+        _lib.check(L.gvf_rowblock_pack_weight(_p(tq), tq.stride(0), 3 * ROWBLOCK_C, ROWBLOCK_C, _p(out[sizes[0]:]), st), "gvf_rowblock_pack_weight")
+        _lib.check(L.gvf_rowblock_pack_weight(_p(to), to.stride(0), ROWBLOCK_C, ROWBLOCK_C, _p(out[sizes[0] + 3 * ROWBLOCK_C * ROWBLOCK_C * 2:]), st),
+                   "gvf_rowblock_pack_weight")
     if w3 is not None:
         assert w3.dtype in LP_DTYPES and w3.shape[1] == ROWBLOCK_C and w3.is_contiguous() and w3.shape[0] % ROWBLOCK_C == 0
         _lib.check(L.gvf_rowblock_pack_weight(_p(w3), w3.stride(0), w3.shape[0], ROWBLOCK_C, _p(out[sizes[0] + sizes[1]:]), st),
@@ -268,11 +281,13 @@ def _ln_struct(ln):
 
 def rowblock_fused(a, stream_w, x, b1=None, gate1=None, ln1=None, mod_ld=0, rows_per_group=0, eps=1e-6,
                    mlp_bias=None, hidden=0, gate_m=None, ln2=None, b3=None, out3=None, hb_out=None, x_in=None, x_in_period=0, kv_tiles=None, kv_L=0, gamma_k=None, kv_scale=None, in_x=None, in_wt=None, in_b=None, kv_group_rows=0,
-                   dtype=None):
+                   dtype=None, temporal=None):
     """x += gate1 * (a W1^T + b1); hb = LN1(x); [x += gate_m * MLP(hb); hb = LN2(x)]; out3 = hb W3^T + b3 or hb_out = hb -- ONE launch
     (csrc/rowblock.hip; include/gvf_dit.h).  ln1 / ln2: dict with ln_w, ln_b and / or shift, scale.  mlp_bias = (b_fc1, b_fc2).
     a = None: no closing projection (x already holds the sub-layer's result; the stream has no W1 segment).
-    x_in (f32 [groups * x_in_period][C]): the residual is read from it, broadcast with period x_in_period inside a row group, and x is only written."""
+    x_in (f32 [groups * x_in_period][C]): the residual is read from it, broadcast with period x_in_period inside a row group, and x is only written.
+    temporal = dict(frames=T, stride=N, b_qkv, gamma_q, gamma_k, b_out, gate, ln[, scale]): the temporal self attention of the block
+    between LN1 and the last projection (see include/gvf_dit.h; rows_per_group must be T * N)."""
     _lib.require_cuda(stream_w, x)
     assert x.dtype == torch.float32 and x.is_contiguous()
     M, C = x.shape
@@ -319,6 +334,12 @@ def rowblock_fused(a, stream_w, x, b1=None, gate1=None, ln1=None, mod_ld=0, rows
     if hb_out is not None:
         assert hb_out.is_contiguous() and tuple(hb_out.shape) == (M, C)
         args.hb_out = _pi(hb_out)
+    if temporal is not None:
+        t = temporal
+        args.t_frames, args.t_stride = int(t["frames"]), int(t["stride"])
+        args.t_b_qkv, args.t_gamma_q, args.t_gamma_k = _pi(t.get("b_qkv")), _pi(t.get("gamma_q")), _pi(t.get("gamma_k"))
+        args.t_scale = float(t.get("scale") or 32 ** -0.5)
+        args.t_b_out, args.t_gate, args.t_ln = _pi(t.get("b_out")), _pi(t.get("gate")), _ln_struct(t.get("ln"))
     _lib.check(_lib.lib().gvf_rowblock_fused(ctypes.byref(args), _stream(x)), "gvf_rowblock_fused")
     return x
 

@@ -114,9 +114,20 @@ typedef struct gvf_rowblock_args {
     void* k_tiles; void* v_tiles; int32_t kv_L; float k_scale; const float* gamma_k;
     int32_t kv_group_rows;
     int32_t dtype;                             /* GVF_DT_BF16 / GVF_DT_F16: type of a, the packed weights, out3, hb_out and the K / V^T tiles */
+    /* optional temporal section, t_frames > 0 (no MLP section, K1 > 0, N3 > 0): the launch also runs the block's temporal self attention
+       (model/dit.py:255-261 -> model/attention/modules.py:119-140, heads of 32) between ln1 and the last projection:
+           hb = ln1(x);  [q | k | v] = hb Wqkv^T + t_b_qkv;  o = softmax_frames(rms(q) rms(k)^T * t_scale) v  per token and head;
+           x += t_gate * (o Wout^T + t_b_out);  hb = t_ln(x);  out3 = hb W3^T + b3
+       with the weight stream W1 | Wqkv (3 passes of 512) | Wout | W3.  A token's frames are rows t_stride apart inside a group of
+       rows_per_group = t_frames * t_stride rows (the frame-major stream (B, T, N, C) with t_stride = N); a workgroup owns 48 / t_frames
+       tokens, so t_frames must divide 48 and 48 / t_frames must divide t_stride.  t_gamma_q / t_gamma_k: MultiHeadRMSNorm gains f32 [512]
+       (both or neither). */
+    int32_t t_frames; int32_t t_stride;
+    const float* t_b_qkv; const float* t_gamma_q; const float* t_gamma_k; float t_scale;
+    const float* t_b_out; const float* t_gate; gvf_rowblock_ln t_ln;
 } gvf_rowblock_args;
 /* layout of gvf_rowblock_args as compiled: {sizeof, offsetof x, in_x, gate1, mod_ld, b_fc1, ln2, b3, hb_out, k_tiles, gamma_k, kv_group_rows,
-   dtype}; returns the count */
+   dtype, t_frames, t_b_qkv, t_scale, t_ln}; returns the count */
 int gvf_rowblock_args_layout(int32_t* out, int n);
 int64_t gvf_rowblock_packed_bytes(int N, int K);
 int gvf_rowblock_pack_weight(const void* w_bf16, int ldw, int N, int K, void* packed, void* stream);

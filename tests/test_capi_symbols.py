@@ -51,10 +51,11 @@ def test_rowblock_argument_struct_layout_matches_the_library():
     from gvfdiffusion_amd import _lib
     from gvfdiffusion_amd.ops import dit_ops
     l = _lib.lib()
-    buf = (ctypes.c_int32 * 16)()
-    n = l.gvf_rowblock_args_layout(buf, 16)
+    buf = (ctypes.c_int32 * 32)()
+    n = l.gvf_rowblock_args_layout(buf, 32)
     A = dit_ops.RowblockArgs
-    mine = [ctypes.sizeof(A)] + [getattr(A, f).offset for f in ("x", "in_x", "gate1", "mod_ld", "b_fc1", "ln2", "b3", "hb_out", "k_tiles", "gamma_k", "kv_group_rows", "dtype")]
+    mine = [ctypes.sizeof(A)] + [getattr(A, f).offset for f in ("x", "in_x", "gate1", "mod_ld", "b_fc1", "ln2", "b3", "hb_out", "k_tiles", "gamma_k", "kv_group_rows", "dtype",
+                                                                       "t_frames", "t_b_qkv", "t_scale", "t_ln")]
     assert n == len(mine) and list(buf[:n]) == mine
     assert l.gvf_rowblock_fused_bf16(None, None) == _lib.GVF_EINVAL
     a = A()
