@@ -283,16 +283,20 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
     st.Gt = G1 + 2 * RB_KS * Pm + (TEMPORAL ? 4 * RB_KS : 0) + RB_KS * P3;
     // local row r of this block <-> row of the stream.  TEMPORAL: the block owns 48 / T tokens x all T frames of its group (sample), local
     // row = token * T + frame, so that a token's frames are neighbours (the keys of its attention) while the stream stays frame-major
+    // A group whose token count is not a multiple of 48 / T ends with phantom tokens: their T rows each are the group's padding rows
+    // (behind its T * t_N token rows), computed like any other row and read by nobody.
     const int t_T = TEMPORAL ? p.t_T : 1;
-    long long t_row0 = 0;
+    long long t_grp0 = 0;
+    int t_tok0 = 0;
     if (TEMPORAL) {
         const int bpg = p.rpg / RB_BM, grp = blockIdx.x / bpg;
-        t_row0 = (long long)grp * p.rpg + (blockIdx.x - grp * bpg) * (RB_BM / t_T);
+        t_grp0 = (long long)grp * p.rpg;
+        t_tok0 = (blockIdx.x - grp * bpg) * (RB_BM / t_T);
     }
     auto srow = [&](int r) -> long long {
         if (!TEMPORAL) return m0 + r;
-        const int tok = r / t_T;
-        return t_row0 + (long long)(r - tok * t_T) * p.t_N + tok;
+        const int tl = r / t_T, f = r - tl * t_T, tok = t_tok0 + tl;
+        return t_grp0 + (tok < p.t_N ? (long long)f * p.t_N + tok : (long long)t_T * p.t_N + (tok - p.t_N) * t_T + f);
     };
 
     // ---- prologue: everything the first k-steps and the epilogues need, issued back to back
@@ -877,8 +881,9 @@ static int rowblock_launch(const gvf_rowblock_args* a, int dtype, void* stream_)
     const bool temporal = a->t_frames != 0;
     if (temporal) {
         // blocks of 48 / T tokens x T frames inside a group of T * t_stride rows; one stream: W1 | to_qkv | to_out | W3
-        if (a->t_frames < 0 || RB_BM % a->t_frames != 0 || a->t_stride <= 0 || a->t_stride % (RB_BM / a->t_frames) != 0) return GVF_EINVAL;
-        if (a->rows_per_group != a->t_frames * a->t_stride || a->M % a->rows_per_group != 0) return GVF_EINVAL;
+        if (a->t_frames < 0 || RB_BM % a->t_frames != 0 || a->t_stride <= 0) return GVF_EINVAL;
+        const int tpb = RB_BM / a->t_frames;                      // tokens per workgroup; a group = whole workgroups (its last one may hold phantom tokens)
+        if (a->rows_per_group != (a->t_stride + tpb - 1) / tpb * RB_BM || a->M % a->rows_per_group != 0) return GVF_EINVAL;
         if (mlp || a->K1 == 0 || a->in_x != nullptr || a->x_in != nullptr || a->k_tiles != nullptr || a->hb_out != nullptr || a->N3 == 0) return GVF_EINVAL;
         if ((a->t_gamma_q == nullptr) != (a->t_gamma_k == nullptr) || !(a->t_scale > 0.f)) return GVF_EINVAL;
         if (((a->t_ln.ln_w == nullptr) != (a->t_ln.ln_b == nullptr)) || ((a->t_ln.shift == nullptr) != (a->t_ln.scale == nullptr))) return GVF_EINVAL;

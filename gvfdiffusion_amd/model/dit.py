@@ -615,7 +615,8 @@ class DiT(nn.Module):
         # tiled images the attention kernel stages (no row-major k, v; no pack launch)
         tiled_kv = N % 64 == 0 and self.rowblock_tiled_kv
         R = dit_ops.ROWBLOCK_ROWS
-        temporal_fused = self.rowblock_temporal and not self.no_temporal_attn and not padded and R % T == 0 and N % (R // T) == 0
+        # (a padded sample's padding rows are exactly the phantom tokens of its last block: ceil(N / (R / T)) * R == TNp)
+        temporal_fused = self.rowblock_temporal and not self.no_temporal_attn and R % T == 0
         qs = torch.empty((M, C), dtype=bf, device=dev) if tiled_kv else None
 
         def qkv_out(blk):

@@ -118,10 +118,11 @@ typedef struct gvf_rowblock_args {
        (model/dit.py:255-261 -> model/attention/modules.py:119-140, heads of 32) between ln1 and the last projection:
            hb = ln1(x);  [q | k | v] = hb Wqkv^T + t_b_qkv;  o = softmax_frames(rms(q) rms(k)^T * t_scale) v  per token and head;
            x += t_gate * (o Wout^T + t_b_out);  hb = t_ln(x);  out3 = hb W3^T + b3
-       with the weight stream W1 | Wqkv (3 passes of 512) | Wout | W3.  A token's frames are rows t_stride apart inside a group of
-       rows_per_group = t_frames * t_stride rows (the frame-major stream (B, T, N, C) with t_stride = N); a workgroup owns 48 / t_frames
-       tokens, so t_frames must divide 48 and 48 / t_frames must divide t_stride.  t_gamma_q / t_gamma_k: MultiHeadRMSNorm gains f32 [512]
-       (both or neither). */
+       with the weight stream W1 | Wqkv (3 passes of 512) | Wout | W3.  A group (sample) is the frame-major stream (T, N, C) with
+       t_stride = N: a token's frames are rows t_stride apart.  A workgroup owns 48 / t_frames tokens (t_frames must divide 48), a group
+       ceil(N / (48 / t_frames)) workgroups = rows_per_group rows: when that is more than t_frames * N, the rows behind the tokens are the
+       group's padding (the phantom tokens of its last workgroup; same layout as kv_group_rows).  t_gamma_q / t_gamma_k: MultiHeadRMSNorm
+       gains f32 [512] (both or neither). */
     int32_t t_frames; int32_t t_stride;
     const float* t_b_qkv; const float* t_gamma_q; const float* t_gamma_k; float t_scale;
     const float* t_b_out; const float* t_gate; gvf_rowblock_ln t_ln;

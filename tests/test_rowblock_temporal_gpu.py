@@ -124,7 +124,51 @@ def test_temporal_section_refuses_what_it_cannot_tile(cuda):
     stream = dit_ops.rowblock_pack_stream(d["w1"], temporal=(d["wqkv"], d["wout"]), w3=d["w3"])
     q = torch.empty((d["M"], C), dtype=torch.bfloat16, device=cuda)
     t = dict(frames=24, stride=64, b_qkv=d["bqkv"], gamma_q=d["gq"], gamma_k=d["gk"], b_out=d["bout"], ln=dict(ln_w=d["lw"], ln_b=d["lb"]))
-    for bad in (dict(t, frames=5, stride=64), dict(t, stride=63), dict(t, gamma_k=None)):
+    for bad, rpg in ((dict(t, frames=5), 24 * 64), (dict(t, stride=62), 24 * 64), (dict(t, gamma_k=None), 24 * 64), (t, 24 * 64 + 48)):
         with pytest.raises(_lib.GvfError):
             dit_ops.rowblock_fused(d["a0"], stream, d["x0"].clone(), b1=d["b1"], ln1=dict(ln_w=d["lw"], ln_b=d["lb"]),
-                                   rows_per_group=bad["frames"] * bad["stride"], out3=q, b3=d["b3"], temporal=bad)
+                                   rows_per_group=rpg, out3=q, b3=d["b3"], temporal=bad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lp", ["bf16", "fp16"])
+@pytest.mark.parametrize("B,T,N,fused", [(2, 16, 96, True), (1, 24, 128, True), (1, 6, 64, True), (2, 16, 64, True), (1, 5, 96, False), (1, 32, 64, False)])
+def test_dit_uses_the_temporal_section_where_it_tiles_and_matches_the_three_launch_path(cuda, lp, B, T, N, fused):
+    """DiT._blocks_rowblock: frames that divide 48 (and tokens that fill whole blocks) take the merged launch -- one launch with `temporal`
+    per block and no gvf_attn_fwd -- everything else keeps the three launches; both give the same output."""
+    import json
+    import os
+    from gvfdiffusion_amd import synthetic
+    from gvfdiffusion_amd.model.dit import DiT
+    man = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dit_manifest.json")))
+    cfg = dict(man["config"], num_blocks=2)
+    torch.manual_seed(T * 100 + N)
+    net = DiT(**cfg)
+    with torch.no_grad():
+        for n_, p_ in net.named_parameters():                 # upstream zero-initialises the gates: give every path a signal
+            if p_.dim() >= 2:
+                p_.copy_(torch.randn_like(p_) / math.sqrt(p_.shape[-1]))
+            elif "gamma" in n_ or ("norm" in n_ and "weight" in n_):
+                p_.copy_(1 + 0.1 * torch.randn_like(p_))
+            else:
+                p_.copy_(0.1 * torch.randn_like(p_))
+    net = net.to(cuda).eval().set_compute_dtype(lp)
+    inp = {k: v.to(cuda) for k, v in synthetic.dit_inputs(B=B, T=T, N=N, L_img=70, L_static=130, seed=5).items()}
+    kw = dict(cond_images=inp["cond_images"], static_latent=inp["static_latent"], deformation_position_xyz=inp["deformation_position_xyz"])
+    t = inp["t"] * torch.linspace(0.4, 1.0, B, device=cuda)
+    calls = {"temporal": 0, "attn": 0}
+    orig_f, orig_a = dit_ops.rowblock_fused, dit_ops.attention
+    dit_ops.rowblock_fused = lambda *a, **k: (calls.__setitem__("temporal", calls["temporal"] + (k.get("temporal") is not None)), orig_f(*a, **k))[1]
+    dit_ops.attention = lambda *a, **k: (calls.__setitem__("attn", calls["attn"] + 1), orig_a(*a, **k))[1]
+    try:
+        assert net.rowblock_temporal and net.use_rowblock
+        y1 = net(inp["x"], t, **kw)
+        n_fused, n_attn = calls["temporal"], calls["attn"]
+        net.rowblock_temporal = False
+        y0 = net(inp["x"], t, **kw)
+    finally:
+        dit_ops.rowblock_fused, dit_ops.attention = orig_f, orig_a
+    assert (n_fused, n_attn) == ((2, 0) if fused else (0, 2)) and calls["attn"] == n_attn + 2
+    r = rel_l2(y1, y0)
+    print(f"DiT {lp} B{B} T{T} N{N}: merged temporal launch vs three launches {r:.2e}")
+    assert r < (1e-6 if not fused else 2e-3 if lp == "bf16" else 2.5e-4)
