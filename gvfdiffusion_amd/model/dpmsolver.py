@@ -544,82 +544,82 @@ class DPM_Solver:
                            atol=atol, rtol=rtol, return_intermediate=return_intermediate)
 
     # ---- driver ---------------------------------------------------------------------------------------------
+    _GRID_METHODS = ("multistep", "singlestep", "singlestep_fixed")
+
+    def _walk_multistep(self, x, grid, order, lower_order_final, solver_type, emit):
+        """Linear multistep walk over the time grid.  The history keeps the last `order` (time, model output) pairs; the first
+        order - 1 steps run at the order the history allows, the last ones (short schedules only) at the order the remaining
+        steps allow -- model/dpmsolver.py:1213-1243.  One model evaluation per grid point except the last."""
+        steps = grid.shape[0] - 1
+        hist_t, hist_m = [grid[0]], [self.model_fn(x, grid[0])]
+        x = emit(x, grid[0], 0)
+        for k in range(1, steps + 1):
+            t = grid[k]
+            if k < order:
+                p = k
+            elif lower_order_final and steps < 10:
+                p = min(order, steps + 1 - k)
+            else:
+                p = order
+            x = emit(self.multistep_dpm_solver_update(x, hist_m, hist_t, t, p, solver_type=solver_type), t, k)
+            if k == steps:
+                break
+            hist_t.append(t)
+            hist_m.append(self.model_fn(x, t))
+            del hist_t[:-order], hist_m[:-order]
+        return x, steps + 1
+
+    def _walk_singlestep(self, x, outer, orders, skip_type, solver_type, emit):
+        """One single-step update of the given order per outer interval; the intermediate times of an update are the inner grid of the
+        same skip type, handed to the update as ratios of the log-SNR step (model/dpmsolver.py:1244-1262)."""
+        lam_of = self.noise_schedule.marginal_lambda
+        for k, p in enumerate(orders):
+            s, t = outer[k], outer[k + 1]
+            lam = lam_of(self.get_time_steps(skip_type=skip_type, t_T=s.item(), t_0=t.item(), N=p))
+            ratios = [(lam[j] - lam[0]) / (lam[-1] - lam[0]) for j in range(1, p)] + [None, None]
+            x = emit(self.singlestep_dpm_solver_update(x, s, t, p, solver_type=solver_type, r1=ratios[0], r2=ratios[1]), t, k)
+        return x, len(orders)
+
     def sample(self, x, steps=20, t_start=None, t_end=None, order=2, skip_type="time_uniform", method="multistep",
                lower_order_final=True, denoise_to_zero=False, solver_type="dpmsolver", atol=0.0078, rtol=0.05,
                return_intermediate=False):
-        t_0 = 1.0 / self.noise_schedule.total_N if t_end is None else t_end
-        t_T = self.noise_schedule.T if t_start is None else t_start
-        assert t_0 > 0 and t_T > 0, "Time range needs to be greater than 0. For discrete-time DPMs, it needs to be in [1 / N, 1], where N is the length of betas array"
-        if return_intermediate:
-            assert method in ["multistep", "singlestep", "singlestep_fixed"], "Cannot use adaptive solver when saving intermediate values"
-        if self.correcting_xt_fn is not None:
-            assert method in ["multistep", "singlestep", "singlestep_fixed"], "Cannot use adaptive solver when correcting_xt_fn is not None"
-        intermediates = []
+        """Same contract as model/dpmsolver.py:1089-1273 (names, defaults, the AssertionError / ValueError cases, what the correcting
+        hook and the intermediates list see).  Built differently: `emit` is the one place where a new state passes the correcting hook and
+        is recorded; the two fixed-grid walks are methods of their own; the adaptive walk is dpm_solver_adaptive."""
+        ns = self.noise_schedule
+        t_lo = 1.0 / ns.total_N if t_end is None else t_end
+        t_hi = ns.T if t_start is None else t_start
+        assert t_lo > 0 and t_hi > 0, "Time range needs to be greater than 0. For discrete-time DPMs, it needs to be in [1 / N, 1], where N is the length of betas array"
+        on_grid = method in self._GRID_METHODS
+        assert on_grid or not return_intermediate, "Cannot use adaptive solver when saving intermediate values"
+        assert on_grid or self.correcting_xt_fn is None, "Cannot use adaptive solver when correcting_xt_fn is not None"
+        recorded = []
+
+        def emit(state, t, k):
+            if self.correcting_xt_fn is not None:
+                state = self.correcting_xt_fn(state, t, k)
+            if return_intermediate:
+                recorded.append(state)
+            return state
+
+        kw = dict(skip_type=skip_type, t_T=t_hi, t_0=t_lo)
         with torch.no_grad():
             if method == "adaptive":
-                x = self.dpm_solver_adaptive(x, order=order, t_T=t_T, t_0=t_0, atol=atol, rtol=rtol, solver_type=solver_type)
+                x, k_end = self.dpm_solver_adaptive(x, order=order, t_T=t_hi, t_0=t_lo, atol=atol, rtol=rtol, solver_type=solver_type), 0
             elif method == "multistep":
                 assert steps >= order
-                timesteps = self.get_time_steps(skip_type=skip_type, t_T=t_T, t_0=t_0, N=steps)
-                assert timesteps.shape[0] - 1 == steps
-                step = 0
-                t = timesteps[step]
-                t_prev_list = [t]
-                model_prev_list = [self.model_fn(x, t)]
-                if self.correcting_xt_fn is not None:
-                    x = self.correcting_xt_fn(x, t, step)
-                if return_intermediate:
-                    intermediates.append(x)
-                for step in range(1, order):
-                    t = timesteps[step]
-                    x = self.multistep_dpm_solver_update(x, model_prev_list, t_prev_list, t, step, solver_type=solver_type)
-                    if self.correcting_xt_fn is not None:
-                        x = self.correcting_xt_fn(x, t, step)
-                    if return_intermediate:
-                        intermediates.append(x)
-                    t_prev_list.append(t)
-                    model_prev_list.append(self.model_fn(x, t))
-                for step in range(order, steps + 1):
-                    t = timesteps[step]
-                    step_order = min(order, steps + 1 - step) if (lower_order_final and steps < 10) else order
-                    x = self.multistep_dpm_solver_update(x, model_prev_list, t_prev_list, t, step_order, solver_type=solver_type)
-                    if self.correcting_xt_fn is not None:
-                        x = self.correcting_xt_fn(x, t, step)
-                    if return_intermediate:
-                        intermediates.append(x)
-                    for i in range(order - 1):
-                        t_prev_list[i] = t_prev_list[i + 1]
-                        model_prev_list[i] = model_prev_list[i + 1]
-                    t_prev_list[-1] = t
-                    if step < steps:  # the final model value is never needed
-                        model_prev_list[-1] = self.model_fn(x, t)
-            elif method in ["singlestep", "singlestep_fixed"]:
-                if method == "singlestep":
-                    timesteps_outer, orders = self.get_orders_and_timesteps_for_singlestep_solver(
-                        steps=steps, order=order, skip_type=skip_type, t_T=t_T, t_0=t_0)
-                else:
-                    K = steps // order
-                    orders = [order] * K
-                    timesteps_outer = self.get_time_steps(skip_type=skip_type, t_T=t_T, t_0=t_0, N=K)
-                for step, order in enumerate(orders):
-                    s, t = timesteps_outer[step], timesteps_outer[step + 1]
-                    timesteps_inner = self.get_time_steps(skip_type=skip_type, t_T=s.item(), t_0=t.item(), N=order)
-                    lambda_inner = self.noise_schedule.marginal_lambda(timesteps_inner)
-                    h = lambda_inner[-1] - lambda_inner[0]
-                    r1 = None if order <= 1 else (lambda_inner[1] - lambda_inner[0]) / h
-                    r2 = None if order <= 2 else (lambda_inner[2] - lambda_inner[0]) / h
-                    x = self.singlestep_dpm_solver_update(x, s, t, order, solver_type=solver_type, r1=r1, r2=r2)
-                    if self.correcting_xt_fn is not None:
-                        x = self.correcting_xt_fn(x, t, step)
-                    if return_intermediate:
-                        intermediates.append(x)
+                grid = self.get_time_steps(N=steps, **kw)
+                assert grid.shape[0] - 1 == steps
+                x, k_end = self._walk_multistep(x, grid, order, lower_order_final, solver_type, emit)
+            elif method == "singlestep":
+                outer, orders = self.get_orders_and_timesteps_for_singlestep_solver(steps=steps, order=order, **kw)
+                x, k_end = self._walk_singlestep(x, outer, orders, skip_type, solver_type, emit)
+            elif method == "singlestep_fixed":
+                n = steps // order
+                x, k_end = self._walk_singlestep(x, self.get_time_steps(N=n, **kw), [order] * n, skip_type, solver_type, emit)
             else:
                 raise ValueError("Got wrong method {}".format(method))
             if denoise_to_zero:
-                t = torch.ones((1,)) * t_0
-                x = self.denoise_to_zero_fn(x, t)
-                if self.correcting_xt_fn is not None:
-                    x = self.correcting_xt_fn(x, t, step + 1)
-                if return_intermediate:
-                    intermediates.append(x)
-        return (x, intermediates) if return_intermediate else x
+                t = torch.ones((1,)) * t_lo
+                x = emit(self.denoise_to_zero_fn(x, t), t, k_end)
+        return (x, recorded) if return_intermediate else x
