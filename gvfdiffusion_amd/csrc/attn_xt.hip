@@ -59,6 +59,21 @@
 #ifndef XT_ABL_NOSUM
 #define XT_ABL_NOSUM 0
 #endif
+#ifndef XT_ABL_NOCVT
+#define XT_ABL_NOCVT 0
+#endif
+#ifndef XT_ABL_EXPSRC
+#define XT_ABL_EXPSRC 0       // 1: the exponentials read lane constants instead of the score tile (no MFMA -> VALU dependency; scores kept alive)
+#endif
+#ifndef XT_ORDER
+#define XT_ORDER 0            // 0: every MFMA followed by 8-12 VALU instructions; 1: all VALU work of a phase first, then all its MFMAs
+#endif
+#ifndef XT_SKEW
+#define XT_SKEW 0             // > 0: waves in odd hardware wave slots sleep 64 * XT_SKEW clocks before the main loop
+#endif
+#ifndef XT_ABL_PCONST
+#define XT_ABL_PCONST 0       // 1: the PV / row-sum MFMAs read a loop-invariant operand instead of the probabilities (no VALU -> MFMA dependency)
+#endif
 #ifndef XT_ABL_NOSYNC
 #define XT_ABL_NOSYNC 0
 #endif
@@ -174,6 +189,8 @@ __device__ __forceinline__ void xt_phase(typename GvfLp<DT>::x8 (&kf)[2][2], typ
     const f32x16 zero = LP::kNeedsShift ? c0 : zero_;
     float pe[8];
     unsigned pw[4][4];
+    unsigned pconst[4] = {0x3c003c00u + (unsigned)l31, 0x3c003c01u, 0x3c003c02u, 0x3c003c03u};
+    if (XT_ABL_PCONST) asm volatile("" : "+v"(pconst[0]), "+v"(pconst[1]), "+v"(pconst[2]), "+v"(pconst[3]));
     x8 qf[2];
     if (XT_Q_LDS && DO_QK) { qf[0] = __builtin_bit_cast(x8, sQ[0]); qf[1] = __builtin_bit_cast(x8, sQ[64]); }
     else { qf[0] = qf_in[0]; qf[1] = qf_in[1]; }
@@ -185,7 +202,8 @@ __device__ __forceinline__ void xt_phase(typename GvfLp<DT>::x8 (&kf)[2][2], typ
 #define XT_E(g_)                                                                                            \
     if (DO_SM) {                                                                                            \
         _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                     \
-            pe[e] = XT_ABL_NOEXP ? s_in[(g_) >> 1][8 * ((g_) & 1) + e] * 0.5f : __builtin_amdgcn_exp2f(s_in[(g_) >> 1][8 * ((g_) & 1) + e]); \
+            if (XT_ABL_EXPSRC) { float t_ = 0.001f * (float)(l31 + e); asm volatile("v_exp_f32 %0, %1" : "=v"(pe[e]) : "v"(t_)); if (e == 0) asm volatile("" :: "v"(s_in[(g_) >> 1])); } \
+            else pe[e] = XT_ABL_NOEXP ? s_in[(g_) >> 1][8 * ((g_) & 1) + e] * 0.5f : __builtin_amdgcn_exp2f(s_in[(g_) >> 1][8 * ((g_) & 1) + e]); \
             if (MASK) pe[e] = (16 * (g_) + 4 * half + (e & 3) + 8 * (e >> 2)) < n_valid ? pe[e] : 0.f;     \
         }                                                                                                   \
         XT_FENCE();                                                                                         \
@@ -194,24 +212,51 @@ __device__ __forceinline__ void xt_phase(typename GvfLp<DT>::x8 (&kf)[2][2], typ
 #define XT_SUM(g_)                                                                                          \
     {                                                                                                       \
         const x4 ones = __builtin_bit_cast(x4, make_uint2(LP::ONE2, LP::ONE2));                             \
+        if (XT_ABL_PCONST) { asm volatile("" :: "v"(pw[g_][0]), "v"(pw[g_][1]), "v"(pw[g_][2]), "v"(pw[g_][3])); \
+            l4 = LP::mfma4(ones, __builtin_bit_cast(x4, make_uint2(pconst[0], pconst[1])), l4); l4b = LP::mfma4(ones, __builtin_bit_cast(x4, make_uint2(pconst[2], pconst[3])), l4b); } else { \
         l4 = LP::mfma4(ones, __builtin_bit_cast(x4, make_uint2(pw[g_][0], pw[g_][1])), l4);                 \
         if (XT_SUM2) l4b = LP::mfma4(ones, __builtin_bit_cast(x4, make_uint2(pw[g_][2], pw[g_][3])), l4b);  \
-        else l4 = LP::mfma4(ones, __builtin_bit_cast(x4, make_uint2(pw[g_][2], pw[g_][3])), l4);            \
+        else l4 = LP::mfma4(ones, __builtin_bit_cast(x4, make_uint2(pw[g_][2], pw[g_][3])), l4); }          \
     }
 #else
 #define XT_SUM(g_)                                                                                          \
     if (!XT_ABL_NOSUM) { _Pragma("unroll") for (int e = 0; e < 8; ++e) l_acc[e & 3] += pe[e]; }
 #endif
-#define XT_P(g_)                                                                                            \
+#define XT_C(g_)                                                                                            \
     if (DO_SM) {                                                                                            \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) pw[g_][i] = LP::pack(pe[2 * i], pe[2 * i + 1]);    \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) pw[g_][i] = XT_ABL_NOCVT ? __float_as_uint(pe[2 * i]) : LP::pack(pe[2 * i], pe[2 * i + 1]);    \
+    }
+#define XT_S(g_)                                                                                            \
+    if (DO_SM) {                                                                                            \
         XT_SUM(g_)                                                                                          \
+        XT_FENCE();                                                                                         \
+    }
+#define XT_P(g_) XT_C(g_) XT_S(g_)
+    /* ORDER 2: units of {one big MFMA, 4 exponentials, one row-sum MFMA, 2 conversions}: every MFMA has VALU work of about its own length behind it */
+#define XT_EH(g_, h_)                                                                                       \
+    if (DO_SM) {                                                                                            \
+        _Pragma("unroll") for (int e = 4 * (h_); e < 4 * (h_) + 4; ++e) {                                   \
+            pe2[g_ & 1][e] = __builtin_amdgcn_exp2f(s_in[(g_) >> 1][8 * ((g_) & 1) + e]);                    \
+            if (MASK) pe2[g_ & 1][e] = (16 * (g_) + 4 * half + (e & 3) + 8 * (e >> 2)) < n_valid ? pe2[g_ & 1][e] : 0.f; \
+        }                                                                                                   \
+        XT_FENCE();                                                                                         \
+    }
+#define XT_CH(g_, h_)                                                                                       \
+    if (DO_SM) {                                                                                            \
+        _Pragma("unroll") for (int i = 2 * (h_); i < 2 * (h_) + 2; ++i) pw[g_][i] = LP::pack(pe2[g_ & 1][2 * i], pe2[g_ & 1][2 * i + 1]); \
+        XT_FENCE();                                                                                         \
+    }
+#define XT_SH(g_, h_)                                                                                       \
+    if (DO_SM) {                                                                                            \
+        const x4 ones = __builtin_bit_cast(x4, make_uint2(LP::ONE2, LP::ONE2));                             \
+        if ((h_) == 0) l4 = LP::mfma4(ones, __builtin_bit_cast(x4, make_uint2(pw[g_][0], pw[g_][1])), l4);  \
+        else l4b = LP::mfma4(ones, __builtin_bit_cast(x4, make_uint2(pw[g_][2], pw[g_][3])), l4b);          \
         XT_FENCE();                                                                                         \
     }
 #define XT_V(g_)                                                                                            \
     if (DO_SM && !XT_ABL_NOPV) {                                                                            \
         if (XT_SETPRIO) __builtin_amdgcn_s_setprio(1);                                                      \
-        o_acc = LP::mfma32(vf[g_], __builtin_bit_cast(x8, make_uint4(pw[g_][0], pw[g_][1], pw[g_][2], pw[g_][3])), o_acc); \
+        o_acc = LP::mfma32(vf[g_], XT_ABL_PCONST ? __builtin_bit_cast(x8, make_uint4(pconst[0], pconst[1], pconst[2], pconst[3])) : __builtin_bit_cast(x8, make_uint4(pw[g_][0], pw[g_][1], pw[g_][2], pw[g_][3])), o_acc); \
         if (XT_SETPRIO) __builtin_amdgcn_s_setprio(0);                                                      \
         if (PF == 1 && !XT_ABL_NOLDS) vf[g_] = xt_ld_v<DT>(sNext, g_, l31, half);                              \
         if (PF == 2 && !XT_ABL_NOLDS && ((g_) == 0 || (g_) == 3)) {   /* K fragments of the next tile: sub 0 behind V0 */ \
@@ -229,13 +274,34 @@ __device__ __forceinline__ void xt_phase(typename GvfLp<DT>::x8 (&kf)[2][2], typ
         XT_FENCE();                                                                                         \
     }
     XT_FENCE();
+#if XT_ORDER == 2
+    float pe2[2][8];
+    XT_Q(0) XT_EH(0, 0) XT_CH(0, 0)
+    XT_Q(1) XT_EH(0, 1) XT_SH(0, 0) XT_CH(0, 1)
+    XT_V(0) XT_EH(1, 0) XT_SH(0, 1) XT_CH(1, 0)
+    XT_Q(2) XT_EH(1, 1) XT_SH(1, 0) XT_CH(1, 1)
+    XT_V(1) XT_EH(2, 0) XT_SH(1, 1) XT_CH(2, 0)
+    XT_Q(3) XT_EH(2, 1) XT_SH(2, 0) XT_CH(2, 1)
+    XT_V(2) XT_EH(3, 0) XT_SH(2, 1) XT_CH(3, 0)
+    XT_EH(3, 1) XT_SH(3, 0) XT_CH(3, 1)
+    XT_V(3) XT_SH(3, 1)
+#elif XT_ORDER == 1
+    XT_E(0) XT_C(0) XT_E(1) XT_C(1) XT_E(2) XT_C(2) XT_E(3) XT_C(3) XT_FENCE();
+    XT_Q(0) XT_Q(1) XT_Q(2) XT_Q(3) XT_V(0) XT_S(0) XT_V(1) XT_S(1) XT_V(2) XT_S(2) XT_V(3) XT_S(3)
+#else
     XT_E(0) XT_Q(0) XT_P(0) XT_Q(1) XT_E(1) XT_V(0) XT_P(1) XT_Q(2) XT_E(2) XT_V(1) XT_P(2) XT_Q(3) XT_E(3) XT_V(2) XT_P(3) XT_V(3)
+#endif
     if (PF == 1 && !DO_SM && !XT_ABL_NOLDS) {      // first phase of a workgroup: nothing to chase, load the V^T fragments now
 #pragma unroll
         for (int g = 0; g < 4; ++g) vf[g] = xt_ld_v<DT>(sNext, g, l31, half);
     }
 #undef XT_E
 #undef XT_P
+#undef XT_C
+#undef XT_S
+#undef XT_EH
+#undef XT_CH
+#undef XT_SH
 #undef XT_V
 #undef XT_Q
 #undef XT_SUM
@@ -413,6 +479,9 @@ __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(
         }
         xt_phase<DT, true, false, false, 1>(kf, vf, XT_V(0), qf[0], sQw, sA, sB, oB, lB4, l4B, l4Bb, l31, half, XT_KT, cA);
         if (LP::kNeedsShift) xt_take_shift<DT>(sA, cA);
+#if XT_SKEW
+        if (__builtin_amdgcn_s_getreg(((4 - 1) << 11) | 4) & 1) __builtin_amdgcn_s_sleep(XT_SKEW);      // HW_ID.WAVE_ID
+#endif
         if (T > 1) {
             xt_phase<DT, true, true, false, 2>(kf, vf, XT_K(1), qf[1], sQw + 128, sB, sA, oA, lA4, l4A, l4Ab, l31, half, XT_KT, cB);
             if (LP::kNeedsShift) xt_take_shift<DT>(sB, cB);
