@@ -100,7 +100,11 @@ int main(int argc, char** argv) {
     int bad = 0;
     const int iters = argc > 1 ? atoi(argv[1]) : 20;
     bad |= run_case("static cross B1 T24 Lk4096", 1, 24, 512, 4096, 16, true, 1.f, 0, iters);
-    if (argc > 2) return bad;      // timing-only runs (ablations)
+    if (argc > 2) {                // timing-only runs (ablations): the three DiT shapes
+        bad |= run_case("image cross  B1 T24 Lk1370", 1, 24, 512, 1370, 16, false, 1.f, 0, iters);
+        bad |= run_case("spatial self B1 T24 Lk512 ", 24, 1, 512, 512, 16, false, 1.f, 0, iters);
+        return bad;
+    }
     bad |= run_case("static cross B1 T24 Lk4096", 1, 24, 512, 4096, 16, true, 1.f, 1, iters);
     bad |= run_case("image cross  B1 T24 Lk1370", 1, 24, 512, 1370, 16, false, 1.f, 0, iters);
     bad |= run_case("static cross B3 T24 Lk4096", 3, 24, 512, 4096, 16, true, 1.f, 0, iters);
