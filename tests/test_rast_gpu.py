@@ -341,3 +341,34 @@ def test_hip_matches_cuda_golden(cuda):
             err = np.abs(color.cpu().numpy()[crop] - arr[f"{tag}.color"])
             print(f"{name}/{tag}: HIP vs CUDA max|d| {err.max():.2e}, > 1e-3 on {float((err.max(0) > 1e-3).mean()):.4f} of the pixels")
             assert float((err.max(0) > 1e-3).mean()) <= 0.03 and err.max() <= 2e-2
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_closed_form_scenes_on_the_device(cuda, oracle_lib, mode):
+    """The hand-derived known answers of tests/test_oracle_rast_closed_form.py through the HIP operator: one isotropic Gaussian on the optical
+    axis (pixel-centre convention, both dilation modes) and the stop rule of the front-to-back walk."""
+    import math
+    import test_oracle_rast_closed_form as cf
+    H, W, BG = cf.H, cf.W, cf.BG
+    z, s, op, col = 2.0, 0.08, 0.7, (0.9, 0.3, 0.1)
+    cam, attrs, c = cf._scene([z], [s], [op], [col])
+    rast = _settings(cam, H, W, 0, mode, cuda, kernel_size=0.1, bg=BG)
+    ret = _run(rast, _to(cuda, attrs), shs=None, colors_precomp=c.to(cuda))
+    img = ret[0].cpu().numpy()
+    sig2, coef = cf._sigma2(cam, s, z, mode, 0.1)
+    yy, xx = np.mgrid[0:H, 0:W]
+    a = np.minimum(0.99, op * coef * np.exp(-0.5 * ((xx - 15.5) ** 2 + (yy - 15.5) ** 2) / sig2))
+    a[a < 1.0 / 255.0] = 0.0
+    exp_img = np.asarray(col)[:, None, None] * a[None] + np.asarray(BG)[:, None, None] * (1 - a[None])
+    # (a pixel whose alpha is within float noise of 1/255 may go either way between v_exp_f32 and exp(): none in this scene)
+    assert np.abs(np.abs(a - 1.0 / 255.0) < 1e-6).sum() == 0
+    assert np.abs(img - exp_img).max() < 3e-6
+    assert np.array_equal(img[:, 0, 0], np.asarray(BG, np.float32))
+    if mode == 1:
+        assert np.abs(ret[3][0].cpu().numpy() - a).max() < 3e-6
+        cam, attrs, c = cf._scene([1.2, 1.6, 2.0, 2.4], [0.6, 0.8, 1.0, 1.2], [0.9, 1.0, 1.0, 1.0], [(1.0, 0, 0), (0, 1.0, 0), (0, 0, 1.0), (1.0, 1.0, 1.0)])
+        rast = _settings(cam, H, W, 0, 1, cuda, bg=(0.0, 0.0, 0.0))
+        ret = _run(rast, _to(cuda, attrs), shs=None, colors_precomp=c.to(cuda))
+        g = math.exp(-0.25 / cf._sigma2(cam, 0.6, 1.2, 1, 0.1)[0])
+        px = ret[0][:, 15, 15].cpu().numpy()
+        assert abs(px[0] - 0.9 * g) < 3e-6 and abs(px[1] - 0.99 * (1 - 0.9 * g)) < 3e-6 and px[2] == 0.0
