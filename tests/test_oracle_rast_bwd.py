@@ -106,3 +106,44 @@ def test_backward_matches_finite_differences(mode, deg, use_cov, use_rgb):
     assert checked > 100 and jumps <= 0.05 * checked
     # the screen-space gradient is the pixel-space one in NDC units: cross-check through means3D on a pure translation
     assert np.isfinite(grads["means2D"]).all() and np.abs(grads["means2D"]).max() > 0
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_backward_closed_form_single_gaussian(mode):
+    """One isotropic Gaussian on the optical axis (the scene of tests/test_oracle_rast_closed_form.py): colour = c a + bg (1 - a) with
+    a = o * coef * g(x), so for the loss sum(w * colour)   dL/dc_k = sum_x w_k a   and   dL/do = sum_x sum_k w_k (c_k - bg_k) coef g
+    over the pixels the splat reaches (a >= 1/255, no clamp at o = 0.7) -- worked out by hand, no finite differences; dL/d(scale) by
+    symmetry is the same for the two image-plane axes and dL/d(mean_x) = dL/d(mean_y) = 0 for a symmetric weight."""
+    import math
+    import test_oracle_rast_closed_form as cf
+    H, W = cf.H, cf.W
+    z, s, op, col, bg = 2.0, 0.08, 0.7, np.array([0.9, 0.3, 0.1]), np.array([0.2, 0.4, 0.6])
+    cam, attrs, c = cf._scene([z], [s], [op], [tuple(col)])
+    kw = dict(H=H, W=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], kernel_size=0.1, scale_modifier=1.0,
+              viewmatrix=cam["viewmatrix"].numpy(), projmatrix=cam["projmatrix"].numpy(), campos=cam["campos"].numpy(), sh_degree=0, bg=bg)
+    n = lambda t: t.double().numpy().copy()
+    yy, xx = np.mgrid[0:H, 0:W]
+    d2 = (xx - 15.5) ** 2 + (yy - 15.5) ** 2
+    wgt = np.stack([1.0 + 0.01 * d2, 2.0 - 0.02 * d2, 0.5 + 0.0 * d2])           # radially symmetric weights, different per channel
+    g = oracle.rast64_backward(n(attrs["means3D"]), None, n(c), n(attrs["opacities"]).reshape(-1), n(attrs["scales"]), n(attrs["rotations"]), None,
+                               wgt, mode=mode, **kw)
+    sig2, coef = cf._sigma2(cam, s, z, mode, 0.1)
+    gx = np.exp(-0.5 * d2 / sig2)
+    a = op * coef * gx
+    reach = a >= 1.0 / 255.0
+    exp_dcol = (wgt * (a * reach)[None]).sum(axis=(1, 2))
+    exp_dop = float(((wgt * (col - bg)[:, None, None]).sum(axis=0) * coef * gx * reach).sum())
+    assert np.allclose(g["colors_precomp"][0], exp_dcol, rtol=1e-6, atol=1e-9)
+    assert abs(g["opacities"][0] - exp_dop) < 1e-6 * max(1.0, abs(exp_dop))
+    assert np.abs(g["means2D"][0]).max() < 1e-9 * max(1.0, abs(exp_dop))          # symmetric scene, symmetric weights: no pull on the mean
+    # the camera looks along one world axis: the two scale components that span the image plane get equal gradients, and the sign says
+    # "a bigger splat covers more of the brighter-than-background red / darker blue": checked against the closed-form derivative in sigma^2
+    base = sig2 - (0.1 if mode == 0 else 0.3)
+    dcoef = 0.0 if mode == 1 else (0.1 / (base + 0.1) ** 2)                        # d coef / d base, coef = base / (base + k)
+    da_dbase = op * (dcoef * gx + coef * gx * (0.5 * d2 / sig2 ** 2))
+    dL_dbase = float(((wgt * (col - bg)[:, None, None]).sum(axis=0) * da_dbase * reach).sum())
+    # base = (f s / z)^2 is the variance along BOTH image axes; an isotropic change of the scale moves both: dL/ds_u + dL/ds_v = dL/dbase * 2 base / s
+    # ... with Sigma' = diag(base_u, base_v): a = o coef(base_u, base_v) exp(-dx^2 / 2 su2 - dy^2 / 2 sv2); by symmetry each axis carries half
+    gs = np.sort(np.abs(g["scales"][0]))
+    assert abs(gs[2] - gs[1]) < 1e-6 * max(1.0, gs[2])                             # the two image-plane axes agree
+    assert abs((gs[1] + gs[2]) - abs(dL_dbase * 2 * base / s)) < 2e-5 * max(1.0, abs(dL_dbase * 2 * base / s))
