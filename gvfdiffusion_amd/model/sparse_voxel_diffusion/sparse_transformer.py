@@ -4,7 +4,7 @@ SparseFeedForward, SparseTransformerBlock -- same constructors and parameter nam
 load unchanged).
 
 A block keeps the residual stream as fp32 rows (T, C) and runs, per sub-layer, the same kernels as the DiT:
-LayerNorm -> bf16 operand, bf16 MFMA GEMM with bias / tanh-GELU / residual epilogues, and the varlen flash attention
+LayerNorm -> 16-bit operand (bf16 or fp16: `lp`), MFMA GEMM with bias / tanh-GELU / residual epilogues, and the varlen flash attention
 over the tokens gathered into window (or serialisation) order.  The partition of a SparseTensor is computed once per
 (window, shift) on the device and cached on the tensor, including the device-side cu_seqlens."""
 from typing import *
@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from ... import sparse as sp
-from ...ops import dit_ops
+from ...ops import dit_ops, precision
 from ...sparse.attention.modules import SparseMultiHeadAttention
 from ...sparse.attention.serialized_attn import SerializeMode, SerializeModes, calc_serialization
 from ...sparse.attention.windowed_attn import calc_window_partition
@@ -69,8 +69,8 @@ class SparseFeedForward(nn.Module):
         return self.mlp(x)
 
 
-def _bf(w):
-    return w.detach().to(torch.bfloat16).contiguous()
+def _lpw(w, lp):
+    return w.detach().to(lp).contiguous()
 
 
 def _fb(b):
@@ -114,10 +114,11 @@ class SparseTransformerBlock(nn.Module):
         self.modulated = modulated
         self._wcache = None
 
-    def _weights(self):
-        ver = tuple((p.data_ptr(), p._version) for p in self.parameters())
+    def _weights(self, lp=torch.bfloat16):
+        ver = (tuple((p.data_ptr(), p._version) for p in self.parameters()), lp)
         if self._wcache is not None and self._wcache[0] == ver:
             return self._wcache[1]
+        _bf = lambda w: _lpw(w, lp)
         a = self.attn
         C, H = a.channels, a.num_heads
         wq, bq = a.to_qkv.weight.detach(), a.to_qkv.bias.detach()
@@ -132,46 +133,48 @@ class SparseTransformerBlock(nn.Module):
         return W
 
     @torch.no_grad()
-    def forward_rows(self, x: torch.Tensor, st: sp.SparseTensor) -> torch.Tensor:
-        """x: fp32 (T, C) residual rows of `st` (updated in place and returned)."""
-        W = self._weights()
+    def forward_rows(self, x: torch.Tensor, st: sp.SparseTensor, lp=None) -> torch.Tensor:
+        """x: fp32 (T, C) residual rows of `st` (updated in place and returned).  lp: the 16-bit operand type of the GEMMs and the attention
+        (torch.float16 / torch.bfloat16; None: ops/precision.py's rule -- environment, autocast region, else bf16)."""
+        lp = precision.resolve(lp, (), torch.bfloat16)
+        W = self._weights(lp)
         a = self.attn
         T, C = x.shape
         H = a.num_heads
         d = C // H
-        bf16, dev = torch.bfloat16, x.device
+        bf16, dev = lp, x.device
         fwd, bwd, cu, longest = token_partition(st, a.attn_mode, a.window_size, a.shift_sequence, a.shift_window, a.serialize_mode)
         hb = torch.empty((T, C), dtype=bf16, device=dev)
-        dit_ops.layernorm_modulate_bf16(x, hb, self.norm1.eps)
+        dit_ops.layernorm_modulate(x, hb, self.norm1.eps)
         qkv = torch.empty((T, 3 * C), dtype=bf16, device=dev)
-        dit_ops.gemm_bf16(hb, *W["qkv"], qkv, dit_ops.EPI_STORE_BF16)
+        dit_ops.gemm(hb, *W["qkv"], qkv, dit_ops.EPI_STORE_16)
         g = qkv if fwd is None else qkv.index_select(0, fwd)                      # (M, 3C) in sequence order
         ao = torch.empty((g.shape[0], C), dtype=bf16, device=dev)
         s3 = (0, 0, 3 * C)
-        dit_ops.attention_varlen_bf16(g, g[:, C:], g[:, 2 * C:], ao, cu, cu, longest, longest, H, s3, s3, s3, (0, 0, C),
-                                      W["gq"], W["gk"], head_dim=d)
+        dit_ops.attention_varlen(g, g[:, C:], g[:, 2 * C:], ao, cu, cu, longest, longest, H, s3, s3, s3, (0, 0, C),
+                                 W["gq"], W["gk"], head_dim=d)
         if bwd is not None:
             ao = ao.index_select(0, bwd)
-        dit_ops.gemm_bf16(ao, *W["out"], x, dit_ops.EPI_RESID_F32)
-        dit_ops.layernorm_modulate_bf16(x, hb, self.norm2.eps)
+        dit_ops.gemm(ao, *W["out"], x, dit_ops.EPI_RESID_F32)
+        dit_ops.layernorm_modulate(x, hb, self.norm2.eps)
         hid = torch.empty((T, W["fc1"][0].shape[0]), dtype=bf16, device=dev)
-        dit_ops.gemm_bf16(hb, *W["fc1"], hid, dit_ops.EPI_GELU_BF16)
-        dit_ops.gemm_bf16(hid, *W["fc2"], x, dit_ops.EPI_RESID_F32)
+        dit_ops.gemm(hb, *W["fc1"], hid, dit_ops.EPI_GELU_16)
+        dit_ops.gemm(hid, *W["fc2"], x, dit_ops.EPI_RESID_F32)
         return x
 
     def forward(self, x: sp.SparseTensor, c: torch.Tensor = None) -> sp.SparseTensor:
         rows = x.feats.float().contiguous().clone()
-        return x.replace(self.forward_rows(rows, x).to(x.dtype))
+        return x.replace(self.forward_rows(rows, x, precision.resolve(None, (x.feats,), torch.bfloat16)).to(x.dtype))
 
 
-def edge_weights(lin: nn.Linear):
-    """(weight as bf16 with K zero-padded to a multiple of 64, fp32 bias) of an input / output layer."""
-    return (dit_ops.cast_pad_bf16(lin.weight.detach().float().contiguous(), dit_ops.pad64(lin.in_features)),
+def edge_weights(lin: nn.Linear, lp=torch.bfloat16):
+    """(weight as `lp` (bf16 / fp16) with K zero-padded to a multiple of 64, fp32 bias) of an input / output layer."""
+    return (dit_ops.cast_pad(lin.weight.detach().float().contiguous(), dit_ops.pad64(lin.in_features), dtype=lp),
             lin.bias.detach().float().contiguous())
 
 
 @torch.no_grad()
-def run_torso(st: sp.SparseTensor, rows: torch.Tensor, w_in, pos_embedder, blocks, channels: int) -> torch.Tensor:
+def run_torso(st: sp.SparseTensor, rows: torch.Tensor, w_in, pos_embedder, blocks, channels: int, lp=None) -> torch.Tensor:
     """rows (T, K) of `st` -> fp32 residual stream (T, channels) after  rows @ W_in^T + b (+ position embedding)  and every block.
     The embedding is written first and the input GEMM accumulates onto it (residual epilogue)."""
     T = rows.shape[0]
@@ -179,10 +182,11 @@ def run_torso(st: sp.SparseTensor, rows: torch.Tensor, w_in, pos_embedder, block
         x = pos_embedder(st.coords[:, 1:]).float().contiguous()
     else:
         x = torch.zeros((T, channels), dtype=torch.float32, device=rows.device)
-    a = dit_ops.cast_pad_bf16(rows.float().contiguous(), w_in[0].shape[1])
-    dit_ops.gemm_bf16(a, *w_in, x, dit_ops.EPI_RESID_F32)
+    lp = w_in[0].dtype if lp is None else lp                     # the edge weights were cast to the operand type of this pass
+    a = dit_ops.cast_pad(rows.float().contiguous(), w_in[0].shape[1], dtype=lp)
+    dit_ops.gemm(a, *w_in, x, dit_ops.EPI_RESID_F32)
     for blk in blocks:
-        blk.forward_rows(x, st)
+        blk.forward_rows(x, st, lp)
     return x
 
 

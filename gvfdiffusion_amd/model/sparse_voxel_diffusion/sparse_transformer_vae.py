@@ -3,8 +3,10 @@ the MI355X kernels: same constructor keywords, same parameter tree (`input_layer
 `from_latent`, `decoder.N.*`, `out_layer`), `encode(x, sample_posterior, return_raw)`, `decode(latent)` and
 `forward(x) -> (out, mean, logvar)`.
 
-Precision placement (the reference casts the torso to fp16 under autocast, :164,192): the residual stream stays fp32
-from the input layer to the output layer; every GEMM / attention operand is bf16 with fp32 accumulation.  The elastic
+Precision placement (the reference casts the torso to fp16 with `use_fp16`, :164,192): the residual stream stays fp32
+from the input layer to the output layer; every GEMM / attention operand is 16 bit with fp32 accumulation -- fp16 when the module was
+built with `use_fp16=True` / after `convert_to_fp16()` (the reference's own arithmetic type), bf16 otherwise; `set_compute_dtype`,
+`GVF_DIT_DTYPE` or an autocast region override it (ops/precision.py).  The elastic
 memory controller (gradient checkpointing by memory ratio) is a training device and is accepted but ignored."""
 from contextlib import contextmanager
 from typing import *
@@ -14,7 +16,7 @@ import torch.nn as nn
 
 from ... import sparse as sp
 from ..._lib import require_cuda
-from ...ops import dit_ops
+from ...ops import dit_ops, precision
 from .sparse_transformer import AbsolutePositionEmbedder, build_blocks, edge_weights, run_torso
 
 __all__ = ["SparseTransformerVAE"]
@@ -56,16 +58,25 @@ class SparseTransformerVAE(nn.Module):
         self.out_layer = sp.SparseLinear(model_channels, out_channels)
         self.initialize_weights()
         self._wcache = None
+        self.compute_dtype = None          # None: ops/precision.py's rule with the module default below
 
     @property
     def device(self):
         return next(self.parameters()).device
 
-    def convert_to_fp16(self):   # precision placement is inside the kernels
-        pass
+    def set_compute_dtype(self, dtype):
+        """torch.float16 / torch.bfloat16 (or "fp16" / "bf16"); None hands the choice back to ops/precision.py."""
+        self.compute_dtype = precision.parse(dtype)
+        return self
 
-    def convert_to_fp32(self):
-        pass
+    def _lp(self):
+        return precision.resolve(self.compute_dtype, (), torch.float16 if self.use_fp16 else torch.bfloat16)
+
+    def convert_to_fp16(self):   # the parameters stay fp32 (they are cast once per version); the kernels contract fp16
+        self.use_fp16, self.dtype = True, torch.float16
+
+    def convert_to_fp32(self):   # (no fp32 matrix path: 16-bit operands with fp32 accumulation, bf16 by default)
+        self.use_fp16, self.dtype = False, torch.float32
 
     def initialize_weights(self):
         for m in self.modules():
@@ -83,11 +94,12 @@ class SparseTransformerVAE(nn.Module):
 
     # ---- weights of the four edge layers (bf16, K padded to 64) ----------------------------------------------------------
     def _weights(self):
+        lp = self._lp()
         edge = (self.input_layer, self.to_latent, self.from_latent, self.out_layer)
-        ver = tuple((p.data_ptr(), p._version) for lin in edge for p in lin.parameters())
+        ver = (tuple((p.data_ptr(), p._version) for lin in edge for p in lin.parameters()), lp)
         if self._wcache is not None and self._wcache[0] == ver:
             return self._wcache[1]
-        W = {name: edge_weights(lin) for name, lin in zip(("input", "to_latent", "from_latent", "out"), edge)}
+        W = {name: edge_weights(lin, lp) for name, lin in zip(("input", "to_latent", "from_latent", "out"), edge)}
         self._wcache = (ver, W)
         return W
 
@@ -96,14 +108,15 @@ class SparseTransformerVAE(nn.Module):
         T, C = rows.shape[0], self.model_channels
         if T == 0:                                                                 # an empty voxel list maps to an empty one
             return torch.zeros((0, w_out[0].shape[0]), dtype=torch.float32, device=rows.device)
-        x = run_torso(st, rows, w_in, self.pos_embedder if self.pe_mode == "ape" else None, blocks, C)
+        lp = w_in[0].dtype
+        x = run_torso(st, rows, w_in, self.pos_embedder if self.pe_mode == "ape" else None, blocks, C, lp)
         if self.norm_output:                                                       # F.layer_norm default eps (:166,194)
-            hb = torch.empty((T, C), dtype=torch.bfloat16, device=rows.device)
-            dit_ops.layernorm_modulate_bf16(x, hb, 1e-5)
+            hb = torch.empty((T, C), dtype=lp, device=rows.device)
+            dit_ops.layernorm_modulate(x, hb, 1e-5)
         else:
-            hb = dit_ops.cast_pad_bf16(x, C)
+            hb = dit_ops.cast_pad(x, C, dtype=lp)
         out = torch.empty((T, w_out[0].shape[0]), dtype=torch.float32, device=rows.device)
-        return dit_ops.gemm_bf16(hb, *w_out, out, dit_ops.EPI_STORE_F32)
+        return dit_ops.gemm(hb, *w_out, out, dit_ops.EPI_STORE_F32)
 
     @torch.no_grad()
     def encode(self, x: sp.SparseTensor, sample_posterior=True, return_raw=False):

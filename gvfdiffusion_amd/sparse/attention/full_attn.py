@@ -8,7 +8,7 @@ from typing import *
 import torch
 
 from ..basic import SparseTensor
-from ...ops import dit_ops
+from ...ops import dit_ops, precision
 
 __all__ = ["sparse_scaled_dot_product_attention", "packed_varlen_attention"]
 
@@ -18,13 +18,16 @@ def _cu(lens: List[int], device) -> torch.Tensor:
 
 
 def packed_varlen_attention(q, k, v, q_lens: List[int], kv_lens: List[int], gamma_q=None, gamma_k=None):
-    """q [Tq,H,C], k/v [Tk,H,C] packed over sequences -> [Tq,H,C] (same dtype as q)."""
+    """q [Tq,H,C], k/v [Tk,H,C] packed over sequences -> [Tq,H,C] (same dtype as q).  fp16 / bf16 inputs are contracted in their own type
+    (the reference hands flash-attn whatever autocast produced: fp16 under accelerate's mixed_precision='fp16'); fp32 inputs take
+    ops/precision.py's choice."""
     Tq, H, C = q.shape
     dt = q.dtype
-    q, k, v = (t.to(torch.bfloat16) for t in (q, k, v))
+    lp = precision.resolve(None, (q, k, v))
+    q, k, v = (t.to(lp) for t in (q, k, v))
     q, k, v = (t if (t.stride(2) == 1 and t.stride(1) == C) else t.contiguous() for t in (q, k, v))
-    out = torch.empty((Tq, H, C), dtype=torch.bfloat16, device=q.device)
-    dit_ops.attention_varlen_bf16(q, k, v, out, _cu(q_lens, q.device), _cu(kv_lens, q.device), max(q_lens), max(kv_lens), H,
+    out = torch.empty((Tq, H, C), dtype=lp, device=q.device)
+    dit_ops.attention_varlen(q, k, v, out, _cu(q_lens, q.device), _cu(kv_lens, q.device), max(q_lens), max(kv_lens), H,
                                   (0, 0, q.stride(0)), (0, 0, k.stride(0)), (0, 0, v.stride(0)), (0, 0, out.stride(0)),
                                   gamma_q, gamma_k, head_dim=C)
     return out.to(dt)

@@ -9,6 +9,7 @@ import torch.nn as nn
 
 from .... import sparse as sp
 from ...._lib import require_cuda
+from ....ops import precision
 from ....model.sparse_voxel_diffusion.sparse_transformer import AbsolutePositionEmbedder, build_blocks, edge_weights, run_torso
 
 __all__ = ["SparseTransformerBase"]
@@ -33,15 +34,28 @@ class SparseTransformerBase(nn.Module):
         self.pos_embedder = AbsolutePositionEmbedder(model_channels)
         self.input_layer = sp.SparseLinear(in_channels, model_channels)
         self.blocks = build_blocks(self, model_channels, self.num_heads, mlp_ratio, use_checkpoint, qk_rms_norm=qk_rms_norm)
+        self.compute_dtype = None
 
     @property
     def device(self) -> torch.device:
         return next(self.parameters()).device
 
-    def convert_to_fp16(self) -> None:
-        """No-op: operand precision is fixed inside the kernels (bf16 operands, fp32 accumulation and residual stream)."""
+    def set_compute_dtype(self, dtype):
+        """torch.float16 / torch.bfloat16 (or "fp16" / "bf16"); None hands the choice back to ops/precision.py."""
+        self.compute_dtype = precision.parse(dtype)
+        return self
 
-    convert_to_fp32 = convert_to_fp16
+    def _lp(self):
+        """16-bit operand type of the GEMMs / attention (fp32 accumulation and residual stream either way): fp16 when built with
+        use_fp16 / after convert_to_fp16() -- upstream's torso then IS fp16 (base.py:93-101) --, bf16 otherwise."""
+        return precision.resolve(self.compute_dtype, (), torch.float16 if self.use_fp16 else torch.bfloat16)
+
+    def convert_to_fp16(self) -> None:
+        """The parameters stay fp32 (cast once per version); from here on the kernels contract fp16 operands."""
+        self.use_fp16, self.dtype = True, torch.float16
+
+    def convert_to_fp32(self) -> None:
+        self.use_fp16, self.dtype = False, torch.float32
 
     def initialize_weights(self) -> None:
         for m in self.modules():
@@ -54,7 +68,8 @@ class SparseTransformerBase(nn.Module):
     def forward_rows(self, x: sp.SparseTensor) -> torch.Tensor:
         """-> the residual stream after the last block, fp32 (T, model_channels)."""
         require_cuda(x.feats, x.coords)
-        return run_torso(x, x.feats, edge_weights(self.input_layer), self.pos_embedder, self.blocks, self.model_channels)
+        lp = self._lp()
+        return run_torso(x, x.feats, edge_weights(self.input_layer, lp), self.pos_embedder, self.blocks, self.model_channels, lp)
 
     def forward(self, x: sp.SparseTensor) -> sp.SparseTensor:
         return x.replace(self.forward_rows(x).to(self.dtype))

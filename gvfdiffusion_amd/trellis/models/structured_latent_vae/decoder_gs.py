@@ -59,12 +59,12 @@ class SLatGaussianDecoder(SparseTransformerBase):
         if x.feats.shape[0] == 0:
             return x.replace(torch.zeros((0, self.out_channels), dtype=x.dtype, device=x.device))
         h = self.forward_rows(x)
-        hb = torch.empty(h.shape, dtype=torch.bfloat16, device=h.device)
-        dit_ops.layernorm_modulate_bf16(h, hb, 1e-5)                              # F.layer_norm default eps (:119)
+        lp = self._lp()
+        hb = torch.empty(h.shape, dtype=lp, device=h.device)
+        dit_ops.layernorm_modulate(h, hb, 1e-5)                                   # F.layer_norm default eps (:119)
         lin = self.out_layer
         out = torch.empty((h.shape[0], self.out_channels), dtype=torch.float32, device=h.device)
-        dit_ops.gemm_bf16(hb, lin.weight.detach().to(torch.bfloat16).contiguous(), lin.bias.detach().float().contiguous(), out,
-                          dit_ops.EPI_STORE_F32)
+        dit_ops.gemm(hb, lin.weight.detach().to(lp).contiguous(), lin.bias.detach().float().contiguous(), out, dit_ops.EPI_STORE_F32)
         return x.replace(out.to(x.dtype))
 
     def forward(self, x: sp.SparseTensor) -> List[Gaussian]:

@@ -8,14 +8,17 @@ attention inside a window with scale head_dim^-0.5 (flash_attn_varlen_qkvpacked_
 from its definition); tanh-GELU MLP :115-126.  Operates on (feats (T, C), coords (T, 4) = batch, x, y, z).
 Pinned by tests/golden/sparse_vae_golden.npz (outputs of the reference classes imported in the build container).
 
-precision "bf16" rounds where the HIP path rounds: every GEMM / attention operand (LayerNorm outputs, q k v, the
-probabilities' numerators, the attention output, the GELU output), fp32 everywhere else."""
+precision "bf16" / "fp16" rounds where the HIP path rounds: every GEMM / attention operand (LayerNorm outputs, q k v, the
+probabilities' numerators, the attention output, the GELU output) to that type, fp32 everywhere else."""
 import torch
 import torch.nn.functional as F
 
 
+_LP = {"bf16": torch.bfloat16, "fp16": torch.float16}
+
+
 def _r(x, precision):
-    return x.to(torch.bfloat16).to(torch.float32) if precision == "bf16" else x
+    return x.to(_LP[precision]).to(torch.float32) if precision in _LP else x
 
 
 def _lin(x, sd, name, precision):
@@ -49,7 +52,7 @@ def attention_groups(q, k, v, gid, precision):
         idx = torch.nonzero(gid == g).squeeze(1)
         qg, kg, vg = (t[idx].permute(1, 0, 2) for t in (q, k, v))                 # (H, n, d)
         s = (qg @ kg.transpose(-1, -2)) * d ** -0.5
-        if precision == "bf16":
+        if precision in _LP:
             e = torch.exp(s - s.amax(dim=-1, keepdim=True))
             o = (_r(e, precision) @ vg) / e.sum(dim=-1, keepdim=True)
         else:

@@ -3,6 +3,7 @@ by the reference's own calc_window_partition / calc_serialization, and (GPU) the
 attention operators against dense per-sequence attention."""
 import os
 
+import math
 import numpy as np
 import pytest
 import torch
@@ -109,6 +110,14 @@ def test_varlen_attention_all_call_forms(cuda, C):
     for b, sl in enumerate(kv.layout):
         ref = _dense_ref(qd[b], kv.feats[sl][:, 0], kv.feats[sl][:, 1])
         assert float((o3[b].float() - ref).norm() / ref.norm()) < 6e-3
+    # fp16 inputs (what the reference's fp16 torso / autocast hands flash-attn) are contracted in fp16, not down-cast to bf16: 8 x closer
+    qkv16 = qkv.replace(qkv.feats.to(torch.float16))
+    o16 = spa(qkv16)
+    assert o16.feats.dtype == torch.float16
+    for sl in qkv16.layout:
+        f = qkv16.feats[sl].float()
+        ref = (torch.softmax(torch.einsum("qhc,khc->hqk", f[:, 0], f[:, 1]) / math.sqrt(C), dim=-1) @ f[:, 2].permute(1, 0, 2)).permute(1, 0, 2)
+        assert float((o16.feats[sl].float() - ref).norm() / ref.norm()) < 8e-4
 
 
 @pytest.mark.gpu

@@ -1,8 +1,8 @@
 """Static-VAE backbone on the HIP kernels (gvfdiffusion_amd/model/sparse_voxel_diffusion) against the torch oracle
 (oracle/sparse_vae_ref.py, pinned to the reference by tests/test_oracle_sparse_vae.py).
 
-Tolerances (relative L2, as for the DiT and the motion VAE): 1e-2 vs the bf16-placement oracle (same rounding points;
-differences = accumulation order, exp2 softmax), 3e-2 vs the fp32 oracle."""
+Tolerances (relative L2, measured value + ~50 %, per operand type): vs the same-type oracle (same rounding points; differences =
+accumulation order, exp2 softmax) and vs the fp32 oracle."""
 import json
 import math
 import os
@@ -13,7 +13,10 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-TOL16, TOL32 = 1e-2, 3e-2
+TOL16, TOL32 = 5e-3, 7.5e-3          # bf16 operands: measured 1.4e-3 .. 3.3e-3 vs the bf16-placement oracle, 3.6e-3 .. 4.8e-3 vs fp32
+# fp16 operands (use_fp16=True / convert_to_fp16() / set_compute_dtype("fp16") -- the reference's torso type): measured 2.5e-4 .. 4.7e-4 vs the
+# fp16-placement oracle, 4.2e-4 .. 6.0e-4 vs fp32
+TOL16_FP16, TOL32_FP16 = 7e-4, 9e-4
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "sparse_vae_golden.npz")
 
 
@@ -38,33 +41,38 @@ def _voxels(res, counts, seed):
     return torch.cat(out).int()
 
 
-def _run(cfg, sd, feats, coords, z_in=None):
+def _run(cfg, sd, feats, coords, z_in=None, dtype=None):
     from gvfdiffusion_amd import sparse as sp
     from gvfdiffusion_amd.model.sparse_voxel_diffusion import SparseTransformerVAE
     from oracle import sparse_vae_ref as ref
     m = SparseTransformerVAE(**cfg)
     m.load_state_dict(sd, strict=True)
     m = m.cuda()
+    if dtype is not None:
+        m.set_compute_dtype(dtype)
+    lp = "fp16" if m._lp() == torch.float16 else "bf16"        # the operand type this pass contracts (module default: use_fp16 -> fp16)
+    tol16, tol32 = (TOL16_FP16, TOL32_FP16) if lp == "fp16" else (TOL16, TOL32)
     x = sp.SparseTensor(feats.cuda(), coords.cuda())
     z, mean, logvar = m.encode(x, sample_posterior=False, return_raw=True)
     assert torch.equal(z.feats, mean) and torch.equal(z.coords, x.coords)
-    r32, r16 = ref.encode(sd, cfg, feats, coords), ref.encode(sd, cfg, feats, coords, "bf16")
+    r32, r16 = ref.encode(sd, cfg, feats, coords), ref.encode(sd, cfg, feats, coords, lp)
     for got, a, b, name in ((mean.cpu(), r16[0], r32[0], "mean"), (logvar.cpu(), r16[1], r32[1], "logvar")):
-        print(f"static vae {name}: rel-L2 vs bf16 oracle {_rel(got, a):.2e}, vs fp32 oracle {_rel(got, b):.2e}")
-        assert _rel(got, a) < TOL16 and _rel(got, b) < TOL32
+        print(f"static vae {name} [{lp}]: rel-L2 vs {lp} oracle {_rel(got, a):.2e}, vs fp32 oracle {_rel(got, b):.2e}")
+        assert _rel(got, a) < tol16 and _rel(got, b) < tol32
     zin = r32[0] if z_in is None else z_in
     y = m.decode(sp.SparseTensor(zin.cuda(), coords.cuda()))
-    d32, d16 = ref.decode(sd, cfg, zin, coords), ref.decode(sd, cfg, zin, coords, "bf16")
-    print(f"static vae decode: rel-L2 vs bf16 oracle {_rel(y.feats.cpu(), d16):.2e}, vs fp32 oracle {_rel(y.feats.cpu(), d32):.2e}")
-    assert _rel(y.feats.cpu(), d16) < TOL16 and _rel(y.feats.cpu(), d32) < TOL32
+    d32, d16 = ref.decode(sd, cfg, zin, coords), ref.decode(sd, cfg, zin, coords, lp)
+    print(f"static vae decode [{lp}]: rel-L2 vs {lp} oracle {_rel(y.feats.cpu(), d16):.2e}, vs fp32 oracle {_rel(y.feats.cpu(), d32):.2e}")
+    assert _rel(y.feats.cpu(), d16) < tol16 and _rel(y.feats.cpu(), d32) < tol32
     return m, x, y
 
 
+@pytest.mark.parametrize("dtype", [None, "fp16", "bf16"])
 @pytest.mark.parametrize("old", [False, True])
-def test_golden_config_both_qkv_layouts(cuda, old):
+def test_golden_config_both_qkv_layouts(cuda, old, dtype):
     z, cfg, sd = _golden()
     cfg = dict(cfg, use_old_attn_impl=old)
-    m, x, y = _run(cfg, sd, torch.from_numpy(z["feats"]), torch.from_numpy(z["coords"]))
+    m, x, y = _run(cfg, sd, torch.from_numpy(z["feats"]), torch.from_numpy(z["coords"]), dtype=dtype)
     tag = "old" if old else "new"
     # and against the reference's own outputs (fp32): the fixture's mean through the device decode
     assert _rel(y.feats.cpu(), torch.from_numpy(z[f"{tag}_out"])) < 5e-2
@@ -87,7 +95,11 @@ def test_released_width_ragged_batch(cuda):
     sd = _random_sd(SparseTransformerVAE(**cfg), 1)
     coords = _voxels(64, (3000, 1777), 2)
     feats = torch.randn((coords.shape[0], 1024), generator=torch.Generator().manual_seed(3))
-    _run(cfg, sd, feats, coords)
+    m, _, _ = _run(cfg, sd, feats, coords)                   # use_fp16=True: fp16 operands, as the reference's torso
+    assert m._lp() == torch.float16
+    _run(cfg, sd, feats, coords, dtype="bf16")
+    m.convert_to_fp32()
+    assert m._lp() == torch.bfloat16 and m.dtype == torch.float32
 
 
 def test_full_attention_mode_and_single_block_module(cuda):
@@ -151,8 +163,9 @@ def test_framework_representation_and_render(cuda):
 SLAT = os.path.join(os.path.dirname(__file__), "golden", "slat_decoder_golden.npz")
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("tag,rms", [("rms", True), ("plain", False)])
-def test_slat_gaussian_decoder(cuda, tag, rms):
+def test_slat_gaussian_decoder(cuda, tag, rms, dtype):
     from gvfdiffusion_amd import sparse as sp
     from gvfdiffusion_amd.trellis.models import SLatGaussianDecoder
     from oracle import sparse_vae_ref as ref
@@ -164,13 +177,19 @@ def test_slat_gaussian_decoder(cuda, tag, rms):
     m.load_state_dict(sd, strict=True)                       # incl. the offset_perturbation buffer of the reference
     assert torch.allclose(SLatGaussianDecoder(**cfg).offset_perturbation, sd["offset_perturbation"], atol=1e-6)
     m = m.cuda()
+    if dtype == "fp16":
+        m.convert_to_fp16()                                  # upstream's switch (base.py:93-101): the torso contracts fp16 from here on
+        assert m._lp() == torch.float16 and m.dtype == torch.float16
+    else:
+        assert m._lp() == torch.bfloat16
+    tol16, tol32 = (TOL16_FP16, TOL32_FP16) if dtype == "fp16" else (TOL16, TOL32)
     feats, coords = torch.from_numpy(z["feats"]), torch.from_numpy(z["coords"])
     x = sp.SparseTensor(feats.cuda(), coords.cuda())
     rows = m.decode_rows(x).feats.cpu()
-    r16, r32 = ref.slat_decode_rows(sd, cfg, feats, coords, "bf16"), ref.slat_decode_rows(sd, cfg, feats, coords)
-    print(f"slat decoder ({tag}) rows: rel-L2 vs bf16 oracle {_rel(rows, r16):.2e}, vs fp32 oracle {_rel(rows, r32):.2e}")
-    assert _rel(rows, r16) < TOL16 and _rel(rows, r32) < TOL32
-    assert _rel(rows, torch.from_numpy(z[f"{tag}_rows"])) < TOL32           # the reference's own output
+    r16, r32 = ref.slat_decode_rows(sd, cfg, feats, coords, dtype), ref.slat_decode_rows(sd, cfg, feats, coords)
+    print(f"slat decoder ({tag}, {dtype}) rows: rel-L2 vs {dtype} oracle {_rel(rows, r16):.2e}, vs fp32 oracle {_rel(rows, r32):.2e}")
+    assert _rel(rows, r16) < tol16 and _rel(rows, r32) < tol32
+    assert _rel(rows, torch.from_numpy(z[f"{tag}_rows"])) < tol32           # the reference's own output
     # representation: feed the reference's rows through to_representation -> its Gaussians, accessor by accessor
     reps = m.to_representation(x.replace(torch.from_numpy(z[f"{tag}_rows"]).cuda()))
     g = reps[1]
