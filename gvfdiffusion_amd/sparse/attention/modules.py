@@ -2,7 +2,7 @@
 the reference's model/sparse_attention/modules.py:56-185, so its state dicts load unchanged:
 `to_qkv` | (`to_q`, `to_kv`), `to_out`, `q_rms_norm.gamma` / `k_rms_norm.gamma`.
 
-How a call runs here: the projections are the bf16 MFMA GEMM (fp32 accumulate, fp32 bias), the channels are viewed as
+How a call runs here: the projections are the 16-bit MFMA GEMM (the input's own fp16 / bf16, else ops/precision.py; fp32 accumulate, fp32 bias), the channels are viewed as
 [q|k|v][head][c] (or, with `use_old_attn_impl`, the older [head][q|k|v][c] of sparse/attention/modules.py:150-162), and the
 token lists go to the varlen flash kernel directly or after the window / serialisation gather.  QK-RMSNorm is not a separate
 pass: the per-head gains are handed to the kernel, which normalises q and k in its prologue.  RoPE is not built."""
