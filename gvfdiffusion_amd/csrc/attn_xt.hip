@@ -65,6 +65,9 @@
 #ifndef XT_ABL_EXPSRC
 #define XT_ABL_EXPSRC 0       // 1: the exponentials read lane constants instead of the score tile (no MFMA -> VALU dependency; scores kept alive)
 #endif
+#ifndef XT_UNROLL
+#define XT_UNROLL 1           // 1: the steady-state loop is unrolled over one period of the staging ring (TPS * NBUF tiles): ring slots become constants
+#endif
 #ifndef XT_ORDER
 #define XT_ORDER 0            // 0: every MFMA followed by 8-12 VALU instructions; 1: all VALU work of a phase first, then all its MFMAs
 #endif
@@ -488,7 +491,35 @@ __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(
             // steady state, iterations t = 1 .. T-2.  Entering stage s = t / TPS: one barrier -- stage s+1 has landed
             // (iteration t may prefetch K(t+1) from it) and every wave is done with stage s-1, whose ring slot takes the
             // DMA of stage s+2.
-            for (int t = 1; t + 1 < T; ++t) {
+            int t = 1;
+#if XT_UNROLL
+            // whole periods of the ring: tile t + j sits at ring position (1 + j) % PER whenever (t - 1) % PER == 0 -- every LDS address of the
+            // body is the lane's base plus a constant, the stage test a constant
+            constexpr int PER = XT_TPS * XT_NBUF;
+#define XT_RING(p_) (&smem[((p_) % PER) * XT_TILE_CHUNKS])
+            for (; t + PER < T; t += PER) {
+#pragma unroll
+                for (int j = 0; j < PER; ++j) {
+                    if (!XT_ABL_NOSYNC && (1 + j) % XT_TPS == 0) {
+                        __syncthreads();
+                        const int s2 = (t + j) / XT_TPS + 2;
+#pragma unroll
+                        for (int i_ = 0; i_ < XT_TPS; ++i_) {
+                            const int t_ = s2 * XT_TPS + i_;
+                            if (t_ < T) {
+                                uint4* dst_ = XT_RING((((1 + j) / XT_TPS + 2) % XT_NBUF) * XT_TPS + i_);
+                                xt_dma16(kbase + (long long)t_ * 256 + wave * 64 + lane, dst_ + wave * 64);
+                                xt_dma16(vbase + (long long)t_ * 256 + wave * 64 + lane, dst_ + 256 + wave * 64);
+                            }
+                        }
+                    }
+                    xt_phase<DT, true, true, false, 1>(kf, vf, XT_RING(1 + j) + 256, qf[0], sQw, sA, sB, oB, lB4, l4B, l4Bb, l31, half, XT_KT, cA);
+                    xt_phase<DT, true, true, false, 2>(kf, vf, XT_RING(2 + j), qf[1], sQw + 128, sB, sA, oA, lA4, l4A, l4Ab, l31, half, XT_KT, cB);
+                }
+            }
+#undef XT_RING
+#endif
+            for (; t + 1 < T; ++t) {
                 if (!XT_ABL_NOSYNC && t % XT_TPS == 0) {
                     __syncthreads();
                     const int s2 = t / XT_TPS + 2;
