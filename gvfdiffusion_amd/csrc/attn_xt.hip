@@ -180,7 +180,7 @@ __device__ __forceinline__ typename GvfLp<DT>::x8 xt_ld_v(const uint4* sV, int g
 
 // c0: initial value of the score accumulators.  bf16: zero (the compiler folds it into the MFMA's inline constant).  fp16: the splat of
 // minus the query's shift (see attn_xt_kernel) -- exp2 of a raw score would leave fp16's range.
-template <int DT, bool DO_QK, bool DO_SM, bool MASK, int PF>
+template <int DT, bool DO_QK, bool DO_SM, bool MASK, int PF, bool SHIFT = GvfLp<DT>::kNeedsShift>
 __device__ __forceinline__ void xt_phase(typename GvfLp<DT>::x8 (&kf)[2][2], typename GvfLp<DT>::x8 (&vf)[4], const uint4* __restrict__ sNext,
                                          const typename GvfLp<DT>::x8 (&qf_in)[2], const uint4* __restrict__ sQ,
                                          f32x16 (&s_out)[2], const f32x16 (&s_in)[2], f32x16& o_acc, float (&l_acc)[4], f32x4& l4, f32x4& l4b,
@@ -189,7 +189,7 @@ __device__ __forceinline__ void xt_phase(typename GvfLp<DT>::x8 (&kf)[2][2], typ
     typedef typename LP::x8 x8;
     typedef typename LP::x4 x4;
     const f32x16 zero_ = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const f32x16 zero = LP::kNeedsShift ? c0 : zero_;
+    const f32x16 zero = SHIFT ? c0 : zero_;
     float pe[8];
     unsigned pw[4][4];
     unsigned pconst[4] = {0x3c003c00u + (unsigned)l31, 0x3c003c01u, 0x3c003c02u, 0x3c003c03u};
@@ -376,7 +376,11 @@ __device__ __forceinline__ void xt_take_shift(f32x16 (&s)[2], f32x16& c) {
     for (int r = 0; r < 16; ++r) { s[0][r] -= m; s[1][r] -= m; c[r] = -m; }
 }
 
-template <int DT>
+// SHIFT: the per-query shift of the fp16 path (see xt_take_shift).  false for bf16, and for fp16 when the caller vouches that every score is
+// bounded above (GVF_ATTN_SCORES_BOUNDED: q . k' <= 15.5 in the log2 domain -- RMS-normalised q and k with known gains): P = exp2(s) then
+// fits fp16 by itself, the kernel is the bf16 one with the other MFMA opcode (no 32 splat registers, no shift pass).  A broken
+// promise overflows to inf and lands in the same range guard -> exact fallback.
+template <int DT, bool SHIFT>
 __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(XtParams p, int force_safe) {
     typedef GvfLp<DT> LP;
     typedef typename LP::x8 x8;
@@ -480,14 +484,14 @@ __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(
 #pragma unroll
             for (int i = 0; i < 4; ++i) kf[i >> 1][i & 1] = xt_ld_k<DT>(XT_K(0), i >> 1, i & 1, l31, half);
         }
-        xt_phase<DT, true, false, false, 1>(kf, vf, XT_V(0), qf[0], sQw, sA, sB, oB, lB4, l4B, l4Bb, l31, half, XT_KT, cA);
-        if (LP::kNeedsShift) xt_take_shift<DT>(sA, cA);
+        xt_phase<DT, true, false, false, 1, SHIFT>(kf, vf, XT_V(0), qf[0], sQw, sA, sB, oB, lB4, l4B, l4Bb, l31, half, XT_KT, cA);
+        if (SHIFT) xt_take_shift<DT>(sA, cA);
 #if XT_SKEW
         if (__builtin_amdgcn_s_getreg(((4 - 1) << 11) | 4) & 1) __builtin_amdgcn_s_sleep(XT_SKEW);      // HW_ID.WAVE_ID
 #endif
         if (T > 1) {
-            xt_phase<DT, true, true, false, 2>(kf, vf, XT_K(1), qf[1], sQw + 128, sB, sA, oA, lA4, l4A, l4Ab, l31, half, XT_KT, cB);
-            if (LP::kNeedsShift) xt_take_shift<DT>(sB, cB);
+            xt_phase<DT, true, true, false, 2, SHIFT>(kf, vf, XT_K(1), qf[1], sQw + 128, sB, sA, oA, lA4, l4A, l4Ab, l31, half, XT_KT, cB);
+            if (SHIFT) xt_take_shift<DT>(sB, cB);
             // steady state, iterations t = 1 .. T-2.  Entering stage s = t / TPS: one barrier -- stage s+1 has landed
             // (iteration t may prefetch K(t+1) from it) and every wave is done with stage s-1, whose ring slot takes the
             // DMA of stage s+2.
@@ -513,8 +517,8 @@ __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(
                             }
                         }
                     }
-                    xt_phase<DT, true, true, false, 1>(kf, vf, XT_RING(1 + j) + 256, qf[0], sQw, sA, sB, oB, lB4, l4B, l4Bb, l31, half, XT_KT, cA);
-                    xt_phase<DT, true, true, false, 2>(kf, vf, XT_RING(2 + j), qf[1], sQw + 128, sB, sA, oA, lA4, l4A, l4Ab, l31, half, XT_KT, cB);
+                    xt_phase<DT, true, true, false, 1, SHIFT>(kf, vf, XT_RING(1 + j) + 256, qf[0], sQw, sA, sB, oB, lB4, l4B, l4Bb, l31, half, XT_KT, cA);
+                    xt_phase<DT, true, true, false, 2, SHIFT>(kf, vf, XT_RING(2 + j), qf[1], sQw + 128, sB, sA, oA, lA4, l4A, l4Ab, l31, half, XT_KT, cB);
                 }
             }
 #undef XT_RING
@@ -525,15 +529,15 @@ __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(
                     const int s2 = t / XT_TPS + 2;
                     if (s2 < n_stages) { XT_STAGE(s2) }
                 }
-                xt_phase<DT, true, true, false, 1>(kf, vf, XT_V(t), qf[0], sQw, sA, sB, oB, lB4, l4B, l4Bb, l31, half, XT_KT, cA);
-                xt_phase<DT, true, true, false, 2>(kf, vf, XT_K(t + 1), qf[1], sQw + 128, sB, sA, oA, lA4, l4A, l4Ab, l31, half, XT_KT, cB);
+                xt_phase<DT, true, true, false, 1, SHIFT>(kf, vf, XT_V(t), qf[0], sQw, sA, sB, oB, lB4, l4B, l4Bb, l31, half, XT_KT, cA);
+                xt_phase<DT, true, true, false, 2, SHIFT>(kf, vf, XT_K(t + 1), qf[1], sQw + 128, sB, sA, oA, lA4, l4A, l4Ab, l31, half, XT_KT, cB);
             }
             if ((T - 1) % XT_TPS == 0) __syncthreads();      // the last tile opens a stage: it must have landed
-            xt_phase<DT, true, true, false, 1>(kf, vf, XT_V(T - 1), qf[0], sQw, sA, sB, oB, lB4, l4B, l4Bb, l31, half, XT_KT, cA);
+            xt_phase<DT, true, true, false, 1, SHIFT>(kf, vf, XT_V(T - 1), qf[0], sQw, sA, sB, oB, lB4, l4B, l4Bb, l31, half, XT_KT, cA);
         }
-        xt_phase<DT, true, true, true, 0>(kf, vf, XT_K(0), qf[1], sQw + 128, sB, sA, oA, lA4, l4A, l4Ab, l31, half, last_valid, cB);
-        if (LP::kNeedsShift && T == 1) xt_take_shift<DT>(sB, cB);      // a single key tile: sub-tile B's first scores come out of this phase
-        xt_phase<DT, false, true, true, 0>(kf, vf, XT_K(0), qf[1], sQw, sA, sB, oB, lB4, l4B, l4Bb, l31, half, last_valid, cB);
+        xt_phase<DT, true, true, true, 0, SHIFT>(kf, vf, XT_K(0), qf[1], sQw + 128, sB, sA, oA, lA4, l4A, l4Ab, l31, half, last_valid, cB);
+        if (SHIFT && T == 1) xt_take_shift<DT>(sB, cB);      // a single key tile: sub-tile B's first scores come out of this phase
+        xt_phase<DT, false, true, true, 0, SHIFT>(kf, vf, XT_K(0), qf[1], sQw, sA, sB, oB, lB4, l4B, l4Bb, l31, half, last_valid, cB);
 #if XT_SUM_MFMA
         lA = l4A[0] + l4Ab[0]; lB = l4B[0] + l4Bb[0];
 #else
@@ -544,7 +548,8 @@ __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(
         lB += __shfl_xor(lB, 32, 64);
         // range guard (NaN fails both comparisons).  fp16: with the shift the denominator is >= 1 unless a single, partly padded key tile
         // pushed every probability under 2^-12 (the padding's zero scores took part in the shift)
-        const float l_min = LP::kNeedsShift ? 0.015625f : 7.8886e-31f;
+        // fp16 without the shift (bounded scores): every probability is >= 2^-14, so is the sum; below that the promise was broken
+        const float l_min = SHIFT ? 0.015625f : (LP::kNeedsShift ? 3.0517578125e-05f : 7.8886e-31f);
         const bool okA = lA > l_min && lA < 1.2676e30f, okB = lB > l_min && lB < 1.2676e30f;
         bad = !(okA && okB);
         if (XT_ABL_NOEXP || XT_ABL_NOQK || XT_ABL_NOPV || XT_ABL_NOSUM || XT_ABL_NOSYNC || XT_ABL_NOLDS) bad = false;   // timing experiments
@@ -733,7 +738,11 @@ extern "C" int gvf_attn_tiled_fwd(int dtype, const void* q, const void* k_tiles,
     const long long blocks = (long long)p.q_blocks * H * n_inner * n_outer;
     if (blocks > 0x7fffffffLL) return GVF_EINVAL;
     (void)hipGetLastError();
-    GVF_LP_DISPATCH(dtype, attn_xt_kernel<DT><<<dim3((unsigned)blocks), dim3(XT_THREADS), 0, (hipStream_t)stream_>>>(p, force_exact));
+    const int force_safe = force_exact & GVF_ATTN_FORCE_EXACT;
+    const bool bounded = (force_exact & GVF_ATTN_SCORES_BOUNDED) != 0;
+    GVF_LP_DISPATCH(dtype,
+        if (GvfLp<DT>::kNeedsShift && !bounded) attn_xt_kernel<DT, true><<<dim3((unsigned)blocks), dim3(XT_THREADS), 0, (hipStream_t)stream_>>>(p, force_safe);
+        else attn_xt_kernel<DT, false><<<dim3((unsigned)blocks), dim3(XT_THREADS), 0, (hipStream_t)stream_>>>(p, force_safe));
     GVF_CHECK_LAUNCH();
     return GVF_OK;
 }

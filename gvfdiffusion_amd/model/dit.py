@@ -281,9 +281,11 @@ class DiT(nn.Module):
                 m = getattr(blk, name)
                 if isinstance(m, MultiHeadAttention):
                     b[name] = dict(qkv=prep(m.to_qkv), out=prep(m.to_out), gq=m._gammas()[0], gk=m._gammas()[1])
+                    b[name]["bounded"] = dit_ops.scores_bounded(*m._gammas())     # fp16: no per-query shift needed (see attn_xt.hip)
             for name in ("image_cross_attn", "static_cross_attn"):
                 m = getattr(blk, name)
                 b[name] = dict(q=prep(m.to_q), kv=prep(m.to_kv), kv_f32=prep32(m.to_kv), out=prep(m.to_out), gq=m._gammas()[0], gk=m._gammas()[1])
+                b[name]["bounded"] = dit_ops.scores_bounded(*m._gammas())
             b["fc1"], b["fc2"] = prep(blk.mlp.mlp[0]), prep(blk.mlp.mlp[2])
             b["n3"] = (blk.norm3.weight.detach().float().contiguous(), blk.norm3.bias.detach().float().contiguous())
             b["n4"] = (blk.norm4.weight.detach().float().contiguous(), blk.norm4.bias.detach().float().contiguous())
@@ -536,7 +538,7 @@ class DiT(nn.Module):
             # K (RMS-normed, pre-scaled) and V^T of this step's projection into the tiled image, then the tiled-cache kernel
             dit_ops.attention_pack_kv(qkv, B * T, N, H, C, 2 * C, gamma_k=a["gk"], out=kv_self)
             dit_ops.attention_tiled(qkv, kv_self[0], kv_self[1], ab, B * T, 1, N, N, H, (N * 3 * C, 0, 3 * C), (N * C, 0, C), 1, 0,
-                                    gamma_q=a["gq"])
+                                    gamma_q=a["gq"], bounded=a["bounded"])
             resid(ab, a["out"], g_s)
             # -- temporal self attention over T (strided views, no transposes)
             if not self.no_temporal_attn:
@@ -550,13 +552,13 @@ class DiT(nn.Module):
             a = b["image_cross_attn"]
             ln_gemm(a["q"], ab, dit_ops.EPI_STORE_16, ln_w=b["n3"][0], ln_b=b["n3"][1])
             kt, vt = ctx["kv_img"][i]
-            dit_ops.attention_tiled(ab, kt, vt, hb, B * T, 1, N, Li, H, (N * C, 0, C), (N * C, 0, C), 1, 0, gamma_q=a["gq"])
+            dit_ops.attention_tiled(ab, kt, vt, hb, B * T, 1, N, Li, H, (N * C, 0, C), (N * C, 0, C), 1, 0, gamma_q=a["gq"], bounded=a["bounded"])
             resid(hb, a["out"])
             # -- static cross attention: K/V shared by the T frames of a sample (inner stride 0)
             a = b["static_cross_attn"]
             ln_gemm(a["q"], ab, dit_ops.EPI_STORE_16, ln_w=b["n4"][0], ln_b=b["n4"][1])
             kt, vt = ctx["kv_st"][i]
-            dit_ops.attention_tiled(ab, kt, vt, hb, B, T, N, Ls, H, (TN * C, N * C, C), (TN * C, N * C, C), 1, 0, gamma_q=a["gq"])
+            dit_ops.attention_tiled(ab, kt, vt, hb, B, T, N, Ls, H, (TN * C, N * C, C), (TN * C, N * C, C), 1, 0, gamma_q=a["gq"], bounded=a["bounded"])
             resid(hb, a["out"])
             # -- MLP
             ln_gemm(b["fc1"], hidden, dit_ops.EPI_GELU_16, shift=sh_m, scale=sc_m)
@@ -644,10 +646,10 @@ class DiT(nn.Module):
             n3, n4 = dict(ln_w=b["n3"][0], ln_b=b["n3"][1]), dict(ln_w=b["n4"][0], ln_b=b["n4"][1])
             a = b["spatial_self_attn"]
             if tiled_kv:
-                dit_ops.attention_tiled(qs, kv_self[0], kv_self[1], ab, *fr["n"], N, N, H, fr["c"], fr["c"], *fr["kv"], gamma_q=a["gq"])
+                dit_ops.attention_tiled(qs, kv_self[0], kv_self[1], ab, *fr["n"], N, N, H, fr["c"], fr["c"], *fr["kv"], gamma_q=a["gq"], bounded=a["bounded"])
             else:                                              # (never padded: see _forward)
                 dit_ops.attention_pack_kv(qkv, B * T, N, H, C, 2 * C, gamma_k=a["gk"], out=kv_self)
-                dit_ops.attention_tiled(qkv, kv_self[0], kv_self[1], ab, *fr["n"], N, N, H, fr["c3"], fr["c"], *fr["kv"], gamma_q=a["gq"])
+                dit_ops.attention_tiled(qkv, kv_self[0], kv_self[1], ab, *fr["n"], N, N, H, fr["c3"], fr["c"], *fr["kv"], gamma_q=a["gq"], bounded=a["bounded"])
             ai = b["image_cross_attn"]
             if self.no_temporal_attn:
                 fused(ab, s["s2"], b1=a["out"][1], gate1=g_s, ln1=n3, out3=qb, b3=ai["q"][1])
@@ -663,11 +665,11 @@ class DiT(nn.Module):
                     dit_ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], ab, B, N, T, T, H, st, st, st, (TNp * C, C, N * C), at["gq"], at["gk"])
                     fused(ab, s["s3"], b1=at["out"][1], gate1=g_t, ln1=n3, out3=qb, b3=ai["q"][1])
             kt, vt = ctx["kv_img"][i]
-            dit_ops.attention_tiled(qb, kt, vt, hb, *fr["n"], N, Li, H, fr["c"], fr["c"], *fr["kv"], gamma_q=ai["gq"])
+            dit_ops.attention_tiled(qb, kt, vt, hb, *fr["n"], N, Li, H, fr["c"], fr["c"], *fr["kv"], gamma_q=ai["gq"], bounded=ai["bounded"])
             ast = b["static_cross_attn"]
             fused(hb, s["s4"], b1=ai["out"][1], ln1=n4, out3=qb, b3=ast["q"][1])
             kt, vt = ctx["kv_st"][i]
-            dit_ops.attention_tiled(qb, kt, vt, hb, B, T, N, Ls, H, fr_c, fr_c, 1, 0, gamma_q=ast["gq"])
+            dit_ops.attention_tiled(qb, kt, vt, hb, B, T, N, Ls, H, fr_c, fr_c, 1, 0, gamma_q=ast["gq"], bounded=ast["bounded"])
             kw = dict(b1=ast["out"][1], ln1=dict(shift=sh_m, scale=sc_m), mlp_bias=(b["fc1"][1], b["fc2"][1]), hidden=hidden_units, gate_m=g_m)
             if i + 1 < len(blocks):
                 on = offs[i + 1]

@@ -3,6 +3,7 @@
 The 16-bit operand type of a call (GVF_DT_BF16 / GVF_DT_F16 of the C ABI) is the torch dtype of its operand tensors: torch.bfloat16 or
 torch.float16; buffers without a dtype of their own (the uint8 K / V^T tile images, packed weight streams) take it as an argument."""
 import ctypes
+import os
 
 import torch
 
@@ -408,16 +409,37 @@ def attention_pack_kv(kv: torch.Tensor, n_sets: int, L: int, H: int, k_col0: int
 
 
 def attention_tiled(q, k_tiles, v_tiles, out, n_outer, n_inner, Lq, Lk, H, q_strides, o_strides, kv_stride_outer,
-                         kv_stride_inner, gamma_q=None, force_exact=False, fallback_counter=None):
-    """Cross attention against a tiled K/V cache (head_dim 32) of q's 16-bit type; see include/gvf_dit.h."""
+                         kv_stride_inner, gamma_q=None, force_exact=False, fallback_counter=None, bounded=False):
+    """Cross attention against a tiled K/V cache (head_dim 32) of q's 16-bit type; see include/gvf_dit.h.  bounded: the caller vouches that
+    every log2-domain score is <= 14 in magnitude (scores_bounded() below): fp16 then runs without the per-query shift."""
     _lib.require_cuda(q, k_tiles, v_tiles, out)
     assert q.dtype in LP_DTYPES and out.dtype in (q.dtype, torch.float32)
     _lib.check(_lib.lib().gvf_attn_tiled_fwd(dt_code(q.dtype), _p(q), _p(k_tiles), _p(v_tiles), _p(out), n_outer, n_inner, Lq, Lk, H,
                                              _s4(q_strides), _s4(o_strides), int(kv_stride_outer), int(kv_stride_inner),
-                                             _p(gamma_q), int(out.dtype == torch.float32), int(bool(force_exact)),
+                                             _p(gamma_q), int(out.dtype == torch.float32), int(bool(force_exact)) | (2 if bounded else 0),
                                              _p(fallback_counter), _stream(q)),
                "gvf_attn_tiled_fwd")
     return out
+
+
+ATTN_SCORE_BOUND = 15.5          # log2 units: exp2(15.5) < 65504, fp16's largest number (GVF_ATTN_SCORES_BOUNDED, include/gvf_dit.h)
+
+
+def scores_bounded(gamma_q, gamma_k, head_dim=32, scale=None, strict=False) -> bool:
+    """Can the fp16 tiled attention run without its per-query shift (bounded=True)?  With u, v the unit vectors of a query and a key of one
+    head, the log2-domain score of MultiHeadRMSNorm'ed q and k is head_dim * sum_d u_d v_d gq_d gk_d * scale * log2 e.
+    strict: the worst case over every u, v -- head_dim * max_d |gq_d gk_d| ... <= ATTN_SCORE_BOUND (all of a query's and a key's energy in the
+    one channel with the largest gain product).  Default: the same expression with the root-mean-square of gq gk over a head's channels
+    (what aligned u = v with evenly spread energy reach; gains of 1 give 8.2 against 15.5), maximum over the heads: a HINT, not a proof --
+    the launch does not need one: an overflow (or a query whose scores all sit below -15) fails the kernel's range guard and its workgroup
+    is recomputed with the running maximum (tests/test_dit_fp16_gpu.py::test_tiled_cache_attention_fp16_broken_bound_falls_back); a wrong
+    hint costs time, never correctness.  Reads the two gain tensors on the host: call it once per weight version."""
+    if gamma_q is None or gamma_k is None or os.environ.get("GVF_ATTN_BOUNDED", "1") == "0":      # (the switch: A/B measurements)
+        return False
+    scale = head_dim ** -0.5 if scale is None else scale
+    g = (gamma_q.float() * gamma_k.float()).reshape(-1, head_dim)
+    worst = float(g.abs().max()) if strict else float(g.square().mean(dim=1).sqrt().max())
+    return head_dim * worst * scale * LOG2E * 1.01 <= ATTN_SCORE_BOUND
 
 
 def layernorm_modulate(x, out, eps=1e-6, ln_w=None, ln_b=None, shift=None, scale=None, mod_ld=0, rows_per_group=0):

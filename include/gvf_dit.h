@@ -194,7 +194,13 @@ int gvf_attn_pack_kv_bf16(const void* kv, int kv_is_f32, int64_t ld, int k_col0,
  * a workgroup with a query outside recomputes its 256 queries with the exact online softmax (force_exact != 0: always).
  * GVF_DT_F16: every query's scores are shifted by its maximum over the first key tile (through the MFMA accumulator's
  * initial value), so that exp2 stays inside fp16's range; an overflow (a later score 2^16 above that) fails the same guard.
+ * force_exact is a set of flags: GVF_ATTN_FORCE_EXACT (1) = always the exact path; GVF_ATTN_SCORES_BOUNDED (2) = the caller vouches that
+ * no log2-domain score q . k' exceeds 15.5 (RMS-normalised q and k with known gains: 32 max_d |gamma_q gamma_k| scale log2 e): the fp16
+ * kernel then skips the shift (exp2 of such a score fits fp16) and is the bf16 kernel with the other MFMA opcode; a broken promise
+ * overflows to inf -- and a query whose scores all sit below -15 underflows -- into the same guard and is recomputed exactly.  Ignored for bf16.
  * fallback_counter (optional, device int32): += 1 per workgroup that took the exact path. */
+#define GVF_ATTN_FORCE_EXACT 1
+#define GVF_ATTN_SCORES_BOUNDED 2
 int gvf_attn_tiled_fwd(int dtype, const void* q, const void* k_tiles, const void* v_tiles, void* out, int n_outer, int n_inner,
                        int Lq, int Lk, int H, const int64_t* q_strides, const int64_t* o_strides,
                        int64_t kv_set_stride_outer, int64_t kv_set_stride_inner, const float* gamma_q,

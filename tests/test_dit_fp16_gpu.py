@@ -235,6 +235,47 @@ def test_tiled_cache_attention_fp16_range_guard(cuda):
             assert top > 16.0 and 1 <= n_fb < total
 
 
+@pytest.mark.parametrize("n_outer,n_inner,Lq,Lk,H,shared", [(1, 3, 512, 4096, 2, True), (2, 2, 512, 1370, 3, False), (2, 3, 300, 70, 4, False), (1, 1, 1, 1, 1, True)])
+def test_tiled_cache_attention_fp16_bounded_scores_skip_the_shift(cuda, n_outer, n_inner, Lq, Lk, H, shared):
+    """GVF_ATTN_SCORES_BOUNDED: RMS-normalised q and k with gains around 1 cannot score beyond +-14 octaves (dit_ops.scores_bounded), so
+    P = exp2(s) is a normal fp16 number without any shift: the fp16 launch is the bf16 kernel with the other MFMA opcode.  Same accuracy as
+    the shifted path, no fallback."""
+    q, _, kt, vt, gq, st, ref = _tiled_case(cuda, n_outer, n_inner, Lq, Lk, H, shared, True, seed=Lq * 7 + Lk)
+    one = torch.ones((H, 32), device=cuda)
+    # 32 * |gq gk| / sqrt(32) * log2(e) * 1.01 = 8.24 |gq gk| against 15.5: gain products up to 1.88 fit (strict: the largest product of a
+    # channel; default: the root mean square over a head's channels -- a hint, the range guard is what guarantees the result)
+    assert dit_ops.scores_bounded(one, one, strict=True) and dit_ops.scores_bounded(1.3 * one, 1.4 * one, strict=True)
+    assert not dit_ops.scores_bounded(1.4 * one, 1.4 * one) and not dit_ops.scores_bounded(1.4 * one, 1.4 * one, strict=True)
+    spiky = one.clone(); spiky[0, 0] = 2.5
+    assert dit_ops.scores_bounded(spiky, one) and not dit_ops.scores_bounded(spiky, one, strict=True)
+    assert not dit_ops.scores_bounded(None, one)            # no RMSNorm, no bound
+    fb = torch.zeros(1, dtype=torch.int32, device=cuda)
+    kso, ksi = (1, 0) if shared else (n_inner, 1)
+    out, out_s = torch.empty_like(q), torch.empty_like(q)
+    dit_ops.attention_tiled(q, kt, vt, out, n_outer, n_inner, Lq, Lk, H, st, st, kso, ksi, gamma_q=gq, fallback_counter=fb, bounded=True)
+    dit_ops.attention_tiled(q, kt, vt, out_s, n_outer, n_inner, Lq, Lk, H, st, st, kso, ksi, gamma_q=gq)
+    r, rs = rel_l2(out, ref), rel_l2(out_s, ref)
+    print(f"fp16 tiled attention, bounded scores, o{n_outer} i{n_inner} Lq{Lq} Lk{Lk} H{H}: rel_l2 {r:.2e} (with the shift {rs:.2e}), fallbacks {int(fb.item())}")
+    assert int(fb.item()) == 0 and r < 5e-4
+
+
+def test_tiled_cache_attention_fp16_broken_bound_falls_back(cuda):
+    """The caller's promise is checked by the same range guard: keys 40 x larger than promised overflow exp2 to inf, every affected workgroup
+    recomputes with the running maximum, the result stays exact."""
+    n_outer, n_inner, Lq, Lk, H = 1, 2, 512, 1000, 2
+    q, kv, kt, vt, _, st, _ = _tiled_case(cuda, n_outer, n_inner, Lq, Lk, H, True, False, seed=3, k_gain=40.0)
+    fb = torch.zeros(1, dtype=torch.int32, device=cuda)
+    out = torch.empty_like(q)
+    dit_ops.attention_tiled(q, kt, vt, out, n_outer, n_inner, Lq, Lk, H, st, st, 1, 0, fallback_counter=fb, bounded=True)
+    kset = kv.reshape(n_outer, Lk, 2, H, 32)[:, None].expand(n_outer, n_inner, Lk, 2, H, 32).reshape(n_outer * n_inner, Lk, 2, H, 32)
+    k2 = h(kset[:, :, 0] * (dit_ref.LOG2E / math.sqrt(32))).double().permute(0, 2, 1, 3)
+    s = q.reshape(n_outer * n_inner, Lq, H, 32).double().permute(0, 2, 1, 3) @ k2.transpose(-2, -1)
+    p = torch.exp2(s - s.amax(-1, keepdim=True))
+    ref = ((p @ h(kset[:, :, 1]).double().permute(0, 2, 1, 3)) / p.sum(-1, keepdim=True)).permute(0, 2, 1, 3).reshape(q.shape)
+    print(f"fp16 bounded promise broken: {int(fb.item())} of {n_outer * n_inner * H * 2} workgroups fell back, rel_l2 {rel_l2(out.double(), ref):.2e}")
+    assert int(fb.item()) == n_outer * n_inner * H * 2 and torch.isfinite(out.float()).all() and rel_l2(out.double(), ref) < 8e-4
+
+
 # ---- row-block launch ------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,rpg,K1,hidden,N3,adaln1", [(96, 48, 128, 0, 512, True), (192, 96, 512, 2048, 1536, False), (12288, 12288, 512, 2048, 0, False)])
 def test_rowblock_launch_fp16_equals_the_unfused_launches(cuda, M, rpg, K1, hidden, N3, adaln1):
