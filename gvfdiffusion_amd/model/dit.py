@@ -423,9 +423,11 @@ class DiT(nn.Module):
         g = self._graph
         if g is None or g["key"] != key or not self._same_tensors(g["held"], conds):
             sx, st = x.clone(), t.clone()
-            # One capture at a time per process, and in thread-local capture mode: other host threads (another sample in flight on its own
-            # stream and DiT instance, utils/in_flight.py) keep launching and allocating while this one captures -- a new condition set (a new
-            # sample) means a new capture, so captures do happen inside the in-flight phase, not only in a serial warm-up.
+            # One capture at a time per process, and in thread-local capture mode, so that a capture on one host thread does not FAIL because
+            # another thread (another sample in flight on its own stream and DiT instance, utils/in_flight.py) launches or allocates
+            # meanwhile.  That makes such captures possible, not safe: 3 of 50 runs of inference_dpm_latent.py with two samples in flight
+            # and a capture per sample returned a sample that differed in its last bits (0 of 25 with eager launches), so callers capture
+            # BEFORE going in flight (bench.py) or run their in-flight instances eagerly (inference_dpm_latent.py).
             with _CAPTURE_LOCK:
                 # eager run first: builds the weight / condition caches and warms the allocator outside the capture
                 self._forward(sx, st, cond_images, static_latent, deformation_position_xyz)

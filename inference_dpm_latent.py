@@ -102,7 +102,13 @@ def build_models(args, dev, n_copies=1):
         else:
             dit.load_state_dict(_strip_module(torch.load(args.ckpt, map_location="cpu")), strict=True)
             vae.load_state_dict(_strip_module(torch.load(args.vae_ckpt, map_location="cpu")), strict=True)
-        copies.append((dit.to(dev).eval().enable_graph(True), vae.to(dev).eval()))
+        # One sample at a time: every forward of a sample replays ONE hipGraph (captured on the sample's first step: new conditions, new
+        # capture).  Several samples in flight: eager launches -- a capture per sample would happen on the slots' threads while the other
+        # slot launches and allocates, and that is not safe on this stack even one capture at a time in thread-local mode: measured on
+        # MI355X / ROCm 7.0, 3 of 50 two-in-flight runs of this script came back with one sample off in the last bits of ~2 % of its
+        # pixels, 0 of 25 without graphs (the serial path: always identical).  utils/in_flight.py states the rule: capture before going
+        # in flight (bench.py does: its slots re-run fixed conditions, captured in a serial warm-up).
+        copies.append((dit.to(dev).eval().enable_graph(n_copies == 1), vae.to(dev).eval()))
     return copies, model_cfg, diff_cfg, vae_cfg
 
 
