@@ -77,3 +77,22 @@ def test_operators_refuse_cpu_tensors():
     with pytest.raises(_lib.GvfError):
         R.rasterize(st, fr, torch.zeros(4, 3), torch.ones(4, 1), shs=torch.zeros(4, 1, 3), scales=torch.ones(4, 3),
                     rotations=torch.ones(4, 4))
+
+
+def test_scores_bounded_hint_and_worst_case(monkeypatch):
+    """dit_ops.scores_bounded (host logic of GVF_ATTN_SCORES_BOUNDED): 32 |gq gk| / sqrt(32) * log2 e * 1.01 = 8.24 |gq gk| against 15.5 octaves;
+    default = root mean square of the gain product over a head's channels (a hint: the kernel's range guard is the guarantee), strict = the
+    largest product of one channel (the worst case over every query / key direction)."""
+    import torch
+    from gvfdiffusion_amd.ops import dit_ops
+    one = torch.ones((4, 32))
+    assert dit_ops.scores_bounded(one, one) and dit_ops.scores_bounded(one, one, strict=True)
+    assert dit_ops.scores_bounded(1.3 * one, 1.4 * one, strict=True) and not dit_ops.scores_bounded(1.4 * one, 1.4 * one)
+    spiky = one.clone(); spiky[2, 5] = 2.5                     # one channel of one head with a large gain: typical directions still fit
+    assert dit_ops.scores_bounded(spiky, one) and not dit_ops.scores_bounded(spiky, one, strict=True)
+    loud_head = one.clone(); loud_head[1] = 2.0                # a whole head with gain 2: its scores reach 16.5 octaves
+    assert not dit_ops.scores_bounded(loud_head, one)
+    assert not dit_ops.scores_bounded(None, one) and not dit_ops.scores_bounded(one, None)      # no RMSNorm, no bound
+    assert dit_ops.scores_bounded(one.reshape(2, 64), one.reshape(2, 64), head_dim=64)
+    monkeypatch.setenv("GVF_ATTN_BOUNDED", "0")
+    assert not dit_ops.scores_bounded(one, one)
