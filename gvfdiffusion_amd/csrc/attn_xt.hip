@@ -712,6 +712,14 @@ extern "C" int gvf_attn_pack_kv_bf16(const void* kv, int kv_is_f32, int64_t ld, 
     return gvf_attn_pack_kv(GVF_DT_BF16, kv, kv_is_f32, ld, k_col0, v_col0, n_sets, L, H, k_scale, gamma_k, k_tiles, v_tiles, stream_);
 }
 
+template <int DT>
+static void xt_launch(const XtParams& p, int force_safe, bool bounded, unsigned blocks, hipStream_t stream) {
+    if constexpr (GvfLp<DT>::kNeedsShift) {            // (bf16 has no shifted variant: nothing to instantiate)
+        if (!bounded) { attn_xt_kernel<DT, true><<<dim3(blocks), dim3(XT_THREADS), 0, stream>>>(p, force_safe); return; }
+    }
+    attn_xt_kernel<DT, false><<<dim3(blocks), dim3(XT_THREADS), 0, stream>>>(p, force_safe);
+}
+
 extern "C" int gvf_attn_tiled_fwd(int dtype, const void* q, const void* k_tiles, const void* v_tiles, void* out, int n_outer, int n_inner,
                                   int Lq, int Lk, int H, const int64_t* q_strides, const int64_t* o_strides,
                                   int64_t kv_set_stride_outer, int64_t kv_set_stride_inner, const float* gamma_q, int out_is_f32,
@@ -740,9 +748,7 @@ extern "C" int gvf_attn_tiled_fwd(int dtype, const void* q, const void* k_tiles,
     (void)hipGetLastError();
     const int force_safe = force_exact & GVF_ATTN_FORCE_EXACT;
     const bool bounded = (force_exact & GVF_ATTN_SCORES_BOUNDED) != 0;
-    GVF_LP_DISPATCH(dtype,
-        if (GvfLp<DT>::kNeedsShift && !bounded) attn_xt_kernel<DT, true><<<dim3((unsigned)blocks), dim3(XT_THREADS), 0, (hipStream_t)stream_>>>(p, force_safe);
-        else attn_xt_kernel<DT, false><<<dim3((unsigned)blocks), dim3(XT_THREADS), 0, (hipStream_t)stream_>>>(p, force_safe));
+    GVF_LP_DISPATCH(dtype, xt_launch<DT>(p, force_safe, bounded, (unsigned)blocks, (hipStream_t)stream_));
     GVF_CHECK_LAUNCH();
     return GVF_OK;
 }
