@@ -172,3 +172,47 @@ def test_dit_uses_the_temporal_section_where_it_tiles_and_matches_the_three_laun
     r = rel_l2(y1, y0)
     print(f"DiT {lp} B{B} T{T} N{N}: merged temporal launch vs three launches {r:.2e}")
     assert r < (1e-6 if not fused else 2e-3 if lp == "bf16" else 2.5e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lp", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,T,N", [(2, 16, 64), (1, 4, 512), (3, 8, 100)])
+def test_temporal_section_on_padded_groups(cuda, lp, B, T, N):
+    """T * N tokens that do not fill whole 48-row blocks: a group (sample) owns ceil(N / (48 / T)) blocks, the rows behind its tokens are
+    padding = the phantom tokens of its last block (the layout DiT._blocks_rowblock uses for T = 16 at N = 512).  Token rows of the merged
+    launch against the three launches on the same padded buffers; the padding rows stay finite."""
+    tpb = 48 // T
+    TN, TNp = T * N, (N + tpb - 1) // tpb * 48
+    assert TNp > TN and TNp == dit_ops.rowblock_padded_rows(TN)
+    d = _case(cuda, B, T, N, lp, seed=17 * T + N)
+    M = B * TNp
+
+    def pad(t):                                         # (B * TN, c) -> (B * TNp, c), zeros behind every group's tokens
+        out = torch.zeros((B, TNp, t.shape[1]), dtype=t.dtype, device=t.device)
+        out[:, :TN] = t.view(B, TN, -1)
+        return out.view(M, -1)
+    a0, x0, mod = pad(d["a0"]), pad(d["x0"]), d["mod"]
+    ld = 9 * C
+    ln1, n3 = dict(shift=mod[:, C:], scale=mod[:, 2 * C:]), dict(ln_w=d["lw"], ln_b=d["lb"])
+    # three launches
+    x_ref = x0.clone()
+    qkv = torch.zeros((M, 3 * C), dtype=lp, device=cuda)
+    dit_ops.rowblock_fused(a0, dit_ops.rowblock_pack_stream(d["w1"], w3=d["wqkv"]), x_ref, b1=d["b1"], gate1=mod[:, 0:], ln1=ln1, mod_ld=ld,
+                           rows_per_group=TNp, out3=qkv, b3=d["bqkv"])
+    ab = torch.zeros((M, C), dtype=lp, device=cuda)
+    st = (TNp * 3 * C, 3 * C, N * 3 * C)
+    dit_ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], ab, B, N, T, T, H, st, st, st, (TNp * C, C, N * C), d["gq"], d["gk"])
+    q_ref = torch.empty((M, C), dtype=lp, device=cuda)
+    dit_ops.rowblock_fused(ab, dit_ops.rowblock_pack_stream(d["wout"], w3=d["w3"]), x_ref, b1=d["bout"], gate1=mod[:, 3 * C:], ln1=n3, mod_ld=ld,
+                           rows_per_group=TNp, out3=q_ref, b3=d["b3"])
+    # merged
+    x = x0.clone()
+    q = torch.full((M, C), float("nan"), dtype=lp, device=cuda)
+    dit_ops.rowblock_fused(a0, dit_ops.rowblock_pack_stream(d["w1"], temporal=(d["wqkv"], d["wout"]), w3=d["w3"]), x, b1=d["b1"], gate1=mod[:, 0:],
+                           ln1=ln1, mod_ld=ld, rows_per_group=TNp, out3=q, b3=d["b3"],
+                           temporal=dict(frames=T, stride=N, b_qkv=d["bqkv"], gamma_q=d["gq"], gamma_k=d["gk"], b_out=d["bout"], gate=mod[:, 3 * C:], ln=n3))
+    tok = lambda t: t.view(B, TNp, -1)[:, :TN]
+    rx, rq = rel_l2(tok(x), tok(x_ref)), rel_l2(tok(q), tok(q_ref))
+    print(f"temporal section, padded groups {lp} B{B} T{T} N{N} ({TNp - TN} padding rows): stream {rx:.2e}, projection {rq:.2e}")
+    assert torch.isfinite(q.float()).all() and torch.isfinite(x).all()
+    assert rx < (2e-4 if lp == torch.bfloat16 else 3e-5) and rq < (3e-3 if lp == torch.bfloat16 else 4e-4)
