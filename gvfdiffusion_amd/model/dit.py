@@ -190,8 +190,8 @@ class DiT(nn.Module):
         # one launch per sub-layer boundary (csrc/rowblock.hip) where the shapes allow it: 0 = the unfused GEMM / LayerNorm launches
         self.use_rowblock = int(os.environ.get("GVF_DIT_ROWBLOCK", "1")) != 0
         self.rowblock_tiled_kv = int(os.environ.get("GVF_DIT_TILED_KV", "1")) != 0    # to_qkv's launch writes the attention's K / V^T tiles itself
-        # the temporal self attention runs INSIDE the row-block launch between the spatial and the image attention (T | 48): 7 launches per
-        # block instead of 9, the qkv / attention-output buffers of the temporal sub-layer never exist
+        # the temporal self attention runs INSIDE the row-block launch between the spatial and the image attention (T | 48): 6 launches per
+        # block instead of 8, the qkv / attention-output buffers of the temporal sub-layer never exist
         self.rowblock_temporal = int(os.environ.get("GVF_DIT_TEMPORAL_FUSED", "1")) != 0
         self._graph = None
         self.capture_blocks = None     # diagnostics: a list -> _blocks_rowblock appends a copy of the fp32 stream after every block
