@@ -65,6 +65,9 @@
 #ifndef XT_ABL_EXPSRC
 #define XT_ABL_EXPSRC 0       // 1: the exponentials read lane constants instead of the score tile (no MFMA -> VALU dependency; scores kept alive)
 #endif
+#ifndef XT_LATE_STAGE
+#define XT_LATE_STAGE 0       // 1: the first two stages are requested after the query fragments are built (the order up to round 3's last session)
+#endif
 #ifndef XT_UNROLL
 #define XT_UNROLL 1           // 1: the steady-state loop is unrolled over one period of the staging ring (TPS * NBUF tiles): ring slots become constants
 #endif
@@ -406,6 +409,28 @@ __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(
     const int T = p.n_tiles;
     const int last_valid = p.Lk - (T - 1) * XT_KT;             // valid keys of the last tile (1..64)
 
+    // ---- staging: stage s = tiles [s * TPS, (s+1) * TPS) -> ring slot s % 3.  Wave w copies chunks [64w, 64w+64) of every
+    // K image and of every V^T image of the stage (linear 1 KiB LDS-DMA pieces).
+#define XT_TILE_AT(t_) (&smem[((((t_) / XT_TPS) % XT_NBUF) * XT_TPS + (t_) % XT_TPS) * XT_TILE_CHUNKS])
+#define XT_STAGE(s_)                                                                                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < XT_TPS; ++i_) {                                            \
+        const int t_ = (s_) * XT_TPS + i_;                                                             \
+        if (t_ < T) {                                                                                  \
+            uint4* dst_ = XT_TILE_AT(t_);                                                              \
+            xt_dma16(kbase + (long long)t_ * 256 + wave * 64 + lane, dst_ + wave * 64);                \
+            xt_dma16(vbase + (long long)t_ * 256 + wave * 64 + lane, dst_ + 256 + wave * 64);          \
+        }                                                                                              \
+    }
+#define XT_K(t_) XT_TILE_AT(t_)
+#define XT_V(t_) (XT_TILE_AT(t_) + 256)
+    // The first two stages are requested BEFORE the query rows: the K / V^T tiles and the queries come from memory at the same time instead of
+    // one latency after the other (the fast path's first barrier below waits for them; the exact path stages for itself).
+    const int n_stages = (T + XT_TPS - 1) / XT_TPS;
+    if (!XT_LATE_STAGE && force_safe == 0) {
+        XT_STAGE(0)
+        if (n_stages > 1) { XT_STAGE(1) }
+    }
+
     // ---- Q fragments (B operand of S^T = K' Q^T): lane (q = l31, half): Q[q][16 st + 8 half .. +7]
     int qrow[2];
     bool qvalid[2];
@@ -440,20 +465,6 @@ __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(
         __builtin_amdgcn_wave_barrier();
     }
 
-    // ---- staging: stage s = tiles [s * TPS, (s+1) * TPS) -> ring slot s % 3.  Wave w copies chunks [64w, 64w+64) of every
-    // K image and of every V^T image of the stage (linear 1 KiB LDS-DMA pieces).
-#define XT_TILE_AT(t_) (&smem[((((t_) / XT_TPS) % XT_NBUF) * XT_TPS + (t_) % XT_TPS) * XT_TILE_CHUNKS])
-#define XT_STAGE(s_)                                                                                   \
-    _Pragma("unroll") for (int i_ = 0; i_ < XT_TPS; ++i_) {                                            \
-        const int t_ = (s_) * XT_TPS + i_;                                                             \
-        if (t_ < T) {                                                                                  \
-            uint4* dst_ = XT_TILE_AT(t_);                                                              \
-            xt_dma16(kbase + (long long)t_ * 256 + wave * 64 + lane, dst_ + wave * 64);                \
-            xt_dma16(vbase + (long long)t_ * 256 + wave * 64 + lane, dst_ + 256 + wave * 64);          \
-        }                                                                                              \
-    }
-#define XT_K(t_) XT_TILE_AT(t_)
-#define XT_V(t_) (XT_TILE_AT(t_) + 256)
 
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x16 oA = zero, oB = zero;
@@ -475,9 +486,10 @@ __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(
         // The first and the last tile are peeled so that the steady-state loop body is branch-free straight-line code
         // (with both variants of a phase behind an if / else the compiler hoists their common exp2 block above the
         // branch and the interleave is gone).
-        const int n_stages = (T + XT_TPS - 1) / XT_TPS;
-        XT_STAGE(0)
-        if (n_stages > 1) { XT_STAGE(1) }
+        if (XT_LATE_STAGE) {
+            XT_STAGE(0)
+            if (n_stages > 1) { XT_STAGE(1) }
+        }
         __syncthreads();            // stages 0 and 1 have landed (own DMA drained before the barrier)
         if (n_stages > 2) { XT_STAGE(2) }
         if (!XT_ABL_NOLDS) {
