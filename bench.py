@@ -542,11 +542,12 @@ def main():
     slots = [work] + [RasterWorkload(dev, a.gaussians, a.res, a.frames, a.sh_degree, seed=rank + 1000 * k) for k in range(1, n_slots)]
     rstreams = [torch.cuda.Stream(device=dev) for _ in range(n_slots)]
 
-    # Frame exchange (N > 1), BASELINE's "all-gather over xGMI only for the final frame collection": the job this loop measures is a batch
-    # of `world` samples, one per rank per step; its ONE collective -- gvfdiffusion_amd.distributed.gather_frames of every rank's finished
-    # uint8 frames (46 MB per sample) -- runs once, at the end of the timed region, inside it.  GVF_BENCH_GATHER_EVERY_STEP=1 restores
-    # the round-2 variant (a gather of every step's frames on a side stream, overlapped with the next step's rendering).
-    every_step = multi and os.environ.get("GVF_BENCH_GATHER_EVERY_STEP", "0") == "1"
+    # Frame exchange (N > 1), BASELINE's "all-gather over xGMI only for the final frame collection": the job this loop measures is `steps`
+    # batches of `world` samples, one per rank per step, and EVERY sample that `value` counts is collected inside the timed region: its
+    # frames are converted to uint8 (46 MB per sample) and all-gathered on a side stream while the next step renders (one
+    # all_gather_into_tensor per step; the closing barrier + synchronize waits for the last one).  GVF_BENCH_GATHER_EVERY_STEP=0 is the
+    # render-only variant (ONE gather of the last step's frames at the end) and says so in config.collective.
+    every_step = multi and os.environ.get("GVF_BENCH_GATHER_EVERY_STEP", "1") == "1"
     side = torch.cuda.Stream(device=dev) if every_step else None
     nbuf = max(2, n_slots)
     u8 = [torch.empty((F, 3, S, S), dtype=torch.uint8, device=dev) for _ in range(nbuf)] if multi else None
@@ -574,7 +575,10 @@ def main():
                 ready[b].record()
                 with torch.cuda.stream(side):
                     side.wait_event(ready[b])
-                    dist.all_gather_into_tensor(gathered[b], u8[b])
+                    if dist.get_backend() == "nccl":
+                        dist.all_gather_into_tensor(gathered[b], u8[b])
+                    else:                          # gloo test aid (ranks sharing one GPU box): gather_frames stages through the host
+                        gathered[b].copy_(D.gather_frames(u8[b][None], total=world).view_as(gathered[b]))
                     consumed[b].record(side)
 
     def barrier():
@@ -625,6 +629,9 @@ def main():
     if got is not None:
         k = (a.steps - 1) % n_slots
         assert got.shape == (world, F, 3, S, S) and torch.equal(got[rank], work.R.frames_to_uint8(slots[k].color))
+    if every_step:                               # the last gathered batch holds this rank's last sample at its rank-major position
+        b, k = (a.steps - 1) % nbuf, (a.steps - 1) % n_slots
+        assert torch.equal(gathered[b].view(world, F, 3, S, S)[rank], work.R.frames_to_uint8(slots[k].color))
 
     t = torch.tensor([dt, dt_serial], dtype=torch.float64, device=dev if (not multi or dist.get_backend() == "nccl") else "cpu")
     if multi:
@@ -660,9 +667,11 @@ def main():
                        "pipelining": f"{n_slots} DIFFERENT samples in flight per GPU (own Gaussians, deltas, HIP stream, workspace and frame buffer "
                                      "each; every slot's frames are asserted bit-identical to its serial render); stage_ms_per_step, roofline and "
                                      "ms_per_step_serial are from a serial instrumented pass over the same steps",
-                       "collective": None if not multi else ("one all_gather_into_tensor per step on a side stream" if every_step else
-                                                             "ONE gather of every rank's finished uint8 frames at the end of the timed region "
-                                                             "(gvfdiffusion_amd.distributed.gather_frames)")},
+                       "collective": None if not multi else (
+                           "every counted sample is collected inside the timed region: uint8 conversion + one all_gather_into_tensor per step "
+                           f"({world} x {F * 3 * S * S / 1e6:.0f} MB) on a side stream, overlapped with the next step's rendering" if every_step else
+                           "RENDER-ONLY timing (GVF_BENCH_GATHER_EVERY_STEP=0): only the LAST step's frames are gathered (once, at the end of the "
+                           "timed region); the other steps' frames are counted but not collected")},
             "roofline": {"bound": "hbm", "kernel": "blend_kernel (R6, one launch = all frames of the step)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,

@@ -108,10 +108,12 @@ def sample_decode_render_sharded(chain: Callable[[int, int], torch.Tensor], tota
     it; then the one frame all-gather.  Returns (frames, mine): frames (total, T, 3, H, W) in global order on every rank (gather=True)
     or this rank's (n_local, T, 3, H, W) block; mine = this rank's global sample indices."""
     rank, world = rank_world(group)
+    if total < world:
+        # decided from (total, world) alone, i.e. identically on EVERY rank and before any work: a check on the owner-less ranks only would
+        # leave the others waiting in the all-gather until the collective times out
+        raise ValueError(f"sample_decode_render_sharded: {total} samples over {world} ranks leaves ranks without a sample; run with fewer ranks")
     mine = shard_indices(total, rank, world)
     res = run_sharded(chain, total, device, in_flight, group)
-    if len(res) == 0:
-        raise ValueError("sample_decode_render_sharded: this rank owns no sample (total < world); run with fewer ranks")
     local = torch.stack([r if torch.is_tensor(r) else r[0] for r in res])
     if not gather:
         return local, mine

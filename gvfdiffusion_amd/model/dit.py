@@ -156,6 +156,10 @@ class DiT(nn.Module):
             raise NotImplementedError("share_mod=True is not built (configs/diffusion.yml uses per-block adaLN)")
         if pe_mode == "rope":
             raise NotImplementedError("pe_mode='rope' is not built (configs/diffusion.yml uses 'ape')")
+        if model_channels % self.num_heads != 0 or model_channels // self.num_heads != 32:
+            # the tiled K / V cache (csrc/attn_xt.hip), its pack kernels and the temporal section of csrc/rowblock.hip are head_dim-32 code
+            # (configs/diffusion.yml: 512 channels / 16 heads); anything else would compute a different attention without an error
+            raise NotImplementedError(f"the DiT's HIP attention path is built for head_dim 32, got {model_channels} / {self.num_heads}")
 
         self.t_embedder = TimestepEmbedder(model_channels)
         if pe_mode == "ape":

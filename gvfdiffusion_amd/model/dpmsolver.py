@@ -212,6 +212,8 @@ class DPM_Solver:
         self.correcting_xt_fn = correcting_xt_fn
         self.dynamic_thresholding_ratio = dynamic_thresholding_ratio
         self.thresholding_max_val = thresholding_max_val
+        self.verbose = True
+        self.last_nfe = None
 
     # ---- scalar schedule helpers (host) -------------------------------------------------------
     def _sched(self, t):
@@ -520,7 +522,9 @@ class DPM_Solver:
             E_f = float(E)      # E == 0 (both orders agree exactly): float_power gives inf upstream, the min() clamps it
             h = min(theta * h * (math.inf if E_f == 0.0 else E_f ** (-1.0 / order)), lambda_0 - lambda_s)
             nfe += order
-        print("adaptive solver nfe", nfe)
+        self.last_nfe = nfe
+        if self.verbose:          # the reference prints unconditionally (model/dpmsolver.py:1026); callers that sample on worker threads switch it off
+            print("adaptive solver nfe", nfe)
         return x
 
     def add_noise(self, x, t, noise=None):

@@ -108,7 +108,7 @@ def build_models(args, dev, n_copies=1):
         # MI355X / ROCm 7.0, 3 of 50 two-in-flight runs of this script came back with one sample off in the last bits of ~2 % of its
         # pixels, 0 of 25 without graphs (the serial path: always identical).  utils/in_flight.py states the rule: capture before going
         # in flight (bench.py does: its slots re-run fixed conditions, captured in a serial warm-up).
-        copies.append((dit.to(dev).eval().enable_graph(n_copies == 1), vae.to(dev).eval()))
+        copies.append((dit.to(dev).eval().enable_graph(n_copies == 1 or os.environ.get("GVF_INFLIGHT_GRAPH") == "1"), vae.to(dev).eval()))
     return copies, model_cfg, diff_cfg, vae_cfg
 
 
@@ -129,19 +129,15 @@ def sample_inputs(args, i, dev, model_cfg):
     return gs, cond
 
 
-def main(argv=None):
-    args = create_argparser().parse_args(argv)
-    if not torch.cuda.is_available():
-        raise SystemExit("inference_dpm_latent.py needs an MI355X (the package has no CPU path)")
-    from gvfdiffusion_amd import distributed as D, synthetic
+def build_chain(args, dev, probe=None):
+    """Models, schedule, renderers and cameras of one rank -> (chain, stats, n_fl): chain(slot, i) produces global sample i's finished frames
+    on copy `slot` of the models; stats collects (sample, NFE, seconds).  probe: optional dict, filled with {i: (latents, deltas)} clones
+    (scripts/inflight_capture_repro.py compares them between runs)."""
+    from gvfdiffusion_amd import synthetic
     from gvfdiffusion_amd.model.dpmsolver import NoiseScheduleVP, model_wrapper, DPM_Solver
     from gvfdiffusion_amd.model.gaussian_diffusion import create_gaussian_diffusion
     from gvfdiffusion_amd.renderers import GaussianRenderer
-    from gvfdiffusion_amd.utils import orbit_cameras, pad_static_gs, render_sample_frames, sample_gs, seed_everything
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
-    torch.cuda.set_device(dev)
-    rank, world = D.init_from_env(dev)
-    seed_everything(args.seed + rank)
+    from gvfdiffusion_amd.utils import orbit_cameras, pad_static_gs, render_sample_frames, sample_gs
     n_fl = max(1, args.in_flight)
     copies, model_cfg, diff_cfg, vae_cfg = build_models(args, dev, n_fl)
     diffusion = create_gaussian_diffusion(**{k: v for k, v in diff_cfg.items() if k in ("steps", "noise_schedule", "predict_type")})
@@ -178,12 +174,16 @@ def main(argv=None):
         nfe = {"n": 0}
         counted = lambda x, t: (nfe.__setitem__("n", nfe["n"] + 1), fn(x, t))[1]                  # noqa: E731
         noise = torch.randn((1, T, model_cfg["resolution"], model_cfg["in_channels"]), generator=torch.Generator().manual_seed(args.seed + i)).to(dev)
-        with torch.no_grad(), autocast(), contextlib.redirect_stdout(open(os.devnull, "w")):
-            samples = DPM_Solver(counted, ns, algorithm_type="dpmsolver++").sample(
+        solver = DPM_Solver(counted, ns, algorithm_type="dpmsolver++")
+        solver.verbose = False          # (not contextlib.redirect_stdout: chain() runs on worker threads with --in_flight > 1, sys.stdout is process-global)
+        with torch.no_grad(), autocast():
+            samples = solver.sample(
                 noise, steps=args.rescale_timesteps, t_start=1.0, t_end=1 / 1000, order=2, skip_type="time_uniform",
                 method="adaptive" if args.adaptive else "multistep")                              # :241-249
             lat = (samples * d_std + d_mean).reshape(T, samples.shape[2], samples.shape[3])        # :250-253
             pred_delta = vae.decode(lat, padded).float()                                           # :256-259
+        if probe is not None:
+            probe[i] = (samples.detach().clone(), pred_delta.detach().clone())
         # renderer input: the canonical Gaussians as a GaussianModel (the TRELLIS stage hands one over; here rebuilt from the (P, 14) tensor)
         from gvfdiffusion_amd.representations.gaussian import Gaussian
         gm = Gaussian(sh_degree=0, aabb=[-0.5, -0.5, -0.5, 1.0, 1.0, 1.0], mininum_kernel_size=synthetic.KERNEL_3D, scaling_bias=synthetic.SCALING_BIAS,
@@ -195,6 +195,21 @@ def main(argv=None):
         torch.cuda.current_stream().synchronize()
         stats.append((i, nfe["n"], time.perf_counter() - t0))
         return frames
+
+    return chain, stats, n_fl
+
+
+def main(argv=None):
+    args = create_argparser().parse_args(argv)
+    if not torch.cuda.is_available():
+        raise SystemExit("inference_dpm_latent.py needs an MI355X (the package has no CPU path)")
+    from gvfdiffusion_amd import distributed as D
+    from gvfdiffusion_amd.utils import seed_everything
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    rank, world = D.init_from_env(dev)
+    seed_everything(args.seed + rank)
+    chain, stats, n_fl = build_chain(args, dev)
 
     t0 = time.perf_counter()
     frames, mine = D.sample_decode_render_sharded(chain, args.num_samples, device=dev, in_flight=n_fl)

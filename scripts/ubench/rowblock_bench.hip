@@ -28,6 +28,17 @@ template <class T> static T* dev(const std::vector<T>& h) {
     return d;
 }
 
+// reads one dword per 128-byte line of [p, p + bytes): `copies` > 1 = every XCD (block % 8) reads the whole range
+__global__ void rb_touch_kernel(const char* p, size_t bytes, int copies, unsigned* sink) {
+    const size_t per = (bytes / 128 + 255) / 256;                    // blocks per copy
+    const size_t blk = copies > 1 ? blockIdx.x / 8 : blockIdx.x;    // (block b runs on XCD b % 8)
+    const size_t off = (blk * 256 + threadIdx.x) * 128;
+    if (blk < per && off < bytes) {
+        const unsigned v = *reinterpret_cast<const unsigned*>(p + off);
+        if (v == 0x12345678u) sink[threadIdx.x] = v;
+    }
+}
+
 static int run_case(const char* name, int B, int TN, int K1, int hidden, int N3, bool adaln, int iters) {
     const int C = 512, M = B * TN, mod_ld = 4 * C;
     std::mt19937 rng(99);
@@ -155,34 +166,46 @@ static int run_case(const char* name, int B, int TN, int K1, int hidden, int N3,
     // the same launch with everything it reads COLD in the caches, as inside the denoise step (every launch there has its own weights,
     // 115 MB per step, and its inputs were written by the launch before): rotate over copies of the weight stream, the activations and
     // the residual stream that together exceed the 256 MB Infinity Cache
-    double us_cold = 0;
+    // RB_COLD=1: everything cold; 2: weights warm (same stream every launch), activations + residual stream cold; 3: weights cold only;
+    // 4: everything cold, but a prefetch launch reads the weight stream ONCE just before (-> Infinity Cache, one XCD's L2 per line);
+    // 5: as 4 with every XCD reading the whole stream (-> every L2).  The prefetch launches of 4 / 5 are timed separately and subtracted.
+    double us_cold = 0, us_pref = 0;
     if (getenv("RB_COLD")) {
+        const int cm = atoi(getenv("RB_COLD"));
         const int n_rot = 24;
         const size_t wbytes_ = (size_t)(bytes1 + bytesm + bytes3);
-        char* dWr; unsigned short* dAr; float* dxr;
-        CK(hipMalloc(&dWr, wbytes_ * n_rot)); CK(hipMalloc(&dAr, hA.size() * 2 * n_rot)); CK(hipMalloc(&dxr, hx.size() * 4 * n_rot));
+        char* dWr; unsigned short* dAr; float* dxr; unsigned* dsink;
+        CK(hipMalloc(&dWr, wbytes_ * n_rot)); CK(hipMalloc(&dAr, hA.size() * 2 * n_rot)); CK(hipMalloc(&dxr, hx.size() * 4 * n_rot)); CK(hipMalloc(&dsink, 4096 * 4));
         for (int r = 0; r < n_rot; ++r) {
             CK(hipMemcpy(dWr + wbytes_ * r, dW, wbytes_, hipMemcpyDeviceToDevice));
             CK(hipMemcpy(dAr + hA.size() * r, dA, hA.size() * 2, hipMemcpyDeviceToDevice));
             CK(hipMemcpy(dxr + hx.size() * r, dx, hx.size() * 4, hipMemcpyDeviceToDevice));
         }
         CK(hipDeviceSynchronize());
-        CK(hipEventRecord(e0));
-        for (int i = 0; i < iters; ++i) {
-            gvf_rowblock_args b = a;
-            b.w = dWr + wbytes_ * (i % n_rot); b.a = dAr + hA.size() * (i % n_rot); b.x = dxr + hx.size() * (i % n_rot);
-            (void)gvf_rowblock_fused_bf16(&b, nullptr);
+        const bool w_rot = cm != 2, ax_rot = cm != 3;
+        for (int pass = 0; pass < 2; ++pass) {          // pass 0: the prefetch launches alone (modes 4, 5), pass 1: everything
+            if (pass == 0 && cm < 4) continue;
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < iters; ++i) {
+                gvf_rowblock_args b = a;
+                if (w_rot) b.w = dWr + wbytes_ * (i % n_rot);
+                if (ax_rot) { b.a = dAr + hA.size() * (i % n_rot); b.x = dxr + hx.size() * (i % n_rot); }
+                if (cm == 4) rb_touch_kernel<<<dim3((unsigned)((wbytes_ / 128 + 255) / 256)), dim3(256)>>>((const char*)b.w, wbytes_, 1, dsink);
+                if (cm == 5) rb_touch_kernel<<<dim3(8 * (unsigned)((wbytes_ / 128 + 255) / 256)), dim3(256)>>>((const char*)b.w, wbytes_, 8, dsink);
+                if (pass == 1) (void)gvf_rowblock_fused_bf16(&b, nullptr);
+            }
+            CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            if (pass == 0) us_pref = ms * 1e3 / iters; else us_cold = ms * 1e3 / iters;
         }
-        CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
-        CK(hipEventElapsedTime(&ms, e0, e1));
-        us_cold = ms * 1e3 / iters;
-        (void)hipFree(dWr); (void)hipFree(dAr); (void)hipFree(dxr);
+        (void)hipFree(dWr); (void)hipFree(dAr); (void)hipFree(dxr); (void)hipFree(dsink);
     }
     const double flops = 2.0 * M * C * ((double)K1 + 2.0 * hidden + N3);
     const double wbytes = (double)(bytes1 + bytesm + bytes3) * (M / 48);
     printf("%-44s: stream rel_l2 %.2e  out rel_l2 %.2e | %7.1f us  %6.1f TFLOP/s  weight stream %5.1f TB/s (L2)", name, rx, ro, us, flops / us / 1e6,
            wbytes / us / 1e6);
-    if (us_cold > 0) printf("  | cold caches %7.1f us", us_cold);
+    if (us_cold > 0) printf("  | RB_COLD=%s %7.1f us", getenv("RB_COLD"), us_cold);
+    if (us_pref > 0) printf(" (of which the prefetch launch alone: %5.1f)", us_pref);
     printf("\n");
     (void)hipFree(dA); (void)hipFree(dW1); (void)hipFree(dWf1); (void)hipFree(dWf2); (void)hipFree(dW3); (void)hipFree(dW); (void)hipFree(dout); (void)hipFree(dhb);
     (void)hipFree(dx); (void)hipFree(dmod);

@@ -82,6 +82,42 @@ def test_two_rank_sample_sharding_and_frame_gather(tmp_path):
     assert not np.array_equal(g0[0], g0[1])                         # different samples per rank (sharded, not replicated)
 
 
+def _wide_worker(rank, world, port, out_dir, total):
+    """sample_decode_render_sharded at the widths of the node (4 and 8 ranks): even and uneven shards, every rank checks the gathered job
+    against its own shard, rank 0 saves it."""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    from gvfdiffusion_amd import distributed as D
+    D.init_from_env()
+    chain = lambda slot, i: _oracle_frames(i, F=1, S=32)            # noqa: E731
+    frames, mine = D.sample_decode_render_sharded(chain, total)
+    assert mine == list(range(rank, total, world)) and frames.shape[0] == total
+    for i in mine:
+        assert torch.equal(frames[i], _oracle_frames(i, F=1, S=32))
+    digest = torch.tensor([float(frames.to(torch.float64).sum())], dtype=torch.float64)
+    lo, hi = digest.clone(), digest.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    assert float(lo) == float(hi)                                     # every rank holds the same gathered job
+    with pytest.raises(ValueError):                                   # fewer samples than ranks: refused on EVERY rank, before any work
+        D.sample_decode_render_sharded(chain, world - 1)              # (a refusal on the owner-less ranks only would hang the others)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "wide.npy"), frames.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,total", [(4, 8), (8, 11)])
+def test_node_wide_sample_sharding(tmp_path, world, total):
+    """The node's widths on CPU (gloo): 4 ranks x 2 samples and 8 ranks over 11 samples (three ranks own two, five own one + a zero pad)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    mp.spawn(_wide_worker, args=(world, _free_port(), str(tmp_path), total), nprocs=world, join=True)
+    got = np.load(tmp_path / "wide.npy")
+    assert got.shape[0] == total
+    for i in range(total):
+        assert np.array_equal(got[i], _oracle_frames(i, F=1, S=32).numpy()), i
+
+
 # ---- BASELINE configs[4]: the sampler is what shards -------------------------------------------------------------------
 def _toy_denoiser(x, t_input, cond_images=None, static_latent=None, deformation_position_xyz=None):
     """A per-sample network with the DiT's keyword interface: no cross-sample term, like the real denoiser
