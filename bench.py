@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--no-dit", action="store_true")
     ap.add_argument("--e2e-only", action="store_true", help="profiling aid: run only the end-to-end leg and print its object")
     ap.add_argument("--dit-only", action="store_true", help="profiling aid: run only the DiT leg and print its object")
+    ap.add_argument("--live-only", action="store_true", help="profiling aid: run only the live-render leg (32 x 128 x 512^2) and print its object")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("GVF_BENCH_STREAMS", "2")),
                     help="4D samples kept in flight by the timed loop, one HIP stream + workspace + output buffer each (1 = strictly serial)")
     return ap.parse_args()
@@ -313,6 +314,42 @@ def bench_e2e(dev, P=262_144, S=800, T=24):
                        "dtype": f"{e.w.dtype_name} models (DiT and motion VAE), f32 rasteriser"}}
 
 
+def bench_live_render(dev, P=262_144, T=32, V=128, S=512):
+    """The reference's LIVE render job of one sample (utils/inference_utils.py:240-269): 32 timesteps x 128 orbit cameras
+    = 4096 frames of 512 x 512, SH degree 0, mip filter, per-timestep 14-channel deltas, frames leave as uint8 -- through the product's
+    batched driver gvfdiffusion_amd.utils.render_sample_frames (96-frame launches, two in flight).  Secondary figure, not part of `value`."""
+    from gvfdiffusion_amd import synthetic
+    from gvfdiffusion_amd.renderers import GaussianRenderer
+    from gvfdiffusion_amd.utils import orbit_cameras, render_sample_frames
+    attrs = synthetic.random_gaussians(P, sh_degree=0, seed=7)
+    gm = synthetic.gaussian_model_from(attrs, 0, dev)
+    g = torch.Generator().manual_seed(11)
+    delta = (torch.randn((T, P, 14), generator=g) * 0.01).to(dev)
+    rend = GaussianRenderer({"resolution": S, "near": synthetic.NEAR, "far": synthetic.FAR, "ssaa": 1, "bg_color": (1, 1, 1)})
+    rend.pipe.kernel_size = synthetic.KERNEL_2D
+    K, cams = synthetic.intrinsics().to(dev), orbit_cameras(V).to(dev)
+
+    def job():
+        n, acc = 0, 0
+        for _, frames in render_sample_frames(rend, gm, delta, K, extrinsics=cams, chunk_frames=96, streams=2):
+            n += frames.shape[0]
+            acc += int(frames[0, 0, 0, 0])        # (touch each chunk on the host, as a consumer that writes PNGs would)
+        return n
+
+    with torch.no_grad():
+        job()                                      # warm-up: workspace sizing
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = job()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    assert n == T * V
+    return {"metric": "the reference's live render job: one sample = 32 timesteps x 128 orbit cameras x 512x512, SH degree 0, uint8 frames "
+                      "(utils/inference_utils.py:240-269) through render_sample_frames",
+            "value": round(n / dt, 1), "unit": "frames/s", "ms_per_sample": round(dt * 1e3, 2), "frames": n, "gaussians": P, "resolution": S,
+            "chunk_frames": 96, "chunks_in_flight": 2}
+
+
 def bench_sharded_sampling(dev, dist, rank, world, P, S, T, total_batch=8, steps=32):
     """BASELINE configs[4]: batch-sharded sampling (inference_dpm_latent.py:168-273 processes its batch sample by sample with no
     cross-sample operation).  Rank r owns samples r, r + world, ... of a batch of `total_batch`: 32-step DPM-Solver++(2M) on the
@@ -525,6 +562,9 @@ def main():
     if a.dit_only:
         print(json.dumps(bench_dit(dev)))
         return
+    if a.live_only:
+        print(json.dumps(bench_live_render(dev, a.gaussians)))
+        return
     if a.e2e_only:
         print(json.dumps(bench_e2e(dev, a.gaussians, a.res, a.frames)))
         return
@@ -702,6 +742,8 @@ def main():
             out["dit"] = bench_dit(dev)
             torch.cuda.empty_cache()
             out["end_to_end"] = bench_e2e(dev, a.gaussians, a.res, a.frames)
+            torch.cuda.empty_cache()
+            out["live_render"] = bench_live_render(dev, a.gaussians)
         if multi and not a.no_dit:
             for w_ in slots:
                 w_.__dict__.pop("ws", None)

@@ -116,6 +116,7 @@ constexpr int XT_KT = 64;              // keys per tile
 constexpr int XT_NBUF = 3;             // LDS ring depth (stages)
 constexpr int XT_TPS = XT_TILES_PER_STAGE;   // tiles per stage = per barrier
 constexpr int XT_TILE_CHUNKS = 512;    // 16-byte chunks per staged tile: 256 K + 256 V^T
+constexpr int XT_PF_CHUNKS = 16;       // landing zone of the prefetch loads (one dword per lane of one wave: 256 B that nobody reads)
 
 struct XtParams {
     const unsigned short* q;
@@ -128,6 +129,7 @@ struct XtParams {
     int* fallbacks;                    // optional: += 1 per workgroup that took the exact path
     const float* gamma_q;              // optional MultiHeadRMSNorm gain of q, f32 [H][32]
     int out_f32;                       // out is float (same element strides): the kernel's arithmetic without the output rounding
+    const char* pf; long long pf_lines; int pf_iters;      // optional: [pf, pf + 128 pf_lines) is touched once by the launch (see gvf_attn_tiled_fwd_pf)
 };
 
 template <int DT>
@@ -389,7 +391,7 @@ __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(
     typedef typename LP::x8 x8;
     // ring of XT_NBUF stages x XT_TPS tiles x (256 K chunks + 256 V^T chunks) + one chunk for the guard flag.  ONE LDS object on purpose:
     // with a second __shared__ variable hipcc drains the LDS-DMA queue (vmcnt(0)) in front of every ds_read.
-    __shared__ uint4 smem[XT_NBUF * XT_TPS * XT_TILE_CHUNKS + 1 + XT_ABL_LDSPAD + (XT_Q_LDS ? XT_THREADS * 4 : 0)];
+    __shared__ uint4 smem[XT_NBUF * XT_TPS * XT_TILE_CHUNKS + 1 + XT_ABL_LDSPAD + (XT_Q_LDS ? XT_THREADS * 4 : 0) + XT_PF_CHUNKS];
     volatile int* s_bad = reinterpret_cast<volatile int*>(&smem[XT_NBUF * XT_TPS * XT_TILE_CHUNKS]);
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -492,6 +494,17 @@ __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(
         }
         __syncthreads();            // stages 0 and 1 have landed (own DMA drained before the barrier)
         if (n_stages > 2) { XT_STAGE(2) }
+        if (p.pf != nullptr && wave == 0) {
+            // warm the NEXT launch's weights: one dword per 128-byte line, LDS-DMA into a landing zone nobody reads (no register, no wait of
+            // its own: the loads ride with the stage requests and are drained by the loop's barriers).  The lines end up in the Infinity
+            // Cache (and this XCD's L2), where the row-block launch that follows finds them instead of going to HBM.
+            uint4* pz = &smem[XT_NBUF * XT_TPS * XT_TILE_CHUNKS + 1 + XT_ABL_LDSPAD + (XT_Q_LDS ? XT_THREADS * 4 : 0)];
+            for (int it = 0; it < p.pf_iters; ++it) {
+                const long long line = ((long long)it * gridDim.x + blockIdx.x) * 64 + lane;
+                if (line < p.pf_lines)
+                    __builtin_amdgcn_global_load_lds(p.pf + line * 128, (__attribute__((address_space(3))) void*)pz, 4, 0, 0);
+            }
+        }
         if (!XT_ABL_NOLDS) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) kf[i >> 1][i & 1] = xt_ld_k<DT>(XT_K(0), i >> 1, i & 1, l31, half);
@@ -562,7 +575,10 @@ __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(
         // pushed every probability under 2^-12 (the padding's zero scores took part in the shift)
         // fp16 without the shift (bounded scores): every probability is >= 2^-14, so is the sum; below that the promise was broken
         const float l_min = SHIFT ? 0.015625f : (LP::kNeedsShift ? 3.0517578125e-05f : 7.8886e-31f);
-        const bool okA = lA > l_min && lA < 1.2676e30f, okB = lB > l_min && lB < 1.2676e30f;
+        // upper bound: with XT_SUM_MFMA the sum is taken over the ROUNDED probabilities, so an fp16 overflow shows up as l = inf; a build that
+        // sums the fp32 values (XT_SUM_MFMA=0) must bound l below fp16's largest number itself (as attn.hip's kvres kernel does)
+        const float l_max = (!XT_SUM_MFMA && LP::kNeedsShift) ? 32768.0f : 1.2676e30f;
+        const bool okA = lA > l_min && lA < l_max, okB = lB > l_min && lB < l_max;
         bad = !(okA && okB);
         if (XT_ABL_NOEXP || XT_ABL_NOQK || XT_ABL_NOPV || XT_ABL_NOSUM || XT_ABL_NOSYNC || XT_ABL_NOLDS) bad = false;   // timing experiments
     }
@@ -732,10 +748,10 @@ static void xt_launch(const XtParams& p, int force_safe, bool bounded, unsigned 
     attn_xt_kernel<DT, false><<<dim3(blocks), dim3(XT_THREADS), 0, stream>>>(p, force_safe);
 }
 
-extern "C" int gvf_attn_tiled_fwd(int dtype, const void* q, const void* k_tiles, const void* v_tiles, void* out, int n_outer, int n_inner,
+extern "C" int gvf_attn_tiled_fwd_pf(int dtype, const void* q, const void* k_tiles, const void* v_tiles, void* out, int n_outer, int n_inner,
                                   int Lq, int Lk, int H, const int64_t* q_strides, const int64_t* o_strides,
                                   int64_t kv_set_stride_outer, int64_t kv_set_stride_inner, const float* gamma_q, int out_is_f32,
-                                  int force_exact, int32_t* fallback_counter, void* stream_) {
+                                  int force_exact, int32_t* fallback_counter, const void* prefetch, int64_t prefetch_bytes, void* stream_) {
     if (dtype != GVF_DT_BF16 && dtype != GVF_DT_F16) return GVF_EINVAL;
     if (n_outer < 0 || n_inner <= 0 || Lq < 0 || Lk <= 0 || H <= 0) return GVF_EINVAL;
     if (n_outer == 0 || Lq == 0) return GVF_OK;
@@ -755,14 +771,25 @@ extern "C" int gvf_attn_tiled_fwd(int dtype, const void* q, const void* k_tiles,
     p.fallbacks = fallback_counter;
     p.gamma_q = gamma_q;
     p.out_f32 = out_is_f32;
+    if (prefetch_bytes < 0 || (prefetch_bytes > 0 && !prefetch)) return GVF_EINVAL;
+    p.pf = prefetch_bytes > 0 ? (const char*)prefetch : nullptr; p.pf_lines = prefetch_bytes / 128; p.pf_iters = 0;
     const long long blocks = (long long)p.q_blocks * H * n_inner * n_outer;
     if (blocks > 0x7fffffffLL) return GVF_EINVAL;
+    if (p.pf != nullptr) p.pf_iters = (int)((p.pf_lines + blocks * 64 - 1) / (blocks * 64));
     (void)hipGetLastError();
     const int force_safe = force_exact & GVF_ATTN_FORCE_EXACT;
     const bool bounded = (force_exact & GVF_ATTN_SCORES_BOUNDED) != 0;
     GVF_LP_DISPATCH(dtype, xt_launch<DT>(p, force_safe, bounded, (unsigned)blocks, (hipStream_t)stream_));
     GVF_CHECK_LAUNCH();
     return GVF_OK;
+}
+
+extern "C" int gvf_attn_tiled_fwd(int dtype, const void* q, const void* k_tiles, const void* v_tiles, void* out, int n_outer, int n_inner,
+                                  int Lq, int Lk, int H, const int64_t* q_strides, const int64_t* o_strides,
+                                  int64_t kv_set_stride_outer, int64_t kv_set_stride_inner, const float* gamma_q, int out_is_f32,
+                                  int force_exact, int32_t* fallback_counter, void* stream_) {
+    return gvf_attn_tiled_fwd_pf(dtype, q, k_tiles, v_tiles, out, n_outer, n_inner, Lq, Lk, H, q_strides, o_strides, kv_set_stride_outer,
+                                 kv_set_stride_inner, gamma_q, out_is_f32, force_exact, fallback_counter, nullptr, 0, stream_);
 }
 
 extern "C" int gvf_attn_tiled_fwd_bf16(const void* q, const void* k_tiles, const void* v_tiles, void* out, int n_outer, int n_inner,

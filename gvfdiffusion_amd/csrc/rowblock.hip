@@ -190,6 +190,29 @@ __device__ __forceinline__ void rb_put_frag(uint2* base, int ct, int rt, uint2 o
     base[(((ct >> 1) * 3 + rt) * 64 + 2 * (ct & 1) * 16) * 2] = o;
 }
 
+// Row reductions over the 4 lanes (l15, lq = 0..3) that share a row, without index registers: lane ^ 16 by ds_swizzle (bit mode, inside each
+// 32-lane half), lane ^ 32 by v_permlane32_swap (both results of the swap are the two halves' values: their sum / maximum IS the reduction).
+// __shfl_xor keeps its bounds-checked ds_bpermute index alive across the whole kernel (one of them was the MLP variant's last spilled register).
+__device__ __forceinline__ float rb_x16(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));
+}
+// (Pitfall, hipcc 7.2: __builtin_bit_cast(float, r[1]) on an ELEMENT of the builtin's vector result reads element 0 -- both "halves" came out
+// as r[0], i.e. the other half of the wave silently dropped out of every sum.  The elements are copied into scalars first.)
+__device__ __forceinline__ float rb_rowsum4(float v) {
+    v += rb_x16(v);
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const unsigned r0 = r[0], r1 = r[1];
+    return __uint_as_float(r0) + __uint_as_float(r1);
+}
+__device__ __forceinline__ float rb_rowmax4(float v) {
+    v = fmaxf(v, rb_x16(v));
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const unsigned r0 = r[0], r1 = r[1];
+    return fmaxf(__uint_as_float(r0), __uint_as_float(r1));
+}
+
 // LayerNorm of the 48 rows held in v (row 16 rt + l15, columns colw + 16 ct + i), times mul plus add, as bf16 fragments into
 // `block` (and to hb_out).  v is left centred.  Two barriers; the caller adds the one that publishes `block`.
 template <int DT>
@@ -201,8 +224,7 @@ __device__ __forceinline__ void rb_layernorm(f32x4 (&v)[3][RB_CT], float* sRed, 
         float s = 0.f;
 #pragma unroll
         for (int ct = 0; ct < RB_CT; ++ct) s += (v[rt][ct][0] + v[rt][ct][1]) + (v[rt][ct][2] + v[rt][ct][3]);
-        s += __shfl_xor(s, 16, 64);
-        s += __shfl_xor(s, 32, 64);
+        s = rb_rowsum4(s);
         rsum[rt] = s;
         if (lane < 16) sRed[wave * RB_BM + 16 * rt + lane] = s;
     }
@@ -220,8 +242,7 @@ __device__ __forceinline__ void rb_layernorm(f32x4 (&v)[3][RB_CT], float* sRed, 
         for (int ct = 0; ct < RB_CT; ++ct)
 #pragma unroll
             for (int i = 0; i < 4; ++i) { const float d = v[rt][ct][i] - mean; v[rt][ct][i] = d; q += d * d; }
-        q += __shfl_xor(q, 16, 64);
-        q += __shfl_xor(q, 32, 64);
+        q = rb_rowsum4(q);
         if (lane < 16) sRed[RB_NW * RB_BM + wave * RB_BM + 16 * rt + lane] = q;
     }
     rb_lds_barrier();
@@ -270,6 +291,9 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
 #define RB_STAMP() do { } while (0)
 #endif
     RB_STAMP();
+    // the launcher refuses these options for a TEMPORAL launch: compile their code (and the registers it holds) out of that variant
+    // (x_in / in_x belong to the first launch of a forward, which has neither an MLP nor a temporal section)
+    const bool has_x_in = !TEMPORAL && !MLP && p.x_in != nullptr, has_in_x = !TEMPORAL && !MLP && p.in_x != nullptr, has_kt = !TEMPORAL && p.kt != nullptr;
     uint4* R0 = &smem[0];                        // normalised rows (operand of mlp.0 / of the last projection)
     uint4* R1 = &smem[RB_BUF];                   // phase-1 activations, then the GELU'd hidden units of one 512-wide slice
     float* sPar = reinterpret_cast<float*>(&smem[RB_PAR]);
@@ -318,15 +342,18 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
         for (int ct = 0; ct < RB_CT; ++ct) wf[b][ct] = rb_ldw<DT>(s0 + ct * 64);
     }
     const int colw = wave * 64 + 4 * lq;        // this lane's first column inside column tile 0
-    float* xr[3];                                // this lane's three rows of the stream, at its first column
+    // this lane's three rows of the stream, at its first column: 32-bit element offsets from p.x (M * 512 floats < 2^32; three registers
+    // instead of three 64-bit pointers alive from the prologue to the last update)
+    unsigned xo[3];
 #pragma unroll
-    for (int rt = 0; rt < 3; ++rt) xr[rt] = p.x + srow(16 * rt + l15) * RB_C + colw;
+    for (int rt = 0; rt < 3; ++rt) xo[rt] = (unsigned)(srow(16 * rt + l15) * RB_C + colw);
+#define xr(rt_) (p.x + xo[rt_])
     f32x4 rs[3][RB_CT];                              // residual tile of x (or of x_in: input_layer adds to the position embedding,
                                                      // [sample][N][512] broadcast over the frames -- no 25 MB copy to initialise the stream)
 #pragma unroll
     for (int rt = 0; rt < 3; ++rt) {
-        const float* src = xr[rt];
-        if (p.x_in != nullptr) {
+        const float* src = xr(rt);
+        if (has_x_in) {
             const int grp = p.rpg > 0 ? m0 / p.rpg : 0, in_grp = p.rpg > 0 ? m0 % p.rpg : m0;
             src = p.x_in + ((long long)grp * p.x_in_period + (in_grp + 16 * rt + l15) % p.x_in_period) * RB_C + colw;
         }
@@ -383,9 +410,9 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
         for (int j = 0; j < RB_MAX_N3 / RB_THREADS; ++j)
             sPar[8 * RB_C + RB_MAX_HIDDEN + tid + RB_THREADS * j] = (p.b3 && tid + RB_THREADS * j < P3 * RB_C) ? vb3[j] : 0.f;
         if (TEMPORAL) sPar[8 * RB_C + RB_MAX_HIDDEN + RB_MAX_N3 + tid] = p.t_gk ? p.t_gk[tid] : 1.0f;
-        else if (p.kt != nullptr) sPar[8 * RB_C + RB_MAX_HIDDEN + RB_MAX_N3 + tid] = p.gamma_k ? p.gamma_k[tid] : 1.0f;
+        else if (has_kt) sPar[8 * RB_C + RB_MAX_HIDDEN + RB_MAX_N3 + tid] = p.gamma_k ? p.gamma_k[tid] : 1.0f;
     }
-    if (p.in_x != nullptr) {
+    if (has_in_x) {
         // input_layer in fp32 on the plain ALUs (16 input channels: 0.4 MFLOP per workgroup): W_in^T [Cin][512] and the block's 48 input rows
         // go to R1 (free: there is no phase-1 operand)
         float* sWt = reinterpret_cast<float*>(R1);
@@ -409,7 +436,7 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
     __syncthreads();                             // activations landed (own DMA drained before the barrier), parameters visible
     RB_STAMP();
 
-    if (p.in_x != nullptr) {                     // rs (= position embedding or x) += b_in + in_x W_in^T, column by column in fp32
+    if (has_in_x) {                     // rs (= position embedding or x) += b_in + in_x W_in^T, column by column in fp32
         const float* sWt = reinterpret_cast<const float*>(R1);
         const float* sXin = sWt + 16 * RB_C;
 #pragma unroll
@@ -450,12 +477,13 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
             for (int i = 0; i < 4; ++i) v[i] = rs[rt][ct][i] + g4[i] * (acc[rt][ct][i] + b4[i]);
             acc[rt][ct] = v;                     // LayerNorm works on (and overwrites) this copy;
             rs[rt][ct] = v;                      // the store reads this one: overwriting a register a store in flight still has to read
-            if (!MLP && !TEMPORAL) *reinterpret_cast<f32x4*>(xr[rt] + 16 * ct) = rs[rt][ct];      // means waiting for it, in order, behind the weight prefetch.
-                                                 // (MLP / TEMPORAL: the stream is written once, after the second update)
+            if (!MLP) *reinterpret_cast<f32x4*>(xr(rt) + 16 * ct) = rs[rt][ct];      // means waiting for it, in order, behind the weight prefetch.
+                                                 // (MLP: the stream is written once, after the second update.  TEMPORAL: written here and read
+                                                 // back for the second update -- 48 registers that the q / k / v passes and the attention need)
         }
     }
     RB_STAMP();
-    unsigned short* hb_rows = p.hb_out != nullptr ? p.hb_out + (long long)m0 * RB_C : nullptr;
+    unsigned short* hb_rows = (!TEMPORAL && p.hb_out != nullptr) ? p.hb_out + (long long)m0 * RB_C : nullptr;
     rb_layernorm<DT>(acc, sRed, sPar + 2 * RB_C, sPar + 3 * RB_C, p.eps, R0, MLP ? nullptr : hb_rows, wave, lane, lq, l15, colw);
 
     RB_STAMP();
@@ -491,9 +519,8 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
                         ss += f[e] * f[e];
                     }
                     if (rms) {
-                        ss += __shfl_xor(ss, 16, 64);
-                        ss += __shfl_xor(ss, 32, 64);
-                        const float inv = 5.656854249492381f / fmaxf(sqrtf(ss), 1e-12f);
+                        ss = rb_rowsum4(ss);
+                        const float inv = 5.656854249492381f * __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f));      // sqrt(32) / max(|x|, 1e-12), hardware rsq (1 ulp)
 #pragma unroll
                         for (int e = 0; e < 8; ++e) f[e] = f[e] * inv * g4[e >> 2][e & 3];
                     }
@@ -502,6 +529,23 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
             }
         };
         rb_lds_barrier();                                     // the normalised rows are complete in R0
+        // v FIRST (its weights lead the to_qkv segment of the stream: gvf_rowblock args / dit_ops.rowblock_pack_stream order the passes v | q | k):
+        // v^T, transposed by the MFMA itself (swapped operands), waits as 24 packed registers for the probabilities -- the other way round the
+        // 36 + 6 registers of probabilities and row sums would sit on top of the v pass's accumulators, weight fragments and the residual tile
+        // (round 3: 39 registers spilled, one reload inside the k-step loop)
+        // ... parked in the wave's own 6 KiB of R1 (free until the attention output goes there: head hh's output fragments are the 3 KiB behind
+        // wave * 6 KiB + hh * 3 KiB, and that is where head hh's v^T waits -- it is read back before the head's output is written; LDS
+        // operations of one wave execute in order).  24 registers less across the q and k passes.
+        uint2* vst = reinterpret_cast<uint2*>(R1) + wave * (6 * 64 * 2) + lane;
+        rb_zero(acc);
+        rb_gemm<D, DT, true>(acc, wf, R0 + lane, RB_KS, g, st);
+#pragma unroll
+        for (int ct = 0; ct < RB_CT; ++ct) {
+            const float bv = tb[2 * RB_C + wave * 64 + 16 * ct + l15];
+#pragma unroll
+            for (int rt = 0; rt < 3; ++rt)
+                vst[(ct * 3 + rt) * 64] = make_uint2(LP::pack(acc[rt][ct][0] + bv, acc[rt][ct][1] + bv), LP::pack(acc[rt][ct][2] + bv, acc[rt][ct][3] + bv));
+        }
         qk_pass(qop, tb, tb + 3 * RB_C);
         qk_pass(kop, tb + RB_C, tgk);
         // S^T tile (rk, rq) = K_rk Q_rq^T: lane (l15, lq) holds query row 16 rq + l15 against key rows 16 rk + 4 lq .. + 4.  A key counts
@@ -524,11 +568,12 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
                 same_tok[rq] = mm;
             }
         }
-        uint2 ppk[2][3][3];                                   // [head][rq][rk]: the probabilities, 16 bit
-        float linv[2][3];
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        uint2* fb1 = rb_frag_base(R1, wave, lq, l15);
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
+            uint2 ppk[3][3];                                  // [rq][rk]: this head's probabilities, 16 bit
+            float linv[3];
 #pragma unroll
             for (int rq = 0; rq < 3; ++rq) {
                 f32x4 sc[3];
@@ -542,42 +587,45 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
                         m = fmaxf(m, sc[rk][i]);
                     }
                 }
-                m = fmaxf(m, __shfl_xor(m, 16, 64));
-                m = fmaxf(m, __shfl_xor(m, 32, 64));            // finite: the query's own row is one of its keys
+                m = rb_rowmax4(m);            // finite: the query's own row is one of its keys
                 const float ms = m * p.t_kscale;
                 float l = 0.f;
 #pragma unroll
                 for (int rk = 0; rk < 3; ++rk) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) { sc[rk][i] = exp2f(sc[rk][i] * p.t_kscale - ms); l += sc[rk][i]; }
-                    ppk[hh][rq][rk] = make_uint2(LP::pack(sc[rk][0], sc[rk][1]), LP::pack(sc[rk][2], sc[rk][3]));
+                    for (int i = 0; i < 4; ++i) { sc[rk][i] = __builtin_amdgcn_exp2f(sc[rk][i] * p.t_kscale - ms); l += sc[rk][i]; }
+                    ppk[rq][rk] = make_uint2(LP::pack(sc[rk][0], sc[rk][1]), LP::pack(sc[rk][2], sc[rk][3]));
                 }
-                l += __shfl_xor(l, 16, 64);
-                l += __shfl_xor(l, 32, 64);
-                linv[hh][rq] = 1.0f / l;
+                l = rb_rowsum4(l);
+                linv[rq] = __builtin_amdgcn_rcpf(l);
             }
-        }
-        // v, transposed by the MFMA itself
-        rb_zero(acc);
-        rb_gemm<D, DT, true>(acc, wf, R0 + lane, RB_KS, g, st);
-        uint2* fb1 = rb_frag_base(R1, wave, lq, l15);
-#pragma unroll
-        for (int ct = 0; ct < RB_CT; ++ct) {
-            const float bv = tb[2 * RB_C + wave * 64 + 16 * ct + l15];
-            uint2 vp[3];
-#pragma unroll
-            for (int rt = 0; rt < 3; ++rt)
-                vp[rt] = make_uint2(LP::pack(acc[rt][ct][0] + bv, acc[rt][ct][1] + bv), LP::pack(acc[rt][ct][2] + bv, acc[rt][ct][3] + bv));
             // O^T = V^T P^T: contraction slots 0..3 <-> keys 4 lq .. + 4 of one 16-row tile, 4..7 of another (the third pairs with zeros)
-            const x8 v01 = __builtin_bit_cast(x8, make_uint4(vp[0].x, vp[0].y, vp[1].x, vp[1].y));
-            const x8 v2z = __builtin_bit_cast(x8, make_uint4(vp[2].x, vp[2].y, 0u, 0u));
+            uint2 vpk[2][3];
 #pragma unroll
-            for (int rq = 0; rq < 3; ++rq) {
-                const uint2 (&pp)[3] = ppk[ct >> 1][rq];
-                f32x4 o = LP::mfma16(v01, __builtin_bit_cast(x8, make_uint4(pp[0].x, pp[0].y, pp[1].x, pp[1].y)), zero4);
-                o = LP::mfma16(v2z, __builtin_bit_cast(x8, make_uint4(pp[2].x, pp[2].y, 0u, 0u)), o);
-                const float li = linv[ct >> 1][rq];
-                rb_put_frag(fb1, ct, rq, make_uint2(LP::pack(o[0] * li, o[1] * li), LP::pack(o[2] * li, o[3] * li)));
+            for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                for (int rt = 0; rt < 3; ++rt) vpk[c2][rt] = vst[((2 * hh + c2) * 3 + rt) * 64];
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                const int ct = 2 * hh + c2;
+                const x8 v01 = __builtin_bit_cast(x8, make_uint4(vpk[c2][0].x, vpk[c2][0].y, vpk[c2][1].x, vpk[c2][1].y));
+                const x8 v2z = __builtin_bit_cast(x8, make_uint4(vpk[c2][2].x, vpk[c2][2].y, 0u, 0u));
+#pragma unroll
+                for (int rq = 0; rq < 3; ++rq) {
+                    const uint2 (&pp)[3] = ppk[rq];
+                    f32x4 o = LP::mfma16(v01, __builtin_bit_cast(x8, make_uint4(pp[0].x, pp[0].y, pp[1].x, pp[1].y)), zero4);
+                    o = LP::mfma16(v2z, __builtin_bit_cast(x8, make_uint4(pp[2].x, pp[2].y, 0u, 0u)), o);
+                    const float li = linv[rq];
+                    rb_put_frag(fb1, ct, rq, make_uint2(LP::pack(o[0] * li, o[1] * li), LP::pack(o[2] * li, o[3] * li)));
+                }
+            }
+            if (hh == 0) {
+                // the residual tile comes back now (this lane's own stores of the phase-1 epilogue: same wave, same addresses, program
+                // order), under the second head's softmax arithmetic (the first head's operands are dead); consumed behind the to_out GEMM
+#pragma unroll
+                for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < RB_CT; ++ct) rs[rt][ct] = *reinterpret_cast<const volatile f32x4*>(xr(rt) + 16 * ct);
             }
         }
         rb_lds_barrier();                                     // the attention output is complete in R1
@@ -595,7 +643,7 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
                 for (int i = 0; i < 4; ++i) v[i] = rs[rt][ct][i] + g4[i] * (acc[rt][ct][i] + b4[i]);
                 acc[rt][ct] = v;
                 rs[rt][ct] = v;
-                *reinterpret_cast<f32x4*>(xr[rt] + 16 * ct) = rs[rt][ct];
+                *reinterpret_cast<f32x4*>(xr(rt) + 16 * ct) = rs[rt][ct];
             }
         }
         rb_layernorm<DT>(acc, sRed, sPar + 6 * RB_C, sPar + 7 * RB_C, p.eps, R0, nullptr, wave, lane, lq, l15, colw);
@@ -637,7 +685,7 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
                 for (int i = 0; i < 4; ++i) v[i] = rs[rt][ct][i] + g4[i] * (acc2[rt][ct][i] + b4[i]);
                 acc2[rt][ct] = v;
                 rs[rt][ct] = v;
-                *reinterpret_cast<f32x4*>(xr[rt] + 16 * ct) = rs[rt][ct];
+                *reinterpret_cast<f32x4*>(xr(rt) + 16 * ct) = rs[rt][ct];
             }
         }
         RB_STAMP();
@@ -672,7 +720,7 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
             }
         }
         rb_lds_barrier();
-        if (p.kt != nullptr && pass == 1) {
+        if (has_kt && pass == 1) {
             // K rows -> tile images: lane = 16-byte chunk of the row = (head lane / 4, dims 8 (lane & 3) ..): MultiHeadRMSNorm over the 4
             // lanes of a head in fp32, gain, softmax scale * log2 e, ONE rounding; chunk c of key slot s at s * 4 + (c ^ ((s >> 2) & 3)).
             // Exactly gvf_attn_pack_kv_bf16's arithmetic on the same bf16 values: the tiles are bit-identical.
@@ -707,7 +755,7 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
                 const int set = row / p.kv_L, key = row - set * p.kv_L, key_l = key & 63;
                 p.kt[((long long)(set * (RB_C / 32) + h) * p.kv_tiles + (key >> 6)) * 256 + key_l * 4 + (c ^ ((key_l >> 2) & 3))] = o;
             }
-        } else if (p.kt != nullptr && pass == 2) {
+        } else if (has_kt && pass == 2) {
             // V rows -> V^T tile images: thread = one (head, d) column; per 16-row group g' and half hf one 16-byte chunk = the 8 keys
             // 16 g' + 4 hf + {0,1,2,3,8,9,10,11} (the order the score accumulator of attn_xt holds them), chunk j = 2 g + hf of row d at
             // d * 8 + (j ^ ((d >> 1) & 7)).  A 16-row group never straddles a frame or a 64-key tile (kv_L % 64 == 0, m0 % 16 == 0).
@@ -738,7 +786,7 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
                 }
             }
         } else {
-            const int ldo = p.kt != nullptr ? RB_C : p.N3;
+            const int ldo = has_kt ? RB_C : p.N3;
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
                 const int r = wave * 6 + j;
@@ -752,6 +800,7 @@ __global__ __launch_bounds__(RB_THREADS, 1) void rowblock_kernel(RbParams p) {
         RB_STAMP();
     }
 #undef RB_STAMP
+#undef xr
 }
 
 // W bf16 [N][ldw] (nn.Linear layout) -> fragment order.  One 16-byte chunk per thread.
@@ -862,6 +911,8 @@ static int rowblock_launch(const gvf_rowblock_args* a, int dtype, void* stream_)
     }
     if (grouped && (a->rows_per_group <= 0 || a->rows_per_group % RB_BM != 0 || a->mod_ld < RB_C)) return GVF_EINVAL;
     const bool mlp = a->hidden != 0;
+    if (mlp && (a->in_x != nullptr || a->x_in != nullptr)) return GVF_EINVAL;      // (compiled out of the MLP variant)
+    if ((long long)a->M * RB_C >= (1LL << 32)) return GVF_EINVAL;                     // 32-bit element offsets into the stream
     if (mlp && (a->hidden < 0 || a->hidden % RB_C != 0 || a->hidden > RB_MAX_HIDDEN)) return GVF_EINVAL;
     if (a->N3 != 0 && (!a->out3 || a->N3 < 0 || a->N3 % RB_C != 0 || a->N3 > RB_MAX_N3 || a->epi3 != GVF_EPI_STORE_BF16))
         return GVF_EINVAL;

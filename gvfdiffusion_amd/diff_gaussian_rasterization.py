@@ -26,6 +26,26 @@ class GaussianRasterizationSettings(NamedTuple):
     debug: bool
 
 
+_ZERO_SEEN = {}       # id(tensor) -> (weakref, _version, data_ptr, all_zero): one device -> host read per tensor VERSION, not per call
+
+
+def _is_all_zero(t: torch.Tensor) -> bool:
+    """`not any(t != 0)` with the host sync paid once per (tensor object, version): a caller that hands the SAME zeros tensor to every call
+    (the usual way to satisfy the reference's subpixel_offset argument) pays it once.  A tensor rebuilt per call -- what
+    renderers/gaussian_render.py:108 does -- still costs one read-back per call, as the comparison itself would."""
+    import weakref
+    k = id(t)
+    hit = _ZERO_SEEN.get(k)
+    if hit is not None and hit[0]() is t and hit[1] == t._version and hit[2] == t.data_ptr():
+        return hit[3]
+    z = not bool(torch.any(t != 0))
+    if len(_ZERO_SEEN) > 64:
+        for kk in [kk for kk, v in _ZERO_SEEN.items() if v[0]() is None]:
+            del _ZERO_SEEN[kk]
+    _ZERO_SEEN[k] = (weakref.ref(t), t._version, t.data_ptr(), z)
+    return z
+
+
 class GaussianRasterizer(nn.Module):
     _MODE = _lib.RAST_MODE_MIP
 
@@ -39,7 +59,7 @@ class GaussianRasterizer(nn.Module):
                               getattr(rs, "kernel_size", 0.0), rs.scale_modifier, rs.bg, rs.prefiltered, rs.debug)
         fr = _r.make_frame(rs.viewmatrix, rs.projmatrix, rs.campos, rs.tanfovx, rs.tanfovy)
         sub = getattr(rs, "subpixel_offset", None)
-        if sub is not None and not bool(torch.any(sub != 0)):
+        if sub is not None and _is_all_zero(sub):
             sub = None  # the reference always passes zeros (gaussian_render.py:108)
         return _r.rasterize(st, fr, means3D, opacities, shs=shs, colors_precomp=colors_precomp, scales=scales,
                             rotations=rotations, cov3D_precomp=cov3D_precomp, subpixel_offset=sub,

@@ -193,6 +193,7 @@ class DiT(nn.Module):
         self.fuse_layernorm = int(os.environ.get("GVF_DIT_FUSE_LN", "0"))
         # one launch per sub-layer boundary (csrc/rowblock.hip) where the shapes allow it: 0 = the unfused GEMM / LayerNorm launches
         self.use_rowblock = int(os.environ.get("GVF_DIT_ROWBLOCK", "1")) != 0
+        self.weight_prefetch = int(os.environ.get("GVF_DIT_PREFETCH", "1")) != 0
         self.rowblock_tiled_kv = int(os.environ.get("GVF_DIT_TILED_KV", "1")) != 0    # to_qkv's launch writes the attention's K / V^T tiles itself
         # the temporal self attention runs INSIDE the row-block launch between the spatial and the image attention (T | 48): 6 launches per
         # block instead of 8, the qkv / attention-output buffers of the temporal sub-layer never exist
@@ -617,6 +618,11 @@ class DiT(nn.Module):
         def fused(a_, stream, **kw):
             dit_ops.rowblock_fused(a_, stream, h, mod_ld=mod_ld, rows_per_group=TNp, eps=1e-6, dtype=bf, **kw)
 
+        # every attention launch also touches the packed weights of the row-block launch behind it (GVF_DIT_PREFETCH=0: off): the 107 MB of
+        # weights of a forward cycle through the caches once per step, so each launch starts on cold weights -- while the attention before it,
+        # bound by its matrix / vector pipes, leaves the memory system idle
+        pf = (lambda t: t) if self.weight_prefetch else (lambda t: None)
+
         o = offs[0]
         # h = pos + input_layer(x); adaLN of block 0; its to_qkv
         # to_qkv of the spatial self attention: with whole 64-key tiles per frame its launch writes q row-major and K / V^T directly as the
@@ -652,7 +658,8 @@ class DiT(nn.Module):
             n3, n4 = dict(ln_w=b["n3"][0], ln_b=b["n3"][1]), dict(ln_w=b["n4"][0], ln_b=b["n4"][1])
             a = b["spatial_self_attn"]
             if tiled_kv:
-                dit_ops.attention_tiled(qs, kv_self[0], kv_self[1], ab, *fr["n"], N, N, H, fr["c"], fr["c"], *fr["kv"], gamma_q=a["gq"], bounded=a["bounded"])
+                dit_ops.attention_tiled(qs, kv_self[0], kv_self[1], ab, *fr["n"], N, N, H, fr["c"], fr["c"], *fr["kv"], gamma_q=a["gq"], bounded=a["bounded"],
+                                        prefetch=pf(s["s23"] if (temporal_fused and not self.no_temporal_attn) else s["s2"]))
             else:                                              # (never padded: see _forward)
                 dit_ops.attention_pack_kv(qkv, B * T, N, H, C, 2 * C, gamma_k=a["gk"], out=kv_self)
                 dit_ops.attention_tiled(qkv, kv_self[0], kv_self[1], ab, *fr["n"], N, N, H, fr["c3"], fr["c"], *fr["kv"], gamma_q=a["gq"], bounded=a["bounded"])
@@ -671,11 +678,11 @@ class DiT(nn.Module):
                     dit_ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], ab, B, N, T, T, H, st, st, st, (TNp * C, C, N * C), at["gq"], at["gk"])
                     fused(ab, s["s3"], b1=at["out"][1], gate1=g_t, ln1=n3, out3=qb, b3=ai["q"][1])
             kt, vt = ctx["kv_img"][i]
-            dit_ops.attention_tiled(qb, kt, vt, hb, *fr["n"], N, Li, H, fr["c"], fr["c"], *fr["kv"], gamma_q=ai["gq"], bounded=ai["bounded"])
+            dit_ops.attention_tiled(qb, kt, vt, hb, *fr["n"], N, Li, H, fr["c"], fr["c"], *fr["kv"], gamma_q=ai["gq"], bounded=ai["bounded"], prefetch=pf(s["s4"]))
             ast = b["static_cross_attn"]
             fused(hb, s["s4"], b1=ai["out"][1], ln1=n4, out3=qb, b3=ast["q"][1])
             kt, vt = ctx["kv_st"][i]
-            dit_ops.attention_tiled(qb, kt, vt, hb, B, T, N, Ls, H, fr_c, fr_c, 1, 0, gamma_q=ast["gq"], bounded=ast["bounded"])
+            dit_ops.attention_tiled(qb, kt, vt, hb, B, T, N, Ls, H, fr_c, fr_c, 1, 0, gamma_q=ast["gq"], bounded=ast["bounded"], prefetch=pf(s["s5"]))
             kw = dict(b1=ast["out"][1], ln1=dict(shift=sh_m, scale=sc_m), mlp_bias=(b["fc1"][1], b["fc2"][1]), hidden=hidden_units, gate_m=g_m)
             if i + 1 < len(blocks):
                 on = offs[i + 1]

@@ -70,6 +70,8 @@ _lib.register({
     "gvf_rowblock_fused": (_i, [ctypes.POINTER(RowblockArgs), _vp]),
     "gvf_rowblock_fused_bf16": (_i, [ctypes.POINTER(RowblockArgs), _vp]),
     "gvf_gemm_stats_parts": (_i, [_i]),
+    "gvf_attn_tiled_fwd_pf": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, ctypes.POINTER(_i64), ctypes.POINTER(_i64), _i64, _i64,
+                                   _vp, _i, _i, _vp, _vp, _i64, _vp]),
 })
 # every entry point that contracts 16-bit operands exists as NAME(dtype, ...) and as the round-1/2 wrapper NAME_bf16(...)
 _GEMM_ARGS = [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]
@@ -261,6 +263,9 @@ def rowblock_pack_stream(w1, mlp=None, w3=None, temporal=None):
         assert f1.shape == (f2.shape[1], ROWBLOCK_C) and f2.shape[0] == ROWBLOCK_C
         _lib.check(L.gvf_rowblock_pack_mlp(_p(f1), _p(f2), f1.shape[0], _p(out[sizes[0]:]), st), "gvf_rowblock_pack_mlp")
     if temporal is not None:
+        # the temporal section runs its passes v | q | k (csrc/rowblock.hip: v^T waits packed while q and k are projected), so the stream
+        # carries to_qkv's rows in that order; the biases stay [b_q | b_k | b_v] (the kernel addresses them by name)
+        tq = torch.cat([tq[2 * ROWBLOCK_C:], tq[:2 * ROWBLOCK_C]]).contiguous()
         _lib.check(L.gvf_rowblock_pack_weight(_p(tq), tq.stride(0), 3 * ROWBLOCK_C, ROWBLOCK_C, _p(out[sizes[0]:]), st), "gvf_rowblock_pack_weight")
         _lib.check(L.gvf_rowblock_pack_weight(_p(to), to.stride(0), ROWBLOCK_C, ROWBLOCK_C, _p(out[sizes[0] + 3 * ROWBLOCK_C * ROWBLOCK_C * 2:]), st),
                    "gvf_rowblock_pack_weight")
@@ -409,16 +414,19 @@ def attention_pack_kv(kv: torch.Tensor, n_sets: int, L: int, H: int, k_col0: int
 
 
 def attention_tiled(q, k_tiles, v_tiles, out, n_outer, n_inner, Lq, Lk, H, q_strides, o_strides, kv_stride_outer,
-                         kv_stride_inner, gamma_q=None, force_exact=False, fallback_counter=None, bounded=False):
+                         kv_stride_inner, gamma_q=None, force_exact=False, fallback_counter=None, bounded=False, prefetch=None):
     """Cross attention against a tiled K/V cache (head_dim 32) of q's 16-bit type; see include/gvf_dit.h.  bounded: the caller vouches that
-    every log2-domain score is <= 14 in magnitude (scores_bounded() below): fp16 then runs without the per-query shift."""
+    every log2-domain score is <= 14 in magnitude (scores_bounded() below): fp16 then runs without the per-query shift.
+    prefetch: optional tensor (the packed weight stream of the launch that follows): its bytes are touched once by this launch, so that the
+    next launch finds them in the Infinity Cache (gvf_attn_tiled_fwd_pf); results do not depend on it."""
     _lib.require_cuda(q, k_tiles, v_tiles, out)
     assert q.dtype in LP_DTYPES and out.dtype in (q.dtype, torch.float32)
-    _lib.check(_lib.lib().gvf_attn_tiled_fwd(dt_code(q.dtype), _p(q), _p(k_tiles), _p(v_tiles), _p(out), n_outer, n_inner, Lq, Lk, H,
-                                             _s4(q_strides), _s4(o_strides), int(kv_stride_outer), int(kv_stride_inner),
-                                             _p(gamma_q), int(out.dtype == torch.float32), int(bool(force_exact)) | (2 if bounded else 0),
-                                             _p(fallback_counter), _stream(q)),
-               "gvf_attn_tiled_fwd")
+    pf_bytes = 0 if prefetch is None else prefetch.numel() * prefetch.element_size()
+    _lib.check(_lib.lib().gvf_attn_tiled_fwd_pf(dt_code(q.dtype), _p(q), _p(k_tiles), _p(v_tiles), _p(out), n_outer, n_inner, Lq, Lk, H,
+                                                _s4(q_strides), _s4(o_strides), int(kv_stride_outer), int(kv_stride_inner),
+                                                _p(gamma_q), int(out.dtype == torch.float32), int(bool(force_exact)) | (2 if bounded else 0),
+                                                _p(fallback_counter), _p(prefetch), pf_bytes, _stream(q)),
+               "gvf_attn_tiled_fwd_pf")
     return out
 
 

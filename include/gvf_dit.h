@@ -118,7 +118,8 @@ typedef struct gvf_rowblock_args {
        (model/dit.py:255-261 -> model/attention/modules.py:119-140, heads of 32) between ln1 and the last projection:
            hb = ln1(x);  [q | k | v] = hb Wqkv^T + t_b_qkv;  o = softmax_frames(rms(q) rms(k)^T * t_scale) v  per token and head;
            x += t_gate * (o Wout^T + t_b_out);  hb = t_ln(x);  out3 = hb W3^T + b3
-       with the weight stream W1 | Wqkv (3 passes of 512) | Wout | W3.  A group (sample) is the frame-major stream (T, N, C) with
+       with the weight stream W1 | Wqkv (3 passes of 512, its row blocks in the order V | Q | K: the v pass runs first; t_b_qkv keeps the
+       module's order [b_q | b_k | b_v]) | Wout | W3.  A group (sample) is the frame-major stream (T, N, C) with
        t_stride = N: a token's frames are rows t_stride apart.  A workgroup owns 48 / t_frames tokens (t_frames must divide 48), a group
        ceil(N / (48 / t_frames)) workgroups = rows_per_group rows: when that is more than t_frames * N, the rows behind the tokens are the
        group's padding (the phantom tokens of its last workgroup; same layout as kv_group_rows).  t_gamma_q / t_gamma_k: MultiHeadRMSNorm
@@ -209,6 +210,15 @@ int gvf_attn_tiled_fwd_bf16(const void* q, const void* k_tiles, const void* v_ti
                             int Lq, int Lk, int H, const int64_t* q_strides, const int64_t* o_strides,
                             int64_t kv_set_stride_outer, int64_t kv_set_stride_inner, const float* gamma_q,
                             int out_is_f32, int force_exact, int32_t* fallback_counter, void* stream);
+/* The same launch, which also TOUCHES [prefetch, prefetch + prefetch_bytes) once (one dword per 128-byte line, spread over the workgroups,
+ * read into an LDS landing zone and discarded): the weights of the launch that FOLLOWS on the stream -- in the DiT block every attention is
+ * followed by a row-block launch whose 1-6 MB weight stream is new to the caches (107 MB of weights cycle through per denoise step) --
+ * arrive in the Infinity Cache while this launch, which is bound by its matrix / vector pipes and leaves the memory system idle, runs.
+ * The result does not depend on it.  prefetch_bytes = 0: exactly gvf_attn_tiled_fwd. */
+int gvf_attn_tiled_fwd_pf(int dtype, const void* q, const void* k_tiles, const void* v_tiles, void* out, int n_outer, int n_inner,
+                          int Lq, int Lk, int H, const int64_t* q_strides, const int64_t* o_strides,
+                          int64_t kv_set_stride_outer, int64_t kv_set_stride_inner, const float* gamma_q,
+                          int out_is_f32, int force_exact, int32_t* fallback_counter, const void* prefetch, int64_t prefetch_bytes, void* stream);
 
 /* out_bf16[r][:] = LN(x[r][:]) (eps, no affine) then either  * ln_w + ln_b  (affine LayerNorm, norm3/4)
  * or  * (1 + scale[g]) + shift[g]  (adaLN, g = r / rows_per_group; shift/scale rows have stride mod_ld),

@@ -18,8 +18,8 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define FENCE __builtin_amdgcn_sched_barrier(0);
 
 // HALVES = how many "half mixes" (8 big, 8 small, 32 exp, 16 cvt) a wave issues per iteration: 2 for one wave per SIMD, 1 for two
-template <int HALVES>
-__global__ __launch_bounds__(HALVES == 2 ? 256 : 512, 1) void k(float* out, long long* cyc, int iters, int mode) {
+template <int HALVES, int mode>
+__global__ __launch_bounds__(HALVES == 2 ? 256 : 512, 1) void k(float* out, long long* cyc, int iters) {
     bf16x8 a, b; bf16x4 a4, b4;
     for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(0.37f + 0.001f * (threadIdx.x % 61)); b[i] = (__bf16)(0.11f * (i + 1)); }
     for (int i = 0; i < 4; ++i) { a4[i] = (__bf16)1.0f; b4[i] = (__bf16)(0.01f * i); }
@@ -111,6 +111,21 @@ __global__ __launch_bounds__(HALVES == 2 ? 256 : 512, 1) void k(float* out, long
     if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
 }
 
+template <int M>
+static void launch_m(int waves, float* out, long long* cyc, int iters) {
+    if (waves == 1) k<2, M><<<256, 256>>>(out, cyc, iters); else k<1, M><<<256, 512>>>(out, cyc, iters);
+}
+static void launch(int waves, int mode, float* out, long long* cyc, int iters) {
+    switch (mode) {
+        case 0: launch_m<0>(waves, out, cyc, iters); break; case 1: launch_m<1>(waves, out, cyc, iters); break;
+        case 2: launch_m<2>(waves, out, cyc, iters); break; case 3: launch_m<3>(waves, out, cyc, iters); break;
+        case 4: launch_m<4>(waves, out, cyc, iters); break; case 5: launch_m<5>(waves, out, cyc, iters); break;
+        case 6: launch_m<6>(waves, out, cyc, iters); break; case 7: launch_m<7>(waves, out, cyc, iters); break;
+        case 8: launch_m<8>(waves, out, cyc, iters); break; case 9: launch_m<9>(waves, out, cyc, iters); break;
+        case 10: launch_m<10>(waves, out, cyc, iters); break; case 11: launch_m<11>(waves, out, cyc, iters); break;
+    }
+}
+
 int main() {
     float* out; (void)hipMalloc(&out, 256 * 512 * sizeof(float));
     long long* cyc; (void)hipMalloc(&cyc, 8);
@@ -122,10 +137,10 @@ int main() {
     for (int waves = 1; waves <= 2; ++waves) {
         for (int mode = 0; mode < 12; ++mode) {
             hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-            if (waves == 1) k<2><<<256, 256>>>(out, cyc, 200, mode); else k<1><<<256, 512>>>(out, cyc, 200, mode);
+            launch(waves, mode, out, cyc, 200);
             (void)hipDeviceSynchronize();
             (void)hipEventRecord(e0);
-            if (waves == 1) k<2><<<256, 256>>>(out, cyc, N, mode); else k<1><<<256, 512>>>(out, cyc, N, mode);
+            launch(waves, mode, out, cyc, N);
             (void)hipEventRecord(e1); (void)hipDeviceSynchronize();
             float ms; (void)hipEventElapsedTime(&ms, e0, e1);
             long long c; (void)hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);

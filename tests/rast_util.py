@@ -27,12 +27,17 @@ def oracle_render(oracle, attrs, cam, H, W, sh_degree, mode=0, kernel_size=synth
 RAST_ATOL = 1e-3
 
 
+FLIP_ATOL = 5e-3       # one splat at the alpha threshold skipped or added: <= (1/255) * colour (<= 1) * T (<= 1) = 3.9e-3, + margin
+
+
 def compare_images(hip: np.ndarray, ref: np.ndarray, flags: np.ndarray, atol=RAST_ATOL, max_flag_frac=0.03,
-                   flagged_atol=2e-2):
-    """max-abs <= atol on every pixel whose blend decisions are not within float noise of a
-    threshold (oracle `flags` == 0); flagged pixels (alpha ~ 1/255, T ~ 1e-4, power ~ 0: the oracle
-    uses libm expf, the device v_exp_f32) may differ by one skipped/added splat and are bounded
-    separately.  Returns (max_err_unflagged, max_err_flagged, flagged_fraction)."""
+                   flagged_atol=RAST_ATOL, max_flips=None, flip_atol=FLIP_ATOL):
+    """max-abs <= atol (north_star: 1e-3) on EVERY pixel, flagged or not, with one exemption: a flagged pixel (oracle `flags` != 0: one of its
+    blend decisions sits within float noise of a threshold -- alpha ~ 1/255, T ~ 1e-4, power ~ 0; the oracle uses libm expf, the device
+    v_exp_f32) may have taken the other side of that decision, i.e. differ by one skipped / added splat (<= FLIP_ATOL).  Such flips are
+    counted, printed and bounded: at most max(2, 1e-4 of the pixels) of them.  (Round 3 let every flagged pixel through at 2e-2; the measured
+    flagged error is ~2e-7, so the exemption now covers real flips only.)
+    Returns (max_err_unflagged, max_err_flagged, flagged_fraction)."""
     err = np.abs(hip - ref)
     if err.ndim == 3:
         err = err.max(axis=0)
@@ -42,5 +47,13 @@ def compare_images(hip: np.ndarray, ref: np.ndarray, flags: np.ndarray, atol=RAS
     frac = float((~clean).mean())
     assert e_clean <= atol, f"unflagged pixels differ by {e_clean} > {atol}"
     assert frac <= max_flag_frac, f"{frac:.4f} of the pixels are threshold-flagged"
-    assert e_flag <= flagged_atol, f"flagged pixels differ by {e_flag}"
+    flips = (~clean) & (err > flagged_atol)
+    n_flips = int(flips.sum())
+    if n_flips:
+        limit = max(2, int(1e-4 * err.size)) if max_flips is None else max_flips
+        worst = float(err[flips].max())
+        print(f"compare_images: {n_flips} of {int((~clean).sum())} flagged pixels took the other side of a threshold decision (max {worst:.2e}); "
+              f"every other pixel <= {atol}")
+        assert n_flips <= limit, f"{n_flips} flagged pixels differ by more than {flagged_atol} (limit {limit})"
+        assert worst <= flip_atol, f"a flagged pixel differs by {worst} > one threshold splat ({flip_atol})"
     return e_clean, e_flag, frac

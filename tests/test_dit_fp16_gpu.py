@@ -56,7 +56,12 @@ def test_gemm_epilogues_fp16(cuda, M, N, K):
     ref = a.float() @ w.float().T + bias
     out = torch.empty((M, N), dtype=F16, device=cuda)
     dit_ops.gemm(a, w, bias, out, dit_ops.EPI_STORE_16)
-    assert rel_l2(out, ref) < 4e-4                     # fp32 accumulation of exact products + ONE fp16 rounding (2^-11 = 4.9e-4 worst case)
+    # Which bar is which.  north_star's "1e-4 rel" is carried by the kernel's ARITHMETIC: fp32 accumulation of exact 16-bit products, asserted
+    # (a) on the fp32 output below (1e-5) and (b) here against the fp32 reference pushed through the SAME single fp16 rounding the output
+    # format forces (what differs is the summation order: a handful of results land on the other side of a rounding boundary).
+    assert rel_l2(out, ref.to(F16)) < 1e-4
+    # The 16-bit OUTPUT itself cannot be within 1e-4 of an fp32 reference: one fp16 rounding is 2^-11 = 4.9e-4 worst case, ~2.8e-4 rms.
+    assert rel_l2(out, ref) < 4e-4
     dit_ops.gemm(a, w, bias, out, dit_ops.EPI_GELU_16)
     assert rel_l2(out, torch.nn.functional.gelu(ref, approximate="tanh")) < 4e-4
     o32 = torch.empty((M, N), dtype=torch.float32, device=cuda)
