@@ -19,8 +19,7 @@ SOURCES = {
     "sort.hip": [],
     # -fno-slp-vectorize: left on, clang packs neighbouring scalar fp32 operations of the compositing loop into
     # v_pk_* instructions (4 cycles each against 2.8 for the scalar form, plus the v_mov traffic that builds the pairs)
-    # mfma-vgpr-form: the matrix-pipe blend reads its exponents straight from VGPRs (no v_accvgpr_read per compositing step)
-    "rast.hip": ["-ffp-contract=off", "-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"],
+    "rast.hip": ["-ffp-contract=off", "-fno-slp-vectorize"],
     "vox2seq.hip": [],
     "resize.hip": [],
     # the squared distances must round exactly as the oracle's binary32 expression does (index-exact parity)

@@ -15,7 +15,6 @@ _ERR = {GVF_EINVAL: "GVF_EINVAL (bad argument)", GVF_ENOSPC: "GVF_ENOSPC (worksp
 
 RAST_MODE_MIP, RAST_MODE_DILATE = 0, 1
 RAST_BIN_AUTO, RAST_BIN_RADIX, RAST_BIN_BUCKET = 0, 1, 2
-RAST_BLEND_AUTO, RAST_BLEND_CLASSIC, RAST_BLEND_MATRIX = 0, 1, 2
 
 
 class GvfError(RuntimeError):
@@ -32,7 +31,7 @@ class GvfRastSettings(ctypes.Structure):
     _fields_ = [("image_height", ctypes.c_int32), ("image_width", ctypes.c_int32), ("sh_degree", ctypes.c_int32),
                 ("mode", ctypes.c_int32), ("kernel_size", ctypes.c_float), ("scale_modifier", ctypes.c_float),
                 ("bg", ctypes.c_float * 3), ("prefiltered", ctypes.c_int32), ("debug", ctypes.c_int32),
-                ("upstream_binning", ctypes.c_int32), ("bin_algo", ctypes.c_int32), ("blend_algo", ctypes.c_int32)]
+                ("upstream_binning", ctypes.c_int32), ("bin_algo", ctypes.c_int32)]
 
 
 class GvfGaussianActivation(ctypes.Structure):

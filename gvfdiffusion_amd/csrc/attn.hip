@@ -167,13 +167,12 @@ __device__ __forceinline__ void tile64(const uint4* __restrict__ sKb, const unsi
 // argument, P = exp2(s), l += sum P.  No maximum tree, no subtraction, no rescale of O: 16 max3 + 32 fma fewer per 64 keys, and the
 // exponentials of one half-tile can issue while the matrix pipe still works on the other.  Valid while no exp2 overflows or all of
 // them vanish; the caller checks the denominators and falls back to tile64 (exact for any input).
-// fp16 operands: exp2 of a raw score leaves fp16's range at 16, so every query carries a SHIFT (cinit = the splat of minus the maximum of its
-// scores against the first key tile, tile_first_max below) that enters each QK^T MFMA as the accumulator's initial value -- the scheme of
-// attn_xt.hip; bf16: cinit is zero and folds into the MFMA's inline constant.
+// fp16 operands: exp2 of a raw score leaves fp16's range at 16, so every query carries a SHIFT (the maximum of its scores against the first
+// key tile, tile_first_max below), subtracted in front of the exponential; bf16 needs none.
 template <int D, bool MASKED, int NQ, int DT>
 __device__ __forceinline__ void tile64_nomax(const uint4* __restrict__ sKb, const unsigned short* __restrict__ sVTb, int key0, int Lk,
                                              const typename GvfLp<DT>::x8 (&qf)[NQ][Cfg<D>::NS], int l31, int half, f32x16 (&o_acc)[NQ][Cfg<D>::ND],
-                                             float (&l_run)[NQ], const f32x16 (&cinit)[NQ]) {
+                                             float (&l_run)[NQ], const float (&shift)[NQ]) {
     typedef GvfLp<DT> LP;
     typedef typename LP::x8 x8;
     // NQ 32-query tiles of the wave against the same 64 keys: every K / V^T fragment read from LDS feeds NQ MFMAs (the LDS port, not
@@ -186,7 +185,7 @@ __device__ __forceinline__ void tile64_nomax(const uint4* __restrict__ sKb, cons
         const int krow_l = sub * 32 + l31;
         const int sw = C::swz(krow_l);
 #pragma unroll
-        for (int t = 0; t < NQ; ++t) s_acc[t][sub] = LP::kNeedsShift ? cinit[t] : zero;
+        for (int t = 0; t < NQ; ++t) s_acc[t][sub] = zero;
 #pragma unroll
         for (int st = 0; st < C::NS; ++st) {
             const x8 kf = __builtin_bit_cast(x8, sKb[krow_l * C::KC + ((2 * st + half) ^ sw)]);
@@ -202,7 +201,11 @@ __device__ __forceinline__ void tile64_nomax(const uint4* __restrict__ sKb, cons
             float psum = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                float p0 = __builtin_amdgcn_exp2f(s_acc[t][sub][r]), p1 = __builtin_amdgcn_exp2f(s_acc[t][sub][r + 1]);
+                // fp16: the per-query shift is subtracted here (one v_sub per score: this kernel waits on its LDS reads and the matrix pipe, the
+                // vector ALUs have the slack) -- as the accumulator's initial value (round 3) it cost a 16-register splat per query tile and
+                // left fp16 with ONE query tile per wave, i.e. twice the fragment reads per query
+                float p0 = __builtin_amdgcn_exp2f(LP::kNeedsShift ? s_acc[t][sub][r] - shift[t] : s_acc[t][sub][r]);
+                float p1 = __builtin_amdgcn_exp2f(LP::kNeedsShift ? s_acc[t][sub][r + 1] - shift[t] : s_acc[t][sub][r + 1]);
                 if (MASKED) {
                     if ((key0 + 32 * sub + (r & 3) + 8 * (r >> 2) + 4 * half) >= Lk) p0 = 0.f;
                     if ((key0 + 32 * sub + ((r + 1) & 3) + 8 * ((r + 1) >> 2) + 4 * half) >= Lk) p1 = 0.f;
@@ -472,8 +475,7 @@ __global__ __launch_bounds__(RES_THREADS) void attn_kvres_kernel(AttnParams p, i
     using C = Cfg<D>;
     typedef GvfLp<DT> LP;
     typedef typename LP::x8 x8;
-    // fp16: the max-free softmax with a per-query shift (tile_first_max), ONE query tile per wave at a time (the shift splats of two would
-    // not fit the register budget of head_dim 64)
+    // fp16: the max-free softmax with a per-query shift (tile_first_max), subtracted in front of the exponential (tile64_nomax)
     constexpr bool NOMAX = RES_NOMAX != 0;
     constexpr int CPT = KT * C::KC;                            // 16-byte chunks per K tile (= per V tile)
     extern __shared__ __attribute__((aligned(16))) unsigned char res_smem[];
@@ -560,7 +562,7 @@ __global__ __launch_bounds__(RES_THREADS) void attn_kvres_kernel(AttnParams p, i
     __syncthreads();
 
     // ---- every wave: its 32-query tiles over all key tiles, straight from LDS; RES_NQ tiles at a time (passes qt, qt + 1, ...)
-    constexpr int NQ = NOMAX ? (LP::kNeedsShift ? 1 : RES_NQ) : 1;
+    constexpr int NQ = NOMAX ? RES_NQ : 1;
     for (int qt = 0; qt < qt_per_wg; qt += NQ) {
         int qrow[NQ];
         bool qvalid[NQ];
@@ -604,13 +606,9 @@ __global__ __launch_bounds__(RES_THREADS) void attn_kvres_kernel(AttnParams p, i
                 for (int r = 0; r < 16; ++r) o_acc[t][dt][r] = 0.f;
         }
         if (NOMAX) {
-            f32x16 cinit[NQ];
+            float cinit[NQ];                     // fp16: the shift of each query tile (its maximum over the first key tile); bf16: unused
 #pragma unroll
-            for (int t = 0; t < NQ; ++t) {
-                const float m0 = LP::kNeedsShift ? tile_first_max<D, DT>(sK, qf[t], l31, half) : 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) cinit[t][r] = -m0;
-            }
+            for (int t = 0; t < NQ; ++t) cinit[t] = LP::kNeedsShift ? tile_first_max<D, DT>(sK, qf[t], l31, half) : 0.f;
             for (int kt = 0; kt < n_tiles; ++kt) {
                 const uint4* kb = sK + (size_t)kt * CPT;
                 const unsigned short* vb = sVT + (size_t)kt * res_vt_tile<D>();

@@ -1434,165 +1434,10 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// R6, matrix-pipe variant (round 4): the exponent of a (pixel, splat) pair is a quadratic form in the pixel's position,
-//     power = ap dx^2 + cp dy^2 + bp dx dy,  (dx, dy) = (X - u, Y - v),  (X, Y) = splat centre, (u, v) = pixel, both relative to the quadrant
-//           = [ap X^2 + cp Y^2 + bp X Y] + u [-2 ap X - bp Y] + v [-2 cp Y - bp X] + u^2 ap + v^2 cp + u v bp,
-// i.e. a K = 6 contraction of a per-SPLAT coefficient vector with a per-PIXEL basis (1, u, v, u^2, v^2, u v): three
-// v_mfma_f32_32x32x2_f32 (exact fp32 products and sums, on the otherwise idle matrix pipe) give the exponents of 32 listed splats
-// against 32 pixels; two such sets cover the wave's 64 pixels.  The accumulator hands a lane 16 of the 32 splats of ONE pixel column, so
-// the two sets are exchanged half against half (16 v_permlane32_swap): afterwards every lane holds, for its OWN pixel, the exponents of
-// all 32 splats of the batch in list order (the rows of the coefficient operand are permuted accordingly), and the compositing loop is
-// the classic one without its seven dx / dy / exponent instructions and without the per-splat index + record reads (the batch's
-// (opacity, r, g, b) sit in list order in LDS: compile-time offsets).  22.75 -> ~15 vector instructions per compositing step.
-// Not bit-compatible with blend_kernel: the expanded form rounds differently (~1e-6 octaves), so a threshold decision (alpha < 1/255,
-// T < 1e-4, power > 0) can fall the other way on a pixel the oracle flags; everything else agrees to ~1e-6 -- north_star's bar is 1e-3.
-// The backward pass replays blend_kernel's arithmetic, so calls that can be differentiated keep the classic kernel (GVF_RAST_BLEND_AUTO).
-// ---------------------------------------------------------------------------------------------
-constexpr int MX_B = 32;          // splats per batch = rows of the coefficient operand
-
-template <bool DEPTH>
-__global__ __launch_bounds__(BLEND_THREADS) void blend_mx_kernel(
-    int P, int H, int W, int gx, int gy, float bg0, float bg1, float bg2, const uint2* __restrict__ ranges,
-    const uint32_t* __restrict__ point_list, const float4* __restrict__ splats,
-    const float* __restrict__ subpixel_offset, float* __restrict__ out_color,
-    float* __restrict__ out_alpha, float* __restrict__ out_depth, int nslab) {
-    typedef __attribute__((ext_vector_type(16))) float f32x16;
-    __shared__ float4 sA[BLEND_THREADS];
-    __shared__ float4 sB[BLEND_THREADS];
-    __shared__ float4 sC[BLEND_THREADS];
-    __shared__ unsigned char sMask[BLEND_THREADS];
-    __shared__ unsigned char sList[4][BLEND_THREADS];
-    __shared__ float4 sCol[4][MX_B];                       // the batch in list order: {opacity, r, g, b}
-    __shared__ float sDep[4][MX_B];
-
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int f = blockIdx.y;
-    const int tile = blockIdx.x;
-    const int tx = tile % gx, ty = tile / gx;
-    const int qx0 = tx * TILE + (wave & 1) * 8, qy0 = ty * TILE + (wave >> 1) * 8;
-    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
-    const bool inside = px < W && py < H;
-    const size_t pid = (size_t)py * W + px;
-    float u = (float)(lane & 7), v = (float)(lane >> 3);   // the pixel relative to its quadrant
-    if (subpixel_offset != nullptr && inside) { u += subpixel_offset[2 * pid]; v += subpixel_offset[2 * pid + 1]; }
-    // basis operands.  Set 0 = the pixels of lanes 0..31, set 1 = those of lanes 32..63; operand lane l = (column l & 31, k = l >> 5):
-    // k = 0 carries (1, v, v^2), k = 1 carries (u, u^2, u v) of the column's pixel -- the lane's own or its partner's (lane ^ 32)
-    const float up = __shfl_xor(u, 32, 64), vp = __shfl_xor(v, 32, 64);
-    const bool lo = lane < 32;
-    const float B0[3] = {lo ? 1.0f : up, lo ? v : up * up, lo ? v * v : up * vp};
-    const float B1[3] = {lo ? 1.0f : u, lo ? vp : u * u, lo ? vp * vp : u * v};
-    // coefficient operand: lane l = (row l & 31, k = l >> 5); row i holds the splat at list position pos(i), so that after the half
-    // exchange accumulator register r of X is position r and of Y position 16 + r
-    const int row = lane & 31;
-    const int pos = (row & 3) + 4 * (row >> 3) + 16 * ((row >> 2) & 1);
-
-    const size_t seg0 = ((size_t)f * gx * gy + tile) * nslab;
-    const uint2 rng = make_uint2(ranges[seg0].x, ranges[seg0 + nslab - 1].y);
-    const size_t gbase = (size_t)f * P;
-    const int rounds = (int)((rng.y - rng.x + BLEND_THREADS - 1) / BLEND_THREADS);
-    int todo = (int)(rng.y - rng.x);
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
-
-    bool done = !inside;
-    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dacc = 0.f;
-    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-
-    for (int r = 0; r < rounds; ++r, todo -= BLEND_THREADS) {
-        if (__syncthreads_count(done) == BLEND_THREADS) break;
-        if (t < todo) {
-            uint32_t id = point_list[rng.x + (uint32_t)r * BLEND_THREADS + t];
-            const float4* rec = splats + 4 * (gbase + id);
-            const float4 a = rec[0];
-            const float4 c = rec[2];
-            sA[t] = a;
-            sC[t] = make_float4(c.x, c.y, 0.f, 0.f);
-            const float4 b = rec[1];
-            sB[t] = b;
-            sMask[t] = (unsigned char)quadrant_mask(a.x, a.y, a.z, a.w, b.x, b.y, c.z, (float)(tx * TILE), (float)(ty * TILE), subpixel_offset != nullptr);
-        }
-        __syncthreads();
-        const int cnt = min(BLEND_THREADS, todo);
-        if (__all(done)) continue;
-        int n_w = 0;
-#pragma unroll
-        for (int k = 0; k < BLEND_THREADS / GVF_WAVE; ++k) {
-            const int idx = k * GVF_WAVE + lane;
-            const bool hit = idx < cnt && ((sMask[idx] >> wave) & 1u);
-            const uint64_t bal = __ballot(hit);
-            if (hit) sList[wave][n_w + __popcll(bal & lt_mask)] = (unsigned char)idx;
-            n_w += __popcll(bal);
-        }
-        __builtin_amdgcn_wave_barrier();
-        for (int base = 0; base < n_w; base += MX_B) {
-            if (__all(done)) break;
-            // ---- coefficients of the batch (each lane: 3 of the 6 of its row's splat) and its colours in list order
-            const bool valid = base + pos < n_w;
-            const int idx = valid ? (int)sList[wave][base + pos] : 0;
-            const float4 a = sA[idx];
-            const float4 b = sB[idx];
-            const float2 c = make_float2(sC[idx].x, sC[idx].y);
-            const float X = a.x - (float)qx0, Y = a.y - (float)qy0;
-            const float ap = a.z, bp = a.w, cp = b.x;
-            const float c0 = __builtin_fmaf(bp * X, Y, __builtin_fmaf(cp * Y, Y, (ap * X) * X));
-            const float c1 = -(__builtin_fmaf(2.0f * ap, X, bp * Y)), c2 = -(__builtin_fmaf(2.0f * cp, Y, bp * X));
-            float A0 = lo ? c0 : c1, A1 = lo ? c2 : ap, A2 = lo ? cp : bp;
-            if (!valid) { A0 = lo ? 1.0f : 0.0f; A1 = 0.0f; A2 = 0.0f; }     // padding rows: power = 1 > 0, skipped at every pixel
-            if (lo) {
-                sCol[wave][pos] = valid ? make_float4(b.y, b.z, b.w, c.x) : make_float4(0.f, 0.f, 0.f, 0.f);
-                if (DEPTH) sDep[wave][pos] = valid ? c.y : 0.f;
-            }
-            f32x16 xa = __builtin_amdgcn_mfma_f32_32x32x2f32(A0, B0[0], zero16, 0, 0, 0);
-            f32x16 ya = __builtin_amdgcn_mfma_f32_32x32x2f32(A0, B1[0], zero16, 0, 0, 0);
-            xa = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, B0[1], xa, 0, 0, 0);
-            ya = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, B1[1], ya, 0, 0, 0);
-            xa = __builtin_amdgcn_mfma_f32_32x32x2f32(A2, B0[2], xa, 0, 0, 0);
-            ya = __builtin_amdgcn_mfma_f32_32x32x2f32(A2, B1[2], ya, 0, 0, 0);
-            float pw[MX_B];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(xa[q]), __float_as_uint(ya[q]), false, false);
-                pw[q] = __uint_as_float(sw[0]);
-                pw[16 + q] = __uint_as_float(sw[1]);
-            }
-            __builtin_amdgcn_wave_barrier();               // sCol / sDep of this batch are written (LDS operations of a wave execute in order)
-            const int nb = min(MX_B, n_w - base);
-#pragma unroll
-            for (int j = 0; j < MX_B; ++j) {
-                if ((j & 3) == 0) {
-                    if (j >= nb) break;
-                    if (j != 0 && __all(done)) break;
-                }
-                const float4 col = sCol[wave][j];
-                const float power = pw[j];
-                const float alpha = fminf(0.99f, col.x * __builtin_amdgcn_exp2f(power));
-                const bool ok = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-                const float w_raw = alpha * T;
-                const float test_T = T - w_raw;
-                const bool stop = ok && test_T < 0.0001f;
-                done = done || stop;
-                const bool acc = ok != stop;
-                const float wgt = acc ? w_raw : 0.0f;
-                C0 = __builtin_fmaf(col.y, wgt, C0);
-                C1 = __builtin_fmaf(col.z, wgt, C1);
-                C2 = __builtin_fmaf(col.w, wgt, C2);
-                if (DEPTH) Dacc = __builtin_fmaf(sDep[wave][j], wgt, Dacc);
-                T = acc ? test_T : T;
-            }
-            __builtin_amdgcn_wave_barrier();               // every lane has read this batch's colours before the next batch overwrites them
-        }
-    }
-    if (inside) {
-        const size_t hw = (size_t)H * W;
-        float* oc = out_color + (size_t)f * 3 * hw;
-        oc[0 * hw + pid] = __builtin_fmaf(T, bg0, C0);
-        oc[1 * hw + pid] = __builtin_fmaf(T, bg1, C1);
-        oc[2 * hw + pid] = __builtin_fmaf(T, bg2, C2);
-        if (out_alpha != nullptr) out_alpha[(size_t)f * hw + pid] = 1.0f - T;
-        if (out_depth != nullptr) out_depth[(size_t)f * hw + pid] = Dacc;
-    }
-}
-
+// (Round 4 measured a matrix-pipe variant of this kernel -- the exponents of 32 splats x 64 pixels from v_mfma_f32_32x32x2_f32 on the expanded
+// quadratic form, or from ONE v_mfma_f32_32x32x16_f16 with hi / lo split coefficients, software-pipelined under the compositing steps;
+// 22.3 -> 14.4 vector instructions per step, images within 1e-6 of this kernel's -- and dropped it: 0.92 ms (fp16 split) / 1.03 ms (f32)
+// against 0.80 ms.  profiles/r04_blend_matrix_pipe.txt has the numbers, git history (round 4) the kernel.)
 // C1 post-process: rgb float -> uint8 exactly as utils/inference_utils.py:280-286 does on the host
 // (clamp(0,1) * 255, truncating cast), so frames leave the device at 1 byte per channel.
 __global__ __launch_bounds__(256) void rgb_to_u8_kernel(const float4* __restrict__ src, uchar4* __restrict__ dst,
@@ -1726,7 +1571,6 @@ int run_pipeline(const GvfRastSettings& st, const GvfRastFrame* frames_host, int
     if (H <= 0 || W <= 0 || P < 0 || F <= 0 || max_rendered < 0 || max_rendered > 0xFFFFFFFFll) return GVF_EINVAL;
     if (st.sh_degree < 0 || st.sh_degree > 3) return GVF_EINVAL;
     if (st.mode != GVF_RAST_MODE_MIP && st.mode != GVF_RAST_MODE_DILATE) return GVF_EINVAL;
-    if (st.blend_algo < GVF_RAST_BLEND_AUTO || st.blend_algo > GVF_RAST_BLEND_MATRIX) return GVF_EINVAL;
     if (!out_color || !out_num_rendered || !frames_host || !workspace) return GVF_EINVAL;
     if (P > 0 && colors_precomp == nullptr) {
         if (sh == nullptr || M < (st.sh_degree + 1) * (st.sh_degree + 1) || M > MAX_SH_COEFFS) return GVF_EINVAL;
@@ -1865,13 +1709,14 @@ int run_pipeline(const GvfRastSettings& st, const GvfRastFrame* frames_host, int
     }
     uint32_t* vals_sorted = w.ids;
     prof_mark(stream, slot, 6);
-    const bool mx = st.blend_algo == GVF_RAST_BLEND_MATRIX || (st.blend_algo == GVF_RAST_BLEND_AUTO && fused);
-#define GVF_LAUNCH_BLEND(K_)                                                                                                    \
-    hipLaunchKernelGGL(K_, dim3(ntiles, F), dim3(BLEND_THREADS), 0, stream, P, H, W, gx, gy, st.bg[0], st.bg[1], st.bg[2], w.ranges,  \
-                       vals_sorted, w.splats, subpixel_offset, out_color, out_alpha, out_depth, nslab_blend)
-    if (mx) { if (out_depth != nullptr) GVF_LAUNCH_BLEND(blend_mx_kernel<true>); else GVF_LAUNCH_BLEND(blend_mx_kernel<false>); }
-    else { if (out_depth != nullptr) GVF_LAUNCH_BLEND(blend_kernel<true>); else GVF_LAUNCH_BLEND(blend_kernel<false>); }
-#undef GVF_LAUNCH_BLEND
+    if (out_depth != nullptr)
+        hipLaunchKernelGGL(blend_kernel<true>, dim3(ntiles, F), dim3(BLEND_THREADS), 0, stream, P, H, W, gx, gy, st.bg[0],
+                           st.bg[1], st.bg[2], w.ranges, vals_sorted, w.splats, subpixel_offset,
+                           out_color, out_alpha, out_depth, nslab_blend);
+    else
+        hipLaunchKernelGGL(blend_kernel<false>, dim3(ntiles, F), dim3(BLEND_THREADS), 0, stream, P, H, W, gx, gy, st.bg[0],
+                           st.bg[1], st.bg[2], w.ranges, vals_sorted, w.splats, subpixel_offset,
+                           out_color, out_alpha, out_depth, nslab_blend);
     GVF_CHECK_LAUNCH();
     prof_mark(stream, slot, 7);
     return GVF_OK;

@@ -49,11 +49,10 @@ def _f32c(t: Optional[torch.Tensor], name: str) -> Optional[torch.Tensor]:
 
 # binning algorithm used when make_settings() is not told otherwise (tests flip it to cover both paths)
 DEFAULT_BIN_ALGO = _lib.RAST_BIN_AUTO
-DEFAULT_BLEND_ALGO = int(os.environ.get("GVF_RAST_BLEND", _lib.RAST_BLEND_AUTO))     # 0 auto, 1 classic, 2 matrix (A/B measurements)
 
 
 def make_settings(H, W, sh_degree, mode, kernel_size, scale_modifier, bg, prefiltered=False, debug=False,
-                  upstream_binning=False, bin_algo=None, blend_algo=None):
+                  upstream_binning=False, bin_algo=None):
     st = _lib.GvfRastSettings()
     st.image_height, st.image_width, st.sh_degree, st.mode = int(H), int(W), int(sh_degree), int(mode)
     st.kernel_size, st.scale_modifier = float(kernel_size), float(scale_modifier)
@@ -62,7 +61,6 @@ def make_settings(H, W, sh_degree, mode, kernel_size, scale_modifier, bg, prefil
     st.prefiltered, st.debug = int(bool(prefiltered)), int(bool(debug))
     st.upstream_binning = int(bool(upstream_binning))   # True: num_rendered counts upstream's 3-sigma tile rects
     st.bin_algo = int(DEFAULT_BIN_ALGO if bin_algo is None else bin_algo)   # _lib.RAST_BIN_*: see include/gvf_rast.h
-    st.blend_algo = int(DEFAULT_BLEND_ALGO if blend_algo is None else blend_algo)      # _lib.RAST_BLEND_*: AUTO = matrix-pipe blend for the batched (inference) path
     return st
 
 

@@ -69,18 +69,7 @@ typedef struct GvfRastSettings {
                                  pair at each pixel, so images are identical and num_rendered is smaller;
                                  1: bin the whole 3-sigma tile rect, num_rendered equals upstream's count */
     int32_t bin_algo;         /* GVF_RAST_BIN_*: how instances reach their tile segment (same image either way) */
-    int32_t blend_algo;       /* GVF_RAST_BLEND_*: which compositing kernel (R6) runs */
 } GvfRastSettings;
-
-/* CLASSIC: every lane evaluates its pixel's exponent against each listed splat on the vector ALUs (upstream's arithmetic; the backward
- * pass replays exactly this kernel's decisions).  MATRIX: the exponents of 32 splats x 64 pixels come from the matrix pipe
- * (v_mfma_f32_32x32x2_f32 on the expanded quadratic form, exact fp32 products and sums) and the compositing loop only exponentiates and
- * blends: ~1/3 fewer vector instructions per (pixel, splat).  The expanded form rounds differently (~1e-6 octaves): images agree to ~1e-6
- * except where a threshold decision (alpha < 1/255, T < 1e-4) sits inside that noise.  AUTO (0): MATRIX for gvf_rast_forward_batched (the
- * inference path, no backward), CLASSIC for gvf_rast_forward (the differentiable operator). */
-#define GVF_RAST_BLEND_AUTO    0
-#define GVF_RAST_BLEND_CLASSIC 1
-#define GVF_RAST_BLEND_MATRIX  2
 
 /* BUCKET (default): Gaussians are put in Morton order once per call, per-tile instance counts are taken in the
  * preprocess kernel (LDS histogram per block, one global atomic per touched tile), their scan gives the tile

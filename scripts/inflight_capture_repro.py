@@ -9,6 +9,9 @@ the sampler's latents, the decoded deltas, the uint8 frames.  Switches (environm
   REPRO_NO_GC=1        gc.collect() likewise
   REPRO_NO_SYNC=1      torch.cuda.synchronize() likewise (the two device-wide syncs of a capture)
   REPRO_PAUSE=1        the OTHER slot is paused (at its next model call) while a slot captures: capture never overlaps foreign launches
+  REPRO_DET=1          torch.use_deterministic_algorithms(True): rocBLAS without atomics
+  REPRO_SOLOCOND=1     DiT.prepare_conditions (the hoisted fp32 library GEMMs) runs with the device to itself: every other slot is held at its
+                       next model call and the device is drained before and after
   REPRO_ROUNDS, REPRO_SAMPLES, REPRO_VIEWS, REPRO_GAUSSIANS, REPRO_STEPS
 
     python scripts/inflight_capture_repro.py            # prints one line per divergent sample and a summary
@@ -72,6 +75,22 @@ def main():
                 real_cap_lock.release(); gate.release()
         dit_mod._CAPTURE_LOCK = Both()
         dit_mod.DiT._forward_graphed = gated
+
+    if env("REPRO_DET") == "1":
+        torch.use_deterministic_algorithms(True, warn_only=True)
+    if env("REPRO_SOLOCOND") == "1":
+        cond_gate = threading.Lock()
+        real_prep = dit_mod.DiT.prepare_conditions
+        real_fwd2 = dit_mod.DiT._forward
+
+        def solo_prep(self, *a, **k):
+            hit = getattr(self, "_ctx_cache", None)
+            with cond_gate:
+                torch.cuda.synchronize()
+                out = real_prep(self, *a, **k)
+                torch.cuda.synchronize()
+            return out
+        dit_mod.DiT.prepare_conditions = solo_prep
 
     def job(slot, i):
         f = chain(slot, i)

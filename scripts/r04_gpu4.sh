@@ -3,8 +3,18 @@
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 O=gpurun_out/r04d; mkdir -p $O
 export TMPDIR=/tmp
-scripts/ubench/f32mfma_overlap.bin > $O/f32mfma_overlap.txt 2>&1
-cat $O/f32mfma_overlap.txt
+# safety net: rebuild on the box if the shipped library does not match the shipped sources (an edit between `gpurun` and the snapshot)
+python - <<'PY'
+import sys
+sys.path.insert(0, '.')
+from gvfdiffusion_amd import _build
+import os
+stamp = open(_build.STAMP_PATH).read().strip() if os.path.exists(_build.STAMP_PATH) else ''
+if stamp != _build.source_hash():
+    print('library stale on the box: rebuilding'); _build.build(force=True)
+PY
+true
+true
 timeout 1500 python -m pytest tests/test_rowblock_temporal_gpu.py tests/test_dit_gpu.py tests/test_dit_fp16_gpu.py -x -q > $O/tests_dit.txt 2>&1
 tail -4 $O/tests_dit.txt
 timeout 900 python -m pytest tests/test_pipeline_gpu.py -x -q -s -k "full_size" > $O/pipeline_full.txt 2>&1

@@ -735,6 +735,44 @@ def test_sampler_drives_the_hip_dit(cuda):
         assert r < 5e-2
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_precomputed_modulation_table_changes_nothing(cuda, graph):
+    """DPM_Solver announces its fixed time grid (model_wrapper.prepare_times -> DiT.precompute_modulation): the timestep embedding and the
+    adaLN projections of all steps come from ONE batched pass and the forwards look their step up by the host values the time tensor
+    carries.  Same kernels on the same inputs: the sample is bit-identical to one drawn with the table switched off, eager and graphed,
+    with and without three-way guidance; a time the table does not know is computed inside the forward."""
+    from gvfdiffusion_amd.model.dpmsolver import NoiseScheduleVP, model_wrapper, DPM_Solver
+    from gvfdiffusion_amd.model.gaussian_diffusion import create_gaussian_diffusion
+    g, cfg, sd, model = _load_small(cuda)
+    model.enable_graph(graph)
+    ns = NoiseScheduleVP("discrete", betas=torch.from_numpy(create_gaussian_diffusion(noise_schedule="cosine", predict_type="v").betas))
+    cond = {"cond_images": torch.from_numpy(g["cond_images"]).to(cuda), "static_latent": torch.from_numpy(g["static_latent"]).to(cuda),
+            "deformation_position_xyz": torch.from_numpy(g["xyz"]).to(cuda)}
+    uncond = dict(cond); uncond["cond_images"] = torch.zeros_like(cond["cond_images"])
+    xT = torch.randn(g["x"].shape, generator=torch.Generator().manual_seed(5)).to(cuda)
+    for scales in ((1.0, 1.0), (2.0, 3.0)):
+        outs = []
+        for use_table in (True, False):
+            model._mod_table = None
+            mf = model_wrapper(model, ns, model_type="v", model_kwargs={}, guidance_type="classifier-free", guidance_scale=scales[0],
+                               guidance_scale2=scales[1], condition=cond, unconditional_condition=uncond)
+            if not use_table:
+                mf.prepare_times = lambda ts: None
+            solver = DPM_Solver(mf, ns, algorithm_type="dpmsolver++")
+            outs.append(solver.sample(xT, steps=5, t_start=1.0, t_end=1 / 1000, order=2, skip_type="time_uniform", method="multistep"))
+            assert (model._mod_table is not None) == use_table
+        assert torch.equal(outs[0], outs[1]), scales
+    # a time outside the table (the adaptive solver's): computed in the forward, as before
+    model._mod_table = None
+    model.precompute_modulation(torch.tensor([500.0, 250.0]))
+    t = torch.tensor([123.0]).to(cuda); t.gvf_host_values = (123.0,)
+    y0 = model(torch.from_numpy(g["x"]).to(cuda), t.expand(g["x"].shape[0]), **cond)
+    model._mod_table = None
+    y1 = model(torch.from_numpy(g["x"]).to(cuda), t.expand(g["x"].shape[0]), **cond)
+    assert torch.equal(y0, y1)
+    model.enable_graph(False)
+
+
 def test_adaptive_solver_on_the_hip_dit_matches_fp32_oracle(cuda):
     """BASELINE configs[3] uses the adaptive DPM-Solver (model/dpmsolver.py:973-1027): its accept / reject decisions are data
     dependent, so reduced-precision noise in the denoiser can change the number of network evaluations.  Covered size: the

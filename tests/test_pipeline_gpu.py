@@ -173,5 +173,7 @@ def test_full_size_adaptive_chain_matches_fp32_oracle_chain(cuda):
     print(f"configs[3] full size: adaptive NFE hip {n_hip} / fp32 oracle {n_ref}; sample rel_l2 {r_x:.2e}; delta rel_l2 {r_d:.2e}; "
           f"frame PSNR {psnr:.1f} dB" + ("" if n_hip == n_ref else "  <- the bf16 denoiser moved an accept / reject decision"))
     assert torch.isfinite(f_hip).all() and f_hip.shape == (T, 3, S, S)
-    assert abs(n_hip - n_ref) <= 4
-    assert r_x < 5e-2 and r_d < 5e-2 and psnr > 40.0
+    # measured (round 4, fp16 denoiser against the fp32 oracle chain): NFE 44 = 44, sample 1.74e-2, deltas 5.3e-3, frames 50.2 dB; bars = measured
+    # + 30 % / - 4 dB, and at most ONE accept / reject decision of the adaptive solver (order 2: two evaluations) may fall the other way
+    assert abs(n_hip - n_ref) <= 2
+    assert r_x < 2.3e-2 and r_d < 7e-3 and psnr > 46.0

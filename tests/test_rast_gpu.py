@@ -29,18 +29,14 @@ def _settings(cam, H, W, deg, mode, dev, kernel_size=synthetic.KERNEL_2D, scale_
     return GaussianRasterizer(GaussianRasterizationSettings(**common))
 
 
-@pytest.fixture(autouse=True, params=["bucket-classic", "radix-classic", "bucket-matrix"])
+@pytest.fixture(autouse=True, params=["bucket", "radix"])
 def bin_algo(request):
-    """Every test of this file runs with both instance-binning algorithms (include/gvf_rast.h GVF_RAST_BIN_*) and with both compositing
-    kernels (GVF_RAST_BLEND_*: the classic one and the matrix-pipe one), forced for the per-frame operator AND the batched path alike (the
-    library's default, AUTO, picks the matrix kernel for the batched path only: test_blend_auto_* below)."""
+    """Every test of this file runs with both instance-binning algorithms (include/gvf_rast.h GVF_RAST_BIN_*)."""
     from gvfdiffusion_amd import rasterizer as R, _lib
-    old = R.DEFAULT_BIN_ALGO, R.DEFAULT_BLEND_ALGO
-    b, k = request.param.split("-")
-    R.DEFAULT_BIN_ALGO = _lib.RAST_BIN_BUCKET if b == "bucket" else _lib.RAST_BIN_RADIX
-    R.DEFAULT_BLEND_ALGO = _lib.RAST_BLEND_CLASSIC if k == "classic" else _lib.RAST_BLEND_MATRIX
+    old = R.DEFAULT_BIN_ALGO
+    R.DEFAULT_BIN_ALGO = _lib.RAST_BIN_BUCKET if request.param == "bucket" else _lib.RAST_BIN_RADIX
     yield request.param
-    R.DEFAULT_BIN_ALGO, R.DEFAULT_BLEND_ALGO = old
+    R.DEFAULT_BIN_ALGO = old
 
 
 def _run(rast, a, **over):
@@ -377,36 +373,3 @@ def test_closed_form_scenes_on_the_device(cuda, oracle_lib, mode):
         px = ret[0][:, 15, 15].cpu().numpy()
         assert abs(px[0] - 0.9 * g) < 3e-6 and abs(px[1] - 0.99 * (1 - 0.9 * g)) < 3e-6 and px[2] == 0.0
 
-
-def test_blend_auto_is_matrix_for_the_batched_path_and_close_to_classic(cuda, oracle_lib, bin_algo):
-    """GVF_RAST_BLEND_AUTO: the batched (inference) path composites with the matrix-pipe kernel, the differentiable per-frame operator with
-    the classic one; the two kernels agree to float noise except where a threshold decision sits inside that noise."""
-    from gvfdiffusion_amd.renderers import GaussianRenderer
-    from gvfdiffusion_amd import rasterizer as R, _lib
-    if bin_algo != "bucket-classic":
-        pytest.skip("the test switches the kernels itself: one run is enough")
-    P, deg, S = 60_000, 1, 320
-    attrs = synthetic.random_gaussians(P, sh_degree=deg, seed=77, scale_lo=0.002, scale_hi=0.05)
-    gm = synthetic.gaussian_model_from(attrs, deg, cuda)
-    cams = [camera_block(azi=33.0 * f, elev=9.0) for f in range(3)]
-    ext = torch.stack([c["extrinsics"] for c in cams]).to(cuda)
-    K = cams[0]["intrinsics"].to(cuda)
-    imgs = {}
-    old = R.DEFAULT_BLEND_ALGO
-    try:
-        for name, algo in (("auto", _lib.RAST_BLEND_AUTO), ("classic", _lib.RAST_BLEND_CLASSIC), ("matrix", _lib.RAST_BLEND_MATRIX)):
-            R.DEFAULT_BLEND_ALGO = algo
-            rend = GaussianRenderer({"resolution": S, "near": synthetic.NEAR, "far": synthetic.FAR, "bg_color": synthetic.BG})
-            rend.pipe.use_mip_gaussian = True
-            imgs[name] = rend.render_frames(gm, ext, K, want_alpha_depth=True)
-            imgs[name + "_single"] = rend.render(gm, ext[0], K).rgb
-    finally:
-        R.DEFAULT_BLEND_ALGO = old
-    assert torch.equal(imgs["auto"].rgb, imgs["matrix"].rgb) and torch.equal(imgs["auto_single"], imgs["classic_single"])
-    assert not torch.equal(imgs["matrix"].rgb, imgs["classic"].rgb)          # two different kernels ...
-    d = (imgs["matrix"].rgb - imgs["classic"].rgb).abs()
-    n_off = int((d > 2e-5).sum())
-    print(f"matrix vs classic blend: max {float(d.max()):.2e}, median {float(d.median()):.2e}, {n_off} of {d.numel()} values beyond 2e-5")
-    assert float(d.max()) <= 5e-3 and n_off <= max(3, int(1e-5 * d.numel()))   # ... that differ only by flipped threshold decisions
-    assert float((imgs["matrix"].alpha - imgs["classic"].alpha).abs().max()) <= 5e-3
-    assert float((imgs["matrix"].depth - imgs["classic"].depth).abs().max()) <= 5e-2
