@@ -12,14 +12,23 @@ CSRC = os.path.join(_HERE, "csrc")
 OBJ_DIR = os.path.join(CSRC, "build")
 LIB_PATH = os.path.join(_HERE, "libgvf_hip.so")
 
-COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# -fno-slp-vectorize for EVERY source (round 4): left on, clang packs neighbouring scalar fp32 operations into v_pk_fma_f32 / v_pk_mul_f32 /
+# v_pk_add_f32 -- and on gfx950 a wave's packed-fp32 results come out WRONG while another wave of the same CU issues MFMAs
+# (scripts/ubench/coresident_victim.hip: the fp32 adaLN GEMV beside a pure-MFMA kernel, 218 of 512 launches wrong with v_pk_*, 0 of 512
+# without; this was the "two samples in flight differ in their last bits" of rounds 3-4: modulation_f32_kernel of one sample's DiT step
+# sharing CUs with the other sample's VAE-decode GEMMs).  No kernel of this library may contain packed fp32 arithmetic
+# (tests/test_capi_symbols.py checks the code objects); the packed forms bought nothing beside MFMAs anyway (MI355X_MICROARCH.md).
+# (-packed-fp32-ops: the target feature itself is switched off as well -- vector-typed source arithmetic, e.g. float4 += float4, selects the
+# packed instructions without any vectoriser.)
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-slp-vectorize",
+          "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 # per-source extra flags.  rast.hip: the floating-point contract shared with oracle/rast_oracle.c
 # (no implicit fma contraction; fmaf only where written).
 SOURCES = {
     "sort.hip": [],
     # -fno-slp-vectorize: left on, clang packs neighbouring scalar fp32 operations of the compositing loop into
     # v_pk_* instructions (4 cycles each against 2.8 for the scalar form, plus the v_mov traffic that builds the pairs)
-    "rast.hip": ["-ffp-contract=off", "-fno-slp-vectorize"],
+    "rast.hip": ["-ffp-contract=off"],
     "vox2seq.hip": [],
     "resize.hip": [],
     # the squared distances must round exactly as the oracle's binary32 expression does (index-exact parity)
@@ -29,10 +38,9 @@ SOURCES = {
     # -fno-honor-nans: no canonicalising v_max in front of fmaxf (infinities stay honoured: -inf masks keys).
     # iterative-ilp: the scheduler variant that measured best for the attention kernels in the denoise step (8.5 -> 8.4 ms
     # per NFE; max-ilp and the default are slower; for rast.hip every non-default strategy slows the blend)
-    "attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp"],
+    "attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp"],
     # tiled-cache cross attention: the issue order of its inner loop is written out (sched_barrier fences), so no scheduler flag
-    "attn_xt.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans", "-fno-slp-vectorize"],
-    # (SLP left ON here: the GELU / LayerNorm epilogues measure 2 % slower in the denoise step without it)
+    "attn_xt.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"],
     "gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
     # row-block kernel: default flags (accumulators in AGPRs: the kernel lives on the 512-register file of a 2-waves-per-SIMD launch)
     "rowblock.hip": [],

@@ -20,10 +20,29 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
     return (unsigned short)(u >> 16);
 }
 
+// Sum over the 64 lanes, every lane gets it -- on the DPP / permlane data paths only (quad_perm, row mirrors, v_permlane16_swap,
+// v_permlane32_swap), nothing through the LDS unit.  #ifdef GVF_WAVE_SUM_BPERMUTE: the round-1 form (six ds_bpermute butterflies).
 __device__ __forceinline__ float wave_sum(float v) {
+#ifdef GVF_WAVE_SUM_BPERMUTE
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
     return v;
+#else
+#define GVF_DPP(x_, ctrl_) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x_), ctrl_, 0xF, 0xF, false))
+    v += GVF_DPP(v, 0xB1);      // quad_perm [1,0,3,2]: lane ^ 1
+    v += GVF_DPP(v, 0x4E);      // quad_perm [2,3,0,1]: lane ^ 2
+    v += GVF_DPP(v, 0x141);     // row_half_mirror: lane i of 8 <-> 7 - i (the other quad of the half row)
+    v += GVF_DPP(v, 0x140);     // row_mirror: lane i of 16 <-> 15 - i (the other half of the row)
+#undef GVF_DPP
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);      // {rows 0,0,2,2 | rows 1,1,3,3}: their sum = rows 0+1 | 2+3
+    const unsigned a0 = r16[0], a1 = r16[1];
+    const float w = __uint_as_float(a0) + __uint_as_float(a1);
+    const unsigned uw = __builtin_bit_cast(unsigned, w);
+    const auto r32 = __builtin_amdgcn_permlane32_swap(uw, uw, false, false);
+    const unsigned b0 = r32[0], b1 = r32[1];
+    return __uint_as_float(b0) + __uint_as_float(b1);
+#endif
 }
 
 // VPL = float4 loads per lane: C = 64 * 4 * VPL

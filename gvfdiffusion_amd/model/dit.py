@@ -462,11 +462,9 @@ class DiT(nn.Module):
         if g is None or g["key"] != key or not self._same_tensors(g["held"], conds):
             sx, st = x.clone(), t.clone()
             smod = None if mod_rows is None else mod_rows.clone()
-            # One capture at a time per process, and in thread-local capture mode, so that a capture on one host thread does not FAIL because
-            # another thread (another sample in flight on its own stream and DiT instance, utils/in_flight.py) launches or allocates
-            # meanwhile.  That makes such captures possible, not safe: 3 of 50 runs of inference_dpm_latent.py with two samples in flight
-            # and a capture per sample returned a sample that differed in its last bits (0 of 25 with eager launches), so callers capture
-            # BEFORE going in flight (bench.py) or run their in-flight instances eagerly (inference_dpm_latent.py).
+            # One capture at a time per process, and in thread-local capture mode, so that a capture on one host thread does not fail because
+            # another thread (another sample in flight on its own stream and DiT instance, utils/in_flight.py) launches or allocates meanwhile.
+            # (Captures in flight are bit-identical to serial sampling: tests/test_inference_script_gpu.py, scripts/inflight_capture_repro.py.)
             with _CAPTURE_LOCK:
                 # eager run first: builds the weight / condition caches and warms the allocator outside the capture
                 self._forward(sx, st, cond_images, static_latent, deformation_position_xyz, mod=smod)

@@ -9,8 +9,10 @@ measured on one MI355X: DiT 157 -> 189-195 denoise steps/s aggregate (scripts/di
 
 Each job runs on its own Python thread (ctypes calls and torch ops release the GIL) inside `torch.cuda.stream(its stream)`.  A job must own
 its mutable state: for the DiT that means one `DiT` instance per job in flight (the condition cache and the hipGraph of an instance belong to
-one sample at a time; instances may share parameters).  Warm every job's instance up serially first -- hipGraph capture does not tolerate
-other threads allocating on the device meanwhile.
+one sample at a time; instances may share parameters).  hipGraph captures of DiT instances are serialised and thread-local
+(DiT._forward_graphed), so an instance may capture while the other slots run; results are bit-identical to serial runs either way
+(tests/test_inference_script_gpu.py; the round-3 "capture in flight differs in the last bits" was packed-fp32 arithmetic beside another
+kernel's MFMAs, profiles/r04_inflight_root_cause.txt, fixed in the build).
 """
 import threading
 from typing import Callable, List, Sequence

@@ -1,5 +1,8 @@
 """Reproducer / bisection harness for "two samples in flight + one hipGraph capture per sample returns a sample that differs in its last bits"
-(3 of 50 runs of inference_dpm_latent.py --in_flight 2 in round 3, never with eager launches, never serially).
+(3 of 50 runs of inference_dpm_latent.py --in_flight 2 in round 3).  ROOT CAUSE (round 4, profiles/r04_inflight_root_cause.txt): not
+the capture -- packed-fp32 VALU arithmetic (v_pk_fma_f32 & co., emitted by clang's SLP vectoriser into modulation_f32_kernel) returns wrong values
+on gfx950 while another wave of the same CU issues MFMAs; one sample's DiT step shared CUs with the other sample's VAE-decode GEMMs.  With the
+library built without packed fp32 (gvfdiffusion_amd/_build.py) this harness reports 0 divergent rounds, captures in flight included.
 
 One process, models built once.  Serial references of K samples first (slot 0, graphs on), then R rounds of the same K samples with two in
 flight -- every sample a NEW capture on its slot's thread while the other slot runs -- each compared with its reference at three points:
@@ -94,8 +97,8 @@ def main():
 
     def job(slot, i):
         f = chain(slot, i)
-        x0, delta = probe[i]
-        return x0, delta, f
+        x0, delta, f4096, f512, trace = probe[i]
+        return x0, delta, f, f4096, f512, trace
 
     with torch.no_grad():
         t0 = time.time()
@@ -109,20 +112,24 @@ def main():
             torch.cuda.synchronize()
             bad = False
             for i in range(K):
-                d = [not torch.equal(a, b) for a, b in zip(res[i], ref[i])]
+                d = [a.shape != b.shape or not torch.equal(a, b) for a, b in zip(res[i], ref[i])]
                 if any(d):
                     bad = True
-                    x0, delta, f = res[i]
-                    ev = {"round": r, "sample": i, "latents_differ": d[0], "deltas_differ": d[1], "frames_differ": d[2],
+                    x0, delta, f = res[i][:3]
+                    ev = {"round": r, "sample": i, "latents_differ": d[0], "deltas_differ": d[1], "frames_differ": d[2], "fps4096_differ": d[3],
+                          "fps512_differ": d[4], "fps4096_rows": int((res[i][3] != ref[i][3]).any(dim=-1).sum()),
+                          "nfe": [int(res[i][5].shape[0]), int(ref[i][5].shape[0])],
+                          "first_divergent_evaluation": int((res[i][5][:min(res[i][5].shape[0], ref[i][5].shape[0])] != ref[i][5][:min(res[i][5].shape[0], ref[i][5].shape[0])]).nonzero()[:1].sum()) if (res[i][5][:min(res[i][5].shape[0], ref[i][5].shape[0])] != ref[i][5][:min(res[i][5].shape[0], ref[i][5].shape[0])]).any() else -1,
                           "latent_max_abs": float((x0 - ref[i][0]).abs().max()), "latent_frac": float((x0 != ref[i][0]).float().mean()),
                           "delta_max_abs": float((delta - ref[i][1]).abs().max()),
                           "frame_frac": float((f != ref[i][2]).float().mean())}
                     events.append(ev)
                     print(json.dumps(ev), flush=True)
             bad_rounds += bad
-        print(json.dumps({"rounds": R, "samples_per_round": K, "divergent_rounds": bad_rounds, "divergent_samples": len(events),
-                          "seconds": round(time.time() - t0, 1),
-                          "switches": {k: v for k, v in os.environ.items() if k.startswith("REPRO_")}}), flush=True)
+        summary = {"rounds": R, "samples_per_round": K, "divergent_rounds": bad_rounds, "divergent_samples": len(events),
+                   "seconds": round(time.time() - t0, 1), "switches": {k: v for k, v in os.environ.items() if k.startswith("REPRO_")}}
+        print(json.dumps(summary), flush=True)
+        return summary
 
 
 if __name__ == "__main__":
