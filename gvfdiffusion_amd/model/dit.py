@@ -19,6 +19,7 @@ same MFMA rate: ops/precision.py has the rule, `set_compute_dtype` / GVF_DIT_DTY
 There is no CPU path: CPU tensors raise (the fp32 CPU restatement lives in oracle/dit_ref.py, tests only).
 """
 import math
+import os
 from typing import *
 
 import numpy as np
@@ -194,6 +195,10 @@ class DiT(nn.Module):
         # one launch per sub-layer boundary (csrc/rowblock.hip) where the shapes allow it: 0 = the unfused GEMM / LayerNorm launches
         self.use_rowblock = int(os.environ.get("GVF_DIT_ROWBLOCK", "1")) != 0
         self.weight_prefetch = int(os.environ.get("GVF_DIT_PREFETCH", "1")) != 0
+        # precompute_modulation: OFF by default.  Measured (round 4, gpurun_out/r04i/modtable_ab.txt, three alternating repeats on one box): 5.59-5.71 ms
+        # per step with the table against 5.25-5.34 without -- the step that no longer starts with the two memory-bound launches (59 us) runs
+        # 0.35 ms SLOWER as a whole, with the rows copied in (225 KB) or gathered inside the graph alike.  Kept (exact, tested) behind the switch.
+        self.modulation_table = int(os.environ.get("GVF_DIT_MODTABLE", "0")) != 0
         self.rowblock_tiled_kv = int(os.environ.get("GVF_DIT_TILED_KV", "1")) != 0    # to_qkv's launch writes the attention's K / V^T tiles itself
         # the temporal self attention runs INSIDE the row-block launch between the spatial and the image attention (T | 48): 6 launches per
         # block instead of 8, the qkv / attention-output buffers of the temporal sub-layer never exist
@@ -414,19 +419,24 @@ class DiT(nn.Module):
         fp32 projection weights cross HBM once per sample instead of once per step.  Same kernels, same numbers; any other call computes the
         modulation inside the forward as before."""
         dev = next(self.parameters()).device
-        if dev.type != "cuda":
+        if dev.type != "cuda" or not self.modulation_table:
             return
         W = self._weights()
         fdim, C = self.t_embedder.frequency_embedding_size, self.model_channels
         if not (fdim % 4 == 0 and fdim <= 1024 and C % 4 == 0 and C <= 1024):
             return
         th = t.detach().reshape(-1).float().cpu()
+        tab = getattr(self, "_mod_table", None)
+        if tab is not None and tab["version"] == (self._param_version(), self._lp()) and all(float(v) in tab["rows"] for v in th.tolist()):
+            return                                     # the same grid as the last sample's: the table is a per-JOB cost (~12 ms for 33 rows), not per sample
         s2 = dit_ops.timestep_embed_f32(th.to(dev).contiguous(), *W["t0_f32"], *W["t2_f32"], freq_dim=fdim)
         mod = dit_ops.modulation_f32(s2, W["mod_w_f32"], W["mod_b"])
-        self._mod_table = {"version": (self._param_version(), self._lp()), "rows": {float(v): i for i, v in enumerate(th.tolist())}, "mod": mod}
+        self._mod_table = {"version": (self._param_version(), self._lp()), "rows": {float(v): i for i, v in enumerate(th.tolist())}, "mod": mod,
+                           "arange": torch.arange(mod.shape[0], device=dev)}
 
     def _mod_from_table(self, t, B):
-        """(B, mod_total) rows of the precomputed table for this forward's times, or None (no table / unknown time / no host values)."""
+        """Row numbers (B,) int64 on the device of this forward's times in the precomputed table, or None (no table / unknown time / no host
+        values).  A view of the table's arange for the usual B = 1 and guided B = 3 (equal times) calls: no launch, no host -> device copy."""
         tab, hv = getattr(self, "_mod_table", None), getattr(t, "gvf_host_values", None)
         if tab is None or hv is None or len(hv) != B or tab["version"] != (self._param_version(), self._lp()):
             return None
@@ -434,7 +444,9 @@ class DiT(nn.Module):
             idx = [tab["rows"][v] for v in hv]
         except KeyError:
             return None
-        return tab["mod"][idx[0]:idx[0] + 1] if B == 1 else tab["mod"][idx]
+        if all(i == idx[0] for i in idx):
+            return tab["arange"][idx[0]:idx[0] + 1].expand(B)
+        return tab["arange"][torch.tensor(idx)]
 
     # ---- forward ------------------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor, t: torch.Tensor, cond_images: torch.Tensor, static_latent: torch.Tensor,
@@ -456,27 +468,28 @@ class DiT(nn.Module):
         _lib.require_cuda(x, t, cond_images, static_latent, deformation_position_xyz)
         mod_rows = self._mod_from_table(t, x.shape[0])       # (looked up from the HOST values the tensor carries: no read-back)
         t = t.to(x.device)
-        key = (tuple(x.shape), x.dtype, tuple(t.shape), t.dtype, self._param_version(), self._lp(), mod_rows is not None)
+        key = (tuple(x.shape), x.dtype, tuple(t.shape), t.dtype, self._param_version(), self._lp(),
+               None if mod_rows is None else self._mod_table["mod"].data_ptr())
         conds = (cond_images, static_latent, deformation_position_xyz)
         g = self._graph
         if g is None or g["key"] != key or not self._same_tensors(g["held"], conds):
             sx, st = x.clone(), t.clone()
-            smod = None if mod_rows is None else mod_rows.clone()
+            smod = None if mod_rows is None else mod_rows.clone()      # the row numbers: the graph gathers its rows of the table itself
             # One capture at a time per process, and in thread-local capture mode, so that a capture on one host thread does not fail because
             # another thread (another sample in flight on its own stream and DiT instance, utils/in_flight.py) launches or allocates meanwhile.
             # (Captures in flight are bit-identical to serial sampling: tests/test_inference_script_gpu.py, scripts/inflight_capture_repro.py.)
             with _CAPTURE_LOCK:
                 # eager run first: builds the weight / condition caches and warms the allocator outside the capture
-                self._forward(sx, st, cond_images, static_latent, deformation_position_xyz, mod=smod)
+                self._forward(sx, st, cond_images, static_latent, deformation_position_xyz, mod_idx=smod)
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                    sy = self._forward(sx, st, cond_images, static_latent, deformation_position_xyz, mod=smod)
+                    sy = self._forward(sx, st, cond_images, static_latent, deformation_position_xyz, mod_idx=smod)
             g = self._graph = {"key": key, "held": (conds, tuple(self._key(c) for c in conds)), "graph": graph, "x": sx,
                                "t": st, "y": sy, "mod": smod}
         g["x"].copy_(x)
         if g["mod"] is not None:
-            g["mod"].copy_(mod_rows)                           # 225 KB device-to-device instead of the embedder + 115 MB GEMV
+            g["mod"].copy_(mod_rows)                           # 8 bytes per sample, like the time itself; the graph gathers the rows (225 KB) of the table
         else:
             g["t"].copy_(t)
         g["graph"].replay()
@@ -487,8 +500,8 @@ class DiT(nn.Module):
         return 1.0, self._forward(x, t, cond_images, static_latent, deformation_position_xyz)
 
     @torch.no_grad()
-    def _forward(self, x, t, cond_images, static_latent, deformation_position_xyz=None, mod=None):
-        """mod: optional (B, mod_total) fp32 rows of precompute_modulation's table (the graphed forward hands its static copy in)."""
+    def _forward(self, x, t, cond_images, static_latent, deformation_position_xyz=None, mod_idx=None):
+        """mod_idx: optional (B,) row numbers into precompute_modulation's table (the graphed forward hands its static copy in)."""
         _lib.require_cuda(x, t, cond_images, static_latent, deformation_position_xyz)
         B, T, N, Cin = x.shape
         C, H = self.model_channels, self.num_heads
@@ -501,10 +514,10 @@ class DiT(nn.Module):
 
         # timestep embedder (sinusoid, two Linears, two SiLUs: one launch) and every adaLN projection of the step (one GEMV), both in fp32
         fdim = self.t_embedder.frequency_embedding_size
-        if mod is None and not self.use_graph:
-            mod = self._mod_from_table(t, B)               # eager calls look the step up here (the graphed forward hands its copy in)
-        if mod is not None:
-            mod = mod.contiguous()
+        if mod_idx is None and not self.use_graph:
+            mod_idx = self._mod_from_table(t, B)           # eager calls look the step up here (the graphed forward hands its copy in)
+        if mod_idx is not None:
+            mod = self._mod_table["mod"].index_select(0, mod_idx)
             assert mod.shape == (B, W["mod_total"]) and mod.dtype == f32
         elif fdim % 4 == 0 and fdim <= 1024 and C % 4 == 0 and C <= 1024:
             s2 = dit_ops.timestep_embed_f32(t.to(dev).float().contiguous(), *W["t0_f32"], *W["t2_f32"], freq_dim=fdim)
