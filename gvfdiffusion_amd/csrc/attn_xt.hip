@@ -113,7 +113,10 @@ typedef gvf_f32x4 f32x4;
 constexpr int XT_THREADS = 256;
 constexpr int XT_QB = 256;             // queries per workgroup (4 waves x 2 sub-tiles x 32)
 constexpr int XT_KT = 64;              // keys per tile
-constexpr int XT_NBUF = 3;             // LDS ring depth (stages)
+#ifndef XT_RING_STAGES
+#define XT_RING_STAGES 3
+#endif
+constexpr int XT_NBUF = XT_RING_STAGES;   // LDS ring depth (stages): a stage is requested XT_NBUF - 1 barriers before it is consumed
 constexpr int XT_TPS = XT_TILES_PER_STAGE;   // tiles per stage = per barrier
 constexpr int XT_TILE_CHUNKS = 512;    // 16-byte chunks per staged tile: 256 K + 256 V^T
 constexpr int XT_PF_CHUNKS = 16;       // landing zone of the prefetch loads (one dword per lane of one wave: 256 B that nobody reads)
@@ -493,7 +496,9 @@ __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(
             if (n_stages > 1) { XT_STAGE(1) }
         }
         __syncthreads();            // stages 0 and 1 have landed (own DMA drained before the barrier)
-        if (n_stages > 2) { XT_STAGE(2) }
+#pragma unroll
+        for (int s_ = 2; s_ < XT_NBUF; ++s_)
+            if (s_ < n_stages) { XT_STAGE(s_) }
         if (p.pf != nullptr && wave == 0) {
             // warm the NEXT launch's weights: one dword per 128-byte line, LDS-DMA into a landing zone nobody reads (no register, no wait of
             // its own: the loads ride with the stage requests and are drained by the loop's barriers).  The lines end up in the Infinity
@@ -531,12 +536,12 @@ __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(
                 for (int j = 0; j < PER; ++j) {
                     if (!XT_ABL_NOSYNC && (1 + j) % XT_TPS == 0) {
                         __syncthreads();
-                        const int s2 = (t + j) / XT_TPS + 2;
+                        const int s2 = (t + j) / XT_TPS + (XT_NBUF - 1);
 #pragma unroll
                         for (int i_ = 0; i_ < XT_TPS; ++i_) {
                             const int t_ = s2 * XT_TPS + i_;
                             if (t_ < T) {
-                                uint4* dst_ = XT_RING((((1 + j) / XT_TPS + 2) % XT_NBUF) * XT_TPS + i_);
+                                uint4* dst_ = XT_RING((((1 + j) / XT_TPS + (XT_NBUF - 1)) % XT_NBUF) * XT_TPS + i_);
                                 xt_dma16(kbase + (long long)t_ * 256 + wave * 64 + lane, dst_ + wave * 64);
                                 xt_dma16(vbase + (long long)t_ * 256 + wave * 64 + lane, dst_ + 256 + wave * 64);
                             }
@@ -551,7 +556,7 @@ __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(
             for (; t + 1 < T; ++t) {
                 if (!XT_ABL_NOSYNC && t % XT_TPS == 0) {
                     __syncthreads();
-                    const int s2 = t / XT_TPS + 2;
+                    const int s2 = t / XT_TPS + (XT_NBUF - 1);
                     if (s2 < n_stages) { XT_STAGE(s2) }
                 }
                 xt_phase<DT, true, true, false, 1, SHIFT>(kf, vf, XT_V(t), qf[0], sQw, sA, sB, oB, lB4, l4B, l4Bb, l31, half, XT_KT, cA);
