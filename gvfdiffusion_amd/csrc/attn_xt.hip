@@ -22,9 +22,8 @@
 // (software pipeline, one phase = {4 QK^T MFMAs of sub-tile X} interleaved with {32 exp2, 16 cvt_pk, row sums, 4 PV
 // MFMAs of sub-tile Y}).  On gfx950 a SIMD overlaps MFMA and VALU work only when ONE wave interleaves them
 // (scripts/ubench/mfma_valu_overlap.hip), so the issue order of a phase is written out and fenced (sched_barrier).
-// The row sums of P are taken by the matrix pipe too (v_mfma_f32_4x4x4_16B_bf16 against ones: every accumulator
-// register += the lane's own four packed probabilities), i.e. the denominator sums the SAME bf16-rounded probabilities
-// the numerator multiplies.  What bounds the loop is VALU issue: 32 v_exp_f32 (two issue slots each) + 16 v_cvt_pk +
+// The row sums of P are taken by the matrix pipe too (one v_mfma_f32_16x16x32 per 8 packed probabilities of a lane against a
+// 0 / 1 selector, see XT_SUM), i.e. the denominator sums the SAME bf16-rounded probabilities the numerator multiplies.  What bounds the loop is VALU issue: 32 v_exp_f32 (two issue slots each) + 16 v_cvt_pk +
 // 16 MFMA issues per phase (profiles/r02_*attn_xt*: 104 issue quads per wave-phase, matrix pipe 43-53 % busy at the
 // 1.7 GHz the chip holds under this load).
 //
@@ -44,7 +43,8 @@
 #define XT_PIPELINE 1        // 1: pin the MFMA / VALU interleave with sched_group_barrier
 #endif
 #ifndef XT_SUM_MFMA
-#define XT_SUM_MFMA 1        // 1: row sums of P by v_mfma_f32_4x4x4_16B_bf16 against ones (8 per tile) instead of 32 v_add
+#define XT_SUM_MFMA 2        // 2: row sums of P by ONE v_mfma_f32_16x16x32 per 8 probabilities of a lane against a 0 / 1 selector (4 per tile and
+                             //    sub-tile, 16 cycles each); 1: by two v_mfma_f32_4x4x4 against ones (17 cycles each: rounds 2-3); 0: v_add
 #endif
 // Ablation switches for scripts/ubench/attn_xt_bench.hip (timing only: results are WRONG when any of them is set)
 #ifndef XT_ABL_NOEXP
@@ -195,7 +195,7 @@ __device__ __forceinline__ void xt_phase(typename GvfLp<DT>::x8 (&kf)[2][2], typ
                                          int l31, int half, int n_valid, const f32x16& c0) {
     typedef GvfLp<DT> LP;
     typedef typename LP::x8 x8;
-    typedef typename LP::x4 x4;
+    typedef typename LP::x4 x4 __attribute__((unused));
     const f32x16 zero_ = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const f32x16 zero = SHIFT ? c0 : zero_;
     float pe[8];
@@ -219,7 +219,16 @@ __device__ __forceinline__ void xt_phase(typename GvfLp<DT>::x8 (&kf)[2][2], typ
         }                                                                                                   \
         XT_FENCE();                                                                                         \
     }
-#if XT_SUM_MFMA
+#if XT_SUM_MFMA == 2
+    /* The lane's 8 probabilities (query l31, key half `half`) are a B operand of the 16x16x32 shape as they stand: there lane l is column l % 16,
+       k-block l / 16 -- blocks 0 / 2 are the two key halves of query l % 16, blocks 1 / 3 those of query 16 + l % 16.  Against the selector
+       A[i][k-block] = (i < 8) == (block even) rows 0-7 of the product sum query n, rows 8-15 query n + 16, both halves included: lane l's
+       accumulator (column l % 16, rows 4 (l / 16) ..) holds the denominator of query (l % 16) + 16 (l / 32), fetched once in the epilogue. */
+    const unsigned selw = ((((unsigned)l31 >> 3) ^ ((unsigned)l31 >> 4)) & 1u) ? 0u : LP::ONE2;
+    const x8 sel = __builtin_bit_cast(x8, make_uint4(selw, selw, selw, selw));
+#define XT_SUM(g_)                                                                                          \
+    l4 = LP::mfma16(sel, __builtin_bit_cast(x8, make_uint4(pw[g_][0], pw[g_][1], pw[g_][2], pw[g_][3])), l4);
+#elif XT_SUM_MFMA
 #define XT_SUM(g_)                                                                                          \
     {                                                                                                       \
         const x4 ones = __builtin_bit_cast(x4, make_uint2(LP::ONE2, LP::ONE2));                             \
@@ -568,6 +577,10 @@ __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(
         xt_phase<DT, true, true, true, 0, SHIFT>(kf, vf, XT_K(0), qf[1], sQw + 128, sB, sA, oA, lA4, l4A, l4Ab, l31, half, last_valid, cB);
         if (SHIFT && T == 1) xt_take_shift<DT>(sB, cB);      // a single key tile: sub-tile B's first scores come out of this phase
         xt_phase<DT, false, true, true, 0, SHIFT>(kf, vf, XT_K(0), qf[1], sQw, sA, sB, oB, lB4, l4B, l4Bb, l31, half, last_valid, cB);
+#if XT_SUM_MFMA == 2
+        lA = __shfl(l4A[0], (l31 & 15) + 32 * (l31 >> 4), 64);      // both key halves are in already
+        lB = __shfl(l4B[0], (l31 & 15) + 32 * (l31 >> 4), 64);
+#else
 #if XT_SUM_MFMA
         lA = l4A[0] + l4Ab[0]; lB = l4B[0] + l4Bb[0];
 #else
@@ -576,14 +589,19 @@ __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(
 #endif
         lA += __shfl_xor(lA, 32, 64);
         lB += __shfl_xor(lB, 32, 64);
-        // range guard (NaN fails both comparisons).  fp16: with the shift the denominator is >= 1 unless a single, partly padded key tile
+#endif
+        // range guard.  fp16: with the shift the denominator is >= 1 unless a single, partly padded key tile
         // pushed every probability under 2^-12 (the padding's zero scores took part in the shift)
         // fp16 without the shift (bounded scores): every probability is >= 2^-14, so is the sum; below that the promise was broken
         const float l_min = SHIFT ? 0.015625f : (LP::kNeedsShift ? 3.0517578125e-05f : 7.8886e-31f);
         // upper bound: with XT_SUM_MFMA the sum is taken over the ROUNDED probabilities, so an fp16 overflow shows up as l = inf; a build that
         // sums the fp32 values (XT_SUM_MFMA=0) must bound l below fp16's largest number itself (as attn.hip's kvres kernel does)
         const float l_max = (!XT_SUM_MFMA && LP::kNeedsShift) ? 32768.0f : 1.2676e30f;
-        const bool okA = lA > l_min && lA < l_max, okB = lB > l_min && lB < l_max;
+        // compared as BIT PATTERNS: this file is built with -fno-honor-nans, under which a float comparison may be inverted; as unsigned integers
+        // positive floats order like their values, NaNs of either sign and every negative number fall outside [l_min, l_max) by themselves
+        // (a NaN is what the selector form of the row sums makes of an infinity: 0 * inf)
+        const unsigned u_min = __float_as_uint(l_min), u_span = __float_as_uint(l_max) - __float_as_uint(l_min);
+        const bool okA = (__float_as_uint(lA) - u_min - 1u) < (u_span - 1u), okB = (__float_as_uint(lB) - u_min - 1u) < (u_span - 1u);
         bad = !(okA && okB);
         if (XT_ABL_NOEXP || XT_ABL_NOQK || XT_ABL_NOPV || XT_ABL_NOSUM || XT_ABL_NOSYNC || XT_ABL_NOLDS) bad = false;   // timing experiments
     }
