@@ -41,6 +41,7 @@ SOURCES = {
     "attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp"],
     # tiled-cache cross attention: the issue order of its inner loop is written out (sched_barrier fences), so no scheduler flag
     "attn_xt.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"],
+    "attn_xt64.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"],
     "gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
     # row-block kernel: default flags (accumulators in AGPRs: the kernel lives on the 512-register file of a 2-waves-per-SIMD launch)
     "rowblock.hip": [],

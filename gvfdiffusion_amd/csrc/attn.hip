@@ -79,7 +79,13 @@ struct Cfg {
     static constexpr int KC = D / 8;         // 16-byte chunks per K row
     static constexpr int LOADS = KC * KT / THREADS;   // K (and V) chunks staged per thread per tile
     // chunk swizzle that makes the per-lane 16-byte K fragment reads conflict-free
+    // (a ds_read_b128 is served in lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32) over 64 banks: with 128-byte rows, lane = row, the
+    // 16 rows of a group reach 16 distinct 16-byte slots for (key >> 1) & 7 -- key & 7 (rounds 1-3) put rows 12 and 20, 4 and 28, ... on one slot)
+#ifndef ATTN_SWZ64_OLD
+    __device__ static __forceinline__ int swz(int key) { return KC == 4 ? ((key >> 2) & 3) : ((key >> 1) & 7); }
+#else
     __device__ static __forceinline__ int swz(int key) { return KC == 4 ? ((key >> 2) & 3) : (key & 7); }
+#endif
 };
 
 // One staged 64-key tile for the 32 queries of a wave: S^T = K Q^T (both 32-key halves issued back to back),
@@ -454,7 +460,10 @@ __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(AttnParams p) {
 // together -- and then every wave walks its 32-query tiles over all key tiles with no further staging and no barrier:
 // the per-tile global-load / LDS-store / __syncthreads of the streaming kernel (whose fixed cost is spread over only
 // Lk / 64 <= 8 tiles here) disappears, and one staging serves QT * 256 queries.
-constexpr int RES_THREADS = 512;
+#ifndef RES_WAVES
+#define RES_WAVES 8
+#endif
+constexpr int RES_THREADS = 64 * RES_WAVES;
 constexpr int RES_MAX_TILES = 8;
 constexpr int RES_ROUND = 4;                 // staging chunks per thread in flight per round
 
@@ -668,7 +677,7 @@ int launch_kvres(AttnParams p, int H, int n_inner, int n_outer, int max_Lq, int 
     const size_t lds = (size_t)tiles_max * (KT * Cfg<D>::KC * 16 + res_vt_tile<D>() * 2);
     const int per_pass = RES_THREADS / 2;                                  // queries one pass of the 8 waves covers
     int qt = (max_Lq + per_pass - 1) / per_pass;
-    qt = qt > 4 ? 4 : qt;                                                  // one staging per <= 1024 queries
+    qt = qt > 1024 / per_pass ? 1024 / per_pass : qt;                      // one staging per <= 1024 queries
     p.q_blocks = (max_Lq + qt * per_pass - 1) / (qt * per_pass);
     const long long blocks = (long long)p.q_blocks * H * n_inner * n_outer;
     if (blocks > 0x7fffffffLL) return GVF_EINVAL;

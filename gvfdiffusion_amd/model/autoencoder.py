@@ -20,6 +20,7 @@ fp32 residual stream, LayerNorm and softmax.
 """
 
 import numpy as np
+import os
 import torch
 import torch.nn as nn
 
@@ -315,26 +316,37 @@ class GSKLTemporalVariationalAutoEncoder(nn.Module):
         dit_ops.layernorm_modulate_bf16(h, hb, 1e-6)
         kv = torch.empty((BT * L, 2 * C), dtype=bf16, device=dev)
         dit_ops.gemm_bf16(hb, W["dec_kv"], None, kv, dit_ops.EPI_STORE_BF16)
-        kc = kv[:, :C].reshape(BT, L, H, d).permute(0, 2, 1, 3).contiguous()
-        Lp = (L + 63) // 64 * 64
-        vt = torch.zeros((BT, H, d, Lp), dtype=bf16, device=dev)
-        vt[..., :L] = kv[:, C:].reshape(BT, L, H, d).permute(0, 2, 3, 1)
+        # K / V^T of the (b, t) latent sets in the image the attention stages (K pre-scaled): csrc/attn_xt64.hip when the key set fits its
+        # LDS (head_dim 64, <= 512 latents: the released config), else head-major K and zero-padded V^T for csrc/attn.hip
+        tiled = d == 64 and L <= 512 and os.environ.get("GVF_VAE_TILED64", "1") != "0"
+        if tiled:
+            kt, vt = dit_ops.attention_pack_kv64(kv, BT, L, H, 0, C)
+        else:
+            kc = kv[:, :C].reshape(BT, L, H, d).permute(0, 2, 1, 3).contiguous()
+            Lp = (L + 63) // 64 * 64
+            vt = torch.zeros((BT, H, d, Lp), dtype=bf16, device=dev)
+            vt[..., :L] = kv[:, C:].reshape(BT, L, H, d).permute(0, 2, 3, 1)
         # queries: embedding + PreNorm + to_q once per static Gaussian (shared by the T frames)
         qe = vae_ops.vae_query_embed_bf16(queries.reshape(B * P, -1).float().contiguous(), W["gs_w"], W["gs_b"], W["omega"], dtype=bf16)
         qp = torch.empty((B * P, C), dtype=bf16, device=dev)
         dit_ops.gemm_bf16(qe, W["dec_q"], None, qp, dit_ops.EPI_STORE_BF16)
         del qe
         out = torch.empty((B, T, P, self.output_dim), dtype=torch.float32, device=dev)
-        Pc = max(128, self.max_chunk_rows // (B * T) // 128 * 128)
-        Pc = min(Pc, P)
+        # chunks of about max_chunk_rows attention-output rows, all the same size up to the attention's 2048-query workgroups (the released
+        # config: 5 x 45056 + 36864 Gaussians; a fixed 43648 left a 256-Gaussian seventh launch pair)
+        n_chunks = max(1, (B * T * P + self.max_chunk_rows // 2) // self.max_chunk_rows)
+        Pc = min(P, ((P + n_chunks - 1) // n_chunks + 2047) // 2048 * 2048)
         ao = torch.empty((B, T, Pc, C), dtype=bf16, device=dev)
         yo = torch.empty((B * T * Pc, self.output_dim), dtype=torch.float32, device=dev)
         qp3 = qp.view(B, P, C)
         for p0 in range(0, P, Pc):
             n = min(Pc, P - p0)
             a = ao if n == Pc else ao.view(-1)[:B * T * n * C].view(B, T, n, C)
-            dit_ops.attention_bf16(qp3[:, p0:], kc, vt, a, B, T, n, L, H, (P * C, 0, C), (T * H * L * d, H * L * d, d, L * d),
-                                   (T * H * d * Lp, H * d * Lp, Lp, d * Lp), (T * n * C, n * C, C), v_transposed=True, head_dim=d)
+            if tiled:
+                dit_ops.attention_tiled64(qp3[:, p0:], kt, vt, a, B, T, n, L, H, (P * C, 0, C), (T * n * C, n * C, C), T, 1)
+            else:
+                dit_ops.attention_bf16(qp3[:, p0:], kc, vt, a, B, T, n, L, H, (P * C, 0, C), (T * H * L * d, H * L * d, d, L * d),
+                                       (T * H * d * Lp, H * d * Lp, Lp, d * Lp), (T * n * C, n * C, C), v_transposed=True, head_dim=d)
             y = yo[:B * T * n]
             dit_ops.gemm_bf16(a.view(B * T * n, C), *W["fold"], y, dit_ops.EPI_STORE_F32)
             out[:, :, p0:p0 + n] = y.view(B, T, n, self.output_dim)

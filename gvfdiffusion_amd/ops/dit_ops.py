@@ -70,6 +70,8 @@ _lib.register({
     "gvf_rowblock_fused": (_i, [ctypes.POINTER(RowblockArgs), _vp]),
     "gvf_rowblock_fused_bf16": (_i, [ctypes.POINTER(RowblockArgs), _vp]),
     "gvf_gemm_stats_parts": (_i, [_i]),
+    "gvf_attn_pack_kv64": (_i, [_i, _vp, _i, _i64, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
+    "gvf_attn_tiled64_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, ctypes.POINTER(_i64), ctypes.POINTER(_i64), _i64, _i64, _i, _vp, _vp]),
     "gvf_attn_tiled_fwd_pf": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, ctypes.POINTER(_i64), ctypes.POINTER(_i64), _i64, _i64,
                                    _vp, _i, _i, _vp, _vp, _i64, _vp]),
 })
@@ -411,6 +413,35 @@ def attention_pack_kv(kv: torch.Tensor, n_sets: int, L: int, H: int, k_col0: int
                                            float(scale * LOG2E), _p(gamma_k), _p(kt), _p(vt), _stream(kv)),
                "gvf_attn_pack_kv")
     return kt, vt
+
+
+def attention_pack_kv64(kv: torch.Tensor, n_sets: int, L: int, H: int, k_col0: int, v_col0: int, scale: float = None, out=None, dtype=None):
+    """kv rows (n_sets * L, ld) fp32 or 16-bit -> (k_tiles, v_tiles) uint8 device buffers in the head_dim-64 image of csrc/attn_xt64.hip
+    (K pre-multiplied by scale * log2 e; default scale 64 ** -0.5).  See include/gvf_dit.h."""
+    _lib.require_cuda(kv)
+    assert kv.dim() == 2 and kv.stride(1) == 1 and kv.dtype in (torch.float32,) + LP_DTYPES
+    dt = dt_code(kv.dtype) if kv.dtype in LP_DTYPES else dt_code(dtype or torch.bfloat16)
+    assert dtype is None or dt_code(dtype) == dt
+    nbytes = n_sets * H * ((L + 63) // 64) * 8192
+    if out is None:
+        out = (torch.empty(nbytes, dtype=torch.uint8, device=kv.device), torch.empty(nbytes, dtype=torch.uint8, device=kv.device))
+    kt, vt = out
+    assert kt.numel() >= nbytes and vt.numel() >= nbytes
+    scale = 64 ** -0.5 if scale is None else scale
+    _lib.check(_lib.lib().gvf_attn_pack_kv64(dt, _p(kv), int(kv.dtype == torch.float32), kv.stride(0), k_col0, v_col0, n_sets, L, H,
+                                             float(scale * LOG2E), _p(kt), _p(vt), _stream(kv)), "gvf_attn_pack_kv64")
+    return kt, vt
+
+
+def attention_tiled64(q, k_tiles, v_tiles, out, n_outer, n_inner, Lq, Lk, H, q_strides, o_strides, kv_stride_outer, kv_stride_inner,
+                      force_exact=False, fallback_counter=None):
+    """Cross attention against a tiled, LDS-resident K/V set (head_dim 64, Lk <= 512) of q's 16-bit type; see include/gvf_dit.h."""
+    _lib.require_cuda(q, k_tiles, v_tiles, out)
+    assert q.dtype in LP_DTYPES and out.dtype == q.dtype
+    _lib.check(_lib.lib().gvf_attn_tiled64_fwd(dt_code(q.dtype), _p(q), _p(k_tiles), _p(v_tiles), _p(out), n_outer, n_inner, Lq, Lk, H,
+                                               _s4(q_strides, 64), _s4(o_strides, 64), int(kv_stride_outer), int(kv_stride_inner),
+                                               int(bool(force_exact)), _p(fallback_counter), _stream(q)), "gvf_attn_tiled64_fwd")
+    return out
 
 
 def attention_tiled(q, k_tiles, v_tiles, out, n_outer, n_inner, Lq, Lk, H, q_strides, o_strides, kv_stride_outer,

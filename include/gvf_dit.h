@@ -220,6 +220,25 @@ int gvf_attn_tiled_fwd_pf(int dtype, const void* q, const void* k_tiles, const v
                           int64_t kv_set_stride_outer, int64_t kv_set_stride_inner, const float* gamma_q,
                           int out_is_f32, int force_exact, int32_t* fallback_counter, const void* prefetch, int64_t prefetch_bytes, void* stream);
 
+/* ---- the same for head_dim 64 and key sets of <= 512 keys (csrc/attn_xt64.hip) --------------------------------------
+ * The decoder cross attention of the motion VAE (model/autoencoder.py:557-577: every static Gaussian queries the 512 latents of a
+ * frame through 12 heads of 64).  gvf_attn_pack_kv64 writes, per (set, head), ceil(L / 64) tiles of 8 KiB of K (pre-multiplied by
+ * k_scale = softmax_scale * log2(e) in fp32 before the one rounding) and 8 KiB of V^T in the order the MFMA fragments are read;
+ * kv rows as for gvf_attn_pack_kv with K of head h at columns [k_col0 + 64 h, +64), V at [v_col0 + 64 h, +64).
+ * k_tiles / v_tiles: n_sets * H * ceil(L / 64) * 8192 bytes each, 16-byte aligned.
+ * gvf_attn_tiled64_fwd: out = softmax(q k^T * scale) v, q / out 16-bit with strides {outer, inner, seq, head} in elements (multiples
+ * of 8; q, out 16-byte aligned), K/V set of (outer, inner) = outer * kv_set_stride_outer + inner * kv_set_stride_inner; Lk <= 512
+ * (the whole key set of a (set, head) is copied into LDS once per 2048 queries).  Numerics as gvf_attn_tiled_fwd: P = exp2(s) without
+ * the running maximum behind the [2^-100, 2^100] denominator guard (GVF_DT_F16: per-query shift, guard [2^-6, ...)); a wave with a
+ * query outside recomputes its 64 queries with the exact online softmax (force_exact & GVF_ATTN_FORCE_EXACT: always).
+ * fallback_counter (optional, device int32): += 1 per 64-query wave pass that took the exact path. */
+int gvf_attn_pack_kv64(int dtype, const void* kv, int kv_is_f32, int64_t ld, int k_col0, int v_col0, int n_sets, int L, int H,
+                       float k_scale, void* k_tiles, void* v_tiles, void* stream);
+int gvf_attn_tiled64_fwd(int dtype, const void* q, const void* k_tiles, const void* v_tiles, void* out, int n_outer, int n_inner,
+                         int Lq, int Lk, int H, const int64_t* q_strides, const int64_t* o_strides,
+                         int64_t kv_set_stride_outer, int64_t kv_set_stride_inner, int force_exact, int32_t* fallback_counter,
+                         void* stream);
+
 /* out_bf16[r][:] = LN(x[r][:]) (eps, no affine) then either  * ln_w + ln_b  (affine LayerNorm, norm3/4)
  * or  * (1 + scale[g]) + shift[g]  (adaLN, g = r / rows_per_group; shift/scale rows have stride mod_ld),
  * x f32 [rows][C]; C a multiple of 256 (<= 1024) takes the register-resident fast path. */

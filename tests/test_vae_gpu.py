@@ -241,3 +241,90 @@ def test_kv_resident_attention_survives_scores_that_overflow_exp2(cuda, lp):
     err = (out.float() - ref).norm(dim=-1) / ref.norm(dim=-1).clamp_min(1e-6)
     tol = 1.0 if lp == torch.bfloat16 else 0.15
     assert float(err[0, 5].max()) < 2e-2 * tol and float(err[0, 1500].max()) < 2e-2 * tol and float(err.max()) < 3e-2 * tol, (err[0, 5], err.max())
+
+
+# ---- csrc/attn_xt64.hip: the decoder cross attention against the pre-tiled, LDS-resident latent set (head_dim 64) ----------------------
+
+def _tiled64_case(cuda, lp, B, T, Lq, Lk, H, seed, spike=None, force_exact=False):
+    from gvfdiffusion_amd.ops import dit_ops
+    D, C = 64, H * 64
+    g = torch.Generator().manual_seed(seed)
+    q = torch.randn((B, Lq, C), generator=g)
+    kv = torch.randn((B * T * Lk, 2 * C), generator=g)
+    if spike is not None:
+        for (b, row, h, gain) in spike:
+            q[b, row, h * D:(h + 1) * D] *= gain
+    qb, kvb = q.to(lp).to(cuda), kv.to(lp).to(cuda)
+    kt, vt = dit_ops.attention_pack_kv64(kvb, B * T, Lk, H, 0, C)
+    out = torch.full((B, T, Lq, C), float("nan"), dtype=lp, device=cuda)
+    fb = torch.zeros(1, dtype=torch.int32, device=cuda)
+    dit_ops.attention_tiled64(qb, kt, vt, out, B, T, Lq, Lk, H, (Lq * C, 0, C), (T * Lq * C, Lq * C, C), T, 1, force_exact=force_exact, fallback_counter=fb)
+    k = kvb[:, :C].float().view(B, T, Lk, H, D)
+    v = kvb[:, C:].float().view(B, T, Lk, H, D)
+    s = torch.einsum("blhd,btmhd->bthlm", qb.float().view(B, Lq, H, D), k) * D ** -0.5
+    ref = torch.einsum("bthlm,btmhd->btlhd", torch.softmax(s, dim=-1), v).reshape(B, T, Lq, C)
+    return out, ref, int(fb.item())
+
+
+@pytest.mark.parametrize("lp", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(1, 3, 2048 + 300, 512, 12), (2, 2, 777, 200, 3), (1, 1, 64, 64, 1), (1, 2, 5000, 40, 2), (1, 1, 1, 512, 2)])
+def test_tiled64_attention_matches_fp32_softmax(cuda, lp, shape):
+    """gvf_attn_pack_kv64 + gvf_attn_tiled64_fwd against softmax(q k^T / 8) v in fp32 on the same 16-bit operands: full and ragged query
+    blocks (one workgroup covers 2048 queries in 8 passes of 256), key sets that end inside a tile, a single tile, one query; every
+    output row written (the buffer starts as NaN), no wave on the exact path.  Bars = the probabilities' 16-bit rounding (bf16 2^-9
+    relative per term, averaged over the keys; fp16 2^-12)."""
+    B, T, Lq, Lk, H = shape
+    out, ref, fb = _tiled64_case(cuda, lp, B, T, Lq, Lk, H, seed=5)
+    assert torch.isfinite(out).all() and fb == 0
+    rel = float((out.float() - ref).norm() / ref.norm())
+    assert rel < (4e-3 if lp == torch.bfloat16 else 6e-4), rel
+    assert float((out.float() - ref).abs().max()) < (3e-2 if lp == torch.bfloat16 else 4e-3)
+
+
+@pytest.mark.parametrize("lp", [torch.bfloat16, torch.float16])
+def test_tiled64_attention_exact_path_and_range_guard(cuda, lp):
+    """force_exact runs every wave through the running-maximum softmax (same bars); queries whose scores leave the exponent range send THEIR
+    wave pass (64 queries) to it and nobody else: the counter says how many."""
+    out, ref, fb = _tiled64_case(cuda, lp, 1, 2, 2048 + 128, 512, 2, seed=6, force_exact=True)
+    assert fb == 2 * 2 * ((2048 + 128) // 64)
+    assert float((out.float() - ref).norm() / ref.norm()) < (4e-3 if lp == torch.bfloat16 else 6e-4)
+    spikes = [(0, 5, 0, 400.0), (0, 1500, 1, -300.0)]
+    out, ref, fb = _tiled64_case(cuda, lp, 1, 2, 2048 + 128, 512, 2, seed=7, spike=spikes)
+    assert torch.isfinite(out).all()
+    assert 1 <= fb <= 2 * 2, fb          # (query row, head) x 2 frames: one 64-query wave pass each; the shift may keep fp16's negative spike in range
+    err = (out.float() - ref).view(1, 2, -1, 2, 64).norm(dim=-1) / ref.view(1, 2, -1, 2, 64).norm(dim=-1).clamp_min(1e-6)
+    tol = 1.0 if lp == torch.bfloat16 else 0.15
+    assert float(err[0, :, 5, 0].max()) < 2e-2 * tol and float(err[0, :, 1500, 1].max()) < 2e-2 * tol and float(err.max()) < 3e-2 * tol
+
+
+def test_tiled64_entry_point_refuses_what_it_cannot_run(cuda):
+    from gvfdiffusion_amd import _lib
+    from gvfdiffusion_amd.ops import dit_ops
+    q = torch.zeros((1, 64, 64), dtype=torch.bfloat16, device=cuda)
+    kv = torch.zeros((576, 128), dtype=torch.bfloat16, device=cuda)
+    kt, vt = dit_ops.attention_pack_kv64(kv, 1, 576, 1, 0, 64)
+    out = torch.empty((1, 1, 64, 64), dtype=torch.bfloat16, device=cuda)
+    with pytest.raises(_lib.GvfError):                 # 576 keys do not fit the LDS-resident set
+        dit_ops.attention_tiled64(q, kt, vt, out, 1, 1, 64, 576, 1, (4096, 0, 64), (4096, 4096, 64), 1, 1)
+    with pytest.raises(_lib.GvfError):                 # output rows must be 16-byte aligned
+        dit_ops.attention_tiled64(q, kt, vt, out, 1, 1, 64, 512, 1, (4096, 0, 64), (4096, 4096, 68), 1, 1)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_decode_is_the_same_through_either_attention_kernel(cuda, dtype):
+    """decode() through csrc/attn_xt64.hip (default) and through csrc/attn.hip's K/V-resident kernel (GVF_VAE_TILED64=0): same operands, same
+    placement, two summation orders."""
+    import os
+    from gvfdiffusion_amd.model.autoencoder import GSKLTemporalVariationalAutoEncoder
+    torch.manual_seed(3)
+    m = GSKLTemporalVariationalAutoEncoder(depth=2, dim=384, queries_dim=384, output_dim=14, num_inputs=512, num_latents=128, latent_dim=16, heads=6,
+                                           dim_head=64, num_timesteps=3).to(cuda).set_compute_dtype(dtype)
+    x = torch.randn(3, 128, 16, device=cuda)
+    qs = torch.randn(1, 3000, 14, device=cuda)
+    y1 = m.decode(x, qs)
+    os.environ["GVF_VAE_TILED64"] = "0"
+    try:
+        y0 = m.decode(x, qs)
+    finally:
+        del os.environ["GVF_VAE_TILED64"]
+    assert float((y1 - y0).norm() / y0.norm()) < (3e-3 if dtype == "bf16" else 4e-4)
