@@ -55,6 +55,8 @@ struct X64Params {
     long long q_so, q_si, q_sl, q_sh, o_so, o_si, o_sl, o_sh;
     long long kv_so, kv_si;
     int* fallbacks;                    // optional: += 1 per WAVE PASS (64 queries) that took the exact path
+    const uint4* fold_w;               // FOLD kernels: [head][4 fragments][64 lanes] of the (<= 16 x H*64) matrix applied to the attention output
+    float* part;                       // FOLD kernels: [set = outer * n_inner + inner][head][Lq][16] f32 partial products (one per head)
 #ifdef X64_TIMING
     long long* dbg;                    // timing builds (scripts/ubench/x64_bench.hip): s_memtime stamps of workgroup 0, wave 0
 #endif
@@ -221,7 +223,7 @@ __device__ __forceinline__ void x64_take_shift(f32x16 (&s)[2], f32x16& c) {
     for (int r = 0; r < 16; ++r) { s[0][r] -= m; s[1][r] -= m; c[r] = -m; }
 }
 
-template <int DT>
+template <int DT, bool FOLD>
 __global__ __launch_bounds__(X64_THREADS) void attn_xt64_kernel(X64Params p, int force_safe) {
     typedef GvfLp<DT> LP;
     typedef typename LP::x8 x8;
@@ -268,6 +270,13 @@ __global__ __launch_bounds__(X64_THREADS) void attn_xt64_kernel(X64Params p, int
             x64_dma16(kbase + (long long)t * 512 + i * 256 + wave * 64 + lane, dst + i * 256 + wave * 64);
             x64_dma16(vbase + (long long)t * 512 + i * 256 + wave * 64 + lane, dst + 512 + i * 256 + wave * 64);
         }
+    }
+    // FOLD: the head's 64 columns of the output matrix as four A operands of the 32x32x16 shape (rows m < 16 of W^T, 8 values of the contraction
+    // per lane in the order a lane's accumulator registers hold d: fragment (dt, j), lane (m, half), element e <-> d = 32 dt + 8 (2 j + (e >> 2)) + 4 half + (e & 3))
+    x8 wf[4];
+    if (FOLD) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wf[i] = __builtin_bit_cast(x8, p.fold_w[(head * 4 + i) * 64 + lane]);
     }
     __syncthreads();
 #define X_K(t_) (&x64_smem[(t_) * X64_TILE])
@@ -350,6 +359,40 @@ __global__ __launch_bounds__(X64_THREADS) void attn_xt64_kernel(X64Params p, int
         // ---- epilogue: O[q][d] / l, d = 32 dt + (r & 3) + 8 (r >> 2) + 4 half.  A lane holds 4 consecutive d of ONE query per (dt, g): stored
         // from the accumulator layout that is 32 eight-byte pieces in 32 different cache lines per instruction.  The wave's 64 x 128-byte tile
         // goes through its own 8 KiB of LDS instead (chunk c of row q at slot c ^ (q & 7)) and leaves as 8 stores of 8 whole rows each.
+        if (FOLD) {
+            // y^T[m][q] = sum_d W[m][head * 64 + d] * bf16(o[q][d] / l): the output projection folded with to_out (<= 16 x 768) applied per head to the
+            // rounded attention output while it is still in registers -- the packed pairs of a lane ARE a B operand (4 consecutive d per pair).
+            // The 16 floats per (query, head) leave as two 16-byte stores per lane; gvf_attn_fold_reduce adds the heads and the bias.
+            f32x16 yA = zero, yB = zero;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const float inv = 1.0f / (a == 0 ? lA : lB);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const f32x16& o = a == 0 ? oA[dt] : oB[dt];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        unsigned w[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) w[u] = LP::pack(o[8 * j + 2 * u] * inv, o[8 * j + 2 * u + 1] * inv);
+                        const x8 bfrag = __builtin_bit_cast(x8, make_uint4(w[0], w[1], w[2], w[3]));
+                        if (a == 0) yA = LP::mfma32(wf[2 * dt + j], bfrag, yA); else yB = LP::mfma32(wf[2 * dt + j], bfrag, yB);
+                    }
+                }
+            }
+            if (pass + 1 < X64_PASSES && row0 + X64_THREADS < p.Lq) take_q(pass + 1);
+            float* pbase = p.part + ((((long long)outer * p.n_inner + inner) * p.H + head) * p.Lq) * 16;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int qr = row0 + a * 32 + l31;
+                const f32x16& y = a == 0 ? yA : yB;
+                if (qr < p.Lq) {                 // rows m = 4 half + (r & 3) + 8 (r >> 2), r = 0 .. 7
+                    float* dst = pbase + (long long)qr * 16 + 4 * half;
+                    *reinterpret_cast<float4*>(dst) = make_float4(y[0], y[1], y[2], y[3]);
+                    *reinterpret_cast<float4*>(dst + 8) = make_float4(y[4], y[5], y[6], y[7]);
+                }
+            }
+        } else
         {
             uint4* so = &x64_smem[T * X64_TILE + wave * 512];
 #pragma unroll
@@ -493,35 +536,36 @@ extern "C" int gvf_attn_pack_kv64(int dtype, const void* kv, int kv_is_f32, int6
     return GVF_OK;
 }
 
-template <int DT>
+template <int DT, bool FOLD>
 static int x64_launch(const X64Params& p, int force_safe, unsigned blocks, size_t lds, hipStream_t stream) {
     static std::mutex m;                                                // per instantiation; callers may be on several host threads
     static bool attr_set = false;
     {
         std::lock_guard<std::mutex> g(m);
         if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_xt64_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_xt64_kernel<DT, FOLD>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (X64_MAX_TILES * X64_TILE + 4 * 512) * 16) != hipSuccess)
                 return GVF_ELAUNCH;
             attr_set = true;
         }
     }
-    attn_xt64_kernel<DT><<<dim3(blocks), dim3(X64_THREADS), lds, stream>>>(p, force_safe);
+    attn_xt64_kernel<DT, FOLD><<<dim3(blocks), dim3(X64_THREADS), lds, stream>>>(p, force_safe);
     return GVF_OK;
 }
 
-extern "C" int gvf_attn_tiled64_fwd(int dtype, const void* q, const void* k_tiles, const void* v_tiles, void* out, int n_outer, int n_inner,
-                                    int Lq, int Lk, int H, const int64_t* q_strides, const int64_t* o_strides,
-                                    int64_t kv_set_stride_outer, int64_t kv_set_stride_inner, int force_exact, int32_t* fallback_counter,
-                                    void* stream_) {
+static int x64_run(int dtype, const void* q, const void* k_tiles, const void* v_tiles, void* out, const void* fold_frags, float* part, int n_outer,
+                   int n_inner, int Lq, int Lk, int H, const int64_t* q_strides, const int64_t* o_strides, int64_t kv_set_stride_outer,
+                   int64_t kv_set_stride_inner, int force_exact, int32_t* fallback_counter, void* stream_) {
+    const bool fold = fold_frags != nullptr;
     if (dtype != GVF_DT_BF16 && dtype != GVF_DT_F16) return GVF_EINVAL;
     if (n_outer < 0 || n_inner <= 0 || Lq < 0 || Lk <= 0 || H <= 0) return GVF_EINVAL;
     if (Lk > X64_MAX_TILES * X64_KT) return GVF_EINVAL;               // the key set must fit in LDS
     if (n_outer == 0 || Lq == 0) return GVF_OK;
-    if (!q || !k_tiles || !v_tiles || !out || !q_strides || !o_strides) return GVF_EINVAL;
+    if (!q || !k_tiles || !v_tiles || !q_strides || (fold ? !part : (!out || !o_strides))) return GVF_EINVAL;
     for (int i = 0; i < 4; ++i)
-        if ((q_strides[i] % 8) || (o_strides[i] % 8)) return GVF_EINVAL;
-    if ((((uintptr_t)q) & 15) || (((uintptr_t)k_tiles) & 15) || (((uintptr_t)v_tiles) & 15) || (((uintptr_t)out) & 15)) return GVF_EINVAL;
+        if ((q_strides[i] % 8) || (!fold && (o_strides[i] % 8))) return GVF_EINVAL;
+    if ((((uintptr_t)q) & 15) || (((uintptr_t)k_tiles) & 15) || (((uintptr_t)v_tiles) & 15)) return GVF_EINVAL;
+    if (fold ? ((((uintptr_t)fold_frags) & 15) || (((uintptr_t)part) & 15)) : ((((uintptr_t)out) & 15) != 0)) return GVF_EINVAL;
     X64Params p;
     p.q = (const unsigned short*)q; p.out = (unsigned short*)out;
     p.kt = (const uint4*)k_tiles; p.vt = (const uint4*)v_tiles;
@@ -529,9 +573,11 @@ extern "C" int gvf_attn_tiled64_fwd(int dtype, const void* q, const void* k_tile
     p.q_blocks = (Lq + X64_PASSES * X64_THREADS - 1) / (X64_PASSES * X64_THREADS);
     p.n_tiles = (Lk + X64_KT - 1) / X64_KT;
     p.q_so = q_strides[0]; p.q_si = q_strides[1]; p.q_sl = q_strides[2]; p.q_sh = q_strides[3];
-    p.o_so = o_strides[0]; p.o_si = o_strides[1]; p.o_sl = o_strides[2]; p.o_sh = o_strides[3];
+    p.o_so = p.o_si = p.o_sl = p.o_sh = 0;
+    if (!fold) { p.o_so = o_strides[0]; p.o_si = o_strides[1]; p.o_sl = o_strides[2]; p.o_sh = o_strides[3]; }
     p.kv_so = kv_set_stride_outer; p.kv_si = kv_set_stride_inner;
     p.fallbacks = fallback_counter;
+    p.fold_w = (const uint4*)fold_frags; p.part = part;
 #ifdef X64_TIMING
     p.dbg = g_x64_dbg;
 #endif
@@ -539,8 +585,86 @@ extern "C" int gvf_attn_tiled64_fwd(int dtype, const void* q, const void* k_tile
     if (blocks > 0x7fffffffLL) return GVF_EINVAL;
     (void)hipGetLastError();
     int rc = GVF_OK;
-    GVF_LP_DISPATCH(dtype, rc = x64_launch<DT>(p, force_exact & GVF_ATTN_FORCE_EXACT, (unsigned)blocks, ((size_t)p.n_tiles * X64_TILE + 4 * 512) * 16, (hipStream_t)stream_));
+    const size_t lds = ((size_t)p.n_tiles * X64_TILE + 4 * 512) * 16;
+    const int fs = force_exact & GVF_ATTN_FORCE_EXACT;
+    GVF_LP_DISPATCH(dtype, rc = fold ? x64_launch<DT, true>(p, fs, (unsigned)blocks, lds, (hipStream_t)stream_)
+                                     : x64_launch<DT, false>(p, fs, (unsigned)blocks, lds, (hipStream_t)stream_));
     if (rc != GVF_OK) return rc;
+    GVF_CHECK_LAUNCH();
+    return GVF_OK;
+}
+
+extern "C" int gvf_attn_tiled64_fwd(int dtype, const void* q, const void* k_tiles, const void* v_tiles, void* out, int n_outer, int n_inner,
+                                    int Lq, int Lk, int H, const int64_t* q_strides, const int64_t* o_strides,
+                                    int64_t kv_set_stride_outer, int64_t kv_set_stride_inner, int force_exact, int32_t* fallback_counter,
+                                    void* stream_) {
+    return x64_run(dtype, q, k_tiles, v_tiles, out, nullptr, nullptr, n_outer, n_inner, Lq, Lk, H, q_strides, o_strides, kv_set_stride_outer,
+                   kv_set_stride_inner, force_exact, fallback_counter, stream_);
+}
+
+extern "C" int gvf_attn_tiled64_fold_fwd(int dtype, const void* q, const void* k_tiles, const void* v_tiles, const void* fold_frags, float* part,
+                                         int n_outer, int n_inner, int Lq, int Lk, int H, const int64_t* q_strides,
+                                         int64_t kv_set_stride_outer, int64_t kv_set_stride_inner, int force_exact, int32_t* fallback_counter,
+                                         void* stream_) {
+    if (!fold_frags) return GVF_EINVAL;
+    return x64_run(dtype, q, k_tiles, v_tiles, nullptr, fold_frags, part, n_outer, n_inner, Lq, Lk, H, q_strides, nullptr, kv_set_stride_outer,
+                   kv_set_stride_inner, force_exact, fallback_counter, stream_);
+}
+
+// W (n_out <= 16 rows x H * 64 columns, row-major 16-bit with leading dimension ld) -> the fragment image attn_xt64_kernel<.., FOLD> reads
+namespace {
+__global__ void x64_pack_fold_kernel(const unsigned short* __restrict__ w, int ld, int n_out, int H, uint4* __restrict__ frags) {
+    const int lane = threadIdx.x & 63, i = threadIdx.x >> 6, head = blockIdx.x;       // 256 threads: fragment i = 2 dt + j
+    const int m = lane & 31, half = lane >> 5, dt = i >> 1, j = i & 1;
+    unsigned short v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int d = 32 * dt + 8 * (2 * j + (e >> 2)) + 4 * half + (e & 3);
+        v[e] = m < n_out ? w[(long long)m * ld + head * 64 + d] : (unsigned short)0;
+    }
+    frags[(head * 4 + i) * 64 + lane] = make_uint4(v[0] | ((unsigned)v[1] << 16), v[2] | ((unsigned)v[3] << 16), v[4] | ((unsigned)v[5] << 16), v[6] | ((unsigned)v[7] << 16));
+}
+
+// out[set][q][0 .. n_out) = bias + sum over heads of part[set][head][q][0 .. n_out)   (fixed order: deterministic)
+__global__ __launch_bounds__(256) void x64_fold_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ out,
+                                                              int H, int Lq, int n_out, long long out_set_stride, long long out_row_stride) {
+    const int q = blockIdx.x * 256 + threadIdx.x, set = blockIdx.y;
+    if (q >= Lq) return;
+    float acc[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) acc[m] = (bias != nullptr && m < n_out) ? bias[m] : 0.f;
+    const float4* src = reinterpret_cast<const float4*>(part + (((long long)set * H) * Lq + q) * 16);
+    for (int h = 0; h < H; ++h) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float4 v = src[(long long)h * Lq * 4 + u];
+            acc[4 * u] += v.x; acc[4 * u + 1] += v.y; acc[4 * u + 2] += v.z; acc[4 * u + 3] += v.w;
+        }
+    }
+    float* dst = out + set * out_set_stride + q * out_row_stride;
+#pragma unroll
+    for (int m = 0; m < 16; ++m)
+        if (m < n_out) dst[m] = acc[m];
+}
+}  // namespace
+
+extern "C" int gvf_attn_fold_pack(int dtype, const void* w, int ld, int n_out, int H, void* fold_frags, void* stream_) {
+    if (dtype != GVF_DT_BF16 && dtype != GVF_DT_F16) return GVF_EINVAL;
+    if (!w || !fold_frags || n_out <= 0 || n_out > 16 || H <= 0 || ld < H * 64 || (((uintptr_t)fold_frags) & 15)) return GVF_EINVAL;
+    (void)hipGetLastError();
+    x64_pack_fold_kernel<<<dim3((unsigned)H), dim3(256), 0, (hipStream_t)stream_>>>((const unsigned short*)w, ld, n_out, H, (uint4*)fold_frags);
+    GVF_CHECK_LAUNCH();
+    return GVF_OK;
+}
+
+extern "C" int gvf_attn_fold_reduce(const float* part, const float* bias, float* out, int n_sets, int H, int Lq, int n_out,
+                                    int64_t out_set_stride, int64_t out_row_stride, void* stream_) {
+    if (n_sets < 0 || H <= 0 || Lq < 0 || n_out <= 0 || n_out > 16) return GVF_EINVAL;
+    if (n_sets == 0 || Lq == 0) return GVF_OK;
+    if (!part || !out || (((uintptr_t)part) & 15) || n_sets > 65535) return GVF_EINVAL;
+    (void)hipGetLastError();
+    x64_fold_reduce_kernel<<<dim3((unsigned)((Lq + 255) / 256), (unsigned)n_sets), dim3(256), 0, (hipStream_t)stream_>>>(part, bias, out, H, Lq, n_out,
+                                                                                                                      out_set_stride, out_row_stride);
     GVF_CHECK_LAUNCH();
     return GVF_OK;
 }

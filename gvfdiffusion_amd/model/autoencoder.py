@@ -336,9 +336,21 @@ class GSKLTemporalVariationalAutoEncoder(nn.Module):
         # config: 5 x 45056 + 36864 Gaussians; a fixed 43648 left a 256-Gaussian seventh launch pair)
         n_chunks = max(1, (B * T * P + self.max_chunk_rows // 2) // self.max_chunk_rows)
         Pc = min(P, ((P + n_chunks - 1) // n_chunks + 2047) // 2048 * 2048)
+        qp3 = qp.view(B, P, C)
+        if tiled and self.output_dim <= 16 and os.environ.get("GVF_VAE_FOLD", "1") != "0":
+            # to_out o to_outputs applied per head in the attention's epilogue: 16 fp32 partial products per (frame, Gaussian, head) instead of
+            # the 768-wide 16-bit rows and the GEMM that re-read them; the heads are added in ascending order by the reduce launch
+            frags = W.get("fold_frags")
+            if frags is None:
+                frags = W["fold_frags"] = dit_ops.attention_fold_pack(W["fold"][0], self.output_dim, H)
+            part = torch.empty((B * T, H, Pc, 16), dtype=torch.float32, device=dev)
+            for p0 in range(0, P, Pc):
+                n = min(Pc, P - p0)
+                dit_ops.attention_tiled64_fold(qp3[:, p0:], kt, vt, frags, part, B, T, n, L, H, (P * C, 0, C), T, 1)
+                dit_ops.attention_fold_reduce(part, W["fold"][1], out[:, :, p0:], B * T, H, n, self.output_dim, P * self.output_dim, self.output_dim)
+            return out.to(queries.dtype if queries.dtype.is_floating_point else torch.float32)
         ao = torch.empty((B, T, Pc, C), dtype=bf16, device=dev)
         yo = torch.empty((B * T * Pc, self.output_dim), dtype=torch.float32, device=dev)
-        qp3 = qp.view(B, P, C)
         for p0 in range(0, P, Pc):
             n = min(Pc, P - p0)
             a = ao if n == Pc else ao.view(-1)[:B * T * n * C].view(B, T, n, C)

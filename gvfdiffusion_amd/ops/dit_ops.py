@@ -72,6 +72,9 @@ _lib.register({
     "gvf_gemm_stats_parts": (_i, [_i]),
     "gvf_attn_pack_kv64": (_i, [_i, _vp, _i, _i64, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "gvf_attn_tiled64_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, ctypes.POINTER(_i64), ctypes.POINTER(_i64), _i64, _i64, _i, _vp, _vp]),
+    "gvf_attn_fold_pack": (_i, [_i, _vp, _i, _i, _i, _vp, _vp]),
+    "gvf_attn_tiled64_fold_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, ctypes.POINTER(_i64), _i64, _i64, _i, _vp, _vp]),
+    "gvf_attn_fold_reduce": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _vp]),
     "gvf_attn_tiled_fwd_pf": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, ctypes.POINTER(_i64), ctypes.POINTER(_i64), _i64, _i64,
                                    _vp, _i, _i, _vp, _vp, _i64, _vp]),
 })
@@ -441,6 +444,36 @@ def attention_tiled64(q, k_tiles, v_tiles, out, n_outer, n_inner, Lq, Lk, H, q_s
     _lib.check(_lib.lib().gvf_attn_tiled64_fwd(dt_code(q.dtype), _p(q), _p(k_tiles), _p(v_tiles), _p(out), n_outer, n_inner, Lq, Lk, H,
                                                _s4(q_strides, 64), _s4(o_strides, 64), int(kv_stride_outer), int(kv_stride_inner),
                                                int(bool(force_exact)), _p(fallback_counter), _stream(q)), "gvf_attn_tiled64_fwd")
+    return out
+
+
+def attention_fold_pack(w16: torch.Tensor, n_out: int, H: int):
+    """(n_out <= 16, >= H*64) 16-bit row-major matrix -> the fragment image the fold epilogue of csrc/attn_xt64.hip reads (uint8, H * 4096 bytes)."""
+    _lib.require_cuda(w16)
+    assert w16.dim() == 2 and w16.stride(1) == 1 and w16.dtype in LP_DTYPES and w16.shape[0] >= n_out
+    frags = torch.empty(H * 4096, dtype=torch.uint8, device=w16.device)
+    _lib.check(_lib.lib().gvf_attn_fold_pack(dt_code(w16.dtype), _p(w16), w16.stride(0), n_out, H, _p(frags), _stream(w16)), "gvf_attn_fold_pack")
+    return frags
+
+
+def attention_tiled64_fold(q, k_tiles, v_tiles, fold_frags, part, n_outer, n_inner, Lq, Lk, H, q_strides, kv_stride_outer, kv_stride_inner,
+                           force_exact=False, fallback_counter=None):
+    """attention_tiled64 with the projection behind it folded into the epilogue: writes part (n_outer * n_inner, H, Lq, 16) fp32; see
+    include/gvf_dit.h (gvf_attn_tiled64_fold_fwd)."""
+    _lib.require_cuda(q, k_tiles, v_tiles, fold_frags, part)
+    assert q.dtype in LP_DTYPES and part.dtype == torch.float32 and part.is_contiguous() and part.numel() >= n_outer * n_inner * H * Lq * 16
+    _lib.check(_lib.lib().gvf_attn_tiled64_fold_fwd(dt_code(q.dtype), _p(q), _p(k_tiles), _p(v_tiles), _p(fold_frags), _p(part), n_outer, n_inner,
+                                                    Lq, Lk, H, _s4(q_strides, 64), int(kv_stride_outer), int(kv_stride_inner),
+                                                    int(bool(force_exact)), _p(fallback_counter), _stream(q)), "gvf_attn_tiled64_fold_fwd")
+    return part
+
+
+def attention_fold_reduce(part, bias, out, n_sets, H, Lq, n_out, out_set_stride, out_row_stride):
+    """out[set][q][:n_out] = bias + sum over heads of part[set][head][q][:n_out] (fp32; `out` may be a view: strides in elements)."""
+    _lib.require_cuda(part, out)
+    assert part.dtype == torch.float32 and out.dtype == torch.float32 and (bias is None or bias.dtype == torch.float32)
+    _lib.check(_lib.lib().gvf_attn_fold_reduce(_p(part), _p(bias), _p(out), n_sets, H, Lq, n_out, int(out_set_stride), int(out_row_stride),
+                                               _stream(part)), "gvf_attn_fold_reduce")
     return out
 
 

@@ -239,6 +239,20 @@ int gvf_attn_tiled64_fwd(int dtype, const void* q, const void* k_tiles, const vo
                          int64_t kv_set_stride_outer, int64_t kv_set_stride_inner, int force_exact, int32_t* fallback_counter,
                          void* stream);
 
+/* The same launch with the projection that follows the attention folded into its epilogue (the decoder's to_out o to_outputs, one
+ * <= 16 x H*64 matrix: model/autoencoder.py:575-577, 606-608): instead of the H*64-wide 16-bit output rows it writes, per head, the 16 fp32
+ * partial products  part[set = outer * n_inner + inner][head][q][m] = sum_d W[m][64 head + d] * r16(o[q][64 head + d])  (r16 = the rounding the
+ * stored output would have had) -- half the bytes, and the GEMM that re-read them is gone.  fold_frags: gvf_attn_fold_pack's image of W
+ * (16-bit row-major [n_out <= 16][ld >= H*64]; H * 4096 bytes, 16-byte aligned).  gvf_attn_fold_reduce then writes
+ * out[set][q][0 .. n_out) = bias + sum over heads (ascending: deterministic), out rows / sets out_row_stride / out_set_stride floats apart. */
+int gvf_attn_fold_pack(int dtype, const void* w, int ld, int n_out, int H, void* fold_frags, void* stream);
+int gvf_attn_tiled64_fold_fwd(int dtype, const void* q, const void* k_tiles, const void* v_tiles, const void* fold_frags, float* part,
+                              int n_outer, int n_inner, int Lq, int Lk, int H, const int64_t* q_strides,
+                              int64_t kv_set_stride_outer, int64_t kv_set_stride_inner, int force_exact, int32_t* fallback_counter,
+                              void* stream);
+int gvf_attn_fold_reduce(const float* part, const float* bias, float* out, int n_sets, int H, int Lq, int n_out,
+                         int64_t out_set_stride, int64_t out_row_stride, void* stream);
+
 /* out_bf16[r][:] = LN(x[r][:]) (eps, no affine) then either  * ln_w + ln_b  (affine LayerNorm, norm3/4)
  * or  * (1 + scale[g]) + shift[g]  (adaLN, g = r / rows_per_group; shift/scale rows have stride mod_ld),
  * x f32 [rows][C]; C a multiple of 256 (<= 1024) takes the register-resident fast path. */

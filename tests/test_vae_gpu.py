@@ -245,6 +245,13 @@ def test_kv_resident_attention_survives_scores_that_overflow_exp2(cuda, lp):
 
 # ---- csrc/attn_xt64.hip: the decoder cross attention against the pre-tiled, LDS-resident latent set (head_dim 64) ----------------------
 
+def _randomise(m):
+    """every matrix ~ N(0, 1 / fan_in), every vector ~ N(0, 0.1): the constructor zero-initialises the output layer as the reference does"""
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_(torch.randn_like(p) * (p.shape[1] ** -0.5 if p.dim() == 2 else 0.1))
+
+
 def _tiled64_case(cuda, lp, B, T, Lq, Lk, H, seed, spike=None, force_exact=False):
     from gvfdiffusion_amd.ops import dit_ops
     D, C = 64, H * 64
@@ -318,7 +325,9 @@ def test_decode_is_the_same_through_either_attention_kernel(cuda, dtype):
     from gvfdiffusion_amd.model.autoencoder import GSKLTemporalVariationalAutoEncoder
     torch.manual_seed(3)
     m = GSKLTemporalVariationalAutoEncoder(depth=2, dim=384, queries_dim=384, output_dim=14, num_inputs=512, num_latents=128, latent_dim=16, heads=6,
-                                           dim_head=64, num_timesteps=3).to(cuda).set_compute_dtype(dtype)
+                                           dim_head=64, num_timesteps=3)
+    _randomise(m)
+    m = m.to(cuda).set_compute_dtype(dtype)
     x = torch.randn(3, 128, 16, device=cuda)
     qs = torch.randn(1, 3000, 14, device=cuda)
     y1 = m.decode(x, qs)
@@ -328,3 +337,51 @@ def test_decode_is_the_same_through_either_attention_kernel(cuda, dtype):
     finally:
         del os.environ["GVF_VAE_TILED64"]
     assert float((y1 - y0).norm() / y0.norm()) < (3e-3 if dtype == "bf16" else 4e-4)
+
+
+@pytest.mark.parametrize("lp", [torch.bfloat16, torch.float16])
+def test_tiled64_fold_epilogue_equals_projection_of_the_stored_output(cuda, lp):
+    """gvf_attn_tiled64_fold_fwd + gvf_attn_fold_reduce = (the 16-bit rows gvf_attn_tiled64_fwd stores) @ W^T + bias in fp32: the fold multiplies
+    the SAME rounded values, only the order of the fp32 additions differs (per head, then over the heads)."""
+    from gvfdiffusion_amd.ops import dit_ops
+    B, T, Lq, Lk, H, n_out = 2, 3, 2048 + 77, 300, 3, 14
+    C = H * 64
+    g = torch.Generator().manual_seed(9)
+    q = torch.randn((B, Lq, C), generator=g).to(lp).to(cuda)
+    kv = torch.randn((B * T * Lk, 2 * C), generator=g).to(lp).to(cuda)
+    w = (torch.randn((n_out, C), generator=g) * C ** -0.5).to(lp).to(cuda)
+    bias = torch.randn(n_out, generator=g).to(cuda)
+    kt, vt = dit_ops.attention_pack_kv64(kv, B * T, Lk, H, 0, C)
+    o16 = torch.empty((B, T, Lq, C), dtype=lp, device=cuda)
+    dit_ops.attention_tiled64(q, kt, vt, o16, B, T, Lq, Lk, H, (Lq * C, 0, C), (T * Lq * C, Lq * C, C), T, 1)
+    ref = o16.float() @ w.float().t() + bias
+    frags = dit_ops.attention_fold_pack(w, n_out, H)
+    part = torch.full((B * T, H, Lq, 16), float("nan"), dtype=torch.float32, device=cuda)
+    dit_ops.attention_tiled64_fold(q, kt, vt, frags, part, B, T, Lq, Lk, H, (Lq * C, 0, C), T, 1)
+    assert torch.isfinite(part).all() and float(part[..., n_out:].abs().max()) == 0.0        # rows past n_out of the padded matrix are zeros
+    big = torch.full((B, T, Lq + 5, n_out), float("nan"), device=cuda)                       # a view with its own row / set strides
+    dit_ops.attention_fold_reduce(part, bias, big[:, :, 5:], B * T, H, Lq, n_out, (Lq + 5) * n_out, n_out)
+    assert torch.isnan(big[:, :, :5]).all()
+    got = big[:, :, 5:]
+    assert float((got - ref).abs().max()) < 2e-5 * float(ref.abs().max()), float((got - ref).abs().max())
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_decode_is_the_same_with_and_without_the_folded_epilogue(cuda, dtype):
+    import os
+    from gvfdiffusion_amd.model.autoencoder import GSKLTemporalVariationalAutoEncoder
+    torch.manual_seed(4)
+    m = GSKLTemporalVariationalAutoEncoder(depth=2, dim=384, queries_dim=384, output_dim=14, num_inputs=512, num_latents=128, latent_dim=16, heads=6,
+                                           dim_head=64, num_timesteps=3)
+    _randomise(m)
+    m = m.to(cuda).set_compute_dtype(dtype)
+    m.max_chunk_rows = 3 * 2048                     # three chunks, the last one ragged
+    x = torch.randn(3, 128, 16, device=cuda)
+    qs = torch.randn(1, 5000, 14, device=cuda)
+    y1 = m.decode(x, qs)
+    os.environ["GVF_VAE_FOLD"] = "0"
+    try:
+        y0 = m.decode(x, qs)
+    finally:
+        del os.environ["GVF_VAE_FOLD"]
+    assert float((y1 - y0).abs().max()) < 2e-5 * float(y0.abs().max())
