@@ -154,9 +154,16 @@ class DiT(nn.Module):
         self.no_temporal_attn = no_temporal_attn
         assert int(np.log2(patch_size)) == np.log2(patch_size), "Patch size must be a power of 2"
         if share_mod:
-            raise NotImplementedError("share_mod=True is not built (configs/diffusion.yml uses per-block adaLN)")
+            # the reference cannot run this option either: its shared projection is 6C wide where the block splits it 9 ways (and 9C / 6 ways
+            # without temporal attention), model/dit.py:234-238 against :354-358 -> RuntimeError at :247 (scripts/reference_dit_variants.py,
+            # profiles/r04_reference_dit_variants.txt).  There is no behaviour to reproduce.
+            raise NotImplementedError("share_mod=True: the reference's own forward fails with a shape error at model/dit.py:247 "
+                                      "(profiles/r04_reference_dit_variants.txt); configs/diffusion.yml uses per-block adaLN")
         if pe_mode == "rope":
-            raise NotImplementedError("pe_mode='rope' is not built (configs/diffusion.yml uses 'ape')")
+            # dead in the reference as well: RotaryPositionEmbedder builds hidden_size // 3 // 2 = 5 phases per token for a 16-pair head and pads
+            # along the token axis (model/attention/modules.py:36, 52-57) -> RuntimeError for every sequence length
+            raise NotImplementedError("pe_mode='rope': the reference's own forward fails with a shape error at model/attention/modules.py:36 "
+                                      "(profiles/r04_reference_dit_variants.txt); configs/diffusion.yml uses 'ape'")
         if model_channels % self.num_heads != 0 or model_channels // self.num_heads != 32:
             # the tiled K / V cache (csrc/attn_xt.hip), its pack kernels and the temporal section of csrc/rowblock.hip are head_dim-32 code
             # (configs/diffusion.yml: 512 channels / 16 heads); anything else would compute a different attention without an error

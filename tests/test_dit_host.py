@@ -55,3 +55,14 @@ def test_attention_backend_seam():
     for other in ("flash_attn", "xformers", "sdpa", "naive"):
         with pytest.raises(ValueError):
             A.set_backend(other)
+
+
+def test_options_the_reference_cannot_run_are_refused_at_construction():
+    """share_mod=True and pe_mode='rope' end in shape errors inside the reference's own forward (profiles/r04_reference_dit_variants.txt,
+    scripts/reference_dit_variants.py): there is no behaviour to match, the module says so instead of failing in a kernel; a head_dim other
+    than 32 has no HIP attention path."""
+    g = np.load(os.path.join(GOLD, "dit_small_golden.npz"))
+    cfg = json.loads(bytes(g["cfg_json"]).decode())
+    for over, word in ((dict(share_mod=True), "model/dit.py:247"), (dict(pe_mode="rope"), "modules.py:36"), (dict(num_heads=1), "head_dim 32")):
+        with pytest.raises(NotImplementedError, match=word):
+            DiT(**dict(cfg, **over))
