@@ -1,7 +1,7 @@
 #!/bin/bash
 # motion-VAE decode: where the 24 ms go (kernel stats of scripts/vae_breakdown.py, bf16 default)
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
-O=$PWD/gpurun_out/r04k; mkdir -p $O
+O=$PWD/gpurun_out/r04o; mkdir -p $O
 python -c "import gvfdiffusion_amd._build as b; b.build(verbose=False)" >/dev/null 2>&1
 python scripts/vae_breakdown.py > $O/vae_breakdown.txt 2>&1
 export TMPDIR=/tmp
