@@ -350,7 +350,8 @@ int launch_gemm(const void* A, int lda, const void* W, int ldw, const float* bia
         return GVF_EINVAL;
     (void)hipGetLastError();
     const int tiles_n = (N + BN_DEFAULT - 1) / BN_DEFAULT;
-    const bool small = ((M + 127) / 128) * tiles_n < 512;      // fewer than two 128-row workgroups per CU: use 64-row tiles
+    static const int bm_override = []() { const char* e = getenv("GVF_GEMM_BM"); return e ? atoi(e) : 0; }();   // tuning aid
+    const bool small = bm_override ? bm_override == 64 : ((M + 127) / 128) * tiles_n < 512;      // fewer than two 128-row workgroups per CU: use 64-row tiles
     const int bm = small ? 64 : 128;
     const int tiles_m = (M + bm - 1) / bm;
     const dim3 grid(tiles_m * tiles_n), block(THREADS);

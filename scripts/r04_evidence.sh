@@ -26,6 +26,15 @@ done
 # 6. SQ counters DiT (fp16)
 GVF_BENCH_DIT_NFE=8 GVF_DIT_DTYPE=fp16 scripts/pmc_py.sh dit8 bench.py --dit-only --no-cpu-baseline > /dev/null 2>&1
 python scripts/pmc_sq_summary.py gpurun_out/r04/pmc_dit_sq_summary.txt - gpurun_out/pmc_dit8/pass1.csv gpurun_out/pmc_dit8/pass2.csv gpurun_out/pmc_dit8/pass3.csv > /dev/null 2>&1
+# 7. motion-VAE decode by kernel, both operand types; the decoder cross attention alone (attn_xt64 against attn.hip's K/V-resident kernel); GEMM yardstick
+for t in bf16 fp16; do
+  ( cd /tmp && TMPDIR=/tmp GVF_DIT_DTYPE=$t rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r04/vae_$t -o vae -- python $GRAFT_REPO_ROOT/scripts/vae_breakdown.py > $GRAFT_REPO_ROOT/gpurun_out/r04/vae_breakdown_$t.txt 2>&1 )
+  find gpurun_out/r04/vae_$t -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/r04/vae_decode_kernel_stats_$t.csv
+  rm -rf gpurun_out/r04/vae_$t
+done
+{ for d in 0 1; do scripts/ubench/x64_vf.bin 5 $d; scripts/ubench/kvres_base.bin 5 $d; done; for L in 64 256; do scripts/ubench/x64_vf.bin 5 0 43648 $L; done
+  scripts/ubench/x64_noq.bin 5 0; scripts/ubench/x64_noqst.bin 5 0; scripts/ubench/x64_vf.bin 2 0 8192 512 40 0; scripts/ubench/x64_vf.bin 2 1 333 40 1 0; } > gpurun_out/r04/attn_xt64_ubench.txt 2>&1
+python scripts/bench_gemm_vae.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r04/gemm_vae_shapes.txt
 rm -rf gpurun_out/pmc_*/pass*.csv gpurun_out/prof_r04/*kernel_trace.csv
 ls -la gpurun_out/r04
 head -c 600 gpurun_out/r04/bench_line.json; echo
