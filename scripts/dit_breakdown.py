@@ -1,7 +1,9 @@
-"""Per-kernel / per-grid breakdown of a rocprofv3 kernel trace of `bench.py --dit-only` (36 NFEs by default)."""
+"""Per-kernel / per-grid breakdown of a rocprofv3 kernel trace of `bench.py --dit-only`.  The number of forwards in the trace is the second
+argument, or (default / "auto") the number of tiled-attention launches / 36 (3 per block x 12 blocks of configs/diffusion.yml)."""
 import csv, collections, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-nfe = float(sys.argv[2]) if len(sys.argv) > 2 else 36.0
+n_attn = sum('attn_xt_kernel' in r['Kernel_Name'] for r in rows)
+nfe = float(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2] != "auto" else (n_attn / 36.0 if n_attn else 36.0)
 
 
 def short_name(n):
@@ -21,4 +23,4 @@ for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
     if sum(v) / nfe / 1e6 > 0.03:
         print(f"{k[0]:28s} grid {k[1]:6d}  n/NFE {len(v) / nfe:6.1f}  avg {sum(v) / len(v) / 1e3:7.1f} us  min {min(v) / 1e3:7.1f}  per NFE {sum(v) / nfe / 1e6:5.2f} ms")
     tot += sum(v); launches += len(v)
-print('sum per NFE %.2f ms, %.0f launches per NFE' % (tot / nfe / 1e6, launches / nfe))
+print('sum per NFE %.2f ms, %.0f launches per NFE (%g forwards in the trace)' % (tot / nfe / 1e6, launches / nfe, nfe))

@@ -19,7 +19,7 @@ python scripts/pmc_sq_summary.py gpurun_out/r04/pmc_raster_sq_summary.txt gpurun
 export GVF_BENCH_DIT_CFG3=0 GVF_BENCH_DIT_INFLIGHT=0 GVF_BENCH_DIT_OTHER_DTYPE=0
 for t in fp16 bf16; do
   GVF_DIT_DTYPE=$t scripts/gpu_profile.sh dit_$t --dit-only > /dev/null 2>&1
-  python scripts/dit_breakdown.py gpurun_out/prof_dit_$t/dit_${t}_kernel_trace.csv 36 > gpurun_out/r04/dit_kernel_breakdown_$t.txt
+  python scripts/dit_breakdown.py gpurun_out/prof_dit_$t/dit_${t}_kernel_trace.csv auto > gpurun_out/r04/dit_kernel_breakdown_$t.txt
   cp gpurun_out/prof_dit_$t/dit_${t}_kernel_stats.csv gpurun_out/r04/dit_kernel_stats_$t.csv
   rm -f gpurun_out/prof_dit_$t/*kernel_trace.csv
 done
