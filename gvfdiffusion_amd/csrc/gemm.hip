@@ -416,6 +416,12 @@ int launch_gemm(const void* A, int lda, const void* W, int ldw, const float* bia
 
 extern "C" int gvf_gemm(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc,
                         int M, int N, int K, int epilogue, const float* gate, int gate_ld, int rows_per_group, void* stream_) {
+    // GVF_GEMM256=1: large plain projections on the 256-wide, one-wave-per-SIMD kernel (csrc/gemm256.hip) once there is a tile per CU.  Off by
+    // default: faster in isolation, not inside the VAE decode (see that file)
+    static const int big_mode = [] { const char* e = getenv("GVF_GEMM256"); return e == nullptr ? 0 : atoi(e); }();
+    if (big_mode != 0 && epilogue == GVF_EPI_STORE_BF16 && (dtype == GVF_DT_BF16 || dtype == GVF_DT_F16) && gvf_gemm256_eligible(M, N, K, lda, ldw, ldc) &&
+        (long long)(M / 256) * (N / 256) >= 256 && A && W && C && ((((uintptr_t)A) | ((uintptr_t)W) | ((uintptr_t)C) | ((uintptr_t)bias)) & 15) == 0)
+        return gvf_gemm256(dtype, A, lda, W, ldw, bias, C, ldc, M, N, K, stream_);
     return GVF_GEMM_DT(dtype, A, lda, W, ldw, bias, C, ldc, M, N, K, epilogue, gate, gate_ld, rows_per_group, nullptr, nullptr, (hipStream_t)stream_);
 }
 

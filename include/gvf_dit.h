@@ -173,6 +173,14 @@ int gvf_attn_varlen_fwd_bf16(const void* q, const void* k, const void* v, void* 
                              const int64_t* o_strides, const float* gamma_q, const float* gamma_k, float scale,
                              void* stream);
 
+/* The plain projection C = r16(A W^T + bias) on 256 x 256 x 64 tiles, one wave per SIMD (csrc/gemm256.hip; opt-in: faster than gvf_gemm's
+ * 128-wide kernel on cache-hot operands, not inside the VAE decode).  gvf_gemm256_eligible: M, N multiples of 256, K of 64, 16-byte rows;
+ * GVF_GEMM256=1 makes gvf_gemm take it for the store epilogue when the output has at least 256 tiles.  A, W, C 16-bit row-major, bias f32 [N]
+ * or null, pointers 16-byte aligned. */
+int gvf_gemm256_eligible(int M, int N, int K, int lda, int ldw, int ldc);
+int gvf_gemm256(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M, int N, int K,
+                void* stream);
+
 /* ---- cross attention against a pre-tiled, step-invariant K/V cache (csrc/attn_xt.hip), head_dim 32 ----------------
  * The two cross attentions of the DiT block (model/dit.py:263-270 -> model/attention/full_attn.py:74-140) read keys /
  * values that depend on the conditions only.  gvf_attn_pack_kv_bf16 stores them ONCE per condition set in the image

@@ -12,6 +12,7 @@ from gvfdiffusion_amd.ops import dit_ops
 from oracle import dit_ref
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
@@ -77,6 +78,35 @@ def test_gemm_epilogues(cuda, M, N, K):
     x = x0.clone()
     dit_ops.gemm_bf16(a, w, bias, x, dit_ops.EPI_RESID_F32)
     assert rel_l2(x, x0 + ref) < 1e-5
+
+
+@pytest.mark.parametrize("lp", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K,has_bias", [(4096, 4096, 768, True), (65536, 256, 64, False), (12288, 2304, 768, False), (256, 768, 128, True)])
+def test_256_wide_projection_kernel_matches_the_128_wide_one(cuda, lp, M, N, K, has_bias):
+    """gvf_gemm256 (csrc/gemm256.hip: 256 x 256 x 64 tiles, one wave per SIMD; opt-in) against gvf_gemm's store epilogue: both round the fp32 sum +
+    bias once, so they differ by the fp32 summation order only -- never more than one 16-bit rounding step, almost always bit-equal; every element
+    written; each XCD mapping covered (N-tiles per XCD: 16 N-tiles; tile rows per XCD: 1 and 9 N-tiles; neither: 1 x 3 tiles).  The operands are
+    views with their own leading dimensions.  Shapes it cannot run are refused."""
+    g = torch.Generator().manual_seed(M + N)
+    abuf = (torch.randn((M, K + 8), generator=g)).to(lp).to(cuda)
+    a = abuf[:, :K]
+    w = (torch.randn((N, K), generator=g) / math.sqrt(K)).to(lp).to(cuda)
+    bias = torch.randn((N,), generator=g).to(cuda) if has_bias else None
+    obuf = torch.full((M, N + 16), float("nan"), dtype=lp, device=cuda)
+    out = obuf[:, :N]
+    dit_ops.gemm256(a, w, bias, out)
+    assert torch.isfinite(out).all() and torch.isnan(obuf[:, N:]).all()
+    rows = torch.randint(0, M, (256,), generator=g).to(cuda)
+    ref = a[rows].float() @ w.float().T + (bias if has_bias else 0.0)
+    assert rel_l2(out[rows], ref) < (2.5e-3 if lp == torch.bfloat16 else 3.5e-4)
+    old = torch.empty((M, N), dtype=lp, device=cuda)
+    dit_ops.gemm(a, w, bias, old, dit_ops.EPI_STORE_BF16)
+    d = (out.float() - old.float()).abs()
+    ulp = out.float().abs() * (2.0 ** -7 if lp == torch.bfloat16 else 2.0 ** -10)
+    assert float((d > 1.01 * ulp + 1e-6).float().mean()) == 0.0
+    assert float((d > 0).float().mean()) < 2e-2
+    with pytest.raises(_lib.GvfError):
+        dit_ops.gemm256(a[:255], w, bias, out[:255])
 
 
 @pytest.mark.parametrize("M,N,K,rpg,affine,adaln", [(512, 384, 512, 256, False, True), (300, 16, 512, 0, True, False), (1024, 1536, 512, 512, True, True),
