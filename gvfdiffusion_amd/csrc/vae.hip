@@ -99,7 +99,10 @@ __global__ __launch_bounds__(256) void query_embed_kernel(const float* __restric
                 e1[i] = acc + sB[c];
                 const int axis = c / (2 * E), j = c - axis * 2 * E;
                 const float p = axis == 0 ? qv[0] : (axis == 1 ? qv[1] : qv[2]);
-                e2[i] = j < E ? sinf(p * sOm[j]) : cosf(p * sOm[j - E]);
+                // PointEmbed's phases are |p omega| <= 0.5 rad (p in [-0.5, 0.5], omega <= 1): the hardware sine / cosine (v_sin_f32 / v_cos_f32 on
+                // the phase in revolutions, ~1e-6 absolute) instead of libm's 25-instruction routines -- the value goes through a LayerNorm and a
+                // 16-bit rounding (2^-9 relative) next
+                e2[i] = j < E ? __sinf(p * sOm[j]) : __cosf(p * sOm[j - E]);
             }
         }
         wave_layernorm(e1, ni, lane, C, eps);
@@ -119,6 +122,64 @@ __global__ __launch_bounds__(256) void query_embed_kernel(const float* __restric
             const int c = lane + 64 * i;
             if (i < ni && c < C) out[row * C + c] = GvfLp<DT>::to16(e1[i]);
         }
+    }
+}
+
+// The same embedding with the Linear's weights in REGISTERS: lane l owns channels l + 64 i, i < NI, and keeps their QD-wide weight rows (NI * QD
+// registers: 168 for the released 768 x 14) across the Gaussians of its wave -- the LDS version pays a ds_read_b32 in front of every one of the
+// NI * QD fused multiply-adds of a Gaussian (1.02 ms for 262 144 Gaussians; the arithmetic alone is a quarter of that).  C = 64 NI, qdim = QD only.
+template <int DT, int NI, int QD>
+__global__ __launch_bounds__(256) void query_embed_reg_kernel(const float* __restrict__ queries, const float* __restrict__ W, const float* __restrict__ bias,
+                                                              const float* __restrict__ omega, unsigned short* __restrict__ out,
+                                                              float* __restrict__ out_embed, long long P, float eps, float eps_pre, int rows_per_wave) {
+    constexpr int C = 64 * NI, E = C / 6;
+    const int lane = threadIdx.x & 63;
+    const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    float w[NI][QD], b[NI], om[NI];
+    int axis[NI];
+    bool is_sin[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int c = lane + 64 * i;
+#pragma unroll
+        for (int k = 0; k < QD; ++k) w[i][k] = W[c * QD + k];
+        b[i] = bias[c];
+        axis[i] = c / (2 * E);
+        const int j = c - axis[i] * 2 * E;
+        is_sin[i] = j < E;
+        om[i] = omega[j < E ? j : j - E];
+    }
+    const long long row_end = (wave_id + 1) * rows_per_wave < P ? (wave_id + 1) * rows_per_wave : P;
+    for (long long row = wave_id * rows_per_wave; row < row_end; ++row) {
+        float qv[QD];
+#pragma unroll
+        for (int k = 0; k < QD; ++k) qv[k] = queries[row * QD + k];
+        float e1[QE_MAXI], e2[QE_MAXI];
+#pragma unroll
+        for (int i = 0; i < QE_MAXI; ++i) {
+            e1[i] = 0.f; e2[i] = 0.f;
+            if (i < NI) {
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < QD; ++k) acc = fmaf(qv[k], w[i < NI ? i : 0][k], acc);
+                e1[i] = acc + b[i < NI ? i : 0];
+                const int ax = axis[i < NI ? i : 0];
+                const float p = ax == 0 ? qv[0] : (ax == 1 ? qv[1] : qv[2]);
+                const float ph = p * om[i < NI ? i : 0];
+                e2[i] = is_sin[i < NI ? i : 0] ? __sinf(ph) : __cosf(ph);
+            }
+        }
+        wave_layernorm(e1, NI, lane, C, eps);
+        wave_layernorm(e2, NI, lane, C, eps);
+#pragma unroll
+        for (int i = 0; i < QE_MAXI; ++i) e1[i] += e2[i];
+        if (out_embed != nullptr) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) out_embed[row * C + lane + 64 * i] = e1[i];
+        }
+        wave_layernorm(e1, NI, lane, C, eps_pre);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) out[row * C + lane + 64 * i] = GvfLp<DT>::to16(e1[i]);
     }
 }
 
@@ -162,6 +223,15 @@ extern "C" int gvf_vae_embed(int dtype, const float* queries, int qdim, const fl
     if (P == 0) return GVF_OK;
     if (!queries || !W || !bias || !omega || !out_bf16) return GVF_EINVAL;
     (void)hipGetLastError();
+    static const int reg_mode = [] { const char* e = getenv("GVF_VAE_EMBED_REG"); return e == nullptr ? 1 : atoi(e); }();
+    if (reg_mode != 0 && C == 768 && qdim == 14) {           // the released width: weights in registers (query_embed_reg_kernel)
+        const int rows_per_wave = 64;
+        const long long waves = (P + rows_per_wave - 1) / rows_per_wave, blocks_r = (waves + 3) / 4;
+        GVF_LP_DISPATCH(dtype, hipLaunchKernelGGL((query_embed_reg_kernel<DT, 12, 14>), dim3((unsigned)blocks_r), dim3(256), 0, (hipStream_t)stream_, queries, W,
+                                                  bias, omega, (unsigned short*)out_bf16, out_embed_f32, (long long)P, eps_embed, eps_prenorm, rows_per_wave));
+        GVF_CHECK_LAUNCH();
+        return GVF_OK;
+    }
     const int rows_per_block = 64;   // amortises the W -> LDS copy (C*qdim floats) over 64 Gaussians
     const size_t smem = ((size_t)C * (qdim | 1) + C + C / 6) * sizeof(float);
     const long long blocks = (P + rows_per_block - 1) / rows_per_block;
