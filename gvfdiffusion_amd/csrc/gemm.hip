@@ -36,6 +36,8 @@ __device__ __forceinline__ float gelu_tanh(float x) {
     return x / (1.0f + __expf(-2.0f * u));
 }
 
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }   // as csrc/vae.hip's geglu kernel
+
 // LDS-DMA of one 16-byte chunk per lane.  Kept out of the kernel template on purpose: with template-dependent
 // arguments clang checks the builtin only at instantiation, where the HOST pass rejects it silently and then emits
 // no stub for the kernel at all (undefined symbol at dlopen).
@@ -282,6 +284,23 @@ __global__ __launch_bounds__(THREADS, BN == 192 ? 3 : (BK == 32 ? 4 : (BM == 64 
         for (int step = 0; step < 4; ++step) {
             const int lr = step * 4 + er;
             const int row = bm + wm * (BM / 2) + i * 16 + lr;
+            if (EPI == GVF_EPI_GEGLU_16) {
+                // the wave's 64 columns are 32 value columns then their 32 gate columns: lanes 0-7 of every 16 pair them up.  Both are rounded to
+                // the operand type first -- the rounding the stored projection would have had -- so the fused result equals gemm + gvf_geglu bit for bit
+                if (ec >= 32 || row >= M || col0 >= N) continue;
+                const float4 va = *reinterpret_cast<const float4*>(&ep[lr * EP_LD + ec]), vg = *reinterpret_cast<const float4*>(&ep[lr * EP_LD + 32 + ec]);
+                float4 bg = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (bias != nullptr) bg = *reinterpret_cast<const float4*>(bias + col0 + 32);
+                const float a4[4] = {va.x + bias4.x, va.y + bias4.y, va.z + bias4.z, va.w + bias4.w};
+                const float g4[4] = {vg.x + bg.x, vg.y + bg.y, vg.z + bg.z, vg.w + bg.w};
+                float o4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o4[e] = LP::from16(LP::to16(a4[e])) * gelu_erf(LP::from16(LP::to16(g4[e])));
+                uint2 w2;
+                w2.x = LP::pack(o4[0], o4[1]); w2.y = LP::pack(o4[2], o4[3]);
+                *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(Cv) + (size_t)row * ldc + ((bn + wn * (BN / 2) + cg * 64) >> 1) + ec) = w2;
+                continue;
+            }
             float4 v = *reinterpret_cast<const float4*>(&ep[lr * EP_LD + ec]);
             v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
             if (row >= M || col0 >= N) continue;
@@ -340,8 +359,10 @@ template <int DT>
 int launch_gemm(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M, int N, int K, int epilogue,
                 const float* gate, int gate_ld, int rows_per_group, float* stats_out, const GemmLnArgs* ln, hipStream_t stream) {
     const bool aln = ln != nullptr;
-    if (M < 0 || N <= 0 || K <= 0 || (K % 32) != 0 || (lda % 8) != 0 || (ldw % 8) != 0 || lda < K || ldw < K || ldc < N)
+    const bool geglu = epilogue == GVF_EPI_GEGLU_16;
+    if (M < 0 || N <= 0 || K <= 0 || (K % 32) != 0 || (lda % 8) != 0 || (ldw % 8) != 0 || lda < K || ldw < K || ldc < (geglu ? N / 2 : N))
         return GVF_EINVAL;
+    if (geglu && ((N % 64) != 0 || (ldc % 4) != 0 || ln != nullptr || (bias != nullptr && (((uintptr_t)bias) & 15) != 0))) return GVF_EINVAL;
     if (M == 0) return GVF_OK;
     if (!A || !W || !C) return GVF_EINVAL;
     if ((((uintptr_t)A) & 15) != 0 || (((uintptr_t)W) & 15) != 0) return GVF_EINVAL;
@@ -380,7 +401,7 @@ int launch_gemm(const void* A, int lda, const void* W, int ldw, const float* bia
     // gains 1.4 % of the step; at B = 3 -- 3456 tiles, tail 37 % of a round -- the wider tile loses 1.7 %.)
     static const int bn192_mode = [] { const char* e = getenv("GVF_GEMM_BN192"); return e == nullptr ? 1 : atoi(e); }();   // 0 off, 1 auto, 2 always
     const int tiles128 = tiles_m * tiles_n, tiles192 = tiles_m * (N / 192), tail128 = tiles128 % 1024, tail192 = tiles192 % 768;
-    const bool wide = !aln && !small && !bk64 && stats_out == nullptr && (N % 192) == 0 && epilogue != GVF_EPI_RESID_F32 &&
+    const bool wide = !aln && !small && !bk64 && !geglu && stats_out == nullptr && (N % 192) == 0 && epilogue != GVF_EPI_RESID_F32 &&
                       bn192_mode != 0 && (bn192_mode == 2 || (tail128 > 0 && tail128 <= 256 && (tail192 == 0 || tail192 > 384)));
     const dim3 grid_w(tiles_m * (N / 192 > 0 ? N / 192 : 1));
     const int tiles_n_w = N / 192;
@@ -400,6 +421,7 @@ int launch_gemm(const void* A, int lda, const void* W, int ldw, const float* bia
     switch (epilogue) {
         case GVF_EPI_STORE_BF16: GVF_GEMM_LAUNCH(GVF_EPI_STORE_BF16) break;
         case GVF_EPI_GELU_BF16: GVF_GEMM_LAUNCH(GVF_EPI_GELU_BF16) break;
+        case GVF_EPI_GEGLU_16: GVF_GEMM_LAUNCH(GVF_EPI_GEGLU_16) break;
         case GVF_EPI_STORE_F32: GVF_GEMM_LAUNCH(GVF_EPI_STORE_F32) break;
         case GVF_EPI_RESID_F32: GVF_GEMM_LAUNCH(GVF_EPI_RESID_F32) break;
         default: return GVF_EINVAL;

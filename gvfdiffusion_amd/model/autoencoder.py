@@ -202,9 +202,8 @@ class GSKLTemporalVariationalAutoEncoder(nn.Module):
         dit_ops.gemm_bf16(ao, *e["out"], x, dit_ops.EPI_RESID_F32)
         hb = torch.empty((M, C), dtype=bf16, device=dev)
         dit_ops.layernorm_modulate_bf16(x, hb, 1e-6)
-        hid = torch.empty((M, 8 * C), dtype=bf16, device=dev)
-        dit_ops.gemm_bf16(hb, *e["fc1"], hid, dit_ops.EPI_STORE_BF16)
-        act = vae_ops.geglu_bf16(hid)
+        act = torch.empty((M, 4 * C), dtype=bf16, device=dev)
+        dit_ops.gemm_bf16(hb, *e["fc1g"], act, dit_ops.EPI_GEGLU_16)            # fc1 + GEGLU in one launch (rows interleaved at pack time)
         dit_ops.gemm_bf16(act, *e["fc2"], x, dit_ops.EPI_RESID_F32)
         xb = dit_ops.cast_pad(x, C, dtype=bf16)
         Dl = self.mean_fc.out_features
@@ -244,12 +243,16 @@ class GSKLTemporalVariationalAutoEncoder(nn.Module):
         def fb(b):
             return None if b is None else b.detach().float().contiguous()
 
+        def glu(lin):                   # GEGLU projection: rows interleaved for the GEMM's EPI_GEGLU_16 epilogue
+            wi, bi = dit_ops.geglu_interleave(lin.weight.detach().float(), None if lin.bias is None else lin.bias.detach().float())
+            return bf(wi), fb(bi)
+
         W = {"ver": ver, "lp": lp, "proj": (bf(self.proj.weight), fb(self.proj.bias)), "layers": []}
         for a, f in self.layers:
             W["layers"].append(dict(
                 qkv=bf(torch.cat([a.fn.to_q.weight, a.fn.to_kv.weight], 0)),
                 out=(bf(a.fn.to_out.weight), fb(a.fn.to_out.bias)),
-                fc1=(bf(f.fn.net[0].weight), fb(f.fn.net[0].bias)),
+                fc1g=glu(f.fn.net[0]),
                 fc2=(bf(f.fn.net[2].weight), fb(f.fn.net[2].bias))))
         d = self.decoder_cross_attn.fn
         W["dec_q"], W["dec_kv"] = bf(d.to_q.weight), bf(d.to_kv.weight)
@@ -259,7 +262,7 @@ class GSKLTemporalVariationalAutoEncoder(nn.Module):
         # encoder half
         c = self.cross_attend_blocks
         W["enc"] = dict(q=bf(c[0].fn.to_q.weight), kv=bf(c[0].fn.to_kv.weight), out=(bf(c[0].fn.to_out.weight), fb(c[0].fn.to_out.bias)),
-                        fc1=(bf(c[1].fn.net[0].weight), fb(c[1].fn.net[0].bias)), fc2=(bf(c[1].fn.net[2].weight), fb(c[1].fn.net[2].bias)),
+                        fc1g=glu(c[1].fn.net[0]), fc2=(bf(c[1].fn.net[2].weight), fb(c[1].fn.net[2].bias)),
                         mean=(bf(self.mean_fc.weight), fb(self.mean_fc.bias)), logvar=(bf(self.logvar_fc.weight), fb(self.logvar_fc.bias)))
         wi = self.input_embedding[0].weight.detach().float()                      # (dim, input_dim = 3): acts on the delta columns
         W["in_w6"] = torch.cat([torch.zeros_like(wi), wi], dim=1).contiguous()     # rows are [xyz | delta]
@@ -285,7 +288,6 @@ class GSKLTemporalVariationalAutoEncoder(nn.Module):
         dit_ops.gemm_bf16(xb, *W["proj"], h, dit_ops.EPI_STORE_F32)
         hb = torch.empty((M, C), dtype=bf16, device=dev)
         qkv = torch.empty((M, 3 * C), dtype=bf16, device=dev)
-        hid = torch.empty((M, 8 * C), dtype=bf16, device=dev)
         act = torch.empty((M, 4 * C), dtype=bf16, device=dev)
         s3 = (L * 3 * C, 0, 3 * C)
         for w in W["layers"]:
@@ -294,8 +296,9 @@ class GSKLTemporalVariationalAutoEncoder(nn.Module):
             dit_ops.attention_bf16(qkv, qkv[:, C:], qkv[:, 2 * C:], hb, BT, 1, L, L, H, s3, s3, s3, (L * C, 0, C), head_dim=d)
             dit_ops.gemm_bf16(hb, *w["out"], h, dit_ops.EPI_RESID_F32)
             dit_ops.layernorm_modulate_bf16(h, hb, 1e-6)
-            dit_ops.gemm_bf16(hb, *w["fc1"], hid, dit_ops.EPI_STORE_BF16)
-            vae_ops.geglu_bf16(hid, act)
+            # fc1 + GEGLU in one launch: the projection's rows are interleaved (32 value rows, their 32 gate rows) when the weights are packed, the
+            # epilogue pairs them up -- bit-identical to the store epilogue + gvf_geglu, without the 6144-wide intermediate (151 MB written and re-read per block)
+            dit_ops.gemm_bf16(hb, *w["fc1g"], act, dit_ops.EPI_GEGLU_16)
             dit_ops.gemm_bf16(act, *w["fc2"], h, dit_ops.EPI_RESID_F32)
         return h
 

@@ -11,7 +11,7 @@ from .. import _lib
 
 _vp, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 
-EPI_STORE_BF16, EPI_GELU_BF16, EPI_STORE_F32, EPI_RESID_F32 = 0, 1, 2, 3
+EPI_STORE_BF16, EPI_GELU_BF16, EPI_STORE_F32, EPI_RESID_F32, EPI_GEGLU_16 = 0, 1, 2, 3, 4
 EPI_STORE_16, EPI_GELU_16 = EPI_STORE_BF16, EPI_GELU_BF16        # (the 16-bit output takes the call's operand type)
 DT_BF16, DT_F16 = 0, 1
 LP_DTYPES = (torch.bfloat16, torch.float16)
@@ -139,6 +139,17 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, epilogue: in
     _lib.check(_lib.lib().gvf_gemm(dt, _p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), M, N, K,
                                    epilogue, _p(gate), gate_ld, rows_per_group, _stream(a)), "gvf_gemm")
     return out
+
+
+def geglu_interleave(w: torch.Tensor, bias: torch.Tensor = None):
+    """Rows of a GEGLU projection [value rows (F) | gate rows (F)] -> 64-row groups of 32 value rows then their 32 gate rows: the order
+    EPI_GEGLU_16 expects (include/gvf_dit.h).  F % 32 == 0.  Returns (w', bias')."""
+    F = w.shape[0] // 2
+    assert w.shape[0] == 2 * F and F % 32 == 0
+    idx = torch.arange(2 * F, device=w.device)
+    blk, r = idx // 64, idx % 64
+    src = torch.where(r < 32, blk * 32 + r, F + blk * 32 + (r - 32))
+    return w[src].contiguous(), (None if bias is None else bias[src].contiguous())
 
 
 def gemm_stats_parts(n: int) -> int:

@@ -33,6 +33,9 @@ extern "C" {
 #define GVF_EPI_GELU_BF16    1   /* C bf16           = gelu_tanh(acc)      (mlp.0)          */
 #define GVF_EPI_STORE_F32    2   /* C f32  [M][ldc]  = acc                                  */
 #define GVF_EPI_RESID_F32    3   /* C f32 (in place) += gate[m / rows_per_group][n] * acc   (gate null -> 1): x = x + g*h */
+#define GVF_EPI_GEGLU_16     4   /* C 16-bit [M][N/2] = r16(v) * gelu_erf(r16(g)): GEGLU (model/autoencoder.py:90-93) of a projection whose rows (and bias)
+                                    come in 64-row groups of 32 value rows then their 32 gate rows (output column 32 b + i <- rows 64 b + i and
+                                    64 b + 32 + i); N % 64 == 0; bit-identical to the store epilogue followed by gvf_geglu */
 
 /* C = A W^T (+bias): A bf16 [M][lda] row-major, W bf16 [N][ldw] row-major (nn.Linear layout),
  * K a multiple of 64 (pad activations and weights), lda/ldw multiples of 8, bias f32 [N] or null.

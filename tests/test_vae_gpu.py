@@ -385,3 +385,25 @@ def test_decode_is_the_same_with_and_without_the_folded_epilogue(cuda, dtype):
     finally:
         del os.environ["GVF_VAE_FOLD"]
     assert float((y1 - y0).abs().max()) < 2e-5 * float(y0.abs().max())
+
+
+@pytest.mark.parametrize("lp", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,F,K", [(300, 96, 64), (12288, 3072, 768), (64, 32, 128)])
+def test_geglu_epilogue_equals_projection_then_geglu(cuda, lp, M, F, K):
+    """EPI_GEGLU_16 on the row-interleaved projection == the store epilogue followed by gvf_geglu, bit for bit: both round value and gate to the
+    operand type before the erf GELU and the product (model/autoencoder.py:90-93 under autocast)."""
+    from gvfdiffusion_amd.ops import dit_ops, vae_ops
+    g = torch.Generator().manual_seed(M + F)
+    a = torch.randn((M, K), generator=g).to(lp).to(cuda)
+    w = (torch.randn((2 * F, K), generator=g) / K ** 0.5)
+    b = torch.randn(2 * F, generator=g)
+    hid = torch.empty((M, 2 * F), dtype=lp, device=cuda)
+    dit_ops.gemm(a, w.to(lp).to(cuda), b.to(cuda), hid, dit_ops.EPI_STORE_BF16)
+    ref = vae_ops.geglu_bf16(hid)
+    wi, bi = dit_ops.geglu_interleave(w, b)
+    out = torch.full((M, F + 8), float("nan"), dtype=lp, device=cuda)
+    dit_ops.gemm(a, wi.to(lp).to(cuda), bi.to(cuda), out[:, :F], dit_ops.EPI_GEGLU_16)
+    assert torch.isnan(out[:, F:]).all()
+    assert torch.equal(out[:, :F], ref)
+    with pytest.raises(Exception):                                # 2F must be a multiple of 64
+        dit_ops.gemm(a, wi[:32].to(lp).to(cuda), None, out[:, :16], dit_ops.EPI_GEGLU_16)
