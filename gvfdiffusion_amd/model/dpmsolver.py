@@ -121,14 +121,54 @@ def model_wrapper(model, noise_schedule, model_type="noise", model_kwargs={}, gu
         return t_continuous
 
     def _coef(fn, t, x):
-        return expand_dims(fn(t).to(device=x.device, dtype=x.dtype), x.dim())
+        """Schedule coefficient at time t as a factor for x.  The schedule tables live on the host and the solver keeps its times there: when all
+        samples of the call share one time (every solver in this file) the coefficient is a python float -- a kernel argument -- and nothing is
+        copied.  (As a one-element DEVICE tensor it cost a pageable host-to-device copy per use, which waits for everything queued before it:
+        the sampler ran in lock-step with the device and the device idled ~0.9 ms per step while the host prepared the next one.)"""
+        v = fn(t)
+        if not v.is_cuda:
+            v = v.reshape(-1)
+            if v.numel() == 1 or bool((v == v[0]).all()):
+                return float(v[0])
+        return expand_dims(v.to(device=x.device, dtype=x.dtype), x.dim())
+
+    _t_dev = {"grid": {}, "pending": None, "ring": None, "next": 0}
 
     def _to_device_tagged(t_host, device):
-        """The model's time input on the device, carrying its host values as a plain attribute: a denoiser that keeps a table of
-        per-timestep quantities (DiT.precompute_modulation) can look the step up without reading the tensor back."""
-        t_dev = t_host.to(device)
-        if not t_host.is_cuda:
-            t_dev.gvf_host_values = tuple(float(v) for v in t_host.reshape(-1))
+        """The model's time input on the device, carrying its host values as a plain attribute (a denoiser that keeps a table of per-timestep
+        quantities -- DiT.precompute_modulation -- can look the step up without reading the tensor back).  No synchronous copy: times announced
+        through prepare_times were uploaded in one piece, any other time goes through a small ring of pinned buffers with an asynchronous copy."""
+        if t_host.is_cuda:
+            return t_host
+        vals = tuple(float(v) for v in t_host.reshape(-1))
+        dev_key = str(torch.device(device))
+        if _t_dev["pending"] is not None and torch.device(device).type == "cuda":      # an announced grid: one upload for all its steps
+            tm, _t_dev["pending"] = _t_dev["pending"], None
+            allt = tm.to(device)
+            _t_dev["grid"] = {}
+            for i in range(tm.numel()):
+                td = allt[i:i + 1]
+                td.gvf_host_values = (float(tm[i]),)
+                _t_dev["grid"][((float(tm[i]),), (1,), dev_key, tm.dtype)] = td
+        hit = _t_dev["grid"].get((vals, tuple(t_host.shape), dev_key, t_host.dtype))
+        if hit is not None:
+            return hit
+        if torch.device(device).type != "cuda":
+            t_dev = t_host.to(device)
+        else:
+            ring = _t_dev["ring"]
+            n = t_host.numel()
+            if ring is None or ring["n"] < n or ring["dtype"] != t_host.dtype:
+                ring = _t_dev["ring"] = {"n": max(n, 8), "dtype": t_host.dtype, "buf": [torch.empty(max(n, 8), dtype=t_host.dtype).pin_memory() for _ in range(64)],
+                                         "ev": [None] * 64}
+            i = _t_dev["next"] = (_t_dev["next"] + 1) % 64
+            if ring["ev"][i] is not None:
+                ring["ev"][i].synchronize()                 # the copy that last read this slot (64 uses ago) has run
+            ring["buf"][i][:n].copy_(t_host.reshape(-1))
+            t_dev = torch.empty(t_host.shape, dtype=t_host.dtype, device=device)
+            t_dev.copy_(ring["buf"][i][:n].view(t_host.shape), non_blocking=True)
+            ev = torch.cuda.Event(); ev.record(); ring["ev"][i] = ev
+        t_dev.gvf_host_values = vals
         return t_dev
 
     def noise_pred_fn(x, t_continuous, cond=None):
@@ -212,6 +252,9 @@ def model_wrapper(model, noise_schedule, model_type="noise", model_kwargs={}, gu
         pre = getattr(model, "precompute_modulation", None)
         if pre is not None:
             pre(get_model_input_time(t_continuous))
+        # ... and the wrapper uploads the grid's model-input times in one piece at the first step (_to_device_tagged) instead of one copy per step
+        if not t_continuous.is_cuda:
+            _t_dev["pending"] = get_model_input_time(t_continuous).reshape(-1).clone()
     model_fn.prepare_times = prepare_times
     return model_fn
 
