@@ -295,7 +295,10 @@ class E2EWorkload:
         ev[3].record()
         torch.cuda.current_stream().synchronize()      # this chain's stream only: another sample may be in flight on its own
         assert out.rgb.shape == (T, 3, S, S)
-        return [ev[i].elapsed_time(ev[i + 1]) for i in range(3)], self.calls["n"], out
+        # NFE as the solver reports it (the reference's count: `order` evaluations per attempted adaptive step); the evaluations actually run can
+        # differ by a few (a rejected step keeps its first evaluation; a speculated one is dropped): self.calls["n"]
+        nfe = self.w.solver.last_nfe if method == "adaptive" and self.w.solver.last_nfe is not None else self.calls["n"]
+        return [ev[i].elapsed_time(ev[i + 1]) for i in range(3)], nfe, out
 
 
 def bench_e2e(dev, P=262_144, S=800, T=24):
@@ -310,7 +313,8 @@ def bench_e2e(dev, P=262_144, S=800, T=24):
         wall = time.perf_counter() - t0
     assert bool(torch.isfinite(out.rgb).all())
     return {"metric": "end-to-end 4D sample (adaptive DPM-Solver -> VAE decode -> 24-frame render), BASELINE configs[3]",
-            "value": round(T / wall, 2), "unit": "frames/s", "wall_ms": round(wall * 1e3, 2), "nfe": nfe,
+            "value": round(T / wall, 2), "unit": "frames/s", "wall_ms": round(wall * 1e3, 2), "nfe": nfe, "model_calls": e.calls["n"],
+            "adaptive_steps": dict(getattr(e.w.solver, "spec_stats", {})),
             "stage_ms": {"sample": round(ms_sample, 2), "vae_decode": round(ms_decode, 2), "render": round(ms_render, 2)},
             "config": {"gaussians": P, "resolution": S, "frames": T, "sampler": "dpmsolver++ adaptive, steps=100, order 2",
                        "dtype": f"{e.w.dtype_name} models (DiT and motion VAE), f32 rasteriser"}}

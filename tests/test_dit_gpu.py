@@ -871,3 +871,31 @@ def test_two_samplers_in_flight_equal_serial_sampling(cuda):
         raise RuntimeError("job failed")
     with pytest.raises(RuntimeError, match="job failed"):
         run_in_flight([jobs[0], boom], cuda, 2)
+
+
+def test_adaptive_solver_speculation_changes_nothing_but_the_call_count(cuda):
+    """DPM_Solver.speculate queues the next step's first evaluation before the host reads the error norm: same samples bit for bit, same reported
+    NFE; model calls = reported NFE - rejected steps (kept evaluations) + dropped speculations."""
+    from gvfdiffusion_amd.model.dpmsolver import NoiseScheduleVP, model_wrapper, DPM_Solver
+    from gvfdiffusion_amd.model.gaussian_diffusion import create_gaussian_diffusion
+    ns = NoiseScheduleVP("discrete", betas=torch.from_numpy(create_gaussian_diffusion(noise_schedule="cosine", predict_type="v").betas))
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn((16, 16), generator=g).to(cuda) * 0.4
+    calls = {"n": 0}
+
+    def net(x, t, **kw):
+        calls["n"] += 1
+        return torch.tanh(x @ w) * (1.0 + 0.001 * t.reshape(-1, 1, 1, 1))
+    xT = torch.randn((1, 3, 40, 16), generator=g).to(cuda)
+    out = {}
+    for spec in (False, True):
+        mf = model_wrapper(net, ns, model_type="v", guidance_type="uncond")
+        solver = DPM_Solver(mf, ns, algorithm_type="dpmsolver++")
+        solver.speculate, solver.verbose = spec, False
+        calls["n"] = 0
+        x0 = solver.sample(xT, steps=100, t_start=1.0, t_end=1 / 1000, order=2, skip_type="time_uniform", method="adaptive")
+        st = solver.spec_stats
+        assert calls["n"] == solver.last_nfe - st["rejected"] + st["dropped"] and solver.last_nfe == 2 * st["steps"]
+        assert (st["speculated"] > 0) == spec
+        out[spec] = (x0, solver.last_nfe)
+    assert torch.equal(out[False][0], out[True][0]) and out[False][1] == out[True][1]
