@@ -202,10 +202,10 @@ class DiT(nn.Module):
         # one launch per sub-layer boundary (csrc/rowblock.hip) where the shapes allow it: 0 = the unfused GEMM / LayerNorm launches
         self.use_rowblock = int(os.environ.get("GVF_DIT_ROWBLOCK", "1")) != 0
         self.weight_prefetch = int(os.environ.get("GVF_DIT_PREFETCH", "1")) != 0
-        # precompute_modulation: OFF by default.  Measured (round 4, gpurun_out/r04i/modtable_ab.txt, three alternating repeats on one box): 5.59-5.71 ms
-        # per step with the table against 5.25-5.34 without -- the step that no longer starts with the two memory-bound launches (59 us) runs
-        # 0.35 ms SLOWER as a whole, with the rows copied in (225 KB) or gathered inside the graph alike.  Kept (exact, tested) behind the switch.
-        self.modulation_table = int(os.environ.get("GVF_DIT_MODTABLE", "0")) != 0
+        # precompute_modulation: on (GVF_DIT_MODTABLE=0 switches it off).  4.84-4.86 ms per step with the table against 4.88-4.89 without (two alternating
+        # repeats on one box).  It first measured 0.35 ms SLOWER (profiles/r04_modtable_ab.txt) -- under the sampler that still ran in lock-step with
+        # the device, which paid the table's host-side lookup on the critical path.
+        self.modulation_table = int(os.environ.get("GVF_DIT_MODTABLE", "1")) != 0
         self.rowblock_tiled_kv = int(os.environ.get("GVF_DIT_TILED_KV", "1")) != 0    # to_qkv's launch writes the attention's K / V^T tiles itself
         # the temporal self attention runs INSIDE the row-block launch between the spatial and the image attention (T | 48): 6 launches per
         # block instead of 8, the qkv / attention-output buffers of the temporal sub-layer never exist

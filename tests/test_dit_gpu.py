@@ -775,7 +775,7 @@ def test_precomputed_modulation_table_changes_nothing(cuda, graph):
     from gvfdiffusion_amd.model.gaussian_diffusion import create_gaussian_diffusion
     g, cfg, sd, model = _load_small(cuda)
     model.enable_graph(graph)
-    model.modulation_table = True               # (off by default: DiT.__init__ has the measurement)
+    model.modulation_table = True               # (the default; GVF_DIT_MODTABLE=0 in the environment would switch it off)
     ns = NoiseScheduleVP("discrete", betas=torch.from_numpy(create_gaussian_diffusion(noise_schedule="cosine", predict_type="v").betas))
     cond = {"cond_images": torch.from_numpy(g["cond_images"]).to(cuda), "static_latent": torch.from_numpy(g["static_latent"]).to(cuda),
             "deformation_position_xyz": torch.from_numpy(g["xyz"]).to(cuda)}
