@@ -250,15 +250,17 @@ class DiT(nn.Module):
     # ---- weight preparation ---------------------------------------------------------------------
     def _param_version(self):
         """(version counter, storage address) of every parameter: what the packed-weight caches and the captured graph are keyed on.  Asked for on
-        every forward, so the parameter LIST is kept (walking the module tree costs 1.4 ms per call, a quarter of a denoise step once the sampler
-        no longer waits for the device) and re-collected every 256 calls in case a Parameter object itself was replaced."""
+        every forward, so the walk over the module tree (1.4 ms per call, a quarter of a denoise step once the sampler no longer waits for the
+        device) is done once: the (module._parameters dict, name) slots are kept and read each time -- an in-place update, a .to() / .half(), a
+        load_state_dict and a Parameter assigned to an existing module all show up at once; a replaced SUBMODULE is picked up when the slots are
+        re-collected (every 256 calls, and whenever the number of modules changes)."""
         d = self.__dict__
-        n = d.get("_plist_calls", 0)
-        pl = d.get("_plist")
-        if pl is None or (n & 255) == 0:
-            pl = d["_plist"] = list(self.parameters())
-        d["_plist_calls"] = n + 1
-        return tuple((p._version, p.data_ptr()) for p in pl)
+        n = d.get("_pslot_calls", 0)
+        slots = d.get("_pslots")
+        if slots is None or (n & 255) == 0:
+            slots = d["_pslots"] = [(m._parameters, k) for m in self.modules() for k, v in m._parameters.items() if v is not None]
+        d["_pslot_calls"] = n + 1
+        return tuple((q._version, q.data_ptr()) for q in (pd[k] for pd, k in slots))
 
     def _weights(self, lp=None):
         lp = self._lp() if lp is None else lp
@@ -450,11 +452,11 @@ class DiT(nn.Module):
         self._mod_table = {"version": (self._param_version(), self._lp()), "rows": {float(v): i for i, v in enumerate(th.tolist())}, "mod": mod,
                            "arange": torch.arange(mod.shape[0], device=dev)}
 
-    def _mod_from_table(self, t, B):
+    def _mod_from_table(self, t, B, pv=None):
         """Row numbers (B,) int64 on the device of this forward's times in the precomputed table, or None (no table / unknown time / no host
         values).  A view of the table's arange for the usual B = 1 and guided B = 3 (equal times) calls: no launch, no host -> device copy."""
         tab, hv = getattr(self, "_mod_table", None), getattr(t, "gvf_host_values", None)
-        if tab is None or hv is None or len(hv) != B or tab["version"] != (self._param_version(), self._lp()):
+        if tab is None or hv is None or len(hv) != B or tab["version"] != (self._param_version() if pv is None else pv, self._lp()):
             return None
         try:
             idx = [tab["rows"][v] for v in hv]
@@ -482,9 +484,10 @@ class DiT(nn.Module):
     @torch.no_grad()
     def _forward_graphed(self, x, t, cond_images, static_latent, deformation_position_xyz=None):
         _lib.require_cuda(x, t, cond_images, static_latent, deformation_position_xyz)
-        mod_rows = self._mod_from_table(t, x.shape[0])       # (looked up from the HOST values the tensor carries: no read-back)
+        pv = self._param_version()                           # once per forward: 0.1-0.4 ms of host time
+        mod_rows = self._mod_from_table(t, x.shape[0], pv)   # (looked up from the HOST values the tensor carries: no read-back)
         t = t.to(x.device)
-        key = (tuple(x.shape), x.dtype, tuple(t.shape), t.dtype, self._param_version(), self._lp(),
+        key = (tuple(x.shape), x.dtype, tuple(t.shape), t.dtype, pv, self._lp(),
                None if mod_rows is None else self._mod_table["mod"].data_ptr())
         conds = (cond_images, static_latent, deformation_position_xyz)
         g = self._graph

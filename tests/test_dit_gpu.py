@@ -899,3 +899,36 @@ def test_adaptive_solver_speculation_changes_nothing_but_the_call_count(cuda):
         assert (st["speculated"] > 0) == spec
         out[spec] = (x0, solver.last_nfe)
     assert torch.equal(out[False][0], out[True][0]) and out[False][1] == out[True][1]
+
+
+def test_graph_and_weight_caches_follow_every_kind_of_weight_change(cuda):
+    """The captured graph and the packed weights are keyed on (version, address) of every parameter, read through kept (module._parameters, name)
+    slots (DiT._param_version): an in-place update, a Parameter ASSIGNED to a module and a replaced SUBMODULE (picked up when the slots are
+    re-collected) must each give the forward of a freshly built model with the same weights."""
+    import copy
+    g, cfg, sd, model = _load_small(cuda)
+    model.enable_graph(True)
+    args = [torch.from_numpy(g[k]).to(cuda) for k in ("x", "t", "cond_images", "static_latent", "xyz")]
+
+    def fresh():
+        from gvfdiffusion_amd.model.dit import DiT
+        m2 = DiT(**cfg)
+        m2.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()}, strict=True)
+        return m2.to(cuda).eval()(*args)
+    y0 = model(*args)
+    assert torch.equal(y0, fresh())
+    with torch.no_grad():
+        model.blocks[0].mlp.mlp[0].weight.mul_(1.5)                                     # in place
+    y1 = model(*args)
+    assert not torch.equal(y1, y0) and torch.equal(y1, fresh())
+    lin = model.blocks[1].spatial_self_attn.to_out
+    lin.weight = torch.nn.Parameter(lin.weight.detach() * 0.5)                           # a new Parameter object in an existing module
+    y2 = model(*args)
+    assert not torch.equal(y2, y1) and torch.equal(y2, fresh())
+    new_mlp = copy.deepcopy(model.blocks[0].mlp)
+    with torch.no_grad():
+        new_mlp.mlp[2].weight.mul_(-1.0)
+    model.blocks[0].mlp = new_mlp                                                        # a replaced submodule: seen at the next re-collection
+    model.__dict__["_pslot_calls"] = 256
+    y3 = model(*args)
+    assert not torch.equal(y3, y2) and torch.equal(y3, fresh())
