@@ -57,7 +57,7 @@ constexpr int TILE = GVF_TILE;
 constexpr int BLEND_THREADS = TILE * TILE;
 constexpr int MAX_SH_COEFFS = 16;
 // The splat record holds the conic PRE-SCALED for the blend: (a, b, c) -> (CONIC_K1 a, CONIC_K2 b, CONIC_K1 c), so that
-//   log2(e) * power = log2(e) * (-0.5 (a dx^2 + c dy^2) - b dx dy) = a' dx^2 + c' dy^2 + b' dx dy
+//   log2(e) * power = log2(e) * (-0.5 (a dx^2 + c dy^2) - b dx dy) = (a' dx + b' dy) dx + c' dy^2
 // is three multiplies and two fmas straight into v_exp_f32 (upstream's form costs nine VALU instructions plus the
 // exp's own log2(e) multiply; the compositing loop is VALU-bound).  Readers that need the conic itself un-scale it.
 constexpr float CONIC_K1 = -0.7213475204444817f;   // -0.5 log2(e)
@@ -66,7 +66,9 @@ constexpr float CONIC_IK1 = -1.3862943611198906f;  // 1 / CONIC_K1 = -2 ln 2
 constexpr float CONIC_IK2 = -0.6931471805599453f;  // 1 / CONIC_K2 = -ln 2
 // exponent (in octaves) of the Gaussian weight at offset (dx, dy) from the splat centre; `power > 0` <=> result > 0
 __device__ __forceinline__ float splat_exponent(float ap, float bp, float cp, float dx, float dy) {
-    return __builtin_fmaf(bp * dx, dy, __builtin_fmaf(cp * dy, dy, (ap * dx) * dx));
+    // (a' dx + b' dy) dx + (c' dy) dy: 3 mul + 2 fma (rounds 1-3 had (a' dx) dx + (c' dy) dy + (b' dx) dy: 4 mul + 2 fma, one more of the ~22 vector
+    // instructions of a compositing step)
+    return __builtin_fmaf(cp * dy, dy, __builtin_fmaf(bp, dy, ap * dx) * dx);
 }
 
 __constant__ float SH_C0 = 0.28209479177387814f;
