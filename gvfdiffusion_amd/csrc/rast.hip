@@ -57,18 +57,42 @@ constexpr int TILE = GVF_TILE;
 constexpr int BLEND_THREADS = TILE * TILE;
 constexpr int MAX_SH_COEFFS = 16;
 // The splat record holds the conic PRE-SCALED for the blend: (a, b, c) -> (CONIC_K1 a, CONIC_K2 b, CONIC_K1 c), so that
-//   log2(e) * power = log2(e) * (-0.5 (a dx^2 + c dy^2) - b dx dy) = (a' dx + b' dy) dx + c' dy^2
-// is three multiplies and two fmas straight into v_exp_f32 (upstream's form costs nine VALU instructions plus the
-// exp's own log2(e) multiply; the compositing loop is VALU-bound).  Readers that need the conic itself un-scale it.
+//   log2(e) * power = log2(e) * (-0.5 (a dx^2 + c dy^2) - b dx dy) = a' dx^2 + c' dy^2 + b' dx dy
+// needs no scaling on its way into v_exp_f32 (upstream's form costs nine VALU instructions plus the exp's own log2(e) multiply; the
+// compositing loop is VALU-bound).  Readers that need the conic itself un-scale it; the compositing kernels factor it (splat_cholesky below).
 constexpr float CONIC_K1 = -0.7213475204444817f;   // -0.5 log2(e)
 constexpr float CONIC_K2 = -1.4426950408889634f;   // -log2(e)
 constexpr float CONIC_IK1 = -1.3862943611198906f;  // 1 / CONIC_K1 = -2 ln 2
 constexpr float CONIC_IK2 = -0.6931471805599453f;  // 1 / CONIC_K2 = -ln 2
-// exponent (in octaves) of the Gaussian weight at offset (dx, dy) from the splat centre; `power > 0` <=> result > 0
-__device__ __forceinline__ float splat_exponent(float ap, float bp, float cp, float dx, float dy) {
-    // (a' dx + b' dy) dx + (c' dy) dy: 3 mul + 2 fma (rounds 1-3 had (a' dx) dx + (c' dy) dy + (b' dx) dy: 4 mul + 2 fma, one more of the ~22 vector
-    // instructions of a compositing step)
-    return __builtin_fmaf(cp * dy, dy, __builtin_fmaf(bp, dy, ap * dx) * dx);
+// The compositing kernels evaluate the exponent from the CHOLESKY factor of the (scaled, negated) conic in tile-relative coordinates:
+//   -power_oct = m11 dx^2 + 2 m12 dx dy + m22 dy^2 = s1^2 + s2^2,   s1 = l11 dx + l12 dy,  s2 = l22 dy,   M = [[-a', -b'/2], [-b'/2, -c']]
+// with dx = xr - px, dy = yr - py (splat centre and pixel relative to the tile origin):  s1 = c1 - l11 px - l12 py,  s2 = c2 - l22 py.
+// Per (pixel, splat) that is 3 fma + 1 mul + 1 fma and the negation rides on v_exp_f32's source modifier -- against 2 subtractions + 5 for the
+// conic form -- and the exponent cannot come out positive, so upstream's `power > 0` test (which only ever fires on rounding noise at the
+// centre of a valid splat) has nothing to do: 3 of the ~21 vector instructions of a compositing step.  |c1|, |c2| stay small because a splat
+// reaches a tile only within ~3 sigma (|c| <~ 3 + 16 / sigma), so the cancellation in s1 costs ~1e-5 of the exponent.  A conic that is not
+// positive definite (NaN / overflowed covariances: upstream composites an indefinite form there) is dropped: its opacity is staged as 0.
+struct SplatChol { float l11, l12, l22, c1, c2; bool ok; };
+__device__ __forceinline__ SplatChol splat_cholesky(float x, float y, float ap, float bp, float cp, float tile_x0, float tile_y0) {
+    SplatChol r;
+    const float m11 = -ap, m12 = -0.5f * bp, m22 = -cp;
+    const float il = __builtin_amdgcn_rsqf(m11);
+    r.l11 = m11 * il;                                   // sqrt(m11)
+    r.l12 = m12 * il;
+    const float d = m22 - r.l12 * r.l12;
+    r.l22 = __builtin_amdgcn_sqrtf(d);
+    r.ok = m11 > 0.0f && d > 0.0f && m11 < __builtin_inff() && d < __builtin_inff();
+    if (!r.ok) { r.l11 = 0.f; r.l12 = 0.f; r.l22 = 0.f; }
+    const float xr = x - tile_x0, yr = y - tile_y0;
+    r.c1 = r.ok ? __builtin_fmaf(r.l11, xr, r.l12 * yr) : 0.f;
+    r.c2 = r.ok ? r.l22 * yr : 0.f;
+    return r;
+}
+// s1^2 + s2^2 = -exponent (octaves) at tile-relative pixel (px, py)
+__device__ __forceinline__ float splat_neg_exponent(float l11, float l12, float l22, float c1, float c2, float px, float py) {
+    const float s1 = __builtin_fmaf(-l11, px, __builtin_fmaf(-l12, py, c1));
+    const float s2 = __builtin_fmaf(-l22, py, c2);
+    return __builtin_fmaf(s2, s2, s1 * s1);
 }
 
 __constant__ float SH_C0 = 0.28209479177387814f;
@@ -1355,6 +1379,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
     int todo = (int)(rng.y - rng.x);
     const uint64_t lt_mask = (1ull << lane) - 1ull;
 
+    const float pxr = pxf - (float)(tx * TILE), pyr = pyf - (float)(ty * TILE);      // tile-relative (exact: small integers + the sub-pixel offset)
     bool done = !inside;
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dacc = 0.f;
 
@@ -1365,10 +1390,11 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
             const float4* rec = splats + 4 * (gbase + id);
             const float4 a = rec[0];
             const float4 c = rec[2];
-            sA[t] = a;
-            sC[t] = make_float4(c.x, c.y, 0.f, 0.f);
             const float4 b = rec[1];
-            sB[t] = b;
+            const SplatChol ch = splat_cholesky(a.x, a.y, a.z, a.w, b.x, (float)(tx * TILE), (float)(ty * TILE));
+            sA[t] = make_float4(ch.l11, ch.l12, ch.l22, ch.c1);
+            sB[t] = make_float4(ch.c2, ch.ok ? b.y : 0.f, b.z, b.w);
+            sC[t] = make_float4(c.x, c.y, 0.f, 0.f);
             sMask[t] = (unsigned char)quadrant_mask(a.x, a.y, a.z, a.w, b.x, b.y, c.z, (float)(tx * TILE), (float)(ty * TILE), subpixel_offset != nullptr);
         }
         __syncthreads();
@@ -1393,10 +1419,9 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
             const float4 a = sA[J];                                                                    \
             const float4 b = sB[J];                                                                    \
             const float2 c = DEPTH ? make_float2(sC[J].x, sC[J].y) : make_float2(sC[J].x, 0.f);        \
-            const float dx = a.x - pxf, dy = a.y - pyf;                                                \
-            const float power = splat_exponent(a.z, a.w, b.x, dx, dy);      /* in octaves */            \
-            const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(power));                     \
-            const bool ok = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);                      \
+            const float npow = splat_neg_exponent(a.x, a.y, a.z, a.w, b.x, pxr, pyr);   /* -exponent in octaves, >= 0 */ \
+            const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(-npow));                     \
+            const bool ok = !done && !(alpha < 1.0f / 255.0f);                                         \
             const float w_raw = alpha * T;                                                             \
             const float test_T = T - w_raw;        /* = T (1 - alpha) up to one rounding; one op less */ \
             const bool stop = ok && test_T < 0.0001f;                                                  \
@@ -1777,6 +1802,8 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_backward_kernel(
     __shared__ float4 sB[BLEND_THREADS];
     __shared__ float2 sC[BLEND_THREADS];
     __shared__ uint32_t sId[BLEND_THREADS];
+    __shared__ float4 sL[BLEND_THREADS];                  // the forward's Cholesky form of the exponent (splat_cholesky): l11, l12, l22, c1
+    __shared__ float sL2[BLEND_THREADS];                  // c2
     __shared__ unsigned char sMask[BLEND_THREADS];
     __shared__ unsigned char sList[4][BLEND_THREADS];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -1802,7 +1829,9 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_backward_kernel(
             const float4 a_ = rec_[0];                                                              \
             const float4 c_ = rec_[2];                                                              \
             const float4 b_ = rec_[1];                                                              \
-            sA[t] = a_; sB[t] = b_; sC[t] = make_float2(c_.x, c_.y); sId[t] = id_;                  \
+            const SplatChol ch_ = splat_cholesky(a_.x, a_.y, a_.z, a_.w, b_.x, (float)(tx * TILE), (float)(ty * TILE));   \
+            sA[t] = a_; sB[t] = make_float4(b_.x, ch_.ok ? b_.y : 0.f, b_.z, b_.w); sC[t] = make_float2(c_.x, c_.y); sId[t] = id_;   \
+            sL[t] = make_float4(ch_.l11, ch_.l12, ch_.l22, ch_.c1); sL2[t] = ch_.c2;               \
             sMask[t] = (unsigned char)quadrant_mask(a_.x, a_.y, a_.z, a_.w, b_.x, b_.y, c_.z, (float)(tx * TILE), (float)(ty * TILE), subpixel_offset != nullptr); \
         }                                                                                           \
         __syncthreads();                                                                            \
@@ -1817,6 +1846,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_backward_kernel(
         }                                                                                           \
         __builtin_amdgcn_wave_barrier();                                                            \
     }
+    const float pxr = pxf - (float)(tx * TILE), pyr = pyf - (float)(ty * TILE);
     // ---- phase A: forward replay
     bool done = !inside;
     float T = 1.0f;
@@ -1828,12 +1858,11 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_backward_kernel(
         for (int jj = 0; jj < n_w; ++jj) {
             if (__all(done)) break;
             const int j = sList[wave][jj];
-            const float4 a = sA[j];
             const float4 b = sB[j];
-            const float dx = a.x - pxf, dy = a.y - pyf;
-            const float power = splat_exponent(a.z, a.w, b.x, dx, dy);
-            const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(power));
-            const bool ok = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+            const float4 L = sL[j];
+            const float npow = splat_neg_exponent(L.x, L.y, L.z, L.w, sL2[j], pxr, pyr);      // the forward's arithmetic: same decisions
+            const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(-npow));
+            const bool ok = !done && !(alpha < 1.0f / 255.0f);
             const float test_T = T - alpha * T;            // the forward's form
             const bool stop = ok && test_T < 0.0001f;
             done = done || stop;
@@ -1869,10 +1898,10 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_backward_kernel(
                 const float4 b = sB[j];
                 const float2 c = sC[j];
                 const float dx = a.x - pxf, dy = a.y - pyf;
-                const float power = splat_exponent(a.z, a.w, b.x, dx, dy);
-                const float G = __builtin_amdgcn_exp2f(power);
+                const float4 L = sL[j];
+                const float G = __builtin_amdgcn_exp2f(-splat_neg_exponent(L.x, L.y, L.z, L.w, sL2[j], pxr, pyr));
                 const float alpha = fminf(0.99f, b.y * G);
-                const bool on = inside && k < last && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+                const bool on = inside && k < last && !(alpha < 1.0f / 255.0f);
                 if (!__any(on)) continue;
                 float g[BWD_ACC];
 #pragma unroll
