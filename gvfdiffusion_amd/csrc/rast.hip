@@ -1359,7 +1359,9 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
     __shared__ float4 sB[BLEND_THREADS];
     __shared__ float4 sC[BLEND_THREADS];                  // {b, depth, -, -}: 16-byte stride like sA / sB, one index shift per splat
     __shared__ unsigned char sMask[BLEND_THREADS];
-    __shared__ unsigned char sList[4][BLEND_THREADS];     // per-wave compacted splat indices of the batch
+    // per-wave compacted list of the batch: the BYTE OFFSET (16 x index) of each kept splat's records, one dword each -- four entries are one
+    // ds_read_b128 whose registers ARE the addresses of the record reads (as byte indices they cost an extract-and-shift per compositing step)
+    __shared__ unsigned sList[4][BLEND_THREADS];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int f = blockIdx.y;
@@ -1407,7 +1409,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
             const int idx = k * GVF_WAVE + lane;
             const bool hit = idx < cnt && ((sMask[idx] >> wave) & 1u);
             const uint64_t bal = __ballot(hit);
-            if (hit) sList[wave][n_w + __popcll(bal & lt_mask)] = (unsigned char)idx;
+            if (hit) sList[wave][n_w + __popcll(bal & lt_mask)] = (unsigned)idx * 16u;
             n_w += __popcll(bal);
         }
         __builtin_amdgcn_wave_barrier();
@@ -1416,9 +1418,10 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
         // arithmetic overlap the first one's serial T update.
 #define GVF_BLEND_STEP(J)                                                                              \
         {                                                                                              \
-            const float4 a = sA[J];                                                                    \
-            const float4 b = sB[J];                                                                    \
-            const float2 c = DEPTH ? make_float2(sC[J].x, sC[J].y) : make_float2(sC[J].x, 0.f);        \
+            const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(sA) + (J));          \
+            const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(sB) + (J));          \
+            const float4 c4_ = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(sC) + (J));        \
+            const float2 c = DEPTH ? make_float2(c4_.x, c4_.y) : make_float2(c4_.x, 0.f);              \
             const float npow = splat_neg_exponent(a.x, a.y, a.z, a.w, b.x, pxr, pyr);   /* -exponent in octaves, >= 0 */ \
             const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(-npow));                     \
             const bool ok = !done && !(alpha < 1.0f / 255.0f);                                         \
@@ -1437,7 +1440,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
         int jj = 0;
         for (; jj + 3 < n_w; jj += 4) {
             if (__all(done)) break;
-            const int j0 = sList[wave][jj], j1 = sList[wave][jj + 1], j2 = sList[wave][jj + 2], j3 = sList[wave][jj + 3];
+            const unsigned j0 = sList[wave][jj], j1 = sList[wave][jj + 1], j2 = sList[wave][jj + 2], j3 = sList[wave][jj + 3];
             GVF_BLEND_STEP(j0)
             GVF_BLEND_STEP(j1)
             GVF_BLEND_STEP(j2)
@@ -1445,7 +1448,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
         }
         for (; jj < n_w; ++jj) {
             if (__all(done)) break;
-            const int j0 = sList[wave][jj];
+            const unsigned j0 = sList[wave][jj];
             GVF_BLEND_STEP(j0)
         }
 #undef GVF_BLEND_STEP
