@@ -88,11 +88,13 @@ __device__ __forceinline__ SplatChol splat_cholesky(float x, float y, float ap, 
     r.c2 = r.ok ? r.l22 * yr : 0.f;
     return r;
 }
-// s1^2 + s2^2 = -exponent (octaves) at tile-relative pixel (px, py)
-__device__ __forceinline__ float splat_neg_exponent(float l11, float l12, float l22, float c1, float c2, float px, float py) {
+// s1^2 + s2^2 - lo = -(exponent + lo) (octaves) at tile-relative pixel (px, py).  lo = 0: minus the exponent itself; lo = log2(opacity): the
+// compositing kernels' form -- alpha = exp2(log2(opacity) + exponent) costs no multiply by the opacity (the constant rides in the first square's
+// fma), and an opacity of 0 (or a dropped splat) is lo = -inf -> alpha = 0.
+__device__ __forceinline__ float splat_neg_exponent(float l11, float l12, float l22, float c1, float c2, float px, float py, float lo = 0.0f) {
     const float s1 = __builtin_fmaf(-l11, px, __builtin_fmaf(-l12, py, c1));
     const float s2 = __builtin_fmaf(-l22, py, c2);
-    return __builtin_fmaf(s2, s2, s1 * s1);
+    return __builtin_fmaf(s2, s2, __builtin_fmaf(s1, s1, -lo));
 }
 
 __constant__ float SH_C0 = 0.28209479177387814f;
@@ -1395,7 +1397,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
             const float4 b = rec[1];
             const SplatChol ch = splat_cholesky(a.x, a.y, a.z, a.w, b.x, (float)(tx * TILE), (float)(ty * TILE));
             sA[t] = make_float4(ch.l11, ch.l12, ch.l22, ch.c1);
-            sB[t] = make_float4(ch.c2, ch.ok ? b.y : 0.f, b.z, b.w);
+            sB[t] = make_float4(ch.c2, ch.ok ? __builtin_amdgcn_logf(b.y) : -__builtin_inff(), b.z, b.w);       // log2(opacity)
             sC[t] = make_float4(c.x, c.y, 0.f, 0.f);
             sMask[t] = (unsigned char)quadrant_mask(a.x, a.y, a.z, a.w, b.x, b.y, c.z, (float)(tx * TILE), (float)(ty * TILE), subpixel_offset != nullptr);
         }
@@ -1422,8 +1424,8 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
             const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(sB) + (J));          \
             const float4 c4_ = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(sC) + (J));        \
             const float2 c = DEPTH ? make_float2(c4_.x, c4_.y) : make_float2(c4_.x, 0.f);              \
-            const float npow = splat_neg_exponent(a.x, a.y, a.z, a.w, b.x, pxr, pyr);   /* -exponent in octaves, >= 0 */ \
-            const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(-npow));                     \
+            const float nlog = splat_neg_exponent(a.x, a.y, a.z, a.w, b.x, pxr, pyr, b.y);   /* -log2(opacity * G) */ \
+            const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(-nlog));                           \
             const bool ok = !done && !(alpha < 1.0f / 255.0f);                                         \
             const float w_raw = alpha * T;                                                             \
             const float test_T = T - w_raw;        /* = T (1 - alpha) up to one rounding; one op less */ \
@@ -1806,7 +1808,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_backward_kernel(
     __shared__ float2 sC[BLEND_THREADS];
     __shared__ uint32_t sId[BLEND_THREADS];
     __shared__ float4 sL[BLEND_THREADS];                  // the forward's Cholesky form of the exponent (splat_cholesky): l11, l12, l22, c1
-    __shared__ float sL2[BLEND_THREADS];                  // c2
+    __shared__ float2 sL2[BLEND_THREADS];                 // c2, log2(opacity)
     __shared__ unsigned char sMask[BLEND_THREADS];
     __shared__ unsigned char sList[4][BLEND_THREADS];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -1834,7 +1836,8 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_backward_kernel(
             const float4 b_ = rec_[1];                                                              \
             const SplatChol ch_ = splat_cholesky(a_.x, a_.y, a_.z, a_.w, b_.x, (float)(tx * TILE), (float)(ty * TILE));   \
             sA[t] = a_; sB[t] = make_float4(b_.x, ch_.ok ? b_.y : 0.f, b_.z, b_.w); sC[t] = make_float2(c_.x, c_.y); sId[t] = id_;   \
-            sL[t] = make_float4(ch_.l11, ch_.l12, ch_.l22, ch_.c1); sL2[t] = ch_.c2;               \
+            sL[t] = make_float4(ch_.l11, ch_.l12, ch_.l22, ch_.c1);                                  \
+            sL2[t] = make_float2(ch_.c2, ch_.ok ? __builtin_amdgcn_logf(b_.y) : -__builtin_inff());  \
             sMask[t] = (unsigned char)quadrant_mask(a_.x, a_.y, a_.z, a_.w, b_.x, b_.y, c_.z, (float)(tx * TILE), (float)(ty * TILE), subpixel_offset != nullptr); \
         }                                                                                           \
         __syncthreads();                                                                            \
@@ -1861,10 +1864,9 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_backward_kernel(
         for (int jj = 0; jj < n_w; ++jj) {
             if (__all(done)) break;
             const int j = sList[wave][jj];
-            const float4 b = sB[j];
             const float4 L = sL[j];
-            const float npow = splat_neg_exponent(L.x, L.y, L.z, L.w, sL2[j], pxr, pyr);      // the forward's arithmetic: same decisions
-            const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(-npow));
+            const float2 L2 = sL2[j];
+            const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(-splat_neg_exponent(L.x, L.y, L.z, L.w, L2.x, pxr, pyr, L2.y)));   // the forward's arithmetic: same decisions
             const bool ok = !done && !(alpha < 1.0f / 255.0f);
             const float test_T = T - alpha * T;            // the forward's form
             const bool stop = ok && test_T < 0.0001f;
@@ -1902,8 +1904,9 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_backward_kernel(
                 const float2 c = sC[j];
                 const float dx = a.x - pxf, dy = a.y - pyf;
                 const float4 L = sL[j];
-                const float G = __builtin_amdgcn_exp2f(-splat_neg_exponent(L.x, L.y, L.z, L.w, sL2[j], pxr, pyr));
-                const float alpha = fminf(0.99f, b.y * G);
+                const float2 L2 = sL2[j];
+                const float G = __builtin_amdgcn_exp2f(-splat_neg_exponent(L.x, L.y, L.z, L.w, L2.x, pxr, pyr));
+                const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(-splat_neg_exponent(L.x, L.y, L.z, L.w, L2.x, pxr, pyr, L2.y)));   // (the forward's alpha)
                 const bool on = inside && k < last && !(alpha < 1.0f / 255.0f);
                 if (!__any(on)) continue;
                 float g[BWD_ACC];
