@@ -1325,9 +1325,12 @@ static int launch_tile_sort(hipStream_t stream, const uint2* ranges, uint64_t* k
 // vector instructions per instance on them; blend 0.87 -> 0.82 ms).  An inexact vertex only LOWERS the value (any t of the interval is a
 // lower bound of a concave function's maximum) by ~qc dt^2 ~ 1e-13 -- against the 0.02-octave margin of the test, i.e. never visibly; the
 // forward and the backward kernel share this function, so they evaluate the same splats.
+// (written with explicit fmas: this file is compiled with -ffp-contract=off for the arithmetic it shares with the oracle, and as separate multiplies
+// and adds the four edges of the four quadrants were 110 of the staging pass's 204 vector instructions per instance; the test has a 0.02-octave
+// margin and is shared by the forward and the backward kernel, so its rounding only has to be the same in both)
 __device__ __forceinline__ float edge_max(float qa, float qb, float qc, float kv, float fixed, float lo, float hi) {
-    const float t = fminf(fmaxf(kv * fixed, lo), hi);
-    return qa * fixed * fixed + (qb * fixed + qc * t) * t;
+    const float t = fminf(fmaxf(kv * fixed, lo), hi);                                   // the vertex of the parabola along the edge, clamped
+    return __builtin_fmaf(__builtin_fmaf(qc, t, qb * fixed), t, (qa * fixed) * fixed);  // qa fixed^2 + (qb fixed + qc t) t
 }
 __device__ __forceinline__ unsigned quadrant_mask(float x, float y, float ap, float bp, float cp, float op, float hx,
                                                   float tile_x0, float tile_y0, bool no_cull) {
@@ -1335,11 +1338,12 @@ __device__ __forceinline__ unsigned quadrant_mask(float x, float y, float ap, fl
     if (no_cull || !(hx < __builtin_inff())) return 0xFu; // sub-pixel offsets / degenerate conic: keep everywhere
     const float lim = -(__log2f(255.0f * op) + 0.02f);
     const float kx = -0.5f * bp * __builtin_amdgcn_rcpf(cp), ky = -0.5f * bp * __builtin_amdgcn_rcpf(ap);   // vertex slopes: dy* = kx dx, dx* = ky dy
+    const float xr = x - tile_x0, yr = y - tile_y0;
     unsigned m = 0u;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const float x0 = tile_x0 + (float)((q & 1) * 8), y0 = tile_y0 + (float)((q >> 1) * 8);
-        const float dxl = x - (x0 + 7.0f), dxh = x - x0, dyl = y - (y0 + 7.0f), dyh = y - y0;   // offset ranges over the quadrant
+        const float ox = (float)((q & 1) * 8), oy = (float)((q >> 1) * 8);
+        const float dxl = xr - (ox + 7.0f), dxh = xr - ox, dyl = yr - (oy + 7.0f), dyh = yr - oy;   // offset ranges over the quadrant
         const bool inside = dxl <= 0.0f && dxh >= 0.0f && dyl <= 0.0f && dyh >= 0.0f;
         float e = edge_max(ap, bp, cp, kx, dxl, dyl, dyh);
         e = fmaxf(e, edge_max(ap, bp, cp, kx, dxh, dyl, dyh));
