@@ -105,6 +105,9 @@
 #define XT_WAVES_PER_SIMD 2
 #endif
 
+#ifdef XT_TIMING
+static long long* g_xt_dbg;           // set by the benchmark before the launch
+#endif
 namespace {
 
 typedef gvf_f32x16 f32x16;
@@ -133,6 +136,9 @@ struct XtParams {
     const float* gamma_q;              // optional MultiHeadRMSNorm gain of q, f32 [H][32]
     int out_f32;                       // out is float (same element strides): the kernel's arithmetic without the output rounding
     const char* pf; long long pf_lines; int pf_iters;      // optional: [pf, pf + 128 pf_lines) is touched once by the launch (see gvf_attn_tiled_fwd_pf)
+#ifdef XT_TIMING
+    long long* dbg;                    // timing builds (scripts/ubench/attn_xt_bench.hip): [workgroup][wave][4] = loop ticks, barrier ticks, tiles, -
+#endif
 };
 
 template <int DT>
@@ -409,6 +415,10 @@ __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
+#ifdef XT_TIMING
+    const long long xt_k0 = (long long)__builtin_amdgcn_s_memtime();
+    long long xt_loop0 = 0, xt_loop1 = 0;
+#endif
 
     int bid = (int)gvf_xcd_remap(blockIdx.x, gridDim.x);
     const int qb = bid % p.q_blocks; bid /= p.q_blocks;
@@ -540,11 +550,25 @@ __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(
             // body is the lane's base plus a constant, the stage test a constant
             constexpr int PER = XT_TPS * XT_NBUF;
 #define XT_RING(p_) (&smem[((p_) % PER) * XT_TILE_CHUNKS])
+#ifdef XT_TIMING
+            long long xt_bar = 0, xt_tiles = 0;
+            const long long xt_t0 = (long long)__builtin_amdgcn_s_memtime();
+            xt_loop0 = xt_t0;
+#endif
             for (; t + PER < T; t += PER) {
+#ifdef XT_TIMING
+                xt_tiles += PER;
+#endif
 #pragma unroll
                 for (int j = 0; j < PER; ++j) {
                     if (!XT_ABL_NOSYNC && (1 + j) % XT_TPS == 0) {
+#ifdef XT_TIMING
+                        const long long b0 = (long long)__builtin_amdgcn_s_memtime();
                         __syncthreads();
+                        xt_bar += (long long)__builtin_amdgcn_s_memtime() - b0;
+#else
+                        __syncthreads();
+#endif
                         const int s2 = (t + j) / XT_TPS + (XT_NBUF - 1);
 #pragma unroll
                         for (int i_ = 0; i_ < XT_TPS; ++i_) {
@@ -561,6 +585,13 @@ __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(
                 }
             }
 #undef XT_RING
+#ifdef XT_TIMING
+            if (lane == 0 && p.dbg != nullptr) {
+                long long* d = p.dbg + ((long long)blockIdx.x * 4 + wave) * 4;
+                xt_loop1 = (long long)__builtin_amdgcn_s_memtime();
+                d[0] = xt_loop1 - xt_t0; d[1] = xt_bar; d[2] = xt_tiles; d[3] = xt_loop0 - xt_k0;
+            }
+#endif
 #endif
             for (; t + 1 < T; ++t) {
                 if (!XT_ABL_NOSYNC && t % XT_TPS == 0) {
@@ -656,6 +687,10 @@ __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(
             *reinterpret_cast<uint2*>(orow + 8 * g + 4 * half) = w;
         }
     }
+#ifdef XT_TIMING
+    if (lane == 0 && p.dbg != nullptr && xt_loop1 != 0)
+        p.dbg[((long long)gridDim.x * 4 + (long long)blockIdx.x * 4 + wave) * 4] = (long long)__builtin_amdgcn_s_memtime() - xt_loop1;
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -792,6 +827,9 @@ extern "C" int gvf_attn_tiled_fwd_pf(int dtype, const void* q, const void* k_til
     p.o_so = o_strides[0]; p.o_si = o_strides[1]; p.o_sl = o_strides[2]; p.o_sh = o_strides[3];
     p.kv_so = kv_set_stride_outer; p.kv_si = kv_set_stride_inner;
     p.fallbacks = fallback_counter;
+#ifdef XT_TIMING
+    p.dbg = g_xt_dbg;
+#endif
     p.gamma_q = gamma_q;
     p.out_f32 = out_is_f32;
     if (prefetch_bytes < 0 || (prefetch_bytes > 0 && !prefetch)) return GVF_EINVAL;
