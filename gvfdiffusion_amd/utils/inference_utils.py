@@ -211,9 +211,10 @@ def render_sample_frames(renderer, gaussian, pred_delta: torch.Tensor, intrinsic
     old_mip = renderer.pipe.use_mip_gaussian
     renderer.pipe.use_mip_gaussian = True                 # inference_utils.py:231
 
+    blocks = renderer.make_frames(ext, K)                 # the cameras' blocks once per sample (cached across samples on the same orbit)
+
     def render(part, cap=None):
-        e = ext[torch.tensor([c for _, c in part], device=dev)]
-        out = renderer.render_frames(gaussian, e, K, delta_pc=pred_delta, delta_index=[t for t, _ in part],
+        out = renderer.render_frames(gaussian, None, None, delta_pc=pred_delta, frames=renderer.frames_with_delta_index(blocks, part),
                                      max_rendered=cap, sync=cap is None)
         frames = frames_to_uint8(out.rgb) if as_uint8 else out.rgb
         if resize_to is not None:

@@ -45,6 +45,24 @@ def test_camera_blocks_are_cached_by_tensor_identity_and_version():
     assert all([b[f].projmatrix[k] for k in range(16)] == [fresh[f].projmatrix[k] for k in range(16)] for f in range(3))
 
 
+def test_schedule_blocks_copied_from_the_orbit_equal_the_ones_built_per_chunk():
+    """The chunked driver builds the orbit's camera blocks once and copies them per (timestep, camera) pair: byte for byte what
+    `make_frames` builds from the gathered cameras with that delta mapping.  Host logic only (no GPU)."""
+    import ctypes
+    from gvfdiffusion_amd.renderers import GaussianRenderer
+    from gvfdiffusion_amd.utils import orbit_cameras
+    rend = GaussianRenderer({"resolution": 64, "near": 0.8, "far": 1.6, "ssaa": 1, "bg_color": (1, 1, 1)})
+    ext = orbit_cameras(5)
+    K = torch.tensor([[1.2, 0.0, 0.5], [0.0, 1.2, 0.5], [0.0, 0.0, 1.0]])
+    blocks = rend.make_frames(ext, K)
+    assert all(b.delta_index == -1 for b in blocks)
+    part = [(2, 4), (0, 1), (7, 1), (3, 0)]
+    got = rend.frames_with_delta_index(blocks, part)
+    want = rend.make_frames(ext[torch.tensor([c for _, c in part])], K, [t for t, _ in part])
+    assert [bytes(g) for g in got] == [bytes(w) for w in want] and ctypes.sizeof(got[0]) == 160
+    assert all(b.delta_index == -1 for b in blocks)                   # the orbit's blocks are templates: untouched
+
+
 @pytest.mark.gpu
 def test_driver_matches_per_frame_renders(cuda):
     from gvfdiffusion_amd.renderers import GaussianRenderer
