@@ -601,6 +601,7 @@ constexpr int SCAN_CHUNK = 4096;
 constexpr int SORT_SMALL_N = 2048;     // size classes of the per-tile sort (R4, below)
 constexpr int SORT_LARGE_N = 16384;
 constexpr int SORT_LARGE_BLOCKS = 256, SORT_HUGE_BLOCKS = 64;   // grid of the launch that walks the two rare classes
+constexpr int SORT_MEDIUM_N = 4096, SORT_MEDIUM_BLOCKS = 768;   // the LDS class's lower half has a launch of its own (tile_sort_kernel<1>)
 __global__ __launch_bounds__(1024) void seg_sums_kernel(const uint32_t* __restrict__ cnt, int n, uint32_t* __restrict__ partial) {
     __shared__ uint32_t wsum[16];
     const int t = threadIdx.x, j0 = blockIdx.x * SCAN_CHUNK + 4 * t;
@@ -1172,12 +1173,12 @@ __global__ __launch_bounds__(256) void classify_kernel(const uint2* __restrict__
     else if (n > (uint32_t)SORT_SMALL_N) cls[2 + atomicAdd(&cls[0], 1u)] = i;
 }
 
-template <int MODE>   // 0: small (registers + shuffles), 1: large (dynamic LDS), 2: huge (global, in place)
-__global__ void tile_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __restrict__ keys,
+template <int MODE>   // 0: small (registers + shuffles), 1: large (dynamic LDS), 2: huge (global, in place), 3: the large class's lower half
+__global__ __launch_bounds__(MODE == 3 ? 512 : 1024, MODE == 3 ? 2 : 1) void tile_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __restrict__ keys,
                                  const uint32_t* __restrict__ vals, uint32_t* __restrict__ ids,
-                                 const uint32_t* __restrict__ cls, uint32_t nseg) {
+                                 const uint32_t* __restrict__ cls, uint32_t nseg, uint32_t split = 0u /*MODE 1: MODE 3 ran too*/) {
     __shared__ uint64_t s_small[MODE == 0 ? SORT_SMALL_N : 1];
-    __shared__ uint32_t s_hist[MODE == 0 ? SORT_SMALL_N + 1 + BKT_AUX : (MODE == 1 ? BKT_LARGE_NB + 1 + BKT_AUX : 1)];
+    __shared__ uint32_t s_hist[MODE == 0 ? SORT_SMALL_N + 1 + BKT_AUX : (MODE == 1 || MODE == 3 ? BKT_LARGE_NB + 1 + BKT_AUX : 1)];
     extern __shared__ __attribute__((aligned(16))) uint64_t s_large[];
     if (MODE == 0) {
         const uint2 rng = ranges[blockIdx.x];
@@ -1230,7 +1231,11 @@ __global__ void tile_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __r
     // rare classes: a small fixed grid walks the lists built by classify_kernel / seg_scan_kernel.  MODE 1 is launched with
     // SORT_LARGE_BLOCKS + SORT_HUGE_BLOCKS blocks: the first take the LDS class (one workgroup per CU: 145 KB of LDS), the rest the
     // global class (one launch for both: at the bench shape they are empty)
-    const bool huge = MODE == 2 || blockIdx.x >= (uint32_t)SORT_LARGE_BLOCKS;
+    // The LDS class is walked by TWO launches over the same list: MODE 3 takes the segments of up to SORT_MEDIUM_N keys with workgroups of
+    // 512 threads and 32 KiB of dynamic LDS, i.e. three per CU (a segment is a chain of ~6 barriers and LDS round trips: the other
+    // workgroups fill one's waits), MODE 1 the rest with 1024 threads and the full 128 KiB.  At 512 x 512 with 262 144 Gaussians
+    // about a fifth of the tiles are in this class (the reference's live render job), at 800 x 800 none.
+    const bool huge = MODE == 2 || (MODE == 1 && blockIdx.x >= (uint32_t)SORT_LARGE_BLOCKS);
     const uint32_t bid = (MODE == 1 && huge) ? blockIdx.x - SORT_LARGE_BLOCKS : blockIdx.x;
     const uint32_t stride = MODE == 1 ? (huge ? (uint32_t)SORT_HUGE_BLOCKS : (uint32_t)SORT_LARGE_BLOCKS) : gridDim.x;
     const uint32_t count = cls[huge ? 1 : 0];
@@ -1239,6 +1244,7 @@ __global__ void tile_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __r
     for (uint32_t li = bid; li < count; li += stride) {
         const uint2 rng = ranges[list[li]];
         const int n = (int)(rng.y - rng.x);
+        if ((MODE == 3 && n > SORT_MEDIUM_N) || (MODE == 1 && !huge && split != 0u && n <= SORT_MEDIUM_N)) continue;   // the other launch's segment
         uint64_t* k = keys + rng.x;
         const uint32_t* v = vals != nullptr ? vals + rng.x : nullptr;
         if (huge) {
@@ -1248,6 +1254,11 @@ __global__ void tile_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __r
             bitonic_sort_asc(k, n, tid, nt);
             for (int i = tid; i < n; i += nt) ids[rng.x + i] = (uint32_t)k[i];
         } else {
+            if (MODE == 3 && SORT_BUCKETS) {             // the distribution sort on 512 threads
+                const bool sorted = tile_sort_buckets<8, 512, BKT_LARGE_NB / 512>(k, v, ids + rng.x, n, s_large, s_hist);
+                __syncthreads();
+                if (sorted) continue;
+            }
             if (MODE == 1 && SORT_BUCKETS) {             // the distribution sort on 1024 threads; false = crowded bucket, take the network
                 bool sorted;
                 if (n <= 4096) sorted = tile_sort_buckets<4, 1024, BKT_LARGE_NB / 1024>(k, v, ids + rng.x, n, s_large, s_hist);
@@ -1291,9 +1302,14 @@ static int launch_tile_sort(hipStream_t stream, const uint2* ranges, uint64_t* k
         hipLaunchKernelGGL(classify_kernel, dim3((nseg + 255) / 256), dim3(256), 0, stream, ranges, nseg, cls);
     hipLaunchKernelGGL(tile_sort_kernel<0>, dim3(nseg), dim3(256), 0, stream, ranges, keys, vals, ids, cls, nseg);
     if (tile_sort_set_lds_limit() != GVF_OK) return GVF_ELAUNCH;
-    // the two rare classes in one launch
+    // the LDS class up to SORT_MEDIUM_N keys: three workgroups of 512 threads per CU (GVF_TILE_SORT_MEDIUM=0: measurement switch)
+    static const bool medium = [] { const char* e = getenv("GVF_TILE_SORT_MEDIUM"); return !(e && e[0] == '0'); }();
+    if (medium)
+        hipLaunchKernelGGL(tile_sort_kernel<3>, dim3(SORT_MEDIUM_BLOCKS), dim3(512), SORT_MEDIUM_N * 8, stream, ranges, keys, vals, ids, cls,
+                           nseg, 0u);
+    // the rest of it and the global class in one launch
     hipLaunchKernelGGL(tile_sort_kernel<1>, dim3(SORT_LARGE_BLOCKS + SORT_HUGE_BLOCKS), dim3(1024), SORT_LARGE_N * 8, stream, ranges, keys,
-                       vals, ids, cls, nseg);
+                       vals, ids, cls, nseg, medium ? 1u : 0u);
     GVF_CHECK_LAUNCH();
     return GVF_OK;
 }

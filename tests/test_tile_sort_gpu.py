@@ -8,7 +8,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 SIZES = [0, 1, 2, 63, 64, 65, 128, 129, 200, 256, 257, 511, 512, 513, 700, 768, 769, 1000, 1024, 1025, 1279, 1280, 1281, 1500,
-         1536, 1537, 2047, 2048, 2049, 5000, 16384, 16385, 20000]
+         1536, 1537, 2047, 2048, 2049, 3000, 4095, 4096, 4097, 5000, 16384, 16385, 20000]
 
 
 def _depths(kind, n, rng):
