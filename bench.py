@@ -335,9 +335,11 @@ def bench_live_render(dev, P=262_144, T=32, V=128, S=512):
     rend.pipe.kernel_size = synthetic.KERNEL_2D
     K, cams = synthetic.intrinsics().to(dev), orbit_cameras(V).to(dev)
 
+    chunk, n_streams = int(os.environ.get("GVF_LIVE_CHUNK", "96")), int(os.environ.get("GVF_LIVE_STREAMS", "2"))   # (the driver's defaults)
+
     def job():
         n, acc = 0, 0
-        for _, frames in render_sample_frames(rend, gm, delta, K, extrinsics=cams, chunk_frames=96, streams=2):
+        for _, frames in render_sample_frames(rend, gm, delta, K, extrinsics=cams, chunk_frames=chunk, streams=n_streams):
             n += frames.shape[0]
             acc += int(frames[0, 0, 0, 0])        # (touch each chunk on the host, as a consumer that writes PNGs would)
         return n
@@ -353,7 +355,7 @@ def bench_live_render(dev, P=262_144, T=32, V=128, S=512):
     return {"metric": "the reference's live render job: one sample = 32 timesteps x 128 orbit cameras x 512x512, SH degree 0, uint8 frames "
                       "(utils/inference_utils.py:240-269) through render_sample_frames",
             "value": round(n / dt, 1), "unit": "frames/s", "ms_per_sample": round(dt * 1e3, 2), "frames": n, "gaussians": P, "resolution": S,
-            "chunk_frames": 96, "chunks_in_flight": 2}
+            "chunk_frames": chunk, "chunks_in_flight": n_streams}
 
 
 def bench_sharded_sampling(dev, dist, rank, world, P, S, T, total_batch=8, steps=32):
