@@ -62,6 +62,13 @@ def test_schedule_blocks_copied_from_the_orbit_equal_the_ones_built_per_chunk():
     assert [bytes(g) for g in got] == [bytes(w) for w in want] and ctypes.sizeof(got[0]) == 160
     assert all(b.delta_index == -1 for b in blocks)                   # the orbit's blocks are templates: untouched
 
+    class _Model:                                                     # render_frames refuses a block that selects a slice delta_pc lacks,
+        _xyz = torch.zeros(4, 3)                                      # before any device work (the C entry point would return GVF_EINVAL)
+    with pytest.raises(ValueError):
+        rend.render_frames(_Model(), None, None, delta_pc=torch.zeros(3, 4, 14), frames=got)     # (7, 1) needs 8 slices
+    with pytest.raises(ValueError):
+        rend.render_frames(_Model(), None, None, delta_pc=None, frames=got[:1])                  # a delta index without deltas
+
 
 @pytest.mark.gpu
 def test_driver_matches_per_frame_renders(cuda):
