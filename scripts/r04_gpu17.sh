@@ -1,5 +1,6 @@
 #!/bin/bash
 # preprocess HOIST variant: parity + A/B (live job, forced off / auto) + headline forced on / auto
+# needs the dropped variant: git apply scripts/patches/r04_pre_hoist.patch (then rebuild); the product does not carry it
 mkdir -p gpurun_out/r04live
 python -m pytest tests/test_rast_gpu.py tests/test_render_driver_gpu.py tests/test_pipeline_gpu.py -m gpu -x -q 2>&1 | tail -3
 GVF_PRE_HOIST=1 python -m pytest tests/test_rast_gpu.py tests/test_render_driver_gpu.py -m gpu -x -q 2>&1 | tail -2
