@@ -1,7 +1,9 @@
 """Swin-style windowed self attention over a SparseTensor
 (model/sparse_attention/windowed_attn.py:20-135): voxels are grouped by (batch, window) after an optional
-shift, attention runs inside each group, results are scattered back.  The partition is built entirely on the
-device (stable sort by window id + run lengths) and cached on the tensor's spatial cache."""
+shift, attention runs inside each group, results are scattered back.  The partition's index work (window ids, stable sort,
+run lengths) runs on the device; its return contract is the reference's -- python lists of window lengths and batch indices --
+so building it reads the device three times (the coordinate maxima, then the two lists).  It is cached on the tensor's spatial
+cache: one build per (tensor layout, window, shift), not per attention call."""
 import math
 from typing import *
 
