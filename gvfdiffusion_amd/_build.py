@@ -121,5 +121,34 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+def build_variant(name: str, defines: dict, verbose: bool = False) -> str:
+    """A/B aid: a second library `variants/libgvf_hip_<name>.so` in which the sources named in `defines` ({"attn_xt.hip": ["-DXT_RING_STAGES=4"],
+    ...}) are compiled with extra flags and every other object is the product's.  Selected at run time with GVF_LIB=<path>
+    (gvfdiffusion_amd/_lib.py), so ONE gpurun call can alternate variants on one box (scripts/gpu_ab.sh); never loaded by default."""
+    build()
+    vdir = os.path.join(OBJ_DIR, "variant_" + name)
+    os.makedirs(vdir, exist_ok=True)
+    os.makedirs(os.path.join(_HERE, "variants"), exist_ok=True)
+    hipcc = _hipcc()
+    objs = []
+    for src, extra in SOURCES.items():
+        obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+        if src in defines:
+            obj = os.path.join(vdir, src.replace(".hip", ".o"))
+            cmd = [hipcc] + COMMON + extra + list(defines[src]) + ["-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        objs.append(obj)
+    out = os.path.join(_HERE, "variants", f"libgvf_hip_{name}.so")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    return out
+
+
 if __name__ == "__main__":
-    print(build(force=False, verbose=True))
+    import sys
+    if len(sys.argv) >= 3 and sys.argv[1] == "--variant":
+        # python -m gvfdiffusion_amd._build --variant ring4 attn_xt.hip=-DXT_RING_STAGES=4 [rast.hip=-DFOO=1,-DBAR=2 ...]
+        print(build_variant(sys.argv[2], {a.split("=", 1)[0]: a.split("=", 1)[1].split(",") for a in sys.argv[3:]}, verbose=True))
+    else:
+        print(build(force=False, verbose=True))

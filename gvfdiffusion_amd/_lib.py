@@ -57,6 +57,7 @@ SIGNATURES = {
     "gvf_gaussian_activate": (_i, [ctypes.POINTER(GvfGaussianActivation), _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                    _vp, _vp, _vp, _vp, _vp, _vp]),
     "gvf_rgb_to_u8": (_i, [_vp, _vp, _i64, _vp]),
+    "gvf_rast_sort_class_counts": (_i, [_vp, _sz, _i, _i, _i, _i, _i64, ctypes.POINTER(ctypes.c_uint32), _vp]),
     "gvf_rast_profile_enable": (_i, [_i]),
     "gvf_rast_profile_read": (_i, [ctypes.POINTER(_f), ctypes.POINTER(_i)]),
     "gvf_sort_tmp_bytes": (_sz, [_i64]),
@@ -99,7 +100,9 @@ def lib():
         # device context and streams.  Loaded the other way round, the process ends up with two HIP
         # runtimes and this library's one reports "no ROCm-capable device".
         import torch  # noqa: F401
-        l = ctypes.CDLL(LIB_PATH)
+        # GVF_LIB=<path>: a variant build of the same sources with other compile-time switches (gvfdiffusion_amd._build.build_variant), for
+        # A/B measurements on one box; it must export the same C ABI (bound below: a missing symbol raises)
+        l = ctypes.CDLL(os.environ.get("GVF_LIB") or LIB_PATH)
         _bind(l, SIGNATURES)
         _LIB = l
     return _LIB

@@ -682,15 +682,12 @@ int launch_kvres(AttnParams p, int H, int n_inner, int n_outer, int max_Lq, int 
     const long long blocks = (long long)p.q_blocks * H * n_inner * n_outer;
     if (blocks > 0x7fffffffLL) return GVF_EINVAL;
     {
-        static std::mutex m;                                                // per instantiation; callers may be on several host threads
-        static bool attr_set = false;
-        std::lock_guard<std::mutex> g(m);
-        if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kvres_kernel<D, VT, DT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)((size_t)RES_MAX_TILES * (KT * Cfg<D>::KC * 16 + res_vt_tile<D>() * 2))) != hipSuccess)
-                return GVF_ELAUNCH;
-            attr_set = true;
-        }
+        static GvfPerDeviceOnce once;                                       // per instantiation and per device (gvf_common.h)
+        if (!gvf_once_per_device(once, [] {
+                return hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kvres_kernel<D, VT, DT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)((size_t)RES_MAX_TILES * (KT * Cfg<D>::KC * 16 + res_vt_tile<D>() * 2))) == hipSuccess;
+            }))
+            return GVF_ELAUNCH;
     }
     hipLaunchKernelGGL((attn_kvres_kernel<D, VT, DT>), dim3((unsigned)blocks), dim3(RES_THREADS), lds, stream, p, qt, tiles_max);
     GVF_CHECK_LAUNCH();

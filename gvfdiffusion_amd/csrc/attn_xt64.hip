@@ -511,6 +511,8 @@ __global__ __launch_bounds__(256) void attn_pack_kv64_kernel(const TIn* __restri
 
 }  // namespace
 
+static bool x64_set_lds_limit();
+
 extern "C" int gvf_attn_pack_kv64(int dtype, const void* kv, int kv_is_f32, int64_t ld, int k_col0, int v_col0, int n_sets, int L, int H,
                                   float k_scale, void* k_tiles, void* v_tiles, void* stream_) {
     if (dtype != GVF_DT_BF16 && dtype != GVF_DT_F16) return GVF_EINVAL;
@@ -524,6 +526,7 @@ extern "C" int gvf_attn_pack_kv64(int dtype, const void* kv, int kv_is_f32, int6
     const int al = kv_is_f32 ? 4 : 8;
     if ((ld % al) || (k_col0 % al) || (v_col0 % al) || (((uintptr_t)kv) & 15)) return GVF_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
+    (void)x64_set_lds_limit();               // eager, outside any capture; the attention launch insists
     (void)hipGetLastError();
     GVF_LP_DISPATCH(dtype,
         if (kv_is_f32)
@@ -536,19 +539,24 @@ extern "C" int gvf_attn_pack_kv64(int dtype, const void* kv, int kv_is_f32, int6
     return GVF_OK;
 }
 
+// The resident key set needs more dynamic LDS than the default limit.  All four instantiations are configured together, once per device
+// (gvf_common.h: the attribute is per device and may not be set during a capture): eagerly from the two pack entry points every caller runs
+// before its first attention launch -- gvf_attn_pack_kv64, gvf_attn_fold_pack -- and again, as a no-op, from the launch itself.
+static bool x64_set_lds_limit() {
+    static GvfPerDeviceOnce once;
+    return gvf_once_per_device(once, [] {
+        const int bytes = (X64_MAX_TILES * X64_TILE + 4 * 512) * 16;
+        const void* fns[4] = {reinterpret_cast<const void*>(&attn_xt64_kernel<GVF_DT_BF16, false>), reinterpret_cast<const void*>(&attn_xt64_kernel<GVF_DT_BF16, true>),
+                              reinterpret_cast<const void*>(&attn_xt64_kernel<GVF_DT_F16, false>), reinterpret_cast<const void*>(&attn_xt64_kernel<GVF_DT_F16, true>)};
+        for (const void* f : fns)
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+        return true;
+    });
+}
+
 template <int DT, bool FOLD>
 static int x64_launch(const X64Params& p, int force_safe, unsigned blocks, size_t lds, hipStream_t stream) {
-    static std::mutex m;                                                // per instantiation; callers may be on several host threads
-    static bool attr_set = false;
-    {
-        std::lock_guard<std::mutex> g(m);
-        if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_xt64_kernel<DT, FOLD>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (X64_MAX_TILES * X64_TILE + 4 * 512) * 16) != hipSuccess)
-                return GVF_ELAUNCH;
-            attr_set = true;
-        }
-    }
+    if (!x64_set_lds_limit()) return GVF_ELAUNCH;
     attn_xt64_kernel<DT, FOLD><<<dim3(blocks), dim3(X64_THREADS), lds, stream>>>(p, force_safe);
     return GVF_OK;
 }
@@ -651,6 +659,7 @@ __global__ __launch_bounds__(256) void x64_fold_reduce_kernel(const float* __res
 extern "C" int gvf_attn_fold_pack(int dtype, const void* w, int ld, int n_out, int H, void* fold_frags, void* stream_) {
     if (dtype != GVF_DT_BF16 && dtype != GVF_DT_F16) return GVF_EINVAL;
     if (!w || !fold_frags || n_out <= 0 || n_out > 16 || H <= 0 || ld < H * 64 || (((uintptr_t)fold_frags) & 15)) return GVF_EINVAL;
+    (void)x64_set_lds_limit();               // eager, outside any capture (see x64_set_lds_limit)
     (void)hipGetLastError();
     x64_pack_fold_kernel<<<dim3((unsigned)H), dim3(256), 0, (hipStream_t)stream_>>>((const unsigned short*)w, ld, n_out, H, (uint4*)fold_frags);
     GVF_CHECK_LAUNCH();

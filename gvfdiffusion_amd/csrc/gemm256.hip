@@ -148,16 +148,12 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256_kernel(const unsigned shor
 
 template <int DT>
 int g2_launch(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M, int N, int K, hipStream_t stream) {
-    static std::mutex m;
-    static bool attr_set = false;
-    {
-        std::lock_guard<std::mutex> g(m);
-        if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G2_STAGE * 16) != hipSuccess)
-                return GVF_ELAUNCH;
-            attr_set = true;
-        }
-    }
+    static GvfPerDeviceOnce once;                                           // per instantiation and per device (gvf_common.h)
+    if (!gvf_once_per_device(once, [] {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G2_STAGE * 16) ==
+                   hipSuccess;
+        }))
+        return GVF_ELAUNCH;
     const int tiles_m = M / G2_T, tiles_n = N / G2_T;
     gemm256_kernel<DT><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(G2_THREADS), 2 * G2_STAGE * 16, stream>>>(
         (const unsigned short*)A, lda, (const unsigned short*)W, ldw, bias, (unsigned short*)C, ldc, K, tiles_m, tiles_n);

@@ -21,6 +21,31 @@
 
 static inline size_t gvf_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// hipFuncSetAttribute is PER DEVICE and illegal during stream capture: a kernel that needs more dynamic LDS than the default limit raises it
+// once per (process, device), under a lock (callers may be on several host threads), from an entry point that runs outside any capture
+// (a pack / workspace-size call) -- and the launch site insists, so a first launch on a second device of the same process is covered too.
+#include <mutex>
+struct GvfPerDeviceOnce {
+    std::mutex m;
+    uint64_t done = 0;              // bit d: device d has been configured
+};
+template <typename F>
+static inline bool gvf_once_per_device(GvfPerDeviceOnce& o, F&& configure) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    std::lock_guard<std::mutex> g(o.m);
+    if (dev >= 0 && dev < 64 && ((o.done >> dev) & 1ull)) return true;
+    if (!configure()) {
+        (void)hipGetLastError();
+        return false;
+    }
+    if (dev >= 0 && dev < 64) o.done |= 1ull << dev;
+    return true;
+}
+
 // Bump allocator over a caller-owned workspace; every carve is 256-byte aligned.
 struct GvfCarver {
     char* base;

@@ -1277,21 +1277,15 @@ __global__ __launch_bounds__(MODE == 3 ? 512 : 1024, MODE == 3 ? 2 : 1) void til
 }
 
 // classify + the three size classes of the per-tile sort over nseg segments (cls: 2 + 2 nseg words of scratch)
-// The large-segment sort class needs more dynamic LDS than the default limit: raise it ONCE per process, under a lock (the rasteriser is
-// called from several host threads: utils/in_flight.py), and from gvf_rast_workspace_bytes too -- every caller sizes its workspace before
-// its first forward, i.e. outside any hipGraph capture, where hipFuncSetAttribute would be illegal.
+// The large-segment sort class needs more dynamic LDS than the default limit: raise it ONCE per (process, device), under a lock (the
+// rasteriser is called from several host threads: utils/in_flight.py), and from gvf_rast_workspace_bytes too -- every caller sizes its
+// workspace before its first forward, i.e. outside any hipGraph capture, where hipFuncSetAttribute would be illegal.
 static int tile_sort_set_lds_limit() {
-    static std::mutex m;
-    static bool done = false;
-    std::lock_guard<std::mutex> g(m);
-    if (done) return GVF_OK;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_sort_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LARGE_N * 8) !=
-        hipSuccess) {
-        (void)hipGetLastError();
-        return GVF_ELAUNCH;
-    }
-    done = true;
-    return GVF_OK;
+    static GvfPerDeviceOnce once;
+    return gvf_once_per_device(once, [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_sort_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LARGE_N * 8) ==
+               hipSuccess;
+    }) ? GVF_OK : GVF_ELAUNCH;
 }
 
 // cls_state: 0 = cls holds nothing (clear + classify here), 1 = the two counters are cleared (classify here), 2 = classified
@@ -1322,9 +1316,21 @@ static int launch_tile_sort(hipStream_t stream, const uint2* ranges, uint64_t* k
 //   * the thread that stages splat j of a 256-splat batch into LDS also computes a 4-bit quadrant mask from
 //     the axis-aligned bounding box of the region where alpha = opacity * exp(power) can reach 1/255
 //     ( ca dx^2 + 2 cb dx dy + cc dy^2 <= 2 ln(255 opacity) ), inflated so that float noise can only keep
-//     extra splats, never drop one (a kept splat is evaluated with exactly the upstream arithmetic, so the
-//     image is unchanged; a culled one would have been skipped by the alpha < 1/255 test for every pixel
-//     of the quadrant);
+//     extra splats, never drop one: the list only decides WHICH (splat, quadrant) pairs are evaluated -- a culled pair
+//     would have failed the alpha < 1/255 test at every pixel of the quadrant, so the image does not depend on it.
+//     A kept splat is evaluated by splat_neg_exponent below, which is NOT upstream's expression since round 4:
+//     upstream forms  power = -0.5 (A dx^2 + C dy^2) - B dx dy  from the pixel offsets and the conic, tests
+//     power > 0, and takes  alpha = min(0.99, opacity * exp(power));  here the exponent comes from the Cholesky
+//     factor of the scaled conic in tile-relative coordinates with log2(opacity) folded in,
+//         alpha = min(0.99, exp2(lo - s1^2 - s2^2)),  s1 = c1 - l11 px - l12 py,  s2 = c2 - l22 py,
+//     i.e. the same quadratic evaluated in another order (~1e-5 of the exponent apart: the cancellation in c - l p
+//     over a tile's 16 pixels), with no `power > 0` case of its own (a sum of squares cannot come out positive;
+//     upstream's test only fires on rounding noise at the centre of a valid splat) and with a conic that is not
+//     positive definite dropped (opacity staged as 0) where upstream composites the indefinite form; the
+//     transmittance update is  T - alpha T  (one fma) for upstream's  T (1 - alpha).  Every one of these stands
+//     between this kernel and the published arithmetic only through oracle/rast_oracle.c, which keeps upstream's
+//     forms: images agree to ~4e-7 except at pixels where a decision sits within that noise of its threshold
+//     (flagged by the oracle);
 //   * each wave compacts the batch into its own index list with wave64 ballots (order preserved = depth
 //     order) and iterates over that list only.  A typical splat (3-sigma radius ~9 px) reaches ~40 % of the
 //     quadrants of the tiles it was binned to, so ~60 % of upstream's (pixel, splat) evaluations disappear.
@@ -1334,8 +1340,9 @@ static int launch_tile_sort(hipStream_t stream, const uint2* ranges, uint64_t* k
 // concave, so its maximum over a rectangle that does not contain the centre sits on one of the four edges, at the
 // clamped vertex of a 1-D parabola.  (The axis-aligned box (hx, hy) that the binning uses keeps ~25 % more pairs: the
 // corners of the box of a rotated, elongated ellipse.)  The test only decides which (splat, quadrant) pairs are
-// evaluated; a kept splat is evaluated with the usual arithmetic and a culled one would have failed alpha >= 1/255 at
-// every pixel of the quadrant (margin: 0.02 octaves on the threshold against ~1e-5 of rounding), so images do not change.
+// evaluated; a kept splat is evaluated by the compositing step's own arithmetic (the Cholesky form described above) and
+// a culled one would have failed alpha >= 1/255 at every pixel of the quadrant (margin: 0.02 octaves on the threshold
+// against ~1e-5 of rounding), so images do not depend on the test.
 // max over t in [lo, hi] of  qa fixed^2 + qb fixed t + qc t^2   (qc < 0), the vertex slope kv = -qb / (2 qc) handed in: one hardware
 // reciprocal per splat and orientation instead of an IEEE division per edge (round 3: the staging loop spent 8 divisions = ~100 of its 265
 // vector instructions per instance on them; blend 0.87 -> 0.82 ms).  An inexact vertex only LOWERS the value (any t of the interval is a
@@ -2400,6 +2407,17 @@ extern "C" int gvf_rast_profile_read(float* ms_sum, int* calls) {
     }
     *calls = n_calls;
     g_prof.calls = 0;
+    return GVF_OK;
+}
+
+extern "C" int gvf_rast_sort_class_counts(const void* workspace, size_t workspace_bytes, int P, int F, int H, int W, int64_t max_rendered,
+                                          uint32_t* counts_host, void* stream) {
+    if (!workspace || !counts_host || H <= 0 || W <= 0 || P < 0 || F <= 0 || max_rendered < 0) return GVF_EINVAL;
+    if ((((uintptr_t)workspace) & 255) != 0) return GVF_EINVAL;
+    Workspace w = carve(const_cast<void*>(workspace), workspace_bytes, P, F, H, W, max_rendered);
+    if (!w.ok) return GVF_ENOSPC;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return GVF_ELAUNCH;
+    if (hipMemcpy(counts_host, w.cls, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) return GVF_ELAUNCH;
     return GVF_OK;
 }
 

@@ -1,6 +1,8 @@
 """Drop-in for the `diff_gaussian_rasterization` package of the mip-splatting fork, as imported by
 the reference at renderers/gaussian_render.py:106 (settings :110-125, call :198-206): same class
 names, same NamedTuple fields (incl. kernel_size, subpixel_offset), returns (color, radii)."""
+import threading
+import weakref
 from typing import NamedTuple
 
 import torch
@@ -27,22 +29,24 @@ class GaussianRasterizationSettings(NamedTuple):
 
 
 _ZERO_SEEN = {}       # id(tensor) -> (weakref, _version, data_ptr, all_zero): one device -> host read per tensor VERSION, not per call
+_ZERO_LOCK = threading.Lock()      # the operator is called from the in-flight worker threads: purge + insert are one critical section
 
 
 def _is_all_zero(t: torch.Tensor) -> bool:
     """`not any(t != 0)` with the host sync paid once per (tensor object, version): a caller that hands the SAME zeros tensor to every call
     (the usual way to satisfy the reference's subpixel_offset argument) pays it once.  A tensor rebuilt per call -- what
     renderers/gaussian_render.py:108 does -- still costs one read-back per call, as the comparison itself would."""
-    import weakref
     k = id(t)
-    hit = _ZERO_SEEN.get(k)
+    with _ZERO_LOCK:
+        hit = _ZERO_SEEN.get(k)
     if hit is not None and hit[0]() is t and hit[1] == t._version and hit[2] == t.data_ptr():
         return hit[3]
-    z = not bool(torch.any(t != 0))
-    if len(_ZERO_SEEN) > 64:
-        for kk in [kk for kk, v in _ZERO_SEEN.items() if v[0]() is None]:
-            del _ZERO_SEEN[kk]
-    _ZERO_SEEN[k] = (weakref.ref(t), t._version, t.data_ptr(), z)
+    z = not bool(torch.any(t != 0))                  # (the device read-back stays outside the lock)
+    with _ZERO_LOCK:
+        if len(_ZERO_SEEN) > 64:
+            for kk in [kk for kk, v in list(_ZERO_SEEN.items()) if v[0]() is None]:
+                del _ZERO_SEEN[kk]
+        _ZERO_SEEN[k] = (weakref.ref(t), t._version, t.data_ptr(), z)
     return z
 
 

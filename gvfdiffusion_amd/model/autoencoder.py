@@ -135,7 +135,7 @@ class GSKLTemporalVariationalAutoEncoder(nn.Module):
         self._wcache = None
         self.compute_dtype = None                    # None: ops/precision.py decides per call (GVF_DIT_DTYPE, an autocast region -- the
                                                      # reference decodes under accelerate's fp16 autocast, inference_dpm_latent.py:256 --, else bf16)
-        self.max_chunk_rows = 1 << 20                # rows (B*T*Pc) of the 16-bit attention-output chunk: 1.5 GiB at dim 768
+        self.max_chunk_rows = (1 << 20) + (1 << 16)  # hard cap on the rows (B*T*Pc) of the 16-bit attention-output chunk: 1.6 GiB at dim 768 (released config: 6 chunks of <= 45056 Gaussians x 24 frames)
 
     def set_compute_dtype(self, dtype):
         """torch.float16 / torch.bfloat16 (or "fp16" / "bf16"): the matrix pipe's operand type; None = ops/precision.py's rule."""
@@ -337,8 +337,11 @@ class GSKLTemporalVariationalAutoEncoder(nn.Module):
         out = torch.empty((B, T, P, self.output_dim), dtype=torch.float32, device=dev)
         # chunks of about max_chunk_rows attention-output rows, all the same size up to the attention's 2048-query workgroups (the released
         # config: 5 x 45056 + 36864 Gaussians; a fixed 43648 left a 256-Gaussian seventh launch pair)
-        n_chunks = max(1, (B * T * P + self.max_chunk_rows // 2) // self.max_chunk_rows)
-        Pc = min(P, ((P + n_chunks - 1) // n_chunks + 2047) // 2048 * 2048)
+        # B * T * Pc <= max_chunk_rows is a CAP (the attention-output / partials buffer it sizes): ceil on the chunk count, and the chunk rounded
+        # UP to the workgroup granularity only while that keeps it under the cap, otherwise down (never below one workgroup's 2048 queries)
+        n_chunks = max(1, -(-(B * T * P) // self.max_chunk_rows))
+        cap = max(2048, self.max_chunk_rows // (B * T) // 2048 * 2048)
+        Pc = min(P, cap, ((P + n_chunks - 1) // n_chunks + 2047) // 2048 * 2048)
         qp3 = qp.view(B, P, C)
         if tiled and self.output_dim <= 16 and os.environ.get("GVF_VAE_FOLD", "1") != "0":
             # to_out o to_outputs applied per head in the attention's epilogue: 16 fp32 partial products per (frame, Gaussian, head) instead of

@@ -206,6 +206,7 @@ class DiT(nn.Module):
         # repeats on one box).  It first measured 0.35 ms SLOWER (profiles/r04_modtable_ab.txt) -- under the sampler that still ran in lock-step with
         # the device, which paid the table's host-side lookup on the critical path.
         self.modulation_table = int(os.environ.get("GVF_DIT_MODTABLE", "1")) != 0
+        self._fallbacks = None         # device int32 (1,): count_attention_fallbacks()
         self.rowblock_tiled_kv = int(os.environ.get("GVF_DIT_TILED_KV", "1")) != 0    # to_qkv's launch writes the attention's K / V^T tiles itself
         # the temporal self attention runs INSIDE the row-block launch between the spatial and the image attention (T | 48): 6 launches per
         # block instead of 8, the qkv / attention-output buffers of the temporal sub-layer never exist
@@ -251,16 +252,21 @@ class DiT(nn.Module):
     def _param_version(self):
         """(version counter, storage address) of every parameter: what the packed-weight caches and the captured graph are keyed on.  Asked for on
         every forward, so the walk over the module tree (1.4 ms per call, a quarter of a denoise step once the sampler no longer waits for the
-        device) is done once: the (module._parameters dict, name) slots are kept and read each time -- an in-place update, a .to() / .half(), a
-        load_state_dict and a Parameter assigned to an existing module all show up at once; a replaced SUBMODULE is picked up when the slots are
-        re-collected (every 256 calls, and whenever the number of modules changes)."""
+        device) is done once: the `_modules` / `_parameters` dicts of the tree are kept and read each time.  An in-place update, a .to() / .half(),
+        a load_state_dict and a Parameter assigned to an existing slot show up in the (version, address) pairs; a replaced, added or removed
+        SUBMODULE, a newly registered parameter and a parameter going from None to a tensor show up in the structural fingerprint (identity of
+        every child in every kept `_modules` dict + the size of every `_parameters` dict; ~30 us), which sends the call back to the full walk."""
         d = self.__dict__
-        n = d.get("_pslot_calls", 0)
-        slots = d.get("_pslots")
-        if slots is None or (n & 255) == 0:
-            slots = d["_pslots"] = [(m._parameters, k) for m in self.modules() for k, v in m._parameters.items() if v is not None]
-        d["_pslot_calls"] = n + 1
-        return tuple((q._version, q.data_ptr()) for q in (pd[k] for pd, k in slots))
+        st = d.get("_pstate")
+        if st is not None:
+            mdicts, pdicts, shape = st
+            if shape != (tuple(id(c) for md in mdicts for c in md.values()), tuple(len(pd) for pd in pdicts)):
+                st = None
+        if st is None:
+            mods = list(self.modules())
+            mdicts, pdicts = [m._modules for m in mods], [m._parameters for m in mods]
+            d["_pstate"] = (mdicts, pdicts, (tuple(id(c) for md in mdicts for c in md.values()), tuple(len(pd) for pd in pdicts)))
+        return tuple((-1, 0) if q is None else (q._version, q.data_ptr()) for pd in pdicts for q in pd.values())
 
     def _weights(self, lp=None):
         lp = self._lp() if lp is None else lp
@@ -462,9 +468,35 @@ class DiT(nn.Module):
             idx = [tab["rows"][v] for v in hv]
         except KeyError:
             return None
+        self.__dict__["mod_table_hits"] = self.__dict__.get("mod_table_hits", 0) + 1      # (read by tests: does a caller's solver reach the table?)
         if all(i == idx[0] for i in idx):
             return tab["arange"][idx[0]:idx[0] + 1].expand(B)
         return tab["arange"][torch.tensor(idx)]
+
+    def count_attention_fallbacks(self, on: bool = True):
+        """Instrument the tiled attention launches (spatial self, image cross, static cross: 3 per block) with the C ABI's `fallback_counter`
+        (include/gvf_dit.h): += 1 per 256-query workgroup whose max-free softmax tripped its range guard and was recomputed on the exact
+        running-maximum path.  The counter's address is part of a captured graph, so switching drops the graph.  Read with
+        attention_fallbacks(); attention_workgroups(B, T, N) is the number of workgroups one forward launches."""
+        if on:
+            dev = next(self.parameters()).device
+            self._fallbacks = torch.zeros(1, dtype=torch.int32, device=dev)
+        else:
+            self._fallbacks = None
+        self._graph = None
+        return self
+
+    def attention_fallbacks(self, reset: bool = True) -> int:
+        """Workgroups that took the exact path since the last reset (one device -> host read)."""
+        if self._fallbacks is None:
+            raise RuntimeError("count_attention_fallbacks() first")
+        n = int(self._fallbacks.item())
+        if reset:
+            self._fallbacks.zero_()
+        return n
+
+    def attention_workgroups(self, B: int, T: int, N: int) -> int:
+        return len(self.blocks) * 3 * B * T * self.num_heads * ((N + 255) // 256)
 
     # ---- forward ------------------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor, t: torch.Tensor, cond_images: torch.Tensor, static_latent: torch.Tensor,
@@ -618,7 +650,7 @@ class DiT(nn.Module):
             # K (RMS-normed, pre-scaled) and V^T of this step's projection into the tiled image, then the tiled-cache kernel
             dit_ops.attention_pack_kv(qkv, B * T, N, H, C, 2 * C, gamma_k=a["gk"], out=kv_self)
             dit_ops.attention_tiled(qkv, kv_self[0], kv_self[1], ab, B * T, 1, N, N, H, (N * 3 * C, 0, 3 * C), (N * C, 0, C), 1, 0,
-                                    gamma_q=a["gq"], bounded=a["bounded"])
+                                    gamma_q=a["gq"], bounded=a["bounded"], fallback_counter=self._fallbacks)
             resid(ab, a["out"], g_s)
             # -- temporal self attention over T (strided views, no transposes)
             if not self.no_temporal_attn:
@@ -632,13 +664,13 @@ class DiT(nn.Module):
             a = b["image_cross_attn"]
             ln_gemm(a["q"], ab, dit_ops.EPI_STORE_16, ln_w=b["n3"][0], ln_b=b["n3"][1])
             kt, vt = ctx["kv_img"][i]
-            dit_ops.attention_tiled(ab, kt, vt, hb, B * T, 1, N, Li, H, (N * C, 0, C), (N * C, 0, C), 1, 0, gamma_q=a["gq"], bounded=a["bounded"])
+            dit_ops.attention_tiled(ab, kt, vt, hb, B * T, 1, N, Li, H, (N * C, 0, C), (N * C, 0, C), 1, 0, gamma_q=a["gq"], bounded=a["bounded"], fallback_counter=self._fallbacks)
             resid(hb, a["out"])
             # -- static cross attention: K/V shared by the T frames of a sample (inner stride 0)
             a = b["static_cross_attn"]
             ln_gemm(a["q"], ab, dit_ops.EPI_STORE_16, ln_w=b["n4"][0], ln_b=b["n4"][1])
             kt, vt = ctx["kv_st"][i]
-            dit_ops.attention_tiled(ab, kt, vt, hb, B, T, N, Ls, H, (TN * C, N * C, C), (TN * C, N * C, C), 1, 0, gamma_q=a["gq"], bounded=a["bounded"])
+            dit_ops.attention_tiled(ab, kt, vt, hb, B, T, N, Ls, H, (TN * C, N * C, C), (TN * C, N * C, C), 1, 0, gamma_q=a["gq"], bounded=a["bounded"], fallback_counter=self._fallbacks)
             resid(hb, a["out"])
             # -- MLP
             ln_gemm(b["fc1"], hidden, dit_ops.EPI_GELU_16, shift=sh_m, scale=sc_m)
@@ -731,11 +763,11 @@ class DiT(nn.Module):
             n3, n4 = dict(ln_w=b["n3"][0], ln_b=b["n3"][1]), dict(ln_w=b["n4"][0], ln_b=b["n4"][1])
             a = b["spatial_self_attn"]
             if tiled_kv:
-                dit_ops.attention_tiled(qs, kv_self[0], kv_self[1], ab, *fr["n"], N, N, H, fr["c"], fr["c"], *fr["kv"], gamma_q=a["gq"], bounded=a["bounded"],
+                dit_ops.attention_tiled(qs, kv_self[0], kv_self[1], ab, *fr["n"], N, N, H, fr["c"], fr["c"], *fr["kv"], gamma_q=a["gq"], bounded=a["bounded"], fallback_counter=self._fallbacks,
                                         prefetch=pf(s["s23"] if (temporal_fused and not self.no_temporal_attn) else s["s2"]))
             else:                                              # (never padded: see _forward)
                 dit_ops.attention_pack_kv(qkv, B * T, N, H, C, 2 * C, gamma_k=a["gk"], out=kv_self)
-                dit_ops.attention_tiled(qkv, kv_self[0], kv_self[1], ab, *fr["n"], N, N, H, fr["c3"], fr["c"], *fr["kv"], gamma_q=a["gq"], bounded=a["bounded"])
+                dit_ops.attention_tiled(qkv, kv_self[0], kv_self[1], ab, *fr["n"], N, N, H, fr["c3"], fr["c"], *fr["kv"], gamma_q=a["gq"], bounded=a["bounded"], fallback_counter=self._fallbacks)
             ai = b["image_cross_attn"]
             if self.no_temporal_attn:
                 fused(ab, s["s2"], b1=a["out"][1], gate1=g_s, ln1=n3, out3=qb, b3=ai["q"][1])
@@ -751,11 +783,11 @@ class DiT(nn.Module):
                     dit_ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], ab, B, N, T, T, H, st, st, st, (TNp * C, C, N * C), at["gq"], at["gk"])
                     fused(ab, s["s3"], b1=at["out"][1], gate1=g_t, ln1=n3, out3=qb, b3=ai["q"][1])
             kt, vt = ctx["kv_img"][i]
-            dit_ops.attention_tiled(qb, kt, vt, hb, *fr["n"], N, Li, H, fr["c"], fr["c"], *fr["kv"], gamma_q=ai["gq"], bounded=ai["bounded"], prefetch=pf(s["s4"]))
+            dit_ops.attention_tiled(qb, kt, vt, hb, *fr["n"], N, Li, H, fr["c"], fr["c"], *fr["kv"], gamma_q=ai["gq"], bounded=ai["bounded"], fallback_counter=self._fallbacks, prefetch=pf(s["s4"]))
             ast = b["static_cross_attn"]
             fused(hb, s["s4"], b1=ai["out"][1], ln1=n4, out3=qb, b3=ast["q"][1])
             kt, vt = ctx["kv_st"][i]
-            dit_ops.attention_tiled(qb, kt, vt, hb, B, T, N, Ls, H, fr_c, fr_c, 1, 0, gamma_q=ast["gq"], bounded=ast["bounded"], prefetch=pf(s["s5"]))
+            dit_ops.attention_tiled(qb, kt, vt, hb, B, T, N, Ls, H, fr_c, fr_c, 1, 0, gamma_q=ast["gq"], bounded=ast["bounded"], fallback_counter=self._fallbacks, prefetch=pf(s["s5"]))
             kw = dict(b1=ast["out"][1], ln1=dict(shift=sh_m, scale=sc_m), mlp_bias=(b["fc1"][1], b["fc2"][1]), hidden=hidden_units, gate_m=g_m)
             if i + 1 < len(blocks):
                 on = offs[i + 1]

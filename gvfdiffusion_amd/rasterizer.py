@@ -273,6 +273,8 @@ def rasterize_batched(settings, frames, act, xyz_raw, features_dc, scaling_raw, 
             ctypes.c_void_p(base), nbytes, cap, _lib.ptr(color), _lib.ptr(alpha), _lib.ptr(depth),
             _lib.ptr(radii), _lib.ptr(nr), _lib.current_stream(dev))
         _lib.check(rc, "gvf_rast_forward_batched")
+        _LAST_CARVE[(dev.index if dev.index is not None else torch.cuda.current_device(), int(torch.cuda.current_stream(dev).cuda_stream))] = \
+            (base, nbytes, P, F, H, W, cap)
         if not sync:
             break
         n = int(nr.to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item())
@@ -284,6 +286,24 @@ def rasterize_batched(settings, frames, act, xyz_raw, features_dc, scaling_raw, 
     if sync:
         _CAP_HINT[key] = cap
     return dict(color=color, alpha=alpha, depth=depth, radii=radii, num_rendered=nr, max_rendered=cap)
+
+
+_LAST_CARVE = {}     # (device index, stream handle) -> the workspace arguments of the last batched call there (sort_class_counts)
+
+
+def sort_class_counts(device=None):
+    """(segments with 2049 .. 16384 keys, segments with more) of the LAST rasterize_batched() call on the current stream: how many
+    (frame, tile) segments went through the per-tile sort's LDS launches / its in-place HBM class (gvf_rast_sort_class_counts; a test
+    diagnostic -- it waits for the stream)."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), int(torch.cuda.current_stream(device).cuda_stream))
+    if key not in _LAST_CARVE:
+        raise _lib.GvfError("no batched rasteriser call on this stream yet")
+    base, nbytes, P, F, H, W, cap = _LAST_CARVE[key]
+    out = (ctypes.c_uint32 * 2)()
+    _lib.check(_lib.lib().gvf_rast_sort_class_counts(ctypes.c_void_p(base), nbytes, P, F, H, W, cap, out, _lib.current_stream(device)),
+               "gvf_rast_sort_class_counts")
+    return int(out[0]), int(out[1])
 
 
 def gaussian_activate(act, xyz_raw, features_dc, scaling_raw, rotation_raw, opacity_raw, delta=None):

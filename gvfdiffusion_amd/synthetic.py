@@ -109,6 +109,47 @@ def dit_state_dict(manifest: dict, seed: int = 0) -> dict:
     return sd
 
 
+def dit_state_dict_trained_like(manifest: dict, seed: int = 0, gamma_lo: float = 0.5, gamma_hi: float = 2.0, cross_gain: float = 1.5,
+                                outlier_gain: float = 2.0) -> dict:
+    """dit_state_dict() pushed towards the score statistics of a TRAINED denoiser (none exists in this environment): the seed-generated
+    weights give every attention near-uniform scores (std ~ 1), which is the friendliest case for the tiled attention's max-free softmax.
+      * every QK-RMSNorm gain (model/attention/modules.py:8-15, `*.q_rms_norm.gamma` / `*.k_rms_norm.gamma`) ~ U[gamma_lo, gamma_hi]: the
+        self attentions' log2-domain scores reach 5.66 * gamma_hi^2 * 1.44, outside the `scores_bounded` promise (fp16 takes its shift);
+      * the cross attentions run WITHOUT RMSNorm at qk_rms_norm_cross=False (modules.py:134-143): their `to_q` and the k half of `to_kv`
+        are scaled by cross_gain each, i.e. scores by cross_gain^2;
+      * heavy tails: per cross attention a rank-one term  outlier_gain * u a^T  is added to `to_q` and  outlier_gain * u b^T  to the k rows of
+        `to_kv` (u: one unit direction per head inside that head's 32 dims, a / b: unit directions of the normalised stream / the context):
+        the score gains  outlier_gain^2 * (a . x)(b . c),  a PRODUCT of two near-normal variables -- most pairs move little, a few (query,
+        key) pairs land tens of octaves out, in any key tile (the values are untouched, so the stream stays O(1))."""
+    sd = dit_state_dict(manifest, seed)
+    for idx, name in enumerate(sorted(sd)):
+        g = torch.Generator().manual_seed(seed * 100003 + 50021 + idx)
+        if name.endswith("rms_norm.gamma"):
+            sd[name] = gamma_lo + (gamma_hi - gamma_lo) * torch.rand(sd[name].shape, generator=g)
+        elif "cross_attn.to_q.weight" in name or "cross_attn.to_kv.weight" in name:
+            w = sd[name]
+            C = w.shape[0] if "to_q" in name else w.shape[0] // 2
+            H = C // 32
+            gu = torch.Generator().manual_seed(seed * 100003 + 70001 + sorted(sd).index(name.replace("to_kv", "to_q")))     # the SAME u for q and k
+            u = torch.nn.functional.normalize(torch.randn((H, 32), generator=gu), dim=-1).reshape(C)
+            d_in = torch.nn.functional.normalize(torch.randn((w.shape[1],), generator=g), dim=0)
+            # x, c have unit-variance components, so a . x and b . c are ~ N(0, 1): extra score = outlier_gain^2 * N * N' (natural-log units)
+            k_rows = w[:C] * cross_gain + (outlier_gain * 32.0 ** 0.25) * torch.outer(u, d_in)
+            sd[name] = k_rows if "to_q" in name else torch.cat([k_rows, w[C:]])          # rows [0, C) = k, [C, 2C) = v   (kv.reshape(B, L, 2, H, d))
+    return sd
+
+
+def dit_inputs_hostile(B: int = 1, T: int = 24, seed: int = 1, token_gain: float = 3.0, **kw) -> dict:
+    """dit_inputs() with a few high-norm context tokens, the artefact tokens a DINOv2 backbone is known for: three image tokens per frame
+    and three static tokens carry token_gain x the typical norm (their keys AND values).  Positions: the first, a middle and the last
+    64-key tile of each context."""
+    inp = dit_inputs(B=B, T=T, seed=seed, **kw)
+    Li, Ls = inp["cond_images"].shape[2], inp["static_latent"].shape[1]
+    inp["cond_images"][:, :, [5, Li // 2 + 15, Li - 3]] *= token_gain
+    inp["static_latent"][:, [17, Ls // 2 + 174, Ls - 96]] *= token_gain
+    return inp
+
+
 def dit_inputs(B: int = 1, T: int = 24, N: int = 512, L_img: int = 1370, L_static: int = 4096, C: int = 16,
                img_channels: int = 1024, static_channels: int = 14, seed: int = 1) -> dict:
     """BASELINE configs[2] inputs: x ~ N(0,1) (B,T,N,16), DINOv2-shaped cond_images (B,T,1370,1024),

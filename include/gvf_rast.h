@@ -197,6 +197,13 @@ int gvf_rgb_to_u8(const float* rgb, uint8_t* out, int64_t n, void* stream);
 int gvf_rast_profile_enable(int on);
 int gvf_rast_profile_read(float* ms_sum /*[GVF_RAST_NSTAGES]*/, int* calls);
 
+/* Diagnostic of the per-tile sort (R4): how many (frame, tile) segments of the LAST gvf_rast_forward*() call on this workspace fell into the
+ * size classes above the one-workgroup register sort -- counts[0]: 2049 .. 16384 keys (the two LDS launches), counts[1]: more than 16384
+ * (sorted in place in HBM).  Takes the arguments the forward call carved its workspace with; waits for `stream` and copies two words to the
+ * host (tests use it to assert that a scene really entered those launches; not on any hot path). */
+int gvf_rast_sort_class_counts(const void* workspace, size_t workspace_bytes, int P, int F, int H, int W, int64_t max_rendered,
+                               uint32_t* counts_host /*[2]*/, void* stream);
+
 /* Library identification: returns a static string "gvf_hip <version> gfx950". */
 const char* gvf_version(void);
 

@@ -178,6 +178,7 @@ def build_chain(args, dev, probe=None):
             if probe is not None:                              # one word per evaluation: where does a run leave its reference?
                 trace.append(y.detach().float().view(torch.int32).sum(dtype=torch.int64))
             return y
+        counted.prepare_times = fn.prepare_times          # the solver announces its time grid through the wrapper it is handed (modulation table, one upload)
         noise = torch.randn((1, T, model_cfg["resolution"], model_cfg["in_channels"]), generator=torch.Generator().manual_seed(args.seed + i)).to(dev)
         solver = DPM_Solver(counted, ns, algorithm_type="dpmsolver++")
         solver.verbose = False          # (not contextlib.redirect_stdout: chain() runs on worker threads with --in_flight > 1, sys.stdout is process-global)
@@ -201,6 +202,7 @@ def build_chain(args, dev, probe=None):
         stats.append((i, nfe["n"], time.perf_counter() - t0))
         return frames
 
+    chain.models = copies              # (tests look at the DiT copies: did the solver's announced grid reach the modulation table?)
     return chain, stats, n_fl
 
 
@@ -215,6 +217,7 @@ def main(argv=None):
     rank, world = D.init_from_env(dev)
     seed_everything(args.seed + rank)
     chain, stats, n_fl = build_chain(args, dev)
+    main.last_chain = chain
 
     t0 = time.perf_counter()
     frames, mine = D.sample_decode_render_sharded(chain, args.num_samples, device=dev, in_flight=n_fl)

@@ -107,6 +107,17 @@ def sdpa_tiled(q, k, v, precision, gamma_k=None):
         # score accumulator's initial value; softmax is shift invariant, only the rounding grid of P moves with it
         s = s - s.amax(dim=-1, keepdim=True)
     p = _r(torch.exp2(s), precision, "attn_pv")
+    # the kernel's range guard: a query whose denominator leaves (2^-100, 2^100) (or is not finite) sends its 256-query workgroup to the exact
+    # running-maximum pass; emulated with the row maximum as the shift (the rounding grid of P moves with the shift, nothing else)
+    l = p.sum(dim=-1)
+    bad = ~((l > 2.0 ** -100) & (l < 2.0 ** 100))
+    if bool(bad.any()):
+        Lq = bad.shape[-1]
+        blocks = (Lq + 255) // 256
+        bad_blk = torch.nn.functional.pad(bad, (0, blocks * 256 - Lq)).reshape(*bad.shape[:-1], blocks, 256).any(dim=-1, keepdim=True)
+        bad = bad_blk.expand(*bad.shape[:-1], blocks, 256).reshape(*bad.shape[:-1], blocks * 256)[..., :Lq]
+        p_exact = _r(torch.exp2(s - s.amax(dim=-1, keepdim=True)), precision, "attn_pv")
+        p = torch.where(bad[..., None], p_exact, p)
     o = (p @ _r(v, precision, "attn_pv")) / p.sum(dim=-1, keepdim=True)
     return _r(o.permute(0, 2, 1, 3), precision, "gemm")
 

@@ -280,6 +280,38 @@ def gen_dit_autocast():
     print("dit_autocast_golden.npz", sorted(out))
 
 
+def gen_dit_hostile():
+    """The full configuration again, on "trained-like" weights and hostile conditions (gvfdiffusion_amd.synthetic.dit_state_dict_trained_like /
+    dit_inputs_hostile: QK-RMSNorm gains in [0.5, 3], cross-attention scores with std ~ 7 octaves, a few high-norm context tokens >= 30
+    octaves out) -- the score statistics the tiled attention's max-free softmax and its fp16 shift have never met on the seed-generated
+    weights.  Holds the reference's fp32 output and the reference's own bf16 / fp16 autocast errors on that model."""
+    import json
+    import time
+    import yaml
+    from model.dit import DiT
+    sys.path.insert(0, os.path.join(OUT, "..", ".."))
+    from gvfdiffusion_amd import synthetic
+    cfg = yaml.safe_load(open(f"{REF}/configs/diffusion.yml"))["model"]
+    man = json.load(open(os.path.join(OUT, "dit_manifest.json")))
+    torch.manual_seed(0)
+    model = DiT(**cfg).eval()
+    model.load_state_dict(synthetic.dit_state_dict_trained_like(man["state_dict"], seed=0))
+    inp = synthetic.dit_inputs_hostile(B=1, T=24, seed=1)
+    kw = dict(cond_images=inp["cond_images"], static_latent=inp["static_latent"], deformation_position_xyz=inp["deformation_position_xyz"])
+    t0 = time.time()
+    with torch.no_grad():
+        y = model(inp["x"], inp["t"], **kw)
+    print("hostile full-config reference forward: %.1f s" % (time.time() - t0), y.shape, float(y.abs().mean()), float(y.std()))
+    out = {"y": y.numpy(), "t": inp["t"].numpy()}
+    for dt, name in ((torch.bfloat16, "bf16"), (torch.float16, "fp16")):
+        t0 = time.time()
+        with torch.no_grad(), torch.autocast("cpu", dtype=dt):
+            ya = model(inp["x"], inp["t"], **kw).float()
+        out[f"rel_l2_{name}"] = np.float64(float((ya - y).norm() / y.norm()))
+        print(f"hostile autocast {name}: rel_l2 vs fp32 {out[f'rel_l2_{name}']:.3e}  ({time.time() - t0:.1f} s)")
+    np.savez_compressed(os.path.join(OUT, "dit_hostile_golden.npz"), **out)
+
+
 def gen_align():
     """utils/inference_utils.py:37-177 align_gaussian_to_canonical, the REFERENCE function, on a stand-in renderer
     (tests/align_util.py: the image an object shows from azimuth index v) with its CLIP term neutralised (constant image
@@ -712,7 +744,7 @@ def gen_sparse_layers():
     print("sparse_layers_golden.npz", {k: v.shape for k, v in out.items()})
 
 
-SECTIONS = {"sparse_layers": gen_sparse_layers, "slat_decoder": gen_slat_decoder, "sparse_vae": gen_sparse_vae, "vae_encode": gen_vae_encode, "vae": gen_vae, "raster": gen_raster, "vox2seq": gen_vox2seq, "dit": gen_dit, "dit_notemporal": gen_dit_notemporal, "dit_autocast": gen_dit_autocast, "align": gen_align, "sampler": gen_sampler, "sparse": gen_sparse}
+SECTIONS = {"sparse_layers": gen_sparse_layers, "slat_decoder": gen_slat_decoder, "sparse_vae": gen_sparse_vae, "vae_encode": gen_vae_encode, "vae": gen_vae, "raster": gen_raster, "vox2seq": gen_vox2seq, "dit": gen_dit, "dit_notemporal": gen_dit_notemporal, "dit_autocast": gen_dit_autocast, "dit_hostile": gen_dit_hostile, "align": gen_align, "sampler": gen_sampler, "sparse": gen_sparse}
 
 if __name__ == "__main__":
     install_stubs()

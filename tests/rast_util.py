@@ -22,6 +22,24 @@ def oracle_render(oracle, attrs, cam, H, W, sh_degree, mode=0, kernel_size=synth
         subpixel_offset=n(subpixel_offset), brute=brute, tight=tight)
 
 
+def cam_from_frame(fr):
+    """The camera dict oracle_render() takes, read back from a GvfRastFrame camera block (what the batched driver hands the kernels)."""
+    return {"viewmatrix": torch.tensor(list(fr.viewmatrix), dtype=torch.float32).reshape(4, 4),
+            "projmatrix": torch.tensor(list(fr.projmatrix), dtype=torch.float32).reshape(4, 4),
+            "campos": torch.tensor(list(fr.campos), dtype=torch.float32), "tanfovx": float(fr.tanfovx), "tanfovy": float(fr.tanfovy)}
+
+
+def oracle_activated(oracle, gm, delta_row, min_kernel_size=synthetic.KERNEL_3D):
+    """GaussianModel.get_*_with_delta on the CPU oracle -> the attribute dict oracle_render() takes."""
+    n = lambda t: None if t is None else t.detach().cpu().numpy()
+    oa = oracle.gaussian_activate(n(gm._xyz), n(gm.get_features), n(gm._scaling), n(gm._rotation), n(gm._opacity), n(delta_row),
+                                  aabb=[-0.5, -0.5, -0.5, 1, 1, 1], scale_bias=float(gm.scale_bias), opacity_bias=float(gm.opacity_bias),
+                                  min_kernel_size=min_kernel_size, scaling_activation=1)
+    attrs = {k: torch.from_numpy(oa[k]) for k in ("means3D", "scales", "rotations", "shs")}
+    attrs["opacities"] = torch.from_numpy(oa["opacities"])
+    return attrs
+
+
 # Tolerance of the rasteriser parity tests (BASELINE.json north_star: "rendered RGBA frames must
 # match ... within 1e-3 max-abs per pixel").
 RAST_ATOL = 1e-3

@@ -173,3 +173,31 @@ def test_two_rank_sharded_sampling_equals_single_process(tmp_path):
     for i in range(total):
         assert np.allclose(sharded[i], single[i], rtol=0, atol=1e-6), i
     assert not np.allclose(single[0], single[1])
+
+
+@pytest.mark.gpu
+def test_bench_n2_line_carries_the_multi_rank_record(tmp_path):
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), on the one-GPU box: the two ranks share
+    the GPU and talk over gloo (GVF_BENCH_BACKEND=gloo, a test aid of bench.py; RCCL needs one GPU per rank), reduced raster size, the full
+    DiT / VAE sharded-sampling leg.  A FUNCTIONAL record of the N > 1 code path -- the per-step frame gather inside the timed region, the
+    batch-sharded sampling of BASELINE configs[4], the max-over-ranks reductions -- not a performance figure: the line must say who took part
+    (`rccl_ranks`, `backend`), carry every rank's own ms per NFE, and the gather's bytes and time."""
+    import json
+    import subprocess
+    env = dict(os.environ, GVF_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--gaussians", "32768", "--res", "256"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                          # rank 0 prints ONE JSON line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["collective"].startswith("every counted sample")
+    assert d["rccl_ranks"] == 2 and d["backend"] == "gloo"
+    assert len(d["per_rank_ms_per_nfe"]) == 2 and all(v > 0 for v in d["per_rank_ms_per_nfe"])
+    e = d["end_to_end"]
+    assert e["samples"] == 8 and e["samples_per_rank"] == 4
+    assert d["gather"]["bytes_per_rank"] == 4 * 24 * 3 * 256 * 256 and d["gather"]["bytes_total"] == 2 * d["gather"]["bytes_per_rank"]
+    assert d["gather"]["us"] > 0 and len(d["gather"]["per_rank_us"]) == 2
+    assert max(e["per_rank"]["ms_per_nfe"]) == pytest.approx(e["ms_per_nfe_slowest_rank"], rel=1e-3)
+    print("bench --gpus 2 over gloo:", json.dumps({k: d[k] for k in ("value", "rccl_ranks", "backend", "per_rank_ms_per_nfe", "gather")}))

@@ -902,9 +902,9 @@ def test_adaptive_solver_speculation_changes_nothing_but_the_call_count(cuda):
 
 
 def test_graph_and_weight_caches_follow_every_kind_of_weight_change(cuda):
-    """The captured graph and the packed weights are keyed on (version, address) of every parameter, read through kept (module._parameters, name)
-    slots (DiT._param_version): an in-place update, a Parameter ASSIGNED to a module and a replaced SUBMODULE (picked up when the slots are
-    re-collected) must each give the forward of a freshly built model with the same weights."""
+    """The captured graph and the packed weights are keyed on (version, address) of every parameter, read through the kept `_parameters` dicts
+    of the module tree (DiT._param_version): an in-place update, a Parameter ASSIGNED to a module and a replaced SUBMODULE (seen at once through
+    the structural fingerprint) must each give the forward of a freshly built model with the same weights."""
     import copy
     g, cfg, sd, model = _load_small(cuda)
     model.enable_graph(True)
@@ -928,7 +928,6 @@ def test_graph_and_weight_caches_follow_every_kind_of_weight_change(cuda):
     new_mlp = copy.deepcopy(model.blocks[0].mlp)
     with torch.no_grad():
         new_mlp.mlp[2].weight.mul_(-1.0)
-    model.blocks[0].mlp = new_mlp                                                        # a replaced submodule: seen at the next re-collection
-    model.__dict__["_pslot_calls"] = 256
+    model.blocks[0].mlp = new_mlp                                                        # a replaced submodule: seen on the very next call
     y3 = model(*args)
     assert not torch.equal(y3, y2) and torch.equal(y3, fresh())

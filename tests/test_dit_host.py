@@ -66,3 +66,40 @@ def test_options_the_reference_cannot_run_are_refused_at_construction():
     for over, word in ((dict(share_mod=True), "model/dit.py:247"), (dict(pe_mode="rope"), "modules.py:36"), (dict(num_heads=1), "head_dim 32")):
         with pytest.raises(NotImplementedError, match=word):
             DiT(**dict(cfg, **over))
+
+
+def test_param_version_sees_every_kind_of_weight_change_on_the_next_call():
+    """DiT._param_version keys the packed-weight caches, the modulation table and the captured graph (the kept slots missed a replaced
+    submodule for up to 255 forwards).  No GPU needed: the key itself must change on the very next call after an in-place update, a Parameter
+    assigned to an existing slot, a replaced / added submodule, a newly registered parameter and a None -> tensor parameter -- and must NOT change
+    when nothing happened."""
+    import copy
+    g = np.load(os.path.join(GOLD, "dit_small_golden.npz"))
+    cfg = json.loads(bytes(g["cfg_json"]).decode())
+    model = DiT(**cfg)
+    seen = [model._param_version()]
+
+    def moved():
+        v = model._param_version()
+        changed = v != seen[-1]
+        seen.append(v)
+        return changed
+    assert not moved() and not moved()
+    with torch.no_grad():
+        model.blocks[0].mlp.mlp[0].weight.mul_(1.5)
+    assert moved() and not moved()
+    lin = model.blocks[1].spatial_self_attn.to_out
+    lin.weight = torch.nn.Parameter(lin.weight.detach() * 0.5)
+    assert moved() and not moved()
+    model.blocks[0].mlp = copy.deepcopy(model.blocks[0].mlp)                   # a replaced submodule (new storage addresses)
+    assert moved() and not moved()
+    lin.bias = None                                                             # a parameter that goes away ...
+    assert moved() and not moved()
+    lin.bias = torch.nn.Parameter(torch.zeros(lin.out_features))                # ... and comes back (None -> tensor)
+    assert moved() and not moved()
+    model.blocks[0].register_parameter("extra_gain", torch.nn.Parameter(torch.ones(3)))
+    assert moved() and not moved()
+    model.blocks[1].add_module("extra", torch.nn.Linear(4, 4))
+    assert moved() and not moved()
+    # and the key is exactly what a full walk gives (slots registered as None are kept as (-1, 0) place holders)
+    assert tuple(e for e in model._param_version() if e != (-1, 0)) == tuple((p._version, p.data_ptr()) for p in model.parameters())
