@@ -65,9 +65,6 @@
 #ifndef XT_ABL_EXPSRC
 #define XT_ABL_EXPSRC 0       // 1: the exponentials read lane constants instead of the score tile (no MFMA -> VALU dependency; scores kept alive)
 #endif
-#ifndef XT_LATE_STAGE
-#define XT_LATE_STAGE 0       // 1: the first two stages are requested after the query fragments are built (the order up to round 3's last session)
-#endif
 #ifndef XT_UNROLL
 #define XT_UNROLL 1           // 1: the steady-state loop is unrolled over one period of the staging ring (TPS * NBUF tiles): ring slots become constants
 #endif
@@ -97,6 +94,10 @@
 #endif
 #ifndef XT_SETPRIO
 #define XT_SETPRIO 0
+#endif
+#ifndef XT_PERSIST
+#define XT_PERSIST 1          // 1: the grid is capped at the resident workgroup count and a workgroup walks several 256-query items, the next
+                              //    item's query rows and first two stages requested under the current item's epilogue; 0: one item per workgroup
 #endif
 #ifndef XT_TILES_PER_STAGE
 #define XT_TILES_PER_STAGE 2  // key tiles staged (and consumed) per workgroup barrier
@@ -130,6 +131,7 @@ struct XtParams {
     const uint4* kt;                   // [set][head][tile][256 chunks]
     const uint4* vt;                   // [set][head][tile][256 chunks]
     int n_outer, n_inner, Lq, Lk, H, q_blocks, n_tiles;
+    int n_items;                       // q_blocks * n_inner * n_outer * H: the units of work the grid's workgroups share out
     long long q_so, q_si, q_sl, q_sh, o_so, o_si, o_sl, o_sh;
     long long kv_so, kv_si;            // K/V set of (outer, inner) = outer * kv_so + inner * kv_si
     int* fallbacks;                    // optional: += 1 per workgroup that took the exact path
@@ -399,10 +401,60 @@ __device__ __forceinline__ void xt_take_shift(f32x16 (&s)[2], f32x16& c) {
     for (int r = 0; r < 16; ++r) { s[0][r] -= m; s[1][r] -= m; c[r] = -m; }
 }
 
+// One unit of work: 256 queries of one (sample, frame, head) against that (set, head)'s tiles.
+struct XtItem {
+    const unsigned short* qp;          // first query row of the (outer, inner, head) slice
+    long long o_off;                   // element offset of the slice in `out` (16-bit and fp32 output alike)
+    const uint4* kbase;
+    const uint4* vbase;
+    int qb, head;
+};
+template <typename P>
+__device__ __forceinline__ XtItem xt_item(const P& p, int bid) {
+    XtItem it;
+    it.qb = bid % p.q_blocks; bid /= p.q_blocks;
+    const int inner = bid % p.n_inner; bid /= p.n_inner;
+    const int outer = bid % p.n_outer;
+    it.head = bid / p.n_outer;
+    it.qp = p.q + outer * p.q_so + inner * p.q_si + it.head * p.q_sh;
+    it.o_off = outer * p.o_so + inner * p.o_si + it.head * p.o_sh;
+    const long long set = outer * p.kv_so + inner * p.kv_si;
+    it.kbase = p.kt + ((set * p.H + it.head) * p.n_tiles) * 256;
+    it.vbase = p.vt + ((set * p.H + it.head) * p.n_tiles) * 256;
+    return it;
+}
+// the wave's two 32-query sub-tiles, RAW: lane (q = l31, half) holds Q[q][16 st + 8 half .. +7]; rows past Lq read row 0 and are zeroed by
+// xt_mask_q where the fragments are formed -- NOT here: an AND on the loaded words right behind the loads makes the compiler wait for them
+// on the spot, and the tail of an item issues these loads precisely so that they fly under its normalisation and stores
+template <typename P>
+__device__ __forceinline__ void xt_load_q(const P& p, const XtItem& it, int wave, int l31, int half, uint4 (&qraw)[2][2]) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int row = it.qb * XT_QB + wave * 64 + a * 32 + l31;
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+            qraw[a][st] = *reinterpret_cast<const uint4*>(it.qp + (long long)(row < p.Lq ? row : 0) * p.q_sl + 16 * st + 8 * half);
+    }
+}
+__device__ __forceinline__ uint4 xt_mask_q(uint4 v4, bool valid) {
+    const unsigned m = valid ? 0xffffffffu : 0u;
+    return make_uint4(v4.x & m, v4.y & m, v4.z & m, v4.w & m);
+}
+
 // SHIFT: the per-query shift of the fp16 path (see xt_take_shift).  false for bf16, and for fp16 when the caller vouches that every score is
 // bounded above (GVF_ATTN_SCORES_BOUNDED: q . k' <= 15.5 in the log2 domain -- RMS-normalised q and k with known gains): P = exp2(s) then
 // fits fp16 by itself, the kernel is the bf16 one with the other MFMA opcode (no 32 splat registers, no shift pass).  A broken
 // promise overflows to inf and lands in the same range guard -> exact fallback.
+//
+// PERSISTENT WORKGROUPS (round 5, XT_PERSIST).  What a 256-query workgroup does BEFORE its loop -- query rows from HBM, the first two
+// stages, the two fill phases: 7-10 k cycles, ~4 k of them memory latency nothing hides at the start of a launch -- is 60 % of the loop time
+// of a spatial-attention workgroup (8 key tiles), 22 % of an image one (22), 8 % of a static one (64): profiles/r04_attn_xt_timing.txt.  The
+// DiT's launches have 768 such items for 512 resident workgroups, so the grid is capped at the resident count and a workgroup walks
+// its items (XCD x owns ONE contiguous range of the item space, its workgroups stride through it -- neighbours in item order share K / V
+// sets, i.e. one L2): the NEXT item's query rows and first two stages are requested as soon as every wave is done with the ring
+// (behind the guard's barriers), i.e. they fly under the current item's normalisation and stores, and the next item starts with its
+// operands on the way instead of with a cold round trip.  A launch with no more items than resident slots is the one-item kernel of
+// round 4, instruction for instruction.
 template <int DT, bool SHIFT>
 __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(XtParams p, int force_safe) {
     typedef GvfLp<DT> LP;
@@ -412,72 +464,99 @@ __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(
     __shared__ uint4 smem[XT_NBUF * XT_TPS * XT_TILE_CHUNKS + 1 + XT_ABL_LDSPAD + (XT_Q_LDS ? XT_THREADS * 4 : 0) + XT_PF_CHUNKS];
     volatile int* s_bad = reinterpret_cast<volatile int*>(&smem[XT_NBUF * XT_TPS * XT_TILE_CHUNKS]);
 
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int half = lane >> 5, l31 = lane & 31;
+    const int tid0 = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
 #ifdef XT_TIMING
     const long long xt_k0 = (long long)__builtin_amdgcn_s_memtime();
     long long xt_loop0 = 0, xt_loop1 = 0;
+    long long xs[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // stamps around the FIRST item boundary of the workgroup (see the benchmark's printout)
+    int xt_item_no = 0;
+#define XT_STAMP(k_, cond_) if (cond_) xs[k_] = (long long)__builtin_amdgcn_s_memtime();
+#else
+#define XT_STAMP(k_, cond_)
 #endif
 
-    int bid = (int)gvf_xcd_remap(blockIdx.x, gridDim.x);
-    const int qb = bid % p.q_blocks; bid /= p.q_blocks;
-    const int inner = bid % p.n_inner; bid /= p.n_inner;
-    const int outer = bid % p.n_outer, head = bid / p.n_outer;
-
-    const unsigned short* qp = p.q + outer * p.q_so + inner * p.q_si + head * p.q_sh;
-    unsigned short* op = p.out + outer * p.o_so + inner * p.o_si + head * p.o_sh;
-    const long long set = outer * p.kv_so + inner * p.kv_si;
-    const uint4* kbase = p.kt + ((set * p.H + head) * p.n_tiles) * 256;
-    const uint4* vbase = p.vt + ((set * p.H + head) * p.n_tiles) * 256;
+    // ---- the items of this workgroup: XCD (blockIdx.x & 7) owns items [lo, lo + cnt), its workgroups walk them with stride n_slots.
+    // (gridDim.x == n_items: one item each, at gvf_xcd_remap's position.)
+    int item, item_end, item_step;
+    {
+        const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+        const unsigned iq = (unsigned)p.n_items >> 3, ir = (unsigned)p.n_items & 7u;
+        const unsigned lo = xcd < ir ? xcd * (iq + 1u) : ir * (iq + 1u) + (xcd - ir) * iq, cnt = iq + (xcd < ir ? 1u : 0u);
+        const unsigned n_slots = (gridDim.x >> 3) + (xcd < (gridDim.x & 7u) ? 1u : 0u);
+        item = (int)(lo + slot); item_end = (int)(lo + cnt); item_step = (int)n_slots;
+        if (slot >= cnt) return;                                 // (uniform per workgroup, before any barrier)
+    }
     const int T = p.n_tiles;
     const int last_valid = p.Lk - (T - 1) * XT_KT;             // valid keys of the last tile (1..64)
+    const int n_stages = (T + XT_TPS - 1) / XT_TPS;
 
     // ---- staging: stage s = tiles [s * TPS, (s+1) * TPS) -> ring slot s % 3.  Wave w copies chunks [64w, 64w+64) of every
     // K image and of every V^T image of the stage (linear 1 KiB LDS-DMA pieces).
 #define XT_TILE_AT(t_) (&smem[((((t_) / XT_TPS) % XT_NBUF) * XT_TPS + (t_) % XT_TPS) * XT_TILE_CHUNKS])
-#define XT_STAGE(s_)                                                                                   \
+#define XT_STAGE_OF(it_, s_)                                                                           \
     _Pragma("unroll") for (int i_ = 0; i_ < XT_TPS; ++i_) {                                            \
         const int t_ = (s_) * XT_TPS + i_;                                                             \
         if (t_ < T) {                                                                                  \
             uint4* dst_ = XT_TILE_AT(t_);                                                              \
-            xt_dma16(kbase + (long long)t_ * 256 + wave * 64 + lane, dst_ + wave * 64);                \
-            xt_dma16(vbase + (long long)t_ * 256 + wave * 64 + lane, dst_ + 256 + wave * 64);          \
+            xt_dma16((it_).kbase + (long long)t_ * 256 + wave * 64 + lane, dst_ + wave * 64);          \
+            xt_dma16((it_).vbase + (long long)t_ * 256 + wave * 64 + lane, dst_ + 256 + wave * 64);    \
         }                                                                                              \
     }
+#define XT_STAGE(s_) XT_STAGE_OF(cur, s_)
 #define XT_K(t_) XT_TILE_AT(t_)
 #define XT_V(t_) (XT_TILE_AT(t_) + 256)
-    // The first two stages are requested BEFORE the query rows: the K / V^T tiles and the queries come from memory at the same time instead of
-    // one latency after the other (the fast path's first barrier below waits for them; the exact path stages for itself).
-    const int n_stages = (T + XT_TPS - 1) / XT_TPS;
-    if (!XT_LATE_STAGE && force_safe == 0) {
-        XT_STAGE(0)
-        if (n_stages > 1) { XT_STAGE(1) }
+    XtItem cur = xt_item(p, item);
+    uint4 qraw[2][2];
+    {
+        const int lane = tid0 & 63;
+        // The first two stages are requested BEFORE the query rows: the K / V^T tiles and the queries come from memory at the same time instead
+        // of one latency after the other (the fast path's first barrier below waits for them; the exact path stages for itself).
+        if (force_safe == 0) {
+            XT_STAGE(0)
+            if (n_stages > 1) { XT_STAGE(1) }
+        }
+        xt_load_q(p, cur, wave, lane & 31, lane >> 5, qraw);
     }
+    bool first_item = true;
 
+    for (;;) {
+    // The lane id is LAUNDERED once per item: everything below derives from it, and left alone the compiler hoists every loop-invariant
+    // lane value of the body (fragment addresses, selector constants, row addresses of the stores: ~45 registers) in front of the item loop
+    // and keeps them alive across the attention loop -- 28 spilled VGPRs measured; an item's code is meant to be the one-item kernel's.
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    // The NEXT item is decoded here, while this one's operands are still on their way (its descriptor then sits in scalar registers across
+    // the attention loop): decoded in the tail -- kernel arguments re-read, three integer divisions -- it cost 3.4 k cycles between the
+    // guard's barriers and the first request (s_memtime stamps, profiles/r05_attn_xt_item_boundary.txt).  Its query rows are touched
+    // (one dword per row into the landing zone nobody reads) so that the tail's real loads find them in L2.
+    const bool has_next = XT_PERSIST && item + item_step < item_end;
+    XtItem nxt = cur;
+    if (has_next) {
+        nxt = xt_item(p, item + item_step);
+        uint4* pz = &smem[XT_NBUF * XT_TPS * XT_TILE_CHUNKS + 1 + XT_ABL_LDSPAD + (XT_Q_LDS ? XT_THREADS * 4 : 0)];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int row = nxt.qb * XT_QB + wave * 64 + a * 32 + l31;
+            __builtin_amdgcn_global_load_lds(nxt.qp + (long long)(row < p.Lq ? row : 0) * p.q_sl + 16 * half, (__attribute__((address_space(3))) void*)pz, 4, 0, 0);
+        }
+    }
     // ---- Q fragments (B operand of S^T = K' Q^T): lane (q = l31, half): Q[q][16 st + 8 half .. +7]
-    int qrow[2];
-    bool qvalid[2];
     x8 qf[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
-        qrow[a] = qb * XT_QB + wave * 64 + a * 32 + l31;
-        qvalid[a] = qrow[a] < p.Lq;
-        uint4 qraw[2];
+        const bool qvalid = cur.qb * XT_QB + wave * 64 + a * 32 + l31 < p.Lq;
 #pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            const uint4 v4 = *reinterpret_cast<const uint4*>(qp + (long long)(qvalid[a] ? qrow[a] : 0) * p.q_sl + 16 * st + 8 * half);
-            const unsigned m = qvalid[a] ? 0xffffffffu : 0u;
-            qraw[st] = make_uint4(v4.x & m, v4.y & m, v4.z & m, v4.w & m);
-        }
+        for (int st = 0; st < 2; ++st) qraw[a][st] = xt_mask_q(qraw[a][st], qvalid);
         if (p.gamma_q != nullptr) {     // fused MultiHeadRMSNorm (model/attention/modules.py:8-15): the row lives in this lane and lane ^ 32
-            float ss = xt_sumsq8<DT>(qraw[0]) + xt_sumsq8<DT>(qraw[1]);
+            float ss = xt_sumsq8<DT>(qraw[a][0]) + xt_sumsq8<DT>(qraw[a][1]);
             ss += __shfl_xor(ss, 32, 64);
 #pragma unroll
-            for (int st = 0; st < 2; ++st) qraw[st] = xt_rms_apply<DT>(qraw[st], ss, p.gamma_q + head * 32 + 16 * st + 8 * half, 1.0f);
+            for (int st = 0; st < 2; ++st) qraw[a][st] = xt_rms_apply<DT>(qraw[a][st], ss, p.gamma_q + cur.head * 32 + 16 * st + 8 * half, 1.0f);
         }
 #pragma unroll
-        for (int st = 0; st < 2; ++st) qf[a][st] = __builtin_bit_cast(x8, qraw[st]);
+        for (int st = 0; st < 2; ++st) qf[a][st] = __builtin_bit_cast(x8, qraw[a][st]);
     }
     // XT_Q_LDS: the wave's four Q fragments live in its own 4 KiB of LDS ([sub-tile][k-step][lane]); no barrier needed (wave-private)
     uint4* sQw = &smem[XT_NBUF * XT_TPS * XT_TILE_CHUNKS + 1 + XT_ABL_LDSPAD] + wave * 256 + lane;
@@ -489,13 +568,14 @@ __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(
         __builtin_amdgcn_wave_barrier();
     }
 
-
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x16 oA = zero, oB = zero;
     float lA4[4] = {0.f, 0.f, 0.f, 0.f}, lB4[4] = {0.f, 0.f, 0.f, 0.f};
     float lA = 0.f, lB = 0.f;
     f32x4 l4A = {0.f, 0.f, 0.f, 0.f}, l4B = {0.f, 0.f, 0.f, 0.f}, l4Ab = {0.f, 0.f, 0.f, 0.f}, l4Bb = {0.f, 0.f, 0.f, 0.f};
     bool bad = force_safe != 0;
+    const uint4* const kbase = cur.kbase;
+    const uint4* const vbase = cur.vbase;
 
     if (!bad) {
         f32x16 sA[2], sB[2];
@@ -510,15 +590,13 @@ __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(
         // The first and the last tile are peeled so that the steady-state loop body is branch-free straight-line code
         // (with both variants of a phase behind an if / else the compiler hoists their common exp2 block above the
         // branch and the interleave is gone).
-        if (XT_LATE_STAGE) {
-            XT_STAGE(0)
-            if (n_stages > 1) { XT_STAGE(1) }
-        }
+        XT_STAMP(4, xt_item_no == 1)
         __syncthreads();            // stages 0 and 1 have landed (own DMA drained before the barrier)
+        XT_STAMP(5, xt_item_no == 1)
 #pragma unroll
         for (int s_ = 2; s_ < XT_NBUF; ++s_)
             if (s_ < n_stages) { XT_STAGE(s_) }
-        if (p.pf != nullptr && wave == 0) {
+        if (p.pf != nullptr && wave == 0 && first_item) {
             // warm the NEXT launch's weights: one dword per 128-byte line, LDS-DMA into a landing zone nobody reads (no register, no wait of
             // its own: the loads ride with the stage requests and are drained by the loop's barriers).  The lines end up in the Infinity
             // Cache (and this XCD's L2), where the row-block launch that follows finds them instead of going to HBM.
@@ -553,7 +631,8 @@ __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(
 #ifdef XT_TIMING
             long long xt_bar = 0, xt_tiles = 0;
             const long long xt_t0 = (long long)__builtin_amdgcn_s_memtime();
-            xt_loop0 = xt_t0;
+            if (first_item) xt_loop0 = xt_t0;
+            XT_STAMP(6, xt_item_no == 1)
 #endif
             for (; t + PER < T; t += PER) {
 #ifdef XT_TIMING
@@ -586,7 +665,7 @@ __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(
             }
 #undef XT_RING
 #ifdef XT_TIMING
-            if (lane == 0 && p.dbg != nullptr) {
+            if (lane == 0 && p.dbg != nullptr && first_item) {
                 long long* d = p.dbg + ((long long)blockIdx.x * 4 + wave) * 4;
                 xt_loop1 = (long long)__builtin_amdgcn_s_memtime();
                 d[0] = xt_loop1 - xt_t0; d[1] = xt_bar; d[2] = xt_tiles; d[3] = xt_loop0 - xt_k0;
@@ -636,17 +715,19 @@ __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(
         bad = !(okA && okB);
         if (XT_ABL_NOEXP || XT_ABL_NOQK || XT_ABL_NOPV || XT_ABL_NOSUM || XT_ABL_NOSYNC || XT_ABL_NOLDS) bad = false;   // timing experiments
     }
+    XT_STAMP(0, xt_item_no == 0)
+    XT_STAMP(7, xt_item_no == 1)
     if (tid == 0) *s_bad = 0;
     __syncthreads();
     if (bad) *s_bad = 1;
     __syncthreads();
+    XT_STAMP(1, xt_item_no == 0)
     if (*s_bad != 0) {
         // exact fallback for the whole workgroup (staging is cooperative): classic online softmax, two sub-tiles per wave
         float mA = -INFINITY, mB = -INFINITY;
         if (tid == 0 && p.fallbacks != nullptr) atomicAdd(p.fallbacks, 1);
         oA = zero; oB = zero; lA = 0.f; lB = 0.f;
         __syncthreads();
-        const int n_stages = (T + XT_TPS - 1) / XT_TPS;
         XT_STAGE(0)
         for (int t = 0; t < T; ++t) {
             if (t % XT_TPS == 0) {
@@ -659,38 +740,72 @@ __global__ __launch_bounds__(XT_THREADS, XT_WAVES_PER_SIMD) void attn_xt_kernel(
         }
         lA += __shfl_xor(lA, 32, 64);
         lB += __shfl_xor(lB, 32, 64);
+        __syncthreads();            // every wave is done with the ring before the next item's stages may land in it
     }
-#undef XT_STAGE
-#undef XT_TILE_AT
-#undef XT_K
-#undef XT_V
+
+    // ---- the next item's operands: every wave is past the guard's barriers, i.e. done with the ring -- request the next item's first two
+    // stages and its query rows NOW, under this item's normalisation and stores.
+    const int l31e = l31, halfe = half, wavee = wave;
+    uint4 qnext[2][2];
+    if (has_next) {
+        if (force_safe == 0) {
+            XT_STAGE_OF(nxt, 0)
+            if (n_stages > 1) { XT_STAGE_OF(nxt, 1) }
+        }
+        xt_load_q(p, nxt, wave, l31, half, qnext);
+    }
+    XT_STAMP(2, xt_item_no == 0)
 
     // ---- epilogue: O[q][d] / l, d = (r&3) + 8 (r>>2) + 4 half
+    const long long o_sl = p.o_sl;
+    const int Lq_e = p.Lq;
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
-        if (!qvalid[a]) continue;
+        const int qrow_e = cur.qb * XT_QB + wavee * 64 + a * 32 + l31e;
+        if (!(qrow_e < Lq_e)) continue;
         const f32x16& o = a == 0 ? oA : oB;
         const float inv = 1.0f / (a == 0 ? lA : lB);
         if (p.out_f32) {
-            float* orow = reinterpret_cast<float*>(p.out) + (outer * p.o_so + inner * p.o_si + head * p.o_sh) + (long long)qrow[a] * p.o_sl;
+            float* orow = reinterpret_cast<float*>(p.out) + cur.o_off + (long long)qrow_e * o_sl;
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<float4*>(orow + 8 * g + 4 * half) = make_float4(o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+                *reinterpret_cast<float4*>(orow + 8 * g + 4 * halfe) = make_float4(o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv);
             continue;
         }
-        unsigned short* orow = op + (long long)qrow[a] * p.o_sl;
+        unsigned short* orow = p.out + cur.o_off + (long long)qrow_e * o_sl;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             uint2 w;
             w.x = LP::pack(o[4 * g] * inv, o[4 * g + 1] * inv);
             w.y = LP::pack(o[4 * g + 2] * inv, o[4 * g + 3] * inv);
-            *reinterpret_cast<uint2*>(orow + 8 * g + 4 * half) = w;
+            *reinterpret_cast<uint2*>(orow + 8 * g + 4 * halfe) = w;
         }
     }
 #ifdef XT_TIMING
-    if (lane == 0 && p.dbg != nullptr && xt_loop1 != 0)
+    XT_STAMP(3, xt_item_no == 0)
+    if (lane == 0 && p.dbg != nullptr && xt_loop1 != 0 && first_item)
         p.dbg[((long long)gridDim.x * 4 + (long long)blockIdx.x * 4 + wave) * 4] = (long long)__builtin_amdgcn_s_memtime() - xt_loop1;
+    if (lane == 0 && p.dbg != nullptr && xt_item_no == 1) {       // second item done: its boundary stamps, relative to the first item's loop end
+        long long* d = p.dbg + (long long)gridDim.x * 32 + ((long long)blockIdx.x * 4 + wave) * 8;
+        for (int k = 1; k < 8; ++k) d[k] = xs[k] - xs[0];
+        d[0] = 1;
+    }
+    ++xt_item_no;
 #endif
+    if (!has_next) break;
+    item += item_step;
+    cur = nxt;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int st = 0; st < 2; ++st) qraw[a][st] = qnext[a][st];
+    first_item = false;
+    }
+#undef XT_STAGE
+#undef XT_STAGE_OF
+#undef XT_TILE_AT
+#undef XT_K
+#undef XT_V
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -718,7 +833,7 @@ constexpr int XT_PK_LD = 40;     // bf16 pitch of the staged V rows (80 B): the 
 template <typename TIn, int DT>
 __global__ __launch_bounds__(256) void attn_pack_kv_kernel(const TIn* __restrict__ kv, long long ld, int k_col0, int v_col0, int L, int H,
                                                            int n_tiles, float k_scale, const float* __restrict__ gamma_k,
-                                                           uint4* __restrict__ kt, uint4* __restrict__ vt) {
+                                                           const int* __restrict__ key_order, uint4* __restrict__ kt, uint4* __restrict__ vt) {
     __shared__ unsigned short sV[XT_KT * XT_PK_LD];
     const int tid = threadIdx.x;
     long long rest = blockIdx.x;
@@ -727,7 +842,10 @@ __global__ __launch_bounds__(256) void attn_pack_kv_kernel(const TIn* __restrict
     const long long set = rest / H;
     const int key_l = tid >> 2, c = tid & 3, key = tile * XT_KT + key_l;
     const bool valid = key < L;
-    const TIn* row = kv + (set * L + (valid ? key : 0)) * ld + h * 32 + 8 * c;
+    // key_order (optional, [set][head][L]): slot `key` of this (set, head) holds source row key_order[..][key] -- a permutation of the keys
+    // (softmax attention does not depend on their order; K and V move together)
+    const int src_key = valid ? (key_order != nullptr ? key_order[(set * H + h) * L + key] : key) : 0;
+    const TIn* row = kv + (set * L + src_key) * ld + h * 32 + 8 * c;
     float k8[8], v8[8];
     xt_ld8<DT>(row + k_col0, k8);
     xt_ld8<DT>(row + v_col0, v8);
@@ -764,10 +882,104 @@ __global__ __launch_bounds__(256) void attn_pack_kv_kernel(const TIn* __restrict
     vt[base + d * 8 + pos] = make_uint4(vw[0], vw[1], vw[2], vw[3]);
 }
 
+// Key order of a cross attention's cache (gvf_attn_pack_kv_ordered): the n_first largest-norm keys of every (set, head) first, everything else
+// behind them, both groups in context order (a stable partition -- all the fp16 kernel's first-tile shift needs; a full sort by norm cost 2.7 ms
+// per sample through torch.sort).  One workgroup per (set, head): squared norms as ordered integers in LDS, the n_first-th largest by a
+// 4 x 8-bit radix select over them (ties at the threshold: the first ones in context order), then ballot prefix sums hand out the slots.
+constexpr int KO_THREADS = 256, KO_MAX_L = 8192;
+__global__ __launch_bounds__(KO_THREADS) void key_order_kernel(const float* __restrict__ kv, long long ld, int k_col0, int L, int H, int n_first,
+                                                               int* __restrict__ order) {
+    __shared__ unsigned sN[KO_MAX_L];
+    __shared__ unsigned sHist[256];
+    __shared__ unsigned sSel[4];                 // prefix, remaining, (partition) running counts
+    __shared__ unsigned sWave[2][KO_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x % H;
+    const long long set = blockIdx.x / H;
+    for (int k = tid; k < L; k += KO_THREADS) {
+        const float4* r = reinterpret_cast<const float4*>(kv + (set * L + k) * ld + k_col0 + h * 32);
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float4 v = r[i]; ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w); }
+        sN[k] = (ss == ss) ? __float_as_uint(ss) : 0u;            // non-negative floats order like their bit patterns; a NaN row sorts last
+    }
+    const int want = n_first < L ? n_first : L;
+    if (tid == 0) { sSel[0] = 0u; sSel[1] = (unsigned)want; }
+    __syncthreads();
+    // radix select, most significant byte first: after the loop sSel[0] = the want-th largest value, sSel[1] = how many keys EQUAL to it are taken
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        sHist[tid] = 0u;
+        __syncthreads();
+        const unsigned prefix = sSel[0], hi_mask = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
+        for (int k = tid; k < L; k += KO_THREADS) {
+            const unsigned v = sN[k];
+            if ((v & hi_mask) == prefix) atomicAdd(&sHist[(v >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        {   // the digit d whose bin holds the rem-th largest candidate: above(d) < rem <= above(d) + hist[d], above(d) = candidates with a larger
+            // digit.  Every thread sums the bins above its own (LDS broadcast reads; one thread doing the scan alone was 50 us per workgroup)
+            const unsigned rem = sSel[1], mine = sHist[tid];
+            unsigned above = 0u;
+            for (int j = tid + 1; j < 256; ++j) above += sHist[j];
+            __syncthreads();                                 // (everyone has read sSel[1])
+            if (above < rem && rem <= above + mine) { sSel[0] = prefix | ((unsigned)tid << shift); sSel[1] = rem - above; }
+        }
+        __syncthreads();
+    }
+    const unsigned thr = sSel[0], n_eq = sSel[1];
+    // stable partition: a key goes first if it is above the threshold, or equal to it and among the first n_eq such keys
+    unsigned base_first = 0u, base_rest = (unsigned)want, seen_eq = 0u;
+    for (int k0 = 0; k0 < L; k0 += KO_THREADS) {
+        const int k = k0 + tid;
+        const unsigned v = k < L ? sN[k] : 0u;
+        const bool gt = k < L && v > thr, eq = k < L && v == thr;
+        // equal keys: rank among equals so far (workgroup-wide exclusive count)
+        const unsigned long long beq = __ballot(eq);
+        if (lane == 0) sWave[0][wave] = (unsigned)__popcll(beq);
+        __syncthreads();
+        unsigned eq_before = seen_eq, eq_total = 0u;
+        for (int w = 0; w < KO_THREADS / 64; ++w) { if (w < wave) eq_before += sWave[0][w]; eq_total += sWave[0][w]; }
+        eq_before += (unsigned)__popcll(beq & ((1ull << lane) - 1ull));
+        const bool first = gt || (eq && eq_before < n_eq);
+        __syncthreads();
+        const unsigned long long bf = __ballot(first), br = __ballot(k < L && !first);
+        if (lane == 0) { sWave[0][wave] = (unsigned)__popcll(bf); sWave[1][wave] = (unsigned)__popcll(br); }
+        __syncthreads();
+        unsigned f_before = base_first, r_before = base_rest, f_total = 0u, r_total = 0u;
+        for (int w = 0; w < KO_THREADS / 64; ++w) {
+            if (w < wave) { f_before += sWave[0][w]; r_before += sWave[1][w]; }
+            f_total += sWave[0][w]; r_total += sWave[1][w];
+        }
+        if (k < L) {
+            const unsigned slot = first ? f_before + (unsigned)__popcll(bf & ((1ull << lane) - 1ull)) : r_before + (unsigned)__popcll(br & ((1ull << lane) - 1ull));
+            order[(set * H + h) * L + slot] = k;
+        }
+        base_first += f_total; base_rest += r_total; seen_eq += eq_total;
+        __syncthreads();
+    }
+}
+
 }  // namespace
+
+extern "C" int gvf_attn_key_order(const float* kv, int64_t ld, int k_col0, int n_sets, int L, int H, int n_first, int32_t* key_order, void* stream_) {
+    if (n_sets < 0 || L <= 0 || L > KO_MAX_L || H <= 0 || ld <= 0 || k_col0 < 0 || n_first <= 0 || (ld % 4) || (k_col0 % 4)) return GVF_EINVAL;
+    if (n_sets == 0) return GVF_OK;
+    if (!kv || !key_order || (((uintptr_t)kv) & 15)) return GVF_EINVAL;
+    const long long blocks = (long long)n_sets * H;
+    if (blocks > 0x7fffffffLL) return GVF_EINVAL;
+    (void)hipGetLastError();
+    key_order_kernel<<<dim3((unsigned)blocks), dim3(KO_THREADS), 0, (hipStream_t)stream_>>>(kv, (long long)ld, k_col0, L, H, n_first, key_order);
+    GVF_CHECK_LAUNCH();
+    return GVF_OK;
+}
 
 extern "C" int gvf_attn_pack_kv(int dtype, const void* kv, int kv_is_f32, int64_t ld, int k_col0, int v_col0, int n_sets, int L, int H,
                                 float k_scale, const float* gamma_k, void* k_tiles, void* v_tiles, void* stream_) {
+    return gvf_attn_pack_kv_ordered(dtype, kv, kv_is_f32, ld, k_col0, v_col0, n_sets, L, H, k_scale, gamma_k, nullptr, k_tiles, v_tiles, stream_);
+}
+
+extern "C" int gvf_attn_pack_kv_ordered(int dtype, const void* kv, int kv_is_f32, int64_t ld, int k_col0, int v_col0, int n_sets, int L, int H,
+                                        float k_scale, const float* gamma_k, const int32_t* key_order, void* k_tiles, void* v_tiles, void* stream_) {
     if (dtype != GVF_DT_BF16 && dtype != GVF_DT_F16) return GVF_EINVAL;
     if (n_sets < 0 || L <= 0 || H <= 0 || ld <= 0 || k_col0 < 0 || v_col0 < 0) return GVF_EINVAL;
     if (n_sets == 0) return GVF_OK;
@@ -784,10 +996,10 @@ extern "C" int gvf_attn_pack_kv(int dtype, const void* kv, int kv_is_f32, int64_
     GVF_LP_DISPATCH(dtype,
         if (kv_is_f32)
             attn_pack_kv_kernel<float, DT><<<dim3((unsigned)blocks), dim3(256), 0, stream>>>((const float*)kv, ld, k_col0, v_col0, L, H, n_tiles, k_scale,
-                                                                                             gamma_k, (uint4*)k_tiles, (uint4*)v_tiles);
+                                                                                             gamma_k, key_order, (uint4*)k_tiles, (uint4*)v_tiles);
         else
             attn_pack_kv_kernel<unsigned short, DT><<<dim3((unsigned)blocks), dim3(256), 0, stream>>>((const unsigned short*)kv, ld, k_col0, v_col0, L, H,
-                                                                                                      n_tiles, k_scale, gamma_k, (uint4*)k_tiles,
+                                                                                                      n_tiles, k_scale, gamma_k, key_order, (uint4*)k_tiles,
                                                                                                       (uint4*)v_tiles));
     GVF_CHECK_LAUNCH();
     return GVF_OK;
@@ -796,6 +1008,21 @@ extern "C" int gvf_attn_pack_kv(int dtype, const void* kv, int kv_is_f32, int64_
 extern "C" int gvf_attn_pack_kv_bf16(const void* kv, int kv_is_f32, int64_t ld, int k_col0, int v_col0, int n_sets, int L, int H,
                                      float k_scale, const float* gamma_k, void* k_tiles, void* v_tiles, void* stream_) {
     return gvf_attn_pack_kv(GVF_DT_BF16, kv, kv_is_f32, ld, k_col0, v_col0, n_sets, L, H, k_scale, gamma_k, k_tiles, v_tiles, stream_);
+}
+
+// resident workgroups of attn_xt_kernel on the current device: XT_WAVES_PER_SIMD of them per CU (its register and LDS budgets are cut for that)
+static unsigned xt_resident_workgroups() {
+    static GvfPerDeviceOnce once;
+    static int cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 512u; }
+    gvf_once_per_device(once, [dev] {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev] = n;
+        return true;
+    });
+    return (unsigned)(cus[dev] > 0 ? cus[dev] : 256) * XT_WAVES_PER_SIMD;
 }
 
 template <int DT>
@@ -834,8 +1061,14 @@ extern "C" int gvf_attn_tiled_fwd_pf(int dtype, const void* q, const void* k_til
     p.out_f32 = out_is_f32;
     if (prefetch_bytes < 0 || (prefetch_bytes > 0 && !prefetch)) return GVF_EINVAL;
     p.pf = prefetch_bytes > 0 ? (const char*)prefetch : nullptr; p.pf_lines = prefetch_bytes / 128; p.pf_iters = 0;
-    const long long blocks = (long long)p.q_blocks * H * n_inner * n_outer;
+    long long blocks = (long long)p.q_blocks * H * n_inner * n_outer;
     if (blocks > 0x7fffffffLL) return GVF_EINVAL;
+    p.n_items = (int)blocks;
+    if (XT_PERSIST) {                 // no more workgroups than are resident at once: each walks its share of the items (see attn_xt_kernel)
+        const long long res = (long long)xt_resident_workgroups();
+        static const bool off = [] { const char* e = getenv("GVF_ATTN_PERSIST"); return e && e[0] == '0'; }();      // measurement switch
+        if (!off && blocks > res) blocks = res;
+    }
     if (p.pf != nullptr) p.pf_iters = (int)((p.pf_lines + blocks * 64 - 1) / (blocks * 64));
     (void)hipGetLastError();
     const int force_safe = force_exact & GVF_ATTN_FORCE_EXACT;

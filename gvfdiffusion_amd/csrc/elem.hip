@@ -136,6 +136,44 @@ __global__ __launch_bounds__(256) void cast_pad_kernel(const float* __restrict__
 }
 
 
+// fp32 matrix -> its two-term bf16 expansion laid out along K for ONE plain bf16 GEMM (the hoisted condition projections, DiT.prepare_conditions):
+//   x = hi + lo + O(2^-17 |x|),  hi = bf16(x),  lo = bf16(x - hi)        (bf16 keeps fp32's exponent range: no scaling, no subnormal cases)
+//   activations (mode 0):  A' = [ hi | lo | hi ]   (rows x 3 Kp)
+//   weights     (mode 1):  W' = [ hi | hi | lo ]   (rows x 3 Kp)
+//   A' W'^T = A_hi W_hi^T + A_lo W_hi^T + A_hi W_lo^T = A W^T - A_lo W_lo^T   -- the fp32 product up to a relative 2^-16 per term, accumulated
+// in fp32 by the MFMA in a fixed order per output row (no split-K), at 16-bit matrix-pipe rate: 3 products at 2.5 PFLOP/s peak against one at
+// the 0.157 PFLOP/s of v_mfma_f32_32x32x2_f32.  Kp = K rounded up to 64 (zero padded), so every third of A' / W' is a whole number of k-steps.
+__global__ __launch_bounds__(256) void split3_bf16_kernel(const float* __restrict__ src, long long ld_src, unsigned short* __restrict__ dst, long long rows,
+                                                          int cols, int Kp, int mode) {
+    const int per_row = Kp / 4;                                   // one thread = 4 consecutive columns
+    const long long total = rows * (long long)per_row;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / per_row;
+        const int c = (int)(i - r * per_row) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* sp = src + r * ld_src + c;
+        if (c + 3 < cols && ((((uintptr_t)sp) & 15) == 0)) {
+            const float4 q = *reinterpret_cast<const float4*>(sp);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = c + e < cols ? sp[e] : 0.f;
+        }
+        unsigned short hi[4], lo[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            hi[e] = f2bf(v[e]);
+            lo[e] = f2bf(v[e] - __uint_as_float(((unsigned)hi[e]) << 16));       // exact difference (Sterbenz-like: |x - hi| <= ulp_bf16 / 2), one rounding
+        }
+        const uint2 h2 = make_uint2((unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16));
+        const uint2 l2 = make_uint2((unsigned)lo[0] | ((unsigned)lo[1] << 16), (unsigned)lo[2] | ((unsigned)lo[3] << 16));
+        unsigned short* d = dst + r * (3LL * Kp) + c;
+        *reinterpret_cast<uint2*>(d) = h2;
+        *reinterpret_cast<uint2*>(d + Kp) = mode == 0 ? l2 : h2;
+        *reinterpret_cast<uint2*>(d + 2 * Kp) = mode == 0 ? h2 : l2;
+    }
+}
+
 // TimestepEmbedder + the SiLU in front of the adaLN projections in ONE launch (model/dit.py:59-100: sinusoid -> Linear -> SiLU ->
 // Linear; model/dit.py:217-225: SiLU -> Linear): out[b] = bf16(silu(W2 bf16(silu(W0 bf16([cos | sin](t_b f)) + b0)) + b2)), the operand of
 // the one GEMM that produces every block's modulation vectors.  One workgroup (16 waves) per sample; a wave computes 8 outputs at a time
@@ -482,6 +520,20 @@ extern "C" int gvf_cast_pad(int dtype, const float* src, int ld_src, void* dst, 
     if (blocks > 8192) blocks = 8192;
     GVF_LP_DISPATCH(dtype, hipLaunchKernelGGL(cast_pad_kernel<DT>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, src, ld_src,
                                               (unsigned short*)dst, ld_dst, (long long)rows, cols, act));
+    GVF_CHECK_LAUNCH();
+    return GVF_OK;
+}
+
+extern "C" int gvf_split3_bf16(const float* src, int64_t ld_src, void* dst, int64_t rows, int cols, int mode, void* stream_) {
+    if (rows < 0 || cols <= 0 || ld_src < cols || (mode != 0 && mode != 1)) return GVF_EINVAL;
+    if (rows == 0) return GVF_OK;
+    if (!src || !dst || (((uintptr_t)dst) & 7)) return GVF_EINVAL;
+    const int Kp = (cols + 63) / 64 * 64;
+    (void)hipGetLastError();
+    long long blocks = (rows * (long long)(Kp / 4) + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(split3_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, src, (long long)ld_src, (unsigned short*)dst,
+                       (long long)rows, cols, Kp, mode);
     GVF_CHECK_LAUNCH();
     return GVF_OK;
 }

@@ -396,33 +396,39 @@ class DiT(nn.Module):
         B, Tc, Li, Ci = cond_images.shape
         Ls = static_latent.shape[1]
         ctx = {"T": T, "lp": lp, "held": (conds, tuple(self._key(t) for t in conds)), "Li": Li, "Ls": Ls}
-        # Step-invariant, so precision here is free: condition projections and every block's to_kv(context) as plain fp32 library GEMMs
-        # (rocBLAS through torch, ~5 ms per sample), ONE rounding to 16 bits when the cache builder folds the softmax scale in and stores the
-        # tiled image the attention workgroups stage into LDS (csrc/attn_xt.hip); static K/V once per sample, not per frame.
+        # Step-invariant: the condition projections and every block's to_kv(context) (model/dit.py:464-465, model/attention/modules.py:134-143)
+        # at fp32-class accuracy on the bf16 matrix pipe -- both operands as two-term bf16 expansions laid out along K (dit_ops.split3_bf16:
+        # a w^T = a_hi w_hi^T + a_lo w_hi^T + a_hi w_lo^T + O(2^-16)), ONE plain gvf_gemm with fp32 accumulation and fp32 output per projection
+        # (three products at the 16-bit MFMA rate against one at v_mfma_f32's sixteenth of it; rounds 2-4 called rocBLAS here: ~5 ms per
+        # sample).  Every output row is summed in one fixed order (no split-K), so a sample's numbers do not depend on what it is batched
+        # with (tests: batch of three == three single samples, bit for bit).  Then ONE rounding to 16 bits when the cache builder folds the
+        # softmax scale in and stores the tiled image the attention workgroups stage into LDS (csrc/attn_xt.hip); static K/V once per
+        # sample, not per frame.
         H = self.num_heads
         ctx["kv_img"], ctx["kv_st"] = [], []
-        img_emb = torch.empty((B * Tc * Li, C), dtype=torch.float32, device=dev)
-        st_emb = torch.empty((B * Ls, C), dtype=torch.float32, device=dev)
-        kv_i = torch.empty((B * Tc * Li, 2 * C), dtype=torch.float32, device=dev)
-        kv_s = torch.empty((B * Ls, 2 * C), dtype=torch.float32, device=dev)
-
-        def lin_out(x_, wb, out):
-            # one library call per SAMPLE: the GEMM then has the shape (and the summation order) of a batch-1 call, so a sample's result
-            # does not depend on what it is batched with (tests: batch of three == three single samples, bit for bit)
-            rows = x_.shape[0] // B
-            for s_ in range(B):
-                xs, os_ = x_[s_ * rows:(s_ + 1) * rows], out[s_ * rows:(s_ + 1) * rows]
-                if wb[1] is None:
-                    torch.mm(xs, wb[0].t(), out=os_)
-                else:
-                    torch.addmm(wb[1], xs, wb[0].t(), out=os_)
-        lin_out(cond_images.reshape(B * Tc * Li, Ci).float(), W["img_f32"], img_emb)
-        lin_out(static_latent.reshape(B * Ls, -1).float(), W["static_f32"], st_emb)
-        for b in W["blocks"]:
-            lin_out(img_emb, b["image_cross_attn"]["kv_f32"], kv_i)
-            ctx["kv_img"].append(dit_ops.attention_pack_kv(kv_i, B * Tc, Li, H, 0, C, gamma_k=b["image_cross_attn"]["gk"], dtype=lp))
-            lin_out(st_emb, b["static_cross_attn"]["kv_f32"], kv_s)
-            ctx["kv_st"].append(dit_ops.attention_pack_kv(kv_s, B, Ls, H, 0, C, gamma_k=b["static_cross_attn"]["gk"], dtype=lp))
+        S3 = self._split3_weights(W)
+        f32 = torch.float32
+        img_emb = torch.empty((B * Tc * Li, C), dtype=f32, device=dev)
+        st_emb = torch.empty((B * Ls, C), dtype=f32, device=dev)
+        kv_i = torch.empty((B * Tc * Li, 2 * C), dtype=f32, device=dev)
+        kv_s = torch.empty((B * Ls, 2 * C), dtype=f32, device=dev)
+        dit_ops.gemm(dit_ops.split3_bf16(cond_images.reshape(B * Tc * Li, Ci).float().contiguous()), S3["img"], W["img_f32"][1], img_emb, dit_ops.EPI_STORE_F32)
+        dit_ops.gemm(dit_ops.split3_bf16(static_latent.reshape(B * Ls, -1).float().contiguous()), S3["static"], W["static_f32"][1], st_emb, dit_ops.EPI_STORE_F32)
+        img3, st3 = dit_ops.split3_bf16(img_emb), dit_ops.split3_bf16(st_emb)       # shared by the 12 blocks
+        # fp16 caches keep the 64 largest-norm keys of every (set, head) in the first tile (gvf_attn_key_order / gvf_attn_pack_kv_ordered): the kernel's per-query shift is the best
+        # score against the FIRST key tile and a later key that beats it by 2^16 costs the workgroup an exact pass -- on trained-like scores
+        # 38 % of the workgroups with the keys in context order, ~0 with the high-norm keys (attention sinks, artefact tokens) in front
+        # (tests/test_dit_fp16_gpu.py::test_full_config_trained_like_weights).  bf16 needs no shift: context order (GVF_DIT_KEY_ORDER=0/1 forces).
+        want = os.environ.get("GVF_DIT_KEY_ORDER")
+        ordered = (lp == torch.float16) if want is None else want == "1"
+        order = (lambda kv_, n_, L_: dit_ops.key_order_by_norm(kv_, n_, L_, H, 0) if L_ <= 8192 else None) if ordered else (lambda kv_, n_, L_: None)
+        for i, b in enumerate(W["blocks"]):
+            dit_ops.gemm(img3, S3["kv_img"][i], b["image_cross_attn"]["kv_f32"][1], kv_i, dit_ops.EPI_STORE_F32)
+            ctx["kv_img"].append(dit_ops.attention_pack_kv(kv_i, B * Tc, Li, H, 0, C, gamma_k=b["image_cross_attn"]["gk"], dtype=lp,
+                                                           key_order=order(kv_i, B * Tc, Li)))
+            dit_ops.gemm(st3, S3["kv_st"][i], b["static_cross_attn"]["kv_f32"][1], kv_s, dit_ops.EPI_STORE_F32)
+            ctx["kv_st"].append(dit_ops.attention_pack_kv(kv_s, B, Ls, H, 0, C, gamma_k=b["static_cross_attn"]["gk"], dtype=lp,
+                                                          key_order=order(kv_s, B, Ls)))
         if self.pe_mode == "ape":
             assert deformation_position_xyz is not None, "Deformation position xyz is required for APE mode"
             ctx["pos"] = self.pos_embedder(deformation_position_xyz).float().contiguous()      # (B, N, C)
@@ -432,6 +438,15 @@ class DiT(nn.Module):
             ctx["pos"] = None
         self._ctx_cache = ctx
         return ctx
+
+    def _split3_weights(self, W):
+        """[hi | hi | lo] bf16 expansions of the fp32 weights of the hoisted projections (dit_ops.split3_bf16), once per weight version."""
+        S3 = W.get("split3")
+        if S3 is None:
+            S3 = W["split3"] = {"img": dit_ops.split3_bf16(W["img_f32"][0], weights=True), "static": dit_ops.split3_bf16(W["static_f32"][0], weights=True),
+                                "kv_img": [dit_ops.split3_bf16(b["image_cross_attn"]["kv_f32"][0], weights=True) for b in W["blocks"]],
+                                "kv_st": [dit_ops.split3_bf16(b["static_cross_attn"]["kv_f32"][0], weights=True) for b in W["blocks"]]}
+        return S3
 
     # ---- what depends on the timestep alone ---------------------------------------------------------------
     @torch.no_grad()

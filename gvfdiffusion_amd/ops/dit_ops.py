@@ -70,6 +70,9 @@ _lib.register({
     "gvf_rowblock_fused": (_i, [ctypes.POINTER(RowblockArgs), _vp]),
     "gvf_rowblock_fused_bf16": (_i, [ctypes.POINTER(RowblockArgs), _vp]),
     "gvf_gemm_stats_parts": (_i, [_i]),
+    "gvf_attn_key_order": (_i, [_vp, _i64, _i, _i, _i, _i, _i, _vp, _vp]),
+    "gvf_attn_pack_kv_ordered": (_i, [_i, _vp, _i, _i64, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
+    "gvf_split3_bf16": (_i, [_vp, _i64, _vp, _i64, _i, _i, _vp]),
     "gvf_attn_pack_kv64": (_i, [_i, _vp, _i, _i64, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "gvf_attn_tiled64_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, ctypes.POINTER(_i64), ctypes.POINTER(_i64), _i64, _i64, _i, _vp, _vp]),
     "gvf_gemm256_eligible": (_i, [_i, _i, _i, _i, _i, _i]),
@@ -120,6 +123,19 @@ def cast_pad(src: torch.Tensor, ld_dst: int = None, act: int = 0, out: torch.Ten
         out = torch.empty((rows, ld_dst), dtype=dtype, device=src.device)
     _lib.check(_lib.lib().gvf_cast_pad(dt_code(out.dtype), _p(src), src.stride(0), _p(out), ld_dst, rows, cols, act, _stream(src)),
                "gvf_cast_pad")
+    return out
+
+
+def split3_bf16(src: torch.Tensor, weights: bool = False, out: torch.Tensor = None) -> torch.Tensor:
+    """fp32 (rows, K) -> bf16 (rows, 3 * pad64(K)): the two-term expansion hi = bf16(x), lo = bf16(x - hi) laid out [hi | lo | hi] (activations) or
+    [hi | hi | lo] (weights=True), so that gemm(split3(a), split3(w, True)) = a w^T to ~2^-16 on the bf16 matrix pipe; see include/gvf_dit.h."""
+    _lib.require_cuda(src)
+    assert src.dtype == torch.float32 and src.dim() == 2 and src.stride(1) == 1
+    rows, K = src.shape
+    if out is None:
+        out = torch.empty((rows, 3 * pad64(K)), dtype=torch.bfloat16, device=src.device)
+    assert out.dtype == torch.bfloat16 and out.is_contiguous() and out.shape == (rows, 3 * pad64(K))
+    _lib.check(_lib.lib().gvf_split3_bf16(_p(src), src.stride(0), _p(out), rows, K, int(bool(weights)), _stream(src)), "gvf_split3_bf16")
     return out
 
 
@@ -409,11 +425,22 @@ def attention_varlen(q, k, v, out, cu_q, cu_k, max_Lq, max_Lk, H, q_strides, k_s
 LOG2E = 1.4426950408889634
 
 
+def key_order_by_norm(kv: torch.Tensor, n_sets: int, L: int, H: int, k_col0: int, n_first: int = 64) -> torch.Tensor:
+    """int32 (n_sets, H, L): the n_first largest-norm keys of every (set, head) first, the rest behind them, both groups in context order --
+    the order attention_pack_kv(key_order=...) stores a cross attention's cache in, so that the fp16 kernel's first-tile shift sees the
+    high-norm keys (include/gvf_dit.h: gvf_attn_key_order, gvf_attn_pack_kv_ordered).  kv: fp32 rows; L <= 8192."""
+    _lib.require_cuda(kv)
+    assert kv.dtype == torch.float32 and kv.dim() == 2 and kv.stride(1) == 1
+    order = torch.empty((n_sets, H, L), dtype=torch.int32, device=kv.device)
+    _lib.check(_lib.lib().gvf_attn_key_order(_p(kv), kv.stride(0), k_col0, n_sets, L, H, int(n_first), _p(order), _stream(kv)), "gvf_attn_key_order")
+    return order
+
+
 def attention_pack_kv(kv: torch.Tensor, n_sets: int, L: int, H: int, k_col0: int, v_col0: int, scale: float = None,
-                      gamma_k: torch.Tensor = None, out=None, dtype=None):
+                      gamma_k: torch.Tensor = None, out=None, dtype=None, key_order: torch.Tensor = None):
     """kv rows (n_sets * L, ld) fp32, bf16 or fp16 -> (k_tiles, v_tiles) uint8 device buffers in the tiled cache image of
     csrc/attn_xt.hip (K pre-multiplied by scale * log2 e, optional RMSNorm gain).  The tiles' 16-bit type is that of a 16-bit
-    `kv`, else `dtype` (fp32 rows; default bf16)."""
+    `kv`, else `dtype` (fp32 rows; default bf16).  key_order: optional int32 (n_sets, H, L) permutation of the keys per (set, head)."""
     _lib.require_cuda(kv)
     assert kv.dim() == 2 and kv.stride(1) == 1 and kv.dtype in (torch.float32,) + LP_DTYPES
     dt = dt_code(kv.dtype) if kv.dtype in LP_DTYPES else dt_code(dtype or torch.bfloat16)
@@ -425,9 +452,11 @@ def attention_pack_kv(kv: torch.Tensor, n_sets: int, L: int, H: int, k_col0: int
     kt, vt = out
     assert kt.numel() >= nbytes and vt.numel() >= nbytes
     scale = 32 ** -0.5 if scale is None else scale
-    _lib.check(_lib.lib().gvf_attn_pack_kv(dt, _p(kv), int(kv.dtype == torch.float32), kv.stride(0), k_col0, v_col0, n_sets, L, H,
-                                           float(scale * LOG2E), _p(gamma_k), _p(kt), _p(vt), _stream(kv)),
-               "gvf_attn_pack_kv")
+    if key_order is not None:
+        assert key_order.dtype == torch.int32 and key_order.is_contiguous() and key_order.shape == (n_sets, H, L) and key_order.is_cuda
+    _lib.check(_lib.lib().gvf_attn_pack_kv_ordered(dt, _p(kv), int(kv.dtype == torch.float32), kv.stride(0), k_col0, v_col0, n_sets, L, H,
+                                                   float(scale * LOG2E), _p(gamma_k), _p(key_order), _p(kt), _p(vt), _stream(kv)),
+               "gvf_attn_pack_kv_ordered")
     return kt, vt
 
 

@@ -109,8 +109,8 @@ def dit_state_dict(manifest: dict, seed: int = 0) -> dict:
     return sd
 
 
-def dit_state_dict_trained_like(manifest: dict, seed: int = 0, gamma_lo: float = 0.5, gamma_hi: float = 2.0, cross_gain: float = 1.5,
-                                outlier_gain: float = 2.0) -> dict:
+def dit_state_dict_trained_like(manifest: dict, seed: int = 0, gamma_lo: float = 0.5, gamma_hi: float = 2.0, cross_gain: float = 1.3,
+                                outlier_gain: float = 1.6) -> dict:
     """dit_state_dict() pushed towards the score statistics of a TRAINED denoiser (none exists in this environment): the seed-generated
     weights give every attention near-uniform scores (std ~ 1), which is the friendliest case for the tiled attention's max-free softmax.
       * every QK-RMSNorm gain (model/attention/modules.py:8-15, `*.q_rms_norm.gamma` / `*.k_rms_norm.gamma`) ~ U[gamma_lo, gamma_hi]: the
@@ -139,7 +139,7 @@ def dit_state_dict_trained_like(manifest: dict, seed: int = 0, gamma_lo: float =
     return sd
 
 
-def dit_inputs_hostile(B: int = 1, T: int = 24, seed: int = 1, token_gain: float = 3.0, **kw) -> dict:
+def dit_inputs_hostile(B: int = 1, T: int = 24, seed: int = 1, token_gain: float = 2.5, **kw) -> dict:
     """dit_inputs() with a few high-norm context tokens, the artefact tokens a DINOv2 backbone is known for: three image tokens per frame
     and three static tokens carry token_gain x the typical norm (their keys AND values).  Positions: the first, a middle and the last
     64-key tile of each context."""

@@ -196,6 +196,17 @@ int gvf_attn_pack_kv(int dtype, const void* kv, int kv_is_f32, int64_t ld, int k
                      float k_scale, const float* gamma_k, void* k_tiles, void* v_tiles, void* stream);
 int gvf_attn_pack_kv_bf16(const void* kv, int kv_is_f32, int64_t ld, int k_col0, int v_col0, int n_sets, int L, int H,
                           float k_scale, const float* gamma_k, void* k_tiles, void* v_tiles, void* stream);
+/* The same with the keys of every (set, head) stored in a caller-chosen ORDER: key_order int32 [n_sets][H][L], slot j of (set, head) holds
+ * source row key_order[set][head][j] (a permutation of 0 .. L-1; null = identity).  softmax(q k^T) v does not depend on the order of the
+ * keys; the fp16 path of gvf_attn_tiled_fwd does, for SPEED: a query's shift is its best score against the FIRST key tile, and a later key that
+ * beats it by 2^16 sends the workgroup to the exact pass -- with the largest-norm keys first (attention sinks / artefact tokens are
+ * high-norm keys) the first tile's best is almost always within that window of the row's (DiT.prepare_conditions orders its caches so). */
+/* The order DiT.prepare_conditions uses: key_order [n_sets][H][L] <- the n_first largest-norm keys of every (set, head) first, the others behind
+ * them, both groups in context order (ties at the threshold: the earlier keys).  kv: f32 rows as for gvf_attn_pack_kv (K of head h at columns
+ * [k_col0 + 32 h, +32), 16-byte aligned rows); L <= 8192. */
+int gvf_attn_key_order(const float* kv, int64_t ld, int k_col0, int n_sets, int L, int H, int n_first, int32_t* key_order, void* stream);
+int gvf_attn_pack_kv_ordered(int dtype, const void* kv, int kv_is_f32, int64_t ld, int k_col0, int v_col0, int n_sets, int L, int H,
+                             float k_scale, const float* gamma_k, const int32_t* key_order, void* k_tiles, void* v_tiles, void* stream);
 
 /* out = softmax(q k^T * scale) v over such a cache (the scale is inside k_tiles).  q / out: bf16, strides
  * {outer, inner, seq, head} in elements as for gvf_attn_fwd_bf16; (outer, inner) reads K/V set
@@ -282,6 +293,14 @@ int gvf_cast_pad(int dtype, const float* src, int ld_src, void* dst, int ld_dst,
                  void* stream);
 int gvf_cast_pad_bf16(const float* src, int ld_src, void* dst, int ld_dst, int64_t rows, int cols, int act,
                       void* stream);
+
+/* Two-term bf16 expansion of an fp32 matrix, laid out along K so that ONE plain bf16 gvf_gemm (fp32 accumulation, fp32 output) computes the
+ * fp32-class product of the step-invariant condition projections (model/dit.py:464-465 image_cond_proj / static_cond_proj and every block's
+ * to_kv(context), model/attention/modules.py:134-143):  hi = bf16(x), lo = bf16(x - hi);
+ *   mode 0 (activations):  dst [rows][3 Kp] = [ hi | lo | hi ]        mode 1 (nn.Linear weights):  dst [rows][3 Kp] = [ hi | hi | lo ]
+ * Kp = cols rounded up to 64, zero padded.  gemm(dst_a, dst_w) = a w^T - a_lo w_lo^T: relative 2^-16 per term (the K / V cache it feeds is
+ * rounded to 16 bits once, 2^-9 .. 2^-12), every output row summed in one fixed order -- a sample's numbers do not depend on its batch. */
+int gvf_split3_bf16(const float* src, int64_t ld_src, void* dst, int64_t rows, int cols, int mode, void* stream);
 
 /* ---- the small projections of the denoise step in FP32 (csrc/elem.hip) ----------------------------------------------------------------
  * 0.3 % of the step's FLOPs and more than a third of its bf16 error (their results multiply or feed everything else), so they do not go

@@ -86,18 +86,29 @@ static int run_case(const char* name, int n_outer, int n_inner, int Lq, int Lk, 
 #ifdef XT_TIMING
     {   // s_memtime stamps of the steady-state loop: per wave (loop ticks, ticks spent in its barriers incl. the DMA drain in front of them, tiles)
         const long long nwg = (long long)((Lq + 255) / 256) * H * n_inner * n_outer;
-        long long* ddbg; CK(hipMalloc(&ddbg, nwg * 32 * 8)); CK(hipMemset(ddbg, 0, nwg * 32 * 8));
+        long long* ddbg; CK(hipMalloc(&ddbg, nwg * 64 * 8)); CK(hipMemset(ddbg, 0, nwg * 64 * 8));
         g_xt_dbg = ddbg;
         (void)gvf_attn_tiled_fwd_bf16(dq, dkt, dvt, dout, n_outer, n_inner, Lq, Lk, H, qs, qs, shared_kv ? 1 : n_inner, shared_kv ? 0 : 1, nullptr, 0, force_exact, dfb, nullptr);
         CK(hipDeviceSynchronize());
         g_xt_dbg = nullptr;
-        std::vector<long long> hd(nwg * 32);
-        CK(hipMemcpy(hd.data(), ddbg, nwg * 32 * 8, hipMemcpyDeviceToHost));
+        std::vector<long long> hd(nwg * 64);
+        CK(hipMemcpy(hd.data(), ddbg, nwg * 64 * 8, hipMemcpyDeviceToHost));
         double loop = 0, bar = 0, tiles = 0, pre = 0, post = 0; long long nw = 0;
         for (long long i = 0; i < nwg * 4; ++i) if (hd[i * 4 + 2] > 0) { loop += hd[i * 4]; bar += hd[i * 4 + 1]; tiles += hd[i * 4 + 2]; pre += hd[i * 4 + 3]; post += hd[(nwg * 4 + i) * 4]; ++nw; }
         if (nw) printf("    timing (%lld waves): %.0f ticks per tile in the steady-state loop, of which %.0f (%.1f %%) in its barriers; per workgroup: %.0f ticks before the loop "
                        "(queries, first stages, first phases), %.0f in it (%.0f tiles), %.0f after it (remainder tiles, last phases, guard, stores)\n", nw, loop / tiles, bar / tiles,
                        100.0 * bar / loop, pre / nw, loop / nw, tiles / nw, post / nw);
+        {   // persistent workgroups: the first item boundary of every wave that had one (ticks after the first item's last phase)
+            const long long grid = nwg < 512 ? nwg : 512;
+            double acc[8] = {0}; long long n2 = 0;
+            for (long long i = 0; i < grid * 4; ++i) {
+                const long long* d = &hd[grid * 32 + i * 8];
+                if (d[0] == 1) { for (int k = 1; k < 8; ++k) acc[k] += (double)d[k]; ++n2; }
+            }
+            if (n2) printf("    item boundary (%lld waves): guard barriers passed +%.0f, next item's stages + query rows requested +%.0f, stores issued +%.0f | next item: "
+                           "query rows normalised +%.0f, stages landed (barrier) +%.0f, steady loop entered +%.0f, its last phase done +%.0f\n", n2, acc[1] / n2, acc[2] / n2,
+                           acc[3] / n2, acc[4] / n2, acc[5] / n2, acc[6] / n2, acc[7] / n2);
+        }
         (void)hipFree(ddbg);
     }
 #endif

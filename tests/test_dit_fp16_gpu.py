@@ -37,7 +37,10 @@ def rel_l2(a, b):
 FULL_VS_FP32 = {"fp16": 1.0e-3, "bf16": None}            # absolute bar vs the reference's fp32 golden (bf16: the relative bar below)
 FULL_VS_REF_AUTOCAST = {"fp16": 1.5, "bf16": 0.6}        # x the reference's own autocast error of the same dtype
 FULL_VS_SAME_DTYPE_ORACLE = {"fp16": 4.4e-4, "bf16": 3.5e-3}   # measured 3.35e-4 / 2.66e-3, + 30 %
-SMALL_VS_SAME_DTYPE_ORACLE = {"fp16": 1.0e-5, "bf16": 2.5e-5}  # measured 5.0e-6 / 1.4e-5 (2 blocks, 64 channels)
+SMALL_VS_SAME_DTYPE_ORACLE = {"fp16": 2.0e-5, "bf16": 4.5e-5}  # measured 1.15e-5 / 3.4e-5 (2 blocks, 64 channels).  They were 5.0e-6 / 1.4e-5 while the
+#   hoisted condition projections were fp32 library GEMMs; as split-bf16 products on the matrix pipe (round 5, gvf_split3_bf16) they agree with
+#   the oracle's fp32 projections to 3e-6 instead of 1e-7, so a few more of the cache's K / V values round the other way (a flip is a full
+#   16-bit ulp: rms change ~ sqrt(flip probability) x ulp).  Invisible on the full model (3.43e-4 / 2.81e-3 vs the fp32 golden, as before).
 DT = {"fp16": torch.float16, "bf16": torch.bfloat16}
 
 
@@ -238,6 +241,56 @@ def test_tiled_cache_attention_fp16_range_guard(cuda):
             assert n_fb == 0
         else:
             assert top > 16.0 and 1 <= n_fb < total
+
+
+@pytest.mark.parametrize("Lk", [1000, 1370, 70])
+def test_tiled_cache_attention_fp16_key_order_keeps_high_norm_keys_in_the_first_tile(cuda, Lk):
+    """gvf_attn_pack_kv_ordered: the cache of a cross attention stores every (set, head)'s keys by descending norm (DiT.prepare_conditions,
+    fp16).  Attention does not depend on the order of its keys (result == the context-order cache up to summation order), the fp16 fast path
+    does: the "late spike" of the range-guard test -- a high-norm key 20+ octaves above a query's first-tile best, sitting in tile 12 -- is
+    in the FIRST tile of the ordered cache, so no workgroup falls back; per-head orders differ and are honoured."""
+    n_outer, n_inner, Lq, H = 2, 2, 512, 3
+    g = torch.Generator().manual_seed(Lk)
+    q = h(torch.randn((n_outer, n_inner, Lq, H, 32), generator=g) * 1.5).to(cuda)
+    kv = torch.randn((n_outer * Lk, 2 * H * 32), generator=g).to(cuda)
+    kv[:, :H * 32] *= 1.5
+    late = Lk - 5
+    kv[late, 32:64] = q[0, 1, 300, 1].float() * 2.0                 # set 0, head 1: the spike, in the last tile
+    kv[Lk + late // 2, 64:96] = q[1, 0, 17, 2].float() * 2.0         # set 1, head 2: another one, mid-context
+    order = dit_ops.key_order_by_norm(kv, n_outer, Lk, H, 0)
+    assert order.shape == (n_outer, H, Lk) and order.dtype == torch.int32
+    assert torch.equal(torch.sort(order.long(), dim=-1).values, torch.arange(Lk, device=cuda).expand(n_outer, H, Lk))      # permutations
+    # exactly the 64 largest-norm keys in front (ties: the earlier key), both groups in context order -- checked against torch
+    n2 = (kv[:, :H * 32].reshape(n_outer, Lk, H, 32) ** 2).sum(-1).permute(0, 2, 1)                      # (sets, H, L), the kernel's summation tree aside
+    nf = min(64, Lk)
+    srt = torch.sort(n2, dim=-1, descending=True, stable=True)
+    top = srt.indices[..., :nf]
+    clear = (srt.values[..., nf - 1] - srt.values[..., nf]) > 1e-5 * srt.values[..., nf - 1] if Lk > nf else torch.ones_like(srt.values[..., 0], dtype=torch.bool)
+    same = (torch.sort(order[..., :nf].long(), dim=-1).values == torch.sort(top, dim=-1).values).all(dim=-1)
+    assert bool((same | ~clear).all()) and bool(clear.any())       # (a 64th / 65th norm within rounding of each other may go either way)
+    assert bool((order[..., 1:nf] > order[..., :nf - 1]).all()) and (Lk <= nf + 1 or bool((order[..., nf + 1:] > order[..., nf:-1]).all()))
+    assert late in order[0, 1, :nf].tolist() and late // 2 in order[1, 2, :nf].tolist()
+    assert Lk < 640 or (late not in order[0, 0, :nf].tolist() and not torch.equal(order[0, 0], order[0, 1]))        # per head, not per set
+    C = H * 32
+    st = (n_inner * Lq * C, Lq * C, C)
+    res = {}
+    for tag, ko in (("context order", None), ("by norm", order)):
+        kt, vt = dit_ops.attention_pack_kv(kv, n_outer, Lk, H, 0, C, dtype=F16, key_order=ko)
+        fb = torch.zeros(1, dtype=torch.int32, device=cuda)
+        out = torch.empty(q.shape, dtype=torch.float32, device=cuda)
+        dit_ops.attention_tiled(q, kt, vt, out, n_outer, n_inner, Lq, Lk, H, st, st, 1, 0, fallback_counter=fb)
+        res[tag] = (out, int(fb.item()))
+    kset = kv.reshape(n_outer, Lk, 2, H, 32)[:, None].expand(n_outer, n_inner, Lk, 2, H, 32).reshape(n_outer * n_inner, Lk, 2, H, 32)
+    k2 = h(kset[:, :, 0] * (dit_ref.LOG2E / math.sqrt(32))).double().permute(0, 2, 1, 3)
+    s = q.reshape(n_outer * n_inner, Lq, H, 32).double().permute(0, 2, 1, 3) @ k2.transpose(-2, -1)
+    p = torch.exp2(s - s.amax(-1, keepdim=True))
+    ref = ((p @ h(kset[:, :, 1]).double().permute(0, 2, 1, 3)) / p.sum(-1, keepdim=True)).permute(0, 2, 1, 3).reshape(q.shape)
+    r0, r1 = rel_l2(res["context order"][0].double(), ref), rel_l2(res["by norm"][0].double(), ref)
+    print(f"fp16 key order Lk={Lk}: fallbacks {res['context order'][1]} (context order) -> {res['by norm'][1]} (by norm); rel_l2 vs fp64 {r0:.2e} / {r1:.2e}")
+    assert r0 < 8e-4 and r1 < 8e-4
+    if Lk > 64:
+        assert res["context order"][1] >= 1
+    assert res["by norm"][1] == 0
 
 
 @pytest.mark.parametrize("n_outer,n_inner,Lq,Lk,H,shared", [(1, 3, 512, 4096, 2, True), (2, 2, 512, 1370, 3, False), (2, 3, 300, 70, 4, False), (1, 1, 1, 1, 1, True)])
@@ -478,7 +531,10 @@ def test_sampler_on_the_fp16_dit_tracks_the_fp32_oracle_chain(cuda):
 
 # ---- "trained-like" weights + hostile conditions ------------------------------------------------------------------
 HOSTILE_VS_REF_AUTOCAST = {"fp16": 1.5, "bf16": 0.6}          # the same relative bars as on the seed-generated weights
-HOSTILE_VS_SAME_DTYPE_ORACLE = {"fp16": 4.4e-4, "bf16": 3.5e-3}
+# This model is ~9 x as sensitive to rounding as the seed-generated one -- the REFERENCE's own autocast runs leave its fp32 output by 6.6e-3
+# (fp16) / 5.1e-2 (bf16) against 7.4e-4 / 6.0e-3 there (tests/golden/dit_hostile_golden.npz) -- so the distance between two pipelines with the
+# same rounding points but different summation orders scales with it: the friendly model's bars (4.4e-4 / 3.5e-3) x that ratio
+HOSTILE_VS_SAME_DTYPE_ORACLE = {"fp16": 4.0e-3, "bf16": 3.0e-2}
 
 
 @pytest.mark.parametrize("name", ["fp16", "bf16"])
@@ -513,3 +569,6 @@ def test_full_config_trained_like_weights(cuda, name):
     assert r_ref <= HOSTILE_VS_REF_AUTOCAST[name] * ref_err
     # every workgroup forced onto the exact path gives the same answer up to the rounding of P (the guard only decides the speed)
     assert 0 <= n_fb <= n_wg
+    # fp16: with the caches' keys by descending norm (DiT.prepare_conditions) the first-tile shift holds for all but a few workgroups
+    # (measured with the keys in context order: 37.9 %); bf16 has 100 octaves either side
+    assert n_fb <= 0.05 * n_wg

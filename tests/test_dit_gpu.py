@@ -931,3 +931,36 @@ def test_graph_and_weight_caches_follow_every_kind_of_weight_change(cuda):
     model.blocks[0].mlp = new_mlp                                                        # a replaced submodule: seen on the very next call
     y3 = model(*args)
     assert not torch.equal(y3, y2) and torch.equal(y3, fresh())
+
+
+@pytest.mark.parametrize("M,N,K", [(333, 1024, 512), (4096, 512, 14), (1370, 512, 1024)])
+def test_split3_gemm_is_fp32_class(cuda, M, N, K):
+    """The hoisted condition projections (model/dit.py:464-465, model/attention/modules.py:134-143) run as ONE bf16 GEMM over two-term bf16
+    expansions of both operands (gvf_split3_bf16: [hi | lo | hi] x [hi | hi | lo]): a w^T up to the dropped a_lo w_lo^T, i.e. ~2^-16 per term.
+    Against float64: relative L2 <= 2e-5 -- an order of magnitude inside the one 16-bit rounding (2^-12 fp16, 2^-9 bf16) the K / V cache
+    applies afterwards, 50 x closer than a plain bf16 product -- and rows do not depend on their batch (row-wise bit-identical when M changes)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn((M, K), generator=g).to(cuda)
+    w = (torch.randn((N, K), generator=g) / math.sqrt(K)).to(cuda)
+    bias = torch.randn((N,), generator=g).to(cuda)
+    a3, w3 = dit_ops.split3_bf16(a), dit_ops.split3_bf16(w, weights=True)
+    Kp = dit_ops.pad64(K)
+    assert a3.shape == (M, 3 * Kp) and w3.shape == (N, 3 * Kp)
+    hi = a.to(torch.bfloat16)
+    assert torch.equal(a3[:, :K], hi) and torch.equal(a3[:, 2 * Kp:2 * Kp + K], hi) and torch.equal(a3[:, Kp:Kp + K], (a - hi.float()).to(torch.bfloat16))
+    assert torch.equal(w3[:, :K], w.to(torch.bfloat16)) and torch.equal(w3[:, Kp:Kp + K], w.to(torch.bfloat16))
+    if Kp > K:
+        assert float(a3[:, K:Kp].float().abs().max()) == 0.0
+    out = torch.empty((M, N), dtype=torch.float32, device=cuda)
+    dit_ops.gemm(a3, w3, bias, out, dit_ops.EPI_STORE_F32)
+    ref = a.double() @ w.double().t() + bias.double()
+    r3 = float((out.double() - ref).norm() / ref.norm())
+    out1 = torch.empty_like(out)
+    dit_ops.gemm(dit_ops.cast_pad(a, Kp), dit_ops.cast_pad(w, Kp), bias, out1, dit_ops.EPI_STORE_F32)
+    r1 = float((out1.double() - ref).norm() / ref.norm())
+    print(f"split3 GEMM {M}x{N}x{K}: rel_l2 vs float64 {r3:.2e} (plain bf16 operands: {r1:.2e}; torch fp32: "
+          f"{float(((a @ w.t() + bias).double() - ref).norm() / ref.norm()):.2e})")
+    assert r3 < 2e-5 and r3 < r1 / 50
+    half = torch.empty((M // 2, N), dtype=torch.float32, device=cuda)
+    dit_ops.gemm(a3[:M // 2], w3, bias, half, dit_ops.EPI_STORE_F32)
+    assert torch.equal(half, out[:M // 2])
