@@ -1377,6 +1377,25 @@ __device__ __forceinline__ unsigned quadrant_mask(float x, float y, float ap, fl
     return m;
 }
 
+#ifdef BLEND_TIMING
+// timing builds only (scripts/blend_stamps.py, a variant library): wave-cycles per phase of blend_kernel, summed over every wave of a launch
+//   [0] wait at the round's first barrier  [1] id load  [2] record gather  [3] Cholesky + quadrant mask + LDS writes  [4] wait at the second barrier
+//   [5] list compaction  [6] compositing  [7] rounds  [8] list entries  [9] waves  [10] whole wave lifetime  [11] epilogue stores
+__device__ unsigned long long g_blend_t[16];
+extern "C" int gvf_debug_blend_timing(unsigned long long* out16, int reset) {
+    if (out16 != nullptr && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_blend_t), sizeof(g_blend_t)) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_blend_t), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#define BT_DECL unsigned long long bt_acc[12] = {}; unsigned long long bt_last = __builtin_amdgcn_s_memtime(); const unsigned long long bt_first = bt_last;
+#define BT(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); bt_acc[i] += n_ - bt_last; bt_last = n_; } while (0)
+#define BT_VMWAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define BT_DECL
+#define BT(i) do { } while (0)
+#define BT_VMWAIT() do { } while (0)
+#endif
+
 // DEPTH: accumulate the depth channel (diff_gauss outputs; one fma per evaluated splat that the mip path does not pay)
 template <bool DEPTH>
 __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
@@ -1414,21 +1433,39 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
     bool done = !inside;
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dacc = 0.f;
 
+    BT_DECL
     for (int r = 0; r < rounds; ++r, todo -= BLEND_THREADS) {
+        BT(6);
         if (__syncthreads_count(done) == BLEND_THREADS) break;
+        BT(0);
+#ifdef BLEND_TIMING
+        uint32_t id_ = 0;
+        if (t < todo) id_ = point_list[rng.x + (uint32_t)r * BLEND_THREADS + t];
+        BT_VMWAIT(); BT(1);
+        float4 a_ = {}, b_ = {}, c_ = {};
+        if (t < todo) { const float4* rec = splats + 4 * (gbase + id_); a_ = rec[0]; c_ = rec[2]; b_ = rec[1]; }
+        BT_VMWAIT(); BT(2);
+        bt_acc[7] += 1;
+#endif
         if (t < todo) {
+#ifdef BLEND_TIMING
+            const float4 a = a_, b = b_, c = c_;
+#else
             uint32_t id = point_list[rng.x + (uint32_t)r * BLEND_THREADS + t];
             const float4* rec = splats + 4 * (gbase + id);
             const float4 a = rec[0];
             const float4 c = rec[2];
             const float4 b = rec[1];
+#endif
             const SplatChol ch = splat_cholesky(a.x, a.y, a.z, a.w, b.x, (float)(tx * TILE), (float)(ty * TILE));
             sA[t] = make_float4(ch.l11, ch.l12, ch.l22, ch.c1);
             sB[t] = make_float4(ch.c2, ch.ok ? __builtin_amdgcn_logf(b.y) : -__builtin_inff(), b.z, b.w);       // log2(opacity)
             sC[t] = make_float4(c.x, c.y, 0.f, 0.f);
             sMask[t] = (unsigned char)quadrant_mask(a.x, a.y, a.z, a.w, b.x, b.y, c.z, (float)(tx * TILE), (float)(ty * TILE), subpixel_offset != nullptr);
         }
+        BT(3);
         __syncthreads();
+        BT(4);
         const int cnt = min(BLEND_THREADS, todo);
         if (__all(done)) continue;                        // this quadrant is saturated (wave-uniform)
         // compact the batch into this wave's list (ascending index = depth order)
@@ -1442,6 +1479,10 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
             n_w += __popcll(bal);
         }
         __builtin_amdgcn_wave_barrier();
+        BT(5);
+#ifdef BLEND_TIMING
+        bt_acc[8] += n_w;
+#endif
         // Branch-free compositing step (upstream's `continue`s become predicates: a skipped splat gets weight 0,
         // which leaves C and T bit-identical), two splats per trip so that the second one's LDS reads and alpha
         // arithmetic overlap the first one's serial T update.
@@ -1491,6 +1532,13 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
         if (out_alpha != nullptr) out_alpha[(size_t)f * hw + pid] = 1.0f - T;
         if (out_depth != nullptr) out_depth[(size_t)f * hw + pid] = Dacc;
     }
+#ifdef BLEND_TIMING
+    BT(6);
+    BT_VMWAIT(); BT(11);
+    bt_acc[9] = 1; bt_acc[10] = bt_last - bt_first;
+    if (lane == 0)
+        for (int i = 0; i < 12; ++i) atomicAdd(&g_blend_t[i], bt_acc[i]);
+#endif
 }
 
 // (Round 4 measured a matrix-pipe variant of this kernel -- the exponents of 32 splats x 64 pixels from v_mfma_f32_32x32x2_f32 on the expanded

@@ -157,7 +157,9 @@ __device__ __forceinline__ void rb_gemm(f32x4 (&acc)[3][RB_CT], typename GvfLp<D
 #pragma unroll
                 for (int rt = 0; rt < 3; ++rt)
                     acc[rt][ct] = SWAP ? GvfLp<DT>::mfma16(af[b & 1][rt], wf[b][ct], acc[rt][ct]) : GvfLp<DT>::mfma16(wf[b][ct], af[b & 1][rt], acc[rt][ct]);
-#ifndef RB_ABL_NOW                 // timing experiment: no weight refills at all
+#if defined(RB_ABL_WFRAC)          // timing experiment: only RB_ABL_WFRAC of the 4 column tiles are refilled (what a column split across CUs would leave of the fill traffic)
+                if (ct < RB_ABL_WFRAC) wf[b][ct] = rb_ldw<DT>(sn + ct * 64);
+#elif !defined(RB_ABL_NOW)         // timing experiment: no weight refills at all
                 wf[b][ct] = rb_ldw<DT>(sn + ct * 64);
 #endif
             }

@@ -1,0 +1,35 @@
+"""Wave-cycles per phase of blend_kernel on the bench shape (BASELINE configs[1]) -- needs the BLEND_TIMING variant library:
+    python -m gvfdiffusion_amd._build --variant blendt rast.hip=-DBLEND_TIMING
+    GVF_LIB=gvfdiffusion_amd/variants/libgvf_hip_blendt.so python scripts/blend_stamps.py
+Forcing s_waitcnt vmcnt(0) between the phases perturbs the schedule (the product overlaps the id load, the gather and the staging
+arithmetic of one wave only through other waves anyway); the figures are shares of the waves' resident time, not product timings."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from gvfdiffusion_amd import _lib
+
+dev = torch.device("cuda:0")
+P, S, F = int(os.environ.get("P", 262144)), int(os.environ.get("S", 800)), int(os.environ.get("F", 24))
+w = bench.RasterWorkload(dev, P, S, F, 2, 0)
+L = _lib.lib()
+fn = L.gvf_debug_blend_timing
+fn.restype = ctypes.c_int; fn.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
+for _ in range(2): w.step()
+torch.cuda.synchronize()
+out = (ctypes.c_uint64 * 16)()
+fn(None, 1)
+N = 5
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(N): w.step()
+e1.record(); torch.cuda.synchronize()
+fn(out, 0)
+v = [x / N for x in out]
+names = ["wait@barrier1", "id load", "record gather", "stage arithmetic", "wait@barrier2", "compaction", "compositing", "rounds", "list entries", "waves", "lifetime", "epilogue stores"]
+life = v[10]
+print(f"step {e0.elapsed_time(e1) / N:.3f} ms (timing build), {w.D_binned} binned instances, {F} frames, waves {v[9]:.0f}")
+for i in (0, 1, 2, 3, 4, 5, 6, 11):
+    print(f"  {names[i]:18s} {v[i] / life * 100:6.2f} % of wave lifetime   {v[i] / v[9]:9.0f} cycles per wave")
+print(f"  rounds per wave {v[7] / v[9]:.2f}, list entries per wave {v[8] / v[9]:.1f}, cycles per list entry in compositing {v[6] / max(v[8], 1):.1f}, lifetime per wave {life / v[9]:.0f} cycles")
+print(f"  sum of wave lifetimes / (1024 SIMDs) = {life / 1024:.0f} cycles per SIMD-slot-sum -> at 8 waves per SIMD {life / 1024 / 8:.0f} cycles of launch")
