@@ -53,6 +53,18 @@ constexpr int NSLAB = 1;
 #endif
 constexpr int PRE_FB = GVF_PRE_FB;   // frames per preprocess workgroup: the frame-invariant inputs (xyz, scale, rotation, opacity,
                             // SH: 164 of the 220 input bytes per Gaussian at degree 2) come from HBM once per PRE_FB frames
+// Workgroup -> (Gaussian block, frame group) of preprocess_kernel.  1: XCD-aware (round 5 experiment): workgroup n of the 1-D grid runs on XCD n % 8
+// (round-robin dispatch); the FY frame groups of one Gaussian block are consecutive workgroups OF ONE XCD, so the block's frame-invariant
+// 164 B per Gaussian cross the fabric once and are L2 hits for the other FY - 1 groups.  0 (default): round 1-4's (blocks, frame groups) 2-D grid,
+// in which a frame group walks all 43 MB of static inputs before the next one starts.  Measured: 0.363-0.366 ms with the XCD order against
+// 0.358 ms without (profiles/r05_preprocess_variants_ab.txt) -- the launch does not wait for those bytes.
+#ifndef GVF_PRE_XCD
+#define GVF_PRE_XCD 0
+#endif
+// 1: the delta row of frame ff + 1 is requested before frame ff's arithmetic (experiment; no gain: same file)
+#ifndef GVF_PRE_PREFETCH
+#define GVF_PRE_PREFETCH 0
+#endif
 constexpr int TILE = GVF_TILE;
 constexpr int BLEND_THREADS = TILE * TILE;
 constexpr int MAX_SH_COEFFS = 16;
@@ -129,16 +141,14 @@ struct ActGaussian {
     float p[3], s[3], q[4], op, drgb[3];
 };
 
-__device__ __forceinline__ ActGaussian activate_one(int i, const GvfGaussianActivation& a,
-                                                    const float* __restrict__ xyz_raw,
-                                                    const float* __restrict__ scaling_raw,
-                                                    const float* __restrict__ rotation_raw,
-                                                    const float* __restrict__ opacity_raw,
-                                                    const float* __restrict__ d /* delta row or null */) {
+// dl: the delta row (zeros when d is false -- they are not added then, as the reference's get_* accessors do without a delta)
+__device__ __forceinline__ ActGaussian activate_vals(int i, const GvfGaussianActivation& a,
+                                                     const float* __restrict__ xyz_raw,
+                                                     const float* __restrict__ scaling_raw,
+                                                     const float* __restrict__ rotation_raw,
+                                                     const float* __restrict__ opacity_raw,
+                                                     const float (&dl)[14], bool d) {
     ActGaussian g;
-    float dl[14];
-#pragma unroll
-    for (int k = 0; k < 14; ++k) dl[k] = d ? d[k] : 0.0f;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         float v = xyz_raw[3 * (size_t)i + k] * a.aabb[3 + k] + a.aabb[k];
@@ -165,6 +175,17 @@ __device__ __forceinline__ ActGaussian activate_one(int i, const GvfGaussianActi
     g.op = 1.0f / (1.0f + expf(-x));
     g.drgb[0] = dl[10]; g.drgb[1] = dl[11]; g.drgb[2] = dl[12];
     return g;
+}
+__device__ __forceinline__ ActGaussian activate_one(int i, const GvfGaussianActivation& a,
+                                                    const float* __restrict__ xyz_raw,
+                                                    const float* __restrict__ scaling_raw,
+                                                    const float* __restrict__ rotation_raw,
+                                                    const float* __restrict__ opacity_raw,
+                                                    const float* __restrict__ d /* delta row or null */) {
+    float dl[14];
+#pragma unroll
+    for (int k = 0; k < 14; ++k) dl[k] = d ? d[k] : 0.0f;
+    return activate_vals(i, a, xyz_raw, scaling_raw, rotation_raw, opacity_raw, dl, d != nullptr);
 }
 
 __global__ __launch_bounds__(256) void activate_kernel(GvfGaussianActivation a, int P, int M,
@@ -328,14 +349,22 @@ __global__ __launch_bounds__(PRE_THREADS) void preprocess_kernel(
     extern __shared__ __attribute__((aligned(16))) float sh_lds[];  // [PRE_THREADS][M*3] + 4 wave sums
     const int t = threadIdx.x;
     const int P = pp.P, M = pp.M;
-    const int i = blockIdx.x * PRE_THREADS + t;
+    const int nbx = (P + PRE_THREADS - 1) / PRE_THREADS;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (GVF_PRE_XCD) {
+        const int FY = (pp.F + PRE_FB - 1) / PRE_FB, k = (int)(blockIdx.x >> 3);
+        bx = (k / FY) * 8 + (int)(blockIdx.x & 7u);
+        by = k - (k / FY) * FY;
+        if (bx >= nbx) return;                  // the grid is rounded up to whole groups of 8 blocks (workgroup-uniform)
+    }
+    const int i = bx * PRE_THREADS + t;
 
     // Stage this block's SH coefficients through LDS with coalesced 16-byte loads: 256 Gaussians x
     // M*3 floats are one contiguous span of the [P][M][3] tensor.
     const int sh_stride = M * 3;
     if (sh != nullptr) {
-        const size_t span0 = (size_t)blockIdx.x * PRE_THREADS * sh_stride;
-        const int nvalid = min(PRE_THREADS, P - blockIdx.x * PRE_THREADS);
+        const size_t span0 = (size_t)bx * PRE_THREADS * sh_stride;
+        const int nvalid = min(PRE_THREADS, P - bx * PRE_THREADS);
         const int total = nvalid * sh_stride;
         const float4* src4 = reinterpret_cast<const float4*>(sh + span0);  // span0*4 B is 16-B aligned
         float4* dst4 = reinterpret_cast<float4*>(sh_lds);
@@ -346,10 +375,39 @@ __global__ __launch_bounds__(PRE_THREADS) void preprocess_kernel(
     __syncthreads();
 
   const uint32_t my_slot = (bin_slot != nullptr && i < P) ? bin_slot[i] : (uint32_t)i;
+#if GVF_PRE_PREFETCH
+  // the delta row of the NEXT frame of this workgroup is requested before the current frame's arithmetic
+  float dnx[14];
+  bool dnx_has = false;
+  auto fetch_delta = [&](int f_) {
+      dnx_has = false;
+      if (pp.fused && delta != nullptr && i < P && f_ < pp.F) {
+          const int di = frames[f_].delta_index;
+          if (di >= 0) {
+              const float* d = delta + ((size_t)di * P + i) * 14;
+#pragma unroll
+              for (int k = 0; k < 14; ++k) dnx[k] = d[k];
+              dnx_has = true;
+          }
+      }
+      if (!dnx_has) {
+#pragma unroll
+          for (int k = 0; k < 14; ++k) dnx[k] = 0.0f;
+      }
+  };
+  fetch_delta(by * PRE_FB);
+#endif
   for (int ff = 0; ff < PRE_FB; ++ff) {
-    const int f = blockIdx.y * PRE_FB + ff;
+    const int f = by * PRE_FB + ff;
     if (f >= pp.F) break;
     const GvfRastFrame* fr = frames + f;
+#if GVF_PRE_PREFETCH
+    float dcur[14];
+#pragma unroll
+    for (int k = 0; k < 14; ++k) dcur[k] = dnx[k];
+    const bool dcur_has = dnx_has;
+    if (ff + 1 < PRE_FB) fetch_delta(f + 1);
+#endif
     uint32_t touched = 0;
     int radius_out = 0;
     float4 gA = make_float4(0.f, 0.f, 0.f, 0.f), gB = gA, gC = gA;
@@ -358,9 +416,13 @@ __global__ __launch_bounds__(PRE_THREADS) void preprocess_kernel(
     if (i < P) {
         float p[3], s[3], q[4], op, dadd[3] = {0.f, 0.f, 0.f};
         if (pp.fused) {
+#if GVF_PRE_PREFETCH
+            ActGaussian g = activate_vals(i, pp.act, a0, a1, a2, a3, dcur, dcur_has);
+#else
             const int di = fr->delta_index;
             const float* d = (delta != nullptr && di >= 0) ? delta + ((size_t)di * P + i) * 14 : nullptr;
             ActGaussian g = activate_one(i, pp.act, a0, a1, a2, a3, d);
+#endif
 #pragma unroll
             for (int k = 0; k < 3; ++k) { p[k] = g.p[k]; s[k] = g.s[k]; dadd[k] = g.drgb[k]; }
 #pragma unroll
@@ -498,7 +560,7 @@ __global__ __launch_bounds__(PRE_THREADS) void preprocess_kernel(
         __syncthreads();
         if (lane == 63) wsum[w] = incl;
         __syncthreads();
-        if (t == 0) block_sums[(size_t)f * gridDim.x + blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (t == 0) block_sums[(size_t)f * nbx + bx] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     }
   }
 }
@@ -1381,10 +1443,11 @@ __device__ __forceinline__ unsigned quadrant_mask(float x, float y, float ap, fl
 // timing builds only (scripts/blend_stamps.py, a variant library): wave-cycles per phase of blend_kernel, summed over every wave of a launch
 //   [0] wait at the round's first barrier  [1] id load  [2] record gather  [3] Cholesky + quadrant mask + LDS writes  [4] wait at the second barrier
 //   [5] list compaction  [6] compositing  [7] rounds  [8] list entries  [9] waves  [10] whole wave lifetime  [11] epilogue stores
-__device__ unsigned long long g_blend_t[16];
-extern "C" int gvf_debug_blend_timing(unsigned long long* out16, int reset) {
-    if (out16 != nullptr && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_blend_t), sizeof(g_blend_t)) != hipSuccess) return 1;
-    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_blend_t), z, sizeof(z)) != hipSuccess) return 1; }
+__device__ unsigned long long* g_blend_buf;       // [waves of the launch][12], one row per wave (same-address atomics would serialise the launch)
+__device__ unsigned long long g_blend_cap;
+extern "C" int gvf_debug_blend_timing(unsigned long long* device_buf, unsigned long long rows) {
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_blend_buf), &device_buf, sizeof(device_buf)) != hipSuccess) return 1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_blend_cap), &rows, sizeof(rows)) != hipSuccess) return 1;
     return 0;
 }
 #define BT_DECL unsigned long long bt_acc[12] = {}; unsigned long long bt_last = __builtin_amdgcn_s_memtime(); const unsigned long long bt_first = bt_last;
@@ -1536,8 +1599,9 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
     BT(6);
     BT_VMWAIT(); BT(11);
     bt_acc[9] = 1; bt_acc[10] = bt_last - bt_first;
-    if (lane == 0)
-        for (int i = 0; i < 12; ++i) atomicAdd(&g_blend_t[i], bt_acc[i]);
+    const unsigned long long wid = ((unsigned long long)f * gridDim.x + tile) * 4 + wave;
+    if (lane == 0 && g_blend_buf != nullptr && wid < g_blend_cap)
+        for (int i = 0; i < 12; ++i) g_blend_buf[wid * 12 + i] = bt_acc[i];
 #endif
 }
 
@@ -1748,7 +1812,8 @@ int run_pipeline(const GvfRastSettings& st, const GvfRastFrame* frames_host, int
         pp.upstream_binning = (st.upstream_binning != 0 || subpixel_offset != nullptr) ? 1 : 0;
         if (fused) pp.act = *act; else pp.act = GvfGaussianActivation{};
         const size_t sh_lds_bytes = gvf_align_up((size_t)PRE_THREADS * pp.M * 3 * sizeof(float), 16) + 16;
-        hipLaunchKernelGGL(preprocess_kernel, dim3(nb, (F + PRE_FB - 1) / PRE_FB), dim3(PRE_THREADS), sh_lds_bytes, stream, pp,
+        const int pre_fy = (F + PRE_FB - 1) / PRE_FB;
+        hipLaunchKernelGGL(preprocess_kernel, GVF_PRE_XCD ? dim3((nb + 7) / 8 * 8 * pre_fy) : dim3(nb, pre_fy), dim3(PRE_THREADS), sh_lds_bytes, stream, pp,
                            w.frames, a0, a1, a2, a3, colors_precomp ? nullptr : sh, colors_precomp, cov3D_precomp, delta,
                            w.splats, bucket ? nullptr : w.tiles_touched, (bucket && out_radii == nullptr) ? nullptr : w.radii,
                            bucket ? nullptr : w.block_sums, bucket ? w.binrec : nullptr, order != nullptr ? w.order_alt : nullptr,

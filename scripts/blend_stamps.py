@@ -14,18 +14,20 @@ P, S, F = int(os.environ.get("P", 262144)), int(os.environ.get("S", 800)), int(o
 w = bench.RasterWorkload(dev, P, S, F, 2, 0)
 L = _lib.lib()
 fn = L.gvf_debug_blend_timing
-fn.restype = ctypes.c_int; fn.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
+fn.restype = ctypes.c_int; fn.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
+tiles = ((S + 15) // 16) ** 2
+rows = F * tiles * 4
+buf = torch.zeros((rows, 12), dtype=torch.int64, device=dev)
 for _ in range(2): w.step()
 torch.cuda.synchronize()
-out = (ctypes.c_uint64 * 16)()
-fn(None, 1)
-N = 5
+assert fn(ctypes.c_void_p(buf.data_ptr()), rows) == 0
+N = 1
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(N): w.step()
 e1.record(); torch.cuda.synchronize()
-fn(out, 0)
-v = [x / N for x in out]
+b = buf.double()
+v = b.sum(0).tolist()
 names = ["wait@barrier1", "id load", "record gather", "stage arithmetic", "wait@barrier2", "compaction", "compositing", "rounds", "list entries", "waves", "lifetime", "epilogue stores"]
 life = v[10]
 print(f"step {e0.elapsed_time(e1) / N:.3f} ms (timing build), {w.D_binned} binned instances, {F} frames, waves {v[9]:.0f}")
@@ -33,3 +35,11 @@ for i in (0, 1, 2, 3, 4, 5, 6, 11):
     print(f"  {names[i]:18s} {v[i] / life * 100:6.2f} % of wave lifetime   {v[i] / v[9]:9.0f} cycles per wave")
 print(f"  rounds per wave {v[7] / v[9]:.2f}, list entries per wave {v[8] / v[9]:.1f}, cycles per list entry in compositing {v[6] / max(v[8], 1):.1f}, lifetime per wave {life / v[9]:.0f} cycles")
 print(f"  sum of wave lifetimes / (1024 SIMDs) = {life / 1024:.0f} cycles per SIMD-slot-sum -> at 8 waves per SIMD {life / 1024 / 8:.0f} cycles of launch")
+
+# distribution over waves: who is slow?
+life_w = b[:, 10]
+q = torch.quantile(life_w, torch.tensor([0.1, 0.5, 0.9, 0.99, 1.0], dtype=torch.float64, device=dev)).tolist()
+print("  wave lifetime quantiles (cycles) 10/50/90/99/100 %:", [int(x) for x in q])
+for i in (1, 2, 4, 6):
+    q = torch.quantile(b[:, i], torch.tensor([0.5, 0.9, 0.99], dtype=torch.float64, device=dev)).tolist()
+    print(f"  {names[i]:18s} per wave 50/90/99 %: {[int(x) for x in q]}")
