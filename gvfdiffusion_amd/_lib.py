@@ -60,6 +60,7 @@ SIGNATURES = {
     "gvf_rast_sort_class_counts": (_i, [_vp, _sz, _i, _i, _i, _i, _i64, ctypes.POINTER(ctypes.c_uint32), _vp]),
     "gvf_rast_profile_enable": (_i, [_i]),
     "gvf_rast_profile_read": (_i, [ctypes.POINTER(_f), ctypes.POINTER(_i)]),
+    "gvf_rast_shared_activation_calls": (_i64, []),
     "gvf_sort_tmp_bytes": (_sz, [_i64]),
     "gvf_sort_pairs_u64": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _vp, _sz, _vp]),
     "gvf_tile_sort_u64": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),

@@ -36,6 +36,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <mutex>
+#include <vector>
 #include "gvf_common.h"
 #include "gvf_sort.h"
 #include "../../include/gvf_rast.h"
@@ -287,6 +288,32 @@ __device__ __forceinline__ TileRect get_rect(float px, float py, float radius, i
     return r;
 }
 
+// Shared activation (round 5).  The reference renders one timestep from many cameras (utils/inference_utils.py:256-269: for t in 32, for cam in
+// 128), i.e. consecutive frames of a batched call select the SAME delta slice: activations (gaussian_model.py:84-114) and the 3-D covariance do
+// not depend on the camera.  When a call's F frames use few distinct slices, stage A computes them once per (slice, Gaussian) into a 64-byte
+// record {x, y, z, opacity | S00, S01, S02, S11 | S12, S22, drgb0, drgb1 | drgb2, -, -, -} and preprocess_kernel<true> reads the record
+// (one cache line, four 16-byte loads) instead of 112 B of strided raw inputs + the activation arithmetic per frame.  Same functions, same
+// operation order, no contraction (-ffp-contract=off): every output bit equals the fused path's (tests/test_rast_gpu.py::test_shared_activation_*).
+constexpr int ACT_MAX_SLICES = 16;
+struct ActSlices { int n; int di[ACT_MAX_SLICES]; };
+__global__ __launch_bounds__(256) void activate_cov_kernel(GvfGaussianActivation a, float scale_modifier, int P, ActSlices sl,
+                                                           const float* __restrict__ xyz_raw, const float* __restrict__ scaling_raw,
+                                                           const float* __restrict__ rotation_raw, const float* __restrict__ opacity_raw,
+                                                           const float* __restrict__ delta, float4* __restrict__ rec3d) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const int di = sl.di[blockIdx.y];
+    const float* d = (delta != nullptr && di >= 0) ? delta + ((size_t)di * P + i) * 14 : nullptr;
+    const ActGaussian g = activate_one(i, a, xyz_raw, scaling_raw, rotation_raw, opacity_raw, d);
+    float c6[6];
+    cov3d_from_scale_rot(g.s, scale_modifier, g.q, c6);
+    float4* r = rec3d + 4 * ((size_t)blockIdx.y * P + i);
+    r[0] = make_float4(g.p[0], g.p[1], g.p[2], g.op);
+    r[1] = make_float4(c6[0], c6[1], c6[2], c6[3]);
+    r[2] = make_float4(c6[4], c6[5], g.drgb[0], g.drgb[1]);
+    r[3] = make_float4(g.drgb[2], 0.f, 0.f, 0.f);
+}
+
 // Inputs are either activated tensors (fused == 0: a0=means3D, a1=scales, a2=rotations, a3=opacities,
 // sh=shs/colors) or raw GaussianModel parameters (fused != 0: a0=_xyz, a1=_scaling, a2=_rotation,
 // a3=_opacity, sh=_features_dc, delta[n_delta][P][14]).
@@ -337,6 +364,8 @@ __device__ __forceinline__ TileRect tight_rect(TileRect r, float px, float py, f
     return t;
 }
 
+// SHARED: a0 = the stage-A records [slices][P][4 x float4] (see activate_cov_kernel), frames[f].reserved[0] = the frame's slice
+template <bool SHARED>
 __global__ __launch_bounds__(PRE_THREADS) void preprocess_kernel(
     PreParams pp, const GvfRastFrame* __restrict__ frames, const float* __restrict__ a0,
     const float* __restrict__ a1, const float* __restrict__ a2, const float* __restrict__ a3,
@@ -415,7 +444,14 @@ __global__ __launch_bounds__(PRE_THREADS) void preprocess_kernel(
 
     if (i < P) {
         float p[3], s[3], q[4], op, dadd[3] = {0.f, 0.f, 0.f};
-        if (pp.fused) {
+        float c6s[6];
+        if (SHARED) {
+            const float4* r3 = reinterpret_cast<const float4*>(a0) + 4 * ((size_t)fr->reserved[0] * P + i);
+            const float4 r0 = r3[0], r1 = r3[1], r2 = r3[2], r3v = r3[3];
+            p[0] = r0.x; p[1] = r0.y; p[2] = r0.z; op = r0.w;
+            c6s[0] = r1.x; c6s[1] = r1.y; c6s[2] = r1.z; c6s[3] = r1.w; c6s[4] = r2.x; c6s[5] = r2.y;
+            dadd[0] = r2.z; dadd[1] = r2.w; dadd[2] = r3v.x;
+        } else if (pp.fused) {
 #if GVF_PRE_PREFETCH
             ActGaussian g = activate_vals(i, pp.act, a0, a1, a2, a3, dcur, dcur_has);
 #else
@@ -450,7 +486,10 @@ __global__ __launch_bounds__(PRE_THREADS) void preprocess_kernel(
             float projx = ph[0] * pw, projy = ph[1] * pw;
 
             float c6[6];
-            if (!pp.fused && cov3D_precomp != nullptr) {
+            if (SHARED) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) c6[k] = c6s[k];
+            } else if (!pp.fused && cov3D_precomp != nullptr) {
 #pragma unroll
                 for (int k = 0; k < 6; ++k) c6[k] = cov3D_precomp[6 * (size_t)i + k];
             } else {
@@ -1570,6 +1609,31 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
             if (DEPTH) Dacc = __builtin_fmaf(c.y, wgt, Dacc);                                          \
             T = acc ? test_T : T;                                                                      \
         }
+#if defined(GVF_BLEND_BRANCHY)
+        // experiment (round 5): the two predicates as EXEC masks (s_and_saveexec) instead of v_cndmask: one vector instruction less per step,
+        // a handful of scalar ones more.  Same arithmetic on the lanes that run it.
+#undef GVF_BLEND_STEP
+#define GVF_BLEND_STEP(J)                                                                              \
+        {                                                                                              \
+            const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(sA) + (J));          \
+            const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(sB) + (J));          \
+            const float4 c4_ = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(sC) + (J));        \
+            const float nlog = splat_neg_exponent(a.x, a.y, a.z, a.w, b.x, pxr, pyr, b.y);             \
+            const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(-nlog));                           \
+            if (!done && !(alpha < 1.0f / 255.0f)) {                                                   \
+                const float w_raw = alpha * T;                                                         \
+                const float test_T = T - w_raw;                                                        \
+                if (test_T < 0.0001f) done = true;                                                     \
+                else {                                                                                 \
+                    C0 = __builtin_fmaf(b.z, w_raw, C0);                                               \
+                    C1 = __builtin_fmaf(b.w, w_raw, C1);                                               \
+                    C2 = __builtin_fmaf(c4_.x, w_raw, C2);                                             \
+                    if (DEPTH) Dacc = __builtin_fmaf(c4_.y, w_raw, Dacc);                              \
+                    T = test_T;                                                                        \
+                }                                                                                      \
+            }                                                                                          \
+        }
+#endif
         int jj = 0;
         for (; jj + 3 < n_w; jj += 4) {
             if (__all(done)) break;
@@ -1732,6 +1796,8 @@ Workspace carve(void* ws, size_t bytes, int P, int F, int H, int W, int64_t max_
     return w;
 }
 
+std::atomic<long long> g_shared_calls{0};
+
 int run_pipeline(const GvfRastSettings& st, const GvfRastFrame* frames_host, int F, int P, int M, bool fused,
                  const GvfGaussianActivation* act, const float* a0, const float* a1, const float* a2,
                  const float* a3, const float* sh, const float* colors_precomp, const float* cov3D_precomp,
@@ -1759,10 +1825,36 @@ int run_pipeline(const GvfRastSettings& st, const GvfRastFrame* frames_host, int
     if (slot >= PROF_MAX_CALLS) slot = -1;
 
     const bool morton = st.bin_algo != GVF_RAST_BIN_RADIX && F >= 4 && P >= 4096;     // spatial order of the Gaussians (see below)
+    // ---- shared activation (activate_cov_kernel): the call's distinct delta slices, if they are few.  The records live in keys_alt, which only
+    // the radix binning uses (max_rendered x 8 bytes: room for max_rendered / (8 P) slices; a sizing call with max_rendered = 0 takes the fused path,
+    // whose outputs are the same bits).  GVF_RAST_SHARED_ACT=0: measurement / test switch.
+    ActSlices slices; slices.n = 0;
+    bool shared = false;
+    std::vector<int> frame_slice((size_t)F, 0);
+    const char* shared_env = getenv("GVF_RAST_SHARED_ACT");          // read per call: tests switch it inside one process
+    const bool shared_on = !(shared_env && shared_env[0] == '0');
+    if (shared_on && fused && cov3D_precomp == nullptr && st.bin_algo != GVF_RAST_BIN_RADIX && P > 0 && F >= 2) {
+        shared = true;
+        for (int f = 0; f < F && shared; ++f) {
+            const int di = (delta != nullptr && frames_host[f].delta_index >= 0) ? frames_host[f].delta_index : -1;
+            int k = 0;
+            while (k < slices.n && slices.di[k] != di) ++k;
+            if (k == slices.n) {
+                if (slices.n == ACT_MAX_SLICES) { shared = false; break; }
+                slices.di[slices.n++] = di;
+            }
+            frame_slice[(size_t)f] = k;
+        }
+        // worth it from two frames per slice on; the records must fit into keys_alt
+        if (shared && (F < 2 * slices.n || (size_t)slices.n * (size_t)P * 64u > (size_t)(max_rendered > 0 ? max_rendered : 0) * 8u)) shared = false;
+    }
     for (int f0 = 0; f0 < F; f0 += 16) {
         FrameChunk ch;
         const int cnt = F - f0 < 16 ? F - f0 : 16;
-        for (int k = 0; k < cnt; ++k) ch.f[k] = frames_host[f0 + k];
+        for (int k = 0; k < cnt; ++k) {
+            ch.f[k] = frames_host[f0 + k];
+            ch.f[k].reserved[0] = shared ? frame_slice[(size_t)(f0 + k)] : 0;       // the device copy's slice index (the caller's block is not touched)
+        }
         CallTables tab = {};
         if (f0 == 0) {
             const size_t nseg_all = (size_t)F * ntiles * NSLAB;
@@ -1813,7 +1905,18 @@ int run_pipeline(const GvfRastSettings& st, const GvfRastFrame* frames_host, int
         if (fused) pp.act = *act; else pp.act = GvfGaussianActivation{};
         const size_t sh_lds_bytes = gvf_align_up((size_t)PRE_THREADS * pp.M * 3 * sizeof(float), 16) + 16;
         const int pre_fy = (F + PRE_FB - 1) / PRE_FB;
-        hipLaunchKernelGGL(preprocess_kernel, GVF_PRE_XCD ? dim3((nb + 7) / 8 * 8 * pre_fy) : dim3(nb, pre_fy), dim3(PRE_THREADS), sh_lds_bytes, stream, pp,
+        const dim3 pre_grid = GVF_PRE_XCD ? dim3((nb + 7) / 8 * 8 * pre_fy) : dim3(nb, pre_fy);
+        if (shared) {
+            g_shared_calls.fetch_add(1, std::memory_order_relaxed);
+            float4* rec3d = reinterpret_cast<float4*>(w.keys_alt);
+            hipLaunchKernelGGL(activate_cov_kernel, dim3((P + 255) / 256, slices.n), dim3(256), 0, stream, *act, st.scale_modifier, P, slices,
+                               a0, a1, a2, a3, delta, rec3d);
+            hipLaunchKernelGGL(preprocess_kernel<true>, pre_grid, dim3(PRE_THREADS), sh_lds_bytes, stream, pp,
+                               w.frames, reinterpret_cast<const float*>(rec3d), nullptr, nullptr, nullptr, colors_precomp ? nullptr : sh, colors_precomp,
+                               nullptr, nullptr, w.splats, nullptr, out_radii == nullptr ? nullptr : w.radii, nullptr, w.binrec,
+                               order != nullptr ? w.order_alt : nullptr, nslab > 1 ? w.zrange : nullptr);
+        } else
+        hipLaunchKernelGGL(preprocess_kernel<false>, pre_grid, dim3(PRE_THREADS), sh_lds_bytes, stream, pp,
                            w.frames, a0, a1, a2, a3, colors_precomp ? nullptr : sh, colors_precomp, cov3D_precomp, delta,
                            w.splats, bucket ? nullptr : w.tiles_touched, (bucket && out_radii == nullptr) ? nullptr : w.radii,
                            bucket ? nullptr : w.block_sums, bucket ? w.binrec : nullptr, order != nullptr ? w.order_alt : nullptr,
@@ -2503,6 +2606,8 @@ extern "C" int gvf_rast_profile_enable(int on) {
     }
     return GVF_OK;
 }
+
+extern "C" int64_t gvf_rast_shared_activation_calls(void) { return (int64_t)g_shared_calls.load(std::memory_order_relaxed); }
 
 extern "C" int gvf_rast_profile_read(float* ms_sum, int* calls) {
     if (!ms_sum || !calls) return GVF_EINVAL;

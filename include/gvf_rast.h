@@ -197,6 +197,12 @@ int gvf_rgb_to_u8(const float* rgb, uint8_t* out, int64_t n, void* stream);
 int gvf_rast_profile_enable(int on);
 int gvf_rast_profile_read(float* ms_sum /*[GVF_RAST_NSTAGES]*/, int* calls);
 
+/* How many gvf_rast_forward_batched() calls of this process took the shared-activation path: when the F frames of a call select few
+ * distinct delta slices (the reference's render loop, utils/inference_utils.py:256-269: 128 cameras per timestep), the GaussianModel
+ * activations (gaussian_model.py:84-114) and the 3-D covariances are computed once per (slice, Gaussian) instead of once per frame;
+ * the outputs are the same bits either way (GVF_RAST_SHARED_ACT=0 in the environment forces the per-frame form).  A test aid. */
+int64_t gvf_rast_shared_activation_calls(void);
+
 /* Diagnostic of the per-tile sort (R4): how many (frame, tile) segments of the LAST gvf_rast_forward*() call on this workspace fell into the
  * size classes above the one-workgroup register sort -- counts[0]: 2049 .. 16384 keys (the two LDS launches), counts[1]: more than 16384
  * (sorted in place in HBM).  Takes the arguments the forward call carved its workspace with; waits for `stream` and copies two words to the

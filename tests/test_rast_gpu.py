@@ -246,6 +246,54 @@ def test_batched_fused_path_equals_per_frame_operator(cuda, oracle_lib):
             assert err.max() < 0.1
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("deg", [0, 2])
+def test_shared_activation_equals_fused_path(cuda, mode, deg, bin_algo):
+    """Frames of one call that select the same delta slice (the reference's loop: 128 cameras per timestep,
+    utils/inference_utils.py:256-269) share ONE activation + 3-D covariance per (slice, Gaussian) (activate_cov_kernel ->
+    preprocess_kernel<true>); every output must be the bits of the per-frame fused path (GVF_RAST_SHARED_ACT=0)."""
+    from gvfdiffusion_amd import rasterizer as R, _lib
+    P, S = 30_000, 208
+    attrs = synthetic.random_gaussians(P, sh_degree=deg, seed=41 + deg, scale_lo=0.003, scale_hi=0.02)
+    gm = synthetic.gaussian_model_from(attrs, deg, cuda)
+    delta = synthetic.random_deltas(3, P, seed=9).to(cuda)
+    idx = [0, 0, 0, 2, 2, -1, -1, 0, 2]                       # three slices (delta 0, delta 2, none) over nine frames
+    cams = [camera_block(azi=37.0 * f, elev=4.0 * f - 10.0) for f in range(len(idx))]
+    frames = [R.make_frame(c["viewmatrix"], c["projmatrix"], c["campos"], c["tanfovx"], c["tanfovy"], di) for c, di in zip(cams, idx)]
+    st = R.make_settings(S, S, deg, mode, synthetic.KERNEL_2D, 1.0, synthetic.BG)
+    raw = [t.contiguous().float() for t in (gm._xyz, gm.get_features, gm._scaling, gm._rotation, gm._opacity.reshape(-1))]
+    act = gm.activation_struct()
+
+    def run():
+        before = int(_lib.lib().gvf_rast_shared_activation_calls())
+        out = R.rasterize_batched(st, frames, act, *raw, delta=delta, want_alpha_depth=True, want_radii=True)
+        torch.cuda.synchronize()
+        return out, int(_lib.lib().gvf_rast_shared_activation_calls()) - before
+
+    old_env = os.environ.get("GVF_RAST_SHARED_ACT")
+    try:
+        os.environ["GVF_RAST_SHARED_ACT"] = "0"
+        fused, n0 = run()
+        os.environ["GVF_RAST_SHARED_ACT"] = "1"
+        shared, n1 = run()
+    finally:
+        if old_env is None:
+            os.environ.pop("GVF_RAST_SHARED_ACT", None)
+        else:
+            os.environ["GVF_RAST_SHARED_ACT"] = old_env
+    assert n0 == 0
+    # the radix binning keeps its buffers (the records live in one of them): per-frame form there
+    assert (n1 >= 1) == (bin_algo == "bucket"), (n1, bin_algo)
+    for k in ("color", "alpha", "depth", "radii", "num_rendered"):
+        assert torch.equal(fused[k], shared[k]), f"{k}: shared activation differs from the fused path"
+    assert int(shared["num_rendered"].sum()) > 0 and float(shared["color"].std()) > 0
+    # four distinct slices for four frames: not worth a second launch, the call stays fused
+    before = int(_lib.lib().gvf_rast_shared_activation_calls())
+    four = [R.make_frame(c["viewmatrix"], c["projmatrix"], c["campos"], c["tanfovx"], c["tanfovy"], di) for c, di in zip(cams, [0, 1, 2, -1])]
+    R.rasterize_batched(st, four, act, *raw, delta=delta)
+    assert int(_lib.lib().gvf_rast_shared_activation_calls()) == before
+
+
 def test_full_size_frame_config2(cuda, oracle_lib):
     """BASELINE.json configs[1] shapes: 262144 Gaussians, 800x800, SH degree 2 -- one frame checked
     against the oracle (about 1 s of CPU), 24 frames checked through size-independent properties."""
