@@ -1609,31 +1609,6 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
             if (DEPTH) Dacc = __builtin_fmaf(c.y, wgt, Dacc);                                          \
             T = acc ? test_T : T;                                                                      \
         }
-#if defined(GVF_BLEND_BRANCHY)
-        // experiment (round 5): the two predicates as EXEC masks (s_and_saveexec) instead of v_cndmask: one vector instruction less per step,
-        // a handful of scalar ones more.  Same arithmetic on the lanes that run it.
-#undef GVF_BLEND_STEP
-#define GVF_BLEND_STEP(J)                                                                              \
-        {                                                                                              \
-            const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(sA) + (J));          \
-            const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(sB) + (J));          \
-            const float4 c4_ = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(sC) + (J));        \
-            const float nlog = splat_neg_exponent(a.x, a.y, a.z, a.w, b.x, pxr, pyr, b.y);             \
-            const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(-nlog));                           \
-            if (!done && !(alpha < 1.0f / 255.0f)) {                                                   \
-                const float w_raw = alpha * T;                                                         \
-                const float test_T = T - w_raw;                                                        \
-                if (test_T < 0.0001f) done = true;                                                     \
-                else {                                                                                 \
-                    C0 = __builtin_fmaf(b.z, w_raw, C0);                                               \
-                    C1 = __builtin_fmaf(b.w, w_raw, C1);                                               \
-                    C2 = __builtin_fmaf(c4_.x, w_raw, C2);                                             \
-                    if (DEPTH) Dacc = __builtin_fmaf(c4_.y, w_raw, Dacc);                              \
-                    T = test_T;                                                                        \
-                }                                                                                      \
-            }                                                                                          \
-        }
-#endif
         int jj = 0;
         for (; jj + 3 < n_w; jj += 4) {
             if (__all(done)) break;
@@ -1669,6 +1644,10 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
 #endif
 }
 
+// (Round 5 measured two more variants of the compositing step and dropped both: the two predicates as EXEC masks (if / else instead of v_cndmask:
+// one vector instruction less, blend 0.82 ms against 0.70) and the colour accumulation on the idle matrix pipe (one v_mfma_f32_4x4x1_16b_f32 per
+// splat and wave -- weights as A, channel (lane & 3) of {r, g, b, depth} as B -- instead of three v_fma_f32: 14 vector instructions + 1 MFMA per step
+// against 16, blend 0.74 ms against 0.69).  profiles/r05_blend_branchy_ab.txt, r05_blend_mfma_accumulate_ab.txt; git history has both.)
 // (Round 4 measured a matrix-pipe variant of this kernel -- the exponents of 32 splats x 64 pixels from v_mfma_f32_32x32x2_f32 on the expanded
 // quadratic form, or from ONE v_mfma_f32_32x32x16_f16 with hi / lo split coefficients, software-pipelined under the compositing steps;
 // 22.3 -> 14.4 vector instructions per step, images within 1e-6 of this kernel's -- and dropped it: 0.92 ms (fp16 split) / 1.03 ms (f32)
