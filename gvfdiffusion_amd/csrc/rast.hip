@@ -1478,6 +1478,41 @@ __device__ __forceinline__ unsigned quadrant_mask(float x, float y, float ap, fl
     return m;
 }
 
+// Dispatch order of blend_kernel inside a frame: heaviest tiles first.  A workgroup's life is proportional to its tile's instance count
+// (1 k .. 150 k cycles at the bench shape); in image order the heavy centre tiles of the LAST frame start late and the chip drains behind them:
+// list scheduling of the measured workgroup durations on the 2048 resident slots puts the image order 5.7 % above sum / slots and
+// heaviest-first 0.1-0.9 % above (scripts/blend_stamps.py, profiles/r05_blend_phase_stamps.txt).  One workgroup per frame: counting sort of the
+// tiles by count class (64 classes of 32 instances, class 0 = 2016 and more; the order inside a class is whatever the atomics give -- tiles of a
+// class are neighbours in the image anyway, so the splat records stay shared in L2).  Images do not depend on the order.
+// Measured (profiles/r05_blend_order_ab.txt): the reference's live render job (512 x 512, tiles of up to 16 k instances beside empty ones) 167-176 ->
+// 146-149 ms per sample; the bench shape (800 x 800, no tile above 2048) unchanged within noise -- there image order already mixes heavy (vector-pipe)
+// and light (latency) workgroups on every CU.  So a frame is reordered only if it holds a tile of the top class.
+__global__ __launch_bounds__(1024) void blend_order_kernel(const uint2* __restrict__ ranges, int ntiles, uint32_t* __restrict__ order) {
+    __shared__ uint32_t hist[64];
+    const int f = blockIdx.x, t = threadIdx.x;
+    const uint2* r = ranges + (size_t)f * ntiles;
+    if (t < 64) hist[t] = 0u;
+    __syncthreads();
+    for (int tile = t; tile < ntiles; tile += 1024) {
+        const uint32_t n = r[tile].y - r[tile].x;
+        atomicAdd(&hist[63u - min(63u, n >> 5)], 1u);
+    }
+    __syncthreads();
+    if (hist[0] == 0u) {                               // no tile in the top class (>= 2016 instances): image order
+        for (int tile = t; tile < ntiles; tile += 1024) order[(size_t)f * ntiles + tile] = (uint32_t)tile;
+        return;
+    }
+    if (t == 0) {
+        uint32_t run = 0u;
+        for (int c = 0; c < 64; ++c) { const uint32_t h = hist[c]; hist[c] = run; run += h; }
+    }
+    __syncthreads();
+    for (int tile = t; tile < ntiles; tile += 1024) {
+        const uint32_t n = r[tile].y - r[tile].x;
+        order[(size_t)f * ntiles + atomicAdd(&hist[63u - min(63u, n >> 5)], 1u)] = (uint32_t)tile;
+    }
+}
+
 #ifdef BLEND_TIMING
 // timing builds only (scripts/blend_stamps.py, a variant library): wave-cycles per phase of blend_kernel, summed over every wave of a launch
 //   [0] wait at the round's first barrier  [1] id load  [2] record gather  [3] Cholesky + quadrant mask + LDS writes  [4] wait at the second barrier
@@ -1504,7 +1539,8 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
     int P, int H, int W, int gx, int gy, float bg0, float bg1, float bg2, const uint2* __restrict__ ranges,
     const uint32_t* __restrict__ point_list, const float4* __restrict__ splats,
     const float* __restrict__ subpixel_offset, float* __restrict__ out_color,
-    float* __restrict__ out_alpha, float* __restrict__ out_depth, int nslab) {
+    float* __restrict__ out_alpha, float* __restrict__ out_depth, int nslab,
+    const uint32_t* __restrict__ tile_order /* [F][tiles]: workgroup blockIdx.x of frame f takes tile tile_order[f][blockIdx.x]; null = identity */) {
     __shared__ float4 sA[BLEND_THREADS];
     __shared__ float4 sB[BLEND_THREADS];
     __shared__ float4 sC[BLEND_THREADS];                  // {b, depth, -, -}: 16-byte stride like sA / sB, one index shift per splat
@@ -1515,7 +1551,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int f = blockIdx.y;
-    const int tile = blockIdx.x;
+    const int tile = tile_order != nullptr ? (int)tile_order[(size_t)f * gridDim.x + blockIdx.x] : (int)blockIdx.x;
     const int tx = tile % gx, ty = tile / gx;
     const int px = tx * TILE + (wave & 1) * 8 + (lane & 7), py = ty * TILE + (wave >> 1) * 8 + (lane >> 3);
     const bool inside = px < W && py < H;
@@ -1962,15 +1998,23 @@ int run_pipeline(const GvfRastSettings& st, const GvfRastFrame* frames_host, int
         }
     }
     uint32_t* vals_sorted = w.ids;
+    // heaviest tiles first (blend_order_kernel; the scatter pass is done with its cursors: their array takes the order).  Worth a launch when the
+    // frames' workgroups outnumber the chip's resident slots; GVF_RAST_BLEND_ORDER=0: measurement switch
+    const char* order_env = getenv("GVF_RAST_BLEND_ORDER");
+    const uint32_t* tile_order = nullptr;
+    if (!(order_env && order_env[0] == '0') && P > 0 && nb > 0 && max_rendered > 0 && nslab_blend == 1 && (size_t)F * ntiles >= 2048) {
+        hipLaunchKernelGGL(blend_order_kernel, dim3(F), dim3(1024), 0, stream, w.ranges, ntiles, w.cursor);
+        tile_order = w.cursor;
+    }
     prof_mark(stream, slot, 6);
     if (out_depth != nullptr)
         hipLaunchKernelGGL(blend_kernel<true>, dim3(ntiles, F), dim3(BLEND_THREADS), 0, stream, P, H, W, gx, gy, st.bg[0],
                            st.bg[1], st.bg[2], w.ranges, vals_sorted, w.splats, subpixel_offset,
-                           out_color, out_alpha, out_depth, nslab_blend);
+                           out_color, out_alpha, out_depth, nslab_blend, tile_order);
     else
         hipLaunchKernelGGL(blend_kernel<false>, dim3(ntiles, F), dim3(BLEND_THREADS), 0, stream, P, H, W, gx, gy, st.bg[0],
                            st.bg[1], st.bg[2], w.ranges, vals_sorted, w.splats, subpixel_offset,
-                           out_color, out_alpha, out_depth, nslab_blend);
+                           out_color, out_alpha, out_depth, nslab_blend, tile_order);
     GVF_CHECK_LAUNCH();
     prof_mark(stream, slot, 7);
     return GVF_OK;

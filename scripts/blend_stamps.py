@@ -43,3 +43,25 @@ print("  wave lifetime quantiles (cycles) 10/50/90/99/100 %:", [int(x) for x in 
 for i in (1, 2, 4, 6):
     q = torch.quantile(b[:, i], torch.tensor([0.5, 0.9, 0.99], dtype=torch.float64, device=dev)).tolist()
     print(f"  {names[i]:18s} per wave 50/90/99 %: {[int(x) for x in q]}")
+
+# How much of the launch is tail?  List-scheduling simulation on the measured workgroup durations (a workgroup = the longest of its 4 waves; 2048 resident
+# slots = 8 per CU; durations are what the waves took while sharing their SIMD with 7 others, so this prices the ORDER only): makespan in dispatch order
+# (blockIdx.x = tile fastest, then frames), heaviest first, and the bound sum / slots.
+import heapq
+import numpy as np
+wg = b[:, 10].reshape(-1, 4).max(1).values.cpu().numpy()          # [frames * tiles] in dispatch order (f major, tile minor)
+def makespan(d, slots=2048):
+    h = [0.0] * slots
+    heapq.heapify(h)
+    end = 0.0
+    for x in d:
+        t = heapq.heappop(h) + float(x)
+        end = max(end, t)
+        heapq.heappush(h, t)
+    return end
+ideal = wg.sum() / 2048
+print(f"  schedule simulation (cycles): ideal {ideal:.0f}, dispatch order {makespan(wg):.0f} (+{(makespan(wg) / ideal - 1) * 100:.1f} %), "
+      f"heaviest first {makespan(np.sort(wg)[::-1]):.0f} (+{(makespan(np.sort(wg)[::-1]) / ideal - 1) * 100:.1f} %), longest workgroup {wg.max():.0f}")
+cnt = b[:, 8].reshape(-1, 4).sum(1).cpu().numpy()
+order = np.argsort(-cnt, kind="stable")                        # by list entries (known before the launch would be: instances per tile)
+print(f"  ... ordered by list entries per tile (a proxy the device has before the launch): {makespan(wg[order]):.0f} (+{(makespan(wg[order]) / ideal - 1) * 100:.1f} %)")

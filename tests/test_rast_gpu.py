@@ -253,7 +253,7 @@ def test_shared_activation_equals_fused_path(cuda, mode, deg, bin_algo):
     utils/inference_utils.py:256-269) share ONE activation + 3-D covariance per (slice, Gaussian) (activate_cov_kernel ->
     preprocess_kernel<true>); every output must be the bits of the per-frame fused path (GVF_RAST_SHARED_ACT=0)."""
     from gvfdiffusion_amd import rasterizer as R, _lib
-    P, S = 30_000, 208
+    P, S = 30_000, 256                                        # 9 frames x 256 tiles: enough workgroups for the heaviest-first blend order too
     attrs = synthetic.random_gaussians(P, sh_degree=deg, seed=41 + deg, scale_lo=0.003, scale_hi=0.02)
     gm = synthetic.gaussian_model_from(attrs, deg, cuda)
     delta = synthetic.random_deltas(3, P, seed=9).to(cuda)
@@ -287,6 +287,14 @@ def test_shared_activation_equals_fused_path(cuda, mode, deg, bin_algo):
     for k in ("color", "alpha", "depth", "radii", "num_rendered"):
         assert torch.equal(fused[k], shared[k]), f"{k}: shared activation differs from the fused path"
     assert int(shared["num_rendered"].sum()) > 0 and float(shared["color"].std()) > 0
+    # the blend's dispatch order (heaviest tiles of a frame first, blend_order_kernel) is invisible in the outputs
+    os.environ["GVF_RAST_BLEND_ORDER"] = "0"
+    try:
+        image_order, _ = run()
+    finally:
+        os.environ.pop("GVF_RAST_BLEND_ORDER", None)
+    for k in ("color", "alpha", "depth", "radii", "num_rendered"):
+        assert torch.equal(image_order[k], shared[k]), f"{k}: depends on the blend's dispatch order"
     # four distinct slices for four frames: not worth a second launch, the call stays fused
     before = int(_lib.lib().gvf_rast_shared_activation_calls())
     four = [R.make_frame(c["viewmatrix"], c["projmatrix"], c["campos"], c["tanfovx"], c["tanfovy"], di) for c, di in zip(cams, [0, 1, 2, -1])]
