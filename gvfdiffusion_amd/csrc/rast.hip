@@ -62,6 +62,11 @@ constexpr int PRE_FB = GVF_PRE_FB;   // frames per preprocess workgroup: the fra
 #ifndef GVF_PRE_XCD
 #define GVF_PRE_XCD 0
 #endif
+// 1: preprocess_kernel<true> (the shared-activation launch) stores its splat records quad-transposed, whole 64-byte lines per instruction (see there);
+// the fused launch keeps three 16-byte stores per lane (the transposed form costs it 13 registers; 0.377 -> 0.368 ms, inside the noise)
+#ifndef GVF_PRE_REC_QUAD
+#define GVF_PRE_REC_QUAD 1
+#endif
 // 1: the delta row of frame ff + 1 is requested before frame ff's arithmetic (experiment; no gain: same file)
 #ifndef GVF_PRE_PREFETCH
 #define GVF_PRE_PREFETCH 0
@@ -572,10 +577,14 @@ __global__ __launch_bounds__(PRE_THREADS) void preprocess_kernel(
             }
         }
         const size_t o = (size_t)f * P + i;
-        if (touched != 0) {   // records of culled Gaussians are never read (no instance refers to them)
+#if defined(PRE_ABL_NOREC)      // timing experiment: no record stores (one dword keeps the arithmetic alive)
+        if (touched != 0 && gA.x == 12345.678f) splats[4 * o] = gA;
+#else
+        if (!(GVF_PRE_REC_QUAD && SHARED) && touched != 0) {   // records of culled Gaussians are never read (no instance refers to them)
             float4* rec = splats + 4 * o;
             rec[0] = gA; rec[1] = gB; rec[2] = gC;
         }
+#endif
         if (tiles_touched != nullptr) tiles_touched[o] = touched;   // radix binning only
         if (radii != nullptr) radii[o] = radius_out;
         // bucket binning: the final tile rect and the depth, 16 B that the count / scatter passes gather by id
@@ -586,10 +595,42 @@ __global__ __launch_bounds__(PRE_THREADS) void preprocess_kernel(
                 const float2 zr = zrange[f];
                 slab = (uint32_t)fminf(fmaxf((gC.y - zr.x) * zr.y, 0.0f), (float)(NSLAB - 1));
             }
+#if defined(PRE_ABL_NOBIN)      // timing experiment: no bin-record stores
+            if (gC.y == 12345.678f)
+#elif defined(PRE_ABL_BINLINEAR) // timing experiment: bin records at the Gaussian's own index (coalesced) instead of its Morton slot
+            binrec[(size_t)f * P + i] = make_uint4((uint32_t)rect.x0 | ((uint32_t)rect.y0 << 16), (uint32_t)rect.x1 | ((uint32_t)rect.y1 << 16), __float_as_uint(gC.y), slab);
+            if (false)
+#endif
             binrec[(size_t)f * P + my_slot] = make_uint4((uint32_t)rect.x0 | ((uint32_t)rect.y0 << 16),
                                                          (uint32_t)rect.x1 | ((uint32_t)rect.y1 << 16), __float_as_uint(gC.y), slab);
         }
     }
+
+#if !defined(PRE_ABL_NOREC)
+    if (GVF_PRE_REC_QUAD && SHARED) {
+        // Quad-transposed record store (shared-activation launch): lane 4 g + j writes piece j (16 bytes; piece 3 = the padding) of the records of lanes
+        // 4 g + k, k = 0 .. 3, so ONE instruction stores 16 whole 64-byte lines where the per-lane form stores 64 quarter lines three times (48 of a
+        // line's 64 bytes, masked at the memory side).  The launch is bound by its stores (no record stores: -26 %, no bin-record stores: -21 %,
+        // profiles/r05_preprocess_store_ablation.txt); this form: live job 146-148 -> 141-142 ms per sample.  All 64 lanes run it (a lane past P or
+        // with a culled Gaussian has touched = 0 and zero pieces), lanes of a quad exchange through DPP quad broadcasts.
+        const int lj = t & 3;
+        float4* qbase = splats + 4 * ((size_t)f * P + (size_t)(i & ~3));
+#define GVF_QB(v_, k_) __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, (v_)), (k_) * 0x55, 0xF, 0xF, true))
+#define GVF_QSTORE(k_)                                                                                          \
+        {                                                                                                       \
+            const int tk = __builtin_amdgcn_mov_dpp((int)touched, (k_) * 0x55, 0xF, 0xF, true);                 \
+            float4 o4;                                                                                          \
+            { const float a = GVF_QB(gA.x, k_), b = GVF_QB(gB.x, k_), c = GVF_QB(gC.x, k_); o4.x = lj == 0 ? a : (lj == 1 ? b : (lj == 2 ? c : 0.f)); } \
+            { const float a = GVF_QB(gA.y, k_), b = GVF_QB(gB.y, k_), c = GVF_QB(gC.y, k_); o4.y = lj == 0 ? a : (lj == 1 ? b : (lj == 2 ? c : 0.f)); } \
+            { const float a = GVF_QB(gA.z, k_), b = GVF_QB(gB.z, k_), c = GVF_QB(gC.z, k_); o4.z = lj == 0 ? a : (lj == 1 ? b : (lj == 2 ? c : 0.f)); } \
+            { const float a = GVF_QB(gA.w, k_), b = GVF_QB(gB.w, k_), c = GVF_QB(gC.w, k_); o4.w = lj == 0 ? a : (lj == 1 ? b : (lj == 2 ? c : 0.f)); } \
+            if (tk != 0) qbase[4 * (k_) + lj] = o4;                                                             \
+        }
+        GVF_QSTORE(0) GVF_QSTORE(1) GVF_QSTORE(2) GVF_QSTORE(3)
+#undef GVF_QSTORE
+#undef GVF_QB
+    }
+#endif
 
     // block sum of tiles_touched (feeds the instance-offset scan, R2; radix binning only)
     if (block_sums != nullptr) {

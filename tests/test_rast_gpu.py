@@ -253,7 +253,9 @@ def test_shared_activation_equals_fused_path(cuda, mode, deg, bin_algo):
     utils/inference_utils.py:256-269) share ONE activation + 3-D covariance per (slice, Gaussian) (activate_cov_kernel ->
     preprocess_kernel<true>); every output must be the bits of the per-frame fused path (GVF_RAST_SHARED_ACT=0)."""
     from gvfdiffusion_amd import rasterizer as R, _lib
-    P, S = 30_000, 256                                        # 9 frames x 256 tiles: enough workgroups for the heaviest-first blend order too
+    # 9 frames x 256 tiles: enough workgroups for the heaviest-first blend order too; P = 30 003: the last quad of lanes of the quad-transposed
+    # record store is partly past P
+    P, S = 30_000 + 3 * (deg == 2), 256
     attrs = synthetic.random_gaussians(P, sh_degree=deg, seed=41 + deg, scale_lo=0.003, scale_hi=0.02)
     gm = synthetic.gaussian_model_from(attrs, deg, cuda)
     delta = synthetic.random_deltas(3, P, seed=9).to(cuda)
