@@ -1539,7 +1539,9 @@ __global__ __launch_bounds__(1024) void blend_order_kernel(const uint2* __restri
         atomicAdd(&hist[63u - min(63u, n >> 5)], 1u);
     }
     __syncthreads();
-    if (hist[0] == 0u) {                               // no tile in the top class (>= 2016 instances): image order
+    const bool reorder = hist[0] != 0u;                // a tile in the top class (>= 2016 instances)?  Read by everyone BEFORE thread 0's scan overwrites it
+    __syncthreads();
+    if (!reorder) {                                    // image order
         for (int tile = t; tile < ntiles; tile += 1024) order[(size_t)f * ntiles + tile] = (uint32_t)tile;
         return;
     }
