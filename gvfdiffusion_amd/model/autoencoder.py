@@ -256,9 +256,12 @@ class GSKLTemporalVariationalAutoEncoder(nn.Module):
                 fc2=(bf(f.fn.net[2].weight), fb(f.fn.net[2].bias))))
         d = self.decoder_cross_attn.fn
         W["dec_q"], W["dec_kv"] = bf(d.to_q.weight), bf(d.to_kv.weight)
-        wo, wy = d.to_out.weight.detach().double(), self.to_outputs.weight.detach().double()
-        W["fold"] = (bf((wy @ wo).float()),
-                     (wy @ d.to_out.bias.detach().double() + self.to_outputs.bias.detach().double()).float().contiguous())
+        # (on the HOST: 14 x 768 x 768 in double.  A torch GEMM on the device creates a hipBLASLt handle on the calling thread's first use, which
+        # touches the legacy stream -- illegal while another in-flight slot captures its hipGraph: hipBLASLt answers error 906 with exit(1).)
+        dev_w = d.to_out.weight.device
+        wo, wy = d.to_out.weight.detach().double().cpu(), self.to_outputs.weight.detach().double().cpu()
+        W["fold"] = (bf((wy @ wo).float().to(dev_w)),
+                     (wy @ d.to_out.bias.detach().double().cpu() + self.to_outputs.bias.detach().double().cpu()).float().contiguous().to(dev_w))
         # encoder half
         c = self.cross_attend_blocks
         W["enc"] = dict(q=bf(c[0].fn.to_q.weight), kv=bf(c[0].fn.to_kv.weight), out=(bf(c[0].fn.to_out.weight), fb(c[0].fn.to_out.bias)),

@@ -42,10 +42,24 @@ def run_in_flight(jobs: Sequence[Callable[[int], object]], device, in_flight: in
     next_job = [0]
     lock = threading.Lock()
 
+    # Library handles are created lazily per thread (torch: hipBLASLt / rocBLAS on a thread's first GEMM) and their creation touches the legacy
+    # stream, which is illegal while ANOTHER slot captures a hipGraph (hipErrorStreamCaptureImplicit; hipBLASLt exits the process on it).  The
+    # package's own paths launch no library GEMM, but a job is free to: every worker makes its first GEMM here, and nobody starts a job (and so
+    # a capture) before all of them have.
+    ready = threading.Barrier(in_flight) if in_flight > 1 else None
+
     def worker(slot):
         torch.cuda.set_device(dev)
         s = streams[slot]
         s.wait_stream(cur)
+        if ready is not None:
+            try:
+                with torch.cuda.stream(s):
+                    w_ = torch.zeros((8, 8), device=dev)
+                    torch.mm(w_, w_)
+                    s.synchronize()
+            finally:
+                ready.wait()
         while True:
             with lock:
                 j = next_job[0]

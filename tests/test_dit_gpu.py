@@ -864,8 +864,23 @@ def test_two_samplers_in_flight_equal_serial_sampling(cuda):
         both = run_in_flight(jobs, cuda, 2)
         assert torch.equal(both[0], serial[0]) and torch.equal(both[1], serial[1])
     assert not torch.equal(serial[0], serial[1])
-    three = run_in_flight(jobs + [jobs[0]], cuda, 2)          # more jobs than slots: the third reuses a slot
-    assert torch.equal(three[2], serial[0])
+    # more jobs than slots: the third reuses a slot.  It samples with jobs[0]'s DiT instance again, and an instance belongs to one job at a
+    # time (utils/in_flight.py): it starts only when the first job has returned (un-gated, the third job ran beside the first whenever the
+    # second finished first -- two users of one instance's graph buffers: a test bug that failed one run in a few)
+    import threading
+    first_done = threading.Event()
+
+    def first(slot):
+        try:
+            return jobs[0](slot)
+        finally:
+            first_done.set()
+
+    def third(slot):
+        first_done.wait()
+        return jobs[0](slot)
+    three = run_in_flight([first, jobs[1], third], cuda, 2)
+    assert torch.equal(three[0], serial[0]) and torch.equal(three[1], serial[1]) and torch.equal(three[2], serial[0])
 
     def boom(slot):
         raise RuntimeError("job failed")

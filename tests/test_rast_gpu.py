@@ -304,6 +304,41 @@ def test_shared_activation_equals_fused_path(cuda, mode, deg, bin_algo):
     assert int(_lib.lib().gvf_rast_shared_activation_calls()) == before
 
 
+def test_blend_dispatch_order_heaviest_first_is_invisible(cuda):
+    """blend_order_kernel: a frame that holds a tile of 2016+ instances has its blend workgroups dispatched heaviest tile first (a counting sort
+    of the frame's tiles by count class).  The order must be a permutation of the tiles -- every pixel of every frame written exactly as in
+    image order -- whatever the class populations: a crowded cluster (thousands of instances in a few tiles) in front of a thin background."""
+    from gvfdiffusion_amd import rasterizer as R
+    P, S, F = 40_000, 240, 10                                  # 225 tiles x 10 frames >= 2048 workgroups: the order launch runs
+    attrs = synthetic.random_gaussians(P, sh_degree=0, seed=77, scale_lo=0.002, scale_hi=0.004)
+    m = attrs["means3D"]
+    m[: P - 4000] = m[: P - 4000] * 0.04                       # 36 000 of them inside a small cube at the origin, the rest spread out
+    attrs["opacities"] = attrs["opacities"] * 0.05             # keep T above the cut so that every instance is composited
+    gm = synthetic.gaussian_model_from(attrs, 0, cuda)
+    cams = [camera_block(azi=36.0 * f, elev=3.0 * f) for f in range(F)]
+    frames = [R.make_frame(c["viewmatrix"], c["projmatrix"], c["campos"], c["tanfovx"], c["tanfovy"], -1) for c in cams]
+    st = R.make_settings(S, S, 0, 1, synthetic.KERNEL_2D, 1.0, synthetic.BG)
+    raw = [t.contiguous().float() for t in (gm._xyz, gm.get_features, gm._scaling, gm._rotation, gm._opacity.reshape(-1))]
+    act = gm.activation_struct()
+    out = {}
+    try:
+        for mode in ("1", "0"):
+            os.environ["GVF_RAST_BLEND_ORDER"] = mode
+            out[mode] = R.rasterize_batched(st, frames, act, *raw, want_alpha_depth=True)
+            torch.cuda.synchronize()
+            if mode == "1":
+                medium, huge = R.sort_class_counts()
+                assert medium + huge > 0, "the scene is meant to put 2049+ instances into some tiles (the reorder path)"
+    finally:
+        os.environ.pop("GVF_RAST_BLEND_ORDER", None)
+    for k in ("color", "alpha", "depth", "num_rendered"):
+        assert torch.equal(out["1"][k], out["0"][k]), f"{k} depends on the blend's dispatch order"
+    # ... and a frame rendered alone (too few workgroups for the order launch) is the same frame
+    one = R.rasterize_batched(st, frames[3:4], act, *raw, want_alpha_depth=True)
+    assert torch.equal(one["color"][0], out["1"]["color"][3]) and torch.equal(one["alpha"][0], out["1"]["alpha"][3])
+    assert float(out["1"]["alpha"].max()) > 0.5
+
+
 def test_full_size_frame_config2(cuda, oracle_lib):
     """BASELINE.json configs[1] shapes: 262144 Gaussians, 800x800, SH degree 2 -- one frame checked
     against the oracle (about 1 s of CPU), 24 frames checked through size-independent properties."""
