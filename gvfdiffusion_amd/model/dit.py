@@ -257,6 +257,9 @@ class DiT(nn.Module):
         SUBMODULE, a newly registered parameter and a parameter going from None to a tensor show up in the structural fingerprint (identity of
         every child in every kept `_modules` dict + the size of every `_parameters` dict; ~30 us), which sends the call back to the full walk."""
         d = self.__dict__
+        held = d.get("_pver_held")
+        if held is not None:
+            return held
         st = d.get("_pstate")
         if st is not None:
             mdicts, pdicts, shape = st
@@ -267,6 +270,17 @@ class DiT(nn.Module):
             mdicts, pdicts = [m._modules for m in mods], [m._parameters for m in mods]
             d["_pstate"] = (mdicts, pdicts, (tuple(id(c) for md in mdicts for c in md.values()), tuple(len(pd) for pd in pdicts)))
         return tuple((-1, 0) if q is None else (q._version, q.data_ptr()) for pd in pdicts for q in pd.values())
+
+    def hold_param_version(self, active: bool):
+        """A sampler brackets ONE sample() call with hold_param_version(True) / (False) (DPM_Solver.sample through model_wrapper's
+        `sampling_scope`): nobody updates weights inside a sampling call, so the parameter walk is done once for all its evaluations instead of
+        once per forward.  It is host time, and exposed exactly where the sampler waits for the device -- the adaptive solver's step-size test
+        empties the queue 22 times per sample, and the next launch then waits for the walk (~0.15 ms)."""
+        d = self.__dict__
+        d.pop("_pver_held", None)
+        if active and os.environ.get("GVF_DIT_HOLD_PVER", "1") != "0":          # (=0: measurement switch)
+            d["_pver_held"] = self._param_version()
+        return self
 
     def _weights(self, lp=None):
         lp = self._lp() if lp is None else lp

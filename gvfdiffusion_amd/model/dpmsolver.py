@@ -256,6 +256,14 @@ def model_wrapper(model, noise_schedule, model_type="noise", model_kwargs={}, gu
         if not t_continuous.is_cuda:
             _t_dev["pending"] = get_model_input_time(t_continuous).reshape(-1).clone()
     model_fn.prepare_times = prepare_times
+
+    def sampling_scope(active):
+        """DPM_Solver.sample brackets itself with sampling_scope(True) / (False): a denoiser with `hold_param_version` checks its weights once per
+        sample instead of once per evaluation."""
+        hold = getattr(model, "hold_param_version", None)
+        if hold is not None:
+            hold(bool(active))
+    model_fn.sampling_scope = sampling_scope
     return model_fn
 
 
@@ -265,6 +273,7 @@ class DPM_Solver:
                  correcting_xt_fn=None, thresholding_max_val=1.0, dynamic_thresholding_ratio=0.995):
         self.model = lambda x, t: model_fn(x, t.expand((x.shape[0])))
         self._prepare_times = getattr(model_fn, "prepare_times", None)
+        self._sampling_scope = getattr(model_fn, "sampling_scope", None)
         self.noise_schedule = noise_schedule
         assert algorithm_type in ["dpmsolver", "dpmsolver++"]
         self.algorithm_type = algorithm_type
@@ -699,6 +708,19 @@ class DPM_Solver:
             return state
 
         kw = dict(skip_type=skip_type, t_T=t_hi, t_0=t_lo)
+        if self._sampling_scope is not None:
+            self._sampling_scope(True)
+            try:
+                return self._sample_scoped(x, steps, order, method, lower_order_final, denoise_to_zero, solver_type, atol, rtol, return_intermediate,
+                                           kw, t_hi, t_lo, emit, recorded)
+            finally:
+                self._sampling_scope(False)
+        return self._sample_scoped(x, steps, order, method, lower_order_final, denoise_to_zero, solver_type, atol, rtol, return_intermediate,
+                                   kw, t_hi, t_lo, emit, recorded)
+
+    def _sample_scoped(self, x, steps, order, method, lower_order_final, denoise_to_zero, solver_type, atol, rtol, return_intermediate,
+                       kw, t_hi, t_lo, emit, recorded):
+        skip_type = kw["skip_type"]
         with torch.no_grad():
             if method == "adaptive":
                 x, k_end = self.dpm_solver_adaptive(x, order=order, t_T=t_hi, t_0=t_lo, atol=atol, rtol=rtol, solver_type=solver_type), 0

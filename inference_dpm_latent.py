@@ -178,6 +178,7 @@ def build_chain(args, dev, probe=None):
             if probe is not None:                              # one word per evaluation: where does a run leave its reference?
                 trace.append(y.detach().float().view(torch.int32).sum(dtype=torch.int64))
             return y
+        counted.sampling_scope = fn.sampling_scope      # ... and brackets each sample() call: the DiT checks its weights once per sample
         counted.prepare_times = fn.prepare_times          # the solver announces its time grid through the wrapper it is handed (modulation table, one upload)
         noise = torch.randn((1, T, model_cfg["resolution"], model_cfg["in_channels"]), generator=torch.Generator().manual_seed(args.seed + i)).to(dev)
         solver = DPM_Solver(counted, ns, algorithm_type="dpmsolver++")

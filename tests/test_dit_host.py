@@ -103,3 +103,46 @@ def test_param_version_sees_every_kind_of_weight_change_on_the_next_call():
     assert moved() and not moved()
     # and the key is exactly what a full walk gives (slots registered as None are kept as (-1, 0) place holders)
     assert tuple(e for e in model._param_version() if e != (-1, 0)) == tuple((p._version, p.data_ptr()) for p in model.parameters())
+
+
+def test_sampling_scope_holds_the_param_version_for_one_sample_call():
+    """DPM_Solver.sample brackets itself with model_wrapper's sampling_scope: the DiT walks its parameters once per sample (hold_param_version)
+    instead of once per evaluation -- host time that is exposed wherever the sampler waits for the device (the adaptive solver's step-size test).
+    Inside the bracket the key is the held one; after it a weight change is seen on the next call, and an exception inside sample() releases it."""
+    from gvfdiffusion_amd.model.dpmsolver import NoiseScheduleVP, model_wrapper, DPM_Solver
+    from gvfdiffusion_amd.model.gaussian_diffusion import create_gaussian_diffusion
+    g = np.load(os.path.join(GOLD, "dit_small_golden.npz"))
+    model = DiT(**json.loads(bytes(g["cfg_json"]).decode()))
+    ns = NoiseScheduleVP("discrete", betas=torch.from_numpy(create_gaussian_diffusion(noise_schedule="cosine", predict_type="v").betas))
+    walks, inside = [], []
+    real = type(model)._param_version
+
+    def counting(self):
+        walks.append("_pver_held" in self.__dict__)
+        return real(self)
+    type(model)._param_version = counting
+    try:
+        def fake_forward(x, t, **kw):                       # stands in for the HIP forward: asks for the key as every forward does
+            inside.append(model._param_version())
+            return torch.zeros_like(x)
+        model.forward = fake_forward
+        fn = model_wrapper(model, ns, model_type="v", model_kwargs={})
+        solver = DPM_Solver(fn, ns, algorithm_type="dpmsolver++")
+        solver.verbose = False
+        x = torch.zeros((1, 2, 4, 3))
+        solver.sample(x, steps=5, t_start=1.0, t_end=1 / 1000, order=2, method="multistep")
+        assert len(inside) == 5 and all(v is inside[0] for v in inside)          # one held tuple for the whole call
+        assert "_pver_held" not in model.__dict__
+        before = real(model)
+        with torch.no_grad():
+            model.blocks[0].mlp.mlp[0].weight.mul_(2.0)
+        assert real(model) != before                                              # released: the next call sees the update
+
+        def boom(x, t, **kw):
+            raise RuntimeError("forward failed")
+        model.forward = boom
+        with pytest.raises(RuntimeError, match="forward failed"):
+            solver.sample(x, steps=5, t_start=1.0, t_end=1 / 1000, order=2, method="multistep")
+        assert "_pver_held" not in model.__dict__
+    finally:
+        type(model)._param_version = real
