@@ -304,15 +304,23 @@ struct ActSlices { int n; int di[ACT_MAX_SLICES]; };
 __global__ __launch_bounds__(256) void activate_cov_kernel(GvfGaussianActivation a, float scale_modifier, int P, ActSlices sl,
                                                            const float* __restrict__ xyz_raw, const float* __restrict__ scaling_raw,
                                                            const float* __restrict__ rotation_raw, const float* __restrict__ opacity_raw,
-                                                           const float* __restrict__ delta, float4* __restrict__ rec3d) {
+                                                           const float* __restrict__ delta, float4* __restrict__ rec3d,
+                                                           const uint32_t* __restrict__ slot_of /* Gaussian -> Morton slot, or null */,
+                                                           const float* __restrict__ sh, int sh_floats, float* __restrict__ sh_by_slot) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
+    // SLOT ORDER (slot_of != null): the record of Gaussian i goes to its Morton slot (a whole 64-byte line, scattered ONCE per slice) and slice 0's
+    // workgroups also copy the SH rows into slot order; the per-frame launch then runs over slots: its record reads, its splat records and its bin
+    // records (16 bytes each, scattered to the slot by the index-ordered form: 21 % of that launch) are all contiguous.
+    const size_t dst = slot_of != nullptr ? (size_t)slot_of[i] : (size_t)i;
+    if (sh_by_slot != nullptr && blockIdx.y == 0)
+        for (int k = 0; k < sh_floats; ++k) sh_by_slot[dst * sh_floats + k] = sh[(size_t)i * sh_floats + k];
     const int di = sl.di[blockIdx.y];
     const float* d = (delta != nullptr && di >= 0) ? delta + ((size_t)di * P + i) * 14 : nullptr;
     const ActGaussian g = activate_one(i, a, xyz_raw, scaling_raw, rotation_raw, opacity_raw, d);
     float c6[6];
     cov3d_from_scale_rot(g.s, scale_modifier, g.q, c6);
-    float4* r = rec3d + 4 * ((size_t)blockIdx.y * P + i);
+    float4* r = rec3d + 4 * ((size_t)blockIdx.y * P + dst);
     r[0] = make_float4(g.p[0], g.p[1], g.p[2], g.op);
     r[1] = make_float4(c6[0], c6[1], c6[2], c6[3]);
     r[2] = make_float4(c6[4], c6[5], g.drgb[0], g.drgb[1]);
@@ -586,7 +594,11 @@ __global__ __launch_bounds__(PRE_THREADS) void preprocess_kernel(
         }
 #endif
         if (tiles_touched != nullptr) tiles_touched[o] = touched;   // radix binning only
-        if (radii != nullptr) radii[o] = radius_out;
+        if (radii != nullptr) {
+            // slot order (SHARED with a1 = the slot -> Gaussian table): thread i works on slot i, the radii stay indexed by Gaussian
+            const uint32_t* gid_of = SHARED ? reinterpret_cast<const uint32_t*>(a1) : nullptr;
+            radii[gid_of != nullptr ? (size_t)f * P + gid_of[i] : o] = radius_out;
+        }
         // bucket binning: the final tile rect and the depth, 16 B that the count / scatter passes gather by id
         if (binrec != nullptr) {
             // depth slab: any monotone function of depth keeps the concatenation of the sorted slabs sorted
@@ -1583,7 +1595,8 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
     const uint32_t* __restrict__ point_list, const float4* __restrict__ splats,
     const float* __restrict__ subpixel_offset, float* __restrict__ out_color,
     float* __restrict__ out_alpha, float* __restrict__ out_depth, int nslab,
-    const uint32_t* __restrict__ tile_order /* [F][tiles]: workgroup blockIdx.x of frame f takes tile tile_order[f][blockIdx.x]; null = identity */) {
+    const uint32_t* __restrict__ tile_order /* [F][tiles]: workgroup blockIdx.x of frame f takes tile tile_order[f][blockIdx.x]; null = identity */,
+    const uint32_t* __restrict__ rec_of /* Gaussian id -> index of its splat record inside a frame (slot order); null = the id itself */) {
     __shared__ float4 sA[BLEND_THREADS];
     __shared__ float4 sB[BLEND_THREADS];
     __shared__ float4 sC[BLEND_THREADS];                  // {b, depth, -, -}: 16-byte stride like sA / sB, one index shift per splat
@@ -1622,6 +1635,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
 #ifdef BLEND_TIMING
         uint32_t id_ = 0;
         if (t < todo) id_ = point_list[rng.x + (uint32_t)r * BLEND_THREADS + t];
+        if (t < todo && rec_of != nullptr) id_ = rec_of[id_];
         BT_VMWAIT(); BT(1);
         float4 a_ = {}, b_ = {}, c_ = {};
         if (t < todo) { const float4* rec = splats + 4 * (gbase + id_); a_ = rec[0]; c_ = rec[2]; b_ = rec[1]; }
@@ -1633,6 +1647,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
             const float4 a = a_, b = b_, c = c_;
 #else
             uint32_t id = point_list[rng.x + (uint32_t)r * BLEND_THREADS + t];
+            if (rec_of != nullptr) id = rec_of[id];          // (a 1 MB table, L2-resident; the sorted lists keep Gaussian ids: ties break by index)
             const float4* rec = splats + 4 * (gbase + id);
             const float4 a = rec[0];
             const float4 c = rec[2];
@@ -1928,6 +1943,7 @@ int run_pipeline(const GvfRastSettings& st, const GvfRastFrame* frames_host, int
     GVF_CHECK_LAUNCH();
 
     int nslab_blend = 1;
+    const uint32_t* blend_rec_of = nullptr;           // slot order: Gaussian id -> index of its splat record inside a frame
     if (P == 0 || nb == 0) {
         // nothing to splat: background only
         if (hipMemsetAsync(out_num_rendered, 0, sizeof(uint32_t) * F, stream) != hipSuccess) return GVF_ELAUNCH;
@@ -1967,8 +1983,24 @@ int run_pipeline(const GvfRastSettings& st, const GvfRastFrame* frames_host, int
         if (shared) {
             g_shared_calls.fetch_add(1, std::memory_order_relaxed);
             float4* rec3d = reinterpret_cast<float4*>(w.keys_alt);
+            // slot order (see activate_cov_kernel): needs the Morton order, SH input and room for the slot-ordered SH copy behind the records.
+            // GVF_RAST_SLOT_ORDER=0: measurement / test switch
+            const char* slot_env = getenv("GVF_RAST_SLOT_ORDER");
+            const size_t sh_floats = (size_t)pp.M * 3;
+            const bool slot_mode = !(slot_env && slot_env[0] == '0') && order != nullptr && colors_precomp == nullptr && sh != nullptr &&
+                                   (size_t)slices.n * (size_t)P * 64u + (size_t)P * sh_floats * 4u <= (size_t)max_rendered * 8u;
+            float* sh_by_slot = slot_mode ? reinterpret_cast<float*>(rec3d + 4 * (size_t)slices.n * (size_t)P) : nullptr;
             hipLaunchKernelGGL(activate_cov_kernel, dim3((P + 255) / 256, slices.n), dim3(256), 0, stream, *act, st.scale_modifier, P, slices,
-                               a0, a1, a2, a3, delta, rec3d);
+                               a0, a1, a2, a3, delta, rec3d, slot_mode ? w.order_alt : nullptr, sh, (int)sh_floats, sh_by_slot);
+            if (slot_mode) {
+                // thread i = slot i: records, SH rows, splat records and bin records are all read / written at i; the sorted lists keep Gaussian
+                // ids (ties break by index, as upstream's stable sort does) and the blend looks the record index up (rec_of)
+                blend_rec_of = w.order_alt;
+                hipLaunchKernelGGL(preprocess_kernel<true>, pre_grid, dim3(PRE_THREADS), sh_lds_bytes, stream, pp,
+                                   w.frames, reinterpret_cast<const float*>(rec3d), reinterpret_cast<const float*>(order), nullptr, nullptr, sh_by_slot,
+                                   nullptr, nullptr, nullptr, w.splats, nullptr, out_radii == nullptr ? nullptr : w.radii, nullptr, w.binrec,
+                                   nullptr, nslab > 1 ? w.zrange : nullptr);
+            } else
             hipLaunchKernelGGL(preprocess_kernel<true>, pre_grid, dim3(PRE_THREADS), sh_lds_bytes, stream, pp,
                                w.frames, reinterpret_cast<const float*>(rec3d), nullptr, nullptr, nullptr, colors_precomp ? nullptr : sh, colors_precomp,
                                nullptr, nullptr, w.splats, nullptr, out_radii == nullptr ? nullptr : w.radii, nullptr, w.binrec,
@@ -2053,11 +2085,11 @@ int run_pipeline(const GvfRastSettings& st, const GvfRastFrame* frames_host, int
     if (out_depth != nullptr)
         hipLaunchKernelGGL(blend_kernel<true>, dim3(ntiles, F), dim3(BLEND_THREADS), 0, stream, P, H, W, gx, gy, st.bg[0],
                            st.bg[1], st.bg[2], w.ranges, vals_sorted, w.splats, subpixel_offset,
-                           out_color, out_alpha, out_depth, nslab_blend, tile_order);
+                           out_color, out_alpha, out_depth, nslab_blend, tile_order, blend_rec_of);
     else
         hipLaunchKernelGGL(blend_kernel<false>, dim3(ntiles, F), dim3(BLEND_THREADS), 0, stream, P, H, W, gx, gy, st.bg[0],
                            st.bg[1], st.bg[2], w.ranges, vals_sorted, w.splats, subpixel_offset,
-                           out_color, out_alpha, out_depth, nslab_blend, tile_order);
+                           out_color, out_alpha, out_depth, nslab_blend, tile_order, blend_rec_of);
     GVF_CHECK_LAUNCH();
     prof_mark(stream, slot, 7);
     return GVF_OK;

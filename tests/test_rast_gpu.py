@@ -289,6 +289,16 @@ def test_shared_activation_equals_fused_path(cuda, mode, deg, bin_algo):
     for k in ("color", "alpha", "depth", "radii", "num_rendered"):
         assert torch.equal(fused[k], shared[k]), f"{k}: shared activation differs from the fused path"
     assert int(shared["num_rendered"].sum()) > 0 and float(shared["color"].std()) > 0
+    # shared activation in INDEX order (the default runs the per-frame launch over Morton slots when the call has a Morton order: records,
+    # splat records and bin records contiguous, the blend looking the record index up per Gaussian id): the same bits again
+    os.environ["GVF_RAST_SLOT_ORDER"] = "0"
+    try:
+        index_order, n2 = run()
+    finally:
+        os.environ.pop("GVF_RAST_SLOT_ORDER", None)
+    assert (n2 >= 1) == (bin_algo == "bucket")
+    for k in ("color", "alpha", "depth", "radii", "num_rendered"):
+        assert torch.equal(index_order[k], shared[k]), f"{k}: slot order differs from index order"
     # the blend's dispatch order (heaviest tiles of a frame first, blend_order_kernel) is invisible in the outputs
     os.environ["GVF_RAST_BLEND_ORDER"] = "0"
     try:
