@@ -1215,6 +1215,14 @@ constexpr int BKT_MAX_RUN = 40;
 constexpr int BKT_AUX = 64;            // per wave: minimum, maximum, total, longest run (4 x up to 16 waves)
 constexpr int BKT_LARGE_NB = 4096;     // buckets of the 1024-thread class (2049 .. 16384 keys: 0.5 .. 4 keys per bucket)
 
+#ifdef SORT_STATS
+__device__ unsigned long long g_sort_stats[16];
+extern "C" int gvf_debug_sort_stats(unsigned long long* out16, int reset) {
+    if (out16 != nullptr && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_sort_stats), sizeof(g_sort_stats)) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_sort_stats), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
 // E keys per thread, T threads, C counters per thread: n <= T E keys into NB = T C buckets
 template <int E, int T, int C>
 __device__ __forceinline__ bool tile_sort_buckets(const uint64_t* __restrict__ k, const uint32_t* __restrict__ v,
@@ -1274,6 +1282,14 @@ __device__ __forceinline__ bool tile_sort_buckets(const uint64_t* __restrict__ k
         base += w < wave ? s_aux[2 * NW + w] : 0u;
         longest = max(longest, s_aux[3 * NW + w]);
     }
+#ifdef SORT_STATS            // measurement builds only: [0] segments through the distribution sort, [1] of them sent to the network (crowded bucket),
+                             // [2] keys of [0], [3] keys of [1], [4 + min(11, longest / 8)] histogram of the longest bucket
+    if (tid == 0) {
+        atomicAdd(&g_sort_stats[0], 1ull); atomicAdd(&g_sort_stats[2], (unsigned long long)n);
+        if (longest > (uint32_t)BKT_MAX_RUN) { atomicAdd(&g_sort_stats[1], 1ull); atomicAdd(&g_sort_stats[3], (unsigned long long)n); }
+        atomicAdd(&g_sort_stats[4 + min(11u, longest >> 3)], 1ull);
+    }
+#endif
     if (longest > (uint32_t)BKT_MAX_RUN) return false;                  // workgroup-uniform
 #pragma unroll
     for (int i = 0; i < C; ++i) {
