@@ -58,8 +58,19 @@ class RasterWorkload:
         self._lib, self.R, self.dev = _lib, R, dev
         self.P, self.S, self.F, self.deg, self.M = P, S, F, deg, (deg + 1) ** 2
         self.attrs = synthetic.random_gaussians(P, sh_degree=deg, seed=seed, scale_lo=0.002, scale_hi=0.01)
-        self.gm = synthetic.gaussian_model_from(self.attrs, deg, dev)
         self.delta_cpu = synthetic.random_deltas(F, P, seed=seed + 1)
+        if os.environ.get("GVF_BENCH_PRESORT", "0") == "1":
+            # measurement aid (NOT the default workload): the same sample with its Gaussians stored in Morton order of their positions, as a
+            # caller who sorts a model once per sample would hand it over
+            q = ((self.attrs["means3D"] + 0.5).clamp(0, 1 - 1e-6) * 32).long()
+            code = torch.zeros(P, dtype=torch.long)
+            for b in range(5):
+                for a in range(3):
+                    code |= ((q[:, a] >> b) & 1) << (3 * b + a)
+            perm = torch.argsort(code, stable=True)
+            self.attrs = {k: v[perm].contiguous() for k, v in self.attrs.items()}
+            self.delta_cpu = self.delta_cpu[:, perm].contiguous()
+        self.gm = synthetic.gaussian_model_from(self.attrs, deg, dev)
         self.delta = self.delta_cpu.to(dev)
         self.cams = [camera_block(azi=15.0 * f) for f in range(F)]
         self.frames = (_lib.GvfRastFrame * F)(*[
