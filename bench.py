@@ -48,6 +48,16 @@ def parse():
     return ap.parse_args()
 
 
+def _morton_perm(xyz, bits=5):
+    """Stable argsort of the 3 x `bits`-bit Morton codes of positions in [-0.5, 0.5)^3 (GVF_BENCH_PRESORT)."""
+    q = ((xyz + 0.5).clamp(0, 1 - 1e-6) * (1 << bits)).long()
+    code = torch.zeros(xyz.shape[0], dtype=torch.long)
+    for b in range(bits):
+        for a in range(3):
+            code |= ((q[:, a] >> b) & 1) << (3 * b + a)
+    return torch.argsort(code, stable=True)
+
+
 class RasterWorkload:
     """One 4D sample resident on the device + a preallocated workspace; step() enqueues one
     gvf_rast_forward_batched() on the current stream (no host sync)."""
@@ -62,12 +72,7 @@ class RasterWorkload:
         if os.environ.get("GVF_BENCH_PRESORT", "0") == "1":
             # measurement aid (NOT the default workload): the same sample with its Gaussians stored in Morton order of their positions, as a
             # caller who sorts a model once per sample would hand it over
-            q = ((self.attrs["means3D"] + 0.5).clamp(0, 1 - 1e-6) * 32).long()
-            code = torch.zeros(P, dtype=torch.long)
-            for b in range(5):
-                for a in range(3):
-                    code |= ((q[:, a] >> b) & 1) << (3 * b + a)
-            perm = torch.argsort(code, stable=True)
+            perm = _morton_perm(self.attrs["means3D"])
             self.attrs = {k: v[perm].contiguous() for k, v in self.attrs.items()}
             self.delta_cpu = self.delta_cpu[:, perm].contiguous()
         self.gm = synthetic.gaussian_model_from(self.attrs, deg, dev)
@@ -365,9 +370,14 @@ def bench_live_render(dev, P=262_144, T=32, V=128, S=512):
     from gvfdiffusion_amd.renderers import GaussianRenderer
     from gvfdiffusion_amd.utils import orbit_cameras, render_sample_frames
     attrs = synthetic.random_gaussians(P, sh_degree=0, seed=7)
-    gm = synthetic.gaussian_model_from(attrs, 0, dev)
     g = torch.Generator().manual_seed(11)
-    delta = (torch.randn((T, P, 14), generator=g) * 0.01).to(dev)
+    delta = torch.randn((T, P, 14), generator=g) * 0.01
+    if os.environ.get("GVF_BENCH_PRESORT", "0") == "1":          # measurement aid, see RasterWorkload
+        perm = _morton_perm(attrs["means3D"])
+        attrs = {k: v[perm].contiguous() for k, v in attrs.items()}
+        delta = delta[:, perm].contiguous()
+    delta = delta.to(dev)
+    gm = synthetic.gaussian_model_from(attrs, 0, dev)
     rend = GaussianRenderer({"resolution": S, "near": synthetic.NEAR, "far": synthetic.FAR, "ssaa": 1, "bg_color": (1, 1, 1)})
     rend.pipe.kernel_size = synthetic.KERNEL_2D
     K, cams = synthetic.intrinsics().to(dev), orbit_cameras(V).to(dev)
