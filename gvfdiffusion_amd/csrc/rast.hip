@@ -755,6 +755,9 @@ constexpr int SCAN_CHUNK = 4096;
 constexpr int SORT_SMALL_N = 2048;     // size classes of the per-tile sort (R4, below)
 constexpr int SORT_LARGE_N = 16384;
 constexpr int SORT_LARGE_BLOCKS = 256, SORT_HUGE_BLOCKS = 64;   // grid of the launch that walks the two rare classes
+#ifndef SORT_LIST_BIT
+#define SORT_LIST_BIT 1
+#endif
 constexpr int SORT_MEDIUM_N = 4096, SORT_MEDIUM_BLOCKS = 768;   // the LDS class's lower half has a launch of its own (tile_sort_kernel<1>)
 __global__ __launch_bounds__(1024) void seg_sums_kernel(const uint32_t* __restrict__ cnt, int n, uint32_t* __restrict__ partial) {
     __shared__ uint32_t wsum[16];
@@ -814,7 +817,7 @@ __global__ __launch_bounds__(1024) void seg_scan_kernel(const uint32_t* __restri
             cursor[j] = run;
             if (!overflow && c[k] > (uint32_t)SORT_SMALL_N) {           // rare: a segment for the LDS / global sort classes
                 if (c[k] > (uint32_t)SORT_LARGE_N) cls[2 + n + atomicAdd(&cls[1], 1u)] = (uint32_t)j;
-                else cls[2 + atomicAdd(&cls[0], 1u)] = (uint32_t)j;
+                else cls[2 + atomicAdd(&cls[0], 1u)] = (uint32_t)j | (c[k] > (uint32_t)SORT_MEDIUM_N ? 0x80000000u : 0u);   // top bit: the upper half of the LDS class
             }
             if (j % per_frame == 0) frame_base[j / per_frame] = run;
         }
@@ -1340,7 +1343,7 @@ __global__ __launch_bounds__(256) void classify_kernel(const uint2* __restrict__
     const uint2 r = ranges[i];
     const uint32_t n = r.y - r.x;
     if (n > (uint32_t)SORT_LARGE_N) cls[2 + nseg + atomicAdd(&cls[1], 1u)] = i;
-    else if (n > (uint32_t)SORT_SMALL_N) cls[2 + atomicAdd(&cls[0], 1u)] = i;
+    else if (n > (uint32_t)SORT_SMALL_N) cls[2 + atomicAdd(&cls[0], 1u)] = i | (n > (uint32_t)SORT_MEDIUM_N ? 0x80000000u : 0u);
 }
 
 template <int MODE>   // 0: small (registers + shuffles), 1: large (dynamic LDS), 2: huge (global, in place), 3: the large class's lower half
@@ -1412,9 +1415,19 @@ __global__ __launch_bounds__(MODE == 3 ? 512 : 1024, MODE == 3 ? 2 : 1) void til
     const uint32_t* list = cls + 2 + (huge ? nseg : 0u);
     const int tid = threadIdx.x, nt = blockDim.x;
     for (uint32_t li = bid; li < count; li += stride) {
-        const uint2 rng = ranges[list[li]];
+        // the LDS class's list says in its top bit which half an entry belongs to: the launch that does NOT own a segment skips it on the list word
+        // alone (round 5: it used to read the segment's range first -- a dependent global load per skipped entry; the 1024-thread launch walked
+        // ~80 entries per workgroup to find its few: 75 us per live chunk, mostly that)
+        const uint32_t ent = list[li];
+        const bool upper = !huge && (ent >> 31) != 0u;
+#if SORT_LIST_BIT
+        if (!huge && ((MODE == 3 && upper) || (MODE == 1 && split != 0u && !upper))) continue;       // the other launch's segment
+#endif
+        const uint2 rng = ranges[huge ? ent : (ent & 0x7fffffffu)];
         const int n = (int)(rng.y - rng.x);
-        if ((MODE == 3 && n > SORT_MEDIUM_N) || (MODE == 1 && !huge && split != 0u && n <= SORT_MEDIUM_N)) continue;   // the other launch's segment
+#if !SORT_LIST_BIT                 // A/B switch: the round-4 form (decide on the range)
+        if ((MODE == 3 && n > SORT_MEDIUM_N) || (MODE == 1 && !huge && split != 0u && n <= SORT_MEDIUM_N)) continue;
+#endif
         uint64_t* k = keys + rng.x;
         const uint32_t* v = vals != nullptr ? vals + rng.x : nullptr;
         if (huge) {
