@@ -453,6 +453,42 @@ def test_live_shape_frame_matches_oracle(cuda, oracle_lib):
     assert torch.equal(images[False], images[True])          # the alpha-box rule only drops instances the blend would have skipped
 
 
+def test_live_shape_camera_batch_matches_oracle(cuda, oracle_lib, bin_algo):
+    """The live job as the product runs it since round 5: SEVERAL cameras of one timestep in one call (utils/inference_utils.py:256-269) -- shared
+    activation records, the per-frame launch over Morton slots, the blend dispatched heaviest tile first (512^2 tiles of 2-16 k instances) --
+    at full size against the ORACLE, frame by frame (the single-frame test above never enters those paths)."""
+    from gvfdiffusion_amd.renderers import GaussianRenderer
+    from gvfdiffusion_amd.utils import orbit_cameras
+    from gvfdiffusion_amd import rasterizer as R, _lib
+    P, S, views = 262_144, 512, [5, 37, 70, 101]
+    attrs = synthetic.random_gaussians(P, sh_degree=0, seed=7)
+    gm = synthetic.gaussian_model_from(attrs, 0, cuda)
+    delta = (torch.randn((1, P, 14), generator=torch.Generator().manual_seed(11)) * 0.01).to(cuda)
+    rend = GaussianRenderer({"resolution": S, "near": synthetic.NEAR, "far": synthetic.FAR, "ssaa": 1, "bg_color": (1, 1, 1)})
+    rend.pipe.use_mip_gaussian = True
+    rend.pipe.kernel_size = synthetic.KERNEL_2D
+    ext, K = orbit_cameras(128)[views].to(cuda), synthetic.intrinsics().to(cuda)
+    frames = rend.make_frames(ext, K, [0] * len(views))
+    oattrs = oracle_activated(oracle_lib, gm, delta[0], min_kernel_size=float(gm.mininum_kernel_size))
+    st = R.make_settings(S, S, 0, _lib.RAST_MODE_MIP, rend.pipe.kernel_size, 1.0, (1.0, 1.0, 1.0))
+    before = int(_lib.lib().gvf_rast_shared_activation_calls())
+    out = R.rasterize_batched(st, frames, gm.activation_struct(), gm._xyz, gm.get_features, gm._scaling, gm._rotation, gm._opacity,
+                              delta=delta, want_radii=True)
+    medium, huge = R.sort_class_counts(cuda)
+    took_shared = int(_lib.lib().gvf_rast_shared_activation_calls()) - before
+    assert (took_shared >= 1) == (bin_algo == "bucket") and medium > 0
+    for f in range(len(views)):
+        ref = oracle_render(oracle_lib, oattrs, cam_from_frame(frames[f]), S, S, 0, mode=0, kernel_size=rend.pipe.kernel_size, bg=(1.0, 1.0, 1.0),
+                            tight=True)
+        err = np.abs(out["color"][f].cpu().numpy() - ref["color"]).max(axis=0)
+        bad = (err > RAST_ATOL) & (ref["flags"] == 0)
+        radii_diff = int((out["radii"][f].cpu().numpy() != ref["radii"]).sum())
+        print(f"live shape, camera {views[f]} of a {len(views)}-camera call: D={ref['num_rendered']} (device {int(out['num_rendered'][f])}), "
+              f"max|d|={err.max():.2e}, unflagged pixels off by > 1e-3: {int(bad.sum())}, radii that differ: {radii_diff}")
+        assert abs(int(out["num_rendered"][f]) - ref["num_rendered"]) <= 64 and radii_diff <= 8
+        assert bad.mean() < 2e-4 and err.max() < 0.1
+
+
 @pytest.mark.parametrize("P,spread", [(6000, 0.02), (40_000, 0.01), (20_000, 0.012), (1500, 0.05)])
 def test_crowded_tiles_exercise_every_sort_class(cuda, oracle_lib, P, spread):
     """Per-tile sort classes: <= 2048 keys (registers), <= 4096 and <= 16384 (LDS, two launches), larger (global): a cluster of Gaussians
