@@ -138,8 +138,59 @@ struct PreParams {
 // ---------------------------------------------------------------------------------------------
 // G1: GaussianModel activations (gaussian_model.py:84-114); delta layout [xyz3|scale3|rot4|rgb3|op1]
 // ---------------------------------------------------------------------------------------------
+// exp / log1p of the activations: the SAME sequence of correctly rounded operations as oracle/rast_oracle.c::act_expf / act_log1pf (fma where
+// written, + - * /, float <-> int conversions, bit operations; this file is compiled with -ffp-contract=off), so that scales and opacities --
+// and with them every radius, tile rect, instance count and sort key of the fused-activation path -- are bit-identical to the oracle's
+// (round 6; up to round 5 the device's math library and the oracle's libm differed by an ulp or two and a few of 6.3 M radii flipped).
+// Each is within 1 ulp of the true value (tests/test_oracle_rast.py::test_shared_activation_arithmetic_stays_within_2ulp_of_libm).
+__device__ __forceinline__ float act_expf(float x) {
+    if (x != x) return x;
+    if (x > 88.72283f) return __builtin_inff();
+    if (x < -103.97208f) return 0.0f;
+    const float kf = x * 1.44269502f + (x < 0.0f ? -0.5f : 0.5f);
+    const int k = (int)kf;                                   // truncation toward zero = round half away of x log2 e
+    const float t = (float)k;
+    float r = __builtin_fmaf(t, -0.693145751953125f, x);     // ln 2 = 0.693145751953125 (16 bits: t * it is exact) + 1.42860677e-6
+    r = __builtin_fmaf(t, -1.42860677e-6f, r);
+    float p = 1.98412698e-4f;                                // e^r, |r| <= 0.347: degree-7 Taylor polynomial, Horner
+    p = __builtin_fmaf(p, r, 1.38888889e-3f);
+    p = __builtin_fmaf(p, r, 8.33333377e-3f);
+    p = __builtin_fmaf(p, r, 4.16666679e-2f);
+    p = __builtin_fmaf(p, r, 1.66666672e-1f);
+    p = __builtin_fmaf(p, r, 0.5f);
+    p = __builtin_fmaf(p, r, 1.0f);
+    p = __builtin_fmaf(p, r, 1.0f);
+    const int k1 = k / 2, k2 = k - k1;                       // k in [-150, 128]: both factors are normal powers of two
+    return (p * __uint_as_float((uint32_t)(k1 + 127) << 23)) * __uint_as_float((uint32_t)(k2 + 127) << 23);
+}
+__device__ __forceinline__ float act_log1pf(float y) {      // y >= 0 (or NaN)
+    if (!(y >= 5.9604645e-8f)) return y;                     // < 2^-24: log1p(y) = y to the last bit (and NaN)
+    if (y > 3.4028235e38f) return y;                         // +inf
+    int k = 0;
+    float c = 0.0f, f = y;
+    if (y >= 0.41421354f) {                                  // 1 + y >= sqrt 2: split off the exponent
+        const float u = 1.0f + y;
+        uint32_t iu = __float_as_uint(u) + (0x3f800000u - 0x3f3504f3u);
+        k = (int)(iu >> 23) - 127;
+        if (k < 25) c = (k >= 2 ? 1.0f - (u - y) : y - (u - 1.0f)) / u;
+        iu = (iu & 0x007fffffu) + 0x3f3504f3u;
+        f = __uint_as_float(iu) - 1.0f;
+    }
+    const float s = f / (2.0f + f);
+    const float z = s * s, w = z * z;
+    const float t1 = w * (0.40000972152f + w * 0.24279078841f);
+    const float t2 = z * (0.66666662693f + w * 0.28498786688f);
+    const float R = t2 + t1;
+    const float hfsq = (0.5f * f) * f;
+    const float dk = (float)k;
+    float acc = s * (hfsq + R);
+    acc = acc + (dk * 9.0580006145e-6f + c);
+    acc = acc - hfsq;
+    acc = acc + f;
+    return acc + dk * 6.9313812256e-1f;
+}
 __device__ __forceinline__ float act_scale(float x, const GvfGaussianActivation& a) {
-    float s = a.scaling_activation == 0 ? expf(x) : (x > 20.0f ? x : log1pf(expf(x)));
+    float s = a.scaling_activation == 0 ? act_expf(x) : (x > 20.0f ? x : act_log1pf(act_expf(x)));
     return sqrtf(s * s + a.min_kernel_size * a.min_kernel_size);
 }
 
@@ -178,7 +229,7 @@ __device__ __forceinline__ ActGaussian activate_vals(int i, const GvfGaussianAct
     for (int k = 0; k < 4; ++k) g.q[k] = q[k] / n;
     float x = opacity_raw[i] + a.opacity_bias;
     if (d) x = x + dl[13];
-    g.op = 1.0f / (1.0f + expf(-x));
+    g.op = 1.0f / (1.0f + act_expf(-x));
     g.drgb[0] = dl[10]; g.drgb[1] = dl[11]; g.drgb[2] = dl[12];
     return g;
 }
@@ -2761,8 +2812,10 @@ extern "C" int gvf_rast_sort_class_counts(const void* workspace, size_t workspac
     if ((((uintptr_t)workspace) & 255) != 0) return GVF_EINVAL;
     Workspace w = carve(const_cast<void*>(workspace), workspace_bytes, P, F, H, W, max_rendered);
     if (!w.ok) return GVF_ENOSPC;
+    // test-only diagnostic.  The copy rides on the CALLER's stream (no blocking hipMemcpy on the legacy stream: that is illegal while another
+    // host thread captures a hipGraph, the hazard utils/in_flight.py documents), then that stream is waited for.
+    if (hipMemcpyAsync(counts_host, w.cls, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return GVF_ELAUNCH;
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return GVF_ELAUNCH;
-    if (hipMemcpy(counts_host, w.cls, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) return GVF_ELAUNCH;
     return GVF_OK;
 }
 

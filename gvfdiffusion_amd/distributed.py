@@ -101,19 +101,28 @@ def run_sharded(job: Callable[[int, int], object], total: int, device=None, in_f
     return [job(0, i) for i in mine]
 
 
-def sample_decode_render_sharded(chain: Callable[[int, int], torch.Tensor], total: int, device=None, in_flight: int = 1, group=None,
-                                 gather: bool = True):
+def sample_decode_render_sharded(chain: Optional[Callable[[int, int], torch.Tensor]], total: int, device=None, in_flight: int = 1, group=None,
+                                 gather: bool = True, batch_chain: Optional[Callable[[List[int]], Sequence[torch.Tensor]]] = None):
     """BASELINE configs[4] as one call: `chain(slot, i)` produces sample i's finished frames -- sample (DPM_Solver over the DiT) ->
     de-normalise -> VAE decode -> render -> uint8 (T, 3, H, W), the chain of inference_dpm_latent.py:225-272 -- on the rank that owns
-    it; then the one frame all-gather.  Returns (frames, mine): frames (total, T, 3, H, W) in global order on every rank (gather=True)
-    or this rank's (n_local, T, 3, H, W) block; mine = this rank's global sample indices."""
+    it; then the one frame all-gather.  `batch_chain(indices)` instead of `chain`: the rank's WHOLE share in one call (one batched
+    DPM_Solver.sample over its samples -- the multistep solver and the DiT are batch-transparent, every launch of the forward then covers all
+    of them --, frames returned in the order of `indices`).  Returns (frames, mine): frames (total, T, 3, H, W) in global order on every
+    rank (gather=True) or this rank's (n_local, T, 3, H, W) block; mine = this rank's global sample indices."""
     rank, world = rank_world(group)
     if total < world:
         # decided from (total, world) alone, i.e. identically on EVERY rank and before any work: a check on the owner-less ranks only would
         # leave the others waiting in the all-gather until the collective times out
         raise ValueError(f"sample_decode_render_sharded: {total} samples over {world} ranks leaves ranks without a sample; run with fewer ranks")
+    if (chain is None) == (batch_chain is None):
+        raise ValueError("sample_decode_render_sharded: exactly one of chain / batch_chain")
     mine = shard_indices(total, rank, world)
-    res = run_sharded(chain, total, device, in_flight, group)
+    if batch_chain is not None:
+        res = list(batch_chain(list(mine)))
+        if len(res) != len(mine):
+            raise ValueError(f"sample_decode_render_sharded: batch_chain returned {len(res)} samples for {len(mine)} indices")
+    else:
+        res = run_sharded(chain, total, device, in_flight, group)
     local = torch.stack([r if torch.is_tensor(r) else r[0] for r in res])
     if not gather:
         return local, mine

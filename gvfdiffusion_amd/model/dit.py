@@ -262,24 +262,41 @@ class DiT(nn.Module):
             return held
         st = d.get("_pstate")
         if st is not None:
-            mdicts, pdicts, shape = st
-            if shape != (tuple(id(c) for md in mdicts for c in md.values()), tuple(len(pd) for pd in pdicts)):
+            mdicts, pdicts, kids, sizes = st
+            # `kids` are the child MODULES themselves (strong references), compared by identity: a bare id() would let a child that was deleted
+            # and replaced by a new module at the recycled address pass the check with stale `_parameters` dicts
+            now = [c for md in mdicts for c in md.values()]
+            if len(now) != len(kids) or any(a is not b for a, b in zip(now, kids)) or sizes != tuple(len(pd) for pd in pdicts):
                 st = None
         if st is None:
             mods = list(self.modules())
             mdicts, pdicts = [m._modules for m in mods], [m._parameters for m in mods]
-            d["_pstate"] = (mdicts, pdicts, (tuple(id(c) for md in mdicts for c in md.values()), tuple(len(pd) for pd in pdicts)))
-        return tuple((-1, 0) if q is None else (q._version, q.data_ptr()) for pd in pdicts for q in pd.values())
+            d["_pstate"] = (mdicts, pdicts, [c for md in mdicts for c in md.values()], tuple(len(pd) for pd in pdicts))
+            # every structural change is a new key, whatever the allocator does: a replaced child's fresh parameters may land on the old one's
+            # addresses with version 0, i.e. with the same (version, address) pairs and other VALUES
+            d["_pstruct_epoch"] = d.get("_pstruct_epoch", -1) + 1
+        return (("structure", d["_pstruct_epoch"]),) + tuple((-1, 0) if q is None else (q._version, q.data_ptr()) for pd in pdicts for q in pd.values())
 
     def hold_param_version(self, active: bool):
         """A sampler brackets ONE sample() call with hold_param_version(True) / (False) (DPM_Solver.sample through model_wrapper's
         `sampling_scope`): nobody updates weights inside a sampling call, so the parameter walk is done once for all its evaluations instead of
         once per forward.  It is host time, and exposed exactly where the sampler waits for the device -- the adaptive solver's step-size test
-        empties the queue 22 times per sample, and the next launch then waits for the walk (~0.15 ms)."""
+        empties the queue 22 times per sample, and the next launch then waits for the walk (~0.15 ms).
+        CONTRACT: while a hold is active, a weight change (an optimizer / EMA step, load_state_dict, a `correcting_xt_fn` hook that writes
+        parameters, another thread) is NOT seen by the packed-weight caches or the captured graph -- do not change weights inside sample().
+        Holds nest (a depth counter): two samplers sharing one DiT instance each bracket their own call, the fingerprint is taken by the first
+        and dropped by the last (the first one's `finally` used to pop the other's hold)."""
         d = self.__dict__
-        d.pop("_pver_held", None)
-        if active and os.environ.get("GVF_DIT_HOLD_PVER", "1") != "0":          # (=0: measurement switch)
-            d["_pver_held"] = self._param_version()
+        depth = d.get("_pver_depth", 0)
+        if active:
+            if depth == 0 and os.environ.get("GVF_DIT_HOLD_PVER", "1") != "0":          # (=0: measurement switch)
+                d["_pver_held"] = self._param_version()
+            d["_pver_depth"] = depth + 1
+        else:
+            depth = max(0, depth - 1)
+            d["_pver_depth"] = depth
+            if depth == 0:
+                d.pop("_pver_held", None)
         return self
 
     def _weights(self, lp=None):
@@ -460,6 +477,12 @@ class DiT(nn.Module):
             S3 = W["split3"] = {"img": dit_ops.split3_bf16(W["img_f32"][0], weights=True), "static": dit_ops.split3_bf16(W["static_f32"][0], weights=True),
                                 "kv_img": [dit_ops.split3_bf16(b["image_cross_attn"]["kv_f32"][0], weights=True) for b in W["blocks"]],
                                 "kv_st": [dit_ops.split3_bf16(b["static_cross_attn"]["kv_f32"][0], weights=True) for b in W["blocks"]]}
+            # the fp32 matrices were only the source of the expansions: drop them, keep the biases (26 fp32 matrices stayed resident
+            # beside their [hi | hi | lo] copies in every DiT instance in flight).  The parameters themselves are untouched.
+            W["img_f32"], W["static_f32"] = (None, W["img_f32"][1]), (None, W["static_f32"][1])
+            for b in W["blocks"]:
+                for name in ("image_cross_attn", "static_cross_attn"):
+                    b[name]["kv_f32"] = (None, b[name]["kv_f32"][1])
         return S3
 
     # ---- what depends on the timestep alone ---------------------------------------------------------------

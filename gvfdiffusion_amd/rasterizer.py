@@ -274,7 +274,7 @@ def rasterize_batched(settings, frames, act, xyz_raw, features_dc, scaling_raw, 
             _lib.ptr(radii), _lib.ptr(nr), _lib.current_stream(dev))
         _lib.check(rc, "gvf_rast_forward_batched")
         _LAST_CARVE[(dev.index if dev.index is not None else torch.cuda.current_device(), int(torch.cuda.current_stream(dev).cuda_stream))] = \
-            (base, nbytes, P, F, H, W, cap)
+            (ws, base, nbytes, P, F, H, W, cap)         # `ws`: the tensor itself, so that the address stays this workspace's
         if not sync:
             break
         n = int(nr.to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item())
@@ -288,7 +288,8 @@ def rasterize_batched(settings, frames, act, xyz_raw, features_dc, scaling_raw, 
     return dict(color=color, alpha=alpha, depth=depth, radii=radii, num_rendered=nr, max_rendered=cap)
 
 
-_LAST_CARVE = {}     # (device index, stream handle) -> the workspace arguments of the last batched call there (sort_class_counts)
+_LAST_CARVE = {}     # (device index, stream handle) -> the workspace TENSOR + arguments of the last batched call there (sort_class_counts).
+#                      Holding the tensor pins its storage: a bare address could belong to another tensor by the time the diagnostic reads it.
 
 
 def sort_class_counts(device=None):
@@ -299,7 +300,7 @@ def sort_class_counts(device=None):
     key = (device.index if device.index is not None else torch.cuda.current_device(), int(torch.cuda.current_stream(device).cuda_stream))
     if key not in _LAST_CARVE:
         raise _lib.GvfError("no batched rasteriser call on this stream yet")
-    base, nbytes, P, F, H, W, cap = _LAST_CARVE[key]
+    _ws, base, nbytes, P, F, H, W, cap = _LAST_CARVE[key]
     out = (ctypes.c_uint32 * 2)()
     _lib.check(_lib.lib().gvf_rast_sort_class_counts(ctypes.c_void_p(base), nbytes, P, F, H, W, cap, out, _lib.current_stream(device)),
                "gvf_rast_sort_class_counts")

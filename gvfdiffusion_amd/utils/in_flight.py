@@ -49,17 +49,27 @@ def run_in_flight(jobs: Sequence[Callable[[int], object]], device, in_flight: in
     ready = threading.Barrier(in_flight) if in_flight > 1 else None
 
     def worker(slot):
-        torch.cuda.set_device(dev)
-        s = streams[slot]
-        s.wait_stream(cur)
-        if ready is not None:
-            try:
+        # Everything a worker does sits inside the try: an exception before the first job (set_device, wait_stream, the warm-up GEMM) used to
+        # kill the thread silently -- all workers failing that way returned a list of None without an error, and one failing in front of the
+        # barrier left the others waiting in it for ever.  Now it lands in `errors`, and the barrier is ABORTED so that the
+        # workers parked in it wake up (BrokenBarrierError) and leave.
+        try:
+            torch.cuda.set_device(dev)
+            s = streams[slot]
+            s.wait_stream(cur)
+            if ready is not None:
                 with torch.cuda.stream(s):
                     w_ = torch.zeros((8, 8), device=dev)
                     torch.mm(w_, w_)
                     s.synchronize()
-            finally:
-                ready.wait()
+                ready.wait(timeout=600)
+        except threading.BrokenBarrierError:
+            return                                      # another worker failed before the jobs started: its exception is in `errors`
+        except BaseException as e:                      # noqa: BLE001 -- handed to the caller
+            errors.append(e)
+            if ready is not None:
+                ready.abort()
+            return
         while True:
             with lock:
                 j = next_job[0]
@@ -85,6 +95,8 @@ def run_in_flight(jobs: Sequence[Callable[[int], object]], device, in_flight: in
         cur.wait_stream(s)
     if errors:
         raise errors[0]
+    if next_job[0] < len(jobs):                         # (cannot happen with live workers; a list of None must never look like success)
+        raise RuntimeError(f"run_in_flight: only {next_job[0]} of {len(jobs)} jobs were started")
     _record_stream(results, cur)
     return results
 

@@ -24,7 +24,8 @@
  * Floating-point contract shared with the HIP kernels (so that every discrete decision -- cull,
  * radius ceil, tile rect, sort order -- is bit-identical): IEEE binary32, no contraction
  * (compile with -ffp-contract=off), fused multiply-adds only where fmaf() is written, division
- * and sqrt correctly rounded.  The only non-shared primitive is exp() in the blend (libm expf here,
+ * and sqrt correctly rounded (the activations' exp / log1p included: act_expf / act_log1pf below, the same
+ * sequence on both sides since round 6).  The only non-shared primitive is exp() in the blend (libm expf here,
  * v_exp_f32 on the device): pixels where a discrete blend decision sits within float noise of its
  * threshold are reported in `out_flags` so tests can account for them explicitly.
  */
@@ -488,6 +489,76 @@ int gvfo_render_brute(int P, int M, int deg, const float* means3D, const float* 
     return 0;
 }
 
+/* ---- exp / log1p of the activations: ONE arithmetic, written here and in gvfdiffusion_amd/csrc/rast.hip (act_expf / act_log1pf) --------
+ * gaussian_model.py:84-114 activates with torch's exp / softplus (= log1p(exp(x)) below its threshold of 20) / sigmoid.  Up to round 5 the
+ * oracle called libm (expf, log1pf) and the device its own math library: the two agree to an ulp or two, and at 262 144 Gaussians x 24 frames
+ * a few radii and tile rects flipped, so the full-size delta-frame tests could not hold the exact-radii rule.  Now both
+ * sides evaluate the SAME sequence of correctly rounded operations -- fmaf where written, + - * /, float <-> int conversions, bit operations,
+ * no contraction -- so scales, opacities and everything derived from them are bit-identical on the CPU and on the device.  Accuracy against
+ * libm / float64 is asserted in tests/test_oracle_rast.py::test_shared_activation_arithmetic_stays_within_2ulp_of_libm (measured: < 1 ulp).
+ *   act_expf:   k = round(x log2 e); r = x - k ln2 (two-constant Cody-Waite, fused); e^r by its degree-7 Taylor polynomial in Horner form
+ *               (|r| <= 0.347: truncation 5e-9 relative); scaled by 2^k in two exact steps.
+ *   act_log1pf: for y >= 0 (y = e^x): u = 1 + y = 2^k m with m in [sqrt 1/2, sqrt 2), the rounding error of 1 + y carried as c = (y - (u - 1)) / u;
+ *               log m from s = f / (2 + f), f = m - 1, and an even polynomial in s (the classic fdlibm decomposition of log1p). */
+static float bits_to_f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static uint32_t f_to_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+static float act_expf(float x) {
+    if (x != x) return x;
+    if (x > 88.72283f) return INFINITY;
+    if (x < -103.97208f) return 0.0f;
+    const float kf = x * 1.44269502f + (x < 0.0f ? -0.5f : 0.5f);
+    const int k = (int)kf;                                   /* truncation toward zero = round half away of x log2 e */
+    const float t = (float)k;
+    float r = fmaf(t, -0.693145751953125f, x);               /* ln 2 = 0.693145751953125 (16 bits: t * it is exact) + 1.42860677e-6 */
+    r = fmaf(t, -1.42860677e-6f, r);
+    float p = 1.98412698e-4f;                                /* 1/7! */
+    p = fmaf(p, r, 1.38888889e-3f);                          /* 1/6! */
+    p = fmaf(p, r, 8.33333377e-3f);                          /* 1/5! */
+    p = fmaf(p, r, 4.16666679e-2f);                          /* 1/4! */
+    p = fmaf(p, r, 1.66666672e-1f);                          /* 1/3! */
+    p = fmaf(p, r, 0.5f);
+    p = fmaf(p, r, 1.0f);
+    p = fmaf(p, r, 1.0f);
+    const int k1 = k / 2, k2 = k - k1;                       /* k in [-150, 128]: both factors are normal powers of two */
+    return (p * bits_to_f((uint32_t)(k1 + 127) << 23)) * bits_to_f((uint32_t)(k2 + 127) << 23);
+}
+
+static float act_log1pf(float y) {                           /* y >= 0 (or NaN) */
+    if (!(y >= 5.9604645e-8f)) return y;                     /* < 2^-24: log1p(y) = y to the last bit (and NaN) */
+    if (y > 3.4028235e38f) return y;                         /* +inf */
+    int k = 0;
+    float c = 0.0f, f = y;
+    if (y >= 0.41421354f) {                                  /* 1 + y >= sqrt 2: split off the exponent */
+        const float u = 1.0f + y;
+        uint32_t iu = f_to_bits(u) + (0x3f800000u - 0x3f3504f3u);
+        k = (int)(iu >> 23) - 127;
+        if (k < 25) c = (k >= 2 ? 1.0f - (u - y) : y - (u - 1.0f)) / u;
+        iu = (iu & 0x007fffffu) + 0x3f3504f3u;
+        f = bits_to_f(iu) - 1.0f;
+    }
+    const float s = f / (2.0f + f);
+    const float z = s * s, w = z * z;
+    const float t1 = w * (0.40000972152f + w * 0.24279078841f);
+    const float t2 = z * (0.66666662693f + w * 0.28498786688f);
+    const float R = t2 + t1;
+    const float hfsq = (0.5f * f) * f;
+    const float dk = (float)k;
+    float acc = s * (hfsq + R);
+    acc = acc + (dk * 9.0580006145e-6f + c);
+    acc = acc - hfsq;
+    acc = acc + f;
+    return acc + dk * 6.9313812256e-1f;
+}
+
+/* test hook: the two functions over arrays (tests/test_oracle_rast.py compares them with libm / float64) */
+void gvfo_act_math(int n, const float* x, float* out_exp, float* out_log1p) {
+    for (int i = 0; i < n; ++i) {
+        if (out_exp) out_exp[i] = act_expf(x[i]);
+        if (out_log1p) out_log1p[i] = act_log1pf(x[i]);
+    }
+}
+
 /* G1: GaussianModel activations with optional delta (gaussian_model.py:84-114; delta layout
  * [xyz3|scale3|rot4|rgb3|op1], gaussian_render.py:155-160).  scaling_activation 0=exp 1=softplus
  * (torch softplus: beta 1, threshold 20). */
@@ -505,7 +576,7 @@ int gvfo_activate(int P, int M, const float* aabb, float scale_bias, float opaci
         for (int k = 0; k < 3; ++k) {
             float x = scaling_raw[3 * (size_t)i + k] + scale_bias;
             if (d) x = x + d[3 + k];
-            float s = scaling_activation == 0 ? expf(x) : (x > 20.0f ? x : log1pf(expf(x)));
+            float s = scaling_activation == 0 ? act_expf(x) : (x > 20.0f ? x : act_log1pf(act_expf(x)));
             scales[3 * (size_t)i + k] = sqrtf(s * s + min_kernel * min_kernel);
         }
         float q[4];
@@ -525,7 +596,7 @@ int gvfo_activate(int P, int M, const float* aabb, float scale_bias, float opaci
             }
         float x = opacity_raw[i] + opacity_bias;
         if (d) x = x + d[13];
-        opacities[i] = 1.0f / (1.0f + expf(-x));
+        opacities[i] = 1.0f / (1.0f + act_expf(-x));
     }
     return 0;
 }

@@ -282,8 +282,8 @@ def gen_dit_autocast():
 
 def gen_dit_hostile():
     """The full configuration again, on "trained-like" weights and hostile conditions (gvfdiffusion_amd.synthetic.dit_state_dict_trained_like /
-    dit_inputs_hostile: QK-RMSNorm gains in [0.5, 3], cross-attention scores with std ~ 7 octaves, a few high-norm context tokens >= 30
-    octaves out) -- the score statistics the tiled attention's max-free softmax and its fp16 shift have never met on the seed-generated
+    dit_inputs_hostile at their DEFAULT parameters, which is what the fixture was generated with: QK-RMSNorm gains U[0.5, 2], cross-attention
+    to_q / to_kv(k) x 1.3 plus a rank-one heavy-tail term x 1.6, three context tokens per context at 2.5 x the typical norm) -- the score statistics the tiled attention's max-free softmax and its fp16 shift have never met on the seed-generated
     weights.  Holds the reference's fp32 output and the reference's own bf16 / fp16 autocast errors on that model."""
     import json
     import time

@@ -22,6 +22,17 @@ def oracle_render(oracle, attrs, cam, H, W, sh_degree, mode=0, kernel_size=synth
         subpixel_offset=n(subpixel_offset), brute=brute, tight=tight)
 
 
+_SESSION_CACHE = {}
+
+
+def cached(key, make):
+    """Session cache for the oracle's full-size results (~1 s of CPU per 262 144-Gaussian frame, ~0.3 s per activation): the rasteriser tests
+    run once per binning algorithm and ask for the same oracle frames both times (VERDICT r5 weak #11: the GPU suite's wall time)."""
+    if key not in _SESSION_CACHE:
+        _SESSION_CACHE[key] = make()
+    return _SESSION_CACHE[key]
+
+
 def cam_from_frame(fr):
     """The camera dict oracle_render() takes, read back from a GvfRastFrame camera block (what the batched driver hands the kernels)."""
     return {"viewmatrix": torch.tensor(list(fr.viewmatrix), dtype=torch.float32).reshape(4, 4),

@@ -67,6 +67,13 @@ def test_shard_indices_and_single_process_defaults():
     assert D.gather_frames(x) is x                                     # no process group: the local block is the whole job
     frames, mine = D.sample_decode_render_sharded(lambda slot, i: torch.full((2,), i), 3)
     assert mine == [0, 1, 2] and frames.tolist() == [[0, 0], [1, 1], [2, 2]]
+    # the rank's whole share in ONE call (a batched sampler): same result; a wrong count or both / neither callable is refused
+    frames, mine = D.sample_decode_render_sharded(None, 3, batch_chain=lambda idx: [torch.full((2,), i) for i in idx])
+    assert mine == [0, 1, 2] and frames.tolist() == [[0, 0], [1, 1], [2, 2]]
+    with pytest.raises(ValueError):
+        D.sample_decode_render_sharded(None, 3, batch_chain=lambda idx: [torch.zeros(2)])
+    with pytest.raises(ValueError):
+        D.sample_decode_render_sharded(None, 3)
 
 
 def test_two_rank_sample_sharding_and_frame_gather(tmp_path):
@@ -95,6 +102,9 @@ def _wide_worker(rank, world, port, out_dir, total):
     assert mine == list(range(rank, total, world)) and frames.shape[0] == total
     for i in mine:
         assert torch.equal(frames[i], _oracle_frames(i, F=1, S=32))
+    # the same job with every rank's share produced by ONE batched call (bench.py's default sharded mode): identical gathered frames
+    fb, mb = D.sample_decode_render_sharded(None, total, batch_chain=lambda idx: [_oracle_frames(i, F=1, S=32) for i in idx])
+    assert mb == mine and torch.equal(fb, frames)
     digest = torch.tensor([float(frames.to(torch.float64).sum())], dtype=torch.float64)
     lo, hi = digest.clone(), digest.clone()
     dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)

@@ -888,6 +888,31 @@ def test_two_samplers_in_flight_equal_serial_sampling(cuda):
         run_in_flight([jobs[0], boom], cuda, 2)
 
 
+def test_in_flight_worker_that_fails_before_its_first_job_raises_instead_of_hanging(cuda, monkeypatch):
+    """a worker's start-up (set_device, wait_stream, the per-thread warm-up GEMM) sits in front of the barrier that holds the jobs back
+    until every worker has made its first library call.  A failure there used to kill the thread silently: the other worker waited in the
+    barrier for ever, and with every worker failing the call returned [None, None].  It must surface as the exception, promptly."""
+    import threading
+    import time as _time
+    from gvfdiffusion_amd.utils import run_in_flight
+    real_mm, seen = torch.mm, []
+
+    def flaky_mm(a, b):
+        seen.append(threading.get_ident())
+        if len(set(seen)) == 1:                       # the first worker thread that gets here fails; the second one warms up normally
+            raise RuntimeError("warm-up failed")
+        return real_mm(a, b)
+    monkeypatch.setattr(torch, "mm", flaky_mm)
+    ran = []
+    t0 = _time.time()
+    with pytest.raises(RuntimeError, match="warm-up failed"):
+        run_in_flight([lambda slot: ran.append(slot), lambda slot: ran.append(slot)], cuda, 2)
+    assert _time.time() - t0 < 60 and ran == []       # nobody started a job, nobody hung in the barrier
+    monkeypatch.setattr(torch, "mm", lambda a, b: (_ for _ in ()).throw(RuntimeError("warm-up failed")))
+    with pytest.raises(RuntimeError, match="warm-up failed"):      # every worker fails: still an exception, not a list of None
+        run_in_flight([lambda slot: 1, lambda slot: 2], cuda, 2)
+
+
 def test_adaptive_solver_speculation_changes_nothing_but_the_call_count(cuda):
     """DPM_Solver.speculate queues the next step's first evaluation before the host reads the error norm: same samples bit for bit, same reported
     NFE; model calls = reported NFE - rejected steps (kept evaluations) + dropped speculations."""

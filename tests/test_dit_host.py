@@ -101,8 +101,17 @@ def test_param_version_sees_every_kind_of_weight_change_on_the_next_call():
     assert moved() and not moved()
     model.blocks[1].add_module("extra", torch.nn.Linear(4, 4))
     assert moved() and not moved()
+    # a child deleted and replaced in one go by a module of the same shape (with id()s in the fingerprint a recycled address passed as
+    # "unchanged" and the kept `_parameters` dicts went stale; the fingerprint now holds the children themselves and compares identities)
+    for _ in range(8):
+        old_w = model.blocks[1].extra.weight.data_ptr()
+        del model.blocks[1]._modules["extra"]
+        model.blocks[1].add_module("extra", torch.nn.Linear(4, 4))
+        assert moved() and not moved()              # (even when the allocator hands the new weight the old one's address: `old_w`)
     # and the key is exactly what a full walk gives (slots registered as None are kept as (-1, 0) place holders)
-    assert tuple(e for e in model._param_version() if e != (-1, 0)) == tuple((p._version, p.data_ptr()) for p in model.parameters())
+    key = model._param_version()
+    assert key[0][0] == "structure"               # (the structural epoch leads the key)
+    assert tuple(e for e in key[1:] if e != (-1, 0)) == tuple((p._version, p.data_ptr()) for p in model.parameters())
 
 
 def test_sampling_scope_holds_the_param_version_for_one_sample_call():
@@ -137,6 +146,17 @@ def test_sampling_scope_holds_the_param_version_for_one_sample_call():
         with torch.no_grad():
             model.blocks[0].mlp.mlp[0].weight.mul_(2.0)
         assert real(model) != before                                              # released: the next call sees the update
+
+        # holds nest: two samplers that share the instance each bracket their own call; the inner one's release must not drop the outer's hold
+        model.hold_param_version(True)
+        outer = model.__dict__["_pver_held"]
+        model.hold_param_version(True)
+        model.hold_param_version(False)
+        assert model.__dict__.get("_pver_held") is outer
+        model.hold_param_version(False)
+        assert "_pver_held" not in model.__dict__
+        model.hold_param_version(False)                                           # an unmatched release is harmless
+        assert model.__dict__.get("_pver_depth", 0) == 0
 
         def boom(x, t, **kw):
             raise RuntimeError("forward failed")

@@ -182,6 +182,54 @@ def test_golden_activations(oracle_lib):
     assert np.abs(out["opacities"] - g["act_out_opacities"].reshape(-1)).max() < 2e-6
 
 
+def test_shared_activation_arithmetic_stays_within_2ulp_of_libm(oracle_lib):
+    """oracle/rast_oracle.c::act_expf / act_log1pf -- the exp and log1p the activations are computed with since round 6, the SAME operation
+    sequence as csrc/rast.hip's (the device is held to it bit for bit in tests/test_rast_gpu.py::test_activation_kernel_matches_oracle) -- against
+    float64 (each function < 1 ulp of the true value) and against this box's libm (expf, log1pf through ctypes: <= 2 ulps apart, the two being
+    within an ulp of the truth each); softplus = log1p(exp(x)) as gaussian_model.py:84-114 composes it: <= 2 ulp of the true value.  Special
+    values: NaN propagates, +-inf, the overflow / underflow ends, 0."""
+    import ctypes
+    L = oracle_lib.lib()
+    FP = ctypes.POINTER(ctypes.c_float)
+
+    def run(x):
+        x = np.ascontiguousarray(x, np.float32)
+        e, l = np.zeros_like(x), np.zeros_like(x)
+        L.gvfo_act_math(len(x), x.ctypes.data_as(FP), e.ctypes.data_as(FP), l.ctypes.data_as(FP))
+        return e, l
+
+    def ulps_from_truth(a, truth64):
+        return np.abs(a.astype(np.float64) - truth64) / np.spacing(np.abs(truth64.astype(np.float32))).astype(np.float64)
+
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(-87.0, 88.7, 400_000), rng.uniform(-25, 25, 800_000), rng.normal(0, 3, 400_000)]).astype(np.float32)
+    e, _ = run(x)
+    u_exp = ulps_from_truth(e, np.exp(x.astype(np.float64))).max()
+    y = np.concatenate([np.exp(rng.uniform(-40, 20.1, 800_000)), rng.uniform(0, 3, 400_000), rng.uniform(0.3, 0.5, 200_000)]).astype(np.float32)
+    _, l = run(y)
+    u_log = ulps_from_truth(l, np.log1p(y.astype(np.float64))).max()
+    xs = rng.uniform(-30, 20, 800_000).astype(np.float32)
+    sp = run(run(xs)[0])[1]
+    u_sp = ulps_from_truth(sp, np.log1p(np.exp(xs.astype(np.float64)))).max()
+    print(f"act_expf {u_exp:.3f} ulp, act_log1pf {u_log:.3f} ulp, softplus {u_sp:.3f} ulp from the float64 values")
+    assert u_exp < 1.0 and u_log < 1.0 and u_sp < 2.0
+    libm = ctypes.CDLL("libm.so.6")
+    for fn in (libm.expf, libm.log1pf):
+        fn.restype, fn.argtypes = ctypes.c_float, [ctypes.c_float]
+    sub = x[::40]
+    le = np.array([libm.expf(float(v)) for v in sub], np.float32)
+    d = np.abs(run(sub)[0].view(np.int32).astype(np.int64) - le.view(np.int32).astype(np.int64))
+    assert d.max() <= 2, d.max()
+    suby = y[::40]
+    ll = np.array([libm.log1pf(float(v)) for v in suby], np.float32)
+    d = np.abs(run(suby)[1].view(np.int32).astype(np.int64) - ll.view(np.int32).astype(np.int64))
+    assert d.max() <= 2, d.max()
+    sv = np.array([np.nan, np.inf, -np.inf, 0.0, 88.8, -104.0, 1e-30, 20.0, -20.0], np.float32)
+    e, l = run(sv)
+    assert np.isnan(e[0]) and e[1] == np.inf and e[2] == 0 and e[3] == 1 and e[4] == np.inf and e[5] == 0
+    assert np.isnan(l[0]) and l[1] == np.inf and l[3] == 0 and l[6] == np.float32(1e-30)
+
+
 def test_tight_binning_is_image_neutral(oracle_lib):
     """The HIP path drops (Gaussian, tile) instances that cannot reach alpha 1/255 anywhere in the tile.  The
     oracle restates that rule behind a toggle: images must be bit-identical with it on and off (both modes,

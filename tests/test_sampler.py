@@ -1,5 +1,9 @@
 """Sampler restatement (gvfdiffusion_amd/model/dpmsolver.py, host logic on torch tensors) against
-trajectories produced by the reference's model/dpmsolver.py (tests/golden/sampler_golden.npz)."""
+trajectories produced by the reference's model/dpmsolver.py (tests/golden/sampler_golden.npz).
+
+The two trajectory tests run twice: with the state on the CPU (the `-m "not gpu"` suite) and with the state on the MI355X (`gpu`-marked
+parametrisation: the driver's GPU run then holds the product's solver against the REFERENCE's trajectories too -- the GPU chain tests of
+test_pipeline_gpu.py / test_dit_gpu.py have the product's solver on both sides)."""
 import os
 
 import numpy as np
@@ -54,48 +58,70 @@ def toy_model(counter):
     return toy
 
 
+DEVICES = ["cpu", pytest.param("cuda", marks=pytest.mark.gpu)]
+
+
+def _device(name):
+    if name == "cuda" and not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device(name)
+
+
+@pytest.mark.parametrize("dev", DEVICES)
 @pytest.mark.parametrize("tag,scales", [("g11", (1.0, 1.0)), ("g23", (2.0, 3.0))])
-def test_trajectories_match_reference(tag, scales):
+def test_trajectories_match_reference(tag, scales, dev):
+    dev = _device(dev)
     _, ns = schedule()
-    xT = torch.from_numpy(G["xT"])
-    cond = {"cond_images": torch.from_numpy(G["cond_images"]), "static_latent": torch.from_numpy(G["static_latent"]),
-            "deformation_position_xyz": torch.from_numpy(G["xyz"])}
+    xT = torch.from_numpy(G["xT"]).to(dev)
+    cond = {"cond_images": torch.from_numpy(G["cond_images"]).to(dev), "static_latent": torch.from_numpy(G["static_latent"]).to(dev),
+            "deformation_position_xyz": torch.from_numpy(G["xyz"]).to(dev)}
     uncond = dict(cond); uncond["cond_images"] = torch.zeros_like(cond["cond_images"])
     cnt = {"n": 0}
     mf = model_wrapper(toy_model(cnt), ns, model_type="v", model_kwargs={}, guidance_type="classifier-free",
                        guidance_scale=scales[0], guidance_scale2=scales[1], condition=cond, unconditional_condition=uncond)
     w = mf(xT, torch.tensor([0.7, 0.7]))
-    np.testing.assert_allclose(w.numpy(), G[f"wrap_{tag}"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(w.cpu().numpy(), G[f"wrap_{tag}"], rtol=1e-5, atol=1e-6)
     solver = DPM_Solver(mf, ns, algorithm_type="dpmsolver++")
     for steps in (4, 20, 32):
         cnt["n"] = 0
         out = solver.sample(xT, steps=steps, t_start=1.0, t_end=1 / 1000, order=2, skip_type="time_uniform",
                             method="multistep")
         assert cnt["n"] == int(G[f"multistep_{tag}_{steps}_nfe"]) == steps       # exactly `steps` NFEs
-        np.testing.assert_allclose(out.numpy(), G[f"multistep_{tag}_{steps}"], rtol=2e-4, atol=2e-5)
+        assert out.device.type == dev.type
+        np.testing.assert_allclose(out.cpu().numpy(), G[f"multistep_{tag}_{steps}"], rtol=2e-4, atol=2e-5)
     cnt["n"] = 0
     out = solver.sample(xT, steps=12, t_start=1.0, t_end=1 / 1000, order=2, skip_type="time_uniform", method="singlestep")
     assert cnt["n"] == int(G[f"singlestep_{tag}_12_nfe"])
-    np.testing.assert_allclose(out.numpy(), G[f"singlestep_{tag}_12"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(out.cpu().numpy(), G[f"singlestep_{tag}_12"], rtol=2e-4, atol=2e-5)
     cnt["n"] = 0
     out = solver.sample(xT, steps=100, t_start=1.0, t_end=1 / 1000, order=2, skip_type="time_uniform", method="adaptive")
     # same accept / reject decisions: the NFE the solver REPORTS is the reference's count (order evaluations per attempted step); it runs fewer,
     # because a rejected step keeps its model(x, s) for the retry (same x, same s: the reference evaluates it again)
     nfe_ref = int(G[f"adaptive_{tag}_nfe"])
     assert solver.last_nfe == nfe_ref and cnt["n"] == nfe_ref - solver.spec_stats["rejected"]
-    solver.speculate = True                                                         # (CPU tensors never speculate: the switch changes nothing here)
+    solver.speculate = True                                    # (CPU tensors never speculate: the switch changes nothing there)
     cnt["n"] = 0
     out2 = solver.sample(xT, steps=100, t_start=1.0, t_end=1 / 1000, order=2, skip_type="time_uniform", method="adaptive")
-    assert torch.equal(out, out2) and cnt["n"] == nfe_ref - solver.spec_stats["rejected"]
-    np.testing.assert_allclose(out.numpy(), G[f"adaptive_{tag}"], rtol=5e-4, atol=5e-5)
+    st = solver.spec_stats
+    assert torch.equal(out, out2) and solver.last_nfe == nfe_ref
+    if dev.type == "cpu":
+        assert cnt["n"] == nfe_ref - st["rejected"] and st["speculated"] == 0
+    else:
+        # on the device the next step's first evaluation is queued before the host waits for the error norm: one evaluation per attempted step
+        # is speculated (not behind the last), a rejected step drops its own; accepted steps then start from the speculated evaluation
+        assert st["speculated"] >= st["steps"] - 1 - st["rejected"] and st["dropped"] <= st["rejected"]
+        assert cnt["n"] == nfe_ref - st["rejected"] + st["dropped"]
+    np.testing.assert_allclose(out.cpu().numpy(), G[f"adaptive_{tag}"], rtol=5e-4, atol=5e-5)
 
 
-def test_every_solver_branch_matches_reference():
+@pytest.mark.parametrize("dev", DEVICES)
+def test_every_solver_branch_matches_reference(dev):
     """algorithm x method x order x solver_type x skip_type, 13 NFEs each, against the reference's output."""
+    dev = _device(dev)
     _, ns = schedule()
     cnt = {"n": 0}
     mf = model_wrapper(toy_model(cnt), ns, model_type="v", guidance_type="uncond")
-    xT = torch.from_numpy(G["xT"])
+    xT = torch.from_numpy(G["xT"]).to(dev)
     keys = [k for k in G.files if k.startswith("var_")]
     assert len(keys) == 28
     for key in keys:
@@ -109,6 +135,13 @@ def test_every_solver_branch_matches_reference():
         out = DPM_Solver(mf, ns, algorithm_type=alg).sample(xT, steps=13, t_start=1.0, t_end=1 / 1000, order=int(order),
                                                             skip_type=skip, method=method, solver_type=st,
                                                             denoise_to_zero=(st == "taylor"))
-        np.testing.assert_allclose(out.numpy(), G[key], rtol=5e-4, atol=5e-5, err_msg=key)
+        if dev.type == "cuda" and method == "adaptive":
+            # An adaptive walk is a chain of accept / reject decisions on an error norm; the toy network's sin / cos differ by ulps between the
+            # host's and the device's math libraries, and a norm that lands on the other side of 1.0 once changes every later step size.  Both
+            # walks are valid solutions inside the solver's own tolerance (atol 0.0078, rtol 0.05): held to that on the device (measured on the
+            # order-3 noise-prediction variant: 4e-3 relative, 33 NFE), to the reference's bits-level trajectory on the host.
+            np.testing.assert_allclose(out.cpu().numpy(), G[key], rtol=5e-2, atol=7.8e-3, err_msg=key)
+            continue
+        np.testing.assert_allclose(out.cpu().numpy(), G[key], rtol=5e-4, atol=5e-5, err_msg=key)
     x, inter = DPM_Solver(mf, ns).sample(xT, steps=6, order=2, method="multistep", return_intermediate=True, denoise_to_zero=True)
     assert len(inter) == 8 and torch.equal(inter[-1], x)
