@@ -216,8 +216,17 @@ def bench_dit(dev, nfe=32):
         return dt_
 
     def guard_fields(w_):
-        per_nfe = w_.model.attention_workgroups(1, w_.T, 512)
+        per_nfe = w_.model.attention_workgroups(w_.x.shape[0], w_.T, 512)
         return {"fallback_wgs": w_.fallback_wgs, "attention_wgs": per_nfe * nfe, "fallback_frac": round(w_.fallback_wgs / (per_nfe * nfe), 5)}
+    # GVF_BENCH_DIT_BATCH=B (measurement aid, --dit-only): the same step on a batch of B different samples in ONE forward; the line then carries
+    # ms_per_sample_forward beside ms_per_nfe and skips the B = 1 extras
+    batch = int(os.environ.get("GVF_BENCH_DIT_BATCH", "1"))
+    if batch > 1:
+        wb = DiTWorkload(dev, input_seed=list(range(1, batch + 1)))
+        db = timed(wb)
+        return {"metric": f"DiT denoise step, batch {batch} in one forward (measurement aid)", "batch": batch, "dtype": wb.dtype_name, "nfe": nfe,
+                "ms_per_nfe": round(db / nfe * 1e3, 3), "ms_per_sample_forward": round(db / nfe / batch * 1e3, 3),
+                "value": round(batch * nfe / db, 3), "unit": "sample-steps/s"}
     w = DiTWorkload(dev)
     dt = timed(w)
     per = dt / nfe
@@ -474,29 +483,32 @@ def bench_sharded_sampling(dev, dist, rank, world, P, S, T, total_batch=8, steps
     DiT -> VAE decode -> 24-frame render, uint8 frames, then the ONE collective of the path: an all-gather of every rank's
     frames (RCCL over xGMI).  Reported: whole-job samples / frames / denoise steps per second from the max-over-ranks wall
     time, the slowest rank's per-NFE time, and the gather on its own.
-    mode "batched" (default): a rank's samples are sampled as ONE batch on one DiT (the multistep solver is batch-transparent; every
-    launch of the forward covers all of them), then decoded and rendered one by one.  mode "inflight" (GVF_BENCH_SHARD_MODE=inflight;
-    rounds 3-5): two B = 1 chains in flight on two streams, two DiT instances.  dist=None: one rank, no process group."""
+    mode "inflight" (default; the fastest of the three on every box measured, profiles/r06_sharded_modes.txt): B = 1 chains, two in flight on two
+    streams (two DiT instances).  "batched": a rank's samples sampled as ONE batch on one DiT (the multistep solver is batch-transparent; every
+    launch of the forward covers the whole batch), then decoded and rendered one by one.  "batched_inflight": two such batches in flight.
+    GVF_BENCH_SHARD_MODE selects; the N = 1 line reports all three.  dist=None: one rank, no process group."""
     import contextlib
     from gvfdiffusion_amd import distributed as D, rasterizer as R
     dist = _OneRank if dist is None else dist
-    mode = mode or os.environ.get("GVF_BENCH_SHARD_MODE", "batched")
+    mode = mode or os.environ.get("GVF_BENCH_SHARD_MODE", "inflight")
     total = max(total_batch, world)                     # every rank owns at least one sample
     mine = D.shard_indices(total, rank, world)
     b_loc = len(mine)
     timings = []
-    if mode == "batched":
-        n_fl = 1
-        e_all = E2EWorkload(dev, P, S, T, sample_seed=[rank + 1000 * k for k in range(b_loc)])
-        es = [e_all]
+    if mode in ("batched", "batched_inflight"):
+        # "batched_inflight": the rank's share as TWO batches in flight (own DiT instance, stream and host thread each): the batch amortises the
+        # per-launch costs, the second stream fills the other's tails and the decode / render of one batch runs under the sampling of the other
+        n_fl = 2 if (mode == "batched_inflight" and b_loc >= 2) else 1
+        per = (b_loc + n_fl - 1) // n_fl
+        es = [E2EWorkload(dev, P, S, T, sample_seed=[rank + 1000 * k for k in range(g * per, min(b_loc, (g + 1) * per))]) for g in range(n_fl)]
 
-        def batch_chain(idx):
-            """the rank's samples `idx` (all of them): one batched sampling call -> per-sample decode -> render -> uint8 frames"""
+        def batch_chain(idx, slot=0):
+            """this slot's samples `idx`: one batched sampling call -> per-sample decode -> render -> uint8 frames"""
             with torch.no_grad():
-                res = e_all.chain(method="multistep", steps=steps)
+                res = es[slot].chain(method="multistep", steps=steps)
                 timings.append((res[0], res[1] * len(idx)))              # (one evaluation of the batch = one NFE per sample)
                 return [R.frames_to_uint8(o.rgb) for o in res[2]]
-        run = lambda: D.sample_decode_render_sharded(None, total, device=dev, gather=False, batch_chain=batch_chain)
+        run = lambda: D.sample_decode_render_sharded(None, total, device=dev, gather=False, batch_chain=batch_chain, in_flight=n_fl)
     else:
         # a rank with several samples keeps two of them in flight (own models, stream and thread each: gvfdiffusion_amd.utils.run_in_flight)
         n_fl = 2 if b_loc >= 2 and os.environ.get("GVF_BENCH_DIT_INFLIGHT", "1") == "1" else 1
@@ -512,7 +524,11 @@ def bench_sharded_sampling(dev, dist, rank, world, P, S, T, total_batch=8, steps
 
     with torch.no_grad(), contextlib.redirect_stdout(sys.stderr):
         for e_ in es:
-            e_.chain(method="multistep", steps=4)         # warm-up, serially (graph capture)
+            # warm-up, serially, with the TIMED step count: weight conversion, condition caches, and the per-job state of this time grid -- the
+            # modulation table of its 33 times and the hipGraph captured against that table (bench_dit's timed() does the same).  A 4-step
+            # warm-up left both inside the timed region: ~2 extra eager forwards + 12 ms per DiT instance, i.e. 90 ms of a batch-8 job's 1.4 s
+            # and the reason the first batched figures of this round read 8 % slower than the B = 1 ones.
+            e_.chain(method="multistep", steps=steps)
         timings.clear()
         dist.barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -538,10 +554,11 @@ def bench_sharded_sampling(dev, dist, rank, world, P, S, T, total_batch=8, steps
     torch.cuda.empty_cache()
     return {"metric": "batch-sharded sampling (BASELINE configs[4]): 32-step DPM-Solver++ on the DiT -> VAE decode -> 24-frame "
                       "800x800 render per sample, one frame all-gather at the end",
-            "mode": mode + (": a rank's samples are sampled as ONE batch on one DiT, decoded and rendered one by one" if mode == "batched" else
-                            ": B = 1 chains, two in flight on two streams (two DiT instances)"),
-            "samples": n_samples, "samples_per_rank": b_loc, "samples_in_flight_per_rank": b_loc if mode == "batched" else n_fl,
-            "dit_batch_per_forward": b_loc if mode == "batched" else 1, "wall_ms": round(dt * 1e3, 2),
+            "mode": mode + {"batched": ": a rank's samples are sampled as ONE batch on one DiT, decoded and rendered one by one",
+                            "batched_inflight": ": a rank's samples as TWO batches in flight (two DiT instances, two streams), each sampled as one batch",
+                            }.get(mode, ": B = 1 chains, two in flight on two streams (two DiT instances)"),
+            "samples": n_samples, "samples_per_rank": b_loc, "samples_in_flight_per_rank": b_loc if mode.startswith("batched") else n_fl,
+            "dit_batch_per_forward": (b_loc + n_fl - 1) // n_fl if mode.startswith("batched") else 1, "streams_per_rank": n_fl, "wall_ms": round(dt * 1e3, 2),
             "samples_per_s": round(n_samples / dt, 3), "frames_per_s": round(n_samples * T / dt, 2),
             "denoise_steps_per_s": round(n_samples * steps / dt, 2), "ms_per_nfe_slowest_rank": round(ms_nfe, 3),
             "gather_ms": round(ms_gather, 3), "gather_us": round(ms_gather * 1e3, 1), "gather_bytes_per_rank": int(local.numel()),
@@ -903,9 +920,11 @@ def main():
                 # `serial_B1_equivalent`: 8 x (32 x the B = 1 ms/NFE of this line's dit leg + the e2e leg's decode + render) for comparison.
                 sh = bench_sharded_sampling(dev, None, 0, 1, a.gaussians, a.res, a.frames)
                 if os.environ.get("GVF_BENCH_SHARD_COMPARE", "1") == "1":
-                    alt = bench_sharded_sampling(dev, None, 0, 1, a.gaussians, a.res, a.frames, mode="inflight")
-                    sh["two_in_flight_B1"] = {k_: alt[k_] for k_ in ("wall_ms", "samples_per_s", "denoise_steps_per_s", "ms_per_nfe_per_gpu_throughput",
-                                                                     "rank0_stage_ms_per_sample", "samples_in_flight_per_rank")}
+                    keep = ("wall_ms", "samples_per_s", "denoise_steps_per_s", "ms_per_nfe_per_gpu_throughput", "rank0_stage_ms_per_sample",
+                            "samples_in_flight_per_rank", "dit_batch_per_forward", "streams_per_rank")
+                    for name_, mode_ in (("one_batch_of_8", "batched"), ("two_batches_of_4_in_flight", "batched_inflight")):
+                        alt = bench_sharded_sampling(dev, None, 0, 1, a.gaussians, a.res, a.frames, mode=mode_)
+                        sh[name_] = {k_: alt[k_] for k_ in keep}
                 e2 = out["end_to_end"]["stage_ms"]
                 ser_ms = sh["samples"] * (32 * out["dit"]["ms_per_nfe"] + e2["vae_decode"] + e2["render"])
                 sh["serial_B1_equivalent"] = {"wall_ms": round(ser_ms, 2), "denoise_steps_per_s": round(sh["samples"] * 32 / ser_ms * 1e3, 2),

@@ -189,6 +189,10 @@ __device__ __forceinline__ float act_log1pf(float y) {      // y >= 0 (or NaN)
     acc = acc + f;
     return acc + dk * 6.9313812256e-1f;
 }
+#ifdef ACT_ABL_LIBM     // timing experiment only (variant build): the device math library's expf / log1pf, as up to round 5 (NOT bit-shared with the oracle)
+#define act_expf expf
+#define act_log1pf log1pf
+#endif
 __device__ __forceinline__ float act_scale(float x, const GvfGaussianActivation& a) {
     float s = a.scaling_activation == 0 ? act_expf(x) : (x > 20.0f ? x : act_log1pf(act_expf(x)));
     return sqrtf(s * s + a.min_kernel_size * a.min_kernel_size);
@@ -1668,6 +1672,18 @@ extern "C" int gvf_debug_blend_timing(unsigned long long* device_buf, unsigned l
 #define BT_VMWAIT() do { } while (0)
 #endif
 
+#ifdef BLEND_CONSUMED
+// counting builds only (scripts/blend_consumed.py, a variant library): per size class of a (frame, tile) segment -- <= 2048 keys, <= 4096, <= 16384,
+// more -- [segments, keys sorted, keys the compositing had staged when every pixel of the tile was saturated (whole 256-key rounds)]: how much of
+// the per-tile sort's work the blend ever looks at
+__device__ unsigned long long g_blend_cons[4][3];
+extern "C" int gvf_debug_blend_consumed(unsigned long long* out12, int reset) {
+    if (out12 && hipMemcpyFromSymbol(out12, HIP_SYMBOL(g_blend_cons), sizeof(g_blend_cons)) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[12] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_blend_cons), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
+
 // DEPTH: accumulate the depth channel (diff_gauss outputs; one fma per evaluated splat that the mip path does not pay)
 template <bool DEPTH>
 __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
@@ -1708,9 +1724,16 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dacc = 0.f;
 
     BT_DECL
+#ifdef BLEND_CONSUMED
+    int rounds_done = rounds;
+#endif
     for (int r = 0; r < rounds; ++r, todo -= BLEND_THREADS) {
         BT(6);
+#ifdef BLEND_CONSUMED
+        if (__syncthreads_count(done) == BLEND_THREADS) { rounds_done = r; break; }
+#else
         if (__syncthreads_count(done) == BLEND_THREADS) break;
+#endif
         BT(0);
 #ifdef BLEND_TIMING
         uint32_t id_ = 0;
@@ -1799,6 +1822,13 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
         }
 #undef GVF_BLEND_STEP
     }
+#ifdef BLEND_CONSUMED
+    if (t == 0) {
+        const unsigned n = rng.y - rng.x, used = min(n, (unsigned)rounds_done * BLEND_THREADS);
+        const int cls = n <= 2048u ? 0 : n <= 4096u ? 1 : n <= 16384u ? 2 : 3;
+        atomicAdd(&g_blend_cons[cls][0], 1ull); atomicAdd(&g_blend_cons[cls][1], (unsigned long long)n); atomicAdd(&g_blend_cons[cls][2], (unsigned long long)used);
+    }
+#endif
     if (inside) {
         const size_t hw = (size_t)H * W;
         float* oc = out_color + (size_t)f * 3 * hw;

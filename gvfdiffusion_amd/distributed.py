@@ -107,7 +107,8 @@ def sample_decode_render_sharded(chain: Optional[Callable[[int, int], torch.Tens
     de-normalise -> VAE decode -> render -> uint8 (T, 3, H, W), the chain of inference_dpm_latent.py:225-272 -- on the rank that owns
     it; then the one frame all-gather.  `batch_chain(indices)` instead of `chain`: the rank's WHOLE share in one call (one batched
     DPM_Solver.sample over its samples -- the multistep solver and the DiT are batch-transparent, every launch of the forward then covers all
-    of them --, frames returned in the order of `indices`).  Returns (frames, mine): frames (total, T, 3, H, W) in global order on every
+    of them --, frames returned in the order of `indices`); with in_flight > 1 on a GPU the share is cut into that many batches, each run as
+    batch_chain(indices, slot) on its own stream.  Returns (frames, mine): frames (total, T, 3, H, W) in global order on every
     rank (gather=True) or this rank's (n_local, T, 3, H, W) block; mine = this rank's global sample indices."""
     rank, world = rank_world(group)
     if total < world:
@@ -118,7 +119,17 @@ def sample_decode_render_sharded(chain: Optional[Callable[[int, int], torch.Tens
         raise ValueError("sample_decode_render_sharded: exactly one of chain / batch_chain")
     mine = shard_indices(total, rank, world)
     if batch_chain is not None:
-        res = list(batch_chain(list(mine)))
+        n_groups = max(1, min(int(in_flight), len(mine)))
+        if n_groups > 1 and device is not None and torch.device(device).type == "cuda":
+            # the rank's share as `in_flight` batches, each on its own HIP stream / host thread (utils/in_flight.py: slot k needs its own
+            # mutable state, i.e. its own DiT instance): batch_chain(indices, slot).  Contiguous groups, so the results concatenate in order.
+            per = (len(mine) + n_groups - 1) // n_groups
+            groups = [mine[k * per:(k + 1) * per] for k in range(n_groups) if mine[k * per:(k + 1) * per]]
+            from .utils.in_flight import run_in_flight
+            parts = run_in_flight([lambda slot, g=g: list(batch_chain(list(g), slot)) for g in groups], device, len(groups))
+            res = [r for part in parts for r in part]
+        else:
+            res = list(batch_chain(list(mine)))
         if len(res) != len(mine):
             raise ValueError(f"sample_decode_render_sharded: batch_chain returned {len(res)} samples for {len(mine)} indices")
     else:

@@ -77,12 +77,62 @@ class NoiseScheduleVP:
             log_alphas = log_alphas[:-idx]
         return log_alphas
 
+    # ---- scalar fast path (round 6) ------------------------------------------------------------------------------------------------------
+    # The solvers keep their times on the host and ask for ONE time at a time; interpolate_fn on a one-element tensor is ~15 host tensor
+    # operations (expand, searchsorted, four gathers, ...): 130-180 us per schedule quantity, ~0.8 ms per ADAPTIVE step (two new times, five
+    # quantities), all of it between the step-size test's read-back and the next launch, i.e. with the device idle.  The
+    # same piecewise-linear formula on numpy float32 scalars -- every + - * / is the correctly rounded binary32 operation torch performs, the
+    # segment is found by bisection over the same table -- gives the SAME BITS in ~2 us (tests/test_sampler.py::test_scalar_schedule_fast_path_is_bitwise_the_tensor_path).
+    def _scalar_interp(self, x32, xs, ys):
+        """y(x) on one float32 x through the ascending keypoints xs -> ys (numpy float32 arrays): interpolate_fn's arithmetic, operation for operation."""
+        import bisect
+        lst = self.__dict__.setdefault("_scalar_lists", {})
+        key = id(xs)
+        if key not in lst:
+            lst[key] = (xs, xs.tolist())                      # (the array is kept: its id stays this table's)
+        i = min(max(bisect.bisect_right(lst[key][1], float(x32)) - 1, 0), len(lst[key][1]) - 2)
+        x0, x1, y0, y1 = xs[i], xs[i + 1], ys[i], ys[i + 1]
+        return y0 + (x32 - x0) * (y1 - y0) / (x1 - x0)
+
+    def _scalar_tables(self):
+        tb = self.__dict__.get("_scalar_np")
+        if tb is None:
+            import numpy as np
+            tb = self.__dict__["_scalar_np"] = tuple(np.ascontiguousarray(a.reshape(-1).numpy()) for a in
+                                                     (self.t_array, self.log_alpha_array, self._la_flip, self._t_flip))
+        return tb
+
+    @staticmethod
+    def _is_host_scalar(t):
+        return torch.is_tensor(t) and t.numel() == 1 and not t.is_cuda and t.is_floating_point()
+
     def marginal_log_mean_coeff(self, t):
         if self.schedule == "discrete":
+            if self._is_host_scalar(t) and self.t_array.dtype == torch.float32:
+                import numpy as np
+                ta, la, _, _ = self._scalar_tables()
+                y = self._scalar_interp(np.float32(float(t.detach().reshape(-1)[0].to(torch.float32))), ta, la)
+                return torch.tensor([float(y)], dtype=torch.float32).to(t.dtype)
             tc = t.detach().to("cpu")
             out = interpolate_fn(tc.reshape((-1, 1)).to(self.t_array.dtype), self.t_array, self.log_alpha_array).reshape((-1))
             return out.to(device=t.device, dtype=t.dtype if t.is_floating_point() else out.dtype)
         return -0.25 * t ** 2 * (self.beta_1 - self.beta_0) - 0.5 * t * self.beta_0
+
+    def host_scalars(self, t):
+        """(log_alpha, sigma, lambda, alpha) of ONE host time as python floats, memoised on the fp32 value of t: what the solver's update
+        formulas and the model wrapper's v -> epsilon conversion both need at every time they touch (alpha = exp(log_alpha) and sigma =
+        sqrt(1 - exp(2 log_alpha)) exactly as marginal_alpha / marginal_std compute them; each used to be re-derived per use)."""
+        key = t.item() if t.numel() == 1 else float(t.reshape(-1)[0])
+        memo = self.__dict__.setdefault("_host_memo", {})
+        hit = memo.get(key)
+        if hit is None:
+            la = self.marginal_log_mean_coeff(t.detach().reshape(-1)[:1].to("cpu"))
+            sig = torch.sqrt(1.0 - torch.exp(2.0 * la))
+            hit = (float(la), float(sig), float(la - torch.log(sig)), float(torch.exp(la)))
+            if len(memo) > 4096:
+                memo.clear()
+            memo[key] = hit
+        return hit
 
     def marginal_alpha(self, t):
         return torch.exp(self.marginal_log_mean_coeff(t))
@@ -102,6 +152,11 @@ class NoiseScheduleVP:
             return tmp / (torch.sqrt(Delta) + self.beta_0) / (self.beta_1 - self.beta_0)
         lc = lamb.detach().to("cpu")
         log_alpha = -0.5 * torch.logaddexp(torch.zeros((1,), dtype=lc.dtype), -2.0 * lc)
+        if self._is_host_scalar(lamb) and self._la_flip.dtype == torch.float32:
+            import numpy as np
+            _, _, laf, tf = self._scalar_tables()
+            y = self._scalar_interp(np.float32(float(log_alpha.reshape(-1)[0].to(torch.float32))), laf, tf)
+            return torch.tensor([float(y)], dtype=torch.float32).to(lamb.dtype)
         t = interpolate_fn(log_alpha.reshape((-1, 1)).to(self._la_flip.dtype), self._la_flip, self._t_flip)
         return t.reshape((-1,)).to(device=lamb.device, dtype=lamb.dtype)
 
@@ -120,16 +175,17 @@ def model_wrapper(model, noise_schedule, model_type="noise", model_kwargs={}, gu
             return (t_continuous - 1.0 / noise_schedule.total_N) * 1000.0
         return t_continuous
 
-    def _coef(fn, t, x):
-        """Schedule coefficient at time t as a factor for x.  The schedule tables live on the host and the solver keeps its times there: when all
-        samples of the call share one time (every solver in this file) the coefficient is a python float -- a kernel argument -- and nothing is
-        copied.  (As a one-element DEVICE tensor it cost a pageable host-to-device copy per use, which waits for everything queued before it:
+    def _coef(which, t, x):
+        """Schedule coefficient ("alpha" | "sigma") at time t as a factor for x.  The schedule tables live on the host and the solver keeps its
+        times there: when all samples of the call share one time (every solver in this file) the coefficient is a python float -- a kernel
+        argument -- and nothing is copied; it comes from the schedule's per-time memo (host_scalars), which the solver's own formulas fill and
+        read too.  (As a one-element DEVICE tensor it cost a pageable host-to-device copy per use, which waits for everything queued before it:
         the sampler ran in lock-step with the device and the device idled ~0.9 ms per step while the host prepared the next one.)"""
-        v = fn(t)
-        if not v.is_cuda:
-            v = v.reshape(-1)
-            if v.numel() == 1 or bool((v == v[0]).all()):
-                return float(v[0])
+        if not t.is_cuda:
+            tv = t.reshape(-1)
+            if tv.numel() == 1 or bool((tv == tv[0]).all()):
+                return noise_schedule.host_scalars(tv)[1 if which == "sigma" else 3]
+        v = (noise_schedule.marginal_std if which == "sigma" else noise_schedule.marginal_alpha)(t)
         return expand_dims(v.to(device=x.device, dtype=x.dtype), x.dim())
 
     _t_dev = {"grid": {}, "pending": None, "ring": None, "next": 0}
@@ -183,10 +239,10 @@ def model_wrapper(model, noise_schedule, model_type="noise", model_kwargs={}, gu
         if model_type == "noise":
             return output
         if model_type == "x_start":
-            return (x - _coef(noise_schedule.marginal_alpha, t_continuous, x) * output) / _coef(noise_schedule.marginal_std, t_continuous, x)
+            return (x - _coef("alpha", t_continuous, x) * output) / _coef("sigma", t_continuous, x)
         if model_type == "v":
-            return _coef(noise_schedule.marginal_alpha, t_continuous, x) * output + _coef(noise_schedule.marginal_std, t_continuous, x) * x
-        return -_coef(noise_schedule.marginal_std, t_continuous, x) * output  # score
+            return _coef("alpha", t_continuous, x) * output + _coef("sigma", t_continuous, x) * x
+        return -_coef("sigma", t_continuous, x) * output  # score
 
     def cond_grad_fn(x, t_input):
         with torch.enable_grad():
@@ -235,7 +291,7 @@ def model_wrapper(model, noise_schedule, model_type="noise", model_kwargs={}, gu
             t_input = get_model_input_time(t_continuous).to(x.device)
             cond_grad = cond_grad_fn(x, t_input)
             noise = noise_pred_fn(x, t_continuous)
-            return noise - guidance_scale * _coef(noise_schedule.marginal_std, t_continuous, x) * cond_grad
+            return noise - guidance_scale * _coef("sigma", t_continuous, x) * cond_grad
         # classifier-free
         if (guidance_scale == 1.0 and guidance_scale2 == 1.0) or unconditional_condition is None:
             return noise_pred_fn(x, t_continuous, cond=condition)
@@ -286,21 +342,9 @@ class DPM_Solver:
 
     # ---- scalar schedule helpers (host) -------------------------------------------------------
     def _sched(self, t):
-        """t: (1,) CPU tensor -> python floats (log_alpha, sigma, lambda, alpha).  Memoised on the fp32 bits of t: a step asks for the same
-        few times several times over (each evaluation is a table interpolation in ~30 host tensor ops)."""
-        key = float(t.reshape(-1)[0])
-        cache = self.__dict__.setdefault("_sched_cache", {})
-        hit = cache.get(key)
-        if hit is not None:
-            return hit
-        ns = self.noise_schedule
-        la = ns.marginal_log_mean_coeff(t)
-        sig = torch.sqrt(1.0 - torch.exp(2.0 * la))
-        out = (float(la), float(sig), float(la - torch.log(sig)), float(torch.exp(la)))
-        if len(cache) > 4096:
-            cache.clear()
-        cache[key] = out
-        return out
+        """t: (1,) CPU tensor -> python floats (log_alpha, sigma, lambda, alpha): the schedule's per-time memo (NoiseScheduleVP.host_scalars),
+        shared with the model wrapper -- a step asks for the same few times several times over."""
+        return self.noise_schedule.host_scalars(t)
 
     @staticmethod
     def _host(t):
@@ -585,13 +629,27 @@ class DPM_Solver:
         #    decides, so it can be queued BEFORE the host waits for the error norm (read through a pinned buffer and an event recorded in front
         #    of it) and the device computes while the host decides.  It pays only when rejections are rare -- a rejected step drops the result:
         #    with the 32 % of the chain above it costs 7 evaluations to hide 22 x 0.2 ms of host time (214 vs 184 ms per sample).
+        #  * round 6: the host arithmetic a step needs before it can launch anything that depends on its size -- lambda of the new s, the new t,
+        #    the intermediate time and the schedule scalars of both -- runs AFTER the step's first evaluation model(x, s) has been queued (which
+        #    needs none of it: x and s are known the moment the previous step is accepted), i.e. under 4.7 ms of device work instead of in front of
+        #    it.  Same operations on the same values in the same order of dependence: identical steps, NFE and samples.  Only a REJECTED step
+        #    (no new evaluation of model(x, s)) still pays its ~0.2 ms of host arithmetic with the device idle.
         spec_on = bool(getattr(self, "speculate", False)) and x.is_cuda
         e_pin = torch.empty(1, dtype=torch.float32).pin_memory() if spec_on else None
         known = None                                   # (x, s as float, model(x, s)) carried into the next iteration
         self.spec_stats = {"steps": 0, "rejected": 0, "speculated": 0, "dropped": 0}
+        lambda_s_stale, E_last = False, None           # the step-size update of the previous test, applied at the head of the next iteration
         while abs(float(s) - t_0) > t_err:
-            t = ns.inverse_lambda(torch.tensor([lambda_s + h], dtype=torch.float32))
             model_s = known[2] if known is not None and known[0] is x and known[1] == float(s) else None
+            if model_s is None:
+                model_s = self.model_fn(x, s)          # queued first; everything below up to the next launch is host arithmetic
+            if lambda_s_stale:
+                lambda_s = float(ns.marginal_lambda(s))
+                lambda_s_stale = False
+            if E_last is not None:                      # E == 0 (both orders agree exactly): float_power gives inf upstream, the min() clamps it
+                h = min(theta * h * (math.inf if E_last == 0.0 else E_last ** (-1.0 / order)), lambda_0 - lambda_s)
+                E_last = None
+            t = ns.inverse_lambda(torch.tensor([lambda_s + h], dtype=torch.float32))
             x_lower, lower_noise_kwargs = lower_update(x, s, t, model_s=model_s)
             x_higher = higher_update(x, s, t, **lower_noise_kwargs)
             delta = torch.max(torch.ones_like(x) * atol, rtol * torch.max(torch.abs(x_lower), torch.abs(x_prev)))
@@ -610,18 +668,19 @@ class DPM_Solver:
             else:
                 E = float(E_dev)                       # the one sync
             self.spec_stats["steps"] += 1
+            if getattr(self, "trace", None) is not None:          # diagnostics: a list -> (s, t, h, E) of every attempted step
+                self.trace.append((float(s), float(t), h, E))
             if E <= 1.0:
                 x = x_higher
                 s = t
                 x_prev = x_lower
-                lambda_s = float(ns.marginal_lambda(s))
+                lambda_s_stale = True
                 known = None if spec is None else (x, float(s), spec)
             else:
                 self.spec_stats["rejected"] += 1
                 self.spec_stats["dropped"] += int(spec is not None)
                 known = (x, float(s), lower_noise_kwargs["model_s"])
-            E_f = float(E)      # E == 0 (both orders agree exactly): float_power gives inf upstream, the min() clamps it
-            h = min(theta * h * (math.inf if E_f == 0.0 else E_f ** (-1.0 / order)), lambda_0 - lambda_s)
+            E_last = float(E)
             nfe += order
         self.last_nfe = nfe
         if self.verbose:          # the reference prints unconditionally (model/dpmsolver.py:1026); callers that sample on worker threads switch it off

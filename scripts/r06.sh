@@ -26,5 +26,32 @@ case $CASE in
     timeout 900 python bench.py 2>$O/bench_err.log | tail -1 > $O/bench_line.json; bench_summary $O/bench_line.json; tail -5 $O/bench_err.log ;;
   suite)    # the whole GPU suite with durations
     timeout 1500 python -m pytest tests -m gpu -q --durations=40 > $O/pytest.txt 2>&1; echo "pytest rc=$?"; tail -60 $O/pytest.txt ;;
+  batch)    # where does a batched forward spend its time?  kernel traces of the DiT leg at B = 1, 3, 8 (one forward covers B samples) + the GPU suite's durations
+    export GVF_BENCH_DIT_CFG3=0 GVF_BENCH_DIT_INFLIGHT=0 GVF_BENCH_DIT_OTHER_DTYPE=0 GVF_BENCH_DIT_HOSTILE=0 GVF_BENCH_DIT_NFE=8
+    for B in 1 3 8; do
+      GVF_BENCH_DIT_BATCH=$B scripts/gpu_profile.sh r06b$B --dit-only > $O/prof_b$B.log 2>&1
+      python scripts/dit_breakdown.py gpurun_out/prof_r06b$B/r06b${B}_kernel_trace.csv auto > $O/dit_kernel_breakdown_b$B.txt
+      rm -f gpurun_out/prof_r06b$B/*kernel_trace.csv
+      echo "== B=$B"; tail -1 gpurun_out/prof_r06b$B/bench_under_rocprof.log | cut -c1-300; cat $O/dit_kernel_breakdown_b$B.txt
+    done
+    unset GVF_BENCH_DIT_NFE
+    scripts/gpu_ab.sh $O/act_arith_ab.txt 3 raster "GVF_LIB=gvfdiffusion_amd/variants/libgvf_hip_actlibm.so" "GVF_X=1"
+    timeout 1500 python -m pytest tests -m gpu -q --durations=40 > $O/pytest.txt 2>&1; echo "pytest rc=$?"; tail -60 $O/pytest.txt ;;
+  ubench)   # VERDICT r5 items 6 + 9 (micro-benchmarks before any kernel work), item 4's first measurement, and the adaptive chain after the host-side changes
+    scripts/ubench/exp2_pk16.bin > $O/ubench_exp2_pk16.txt 2>&1; cat $O/ubench_exp2_pk16.txt
+    scripts/ubench/blend_step.bin > $O/ubench_blend_step.txt 2>&1; cat $O/ubench_blend_step.txt
+    for w in live bench; do GVF_LIB=gvfdiffusion_amd/variants/libgvf_hip_blendc.so python scripts/blend_consumed.py $w 2>&1 | grep -v amdgpu.ids > $O/blend_consumed_$w.txt; cat $O/blend_consumed_$w.txt; done
+    python scripts/adaptive_host_profile.py 2>&1 | grep -v amdgpu.ids | head -40 > $O/adaptive_host_profile.txt; head -12 $O/adaptive_host_profile.txt
+    scripts/gpu_ab.sh $O/e2e.txt 3 e2e "GVF_X=1"
+    scripts/gpu_ab.sh $O/dit.txt 2 dit "GVF_X=1"
+    timeout 900 python -m pytest tests/test_sampler.py tests/test_vae_gpu.py tests/test_sparse_vae_gpu.py tests/test_dit_gpu.py -m gpu -q --durations=12 -x > $O/pytest.txt 2>&1; echo "pytest rc=$?"; tail -22 $O/pytest.txt ;;
+  second)   # the fixed blend-step micro-benchmark, the bench line with the three sharded modes, and the tests touched since (durations with the oracle disk cache)
+    scripts/ubench/blend_step.bin > $O/ubench_blend_step.txt 2>&1; cat $O/ubench_blend_step.txt
+    timeout 900 python bench.py 2>$O/bench_err.log | tail -1 > $O/bench_line.json; bench_summary $O/bench_line.json; tail -3 $O/bench_err.log
+    rm -rf /tmp/gvf_oracle_cache
+    timeout 1200 python -m pytest tests/test_sampler.py tests/test_dit_gpu.py tests/test_vae_gpu.py tests/test_sparse_vae_gpu.py tests/test_distributed.py -m gpu -q --durations=12 > $O/pytest.txt 2>&1; echo "pytest rc=$?"; tail -22 $O/pytest.txt ;;
+  clocks)   # is the batched forward clock / power limited?  + the sampler test on the device after the tolerance fix
+    python scripts/dit_clock_probe.py 5 2>&1 | grep -v amdgpu.ids > $O/dit_clock_probe.txt; cat $O/dit_clock_probe.txt
+    timeout 600 python -m pytest tests/test_sampler.py -m gpu -q > $O/pytest.txt 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest.txt ;;
   *) echo "unknown case $CASE"; exit 2 ;;
 esac

@@ -1,0 +1,149 @@
+// blend_step.hip -- VERDICT r5 item 9: a LOOP-ONLY benchmark of blend_kernel's compositing step (csrc/rast.hip GVF_BLEND_STEP), 4 waves per
+// workgroup = four 8 x 8 quadrants, 8 workgroups per CU (the launch's residency), over a synthetic per-wave list of 256 entries in LDS:
+//   MODE 0  today's step: 3 ds_read_b128 + 16 vector instructions per list entry (exponent from the Cholesky factor, v_exp_f32, two predicates,
+//           3 colour fmas, T update), 4 entries per trip
+//   MODE 1  the one shape not yet priced: the exponents of 4 splats x 64 pixels from six v_mfma_f32_4x4x1_16b_f32 on the monomials
+//           (x^2, xy, y^2, x, y, 1) -- lane = pixel, the accumulator's four registers = the pixel's four splats --, computed one group AHEAD of
+//           the compositing, which is then 11 vector instructions per entry
+// Prints wave-cycles per list entry per wave and per SIMD (8 waves per SIMD resident).  Bar to build MODE 1 into the kernel: <= 26 per SIMD.
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form blend_step.hip -o blend_step.bin
+// (inner loops as compiled: 16.25 vector instructions per entry for MODE 0 = the product kernel's count, 12.0 + 1.5 MFMA for MODE 1)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+constexpr int N = 256;
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float neg_exponent(float l11, float l12, float l22, float c1, float c2, float px, float py, float lo) {
+    const float s1 = __builtin_fmaf(-l11, px, __builtin_fmaf(-l12, py, c1));
+    const float s2 = __builtin_fmaf(-l22, py, c2);
+    return __builtin_fmaf(s2, s2, __builtin_fmaf(s1, s1, -lo));
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k(float* out, long long* cyc, int reps) {
+    __shared__ float4 sA[N];            // MODE 0: {l11, l12, l22, c1}          MODE 1: {K_xx, K_xy, K_yy, K_x}
+    __shared__ float4 sB[N];            // MODE 0: {c2, log2 op, r, g}          MODE 1: {K_y, K_1, -, -}
+    __shared__ float4 sC[N];            // MODE 0: {b, depth, -, -}             MODE 1: {r, g, b, -}
+    __shared__ unsigned sList[4][N];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    {   // a splat somewhere around the tile, sigma 3-12 px (the step is branch-free: its cost does not depend on how many pairs contribute)
+        const float cx = -6.f + 28.f * ((t * 37) & 255) / 255.f, cy = -6.f + 28.f * ((t * 101) & 255) / 255.f, sg = 3.f + 9.f * ((t * 13) & 255) / 255.f;
+        const float l11 = 0.85f / sg, l12 = 0.1f / sg, l22 = 0.8f / sg, c1 = l11 * cx + l12 * cy, c2 = l22 * cy, lo = -8.6f + 2.4f * ((t * 7) & 255) / 255.f;       // opacity 2^-8.6 .. 2^-6.2: some pairs pass 1/255, no pixel ever saturates (the loop must not exit early)
+        if (MODE == 0) {
+            sA[t] = make_float4(l11, l12, l22, c1); sB[t] = make_float4(c2, lo, 0.3f, 0.5f); sC[t] = make_float4(0.7f, 1.0f, 0.f, 0.f);
+        } else {
+            sA[t] = make_float4(l11 * l11, 2.f * l11 * l12, l12 * l12 + l22 * l22, -2.f * c1 * l11);
+            sB[t] = make_float4(-2.f * c1 * l12 - 2.f * c2 * l22, c1 * c1 + c2 * c2 - lo, 0.f, 0.f); sC[t] = make_float4(0.3f, 0.5f, 0.7f, 0.f);
+        }
+        for (int w = 0; w < 4; ++w) sList[w][t] = (unsigned)((t * 5 + w * 64) & 255) * 16u;
+    }
+    __syncthreads();
+    const float pxr = (float)((wave & 1) * 8 + (lane & 7)), pyr = (float)((wave >> 1) * 8 + (lane >> 3));
+    bool done = false;
+    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
+    const long long t0 = __builtin_readcyclecounter();
+    if (MODE == 0) {
+#define STEP(J) {                                                                                                              \
+            const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(sA) + (J));               \
+            const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(sB) + (J));               \
+            const float4 c = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(sC) + (J));               \
+            const float nlog = neg_exponent(a.x, a.y, a.z, a.w, b.x, pxr, pyr, b.y);                                           \
+            const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(-nlog));                                                   \
+            const bool ok = !done && !(alpha < 1.0f / 255.0f);                                                                 \
+            const float w_raw = alpha * T;                                                                                     \
+            const float test_T = T - w_raw;                                                                                    \
+            const bool stop = ok && test_T < 0.0001f;                                                                          \
+            done = done || stop;                                                                                               \
+            const bool acc = ok != stop;                                                                                       \
+            const float wgt = acc ? w_raw : 0.0f;                                                                              \
+            C0 = __builtin_fmaf(b.z, wgt, C0); C1 = __builtin_fmaf(b.w, wgt, C1); C2 = __builtin_fmaf(c.x, wgt, C2);           \
+            T = acc ? test_T : T; }
+        for (int r = 0; r < reps; ++r) {
+            for (int jj = 0; jj < N; jj += 4) {
+                if (__all(done)) break;
+                const unsigned j0 = sList[wave][jj], j1 = sList[wave][jj + 1], j2 = sList[wave][jj + 2], j3 = sList[wave][jj + 3];
+                STEP(j0) STEP(j1) STEP(j2) STEP(j3)
+            }
+            T = T * 0.5f + 0.5f;        // keep the pixel unsaturated across repetitions (one instruction per 256 entries)
+        }
+#undef STEP
+    } else {
+        const float m[6] = {pxr * pxr, pxr * pyr, pyr * pyr, pxr, pyr, 1.0f};
+        auto exps = [&](int jj) -> f4 {           // the four exponents of the group at jj for this lane's pixel
+            const unsigned mine = sList[wave][jj + (lane & 3)];
+            const float4 qa = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(sA) + mine);
+            const float4 qb = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(sB) + mine);
+            f4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(qa.x, m[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(qa.y, m[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(qa.z, m[2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(qa.w, m[3], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(qb.x, m[4], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(qb.y, m[5], acc, 0, 0, 0);
+            return acc;
+        };
+#define STEP(J, NLOG) {                                                                                                        \
+            const float4 c = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(sC) + (J));               \
+            const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(-(NLOG)));                                                 \
+            const bool ok = !done && !(alpha < 1.0f / 255.0f);                                                                 \
+            const float w_raw = alpha * T;                                                                                     \
+            const float test_T = T - w_raw;                                                                                    \
+            const bool stop = ok && test_T < 0.0001f;                                                                          \
+            done = done || stop;                                                                                               \
+            const bool acc_ = ok != stop;                                                                                      \
+            const float wgt = acc_ ? w_raw : 0.0f;                                                                             \
+            C0 = __builtin_fmaf(c.x, wgt, C0); C1 = __builtin_fmaf(c.y, wgt, C1); C2 = __builtin_fmaf(c.z, wgt, C2);           \
+            T = acc_ ? test_T : T; }
+        for (int r = 0; r < reps; ++r) {
+            f4 cur = exps(0);
+            for (int jj = 0; jj < N; jj += 4) {
+                if (__all(done)) break;
+                const f4 nxt = exps((jj + 4) & (N - 1));          // one group ahead (the last one wraps: same work, result unused)
+                const unsigned j0 = sList[wave][jj], j1 = sList[wave][jj + 1], j2 = sList[wave][jj + 2], j3 = sList[wave][jj + 3];
+                STEP(j0, cur[0]) STEP(j1, cur[1]) STEP(j2, cur[2]) STEP(j3, cur[3])
+                cur = nxt;
+            }
+            T = T * 0.5f + 0.5f;
+        }
+#undef STEP
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    out[blockIdx.x * 256 + t] = C0 + C1 + C2 + T;
+    if (lane == 0) cyc[blockIdx.x * 4 + wave] = t1 - t0;
+}
+
+template <int MODE>
+void run(const char* name) {
+    const int reps = 200, blocks = 256 * 8;
+    float* out; long long* cyc;
+    (void)hipMalloc(&out, blocks * 256 * sizeof(float));
+    (void)hipMalloc(&cyc, blocks * 4 * sizeof(long long));
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    k<MODE><<<blocks, 256>>>(out, cyc, 4);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    k<MODE><<<blocks, 256>>>(out, cyc, reps);
+    (void)hipEventRecord(e1);
+    (void)hipDeviceSynchronize();
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    std::vector<long long> h(blocks * 4);
+    (void)hipMemcpy(h.data(), cyc, blocks * 4 * sizeof(long long), hipMemcpyDeviceToHost);
+    std::vector<float> o(256);
+    (void)hipMemcpy(o.data(), out, 256 * sizeof(float), hipMemcpyDeviceToHost);
+    double avg = 0; for (auto v : h) avg += v; avg /= h.size();
+    const double entries = (double)reps * N;
+    // 8 workgroups x 4 waves per CU = 8 waves per SIMD; wall-clock form: ns per entry per SIMD = ms * 1e6 / (entries * 8)
+    printf("%-44s %.1f counter ticks per list entry per wave = %.1f per entry per SIMD;  wall %.3f ms = %.2f ns per entry per SIMD   (checksum %.4f)\n",
+           name, avg / entries, avg / entries / 8.0, ms, ms * 1e6 / (entries * 8.0), o[5]);
+    (void)hipFree(out); (void)hipFree(cyc);
+}
+
+int main() {
+    run<0>("today's step (16 VALU + 3 ds_read_b128)");
+    run<1>("6 x v_mfma_f32_4x4x1 per 4 splats + 11 VALU");
+    run<0>("today's step (again)");
+    run<1>("MFMA form (again)");
+    return 0;
+}

@@ -50,9 +50,10 @@ def _check(cfg, B, P, L, chunk_rows=None, gain=1.0, dtype="bf16"):
     m = _model(cfg, gain=gain)
     x, q = _inputs(cfg, B, P, L)
     sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
-    with torch.no_grad():
-        ref32 = vae_ref.vae_decode(sd, cfg, x, q, cfg["num_timesteps"], "fp32")
-        ref16 = vae_ref.vae_decode(sd, cfg, x, q, cfg["num_timesteps"], dtype)
+    from oracle_cache import oracle_cached
+    with torch.no_grad():          # (the oracle's results are cached on disk by content: the fp32 one serves both operand types of a configuration)
+        ref32 = oracle_cached("vae_decode", vae_ref, (cfg, sd, x, q, "fp32"), lambda: vae_ref.vae_decode(sd, cfg, x, q, cfg["num_timesteps"], "fp32"))
+        ref16 = oracle_cached("vae_decode", vae_ref, (cfg, sd, x, q, dtype), lambda: vae_ref.vae_decode(sd, cfg, x, q, cfg["num_timesteps"], dtype))
     m = m.cuda().set_compute_dtype(dtype)
     if chunk_rows:
         m.max_chunk_rows = chunk_rows
