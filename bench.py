@@ -922,7 +922,9 @@ def main():
                 if os.environ.get("GVF_BENCH_SHARD_COMPARE", "1") == "1":
                     keep = ("wall_ms", "samples_per_s", "denoise_steps_per_s", "ms_per_nfe_per_gpu_throughput", "rank0_stage_ms_per_sample",
                             "samples_in_flight_per_rank", "dit_batch_per_forward", "streams_per_rank")
-                    for name_, mode_ in (("one_batch_of_8", "batched"), ("two_batches_of_4_in_flight", "batched_inflight")):
+                    # ("batched_inflight", two batches of 4 on two streams, is the slowest by far -- 1.5-2.8 s against 1.3-1.4 s: two persistent
+                    # attention grids and two one-workgroup-per-CU row-block grids cannot share the chip -- and is left to GVF_BENCH_SHARD_MODE)
+                    for name_, mode_ in (("one_batch_of_8", "batched"),):
                         alt = bench_sharded_sampling(dev, None, 0, 1, a.gaussians, a.res, a.frames, mode=mode_)
                         sh[name_] = {k_: alt[k_] for k_ in keep}
                 e2 = out["end_to_end"]["stage_ms"]

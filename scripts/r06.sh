@@ -53,5 +53,9 @@ case $CASE in
   clocks)   # is the batched forward clock / power limited?  + the sampler test on the device after the tolerance fix
     python scripts/dit_clock_probe.py 5 2>&1 | grep -v amdgpu.ids > $O/dit_clock_probe.txt; cat $O/dit_clock_probe.txt
     timeout 600 python -m pytest tests/test_sampler.py -m gpu -q > $O/pytest.txt 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest.txt ;;
+  streams)  # raster samples in flight 1..4 (the headline's `value`), the three sharded modes with the full-length warm-up, sampler test
+    for n in 2 3 4 2 3; do echo -n "streams $n: "; python bench.py --no-dit --no-cpu-baseline --streams $n 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['ms_per_step_serial'])"; done | tee $O/raster_streams.txt
+    GVF_BENCH_DIT_CFG3=0 GVF_BENCH_DIT_INFLIGHT=0 GVF_BENCH_DIT_OTHER_DTYPE=0 GVF_BENCH_DIT_HOSTILE=0 timeout 900 python bench.py --steps 5 2>$O/bench_err.log | tail -1 > $O/bench_line.json; bench_summary $O/bench_line.json
+    timeout 600 python -m pytest tests/test_sampler.py -m gpu -q -s 2>&1 | tail -6 ;;
   *) echo "unknown case $CASE"; exit 2 ;;
 esac
