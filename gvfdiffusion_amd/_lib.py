@@ -50,6 +50,9 @@ SIGNATURES = {
     "gvf_rast_forward_batched": (_i, [ctypes.POINTER(GvfRastSettings), ctypes.POINTER(GvfRastFrame), _i,
                                       ctypes.POINTER(GvfGaussianActivation), _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                       _i, _vp, _sz, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gvf_rast_forward_batched_u8": (_i, [ctypes.POINTER(GvfRastSettings), ctypes.POINTER(GvfRastFrame), _i,
+                                         ctypes.POINTER(GvfGaussianActivation), _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
+                                         _i, _vp, _sz, _i64, _vp, _vp, _vp]),
     "gvf_rast_backward_scratch_bytes": (_i, [_i, ctypes.POINTER(_sz)]),
     "gvf_rast_backward": (_i, [ctypes.POINTER(GvfRastSettings), ctypes.POINTER(GvfRastFrame), _i, _i,
                                _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i64, _vp, _vp, _vp, _vp, _sz,

@@ -1692,7 +1692,9 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
     const float* __restrict__ subpixel_offset, float* __restrict__ out_color,
     float* __restrict__ out_alpha, float* __restrict__ out_depth, int nslab,
     const uint32_t* __restrict__ tile_order /* [F][tiles]: workgroup blockIdx.x of frame f takes tile tile_order[f][blockIdx.x]; null = identity */,
-    const uint32_t* __restrict__ rec_of /* Gaussian id -> index of its splat record inside a frame (slot order); null = the id itself */) {
+    const uint32_t* __restrict__ rec_of /* Gaussian id -> index of its splat record inside a frame (slot order); null = the id itself */,
+    unsigned char* __restrict__ out_u8 /* non-null: the frames leave as uint8 [F][3][H][W] = clamp(rgb, 0, 1) * 255 truncated (C1's post-process,
+                                          rgb_to_u8_kernel's arithmetic on the same float) and out_color is not written */) {
     __shared__ float4 sA[BLEND_THREADS];
     __shared__ float4 sB[BLEND_THREADS];
     __shared__ float4 sC[BLEND_THREADS];                  // {b, depth, -, -}: 16-byte stride like sA / sB, one index shift per splat
@@ -1831,10 +1833,22 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
 #endif
     if (inside) {
         const size_t hw = (size_t)H * W;
-        float* oc = out_color + (size_t)f * 3 * hw;
-        oc[0 * hw + pid] = __builtin_fmaf(T, bg0, C0);
-        oc[1 * hw + pid] = __builtin_fmaf(T, bg1, C1);
-        oc[2 * hw + pid] = __builtin_fmaf(T, bg2, C2);
+        const float r0 = __builtin_fmaf(T, bg0, C0), r1 = __builtin_fmaf(T, bg1, C1), r2 = __builtin_fmaf(T, bg2, C2);
+#ifdef BLEND_ABL_NO_U8      // timing experiment only (variant build): the epilogue without the uint8 form
+        if (false) {
+#else
+        if (out_u8 != nullptr) {                   // (uniform) round 6: no fp32 frame in HBM at all when the caller wants the uint8 one
+#endif
+            unsigned char* ob = out_u8 + (size_t)f * 3 * hw;
+            ob[0 * hw + pid] = (unsigned char)(fminf(fmaxf(r0, 0.f), 1.f) * 255.0f);
+            ob[1 * hw + pid] = (unsigned char)(fminf(fmaxf(r1, 0.f), 1.f) * 255.0f);
+            ob[2 * hw + pid] = (unsigned char)(fminf(fmaxf(r2, 0.f), 1.f) * 255.0f);
+        } else {
+            float* oc = out_color + (size_t)f * 3 * hw;
+            oc[0 * hw + pid] = r0;
+            oc[1 * hw + pid] = r1;
+            oc[2 * hw + pid] = r2;
+        }
         if (out_alpha != nullptr) out_alpha[(size_t)f * hw + pid] = 1.0f - T;
         if (out_depth != nullptr) out_depth[(size_t)f * hw + pid] = Dacc;
     }
@@ -1986,12 +2000,13 @@ int run_pipeline(const GvfRastSettings& st, const GvfRastFrame* frames_host, int
                  const float* a3, const float* sh, const float* colors_precomp, const float* cov3D_precomp,
                  const float* delta, int n_delta, const float* subpixel_offset, void* workspace,
                  size_t workspace_bytes, int64_t max_rendered, float* out_color, float* out_alpha,
-                 float* out_depth, int32_t* out_radii, uint32_t* out_num_rendered, hipStream_t stream) {
+                 float* out_depth, int32_t* out_radii, uint32_t* out_num_rendered, hipStream_t stream,
+                 unsigned char* out_u8 = nullptr /* instead of out_color: uint8 frames (gvf_rast_forward_batched_u8) */) {
     const int H = st.image_height, W = st.image_width;
     if (H <= 0 || W <= 0 || P < 0 || F <= 0 || max_rendered < 0 || max_rendered > 0xFFFFFFFFll) return GVF_EINVAL;
     if (st.sh_degree < 0 || st.sh_degree > 3) return GVF_EINVAL;
     if (st.mode != GVF_RAST_MODE_MIP && st.mode != GVF_RAST_MODE_DILATE) return GVF_EINVAL;
-    if (!out_color || !out_num_rendered || !frames_host || !workspace) return GVF_EINVAL;
+    if ((out_color == nullptr) == (out_u8 == nullptr) || !out_num_rendered || !frames_host || !workspace) return GVF_EINVAL;
     if (P > 0 && colors_precomp == nullptr) {
         if (sh == nullptr || M < (st.sh_degree + 1) * (st.sh_degree + 1) || M > MAX_SH_COEFFS) return GVF_EINVAL;
     }
@@ -2195,11 +2210,11 @@ int run_pipeline(const GvfRastSettings& st, const GvfRastFrame* frames_host, int
     if (out_depth != nullptr)
         hipLaunchKernelGGL(blend_kernel<true>, dim3(ntiles, F), dim3(BLEND_THREADS), 0, stream, P, H, W, gx, gy, st.bg[0],
                            st.bg[1], st.bg[2], w.ranges, vals_sorted, w.splats, subpixel_offset,
-                           out_color, out_alpha, out_depth, nslab_blend, tile_order, blend_rec_of);
+                           out_color, out_alpha, out_depth, nslab_blend, tile_order, blend_rec_of, out_u8);
     else
         hipLaunchKernelGGL(blend_kernel<false>, dim3(ntiles, F), dim3(BLEND_THREADS), 0, stream, P, H, W, gx, gy, st.bg[0],
                            st.bg[1], st.bg[2], w.ranges, vals_sorted, w.splats, subpixel_offset,
-                           out_color, out_alpha, out_depth, nslab_blend, tile_order, blend_rec_of);
+                           out_color, out_alpha, out_depth, nslab_blend, tile_order, blend_rec_of, out_u8);
     GVF_CHECK_LAUNCH();
     prof_mark(stream, slot, 7);
     return GVF_OK;
@@ -2689,6 +2704,25 @@ extern "C" int gvf_rast_forward_batched(const GvfRastSettings* st, const GvfRast
                         features_dc, nullptr, nullptr, delta, n_delta, nullptr, workspace, workspace_bytes,
                         max_rendered, out_color, out_alpha, out_depth, out_radii, out_num_rendered,
                         (hipStream_t)stream);
+}
+
+// the batched call with the frames leaving as uint8 (the reference's post-process, utils/inference_utils.py:280-286, in the blend's epilogue)
+extern "C" int gvf_rast_forward_batched_u8(const GvfRastSettings* st, const GvfRastFrame* frames_host, int F,
+                                           const GvfGaussianActivation* act, int P, int M, const float* xyz_raw,
+                                           const float* features_dc, const float* scaling_raw,
+                                           const float* rotation_raw, const float* opacity_raw, const float* delta,
+                                           int n_delta, void* workspace, size_t workspace_bytes,
+                                           int64_t max_rendered, uint8_t* out_rgb_u8, uint32_t* out_num_rendered, void* stream) {
+    if (!st || !frames_host || !act || F <= 0 || !out_rgb_u8) return GVF_EINVAL;
+    if (P > 0 && (!xyz_raw || !features_dc || !scaling_raw || !rotation_raw || !opacity_raw)) return GVF_EINVAL;
+    if (act->scaling_activation != 0 && act->scaling_activation != 1) return GVF_EINVAL;
+    for (int f = 0; f < F; ++f) {
+        int di = frames_host[f].delta_index;
+        if (di >= 0 && (delta == nullptr || di >= n_delta)) return GVF_EINVAL;
+    }
+    return run_pipeline(*st, frames_host, F, P, M, true, act, xyz_raw, scaling_raw, rotation_raw, opacity_raw,
+                        features_dc, nullptr, nullptr, delta, n_delta, nullptr, workspace, workspace_bytes,
+                        max_rendered, nullptr, nullptr, nullptr, nullptr, out_num_rendered, (hipStream_t)stream, out_rgb_u8);
 }
 
 extern "C" int gvf_rast_backward_scratch_bytes(int P, size_t* bytes) {

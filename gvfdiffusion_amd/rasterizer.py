@@ -234,8 +234,12 @@ class _RasterizeFn(torch.autograd.Function):
 
 
 def rasterize_batched(settings, frames, act, xyz_raw, features_dc, scaling_raw, rotation_raw, opacity_raw,
-                      delta=None, want_alpha_depth=False, want_radii=False, max_rendered=None, sync=True):
+                      delta=None, want_alpha_depth=False, want_radii=False, max_rendered=None, sync=True, color_u8=False):
     """F frames in one call with GaussianModel activations + per-frame deltas fused in-kernel.
+
+    color_u8: `color` comes back as uint8 (F, 3, H, W) = clamp(rgb, 0, 1) * 255 truncated -- the reference's frame post-process
+    (utils/inference_utils.py:280-286) in the compositing kernel's epilogue (gvf_rast_forward_batched_u8; bit-identical to frames_to_uint8 of the
+    fp32 frames; no alpha / depth / radii then).
 
     frames: list of GvfRastFrame (delta_index selects the (P,14) slice of delta[n_delta,P,14]).
     With sync=False no host sync happens; the caller must check `num_rendered.sum() <= max_rendered`.
@@ -256,7 +260,9 @@ def rasterize_batched(settings, frames, act, xyz_raw, features_dc, scaling_raw, 
     F = len(frames)
     arr = (_lib.GvfRastFrame * F)(*frames)
     H, W = settings.image_height, settings.image_width
-    color = torch.empty((F, 3, H, W), dtype=torch.float32, device=dev)
+    if color_u8 and (want_alpha_depth or want_radii):
+        raise _lib.GvfError("color_u8: the uint8 entry point has no alpha / depth / radii outputs")
+    color = torch.empty((F, 3, H, W), dtype=torch.uint8 if color_u8 else torch.float32, device=dev)
     alpha = torch.empty((F, H, W), dtype=torch.float32, device=dev) if want_alpha_depth else None
     depth = torch.empty((F, H, W), dtype=torch.float32, device=dev) if want_alpha_depth else None
     radii = torch.empty((F, P), dtype=torch.int32, device=dev) if want_radii else None
@@ -267,11 +273,17 @@ def rasterize_batched(settings, frames, act, xyz_raw, features_dc, scaling_raw, 
         nbytes = workspace_bytes(P, F, H, W, cap)
         ws = _workspace(dev, nbytes + 256)
         base = (ws.data_ptr() + 255) // 256 * 256
-        rc = _lib.lib().gvf_rast_forward_batched(
-            ctypes.byref(settings), arr, F, ctypes.byref(act), P, M, _lib.ptr(xyz_raw), _lib.ptr(features_dc),
-            _lib.ptr(scaling_raw), _lib.ptr(rotation_raw), _lib.ptr(opacity_raw), _lib.ptr(delta), n_delta,
-            ctypes.c_void_p(base), nbytes, cap, _lib.ptr(color), _lib.ptr(alpha), _lib.ptr(depth),
-            _lib.ptr(radii), _lib.ptr(nr), _lib.current_stream(dev))
+        if color_u8:
+            rc = _lib.lib().gvf_rast_forward_batched_u8(
+                ctypes.byref(settings), arr, F, ctypes.byref(act), P, M, _lib.ptr(xyz_raw), _lib.ptr(features_dc),
+                _lib.ptr(scaling_raw), _lib.ptr(rotation_raw), _lib.ptr(opacity_raw), _lib.ptr(delta), n_delta,
+                ctypes.c_void_p(base), nbytes, cap, _lib.ptr(color), _lib.ptr(nr), _lib.current_stream(dev))
+        else:
+            rc = _lib.lib().gvf_rast_forward_batched(
+                ctypes.byref(settings), arr, F, ctypes.byref(act), P, M, _lib.ptr(xyz_raw), _lib.ptr(features_dc),
+                _lib.ptr(scaling_raw), _lib.ptr(rotation_raw), _lib.ptr(opacity_raw), _lib.ptr(delta), n_delta,
+                ctypes.c_void_p(base), nbytes, cap, _lib.ptr(color), _lib.ptr(alpha), _lib.ptr(depth),
+                _lib.ptr(radii), _lib.ptr(nr), _lib.current_stream(dev))
         _lib.check(rc, "gvf_rast_forward_batched")
         _LAST_CARVE[(dev.index if dev.index is not None else torch.cuda.current_device(), int(torch.cuda.current_stream(dev).cuda_stream))] = \
             (ws, base, nbytes, P, F, H, W, cap)         # `ws`: the tensor itself, so that the address stays this workspace's

@@ -213,13 +213,16 @@ class GaussianRenderer:
         return out
 
     def render_frames(self, gaussian, extrinsics, intrinsics, delta_pc=None, delta_index=None,
-                      want_alpha_depth=False, max_rendered=None, sync=True, frames=None):
+                      want_alpha_depth=False, max_rendered=None, sync=True, frames=None, as_uint8=False):
         """Render F frames of one sample in a single fused launch sequence.
 
         extrinsics (F,4,4) world-to-camera; intrinsics (3,3) or (F,3,3) normalised; delta_pc (T,P,14)
         or None; delta_index: F ints selecting the delta slice per frame (default: frame f -> min(f,T-1),
         -1 = static).  frames: ready camera blocks (`make_frames` / `frames_with_delta_index`) instead of
-        extrinsics / intrinsics / delta_index.  Returns edict(rgb (F,3,H,W) [, alpha, depth (F,H,W)], num_rendered (F,))."""
+        extrinsics / intrinsics / delta_index.  Returns edict(rgb (F,3,H,W) [, alpha, depth (F,H,W)], num_rendered (F,)).
+        as_uint8: rgb comes back as uint8 = the reference's frame post-process (clamp(0,1) * 255 -> uint8, utils/inference_utils.py:280-286)
+        done in the compositing kernel's epilogue -- bit-identical to rasterizer.frames_to_uint8(rgb), without the fp32 frames' trip through
+        HBM.  Falls back to that two-step form where the fused one does not apply (ssaa > 1, alpha / depth wanted, the dilation mode)."""
         opts = self.rendering_options
         ssaa = int(opts["ssaa"])
         size = int(opts["resolution"]) * ssaa          # supersampled render, down-sampled below as render() does (gaussian_render.py:355-360)
@@ -235,13 +238,16 @@ class GaussianRenderer:
         mode = _lib.RAST_MODE_MIP if self.pipe.use_mip_gaussian else _lib.RAST_MODE_DILATE
         st = _r.make_settings(size, size, gaussian.active_sh_degree, mode, self.pipe.kernel_size,
                               self.pipe.scale_modifier, bg, False, self.pipe.debug)
+        want_ad = want_alpha_depth or not self.pipe.use_mip_gaussian
+        fused_u8 = as_uint8 and ssaa == 1 and not want_ad
         out = _r.rasterize_batched(st, frames, gaussian.activation_struct(), gaussian._xyz, gaussian.get_features,
                                    gaussian._scaling, gaussian._rotation, gaussian._opacity, delta=delta_pc,
-                                   want_alpha_depth=want_alpha_depth or not self.pipe.use_mip_gaussian,
-                                   max_rendered=max_rendered, sync=sync)
+                                   want_alpha_depth=want_ad, max_rendered=max_rendered, sync=sync, color_u8=fused_u8)
         rgb = out["color"]
         if ssaa > 1:                                   # all F frames in one bicubic antialiased resize
             rgb = F.interpolate(rgb, size=(int(opts["resolution"]),) * 2, mode="bicubic", align_corners=False, antialias=True)
+        if as_uint8 and not fused_u8:
+            rgb = _r.frames_to_uint8(rgb)
         ret = edict({"rgb": rgb, "num_rendered": out["num_rendered"]})
         if out["alpha"] is not None:                   # (depth / alpha stay at the supersampled size, as in render())
             ret["alpha"], ret["depth"] = out["alpha"], out["depth"]

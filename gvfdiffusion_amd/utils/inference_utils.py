@@ -214,9 +214,12 @@ def render_sample_frames(renderer, gaussian, pred_delta: torch.Tensor, intrinsic
     blocks = renderer.make_frames(ext, K)                 # the cameras' blocks once per sample (cached across samples on the same orbit)
 
     def render(part, cap=None):
+        # (as_uint8: the frames leave the compositing kernel as uint8 -- round 6; GVF_RENDER_FUSED_U8=0: the fp32 frames + frames_to_uint8, a
+        # measurement switch, same bits)
+        fused = as_uint8 and os.environ.get("GVF_RENDER_FUSED_U8", "1") != "0"
         out = renderer.render_frames(gaussian, None, None, delta_pc=pred_delta, frames=renderer.frames_with_delta_index(blocks, part),
-                                     max_rendered=cap, sync=cap is None)
-        frames = frames_to_uint8(out.rgb) if as_uint8 else out.rgb
+                                     max_rendered=cap, sync=cap is None, as_uint8=fused)
+        frames = frames_to_uint8(out.rgb) if (as_uint8 and not fused) else out.rgb
         if resize_to is not None:
             frames = resize_pad_crop_u8(frames, resize_to, out_size=out_size, pad_value=255)
         return frames, out.num_rendered

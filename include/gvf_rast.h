@@ -160,6 +160,21 @@ int gvf_rast_forward_batched(const GvfRastSettings* settings_host, const GvfRast
                              int32_t* out_radii, uint32_t* out_num_rendered,
                              void* stream);
 
+/* The same call with the frames leaving as uint8: out_rgb_u8[F][3][H][W] = (uint8) (clamp(rgb, 0, 1) * 255), the post-process the
+ * reference applies to every rendered frame on the host (utils/inference_utils.py:280-286: np.clip(...) * 255 -> astype(np.uint8)),
+ * computed in the compositing kernel's epilogue on the same fp32 value gvf_rast_forward_batched would have stored -- bit-identical to
+ * gvf_rast_forward_batched + gvf_rgb_to_u8, without the fp32 frame's round trip through HBM (12 + 12 + 3 bytes per pixel -> 3).
+ * No alpha / depth / radii outputs (the reference's render job reads none of them). */
+int gvf_rast_forward_batched_u8(const GvfRastSettings* settings_host, const GvfRastFrame* frames_host, int F,
+                                const GvfGaussianActivation* act_host,
+                                int P, int M,
+                                const float* xyz_raw, const float* features_dc, const float* scaling_raw,
+                                const float* rotation_raw, const float* opacity_raw,
+                                const float* delta, int n_delta,
+                                void* workspace, size_t workspace_bytes, int64_t max_rendered,
+                                uint8_t* out_rgb_u8, uint32_t* out_num_rendered,
+                                void* stream);
+
 /* GaussianModel activations alone (get_*_with_delta), for callers that want the activated
  * tensors (and for parity tests of the fused path): writes means3D[P][3], scales[P][3],
  * rotations[P][4], shs[P][M][3], opacities[P].  delta may be null. */

@@ -57,5 +57,12 @@ case $CASE in
     for n in 2 3 4 2 3; do echo -n "streams $n: "; python bench.py --no-dit --no-cpu-baseline --streams $n 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['ms_per_step_serial'])"; done | tee $O/raster_streams.txt
     GVF_BENCH_DIT_CFG3=0 GVF_BENCH_DIT_INFLIGHT=0 GVF_BENCH_DIT_OTHER_DTYPE=0 GVF_BENCH_DIT_HOSTILE=0 timeout 900 python bench.py --steps 5 2>$O/bench_err.log | tail -1 > $O/bench_line.json; bench_summary $O/bench_line.json
     timeout 600 python -m pytest tests/test_sampler.py -m gpu -q -s 2>&1 | tail -6 ;;
+  rbfill)   # VERDICT r5 item 2a priced by ablation: the row-block launches with 3 / 2 of a wave's 4 column tiles refilled per k-step = the weight traffic
+            # 64-row / 96-row workgroups would leave (timing only: the results are wrong), at batch 3 and batch 1
+    for B in 3 1; do GVF_BENCH_DIT_BATCH=$B GVF_BENCH_DIT_NFE=16 scripts/gpu_ab.sh $O/rowblock_fill_b$B.txt 2 dit "GVF_X=full" "GVF_LIB=gvfdiffusion_amd/variants/libgvf_hip_rbw3.so" "GVF_LIB=gvfdiffusion_amd/variants/libgvf_hip_rbw2.so"; done ;;
+  u8)       # uint8 frames from the blend's epilogue: parity test, the live job with / without it, and the headline leg (the kernel gained an argument)
+    timeout 900 python -m pytest tests/test_rast_gpu.py tests/test_render_driver_gpu.py -m gpu -q -x 2>&1 | grep -v "^$" | tail -30
+    [ "${SKIP_LIVE:-0}" = 1 ] || scripts/gpu_ab.sh $O/live_u8_ab.txt 3 live "GVF_RENDER_FUSED_U8=0" "GVF_RENDER_FUSED_U8=1"
+    scripts/gpu_ab.sh $O/raster.txt 3 raster "GVF_X=1" "GVF_LIB=gvfdiffusion_amd/variants/libgvf_hip_nou8.so" ;;
   *) echo "unknown case $CASE"; exit 2 ;;
 esac

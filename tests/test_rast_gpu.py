@@ -516,6 +516,45 @@ def test_frames_to_uint8_matches_host_postprocess(cuda):
     assert np.array_equal(frames_to_uint8(x.to(cuda)).cpu().numpy(), ref)
 
 
+def test_uint8_frames_from_the_blend_epilogue_equal_the_two_step_form(cuda, bin_algo):
+    """gvf_rast_forward_batched_u8 (round 6): the frames leave the compositing kernel as uint8 = the reference's post-process
+    (utils/inference_utils.py:280-286) on the very float the fp32 entry point stores -- bit-identical to render + frames_to_uint8, through the C
+    ABI, the renderer facade (as_uint8) and the sample driver (white background; SH offsets push colours above 1, so the upper clamp is
+    exercised -- colours are clamped at 0 before compositing, the lower one cannot trigger); alpha / depth / radii cannot be asked for together with it."""
+    from gvfdiffusion_amd import rasterizer as R, _lib
+    from gvfdiffusion_amd.renderers import GaussianRenderer
+    from gvfdiffusion_amd.utils import orbit_cameras, render_sample_frames
+    P, S = 20_000, 208
+    attrs = synthetic.random_gaussians(P, sh_degree=1, seed=77, scale_lo=0.004, scale_hi=0.03)
+    attrs["shs"][:, 0] *= 1.8                                  # over-shooting colours
+    gm = synthetic.gaussian_model_from(attrs, 1, cuda)
+    delta = synthetic.random_deltas(3, P, seed=8).to(cuda)
+    rend = GaussianRenderer({"resolution": S, "near": synthetic.NEAR, "far": synthetic.FAR, "ssaa": 1, "bg_color": (1, 1, 1)})
+    rend.pipe.use_mip_gaussian = True
+    ext, K = orbit_cameras(8).to(cuda), synthetic.intrinsics().to(cuda)
+    f32 = rend.render_frames(gm, ext, K, delta_pc=delta, delta_index=[0, 0, 1, 1, 2, 2, -1, -1])
+    u8 = rend.render_frames(gm, ext, K, delta_pc=delta, delta_index=[0, 0, 1, 1, 2, 2, -1, -1], as_uint8=True)
+    want = R.frames_to_uint8(f32.rgb)
+    assert u8.rgb.dtype == torch.uint8 and u8.rgb.shape == (8, 3, S, S)
+    assert torch.equal(u8.rgb, want) and torch.equal(u8.num_rendered, f32.num_rendered)
+    assert int((want == 255).sum()) > 0 and float(f32.rgb.max()) > 1.0 and int((want < 128).sum()) > 0      # the upper clamp is exercised
+    # where the fused form does not apply the facade falls back to the two-step one: same bits
+    u8_ad = rend.render_frames(gm, ext, K, delta_pc=delta, delta_index=[0, 0, 1, 1, 2, 2, -1, -1], as_uint8=True, want_alpha_depth=True)
+    assert torch.equal(u8_ad.rgb, want) and u8_ad.alpha.shape == (8, S, S)
+    with pytest.raises(_lib.GvfError):
+        R.rasterize_batched(R.make_settings(S, S, 1, 0, synthetic.KERNEL_2D, 1.0, (1.0, 1.0, 1.0)), rend.make_frames(ext, K, [0] * 8), gm.activation_struct(),
+                            gm._xyz, gm.get_features, gm._scaling, gm._rotation, gm._opacity, delta=delta, color_u8=True, want_radii=True)
+    # the sample driver: fused (default) == GVF_RENDER_FUSED_U8=0
+    got = {}
+    for flag in ("1", "0"):
+        os.environ["GVF_RENDER_FUSED_U8"] = flag
+        try:
+            got[flag] = torch.cat([fr for _, fr in render_sample_frames(rend, gm, delta, K, extrinsics=ext, chunk_frames=6, streams=2)])
+        finally:
+            os.environ.pop("GVF_RENDER_FUSED_U8", None)
+    assert got["1"].dtype == torch.uint8 and got["1"].shape == (24, 3, S, S) and torch.equal(got["1"], got["0"])
+
+
 @pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", "raster_cuda_golden.npz")),
                     reason="raster_cuda_golden.npz not generated yet (scripts/make_cuda_raster_golden.py on a CUDA box)")
 def test_hip_matches_cuda_golden(cuda):
