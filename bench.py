@@ -483,14 +483,15 @@ def bench_sharded_sampling(dev, dist, rank, world, P, S, T, total_batch=8, steps
     DiT -> VAE decode -> 24-frame render, uint8 frames, then the ONE collective of the path: an all-gather of every rank's
     frames (RCCL over xGMI).  Reported: whole-job samples / frames / denoise steps per second from the max-over-ranks wall
     time, the slowest rank's per-NFE time, and the gather on its own.
-    mode "inflight" (default; the fastest of the three on every box measured, profiles/r06_sharded_modes.txt): B = 1 chains, two in flight on two
-    streams (two DiT instances).  "batched": a rank's samples sampled as ONE batch on one DiT (the multistep solver is batch-transparent; every
-    launch of the forward covers the whole batch), then decoded and rendered one by one.  "batched_inflight": two such batches in flight.
-    GVF_BENCH_SHARD_MODE selects; the N = 1 line reports all three.  dist=None: one rank, no process group."""
+    mode "batched" (default): a rank's samples are sampled as ONE batch on one DiT (the multistep solver is batch-transparent; every launch of
+    the forward covers the whole batch), then decoded and rendered one by one: 1.04-1.05 x the serial job on the boxes measured with the
+    full-length warm-up (profiles/r06_sharded_modes.txt).  "inflight" (rounds 3-5): B = 1 chains, two in flight on two streams and two host
+    threads (two DiT instances): 0.98-1.04 x, the spread follows the box's host cores.  "batched_inflight": two batches in flight, the
+    slowest.  GVF_BENCH_SHARD_MODE selects; the N = 1 line reports the first two.  dist=None: one rank, no process group."""
     import contextlib
     from gvfdiffusion_amd import distributed as D, rasterizer as R
     dist = _OneRank if dist is None else dist
-    mode = mode or os.environ.get("GVF_BENCH_SHARD_MODE", "inflight")
+    mode = mode or os.environ.get("GVF_BENCH_SHARD_MODE", "batched")
     total = max(total_batch, world)                     # every rank owns at least one sample
     mine = D.shard_indices(total, rank, world)
     b_loc = len(mine)
@@ -890,6 +891,16 @@ def main():
                          # the same launch priced on the instances the kernel actually touches (alpha-box culled binning), 36 B each
                          "frac_on_binned_instances": round((work.D_binned * 36 + F * S * S * 12) / blend_s / 1e9 / HBM_PEAK_GBS, 5) if blend_s > 0 else 0,
                          "valu_issue": valu_issue,
+                         # The bound that actually binds this launch: the compositing loop is 16 vector instructions per list
+                         # entry of which one is a v_exp_f32; on the `valu_issue` scale (SQ_ACTIVE_INST_VALU x 2 cycles / busy cycles) that mix
+                         # tops out at ~0.69 (profiles/r05_blend_phase_stamps.txt); `achieved` = the counter figure of the committed SQ pass.
+                         # The one restructuring not priced before round 6 -- exponents from six v_mfma_f32_4x4x1 per 4 splats, 11 vector
+                         # instructions per entry -- is 8 % SLOWER in a loop-only micro-benchmark (profiles/r06_ubench_blend_step.txt), so the
+                         # kernel stays and this is its roofline; the HBM figure above is what north_star asked to see.
+                         "binding_bound": None if not valu_issue else {
+                             "bound": "valu", "unit": "fraction of VALU issue cycles", "achieved": valu_issue.get("valu_issue"), "peak": 0.69,
+                             "frac": round(valu_issue.get("valu_issue", 0.0) / 0.69, 4),
+                             "source": valu_issue.get("source")},
                          # BASELINE's north star prices "tile-sort + blend" together: the per-tile sort moves 8 B in + 4 B out per binned
                          # instance (PMC: 0.25 GB per launch = exactly that), priced like the blend on upstream's instance count
                          "tile_sort_plus_blend": (lambda b_, t_: {"alg_bytes": int(b_), "ms": round(t_ * 1e3, 4), "achieved_GBs": round(b_ / t_ / 1e9, 2),
@@ -924,7 +935,7 @@ def main():
                             "samples_in_flight_per_rank", "dit_batch_per_forward", "streams_per_rank")
                     # ("batched_inflight", two batches of 4 on two streams, is the slowest by far -- 1.5-2.8 s against 1.3-1.4 s: two persistent
                     # attention grids and two one-workgroup-per-CU row-block grids cannot share the chip -- and is left to GVF_BENCH_SHARD_MODE)
-                    for name_, mode_ in (("one_batch_of_8", "batched"),):
+                    for name_, mode_ in (("two_B1_chains_in_flight", "inflight"),):
                         alt = bench_sharded_sampling(dev, None, 0, 1, a.gaussians, a.res, a.frames, mode=mode_)
                         sh[name_] = {k_: alt[k_] for k_ in keep}
                 e2 = out["end_to_end"]["stage_ms"]

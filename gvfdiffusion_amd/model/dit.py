@@ -164,10 +164,12 @@ class DiT(nn.Module):
             # along the token axis (model/attention/modules.py:36, 52-57) -> RuntimeError for every sequence length
             raise NotImplementedError("pe_mode='rope': the reference's own forward fails with a shape error at model/attention/modules.py:36 "
                                       "(profiles/r04_reference_dit_variants.txt); configs/diffusion.yml uses 'ape'")
-        if model_channels % self.num_heads != 0 or model_channels // self.num_heads != 32:
-            # the tiled K / V cache (csrc/attn_xt.hip), its pack kernels and the temporal section of csrc/rowblock.hip are head_dim-32 code
-            # (configs/diffusion.yml: 512 channels / 16 heads); anything else would compute a different attention without an error
-            raise NotImplementedError(f"the DiT's HIP attention path is built for head_dim 32, got {model_channels} / {self.num_heads}")
+        if model_channels % self.num_heads != 0 or model_channels // self.num_heads not in (32, 64):
+            # head_dim 32 (configs/diffusion.yml: 512 channels / 16 heads) runs the tiled K / V cache (csrc/attn_xt.hip) and the row-block
+            # launches; head_dim 64 (round 6; the reference takes any num_heads, model/dit.py:337) runs the per-sub-layer launches with the
+            # strided flash attention of csrc/attn.hip, which is built for 32 and 64.  Anything else has no HIP attention path.
+            raise NotImplementedError(f"the DiT's HIP attention paths are built for head_dim 32 and 64, got {model_channels} / {self.num_heads}")
+        self.head_dim = model_channels // self.num_heads
 
         self.t_embedder = TimestepEmbedder(model_channels)
         if pe_mode == "ape":
@@ -346,11 +348,11 @@ class DiT(nn.Module):
                 m = getattr(blk, name)
                 if isinstance(m, MultiHeadAttention):
                     b[name] = dict(qkv=prep(m.to_qkv), out=prep(m.to_out), gq=m._gammas()[0], gk=m._gammas()[1])
-                    b[name]["bounded"] = dit_ops.scores_bounded(*m._gammas())     # fp16: no per-query shift needed (see attn_xt.hip)
+                    b[name]["bounded"] = dit_ops.scores_bounded(*m._gammas(), head_dim=self.head_dim)     # fp16: no per-query shift needed (see attn_xt.hip)
             for name in ("image_cross_attn", "static_cross_attn"):
                 m = getattr(blk, name)
                 b[name] = dict(q=prep(m.to_q), kv=prep(m.to_kv), kv_f32=prep32(m.to_kv), out=prep(m.to_out), gq=m._gammas()[0], gk=m._gammas()[1])
-                b[name]["bounded"] = dit_ops.scores_bounded(*m._gammas())
+                b[name]["bounded"] = dit_ops.scores_bounded(*m._gammas(), head_dim=self.head_dim)
             b["fc1"], b["fc2"] = prep(blk.mlp.mlp[0]), prep(blk.mlp.mlp[2])
             b["n3"] = (blk.norm3.weight.detach().float().contiguous(), blk.norm3.bias.detach().float().contiguous())
             b["n4"] = (blk.norm4.weight.detach().float().contiguous(), blk.norm4.bias.detach().float().contiguous())
@@ -455,9 +457,15 @@ class DiT(nn.Module):
         order = (lambda kv_, n_, L_: dit_ops.key_order_by_norm(kv_, n_, L_, H, 0) if L_ <= 8192 else None) if ordered else (lambda kv_, n_, L_: None)
         for i, b in enumerate(W["blocks"]):
             dit_ops.gemm(img3, S3["kv_img"][i], b["image_cross_attn"]["kv_f32"][1], kv_i, dit_ops.EPI_STORE_F32)
+            dit_ops.gemm(st3, S3["kv_st"][i], b["static_cross_attn"]["kv_f32"][1], kv_s, dit_ops.EPI_STORE_F32)
+            if self.head_dim != 32:
+                # head_dim 64: the strided flash attention reads row-major [k | v] rows of the operand type (one rounding of the fp32-class
+                # projection, as the tile image's); MultiHeadRMSNorm of k is the kernel's prologue (gamma_k)
+                ctx["kv_img"].append(kv_i.to(lp))
+                ctx["kv_st"].append(kv_s.to(lp))
+                continue
             ctx["kv_img"].append(dit_ops.attention_pack_kv(kv_i, B * Tc, Li, H, 0, C, gamma_k=b["image_cross_attn"]["gk"], dtype=lp,
                                                            key_order=order(kv_i, B * Tc, Li)))
-            dit_ops.gemm(st3, S3["kv_st"][i], b["static_cross_attn"]["kv_f32"][1], kv_s, dit_ops.EPI_STORE_F32)
             ctx["kv_st"].append(dit_ops.attention_pack_kv(kv_s, B, Ls, H, 0, C, gamma_k=b["static_cross_attn"]["gk"], dtype=lp,
                                                           key_order=order(kv_s, B, Ls)))
         if self.pe_mode == "ape":
@@ -642,7 +650,7 @@ class DiT(nn.Module):
         # the row-block launches work on whole 48-row blocks of one sample: a sample whose T * N is not a multiple of 48 (T = 16, 32 at
         # N = 512) gets its rows padded (needs whole 64-key tiles per frame for the attention's strided views: N % 64 == 0)
         TNp = dit_ops.rowblock_padded_rows(T * N)
-        if self.use_rowblock and small_f32 and Cin % 4 == 0 and Cin <= 16 and dit_ops.rowblock_supported(C, TNp, int(C * self.mlp_ratio)) \
+        if self.use_rowblock and self.head_dim == 32 and small_f32 and Cin % 4 == 0 and Cin <= 16 and dit_ops.rowblock_supported(C, TNp, int(C * self.mlp_ratio)) \
                 and (TNp == T * N or (N % 64 == 0 and self.rowblock_tiled_kv)):
             y = self._blocks_rowblock(x2d, mod, mod_ld, W, ctx, B, T, N, pos)          # its first launch also does input_layer
             return y.to(x.dtype if x.dtype.is_floating_point else f32)
@@ -659,6 +667,7 @@ class DiT(nn.Module):
         ab = torch.empty((M, C), dtype=bf, device=dev)          # attention output / q projection
         hidden = torch.empty((M, int(C * self.mlp_ratio)), dtype=bf, device=dev)
         TN = T * N
+        hd = self.head_dim
         nb_self = B * T * H * ((N + 63) // 64) * 4096
         kv_self = (torch.empty(nb_self, dtype=torch.uint8, device=dev), torch.empty(nb_self, dtype=torch.uint8, device=dev))
         # LayerNorm is folded into the GEMMs around it (csrc/gemm.hip): every update of the stream x = x + g * h also writes
@@ -699,10 +708,14 @@ class DiT(nn.Module):
             # -- spatial self attention over N
             a = b["spatial_self_attn"]
             ln_gemm(a["qkv"], qkv, dit_ops.EPI_STORE_16, shift=sh_s, scale=sc_s)
-            # K (RMS-normed, pre-scaled) and V^T of this step's projection into the tiled image, then the tiled-cache kernel
-            dit_ops.attention_pack_kv(qkv, B * T, N, H, C, 2 * C, gamma_k=a["gk"], out=kv_self)
-            dit_ops.attention_tiled(qkv, kv_self[0], kv_self[1], ab, B * T, 1, N, N, H, (N * 3 * C, 0, 3 * C), (N * C, 0, C), 1, 0,
-                                    gamma_q=a["gq"], bounded=a["bounded"], fallback_counter=self._fallbacks)
+            if hd != 32:
+                s3 = (N * 3 * C, 0, 3 * C)
+                dit_ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], ab, B * T, 1, N, N, H, s3, s3, s3, (N * C, 0, C), a["gq"], a["gk"], head_dim=hd)
+            else:
+                # K (RMS-normed, pre-scaled) and V^T of this step's projection into the tiled image, then the tiled-cache kernel
+                dit_ops.attention_pack_kv(qkv, B * T, N, H, C, 2 * C, gamma_k=a["gk"], out=kv_self)
+                dit_ops.attention_tiled(qkv, kv_self[0], kv_self[1], ab, B * T, 1, N, N, H, (N * 3 * C, 0, 3 * C), (N * C, 0, C), 1, 0,
+                                        gamma_q=a["gq"], bounded=a["bounded"], fallback_counter=self._fallbacks)
             resid(ab, a["out"], g_s)
             # -- temporal self attention over T (strided views, no transposes)
             if not self.no_temporal_attn:
@@ -710,19 +723,29 @@ class DiT(nn.Module):
                 a = b["temporal_self_attn"]
                 ln_gemm(a["qkv"], qkv, dit_ops.EPI_STORE_16, shift=sh_t, scale=sc_t)
                 st = (TN * 3 * C, 3 * C, N * 3 * C)           # outer = sample, inner = token, seq = frame
-                dit_ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], ab, B, N, T, T, H, st, st, st, (TN * C, C, N * C), a["gq"], a["gk"])
+                dit_ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], ab, B, N, T, T, H, st, st, st, (TN * C, C, N * C), a["gq"], a["gk"], head_dim=hd)
                 resid(ab, a["out"], g_t)
             # -- image cross attention (affine LayerNorm, cached K/V)
             a = b["image_cross_attn"]
             ln_gemm(a["q"], ab, dit_ops.EPI_STORE_16, ln_w=b["n3"][0], ln_b=b["n3"][1])
-            kt, vt = ctx["kv_img"][i]
-            dit_ops.attention_tiled(ab, kt, vt, hb, B * T, 1, N, Li, H, (N * C, 0, C), (N * C, 0, C), 1, 0, gamma_q=a["gq"], bounded=a["bounded"], fallback_counter=self._fallbacks)
+            if hd != 32:
+                kv = ctx["kv_img"][i]                             # (B T Li, 2C) rows [k | v], one key set per (sample, frame)
+                sk = (Li * 2 * C, 0, 2 * C)
+                dit_ops.attention(ab, kv, kv[:, C:], hb, B * T, 1, N, Li, H, (N * C, 0, C), sk, sk, (N * C, 0, C), a["gq"], a["gk"], head_dim=hd)
+            else:
+                kt, vt = ctx["kv_img"][i]
+                dit_ops.attention_tiled(ab, kt, vt, hb, B * T, 1, N, Li, H, (N * C, 0, C), (N * C, 0, C), 1, 0, gamma_q=a["gq"], bounded=a["bounded"], fallback_counter=self._fallbacks)
             resid(hb, a["out"])
             # -- static cross attention: K/V shared by the T frames of a sample (inner stride 0)
             a = b["static_cross_attn"]
             ln_gemm(a["q"], ab, dit_ops.EPI_STORE_16, ln_w=b["n4"][0], ln_b=b["n4"][1])
-            kt, vt = ctx["kv_st"][i]
-            dit_ops.attention_tiled(ab, kt, vt, hb, B, T, N, Ls, H, (TN * C, N * C, C), (TN * C, N * C, C), 1, 0, gamma_q=a["gq"], bounded=a["bounded"], fallback_counter=self._fallbacks)
+            if hd != 32:
+                kv = ctx["kv_st"][i]                              # (B Ls, 2C): one key set per sample, shared by its T frames (inner stride 0)
+                sk = (Ls * 2 * C, 0, 2 * C)
+                dit_ops.attention(ab, kv, kv[:, C:], hb, B, T, N, Ls, H, (TN * C, N * C, C), sk, sk, (TN * C, N * C, C), a["gq"], a["gk"], head_dim=hd)
+            else:
+                kt, vt = ctx["kv_st"][i]
+                dit_ops.attention_tiled(ab, kt, vt, hb, B, T, N, Ls, H, (TN * C, N * C, C), (TN * C, N * C, C), 1, 0, gamma_q=a["gq"], bounded=a["bounded"], fallback_counter=self._fallbacks)
             resid(hb, a["out"])
             # -- MLP
             ln_gemm(b["fc1"], hidden, dit_ops.EPI_GELU_16, shift=sh_m, scale=sc_m)

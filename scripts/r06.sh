@@ -64,5 +64,7 @@ case $CASE in
     timeout 900 python -m pytest tests/test_rast_gpu.py tests/test_render_driver_gpu.py -m gpu -q -x 2>&1 | grep -v "^$" | tail -30
     [ "${SKIP_LIVE:-0}" = 1 ] || scripts/gpu_ab.sh $O/live_u8_ab.txt 3 live "GVF_RENDER_FUSED_U8=0" "GVF_RENDER_FUSED_U8=1"
     scripts/gpu_ab.sh $O/raster.txt 3 raster "GVF_X=1" "GVF_LIB=gvfdiffusion_amd/variants/libgvf_hip_nou8.so" ;;
+  gemmbk)   # the plain GEMM's existing 64-deep k-tile instantiation on the motion VAE's shapes (K = 768 / 3072): in isolation and inside the decode
+    for bk in 0 64 0 64; do echo "== GVF_GEMM_BK=$bk"; GVF_GEMM_BK=$bk python scripts/bench_gemm_vae.py 2>&1 | grep -v amdgpu.ids; GVF_GEMM_BK=$bk python scripts/vae_breakdown.py 2>&1 | grep -v amdgpu.ids | tail -2; done | tee $O/gemm_bk.txt ;;
   *) echo "unknown case $CASE"; exit 2 ;;
 esac

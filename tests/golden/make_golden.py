@@ -222,6 +222,39 @@ def gen_dit_notemporal():
     print("dit_small_notemporal_golden.npz", len(out), "arrays,", y.shape, float(y.abs().mean()))
 
 
+def gen_dit_hd64():
+    """model/dit.py with ONE head of 64 channels (the reference takes any num_heads, model/dit.py:337; configs/diffusion.yml has 16 heads of 32):
+    the reduced model of gen_dit() in that variant with autocast errors of its own, for the head_dim-64 path of the HIP denoiser (the strided flash
+    attention instead of the tiled cache) and the oracle's head handling."""
+    import json
+    from model.dit import DiT
+    cfg = dict(DIT_SMALL, num_heads=1)
+    torch.manual_seed(0)
+    model = DiT(**cfg).eval()
+    _randomise(model, 21)
+    g = torch.Generator().manual_seed(22)
+    B, T, N, Li, Ls = 2, 3, 40, 37, 50
+    x = torch.randn((B, T, N, 16), generator=g)
+    t = torch.tensor([812.5, 97.75])
+    cond = torch.randn((B, T, Li, 32), generator=g)
+    static = torch.randn((B, Ls, 14), generator=g)
+    xyz = torch.rand((B, N, 3), generator=g) - 0.5
+    kw = dict(cond_images=cond, static_latent=static, deformation_position_xyz=xyz)
+    with torch.no_grad():
+        y = model(x, t, **kw)
+        out = {"cfg_json": np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8), "x": x.numpy(), "t": t.numpy(), "cond_images": cond.numpy(),
+               "static_latent": static.numpy(), "xyz": xyz.numpy(), "y": y.numpy()}
+        for name, dt in (("bf16", torch.bfloat16), ("fp16", torch.float16)):
+            with torch.autocast("cpu", dtype=dt):
+                ya = model(x, t, **kw)
+            out[f"rel_l2_{name}"] = np.float64(float((ya.float() - y).norm() / y.norm()))
+            print(f"hd64 autocast {name}: rel_l2 vs fp32 {float(out[f'rel_l2_{name}']):.3e}")
+    for k, v in model.state_dict().items():
+        out["sd." + k] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "dit_small_hd64_golden.npz"), **out)
+    print("dit_small_hd64_golden.npz", len(out), "arrays,", y.shape, float(y.abs().mean()))
+
+
 def gen_dit_autocast():
     """The reference's OWN reduced-precision behaviour: model/dit.py under torch.autocast (the reference runs fp16 autocast,
     inference_dpm_latent.py:171; bf16 is what the MI355X path computes in) on the inputs of dit_small_golden.npz and
@@ -744,7 +777,7 @@ def gen_sparse_layers():
     print("sparse_layers_golden.npz", {k: v.shape for k, v in out.items()})
 
 
-SECTIONS = {"sparse_layers": gen_sparse_layers, "slat_decoder": gen_slat_decoder, "sparse_vae": gen_sparse_vae, "vae_encode": gen_vae_encode, "vae": gen_vae, "raster": gen_raster, "vox2seq": gen_vox2seq, "dit": gen_dit, "dit_notemporal": gen_dit_notemporal, "dit_autocast": gen_dit_autocast, "dit_hostile": gen_dit_hostile, "align": gen_align, "sampler": gen_sampler, "sparse": gen_sparse}
+SECTIONS = {"sparse_layers": gen_sparse_layers, "slat_decoder": gen_slat_decoder, "sparse_vae": gen_sparse_vae, "vae_encode": gen_vae_encode, "vae": gen_vae, "raster": gen_raster, "vox2seq": gen_vox2seq, "dit": gen_dit, "dit_notemporal": gen_dit_notemporal, "dit_hd64": gen_dit_hd64, "dit_autocast": gen_dit_autocast, "dit_hostile": gen_dit_hostile, "align": gen_align, "sampler": gen_sampler, "sparse": gen_sparse}
 
 if __name__ == "__main__":
     install_stubs()

@@ -60,12 +60,13 @@ def test_attention_backend_seam():
 def test_options_the_reference_cannot_run_are_refused_at_construction():
     """share_mod=True and pe_mode='rope' end in shape errors inside the reference's own forward (profiles/r04_reference_dit_variants.txt,
     scripts/reference_dit_variants.py): there is no behaviour to match, the module says so instead of failing in a kernel; a head_dim other
-    than 32 has no HIP attention path."""
+    than 32 or 64 (here 16) has no HIP attention path, while one head of 64 is accepted (round 6)."""
     g = np.load(os.path.join(GOLD, "dit_small_golden.npz"))
     cfg = json.loads(bytes(g["cfg_json"]).decode())
-    for over, word in ((dict(share_mod=True), "model/dit.py:247"), (dict(pe_mode="rope"), "modules.py:36"), (dict(num_heads=1), "head_dim 32")):
+    for over, word in ((dict(share_mod=True), "model/dit.py:247"), (dict(pe_mode="rope"), "modules.py:36"), (dict(num_heads=4), "head_dim 32 and 64")):
         with pytest.raises(NotImplementedError, match=word):
             DiT(**dict(cfg, **over))
+    assert DiT(**dict(cfg, num_heads=1)).head_dim == 64
 
 
 def test_param_version_sees_every_kind_of_weight_change_on_the_next_call():

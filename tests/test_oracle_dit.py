@@ -80,6 +80,21 @@ def test_small_model_without_temporal_attention_matches_reference():
     assert err < 5e-5, err
 
 
+def test_small_model_with_one_head_of_64_matches_reference():
+    """num_heads = 1 at 64 channels, i.e. head_dim 64 (the reference takes any num_heads, model/dit.py:337): the reference's own forward of that
+    variant (make_golden.py::gen_dit_hd64) pins the oracle's head handling (split, MultiHeadRMSNorm gains [H][d], scale d^-0.5)."""
+    import json
+    g = np.load(os.path.join(GOLD, "dit_small_hd64_golden.npz"))
+    cfg = json.loads(bytes(g["cfg_json"]).decode())
+    assert cfg["num_heads"] == 1 and cfg["model_channels"] == 64
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")}
+    args = [torch.from_numpy(g[k]) for k in ("x", "t", "cond_images", "static_latent", "xyz")]
+    with torch.no_grad():
+        y = dit_ref.dit_forward(sd, cfg, *args, precision="fp32")
+    err = np.abs(y.numpy() - g["y"]).max()
+    assert err < 5e-5, err
+
+
 def test_full_config_forward_matches_reference():
     """configs/diffusion.yml, B=1, T=24, 1370 image tokens, 4096 static tokens (5.04 TFLOP on the CPU)."""
     man = json.load(open(os.path.join(GOLD, "dit_manifest.json")))
