@@ -66,5 +66,7 @@ case $CASE in
     scripts/gpu_ab.sh $O/raster.txt 3 raster "GVF_X=1" "GVF_LIB=gvfdiffusion_amd/variants/libgvf_hip_nou8.so" ;;
   gemmbk)   # the plain GEMM's existing 64-deep k-tile instantiation on the motion VAE's shapes (K = 768 / 3072): in isolation and inside the decode
     for bk in 0 64 0 64; do echo "== GVF_GEMM_BK=$bk"; GVF_GEMM_BK=$bk python scripts/bench_gemm_vae.py 2>&1 | grep -v amdgpu.ids; GVF_GEMM_BK=$bk python scripts/vae_breakdown.py 2>&1 | grep -v amdgpu.ids | tail -2; done | tee $O/gemm_bk.txt ;;
+  hd64)     # the DiT with one head of 64 (per-sub-layer path) + the tests touched since the evidence pass
+    timeout 900 python -m pytest tests/test_dit_fp16_gpu.py tests/test_dit_gpu.py tests/test_sampler.py tests/test_distributed.py -m gpu -q -x -s 2>&1 | grep -v "^$" | grep "one head of 64\|passed\|failed\|Error\|assert" | tail -20 ;;
   *) echo "unknown case $CASE"; exit 2 ;;
 esac
