@@ -44,6 +44,7 @@ SOURCES = {
     "attn_xt64.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"],
     "gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
     "gemm256.hip": [],                       # accumulators in AGPRs: 256 of them per wave
+    "gemm8.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
     # row-block kernel: default flags (accumulators in AGPRs: the kernel lives on the 512-register file of a 2-waves-per-SIMD launch)
     "rowblock.hip": [],
     "elem.hip": [],

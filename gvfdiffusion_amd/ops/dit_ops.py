@@ -77,6 +77,8 @@ _lib.register({
     "gvf_attn_tiled64_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, ctypes.POINTER(_i64), ctypes.POINTER(_i64), _i64, _i64, _i, _vp, _vp]),
     "gvf_gemm256_eligible": (_i, [_i, _i, _i, _i, _i, _i]),
     "gvf_gemm256": (_i, [_i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "gvf_gemm8_eligible": (_i, [_i, _i, _i, _i, _i, _i, _i]),
+    "gvf_gemm8": (_i, [_i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "gvf_attn_fold_pack": (_i, [_i, _vp, _i, _i, _i, _vp, _vp]),
     "gvf_attn_tiled64_fold_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, ctypes.POINTER(_i64), _i64, _i64, _i, _vp, _vp]),
     "gvf_attn_fold_reduce": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _vp]),
@@ -486,6 +488,18 @@ def attention_tiled64(q, k_tiles, v_tiles, out, n_outer, n_inner, Lq, Lk, H, q_s
     _lib.check(_lib.lib().gvf_attn_tiled64_fwd(dt_code(q.dtype), _p(q), _p(k_tiles), _p(v_tiles), _p(out), n_outer, n_inner, Lq, Lk, H,
                                                _s4(q_strides, 64), _s4(o_strides, 64), int(kv_stride_outer), int(kv_stride_inner),
                                                int(bool(force_exact)), _p(fallback_counter), _stream(q)), "gvf_attn_tiled64_fwd")
+    return out
+
+
+def gemm8(a: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, epilogue: int = 0):
+    """out = epi(a @ w.T + bias) on csrc/gemm8.hip's 256 x 256 x 64 tiles, eight waves (M, N multiples of 256, K of 64); epilogue EPI_STORE_16 or
+    EPI_GEGLU_16 (out (M, N / 2)).  gvf_gemm takes this kernel by itself for eligible shapes; this is the direct entry (tests, benchmarks)."""
+    _lib.require_cuda(a, w, out)
+    assert a.dtype in LP_DTYPES and w.dtype == a.dtype and out.dtype == a.dtype and a.stride(1) == 1 and w.stride(1) == 1 and out.stride(1) == 1
+    M, K = a.shape
+    N = w.shape[0]
+    _lib.check(_lib.lib().gvf_gemm8(dt_code(a.dtype), _p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), M, N, K, int(epilogue),
+                                    _stream(a)), "gvf_gemm8")
     return out
 
 

@@ -184,6 +184,14 @@ int gvf_gemm256_eligible(int M, int N, int K, int lda, int ldw, int ldc);
 int gvf_gemm256(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M, int N, int K,
                 void* stream);
 
+/* The same projection on 256 x 256 x 64 tiles with EIGHT waves, two per SIMD (csrc/gemm8.hip, round 6): 790-900 TFLOP/s on the motion VAE's large
+ * projections where gvf_gemm's 128-wide kernel reaches 560-640.  epilogue: GVF_EPI_STORE_BF16 (C 16-bit [M][N]) or GVF_EPI_GEGLU_16 (C 16-bit
+ * [M][N/2], the interleaved value / gate convention of gvf_gemm).  gvf_gemm8_eligible: M, N multiples of 256, K of 64, 16-byte rows.  gvf_gemm takes
+ * it by itself for eligible calls with at least one tile per CU (GVF_GEMM8=0: off, =2: from one tile on). */
+int gvf_gemm8_eligible(int M, int N, int K, int lda, int ldw, int ldc, int epilogue);
+int gvf_gemm8(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M, int N, int K,
+              int epilogue, void* stream);
+
 /* ---- cross attention against a pre-tiled, step-invariant K/V cache (csrc/attn_xt.hip), head_dim 32 ----------------
  * The two cross attentions of the DiT block (model/dit.py:263-270 -> model/attention/full_attn.py:74-140) read keys /
  * values that depend on the conditions only.  gvf_attn_pack_kv_bf16 stores them ONCE per condition set in the image

@@ -1,5 +1,6 @@
 """Times gvf_gemm on the motion VAE's latent-block shapes (M = 24 x 512 rows, dim 768, GEGLU FF) next to torch.matmul (hipBLASLt); GPU only.
-GVF_GEMM_BM=64/128 and GVF_GEMM_BK=32/64 force the tile shape (tuning aids of csrc/gemm.hip)."""
+GVF_GEMM_BM=64/128 and GVF_GEMM_BK=32/64 force the tile shape (tuning aids of csrc/gemm.hip); GVF_GEMM8=0 keeps the eligible shapes off the
+eight-wave 256-wide kernel (csrc/gemm8.hip), =2 sends every eligible shape there."""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gvfdiffusion_amd.ops import dit_ops

@@ -68,5 +68,9 @@ case $CASE in
     for bk in 0 64 0 64; do echo "== GVF_GEMM_BK=$bk"; GVF_GEMM_BK=$bk python scripts/bench_gemm_vae.py 2>&1 | grep -v amdgpu.ids; GVF_GEMM_BK=$bk python scripts/vae_breakdown.py 2>&1 | grep -v amdgpu.ids | tail -2; done | tee $O/gemm_bk.txt ;;
   hd64)     # the DiT with one head of 64 (per-sub-layer path) + the tests touched since the evidence pass
     timeout 900 python -m pytest tests/test_dit_fp16_gpu.py tests/test_dit_gpu.py tests/test_sampler.py tests/test_distributed.py -m gpu -q -x -s 2>&1 | grep -v "^$" | grep "one head of 64\|passed\|failed\|Error\|assert" | tail -20 ;;
+  gemm8)    # the eight-wave 256-wide GEMM in the product: parity tests, the VAE's shapes with it off / on / forced, the decode in place, the e2e leg
+    timeout 900 python -m pytest tests/test_dit_gpu.py tests/test_vae_gpu.py tests/test_sparse_vae_gpu.py -m gpu -q -x 2>&1 | grep -v "^$" | tail -12
+    for v in 0 1 2 0 1; do echo "== GVF_GEMM8=$v"; GVF_GEMM8=$v python scripts/bench_gemm_vae.py 2>&1 | grep -v amdgpu.ids | cut -c1-80; GVF_GEMM8=$v python scripts/vae_breakdown.py 2>&1 | grep -v amdgpu.ids | tail -1; GVF_DIT_DTYPE=fp16 GVF_GEMM8=$v python scripts/vae_breakdown.py 2>&1 | grep -v amdgpu.ids | tail -1; done | tee $O/gemm8_vae.txt
+    scripts/gpu_ab.sh $O/e2e_gemm8.txt 2 e2e "GVF_GEMM8=0" "GVF_GEMM8=1" ;;
   *) echo "unknown case $CASE"; exit 2 ;;
 esac

@@ -109,6 +109,70 @@ def test_256_wide_projection_kernel_matches_the_128_wide_one(cuda, lp, M, N, K, 
         dit_ops.gemm256(a[:255], w, bias, out[:255])
 
 
+@pytest.mark.parametrize("lp", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K,has_bias", [(4096, 4096, 768, True), (65536, 256, 64, False), (12288, 2304, 768, False), (256, 768, 128, True)])
+def test_eight_wave_projection_kernel_matches_fp32_and_the_four_wave_one(cuda, lp, M, N, K, has_bias):
+    """gvf_gemm8 (csrc/gemm8.hip, round 6: 256 x 256 x 64 tiles, EIGHT waves; what gvf_gemm runs for large plain / GEGLU projections) against an
+    fp32 product of the same 16-bit operands and against gvf_gemm256 (an independent kernel with the same single rounding: they differ by the
+    fp32 summation order only -- never more than one 16-bit step); every element written, nothing beyond; each XCD mapping covered; operands are
+    views with their own leading dimensions; shapes it cannot run are refused; repeated launches give the same bits (no race in the staging)."""
+    g = torch.Generator().manual_seed(M + N + 1)
+    abuf = (torch.randn((M, K + 8), generator=g)).to(lp).to(cuda)
+    a = abuf[:, :K]
+    w = (torch.randn((N, K), generator=g) / math.sqrt(K)).to(lp).to(cuda)
+    bias = torch.randn((N,), generator=g).to(cuda) if has_bias else None
+    obuf = torch.full((M, N + 16), float("nan"), dtype=lp, device=cuda)
+    out = obuf[:, :N]
+    dit_ops.gemm8(a, w, bias, out, dit_ops.EPI_STORE_BF16)
+    assert torch.isfinite(out).all() and torch.isnan(obuf[:, N:]).all()
+    rows = torch.randint(0, M, (256,), generator=g).to(cuda)
+    ref = a[rows].float() @ w.float().T + (bias if has_bias else 0.0)
+    assert rel_l2(out[rows], ref) < (2.5e-3 if lp == torch.bfloat16 else 3.5e-4)
+    other = torch.empty((M, N), dtype=lp, device=cuda)
+    dit_ops.gemm256(a, w, bias, other)
+    d = (out.float() - other.float()).abs()
+    ulp = out.float().abs() * (2.0 ** -7 if lp == torch.bfloat16 else 2.0 ** -10)
+    assert float((d > 1.01 * ulp + 1e-6).float().mean()) == 0.0
+    assert float((d > 0).float().mean()) < 2e-2
+    first = out.clone()
+    for _ in range(3):
+        obuf.fill_(float("nan"))
+        dit_ops.gemm8(a, w, bias, out, dit_ops.EPI_STORE_BF16)
+        assert torch.equal(out, first)
+    with pytest.raises(_lib.GvfError):
+        dit_ops.gemm8(a[:255], w, bias, out[:255])
+    L = _lib.lib()
+    assert L.gvf_gemm8_eligible(M, N, K, K + 8, K, N + 16, dit_ops.EPI_STORE_BF16) == 1 and L.gvf_gemm8_eligible(M, N, K, K + 8, K, N + 16, dit_ops.EPI_RESID_F32) == 0
+    assert L.gvf_gemm8_eligible(M, N + 64, K, K + 8, K, N + 64, dit_ops.EPI_STORE_BF16) == 0
+
+
+@pytest.mark.parametrize("lp", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,F,K", [(512, 3072, 768), (4096, 128, 64)])
+def test_eight_wave_geglu_epilogue_equals_its_store_epilogue_then_geglu(cuda, lp, M, F, K):
+    """gvf_gemm8's GEGLU epilogue (value and gate of an output sit in one lane: register arithmetic) == its own store epilogue on the row-interleaved
+    projection followed by gvf_geglu, bit for bit (same accumulation, both round value and gate to the operand type first), and close to the fp32
+    GEGLU of the un-interleaved projection (model/autoencoder.py:90-93)."""
+    from gvfdiffusion_amd.ops import vae_ops
+    g = torch.Generator().manual_seed(M + F)
+    a = torch.randn((M, K), generator=g).to(lp).to(cuda)
+    w = (torch.randn((2 * F, K), generator=g) / K ** 0.5)
+    b = torch.randn(2 * F, generator=g)
+    wi, bi = dit_ops.geglu_interleave(w, b)
+    wi16, bi_d = wi.to(lp).to(cuda), bi.to(cuda)
+    out = torch.full((M, F + 8), float("nan"), dtype=lp, device=cuda)
+    dit_ops.gemm8(a, wi16, bi_d, out[:, :F], dit_ops.EPI_GEGLU_16)
+    assert torch.isnan(out[:, F:]).all() and torch.isfinite(out[:, :F]).all()
+    # un-interleave the stored projection of the SAME kernel, then the stand-alone GEGLU
+    hid_i = torch.empty((M, 2 * F), dtype=lp, device=cuda)
+    dit_ops.gemm8(a, wi16, bi_d, hid_i, dit_ops.EPI_STORE_BF16)
+    slabs = hid_i.view(M, 2 * F // 64, 2, 32)                       # [value 32 | gate 32] per 64-column slab
+    hid = torch.cat([slabs[:, :, 0].reshape(M, F), slabs[:, :, 1].reshape(M, F)], dim=1).contiguous()
+    assert torch.equal(out[:, :F], vae_ops.geglu_bf16(hid))
+    h32 = a.float() @ w.to(lp).to(cuda).float().T + b.to(cuda)
+    ref = h32[:, :F] * torch.nn.functional.gelu(h32[:, F:])
+    assert rel_l2(out[:, :F], ref) < (8e-3 if lp == torch.bfloat16 else 1.2e-3)
+
+
 @pytest.mark.parametrize("M,N,K,rpg,affine,adaln", [(512, 384, 512, 256, False, True), (300, 16, 512, 0, True, False), (1024, 1536, 512, 512, True, True),
                                                      (130, 2048, 256, 0, False, False)])
 def test_layernorm_folded_into_the_gemms(cuda, M, N, K, rpg, affine, adaln):
