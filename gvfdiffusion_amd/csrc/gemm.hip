@@ -443,8 +443,8 @@ extern "C" int gvf_gemm(int dtype, const void* A, int lda, const void* W, int ld
     // round 6: large plain / GEGLU projections on the 256-wide EIGHT-wave kernel (csrc/gemm8.hip) once there is a tile per CU: 790-900 TFLOP/s where
     // the 128-wide one below reaches 560-640 (GVF_GEMM8=0: off -- the A/B switch; =2: from one tile on)
     static const int g8_mode = [] { const char* e = getenv("GVF_GEMM8"); return e == nullptr ? 1 : atoi(e); }();
-    if (g8_mode != 0 && gate == nullptr && (dtype == GVF_DT_BF16 || dtype == GVF_DT_F16) && gvf_gemm8_eligible(M, N, K, lda, ldw, ldc, epilogue) &&
-        (long long)(M / 256) * (N / 256) >= (g8_mode == 2 ? 1 : 256) && A && W && C &&
+    const int g8_tile = (g8_mode != 0 && gate == nullptr && (dtype == GVF_DT_BF16 || dtype == GVF_DT_F16)) ? gvf_gemm8_eligible(M, N, K, lda, ldw, ldc, epilogue) : 0;
+    if (g8_tile != 0 && (long long)(M / g8_tile) * (N / g8_tile) >= (g8_mode == 2 ? 1 : 256) && A && W && C &&
         ((((uintptr_t)A) | ((uintptr_t)W) | ((uintptr_t)C) | ((uintptr_t)bias)) & 15) == 0)
         return gvf_gemm8(dtype, A, lda, W, ldw, bias, C, ldc, M, N, K, epilogue, stream_);
     static const int big_mode = [] { const char* e = getenv("GVF_GEMM256"); return e == nullptr ? 0 : atoi(e); }();

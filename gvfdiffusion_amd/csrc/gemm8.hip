@@ -14,10 +14,15 @@
 // What the 128-wide kernel lacks is LDS bandwidth: four workgroups of 4 waves read one fragment per two MFMAs and stage 64 KiB per round, ~75 % of
 // the LDS cycles of an MFMA-bound loop; the 128 x 64 wave tile reads 0.375 fragments per MFMA and stages half as much per flop.
 //
-// Epilogues: GVF_EPI_STORE_BF16 (16-bit store, bias) and GVF_EPI_GEGLU_16 (the wave's 64 columns are 32 value columns then their 32 gate columns,
+// The N = 768 residual projections of a latent block (to_out, mlp.2: 12 288 x 768, x += a w^T + b on the fp32 stream) have 144 tiles of 256^2 for 256 CUs;
+// they run the same loop on 192 x 192 tiles (T = 192: wave tile 96 x 48, 72 accumulator registers, 96 KiB of LDS): 64 x 4 = exactly one tile per CU,
+// each XCD 8 tile rows = its own band of A and all of W.  to_out 410 -> 501 TFLOP/s (hipBLASLt 515), mlp.2 (K = 3072) 596 -> 850 (929).
+//
+// Epilogues: GVF_EPI_RESID_F32 without a gate (T = 192: 16-byte read-modify-writes straight from the accumulators), GVF_EPI_STORE_BF16 (16-bit store, bias) and GVF_EPI_GEGLU_16 (the wave's 64 columns are 32 value columns then their 32 gate columns,
 // csrc/gemm.hip's convention: value and gate of one output sit in ONE lane here, so the GEGLU is register arithmetic; both rounded to the operand
 // type first = bit-identical to the store epilogue + gvf_geglu).  The tile leaves through the (free) operand stages as whole row pieces.
-// gvf_gemm routes eligible calls here (M, N multiples of 256, K of 64, at least one tile per CU); GVF_GEMM8=0 switches it off.
+// gvf_gemm routes eligible calls here (M, N multiples of the tile, K of 64, at least one tile per CU); GVF_GEMM8=0 switches it off.
+// In place (motion-VAE decode, cold operands): latent blocks 5.65 -> 4.84 ms, decode 17.07 -> 16.65 ms bf16 (profiles/r06_gemm8.txt).
 #include <cstdlib>
 #include "gvf_common.h"
 #include "gvf_lp.h"
@@ -29,10 +34,9 @@ namespace {
 typedef gvf_f32x4 f32x4;
 
 constexpr int G8_THREADS = 512;
-constexpr int G8_T = 256;                 // tile rows (M) and columns (N)
 constexpr int G8_BK = 64;
-constexpr int G8_OP = G8_T * 8;           // 16-byte chunks of one operand tile (256 rows x 64 k)
-constexpr int G8_STAGE = 2 * G8_OP;       // A tile, then W tile
+// T = tile rows (M) and columns (N): 256, or 192 -- the square that gives the N = 768 projections of a 12 288-row latent block exactly one tile per CU
+// (64 x 4 tiles, each XCD 8 tile rows = its own band of A and all of W; 256-wide tiles leave 144 workgroups for 256 CUs).  Wave tile T/2 x T/4.
 
 __device__ __forceinline__ void g8_dma16(const unsigned short* g, uint4* l) {
     __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
@@ -40,13 +44,19 @@ __device__ __forceinline__ void g8_dma16(const unsigned short* g, uint4* l) {
 
 __device__ __forceinline__ float g8_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }   // as csrc/gemm.hip / csrc/vae.hip
 
-template <int DT, int EPI>
+template <int DT, int EPI, int T>
 __global__ __launch_bounds__(G8_THREADS, 1) void gemm8_kernel(const unsigned short* __restrict__ A, int lda, const unsigned short* __restrict__ W, int ldw,
-                                                              const float* __restrict__ bias, unsigned short* __restrict__ C, int ldc, int K,
+                                                              const float* __restrict__ bias, void* __restrict__ Cv, int ldc, int K,
                                                               int tiles_m, int tiles_n) {
     typedef GvfLp<DT> LP;
     typedef typename LP::x8 x8;
-    extern __shared__ __attribute__((aligned(16))) uint4 g8_smem[];          // [2 stages][A: 2048 chunks | W: 2048 chunks] = 128 KiB
+    constexpr int G8_T = T;
+    constexpr int G8_OP = G8_T * 8;           // 16-byte chunks of one operand tile (T rows x 64 k)
+    constexpr int G8_STAGE = 2 * G8_OP;       // A tile, then W tile
+    constexpr int FM = T / 32, FN = T / 64;   // 16-row / 16-column fragments of the wave tile (8 x 4 or 6 x 3)
+    constexpr int NDMA = T / 64;              // DMA instructions per wave, operand and k-tile (64 lanes x 16 B = 8 tile rows each)
+    unsigned short* C = reinterpret_cast<unsigned short*>(Cv);
+    extern __shared__ __attribute__((aligned(16))) uint4 g8_smem[];          // [2 stages][A | W]: 128 KiB (T = 256) / 96 KiB (T = 192)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3, l15 = lane & 15, lq = lane >> 4;
@@ -67,18 +77,18 @@ __global__ __launch_bounds__(G8_THREADS, 1) void gemm8_kernel(const unsigned sho
     const unsigned short* a_tile = A + (size_t)bm * lda;
     const unsigned short* w_tile = W + (size_t)bn * ldw;
 #define G8_STAGE_IN(kt_, buf_)                                                                                       \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                  \
+    _Pragma("unroll") for (int i = 0; i < NDMA; ++i) {                                                               \
         g8_dma16(a_tile + ((size_t)(i * 64) * lda + (size_t)(kt_) * G8_BK) + a_off, &g8_smem[(buf_) * G8_STAGE + (i * 8 + wave) * 64]);          \
         g8_dma16(w_tile + ((size_t)(i * 64) * ldw + (size_t)(kt_) * G8_BK) + w_off, &g8_smem[(buf_) * G8_STAGE + G8_OP + (i * 8 + wave) * 64]);  \
     }
 
-    f32x4 acc[4][8];                      // [column fragment][row fragment]: acc[i][j][r] = C[bm + 128 wm + 16 j + l15][bn + 64 wn + 16 i + 4 lq + r]
+    f32x4 acc[FN][FM];                    // [column fragment][row fragment]: acc[i][j][r] = C[bm + (T/2) wm + 16 j + l15][bn + (T/4) wn + 16 i + 4 lq + r]
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < FN; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int a_row0 = wm * 128 + l15, w_row0 = wn * 64 + l15;            // (+ 16 j keeps row & 7)
+    const int a_row0 = wm * (T / 2) + l15, w_row0 = wn * (T / 4) + l15;   // (+ 16 j keeps row & 7)
     const int a_sw = a_row0 & 7, w_sw = w_row0 & 7;
     const int KT = K / G8_BK;
     G8_STAGE_IN(0, 0)
@@ -89,23 +99,40 @@ __global__ __launch_bounds__(G8_THREADS, 1) void gemm8_kernel(const unsigned sho
         const uint4* sA = &g8_smem[buf * G8_STAGE], *sW = sA + G8_OP;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            x8 af[8], wf[4];
+            x8 af[FM], wf[FN];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) af[j] = __builtin_bit_cast(x8, sA[(a_row0 + 16 * j) * 8 + ((4 * ks + lq) ^ a_sw)]);
+            for (int j = 0; j < FM; ++j) af[j] = __builtin_bit_cast(x8, sA[(a_row0 + 16 * j) * 8 + ((4 * ks + lq) ^ a_sw)]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) wf[i] = __builtin_bit_cast(x8, sW[(w_row0 + 16 * i) * 8 + ((4 * ks + lq) ^ w_sw)]);
+            for (int i = 0; i < FN; ++i) wf[i] = __builtin_bit_cast(x8, sW[(w_row0 + 16 * i) * 8 + ((4 * ks + lq) ^ w_sw)]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < FN; ++i)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[i][j] = LP::mfma16(wf[i], af[j], acc[i][j]);       // D[n][m]: a lane gets 4 consecutive columns of one row
+                for (int j = 0; j < FM; ++j) acc[i][j] = LP::mfma16(wf[i], af[j], acc[i][j]);     // D[n][m]: a lane gets 4 consecutive columns of one row
         }
         __syncthreads();                  // drains this wave's DMA (vmcnt(0)), publishes the next stage; everybody is done with this one
     }
 #undef G8_STAGE_IN
 
-    // ---- epilogue: the wave's tile through its own 16 KiB of the (now free) stages, out as whole row pieces
+    if constexpr (EPI == GVF_EPI_RESID_F32) {
+        // x += acc + bias on the fp32 stream, straight from the accumulators: a lane holds 4 consecutive columns of a row (one 16-byte
+        // read-modify-write; a wave instruction covers 16 rows x 64 bytes)
+        float* Cf = reinterpret_cast<float*>(Cv) + (size_t)(bm + wm * (T / 2) + l15) * ldc + bn + wn * (T / 4) + 4 * lq;
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+            const float4 b4 = bias != nullptr ? *reinterpret_cast<const float4*>(bias + bn + wn * (T / 4) + 16 * i + 4 * lq) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < FM; ++j) {
+                float4* c = reinterpret_cast<float4*>(Cf + (size_t)(16 * j) * ldc + 16 * i);
+                float4 x = *c;
+                x.x += acc[i][j][0] + b4.x; x.y += acc[i][j][1] + b4.y; x.z += acc[i][j][2] + b4.z; x.w += acc[i][j][3] + b4.w;
+                *c = x;
+            }
+        }
+    } else {
+    // ---- 16-bit epilogues: the wave's tile through its own slice of the (now free) stages, out as whole row pieces
+    static_assert(T == 256, "the 16-bit epilogues are written for the 128 x 64 wave tile");
     uint4* so = &g8_smem[wave * 1024];
-    if (EPI == GVF_EPI_GEGLU_16) {
+    if constexpr (EPI == GVF_EPI_GEGLU_16) {
         // columns 16 i + 4 lq + r of the wave's 64: i = 0, 1 are values, i = 2, 3 their gates -> 32 output columns, [row][4 chunks of 8 columns],
         // chunk c of row m at slot c ^ ((m >> 1) & 3)
 #pragma unroll
@@ -138,6 +165,7 @@ __global__ __launch_bounds__(G8_THREADS, 1) void gemm8_kernel(const unsigned sho
         }
         return;
     }
+    if constexpr (EPI == GVF_EPI_GEGLU_16) return;          // (the store form below indexes the full wave tile)
     // store: [row][8 chunks of 8 columns], chunk c of row m at slot c ^ (m & 7)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -159,43 +187,56 @@ __global__ __launch_bounds__(G8_THREADS, 1) void gemm8_kernel(const unsigned sho
         const uint4 v = so[row * 8 + ((lane & 7) ^ (row & 7))];
         *reinterpret_cast<uint4*>(crow + (size_t)row * ldc) = v;
     }
+    }
 }
 
-template <int DT, int EPI>
+template <int DT, int EPI, int T>
 int g8_launch(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M, int N, int K, hipStream_t stream) {
     static GvfPerDeviceOnce once;                                           // per instantiation and per device (gvf_common.h)
+    constexpr int lds_bytes = 2 * (2 * T * 8) * 16;
     if (!gvf_once_per_device(once, [] {
-            return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8_kernel<DT, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G8_STAGE * 16) ==
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8_kernel<DT, EPI, T>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) ==
                    hipSuccess;
         }))
         return GVF_ELAUNCH;
-    const int tiles_m = M / G8_T, tiles_n = N / G8_T;
-    gemm8_kernel<DT, EPI><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(G8_THREADS), 2 * G8_STAGE * 16, stream>>>(
-        (const unsigned short*)A, lda, (const unsigned short*)W, ldw, bias, (unsigned short*)C, ldc, K, tiles_m, tiles_n);
+    const int tiles_m = M / T, tiles_n = N / T;
+    gemm8_kernel<DT, EPI, T><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(G8_THREADS), lds_bytes, stream>>>(
+        (const unsigned short*)A, lda, (const unsigned short*)W, ldw, bias, C, ldc, K, tiles_m, tiles_n);
     return GVF_OK;
+}
+
+// the tile this call would run on: 256, 192 (residual epilogue only) or 0 = not eligible
+int g8_tile(int M, int N, int K, int lda, int ldw, int ldc, int epilogue) {
+    if (epilogue != GVF_EPI_STORE_BF16 && epilogue != GVF_EPI_GEGLU_16 && epilogue != GVF_EPI_RESID_F32) return 0;
+    const int n_out = epilogue == GVF_EPI_GEGLU_16 ? N / 2 : N;
+    const int cal = epilogue == GVF_EPI_RESID_F32 ? 4 : 8;                  // C rows: 16-byte aligned pieces
+    if (!(M > 0 && N > 0 && K > 0 && (K % G8_BK) == 0 && (lda % 8) == 0 && (ldw % 8) == 0 && (ldc % cal) == 0 && lda >= K && ldw >= K && ldc >= n_out)) return 0;
+    if (epilogue == GVF_EPI_RESID_F32) {
+        // the fp32 residual epilogue exists for the shapes it was built for: squares of 192 (the motion VAE's to_out / mlp.2: 12 288 x 768)
+        return ((M % 192) == 0 && (N % 192) == 0 && (long long)(M / 192) * (N / 192) <= 0x7fffffffLL) ? 192 : 0;
+    }
+    return ((M % 256) == 0 && (N % 256) == 0 && (long long)(M / 256) * (N / 256) <= 0x7fffffffLL) ? 256 : 0;
 }
 
 }  // namespace
 
-extern "C" int gvf_gemm8_eligible(int M, int N, int K, int lda, int ldw, int ldc, int epilogue) {
-    if (epilogue != GVF_EPI_STORE_BF16 && epilogue != GVF_EPI_GEGLU_16) return 0;
-    const int n_out = epilogue == GVF_EPI_GEGLU_16 ? N / 2 : N;
-    return M > 0 && N > 0 && K > 0 && (M % G8_T) == 0 && (N % G8_T) == 0 && (K % G8_BK) == 0 && (lda % 8) == 0 && (ldw % 8) == 0 && (ldc % 8) == 0 &&
-           lda >= K && ldw >= K && ldc >= n_out && (long long)(M / G8_T) * (N / G8_T) <= 0x7fffffffLL;
-}
+extern "C" int gvf_gemm8_eligible(int M, int N, int K, int lda, int ldw, int ldc, int epilogue) { return g8_tile(M, N, K, lda, ldw, ldc, epilogue); }
 
 extern "C" int gvf_gemm8(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M, int N, int K,
                          int epilogue, void* stream_) {
     if (dtype != GVF_DT_BF16 && dtype != GVF_DT_F16) return GVF_EINVAL;
-    if (!gvf_gemm8_eligible(M, N, K, lda, ldw, ldc, epilogue)) return GVF_EINVAL;
+    const int tile = g8_tile(M, N, K, lda, ldw, ldc, epilogue);
+    if (tile == 0) return GVF_EINVAL;
     if (!A || !W || !C) return GVF_EINVAL;
     if ((((uintptr_t)A) & 15) || (((uintptr_t)W) & 15) || (((uintptr_t)C) & 15) || (bias != nullptr && (((uintptr_t)bias) & 15))) return GVF_EINVAL;
     (void)hipGetLastError();
     int rc = GVF_OK;
     if (epilogue == GVF_EPI_GEGLU_16) {
-        GVF_LP_DISPATCH(dtype, rc = (g8_launch<DT, GVF_EPI_GEGLU_16>(A, lda, W, ldw, bias, C, ldc, M, N, K, (hipStream_t)stream_)));
+        GVF_LP_DISPATCH(dtype, rc = (g8_launch<DT, GVF_EPI_GEGLU_16, 256>(A, lda, W, ldw, bias, C, ldc, M, N, K, (hipStream_t)stream_)));
+    } else if (epilogue == GVF_EPI_RESID_F32) {
+        GVF_LP_DISPATCH(dtype, rc = (g8_launch<DT, GVF_EPI_RESID_F32, 192>(A, lda, W, ldw, bias, C, ldc, M, N, K, (hipStream_t)stream_)));
     } else {
-        GVF_LP_DISPATCH(dtype, rc = (g8_launch<DT, GVF_EPI_STORE_BF16>(A, lda, W, ldw, bias, C, ldc, M, N, K, (hipStream_t)stream_)));
+        GVF_LP_DISPATCH(dtype, rc = (g8_launch<DT, GVF_EPI_STORE_BF16, 256>(A, lda, W, ldw, bias, C, ldc, M, N, K, (hipStream_t)stream_)));
     }
     if (rc != GVF_OK) return rc;
     GVF_CHECK_LAUNCH();

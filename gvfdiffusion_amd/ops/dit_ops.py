@@ -493,9 +493,11 @@ def attention_tiled64(q, k_tiles, v_tiles, out, n_outer, n_inner, Lq, Lk, H, q_s
 
 def gemm8(a: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, epilogue: int = 0):
     """out = epi(a @ w.T + bias) on csrc/gemm8.hip's 256 x 256 x 64 tiles, eight waves (M, N multiples of 256, K of 64); epilogue EPI_STORE_16 or
-    EPI_GEGLU_16 (out (M, N / 2)).  gvf_gemm takes this kernel by itself for eligible shapes; this is the direct entry (tests, benchmarks)."""
+    EPI_GEGLU_16 (out (M, N / 2)), or EPI_RESID_F32 without a gate (out fp32 (M, N) += ..., 192-wide tiles: M, N multiples of 192).  gvf_gemm takes
+    this kernel by itself for eligible shapes; this is the direct entry (tests, benchmarks)."""
     _lib.require_cuda(a, w, out)
-    assert a.dtype in LP_DTYPES and w.dtype == a.dtype and out.dtype == a.dtype and a.stride(1) == 1 and w.stride(1) == 1 and out.stride(1) == 1
+    assert a.dtype in LP_DTYPES and w.dtype == a.dtype and out.dtype == (torch.float32 if epilogue == EPI_RESID_F32 else a.dtype)
+    assert a.stride(1) == 1 and w.stride(1) == 1 and out.stride(1) == 1
     M, K = a.shape
     N = w.shape[0]
     _lib.check(_lib.lib().gvf_gemm8(dt_code(a.dtype), _p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), M, N, K, int(epilogue),

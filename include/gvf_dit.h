@@ -186,8 +186,10 @@ int gvf_gemm256(int dtype, const void* A, int lda, const void* W, int ldw, const
 
 /* The same projection on 256 x 256 x 64 tiles with EIGHT waves, two per SIMD (csrc/gemm8.hip, round 6): 790-900 TFLOP/s on the motion VAE's large
  * projections where gvf_gemm's 128-wide kernel reaches 560-640.  epilogue: GVF_EPI_STORE_BF16 (C 16-bit [M][N]) or GVF_EPI_GEGLU_16 (C 16-bit
- * [M][N/2], the interleaved value / gate convention of gvf_gemm).  gvf_gemm8_eligible: M, N multiples of 256, K of 64, 16-byte rows.  gvf_gemm takes
- * it by itself for eligible calls with at least one tile per CU (GVF_GEMM8=0: off, =2: from one tile on). */
+ * [M][N/2], the interleaved value / gate convention of gvf_gemm) on 256-wide tiles, or GVF_EPI_RESID_F32 WITHOUT a gate (C f32 [M][N] += acc + bias)
+ * on 192 x 192 tiles -- one tile per CU for the VAE's 12 288 x 768 residual projections.  gvf_gemm8_eligible: the tile it would use (256 / 192) or 0:
+ * M, N multiples of the tile, K of 64, 16-byte rows.  gvf_gemm takes it by itself for eligible calls with at least one tile per CU
+ * (GVF_GEMM8=0: off, =2: from one tile on). */
 int gvf_gemm8_eligible(int M, int N, int K, int lda, int ldw, int ldc, int epilogue);
 int gvf_gemm8(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M, int N, int K,
               int epilogue, void* stream);

@@ -142,8 +142,33 @@ def test_eight_wave_projection_kernel_matches_fp32_and_the_four_wave_one(cuda, l
     with pytest.raises(_lib.GvfError):
         dit_ops.gemm8(a[:255], w, bias, out[:255])
     L = _lib.lib()
-    assert L.gvf_gemm8_eligible(M, N, K, K + 8, K, N + 16, dit_ops.EPI_STORE_BF16) == 1 and L.gvf_gemm8_eligible(M, N, K, K + 8, K, N + 16, dit_ops.EPI_RESID_F32) == 0
+    assert L.gvf_gemm8_eligible(M, N, K, K + 8, K, N + 16, dit_ops.EPI_STORE_BF16) == 256 and L.gvf_gemm8_eligible(M, N, K, K + 8, K, N + 16, dit_ops.EPI_STORE_F32) == 0
     assert L.gvf_gemm8_eligible(M, N + 64, K, K + 8, K, N + 64, dit_ops.EPI_STORE_BF16) == 0
+
+
+@pytest.mark.parametrize("lp", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K,has_bias", [(12288, 768, 768, True), (12288, 768, 3072, False), (192, 192, 64, True), (384, 1536, 128, True)])
+def test_eight_wave_residual_epilogue_on_192_wide_tiles(cuda, lp, M, N, K, has_bias):
+    """gvf_gemm8 with GVF_EPI_RESID_F32 (no gate): x += a w^T + bias on the fp32 stream, 192 x 192 tiles (one per CU for the motion VAE's to_out /
+    mlp.2: 12 288 x 768).  Against an fp32 product of the same 16-bit operands (1e-5: fp32 accumulation of exact products), nothing beyond the
+    tile written, repeated launches accumulate the same bits, shapes off the 192 grid refused."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn((M, K), generator=g).to(lp).to(cuda)
+    w = (torch.randn((N, K), generator=g) / math.sqrt(K)).to(lp).to(cuda)
+    bias = torch.randn((N,), generator=g).to(cuda) if has_bias else None
+    x0 = torch.randn((M, N + 4), generator=g).to(cuda)
+    xbuf = x0.clone()
+    x = xbuf[:, :N]
+    dit_ops.gemm8(a, w, bias, x, dit_ops.EPI_RESID_F32)
+    ref = x0[:, :N] + a.float() @ w.float().T + (bias if has_bias else 0.0)
+    assert rel_l2(x, ref) < 1e-5 and torch.equal(xbuf[:, N:], x0[:, N:])
+    x2 = x0.clone()
+    dit_ops.gemm8(a, w, bias, x2[:, :N], dit_ops.EPI_RESID_F32)
+    assert torch.equal(x2, xbuf)
+    assert _lib.lib().gvf_gemm8_eligible(M, N, K, K, K, N + 4, dit_ops.EPI_RESID_F32) == 192
+    assert _lib.lib().gvf_gemm8_eligible(M + 64, N, K, K, K, N + 4, dit_ops.EPI_RESID_F32) == 0
+    with pytest.raises(_lib.GvfError):
+        dit_ops.gemm8(a[:100], w, bias, x[:100], dit_ops.EPI_RESID_F32)
 
 
 @pytest.mark.parametrize("lp", [torch.bfloat16, torch.float16])
