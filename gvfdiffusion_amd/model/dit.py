@@ -429,6 +429,20 @@ class DiT(nn.Module):
         B, Tc, Li, Ci = cond_images.shape
         Ls = static_latent.shape[1]
         ctx = {"T": T, "lp": lp, "held": (conds, tuple(self._key(t) for t in conds)), "Li": Li, "Ls": Ls}
+        # Round 6: the cache's device buffers (the 24 K / V tile images, the position embedding) PERSIST across condition sets of one shape: a new
+        # sample refills them in place, so a captured hipGraph that reads them stays valid -- the next sample costs its condition products
+        # (~4.7 ms at the released config), not those + an eager forward + a re-capture (~16 ms; measured 199.5 -> 215.8 ms per sample with
+        # fresh condition tensors).  `epoch` names the buffer set; the graph is keyed on it (_forward_graphed).  Everything that reads the
+        # buffers runs on the caller's stream, behind the refill.
+        shape_key = (T, lp, str(dev), tuple(cond_images.shape), tuple(static_latent.shape),
+                     None if deformation_position_xyz is None else tuple(deformation_position_xyz.shape), self.head_dim, self.pe_mode)
+        old = self._ctx_cache if self._ctx_cache.get("shape_key") == shape_key else None
+        ctx["shape_key"] = shape_key
+        if old is not None:
+            ctx["epoch"] = old["epoch"]
+        else:
+            DiT._CTX_EPOCH = getattr(DiT, "_CTX_EPOCH", 0) + 1
+            ctx["epoch"] = DiT._CTX_EPOCH
         # Step-invariant: the condition projections and every block's to_kv(context) (model/dit.py:464-465, model/attention/modules.py:134-143)
         # at fp32-class accuracy on the bf16 matrix pipe -- both operands as two-term bf16 expansions laid out along K (dit_ops.split3_bf16:
         # a w^T = a_hi w_hi^T + a_lo w_hi^T + a_hi w_lo^T + O(2^-16)), ONE plain gvf_gemm with fp32 accumulation and fp32 output per projection
@@ -461,20 +475,31 @@ class DiT(nn.Module):
             if self.head_dim != 32:
                 # head_dim 64: the strided flash attention reads row-major [k | v] rows of the operand type (one rounding of the fp32-class
                 # projection, as the tile image's); MultiHeadRMSNorm of k is the kernel's prologue (gamma_k)
-                ctx["kv_img"].append(kv_i.to(lp))
-                ctx["kv_st"].append(kv_s.to(lp))
+                if old is not None:
+                    old["kv_img"][i].copy_(kv_i); old["kv_st"][i].copy_(kv_s)
+                    ctx["kv_img"].append(old["kv_img"][i]); ctx["kv_st"].append(old["kv_st"][i])
+                else:
+                    ctx["kv_img"].append(kv_i.to(lp))
+                    ctx["kv_st"].append(kv_s.to(lp))
                 continue
             ctx["kv_img"].append(dit_ops.attention_pack_kv(kv_i, B * Tc, Li, H, 0, C, gamma_k=b["image_cross_attn"]["gk"], dtype=lp,
-                                                           key_order=order(kv_i, B * Tc, Li)))
+                                                           key_order=order(kv_i, B * Tc, Li), out=None if old is None else old["kv_img"][i]))
             ctx["kv_st"].append(dit_ops.attention_pack_kv(kv_s, B, Ls, H, 0, C, gamma_k=b["static_cross_attn"]["gk"], dtype=lp,
-                                                          key_order=order(kv_s, B, Ls)))
+                                                          key_order=order(kv_s, B, Ls), out=None if old is None else old["kv_st"][i]))
         if self.pe_mode == "ape":
             assert deformation_position_xyz is not None, "Deformation position xyz is required for APE mode"
-            ctx["pos"] = self.pos_embedder(deformation_position_xyz).float().contiguous()      # (B, N, C)
+            pos = self.pos_embedder(deformation_position_xyz).float().contiguous()      # (B, N, C)
         elif self.pe_mode == "learnable":
-            ctx["pos"] = self.pos_embedder.detach().float().expand(B, -1, -1).contiguous()
+            pos = self.pos_embedder.detach().float().expand(B, -1, -1).contiguous()
         else:
-            ctx["pos"] = None
+            pos = None
+        if old is not None and pos is not None and old.get("pos") is not None and old["pos"].shape == pos.shape:
+            old["pos"].copy_(pos)
+            pos = old["pos"]
+        elif old is not None and (pos is None) != (old.get("pos") is None):
+            DiT._CTX_EPOCH += 1                    # (cannot happen for one shape_key; never leave a graph pointing at a dropped buffer)
+            ctx["epoch"] = DiT._CTX_EPOCH
+        ctx["pos"] = pos
         self._ctx_cache = ctx
         return ctx
 
@@ -579,11 +604,15 @@ class DiT(nn.Module):
         pv = self._param_version()                           # once per forward: 0.1-0.4 ms of host time
         mod_rows = self._mod_from_table(t, x.shape[0], pv)   # (looked up from the HOST values the tensor carries: no read-back)
         t = t.to(x.device)
+        # the step-invariant condition products: a hit for every step of a sample (identity of the three tensors); a NEW sample's are computed
+        # here, eagerly, INTO the buffers the captured graph reads (prepare_conditions keeps them per shape: `epoch`), so the graph is replayed
+        # for sample after sample and re-captured only when the buffer set itself changes (another shape, operand type or weight version)
+        ctx = self.prepare_conditions(cond_images, static_latent, deformation_position_xyz, x.shape[1])
         key = (tuple(x.shape), x.dtype, tuple(t.shape), t.dtype, pv, self._lp(),
-               None if mod_rows is None else self._mod_table["mod"].data_ptr())
+               None if mod_rows is None else self._mod_table["mod"].data_ptr(), ctx["epoch"])
         conds = (cond_images, static_latent, deformation_position_xyz)
         g = self._graph
-        if g is None or g["key"] != key or not self._same_tensors(g["held"], conds):
+        if g is None or g["key"] != key:
             sx, st = x.clone(), t.clone()
             smod = None if mod_rows is None else mod_rows.clone()      # the row numbers: the graph gathers its rows of the table itself
             # One capture at a time per process, and in thread-local capture mode, so that a capture on one host thread does not fail because
