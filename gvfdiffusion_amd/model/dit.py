@@ -32,6 +32,7 @@ from .. import _lib
 
 
 _CAPTURE_LOCK = __import__("threading").Lock()      # hipGraph captures of DiT instances are serialised (see DiT._forward_graphed)
+_CTX_EPOCHS = __import__("itertools").count(1)      # names of the condition cache's buffer sets (DiT.prepare_conditions): a captured graph is keyed on one
 
 
 class AbsolutePositionEmbedder(nn.Module):
@@ -441,8 +442,7 @@ class DiT(nn.Module):
         if old is not None:
             ctx["epoch"] = old["epoch"]
         else:
-            DiT._CTX_EPOCH = getattr(DiT, "_CTX_EPOCH", 0) + 1
-            ctx["epoch"] = DiT._CTX_EPOCH
+            ctx["epoch"] = next(_CTX_EPOCHS)               # (itertools.count: unique across instances and host threads)
         # Step-invariant: the condition projections and every block's to_kv(context) (model/dit.py:464-465, model/attention/modules.py:134-143)
         # at fp32-class accuracy on the bf16 matrix pipe -- both operands as two-term bf16 expansions laid out along K (dit_ops.split3_bf16:
         # a w^T = a_hi w_hi^T + a_lo w_hi^T + a_hi w_lo^T + O(2^-16)), ONE plain gvf_gemm with fp32 accumulation and fp32 output per projection
@@ -497,8 +497,7 @@ class DiT(nn.Module):
             old["pos"].copy_(pos)
             pos = old["pos"]
         elif old is not None and (pos is None) != (old.get("pos") is None):
-            DiT._CTX_EPOCH += 1                    # (cannot happen for one shape_key; never leave a graph pointing at a dropped buffer)
-            ctx["epoch"] = DiT._CTX_EPOCH
+            ctx["epoch"] = next(_CTX_EPOCHS)               # (cannot happen for one shape_key; never leave a graph pointing at a dropped buffer)
         ctx["pos"] = pos
         self._ctx_cache = ctx
         return ctx
