@@ -833,9 +833,19 @@ constexpr int XT_PK_LD = 40;     // bf16 pitch of the staged V rows (80 B): the 
 template <typename TIn, int DT>
 __global__ __launch_bounds__(256) void attn_pack_kv_kernel(const TIn* __restrict__ kv, long long ld, int k_col0, int v_col0, int L, int H,
                                                            int n_tiles, float k_scale, const float* __restrict__ gamma_k,
-                                                           const int* __restrict__ key_order, uint4* __restrict__ kt, uint4* __restrict__ vt) {
+                                                           const int* __restrict__ key_order, uint4* __restrict__ kt, uint4* __restrict__ vt,
+                                                           long long group_stride, long long n_sets) {
     __shared__ unsigned short sV[XT_KT * XT_PK_LD];
     const int tid = threadIdx.x;
+    // blockIdx.y = group (gvf_attn_pack_kv_groups: the 12 blocks' to_kv products of one context in ONE launch): its rows start group_stride
+    // elements further, its gain / order / images follow the previous group's
+    if (blockIdx.y != 0) {
+        const long long g = blockIdx.y;
+        kv += g * group_stride;
+        if (gamma_k != nullptr) gamma_k += g * H * 32;
+        if (key_order != nullptr) key_order += g * n_sets * H * L;
+        kt += g * n_sets * H * n_tiles * 256; vt += g * n_sets * H * n_tiles * 256;
+    }
     long long rest = blockIdx.x;
     const int tile = (int)(rest % n_tiles); rest /= n_tiles;
     const int h = (int)(rest % H);
@@ -888,8 +898,10 @@ __global__ __launch_bounds__(256) void attn_pack_kv_kernel(const TIn* __restrict
 // 4 x 8-bit radix select over them (ties at the threshold: the first ones in context order), then ballot prefix sums hand out the slots.
 constexpr int KO_THREADS = 256, KO_MAX_L = 8192;
 __global__ __launch_bounds__(KO_THREADS) void key_order_kernel(const float* __restrict__ kv, long long ld, int k_col0, int L, int H, int n_first,
-                                                               int* __restrict__ order) {
-    __shared__ unsigned sN[KO_MAX_L];
+                                                               int* __restrict__ order, long long group_stride, long long n_sets) {
+    extern __shared__ unsigned sN[];              // L words (up to KO_MAX_L = 32 KiB): sized by the launch so that short contexts fill the CUs
+    kv += (long long)blockIdx.y * group_stride;   // blockIdx.y = group (gvf_attn_key_order_groups)
+    order += (long long)blockIdx.y * n_sets * H * L;
     __shared__ unsigned sHist[256];
     __shared__ unsigned sSel[4];                 // prefix, remaining, (partition) running counts
     __shared__ unsigned sWave[2][KO_THREADS / 64];
@@ -961,16 +973,24 @@ __global__ __launch_bounds__(KO_THREADS) void key_order_kernel(const float* __re
 
 }  // namespace
 
-extern "C" int gvf_attn_key_order(const float* kv, int64_t ld, int k_col0, int n_sets, int L, int H, int n_first, int32_t* key_order, void* stream_) {
-    if (n_sets < 0 || L <= 0 || L > KO_MAX_L || H <= 0 || ld <= 0 || k_col0 < 0 || n_first <= 0 || (ld % 4) || (k_col0 % 4)) return GVF_EINVAL;
-    if (n_sets == 0) return GVF_OK;
+extern "C" int gvf_attn_key_order_groups(const float* kv, int64_t ld, int64_t group_stride, int n_groups, int k_col0, int n_sets, int L, int H, int n_first,
+                                         int32_t* key_order, void* stream_) {
+    if (n_sets < 0 || n_groups < 0 || n_groups > 65535 || group_stride < 0 || L <= 0 || L > KO_MAX_L || H <= 0 || ld <= 0 || k_col0 < 0 || n_first <= 0 ||
+        (ld % 4) || (k_col0 % 4) || (group_stride % 4))
+        return GVF_EINVAL;
+    if (n_sets == 0 || n_groups == 0) return GVF_OK;
     if (!kv || !key_order || (((uintptr_t)kv) & 15)) return GVF_EINVAL;
     const long long blocks = (long long)n_sets * H;
     if (blocks > 0x7fffffffLL) return GVF_EINVAL;
     (void)hipGetLastError();
-    key_order_kernel<<<dim3((unsigned)blocks), dim3(KO_THREADS), 0, (hipStream_t)stream_>>>(kv, (long long)ld, k_col0, L, H, n_first, key_order);
+    key_order_kernel<<<dim3((unsigned)blocks, (unsigned)n_groups), dim3(KO_THREADS), (size_t)L * sizeof(unsigned), (hipStream_t)stream_>>>(
+        kv, (long long)ld, k_col0, L, H, n_first, key_order, (long long)group_stride, (long long)n_sets);
     GVF_CHECK_LAUNCH();
     return GVF_OK;
+}
+
+extern "C" int gvf_attn_key_order(const float* kv, int64_t ld, int k_col0, int n_sets, int L, int H, int n_first, int32_t* key_order, void* stream_) {
+    return gvf_attn_key_order_groups(kv, ld, 0, 1, k_col0, n_sets, L, H, n_first, key_order, stream_);
 }
 
 extern "C" int gvf_attn_pack_kv(int dtype, const void* kv, int kv_is_f32, int64_t ld, int k_col0, int v_col0, int n_sets, int L, int H,
@@ -980,9 +1000,15 @@ extern "C" int gvf_attn_pack_kv(int dtype, const void* kv, int kv_is_f32, int64_
 
 extern "C" int gvf_attn_pack_kv_ordered(int dtype, const void* kv, int kv_is_f32, int64_t ld, int k_col0, int v_col0, int n_sets, int L, int H,
                                         float k_scale, const float* gamma_k, const int32_t* key_order, void* k_tiles, void* v_tiles, void* stream_) {
+    return gvf_attn_pack_kv_groups(dtype, kv, kv_is_f32, ld, 0, 1, k_col0, v_col0, n_sets, L, H, k_scale, gamma_k, key_order, k_tiles, v_tiles, stream_);
+}
+
+extern "C" int gvf_attn_pack_kv_groups(int dtype, const void* kv, int kv_is_f32, int64_t ld, int64_t group_stride, int n_groups, int k_col0, int v_col0,
+                                       int n_sets, int L, int H, float k_scale, const float* gamma_k, const int32_t* key_order, void* k_tiles,
+                                       void* v_tiles, void* stream_) {
     if (dtype != GVF_DT_BF16 && dtype != GVF_DT_F16) return GVF_EINVAL;
-    if (n_sets < 0 || L <= 0 || H <= 0 || ld <= 0 || k_col0 < 0 || v_col0 < 0) return GVF_EINVAL;
-    if (n_sets == 0) return GVF_OK;
+    if (n_sets < 0 || n_groups < 0 || n_groups > 65535 || group_stride < 0 || L <= 0 || H <= 0 || ld <= 0 || k_col0 < 0 || v_col0 < 0) return GVF_EINVAL;
+    if (n_sets == 0 || n_groups == 0) return GVF_OK;
     if (!kv || !k_tiles || !v_tiles) return GVF_EINVAL;
     if ((((uintptr_t)k_tiles) & 15) || (((uintptr_t)v_tiles) & 15)) return GVF_EINVAL;
     const int n_tiles = (L + XT_KT - 1) / XT_KT;
@@ -990,17 +1016,18 @@ extern "C" int gvf_attn_pack_kv_ordered(int dtype, const void* kv, int kv_is_f32
     if (blocks > 0x7fffffffLL) return GVF_EINVAL;
     // 16-byte (bf16) / 2 x 16-byte (fp32) row pieces: the row pitch and the two column offsets must keep that alignment
     const int al = kv_is_f32 ? 4 : 8;
-    if ((ld % al) || (k_col0 % al) || (v_col0 % al) || (((uintptr_t)kv) & 15)) return GVF_EINVAL;
+    if ((ld % al) || (k_col0 % al) || (v_col0 % al) || (group_stride % al) || (((uintptr_t)kv) & 15)) return GVF_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
+    const dim3 grid((unsigned)blocks, (unsigned)n_groups);
     (void)hipGetLastError();
     GVF_LP_DISPATCH(dtype,
         if (kv_is_f32)
-            attn_pack_kv_kernel<float, DT><<<dim3((unsigned)blocks), dim3(256), 0, stream>>>((const float*)kv, ld, k_col0, v_col0, L, H, n_tiles, k_scale,
-                                                                                             gamma_k, key_order, (uint4*)k_tiles, (uint4*)v_tiles);
+            attn_pack_kv_kernel<float, DT><<<grid, dim3(256), 0, stream>>>((const float*)kv, ld, k_col0, v_col0, L, H, n_tiles, k_scale, gamma_k, key_order,
+                                                                           (uint4*)k_tiles, (uint4*)v_tiles, (long long)group_stride, (long long)n_sets);
         else
-            attn_pack_kv_kernel<unsigned short, DT><<<dim3((unsigned)blocks), dim3(256), 0, stream>>>((const unsigned short*)kv, ld, k_col0, v_col0, L, H,
-                                                                                                      n_tiles, k_scale, gamma_k, key_order, (uint4*)k_tiles,
-                                                                                                      (uint4*)v_tiles));
+            attn_pack_kv_kernel<unsigned short, DT><<<grid, dim3(256), 0, stream>>>((const unsigned short*)kv, ld, k_col0, v_col0, L, H, n_tiles, k_scale,
+                                                                                    gamma_k, key_order, (uint4*)k_tiles, (uint4*)v_tiles,
+                                                                                    (long long)group_stride, (long long)n_sets));
     GVF_CHECK_LAUNCH();
     return GVF_OK;
 }

@@ -21,6 +21,8 @@
 // Epilogues: GVF_EPI_RESID_F32 without a gate (T = 192: 16-byte read-modify-writes straight from the accumulators), GVF_EPI_STORE_BF16 (16-bit store, bias) and GVF_EPI_GEGLU_16 (the wave's 64 columns are 32 value columns then their 32 gate columns,
 // csrc/gemm.hip's convention: value and gate of one output sit in ONE lane here, so the GEGLU is register arithmetic; both rounded to the operand
 // type first = bit-identical to the store epilogue + gvf_geglu).  The tile leaves through the (free) operand stages as whole row pieces.
+// GVF_EPI_STORE_F32 (fp32 store + bias from the accumulators, ANY M: the last row tile stages row M - 1 for the rows past the end and skips their
+// stores -- the hoisted condition projections of DiT.prepare_conditions, 24 x 1370 image tokens: 646 -> ~850 TFLOP/s).
 // gvf_gemm routes eligible calls here (M, N multiples of the tile, K of 64, at least one tile per CU); GVF_GEMM8=0 switches it off.
 // In place (motion-VAE decode, cold operands): latent blocks 5.65 -> 4.84 ms, decode 17.07 -> 16.65 ms bf16 (profiles/r06_gemm8.txt).
 #include <cstdlib>
@@ -46,7 +48,7 @@ __device__ __forceinline__ float g8_gelu_erf(float x) { return 0.5f * x * (1.0f 
 
 template <int DT, int EPI, int T>
 __global__ __launch_bounds__(G8_THREADS, 1) void gemm8_kernel(const unsigned short* __restrict__ A, int lda, const unsigned short* __restrict__ W, int ldw,
-                                                              const float* __restrict__ bias, void* __restrict__ Cv, int ldc, int K,
+                                                              const float* __restrict__ bias, void* __restrict__ Cv, int ldc, int M, int K,
                                                               int tiles_m, int tiles_n) {
     typedef GvfLp<DT> LP;
     typedef typename LP::x8 x8;
@@ -76,9 +78,17 @@ __global__ __launch_bounds__(G8_THREADS, 1) void gemm8_kernel(const unsigned sho
     const unsigned a_off = (unsigned)(st_row * lda + st_chunk * 8), w_off = (unsigned)(st_row * ldw + st_chunk * 8);
     const unsigned short* a_tile = A + (size_t)bm * lda;
     const unsigned short* w_tile = W + (size_t)bn * ldw;
+    // GVF_EPI_STORE_F32 takes any M: the last row tile stages row M - 1 in place of the rows past the end (never stored)
+    constexpr bool RAGGED = EPI == GVF_EPI_STORE_F32;
+    size_t a_rag[NDMA];
+    if constexpr (RAGGED) {
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) { const int r = bm + i * 64 + st_row; a_rag[i] = (size_t)(r < M ? r : M - 1) * lda + st_chunk * 8; }
+    }
+#define G8_A_SRC(i_, kt_) (RAGGED ? A + a_rag[i_] + (size_t)(kt_) * G8_BK : a_tile + ((size_t)((i_) * 64) * lda + (size_t)(kt_) * G8_BK) + a_off)
 #define G8_STAGE_IN(kt_, buf_)                                                                                       \
     _Pragma("unroll") for (int i = 0; i < NDMA; ++i) {                                                               \
-        g8_dma16(a_tile + ((size_t)(i * 64) * lda + (size_t)(kt_) * G8_BK) + a_off, &g8_smem[(buf_) * G8_STAGE + (i * 8 + wave) * 64]);          \
+        g8_dma16(G8_A_SRC(i, kt_), &g8_smem[(buf_) * G8_STAGE + (i * 8 + wave) * 64]);                                                            \
         g8_dma16(w_tile + ((size_t)(i * 64) * ldw + (size_t)(kt_) * G8_BK) + w_off, &g8_smem[(buf_) * G8_STAGE + G8_OP + (i * 8 + wave) * 64]);  \
     }
 
@@ -112,8 +122,22 @@ __global__ __launch_bounds__(G8_THREADS, 1) void gemm8_kernel(const unsigned sho
         __syncthreads();                  // drains this wave's DMA (vmcnt(0)), publishes the next stage; everybody is done with this one
     }
 #undef G8_STAGE_IN
+#undef G8_A_SRC
 
-    if constexpr (EPI == GVF_EPI_RESID_F32) {
+    if constexpr (EPI == GVF_EPI_STORE_F32) {
+        // C = acc + bias in fp32, straight from the accumulators (a lane holds 4 consecutive columns of a row: one 16-byte store); rows past M skipped
+        const int row0 = bm + wm * (T / 2) + l15;
+        float* Cf = reinterpret_cast<float*>(Cv) + (size_t)row0 * ldc + bn + wn * (T / 4) + 4 * lq;
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+            const float4 b4 = bias != nullptr ? *reinterpret_cast<const float4*>(bias + bn + wn * (T / 4) + 16 * i + 4 * lq) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < FM; ++j)
+                if (row0 + 16 * j < M)
+                    *reinterpret_cast<float4*>(Cf + (size_t)(16 * j) * ldc + 16 * i) =
+                        make_float4(acc[i][j][0] + b4.x, acc[i][j][1] + b4.y, acc[i][j][2] + b4.z, acc[i][j][3] + b4.w);
+        }
+    } else if constexpr (EPI == GVF_EPI_RESID_F32) {
         // x += acc + bias on the fp32 stream, straight from the accumulators: a lane holds 4 consecutive columns of a row (one 16-byte
         // read-modify-write; a wave instruction covers 16 rows x 64 bytes)
         float* Cf = reinterpret_cast<float*>(Cv) + (size_t)(bm + wm * (T / 2) + l15) * ldc + bn + wn * (T / 4) + 4 * lq;
@@ -199,22 +223,24 @@ int g8_launch(const void* A, int lda, const void* W, int ldw, const float* bias,
                    hipSuccess;
         }))
         return GVF_ELAUNCH;
-    const int tiles_m = M / T, tiles_n = N / T;
+    const int tiles_m = (M + T - 1) / T, tiles_n = N / T;            // (only GVF_EPI_STORE_F32 is let in with a ragged M: g8_tile)
     gemm8_kernel<DT, EPI, T><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(G8_THREADS), lds_bytes, stream>>>(
-        (const unsigned short*)A, lda, (const unsigned short*)W, ldw, bias, C, ldc, K, tiles_m, tiles_n);
+        (const unsigned short*)A, lda, (const unsigned short*)W, ldw, bias, C, ldc, M, K, tiles_m, tiles_n);
     return GVF_OK;
 }
 
 // the tile this call would run on: 256, 192 (residual epilogue only) or 0 = not eligible
 int g8_tile(int M, int N, int K, int lda, int ldw, int ldc, int epilogue) {
-    if (epilogue != GVF_EPI_STORE_BF16 && epilogue != GVF_EPI_GEGLU_16 && epilogue != GVF_EPI_RESID_F32) return 0;
+    if (epilogue != GVF_EPI_STORE_BF16 && epilogue != GVF_EPI_GEGLU_16 && epilogue != GVF_EPI_RESID_F32 && epilogue != GVF_EPI_STORE_F32) return 0;
     const int n_out = epilogue == GVF_EPI_GEGLU_16 ? N / 2 : N;
-    const int cal = epilogue == GVF_EPI_RESID_F32 ? 4 : 8;                  // C rows: 16-byte aligned pieces
+    const int cal = (epilogue == GVF_EPI_RESID_F32 || epilogue == GVF_EPI_STORE_F32) ? 4 : 8;                  // C rows: 16-byte aligned pieces
     if (!(M > 0 && N > 0 && K > 0 && (K % G8_BK) == 0 && (lda % 8) == 0 && (ldw % 8) == 0 && (ldc % cal) == 0 && lda >= K && ldw >= K && ldc >= n_out)) return 0;
     if (epilogue == GVF_EPI_RESID_F32) {
         // the fp32 residual epilogue exists for the shapes it was built for: squares of 192 (the motion VAE's to_out / mlp.2: 12 288 x 768)
         return ((M % 192) == 0 && (N % 192) == 0 && (long long)(M / 192) * (N / 192) <= 0x7fffffffLL) ? 192 : 0;
     }
+    if (epilogue == GVF_EPI_STORE_F32)       // any M (the hoisted condition projections: 24 x 1370 image tokens); the last row tile is guarded
+        return ((N % 256) == 0 && (long long)((M + 255) / 256) * (N / 256) <= 0x7fffffffLL) ? 256 : 0;
     return ((M % 256) == 0 && (N % 256) == 0 && (long long)(M / 256) * (N / 256) <= 0x7fffffffLL) ? 256 : 0;
 }
 
@@ -233,6 +259,8 @@ extern "C" int gvf_gemm8(int dtype, const void* A, int lda, const void* W, int l
     int rc = GVF_OK;
     if (epilogue == GVF_EPI_GEGLU_16) {
         GVF_LP_DISPATCH(dtype, rc = (g8_launch<DT, GVF_EPI_GEGLU_16, 256>(A, lda, W, ldw, bias, C, ldc, M, N, K, (hipStream_t)stream_)));
+    } else if (epilogue == GVF_EPI_STORE_F32) {
+        GVF_LP_DISPATCH(dtype, rc = (g8_launch<DT, GVF_EPI_STORE_F32, 256>(A, lda, W, ldw, bias, C, ldc, M, N, K, (hipStream_t)stream_)));
     } else if (epilogue == GVF_EPI_RESID_F32) {
         GVF_LP_DISPATCH(dtype, rc = (g8_launch<DT, GVF_EPI_RESID_F32, 192>(A, lda, W, ldw, bias, C, ldc, M, N, K, (hipStream_t)stream_)));
     } else {

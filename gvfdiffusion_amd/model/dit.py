@@ -452,40 +452,21 @@ class DiT(nn.Module):
         # softmax scale in and stores the tiled image the attention workgroups stage into LDS (csrc/attn_xt.hip); static K/V once per
         # sample, not per frame.
         H = self.num_heads
-        ctx["kv_img"], ctx["kv_st"] = [], []
         S3 = self._split3_weights(W)
         f32 = torch.float32
         img_emb = torch.empty((B * Tc * Li, C), dtype=f32, device=dev)
         st_emb = torch.empty((B * Ls, C), dtype=f32, device=dev)
-        kv_i = torch.empty((B * Tc * Li, 2 * C), dtype=f32, device=dev)
-        kv_s = torch.empty((B * Ls, 2 * C), dtype=f32, device=dev)
         dit_ops.gemm(dit_ops.split3_bf16(cond_images.reshape(B * Tc * Li, Ci).float().contiguous()), S3["img"], W["img_f32"][1], img_emb, dit_ops.EPI_STORE_F32)
         dit_ops.gemm(dit_ops.split3_bf16(static_latent.reshape(B * Ls, -1).float().contiguous()), S3["static"], W["static_f32"][1], st_emb, dit_ops.EPI_STORE_F32)
-        img3, st3 = dit_ops.split3_bf16(img_emb), dit_ops.split3_bf16(st_emb)       # shared by the 12 blocks
         # fp16 caches keep the 64 largest-norm keys of every (set, head) in the first tile (gvf_attn_key_order / gvf_attn_pack_kv_ordered): the kernel's per-query shift is the best
         # score against the FIRST key tile and a later key that beats it by 2^16 costs the workgroup an exact pass -- on trained-like scores
         # 38 % of the workgroups with the keys in context order, ~0 with the high-norm keys (attention sinks, artefact tokens) in front
         # (tests/test_dit_fp16_gpu.py::test_full_config_trained_like_weights).  bf16 needs no shift: context order (GVF_DIT_KEY_ORDER=0/1 forces).
         want = os.environ.get("GVF_DIT_KEY_ORDER")
         ordered = (lp == torch.float16) if want is None else want == "1"
-        order = (lambda kv_, n_, L_: dit_ops.key_order_by_norm(kv_, n_, L_, H, 0) if L_ <= 8192 else None) if ordered else (lambda kv_, n_, L_: None)
-        for i, b in enumerate(W["blocks"]):
-            dit_ops.gemm(img3, S3["kv_img"][i], b["image_cross_attn"]["kv_f32"][1], kv_i, dit_ops.EPI_STORE_F32)
-            dit_ops.gemm(st3, S3["kv_st"][i], b["static_cross_attn"]["kv_f32"][1], kv_s, dit_ops.EPI_STORE_F32)
-            if self.head_dim != 32:
-                # head_dim 64: the strided flash attention reads row-major [k | v] rows of the operand type (one rounding of the fp32-class
-                # projection, as the tile image's); MultiHeadRMSNorm of k is the kernel's prologue (gamma_k)
-                if old is not None:
-                    old["kv_img"][i].copy_(kv_i); old["kv_st"][i].copy_(kv_s)
-                    ctx["kv_img"].append(old["kv_img"][i]); ctx["kv_st"].append(old["kv_st"][i])
-                else:
-                    ctx["kv_img"].append(kv_i.to(lp))
-                    ctx["kv_st"].append(kv_s.to(lp))
-                continue
-            ctx["kv_img"].append(dit_ops.attention_pack_kv(kv_i, B * Tc, Li, H, 0, C, gamma_k=b["image_cross_attn"]["gk"], dtype=lp,
-                                                           key_order=order(kv_i, B * Tc, Li), out=None if old is None else old["kv_img"][i]))
-            ctx["kv_st"].append(dit_ops.attention_pack_kv(kv_s, B, Ls, H, 0, C, gamma_k=b["static_cross_attn"]["gk"], dtype=lp,
-                                                          key_order=order(kv_s, B, Ls), out=None if old is None else old["kv_st"][i]))
+        for name, emb, n_sets, L in (("kv_img", img_emb, B * Tc, Li), ("kv_st", st_emb, B, Ls)):
+            ctx[name] = self._context_kv(ctx, old, name, dit_ops.split3_bf16(emb), S3[name + "_all"], W[name + "_bias_all"], W[name + "_gk_all"],
+                                         n_sets, L, ordered and L <= 8192)
         if self.pe_mode == "ape":
             assert deformation_position_xyz is not None, "Deformation position xyz is required for APE mode"
             pos = self.pos_embedder(deformation_position_xyz).float().contiguous()      # (B, N, C)
@@ -502,13 +483,65 @@ class DiT(nn.Module):
         self._ctx_cache = ctx
         return ctx
 
+    def _context_kv(self, ctx, old, name, x3, w_all, bias_all, gk_all, n_sets, L, ordered):
+        """Every block's to_kv(context) (model/attention/modules.py:134-143 inside model/dit.py:257-262) for ONE context, all blocks at once: the
+        projections as one wide GEMM per chunk of blocks (weights stacked along N; x3 = the context's [hi | lo | hi] rows, shared), then ONE key
+        order launch and ONE cache-builder launch per chunk (gvf_attn_*_groups: a block = a column band of the wide product).  Round 6: block by
+        block these were 12 + 12 + 12 launches per context, the order kernel latency-bound at 65 us a launch (1.55 ms of the 4.7 ms a new sample's
+        conditions cost).  A chunk's fp32 product is bounded (~2 GiB; the released shapes at B = 1: image context 1.6 GB = all 12 blocks).
+        Returns the per-block list the forward reads: (k_tiles, v_tiles) views of one persistent buffer pair, or row-major 16-bit kv (head_dim 64)."""
+        C, H, lp = self.model_channels, self.num_heads, ctx["lp"]
+        nb = len(self.blocks)
+        M = x3.shape[0]
+        per_block = M * 2 * C * 4
+        G = max(1, min(nb, (2 << 30) // max(per_block, 1)))
+        # the kernel is chosen from N and K alone, so that a sample's numbers do not depend on what it is batched with
+        g8 = lambda n_: dit_ops.gemm8_eligible(256, n_, x3.shape[1], x3.stride(0), w_all.stride(0), n_, dit_ops.EPI_STORE_F32) != 0
+        tiled = self.head_dim == 32
+        if tiled:
+            nbytes = n_sets * H * ((L + 63) // 64) * 4096
+            bufs = old.get(name + "_all") if old is not None else None
+            if bufs is None:
+                bufs = (torch.empty((nb, nbytes), dtype=torch.uint8, device=x3.device), torch.empty((nb, nbytes), dtype=torch.uint8, device=x3.device))
+            ctx[name + "_all"] = bufs
+        out = []
+        for g0 in range(0, nb, G):
+            g1 = min(nb, g0 + G)
+            n = (g1 - g0) * 2 * C
+            wide = torch.empty((M, n), dtype=torch.float32, device=x3.device)
+            (dit_ops.gemm8 if g8(n) else dit_ops.gemm)(x3, w_all[g0 * 2 * C:g1 * 2 * C], None if bias_all is None else bias_all[g0 * 2 * C:g1 * 2 * C], wide,
+                                                       dit_ops.EPI_STORE_F32)
+            if not tiled:
+                # head_dim 64: the strided flash attention reads row-major [k | v] rows of the operand type (one rounding of the fp32-class
+                # projection, as the tile image's); MultiHeadRMSNorm of k is the kernel's prologue (gamma_k)
+                for j in range(g1 - g0):
+                    band = wide[:, j * 2 * C:(j + 1) * 2 * C]
+                    if old is not None:
+                        old[name][g0 + j].copy_(band)
+                        out.append(old[name][g0 + j])
+                    else:
+                        out.append(band.to(lp).contiguous())
+                continue
+            bands = wide.view(M, g1 - g0, 2 * C).permute(1, 0, 2)            # (groups, rows, 2C): group stride 2C, row stride n
+            order = dit_ops.key_order_by_norm_groups(bands, g1 - g0, n_sets, L, H, 0) if ordered else None
+            dit_ops.attention_pack_kv_groups(bands, g1 - g0, n_sets, L, H, 0, C, gamma_k=None if gk_all is None else gk_all[g0:g1], dtype=lp,
+                                             key_order=order, out=(bufs[0][g0:g1], bufs[1][g0:g1]))
+            out.extend((bufs[0][g], bufs[1][g]) for g in range(g0, g1))
+        return out
+
     def _split3_weights(self, W):
         """[hi | hi | lo] bf16 expansions of the fp32 weights of the hoisted projections (dit_ops.split3_bf16), once per weight version."""
         S3 = W.get("split3")
         if S3 is None:
+            # the 12 blocks' to_kv weights of a context stacked along N: one wide projection per context (_context_kv)
+            stack = lambda name: dit_ops.split3_bf16(torch.cat([b[name]["kv_f32"][0] for b in W["blocks"]], 0).contiguous(), weights=True)
             S3 = W["split3"] = {"img": dit_ops.split3_bf16(W["img_f32"][0], weights=True), "static": dit_ops.split3_bf16(W["static_f32"][0], weights=True),
-                                "kv_img": [dit_ops.split3_bf16(b["image_cross_attn"]["kv_f32"][0], weights=True) for b in W["blocks"]],
-                                "kv_st": [dit_ops.split3_bf16(b["static_cross_attn"]["kv_f32"][0], weights=True) for b in W["blocks"]]}
+                                "kv_img_all": stack("image_cross_attn"), "kv_st_all": stack("static_cross_attn")}
+            for key, name in (("kv_img", "image_cross_attn"), ("kv_st", "static_cross_attn")):
+                biases = [b[name]["kv_f32"][1] for b in W["blocks"]]
+                W[key + "_bias_all"] = None if biases[0] is None else torch.cat(biases, 0).contiguous()
+                gks = [b[name]["gk"] for b in W["blocks"]]
+                W[key + "_gk_all"] = None if gks[0] is None else torch.stack([g.reshape(-1) for g in gks], 0).float().contiguous()
             # the fp32 matrices were only the source of the expansions: drop them, keep the biases (ADVICE r5: 26 fp32 matrices stayed resident
             # beside their [hi | hi | lo] copies in every DiT instance in flight).  The parameters themselves are untouched.
             W["img_f32"], W["static_f32"] = (None, W["img_f32"][1]), (None, W["static_f32"][1])

@@ -72,6 +72,8 @@ _lib.register({
     "gvf_gemm_stats_parts": (_i, [_i]),
     "gvf_attn_key_order": (_i, [_vp, _i64, _i, _i, _i, _i, _i, _vp, _vp]),
     "gvf_attn_pack_kv_ordered": (_i, [_i, _vp, _i, _i64, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
+    "gvf_attn_key_order_groups": (_i, [_vp, _i64, _i64, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "gvf_attn_pack_kv_groups": (_i, [_i, _vp, _i, _i64, _i64, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "gvf_split3_bf16": (_i, [_vp, _i64, _vp, _i64, _i, _i, _vp]),
     "gvf_attn_pack_kv64": (_i, [_i, _vp, _i, _i64, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "gvf_attn_tiled64_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, ctypes.POINTER(_i64), ctypes.POINTER(_i64), _i64, _i64, _i, _vp, _vp]),
@@ -462,6 +464,41 @@ def attention_pack_kv(kv: torch.Tensor, n_sets: int, L: int, H: int, k_col0: int
     return kt, vt
 
 
+def key_order_by_norm_groups(kv: torch.Tensor, n_groups: int, n_sets: int, L: int, H: int, k_col0: int, n_first: int = 64) -> torch.Tensor:
+    """key_order_by_norm for n_groups row sets in one launch: kv fp32 (n_groups, n_sets * L, ld) -> int32 (n_groups, n_sets, H, L)."""
+    _lib.require_cuda(kv)
+    assert kv.dtype == torch.float32 and kv.dim() == 3 and kv.stride(2) == 1 and kv.shape[0] == n_groups and kv.shape[1] == n_sets * L
+    order = torch.empty((n_groups, n_sets, H, L), dtype=torch.int32, device=kv.device)
+    _lib.check(_lib.lib().gvf_attn_key_order_groups(_p(kv), kv.stride(1), kv.stride(0), n_groups, k_col0, n_sets, L, H, int(n_first), _p(order),
+                                                    _stream(kv)), "gvf_attn_key_order_groups")
+    return order
+
+
+def attention_pack_kv_groups(kv: torch.Tensor, n_groups: int, n_sets: int, L: int, H: int, k_col0: int, v_col0: int, scale: float = None,
+                             gamma_k: torch.Tensor = None, out=None, dtype=None, key_order: torch.Tensor = None):
+    """attention_pack_kv for n_groups row sets of one shape in ONE launch: kv (n_groups, n_sets * L, ld) fp32 or 16-bit, gamma_k (n_groups, H * 32)
+    fp32 or None, key_order int32 (n_groups, n_sets, H, L) or None -> (k_tiles, v_tiles) uint8 (n_groups, nbytes) -- row g is what
+    attention_pack_kv(kv[g], ...) returns (bit for bit)."""
+    _lib.require_cuda(kv)
+    assert kv.dim() == 3 and kv.stride(2) == 1 and kv.dtype in (torch.float32,) + LP_DTYPES and kv.shape[0] == n_groups and kv.shape[1] == n_sets * L
+    dt = dt_code(kv.dtype) if kv.dtype in LP_DTYPES else dt_code(dtype or torch.bfloat16)
+    assert dtype is None or dt_code(dtype) == dt
+    nbytes = n_sets * H * ((L + 63) // 64) * 4096
+    if out is None:
+        out = (torch.empty((n_groups, nbytes), dtype=torch.uint8, device=kv.device), torch.empty((n_groups, nbytes), dtype=torch.uint8, device=kv.device))
+    kt, vt = out
+    assert kt.shape == (n_groups, nbytes) and vt.shape == (n_groups, nbytes) and kt.is_contiguous() and vt.is_contiguous()
+    scale = 32 ** -0.5 if scale is None else scale
+    if gamma_k is not None:
+        assert gamma_k.dtype == torch.float32 and gamma_k.is_contiguous() and gamma_k.shape == (n_groups, H * 32)
+    if key_order is not None:
+        assert key_order.dtype == torch.int32 and key_order.is_contiguous() and key_order.shape == (n_groups, n_sets, H, L) and key_order.is_cuda
+    _lib.check(_lib.lib().gvf_attn_pack_kv_groups(dt, _p(kv), int(kv.dtype == torch.float32), kv.stride(1), kv.stride(0), n_groups, k_col0, v_col0,
+                                                  n_sets, L, H, float(scale * LOG2E), _p(gamma_k), _p(key_order), _p(kt), _p(vt), _stream(kv)),
+               "gvf_attn_pack_kv_groups")
+    return kt, vt
+
+
 def attention_pack_kv64(kv: torch.Tensor, n_sets: int, L: int, H: int, k_col0: int, v_col0: int, scale: float = None, out=None, dtype=None):
     """kv rows (n_sets * L, ld) fp32 or 16-bit -> (k_tiles, v_tiles) uint8 device buffers in the head_dim-64 image of csrc/attn_xt64.hip
     (K pre-multiplied by scale * log2 e; default scale 64 ** -0.5).  See include/gvf_dit.h."""
@@ -493,16 +530,22 @@ def attention_tiled64(q, k_tiles, v_tiles, out, n_outer, n_inner, Lq, Lk, H, q_s
 
 def gemm8(a: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, epilogue: int = 0):
     """out = epi(a @ w.T + bias) on csrc/gemm8.hip's 256 x 256 x 64 tiles, eight waves (M, N multiples of 256, K of 64); epilogue EPI_STORE_16 or
-    EPI_GEGLU_16 (out (M, N / 2)), or EPI_RESID_F32 without a gate (out fp32 (M, N) += ..., 192-wide tiles: M, N multiples of 192).  gvf_gemm takes
+    EPI_GEGLU_16 (out (M, N / 2)), EPI_RESID_F32 without a gate (out fp32 (M, N) += ..., 192-wide tiles: M, N multiples of 192), or EPI_STORE_F32
+    (out fp32, ANY M).  gvf_gemm takes
     this kernel by itself for eligible shapes; this is the direct entry (tests, benchmarks)."""
     _lib.require_cuda(a, w, out)
-    assert a.dtype in LP_DTYPES and w.dtype == a.dtype and out.dtype == (torch.float32 if epilogue == EPI_RESID_F32 else a.dtype)
+    assert a.dtype in LP_DTYPES and w.dtype == a.dtype and out.dtype == (torch.float32 if epilogue in (EPI_RESID_F32, EPI_STORE_F32) else a.dtype)
     assert a.stride(1) == 1 and w.stride(1) == 1 and out.stride(1) == 1
     M, K = a.shape
     N = w.shape[0]
     _lib.check(_lib.lib().gvf_gemm8(dt_code(a.dtype), _p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), M, N, K, int(epilogue),
                                     _stream(a)), "gvf_gemm8")
     return out
+
+
+def gemm8_eligible(M: int, N: int, K: int, lda: int, ldw: int, ldc: int, epilogue: int) -> int:
+    """The tile gvf_gemm8 would run this call on (256 or 192), 0 = it refuses the shape (include/gvf_dit.h)."""
+    return int(_lib.lib().gvf_gemm8_eligible(int(M), int(N), int(K), int(lda), int(ldw), int(ldc), int(epilogue)))
 
 
 def gemm256(a: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor):

@@ -187,8 +187,9 @@ int gvf_gemm256(int dtype, const void* A, int lda, const void* W, int ldw, const
 /* The same projection on 256 x 256 x 64 tiles with EIGHT waves, two per SIMD (csrc/gemm8.hip, round 6): 790-900 TFLOP/s on the motion VAE's large
  * projections where gvf_gemm's 128-wide kernel reaches 560-640.  epilogue: GVF_EPI_STORE_BF16 (C 16-bit [M][N]) or GVF_EPI_GEGLU_16 (C 16-bit
  * [M][N/2], the interleaved value / gate convention of gvf_gemm) on 256-wide tiles, or GVF_EPI_RESID_F32 WITHOUT a gate (C f32 [M][N] += acc + bias)
- * on 192 x 192 tiles -- one tile per CU for the VAE's 12 288 x 768 residual projections.  gvf_gemm8_eligible: the tile it would use (256 / 192) or 0:
- * M, N multiples of the tile, K of 64, 16-byte rows.  gvf_gemm takes it by itself for eligible calls with at least one tile per CU
+ * on 192 x 192 tiles -- one tile per CU for the VAE's 12 288 x 768 residual projections, or GVF_EPI_STORE_F32 (C f32 [M][N] = acc + bias, 256-wide
+ * tiles, ANY M: the hoisted condition projections of DiT.prepare_conditions).  gvf_gemm8_eligible: the tile it would use (256 / 192) or 0:
+ * M (except GVF_EPI_STORE_F32), N multiples of the tile, K of 64, 16-byte rows.  gvf_gemm takes it by itself for eligible calls with at least one tile per CU
  * (GVF_GEMM8=0: off, =2: from one tile on). */
 int gvf_gemm8_eligible(int M, int N, int K, int lda, int ldw, int ldc, int epilogue);
 int gvf_gemm8(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M, int N, int K,
@@ -217,6 +218,15 @@ int gvf_attn_pack_kv_bf16(const void* kv, int kv_is_f32, int64_t ld, int k_col0,
 int gvf_attn_key_order(const float* kv, int64_t ld, int k_col0, int n_sets, int L, int H, int n_first, int32_t* key_order, void* stream);
 int gvf_attn_pack_kv_ordered(int dtype, const void* kv, int kv_is_f32, int64_t ld, int k_col0, int v_col0, int n_sets, int L, int H,
                              float k_scale, const float* gamma_k, const int32_t* key_order, void* k_tiles, void* v_tiles, void* stream);
+/* The two above for n_groups row sets of ONE shape in one launch each (DiT.prepare_conditions: the 12 blocks' to_kv products of a context --
+ * model/dit.py:257-262 runs them block by block; they depend on the conditions alone): group g reads kv + g * group_stride (elements; e.g. the
+ * next [rows][ld] matrix, or the next column band of one wide matrix), its gain gamma_k + g * H * 32, and writes key_order + g * n_sets * H * L,
+ * k_tiles / v_tiles + g * n_sets * H * ceil(L / 64) * 4096 bytes.  Bit-identical to n_groups single calls.  n_groups <= 65535. */
+int gvf_attn_key_order_groups(const float* kv, int64_t ld, int64_t group_stride, int n_groups, int k_col0, int n_sets, int L, int H, int n_first,
+                              int32_t* key_order, void* stream);
+int gvf_attn_pack_kv_groups(int dtype, const void* kv, int kv_is_f32, int64_t ld, int64_t group_stride, int n_groups, int k_col0, int v_col0,
+                            int n_sets, int L, int H, float k_scale, const float* gamma_k, const int32_t* key_order, void* k_tiles, void* v_tiles,
+                            void* stream);
 
 /* out = softmax(q k^T * scale) v over such a cache (the scale is inside k_tiles).  q / out: bf16, strides
  * {outer, inner, seq, head} in elements as for gvf_attn_fwd_bf16; (outer, inner) reads K/V set

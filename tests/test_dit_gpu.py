@@ -142,8 +142,63 @@ def test_eight_wave_projection_kernel_matches_fp32_and_the_four_wave_one(cuda, l
     with pytest.raises(_lib.GvfError):
         dit_ops.gemm8(a[:255], w, bias, out[:255])
     L = _lib.lib()
-    assert L.gvf_gemm8_eligible(M, N, K, K + 8, K, N + 16, dit_ops.EPI_STORE_BF16) == 256 and L.gvf_gemm8_eligible(M, N, K, K + 8, K, N + 16, dit_ops.EPI_STORE_F32) == 0
+    assert L.gvf_gemm8_eligible(M, N, K, K + 8, K, N + 16, dit_ops.EPI_STORE_BF16) == 256 and L.gvf_gemm8_eligible(M, N, K, K + 8, K, N + 16, dit_ops.EPI_GELU_BF16) == 0
     assert L.gvf_gemm8_eligible(M, N + 64, K, K + 8, K, N + 64, dit_ops.EPI_STORE_BF16) == 0
+
+
+@pytest.mark.parametrize("lp", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K,has_bias", [(24 * 1370, 1024, 1536, True), (300, 256, 64, False), (1, 512, 128, True), (4096, 12 * 1024, 1536, True)])
+def test_eight_wave_fp32_store_takes_any_row_count(cuda, lp, M, N, K, has_bias):
+    """gvf_gemm8 with GVF_EPI_STORE_F32 (DiT.prepare_conditions' hoisted to_kv projections: 24 x 1370 image tokens are not a multiple of the
+    256-row tile): the last row tile stages row M - 1 in place of the rows past the end and skips their stores.  Against an fp32 product of
+    the same 16-bit operands (1e-5: fp32 accumulation of exact products); nothing written beyond row M or column N; a row's bits do not depend
+    on M (the same rows as part of a shorter call); repeated launches give the same bits."""
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn((M, K), generator=g).to(lp).to(cuda)
+    w = (torch.randn((N, K), generator=g) / math.sqrt(K)).to(lp).to(cuda)
+    bias = torch.randn((N,), generator=g).to(cuda) if has_bias else None
+    obuf = torch.full((M + 300, N + 4), float("nan"), dtype=torch.float32, device=cuda)
+    out = obuf[:M, :N]
+    assert dit_ops.gemm8_eligible(M, N, K, K, K, N + 4, dit_ops.EPI_STORE_F32) == 256
+    dit_ops.gemm8(a, w, bias, out, dit_ops.EPI_STORE_F32)
+    assert torch.isfinite(out).all() and torch.isnan(obuf[M:]).all() and torch.isnan(obuf[:, N:]).all()
+    rows = torch.cat([torch.randint(0, M, (256,), generator=g), torch.tensor([0, M - 1])]).to(cuda)
+    ref = a[rows].float() @ w.float().T + (bias if has_bias else 0.0)
+    assert rel_l2(out[rows], ref) < 1e-5
+    first = out.clone()
+    obuf.fill_(float("nan"))
+    dit_ops.gemm8(a, w, bias, out, dit_ops.EPI_STORE_F32)
+    assert torch.equal(out, first)
+    if M > 7:
+        m2 = M - 7
+        short = torch.empty((m2, N), dtype=torch.float32, device=cuda)
+        dit_ops.gemm8(a[:m2], w, bias, short, dit_ops.EPI_STORE_F32)
+        assert torch.equal(short, first[:m2])
+
+
+@pytest.mark.parametrize("lp", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("n_groups,n_sets,L,H,rms", [(12, 3, 1370, 4, True), (5, 1, 4096, 2, True), (3, 2, 70, 16, False), (1, 1, 1, 1, True)])
+def test_grouped_key_order_and_cache_builder_equal_the_single_calls(cuda, lp, n_groups, n_sets, L, H, rms):
+    """gvf_attn_key_order_groups / gvf_attn_pack_kv_groups (DiT.prepare_conditions: the 12 blocks' to_kv products of a context = column bands of
+    ONE wide fp32 matrix, ordered and packed in one launch each): group g == the single call on band g, bit for bit -- order, K image, V image."""
+    C = H * 32
+    g = torch.Generator().manual_seed(n_groups * 1000 + L)
+    wide = torch.randn((n_sets * L, n_groups * 2 * C), generator=g).to(cuda)
+    wide[::7, : C] *= 3.0
+    gk = (1.0 + 0.1 * torch.randn((n_groups, C), generator=g)).to(cuda) if rms else None
+    bands = wide.view(n_sets * L, n_groups, 2 * C).permute(1, 0, 2)
+    order = dit_ops.key_order_by_norm_groups(bands, n_groups, n_sets, L, H, 0)
+    kt, vt = dit_ops.attention_pack_kv_groups(bands, n_groups, n_sets, L, H, 0, C, gamma_k=gk, dtype=lp, key_order=order)
+    kt0, vt0 = dit_ops.attention_pack_kv_groups(bands, n_groups, n_sets, L, H, 0, C, gamma_k=gk, dtype=lp)
+    for j in range(n_groups):
+        band = wide[:, j * 2 * C:(j + 1) * 2 * C]
+        o1 = dit_ops.key_order_by_norm(band, n_sets, L, H, 0)
+        assert torch.equal(order[j], o1)
+        for ko, (kg, vg) in ((o1, (kt, vt)), (None, (kt0, vt0))):
+            k1, v1 = dit_ops.attention_pack_kv(band, n_sets, L, H, 0, C, gamma_k=None if gk is None else gk[j], dtype=lp, key_order=ko)
+            assert torch.equal(kg[j], k1) and torch.equal(vg[j], v1)
+    if n_groups > 1 and L > 64:
+        assert not torch.equal(order[0], order[1])
 
 
 @pytest.mark.parametrize("lp", [torch.bfloat16, torch.float16])
