@@ -432,7 +432,7 @@ class DiT(nn.Module):
         ctx = {"T": T, "lp": lp, "held": (conds, tuple(self._key(t) for t in conds)), "Li": Li, "Ls": Ls}
         # Round 6: the cache's device buffers (the 24 K / V tile images, the position embedding) PERSIST across condition sets of one shape: a new
         # sample refills them in place, so a captured hipGraph that reads them stays valid -- the next sample costs its condition products
-        # (~4.7 ms at the released config), not those + an eager forward + a re-capture (~16 ms; measured 199.5 -> 215.8 ms per sample with
+        # (~3.1 ms at the released config), not those + an eager forward + a re-capture (~16 ms; measured 199.5 -> 215.8 ms per sample with
         # fresh condition tensors).  `epoch` names the buffer set; the graph is keyed on it (_forward_graphed).  Everything that reads the
         # buffers runs on the caller's stream, behind the refill.
         shape_key = (T, lp, str(dev), tuple(cond_images.shape), tuple(static_latent.shape),
