@@ -411,12 +411,19 @@ def bench_e2e(dev, P=262_144, S=800, T=24):
     e = E2EWorkload(dev, P, S, T)
     with torch.no_grad(), contextlib.redirect_stdout(sys.stderr):     # the solver reports its NFE on stdout, as upstream does
         e.chain()                                    # warm-up: weight conversion, graph capture, workspace
-        t0 = time.perf_counter()
-        (ms_sample, ms_decode, ms_render), nfe, out = e.chain()
-        wall = time.perf_counter() - t0
-    assert bool(torch.isfinite(out.rgb).all())
+        # three samples (each on fresh condition tensors), the MEDIAN one reported: a single chain is 37 host round trips and moved by +-3 %
+        # from run to run on one box (profiles/r06_prepare_conditions.txt, the full-bench A/B); all three walls are in the line
+        runs = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            stages, nfe, out = e.chain()
+            runs.append((time.perf_counter() - t0, stages, nfe, e.calls["n"]))
+            assert bool(torch.isfinite(out.rgb).all())
+        wall, (ms_sample, ms_decode, ms_render), nfe, model_calls = sorted(runs, key=lambda r: r[0])[1]
     return {"metric": "end-to-end 4D sample (adaptive DPM-Solver -> VAE decode -> 24-frame render), BASELINE configs[3]",
-            "value": round(T / wall, 2), "unit": "frames/s", "wall_ms": round(wall * 1e3, 2), "nfe": nfe, "model_calls": e.calls["n"],
+            "value": round(T / wall, 2), "unit": "frames/s", "wall_ms": round(wall * 1e3, 2), "wall_ms_of_3_samples": [round(r[0] * 1e3, 2) for r in runs],
+            "nfe": nfe, "model_calls": model_calls,
             "adaptive_steps": dict(getattr(e.w.solver, "spec_stats", {})),
             "stage_ms": {"sample": round(ms_sample, 2), "vae_decode": round(ms_decode, 2), "render": round(ms_render, 2)},
             "config": {"gaussians": P, "resolution": S, "frames": T, "sampler": "dpmsolver++ adaptive, steps=100, order 2",
