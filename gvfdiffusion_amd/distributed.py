@@ -34,6 +34,7 @@ def init_from_env(device: Optional[torch.device] = None, backend: Optional[str] 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1 and dist.is_available() and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (hosts without the legacy mode fail in hipIpcGetMemHandle); launchers normally export it
         use_gpu = device is not None and torch.device(device).type == "cuda"
         kw = {"device_id": torch.device(device)} if use_gpu else {}
         dist.init_process_group(backend or ("nccl" if use_gpu else "gloo"), **kw)

@@ -496,7 +496,7 @@ class DiT(nn.Module):
         per_block = M * 2 * C * 4
         G = max(1, min(nb, int(os.environ.get("GVF_DIT_KV_CHUNK_BYTES", 2 << 30)) // max(per_block, 1)))       # (the variable: a measurement switch)
         # the kernel is chosen from N and K alone, so that a sample's numbers do not depend on what it is batched with
-        g8 = lambda n_: dit_ops.gemm8_eligible(256, n_, x3.shape[1], x3.stride(0), w_all.stride(0), n_, dit_ops.EPI_STORE_F32) != 0
+        g8 = lambda n_: os.environ.get("GVF_GEMM8", "1") != "0" and dit_ops.gemm8_eligible(256, n_, x3.shape[1], x3.stride(0), w_all.stride(0), n_, dit_ops.EPI_STORE_F32) != 0
         tiled = self.head_dim == 32
         if tiled:
             nbytes = n_sets * H * ((L + 63) // 64) * 4096
