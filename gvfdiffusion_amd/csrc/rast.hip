@@ -1676,10 +1676,10 @@ extern "C" int gvf_debug_blend_timing(unsigned long long* device_buf, unsigned l
 // counting builds only (scripts/blend_consumed.py, a variant library): per size class of a (frame, tile) segment -- <= 2048 keys, <= 4096, <= 16384,
 // more -- [segments, keys sorted, keys the compositing had staged when every pixel of the tile was saturated (whole 256-key rounds)]: how much of
 // the per-tile sort's work the blend ever looks at
-__device__ unsigned long long g_blend_cons[4][3];
+__device__ unsigned long long g_blend_cons[4][5];   // + [staged keys whose quadrant mask is 0, sum of the masks' bit counts]
 extern "C" int gvf_debug_blend_consumed(unsigned long long* out12, int reset) {
     if (out12 && hipMemcpyFromSymbol(out12, HIP_SYMBOL(g_blend_cons), sizeof(g_blend_cons)) != hipSuccess) return 1;
-    if (reset) { unsigned long long z[12] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_blend_cons), z, sizeof(z)) != hipSuccess) return 1; }
+    if (reset) { unsigned long long z[20] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_blend_cons), z, sizeof(z)) != hipSuccess) return 1; }
     return 0;
 }
 #endif
@@ -1763,6 +1763,14 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
             sB[t] = make_float4(ch.c2, ch.ok ? __builtin_amdgcn_logf(b.y) : -__builtin_inff(), b.z, b.w);       // log2(opacity)
             sC[t] = make_float4(c.x, c.y, 0.f, 0.f);
             sMask[t] = (unsigned char)quadrant_mask(a.x, a.y, a.z, a.w, b.x, b.y, c.z, (float)(tx * TILE), (float)(ty * TILE), subpixel_offset != nullptr);
+#ifdef BLEND_CONSUMED
+            {
+                const unsigned n_ = rng.y - rng.x;
+                const int cls_ = n_ <= 2048u ? 0 : n_ <= 4096u ? 1 : n_ <= 16384u ? 2 : 3;
+                if (sMask[t] == 0) atomicAdd(&g_blend_cons[cls_][3], 1ull);
+                atomicAdd(&g_blend_cons[cls_][4], (unsigned long long)__popc((unsigned)sMask[t]));
+            }
+#endif
         }
         BT(3);
         __syncthreads();

@@ -35,11 +35,12 @@ else:
         n = sum(fr.shape[0] for _, fr in render_sample_frames(rend, gm, delta, K, extrinsics=cams, chunk_frames=96, streams=1))
     torch.cuda.synchronize()
     print(f"{which}: {n} frames of {S}x{S}")
-out = (ctypes.c_ulonglong * 12)()
+out = (ctypes.c_ulonglong * 20)()
 assert fn(out, 0) == 0
 tot_s = tot_u = 0
 for c, name in enumerate(("<= 2048 keys", "2049-4096", "4097-16384", "> 16384")):
-    segs, srt, used = out[3 * c], out[3 * c + 1], out[3 * c + 2]
+    segs, srt, used, m0, bits = (out[5 * c + k] for k in range(5))
     tot_s += srt; tot_u += used
-    print(f"{name:14s} segments {segs:9d}  keys sorted {srt:12d}  keys staged before saturation {used:12d}  ratio {used / max(srt, 1):.3f}")
+    print(f"{name:14s} segments {segs:9d}  keys sorted {srt:12d}  keys staged before saturation {used:12d}  ratio {used / max(srt, 1):.3f}"
+          f"   of the staged: touching NO 8x8 quadrant of their tile {m0 / max(used, 1):.3f}, quadrants touched per key {bits / max(used, 1):.2f} of 4")
 print(f"all            keys sorted {tot_s}  staged {tot_u}  ratio {tot_u / max(tot_s, 1):.3f}")
