@@ -45,6 +45,8 @@ SOURCES = {
     "gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
     "gemm256.hip": [],                       # accumulators in AGPRs: 256 of them per wave
     "gemm8.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+    # solver state updates: every operation rounded on its own (HIP's __fmul_rn / __fadd_rn are plain operators, so the contraction must be off)
+    "dpm.hip": ["-ffp-contract=off"],
     # row-block kernel: default flags (accumulators in AGPRs: the kernel lives on the 512-register file of a 2-waves-per-SIMD launch)
     "rowblock.hip": [],
     "elem.hip": [],

@@ -17,6 +17,7 @@ adaptive solver's accept/reject test, which is inherent to it (model/dpmsolver.p
 Time tensors therefore live on the CPU inside the solver; the network still receives a device tensor.
 """
 import math
+import os
 
 import torch
 
@@ -323,6 +324,16 @@ def model_wrapper(model, noise_schedule, model_type="noise", model_kwargs={}, gu
     return model_fn
 
 
+def _fused(*tensors):
+    """csrc/dpm.hip's single-launch state updates for contiguous fp32 DEVICE tensors (GVF_DPM_FUSED=0: the chains of tensor operations the
+    reference writes, which CPU tensors always take).  Same operations in the same order, each rounded to fp32 on its own; against the eager
+    chain only a library kernel's fused multiply-add can differ, by one rounding."""
+    if os.environ.get("GVF_DPM_FUSED", "1") == "0" or not (torch.is_tensor(tensors[0]) and tensors[0].is_cuda):
+        return None
+    from ..ops import dit_ops
+    return dit_ops if dit_ops.dpm_fusable(*tensors) else None
+
+
 # --------------------------------------------------------------------------------------------------
 class DPM_Solver:
     def __init__(self, model_fn, noise_schedule, algorithm_type="dpmsolver++", correcting_x0_fn=None,
@@ -364,7 +375,8 @@ class DPM_Solver:
     def data_prediction_fn(self, x, t):
         noise = self.noise_prediction_fn(x, t)
         _, sigma_t, _, alpha_t = self._sched(self._host(t))
-        x0 = (x - sigma_t * noise) / alpha_t
+        ops = _fused(x, noise)
+        x0 = ops.dpm_x0(x, noise, sigma_t, alpha_t) if ops is not None else (x - sigma_t * noise) / alpha_t
         if self.correcting_x0_fn is not None:
             x0 = self.correcting_x0_fn(x0, t)
         return x0
@@ -427,13 +439,17 @@ class DPM_Solver:
         if model_s is None:
             model_s = self.model_fn(x, s)
         if self.algorithm_type == "dpmsolver++":
-            x_t = torch.add(x * (sig_t / sig_s), model_s, alpha=-(alpha_t * math.expm1(-h)))
+            ops = _fused(x, model_s)
+            if ops is not None:
+                x_t = ops.dpm_lincomb(x, model_s, sig_t / sig_s, -(alpha_t * math.expm1(-h)))
+            else:
+                x_t = torch.add(x * (sig_t / sig_s), model_s, alpha=-(alpha_t * math.expm1(-h)))
         else:
             x_t = math.exp(la_t - la_s) * x - (sig_t * math.expm1(h)) * model_s
         return (x_t, {"model_s": model_s}) if return_intermediate else x_t
 
     def singlestep_dpm_solver_second_update(self, x, s, t, r1=0.5, model_s=None, return_intermediate=False,
-                                            solver_type="dpmsolver"):
+                                            solver_type="dpmsolver", err_with=None):
         if solver_type not in ["dpmsolver", "taylor"]:
             raise ValueError("'solver_type' must be either 'dpmsolver' or 'taylor', got {}".format(solver_type))
         if r1 is None:
@@ -451,8 +467,15 @@ class DPM_Solver:
         if self.algorithm_type == "dpmsolver++":
             phi_11 = math.expm1(-r1 * h)
             phi_1 = math.expm1(-h)
-            x_s1 = (sig_s1 / sig_s) * x - (alpha_s1 * phi_11) * model_s
+            ops = _fused(x, model_s)
+            x_s1 = ops.dpm_lincomb(x, model_s, sig_s1 / sig_s, -(alpha_s1 * phi_11)) if ops is not None else (sig_s1 / sig_s) * x - (alpha_s1 * phi_11) * model_s
             model_s1 = self.model_fn(x_s1, s1)
+            ops = None if err_with is None else _fused(x, model_s, model_s1, err_with[0])
+            if solver_type == "dpmsolver" and ops is not None:
+                # the adaptive solver's closing launch: both orders' states and the error norm in one pass (csrc/dpm.hip)
+                x_prev, atol, rtol = err_with
+                x_lower, x_t, E_dev = ops.dpm_second_err(x, model_s, model_s1, x_prev, sig_t / sig_s, alpha_t * phi_1, (0.5 / r1) * (alpha_t * phi_1), atol, rtol)
+                return x_t, {"model_s": model_s, "model_s1": model_s1, "x_lower": x_lower, "E_dev": E_dev}
             if solver_type == "dpmsolver":
                 x_t = (sig_t / sig_s) * x - (alpha_t * phi_1) * model_s - (0.5 / r1) * (alpha_t * phi_1) * (model_s1 - model_s)
             else:
@@ -554,6 +577,9 @@ class DPM_Solver:
         if self.algorithm_type == "dpmsolver++" and solver_type == "dpmsolver":
             # (sig_t / sig_p0) x - c m0 - 0.5 c D1_0 with D1_0 = (m0 - m1) / r0, regrouped by tensor: three launches instead of seven
             c = alpha_t * math.expm1(-h)
+            ops = _fused(x, model_prev_0, model_prev_1)
+            if ops is not None:
+                return ops.dpm_lincomb(x, model_prev_0, sig_t / sig_p0, -(c + 0.5 * c / r0), model_prev_1, 0.5 * c / r0)
             return torch.add(x * (sig_t / sig_p0), model_prev_0, alpha=-(c + 0.5 * c / r0)).add_(model_prev_1, alpha=0.5 * c / r0)
         D1_0 = (1.0 / r0) * (model_prev_0 - model_prev_1)
         if self.algorithm_type == "dpmsolver++":
@@ -634,6 +660,7 @@ class DPM_Solver:
         #    needs none of it: x and s are known the moment the previous step is accepted), i.e. under 4.7 ms of device work instead of in front of
         #    it.  Same operations on the same values in the same order of dependence: identical steps, NFE and samples.  Only a REJECTED step
         #    (no new evaluation of model(x, s)) still pays its ~0.2 ms of host arithmetic with the device idle.
+        fuse_step = order == 2 and self.algorithm_type == "dpmsolver++" and solver_type == "dpmsolver" and self.correcting_xt_fn is None
         spec_on = bool(getattr(self, "speculate", False)) and x.is_cuda
         e_pin = torch.empty(1, dtype=torch.float32).pin_memory() if spec_on else None
         known = None                                   # (x, s as float, model(x, s)) carried into the next iteration
@@ -650,11 +677,24 @@ class DPM_Solver:
                 h = min(theta * h * (math.inf if E_last == 0.0 else E_last ** (-1.0 / order)), lambda_0 - lambda_s)
                 E_last = None
             t = ns.inverse_lambda(torch.tensor([lambda_s + h], dtype=torch.float32))
-            x_lower, lower_noise_kwargs = lower_update(x, s, t, model_s=model_s)
-            x_higher = higher_update(x, s, t, **lower_noise_kwargs)
-            delta = torch.max(torch.ones_like(x) * atol, rtol * torch.max(torch.abs(x_lower), torch.abs(x_prev)))
-            v = (x_higher - x_lower) / delta
-            E_dev = torch.sqrt(torch.square(v.reshape((v.shape[0], -1))).mean(dim=-1, keepdim=True)).max()
+            E_dev = None
+            if fuse_step and _fused(x, model_s, x_prev) is not None:
+                # order 2, dpmsolver++: the first-order state shares its two terms with the second-order one, so the step is the intermediate
+                # state (one launch), the second evaluation, and ONE closing launch that writes both states and the error norm -- 5 launches
+                # and host dispatches per step with the two data predictions, where the chain of tensor operations took ~30
+                x_higher, got = self.singlestep_dpm_solver_second_update(x, s, t, r1=r1, model_s=model_s, return_intermediate=True, solver_type=solver_type,
+                                                                         err_with=(x_prev, atol, rtol))
+                if "E_dev" in got:
+                    x_lower, E_dev, lower_noise_kwargs = got["x_lower"], got["E_dev"], {"model_s": got["model_s"]}
+                else:                                  # (a model whose outputs the fused launch cannot take: the chain, from the states above)
+                    x_lower, lower_noise_kwargs = lower_update(x, s, t, model_s=model_s)
+            else:
+                x_lower, lower_noise_kwargs = lower_update(x, s, t, model_s=model_s)
+                x_higher = higher_update(x, s, t, **lower_noise_kwargs)
+            if E_dev is None:
+                delta = torch.max(torch.ones_like(x) * atol, rtol * torch.max(torch.abs(x_lower), torch.abs(x_prev)))
+                v = (x_higher - x_lower) / delta
+                E_dev = torch.sqrt(torch.square(v.reshape((v.shape[0], -1))).mean(dim=-1, keepdim=True)).max()
             spec = None
             if spec_on:
                 e_pin.copy_(E_dev.reshape(1), non_blocking=True)

@@ -74,6 +74,10 @@ _lib.register({
     "gvf_attn_pack_kv_ordered": (_i, [_i, _vp, _i, _i64, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "gvf_attn_key_order_groups": (_i, [_vp, _i64, _i64, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "gvf_attn_pack_kv_groups": (_i, [_i, _vp, _i, _i64, _i64, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
+    "gvf_dpm_x0": (_i, [_vp, _vp, _f, _f, _vp, _i64, _vp]),
+    "gvf_dpm_lincomb": (_i, [_vp, _vp, _vp, _f, _f, _f, _vp, _i64, _vp]),
+    "gvf_dpm_err_scratch_doubles": (_i64, [_i, _i64]),
+    "gvf_dpm_second_err": (_i, [_vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _vp, _vp, _i, _i64, _vp, _vp, _vp]),
     "gvf_split3_bf16": (_i, [_vp, _i64, _vp, _i64, _i, _i, _vp]),
     "gvf_attn_pack_kv64": (_i, [_i, _vp, _i, _i64, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "gvf_attn_tiled64_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, ctypes.POINTER(_i64), ctypes.POINTER(_i64), _i64, _i64, _i, _vp, _vp]),
@@ -640,3 +644,38 @@ def layernorm_modulate(x, out, eps=1e-6, ln_w=None, ln_b=None, shift=None, scale
 # round-1/2 names (the functions take either 16-bit type)
 gemm_bf16, attention_bf16, attention_varlen_bf16, attention_tiled_bf16 = gemm, attention, attention_varlen, attention_tiled
 layernorm_modulate_bf16 = layernorm_modulate
+
+
+# ---- DPM-Solver state updates (csrc/dpm.hip; include/gvf_dit.h) ------------------------------------------------------------------------
+def dpm_fusable(*tensors) -> bool:
+    """The solver's fused launches take contiguous fp32 device tensors of one shape."""
+    t0 = tensors[0]
+    return all(torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.shape == t0.shape and t.device == t0.device
+               for t in tensors)
+
+
+def dpm_x0(x: torch.Tensor, noise: torch.Tensor, sigma: float, alpha: float) -> torch.Tensor:
+    """x0 = (x - sigma * noise) / alpha in one launch (every operation rounded to fp32 on its own)."""
+    out = torch.empty_like(x)
+    _lib.check(_lib.lib().gvf_dpm_x0(_p(x), _p(noise), float(sigma), float(alpha), _p(out), x.numel(), _stream(x)), "gvf_dpm_x0")
+    return out
+
+
+def dpm_lincomb(x: torch.Tensor, m0: torch.Tensor, a: float, b: float, m1: torch.Tensor = None, c: float = 0.0) -> torch.Tensor:
+    """((a x) + (b m0)) [+ (c m1)] in one launch."""
+    out = torch.empty_like(x)
+    _lib.check(_lib.lib().gvf_dpm_lincomb(_p(x), _p(m0), _p(m1), float(a), float(b), float(c), _p(out), x.numel(), _stream(x)), "gvf_dpm_lincomb")
+    return out
+
+
+def dpm_second_err(x, m, m1, x_prev, a: float, b: float, c: float, atol: float, rtol: float):
+    """The closing launch of an adaptive order-2 step: (x_lower, x_higher, E) with E a one-element device tensor (include/gvf_dit.h)."""
+    B = x.shape[0]
+    n_per = x.numel() // max(B, 1)
+    L = _lib.lib()
+    scratch = torch.empty(int(L.gvf_dpm_err_scratch_doubles(B, n_per)), dtype=torch.float64, device=x.device)
+    x_lower, x_higher = torch.empty_like(x), torch.empty_like(x)
+    E = torch.empty(1, dtype=torch.float32, device=x.device)
+    _lib.check(L.gvf_dpm_second_err(_p(x), _p(m), _p(m1), _p(x_prev), float(a), float(b), float(c), float(atol), float(rtol), _p(x_lower), _p(x_higher),
+                                    B, n_per, _p(scratch), _p(E), _stream(x)), "gvf_dpm_second_err")
+    return x_lower, x_higher, E

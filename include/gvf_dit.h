@@ -350,6 +350,23 @@ int gvf_dit_timestep_embed_bf16(const float* t, int B, int freq_dim, float max_p
                                 const void* w2_bf16, int ldw2, const float* b2, int C, void* out_bf16, int ld_out, float* t_emb,
                                 void* stream);
 
+/* ---- DPM-Solver state updates (csrc/dpm.hip): the tensor arithmetic of the reference's model/dpmsolver.py steps as single launches ----
+ * The schedule coefficients are host floats (the solver keeps its times on the host); x, model outputs and results are contiguous f32 of one shape.
+ * Every product / sum / quotient is rounded to fp32 on its own, in the order the reference's expressions evaluate (no fused multiply-add).
+ * gvf_dpm_x0       x0 = (x - sigma noise) / alpha                                   data_prediction_fn, model/dpmsolver.py:450-461
+ * gvf_dpm_lincomb  out = ((a x) + (b m0)) + (c m1)    (m1 null: (a x) + (b m0))      dpm_solver_first_update :564-609, the intermediate state of
+ *                  singlestep_dpm_solver_second_update :611-690, multistep_dpm_solver_second_update :813-869 (regrouped by tensor)
+ * gvf_dpm_second_err   the closing launch of an adaptive order-2 step (dpmsolver++, solver_type "dpmsolver"), :1013-1019:
+ *                  x_lower = (a x) - (b m);  x_higher = ((a x) - (b m)) - (c (m1 - m));  delta = max(atol, rtol max(|x_lower|, |x_prev|));
+ *                  E[0] = max over the n_samples samples of sqrt(mean(((x_higher - x_lower) / delta)^2)) -- a device float the caller reads back
+ *                  (the step-size test is the solver's one synchronisation point).  scratch: gvf_dpm_err_scratch_doubles(...) doubles, block sums in a
+ *                  fixed order (deterministic).  n_samples <= 65535. */
+int gvf_dpm_x0(const float* x, const float* noise, float sigma, float alpha, float* x0, int64_t n, void* stream);
+int gvf_dpm_lincomb(const float* x, const float* m0, const float* m1, float a, float b, float c, float* out, int64_t n, void* stream);
+int64_t gvf_dpm_err_scratch_doubles(int n_samples, int64_t n_per_sample);
+int gvf_dpm_second_err(const float* x, const float* m, const float* m1, const float* x_prev, float a, float b, float c, float atol, float rtol,
+                       float* x_lower, float* x_higher, int n_samples, int64_t n_per_sample, double* scratch, float* E, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
