@@ -109,19 +109,20 @@ __global__ __launch_bounds__(DPM_THREADS) void dpm_second_err_kernel(const float
     }
 }
 
-// E = max over samples of sqrt(mean(v^2)): one workgroup, the block sums of a sample added in index order
+// E = max over samples of sqrt(mean(v^2)): one wave; a sample's block sums are added in a fixed order (lane l takes blocks l, l + 64, ...; then a
+// butterfly over the lanes)
 __global__ __launch_bounds__(64) void dpm_err_finish_kernel(const double* __restrict__ partial, int n_samples, int blocks, long long n_per, float* __restrict__ E) {
     float best = 0.f;
     bool nan = false;
-    for (int s = (int)threadIdx.x; s < n_samples; s += 64) {
+    for (int s = 0; s < n_samples; ++s) {
         double t = 0.0;
-        for (int k = 0; k < blocks; ++k) t += partial[(long long)s * blocks + k];
+        for (int k = (int)threadIdx.x; k < blocks; k += 64) t += partial[(long long)s * blocks + k];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d, 64);
         const float e = sqrtf((float)(t / (double)n_per));
         nan = nan || (e != e);
         best = fmaxf(best, e);
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { best = fmaxf(best, __shfl_xor(best, d, 64)); nan = nan || (__shfl_xor((int)nan, d, 64) != 0); }
     if (threadIdx.x == 0) *E = nan ? __builtin_nanf("") : best;        // (torch's max propagates a NaN: the caller's accept test must see it)
 }
 

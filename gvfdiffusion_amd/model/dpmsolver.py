@@ -242,7 +242,9 @@ def model_wrapper(model, noise_schedule, model_type="noise", model_kwargs={}, gu
         if model_type == "x_start":
             return (x - _coef("alpha", t_continuous, x) * output) / _coef("sigma", t_continuous, x)
         if model_type == "v":
-            return _coef("alpha", t_continuous, x) * output + _coef("sigma", t_continuous, x) * x
+            a_, s_ = _coef("alpha", t_continuous, x), _coef("sigma", t_continuous, x)
+            ops = _fused(output, x) if isinstance(a_, float) and isinstance(s_, float) else None
+            return ops.dpm_lincomb(output, x, a_, s_) if ops is not None else a_ * output + s_ * x
         return -_coef("sigma", t_continuous, x) * output  # score
 
     def cond_grad_fn(x, t_input):
