@@ -196,6 +196,26 @@ def gen_dit():
     np.savez_compressed(os.path.join(OUT, "dit_full_golden.npz"), y=y.numpy(), t=inp["t"].numpy())
 
 
+def gen_dit_full_t2():
+    """The real configuration (configs/diffusion.yml: every width, head count and context length of dit_full_golden.npz) on TWO frames:
+    0.55 TFLOP instead of 5.04, so that the CPU suite can hold the oracle to the reference's full-width forward on a small host too
+    (tests/test_oracle_dit.py; the T = 24 fixture stays the bar of the device tests and of hosts with cores to spare)."""
+    import json
+    from model.dit import DiT
+    sys.path.insert(0, os.path.join(OUT, "..", ".."))
+    from gvfdiffusion_amd import synthetic
+    man = json.load(open(os.path.join(OUT, "dit_manifest.json")))
+    torch.manual_seed(0)
+    model = DiT(**man["config"]).eval()
+    model.load_state_dict(synthetic.dit_state_dict(man["state_dict"], seed=0))
+    inp = synthetic.dit_inputs(B=1, T=2, seed=1)
+    with torch.no_grad():
+        y = model(inp["x"], inp["t"], cond_images=inp["cond_images"], static_latent=inp["static_latent"],
+                  deformation_position_xyz=inp["deformation_position_xyz"])
+    np.savez_compressed(os.path.join(OUT, "dit_full_t2_golden.npz"), y=y.numpy(), t=inp["t"].numpy())
+    print("dit_full_t2_golden.npz", y.shape, float(y.abs().mean()), float(y.std()))
+
+
 def gen_dit_notemporal():
     """model/dit.py with no_temporal_attn=True (the block's temporal sub-layer and its adaLN projection removed, :241-260, :358): the
     reduced model of gen_dit() in that variant, so that the oracle's branch for it is pinned by the reference too."""
@@ -777,7 +797,7 @@ def gen_sparse_layers():
     print("sparse_layers_golden.npz", {k: v.shape for k, v in out.items()})
 
 
-SECTIONS = {"sparse_layers": gen_sparse_layers, "slat_decoder": gen_slat_decoder, "sparse_vae": gen_sparse_vae, "vae_encode": gen_vae_encode, "vae": gen_vae, "raster": gen_raster, "vox2seq": gen_vox2seq, "dit": gen_dit, "dit_notemporal": gen_dit_notemporal, "dit_hd64": gen_dit_hd64, "dit_autocast": gen_dit_autocast, "dit_hostile": gen_dit_hostile, "align": gen_align, "sampler": gen_sampler, "sparse": gen_sparse}
+SECTIONS = {"sparse_layers": gen_sparse_layers, "slat_decoder": gen_slat_decoder, "sparse_vae": gen_sparse_vae, "vae_encode": gen_vae_encode, "vae": gen_vae, "raster": gen_raster, "vox2seq": gen_vox2seq, "dit": gen_dit, "dit_full_t2": gen_dit_full_t2, "dit_notemporal": gen_dit_notemporal, "dit_hd64": gen_dit_hd64, "dit_autocast": gen_dit_autocast, "dit_hostile": gen_dit_hostile, "align": gen_align, "sampler": gen_sampler, "sparse": gen_sparse}
 
 if __name__ == "__main__":
     install_stubs()
