@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void k(float* out, long long* cyc, int reps) {
     {   // a splat somewhere around the tile, sigma 3-12 px (the step is branch-free: its cost does not depend on how many pairs contribute)
         const float cx = -6.f + 28.f * ((t * 37) & 255) / 255.f, cy = -6.f + 28.f * ((t * 101) & 255) / 255.f, sg = 3.f + 9.f * ((t * 13) & 255) / 255.f;
         const float l11 = 0.85f / sg, l12 = 0.1f / sg, l22 = 0.8f / sg, c1 = l11 * cx + l12 * cy, c2 = l22 * cy, lo = -8.6f + 2.4f * ((t * 7) & 255) / 255.f;       // opacity 2^-8.6 .. 2^-6.2: some pairs pass 1/255, no pixel ever saturates (the loop must not exit early)
-        if (MODE == 0) {
+        if (MODE != 1) {
             sA[t] = make_float4(l11, l12, l22, c1); sB[t] = make_float4(c2, lo, 0.3f, 0.5f); sC[t] = make_float4(0.7f, 1.0f, 0.f, 0.f);
         } else {
             sA[t] = make_float4(l11 * l11, 2.f * l11 * l12, l12 * l12 + l22 * l22, -2.f * c1 * l11);
@@ -68,6 +68,43 @@ __global__ __launch_bounds__(256) void k(float* out, long long* cyc, int reps) {
             }
             T = T * 0.5f + 0.5f;        // keep the pixel unsaturated across repetitions (one instruction per 256 entries)
         }
+#undef STEP
+    } else if (MODE == 2 || MODE == 3) {
+        // MODE 2: today's arithmetic with the step's predicates kept as explicit 64-bit lane masks (ballot / inverse ballot): the
+        //         saturation test at the head of a trip is a scalar compare (today: v_cndmask + v_cmp per trip), one scalar operation less per entry
+        // MODE 3: MODE 2 + the 0.99 clamp on v_exp_f32's output modifier: alpha / 0.99 = clamp(exp2(-(nlog - log2(1 / 0.99)))), state T99 = 0.99 T,
+        //         w = (alpha / 0.99) T99, T99 -= 0.99 w: 15 vector instructions per entry (NOT bit-identical to today's min(0.99, .): two more roundings)
+        unsigned long long dm = 0ull;
+        const unsigned long long all = __builtin_amdgcn_ballot_w64(true);
+        const float thr_a = MODE == 3 ? (1.0f / 255.0f) / 0.99f : 1.0f / 255.0f, thr_t = MODE == 3 ? 0.0001f * 0.99f : 0.0001f;
+#define STEP(J) {                                                                                                              \
+            const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(sA) + (J));               \
+            const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(sB) + (J));               \
+            const float4 c = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(sC) + (J));               \
+            const float nlog = neg_exponent(a.x, a.y, a.z, a.w, b.x, pxr, pyr, b.y);                                           \
+            const float e_ = __builtin_amdgcn_exp2f(-nlog);                                                                    \
+            const float alpha = MODE == 3 ? __builtin_amdgcn_fmed3f(e_, 0.0f, 1.0f) : fminf(0.99f, e_);                        \
+            const unsigned long long okm = __builtin_amdgcn_ballot_w64(!(alpha < thr_a)) & ~dm;                                \
+            const float w_raw = alpha * T;                                                                                     \
+            const float test_T = MODE == 3 ? __builtin_fmaf(-0.99f, w_raw, T) : T - w_raw;                                     \
+            const unsigned long long stopm = okm & __builtin_amdgcn_ballot_w64(test_T < thr_t);                                \
+            dm |= stopm;                                                                                                       \
+            const bool acc = __builtin_amdgcn_inverse_ballot_w64(okm ^ stopm);                                                 \
+            const float wgt = acc ? w_raw : 0.0f;                                                                              \
+            C0 = __builtin_fmaf(b.z, wgt, C0); C1 = __builtin_fmaf(b.w, wgt, C1); C2 = __builtin_fmaf(c.x, wgt, C2);           \
+            T = acc ? test_T : T; }
+        if (MODE == 3) T = 0.99f;
+        for (int r = 0; r < reps; ++r) {
+            for (int jj = 0; jj < N; jj += 4) {
+                if (dm == all) break;
+                const unsigned j0 = sList[wave][jj], j1 = sList[wave][jj + 1], j2 = sList[wave][jj + 2], j3 = sList[wave][jj + 3];
+                STEP(j0) STEP(j1) STEP(j2) STEP(j3)
+            }
+            T = T * 0.5f + (MODE == 3 ? 0.495f : 0.5f);
+        }
+        if (MODE == 3) T = T / 0.99f;
+        done = __builtin_amdgcn_inverse_ballot_w64(dm);
+        if (done) C0 += 1.0f;
 #undef STEP
     } else {
         const float m[6] = {pxr * pxr, pxr * pyr, pyr * pyr, pxr, pyr, 1.0f};
@@ -145,5 +182,10 @@ int main() {
     run<1>("6 x v_mfma_f32_4x4x1 per 4 splats + 11 VALU");
     run<0>("today's step (again)");
     run<1>("MFMA form (again)");
+    run<2>("today's arithmetic, predicates as lane masks");
+    run<3>("lane masks + 0.99 clamp on v_exp's modifier (15 VALU)");
+    run<0>("today's step (third)");
+    run<2>("lane masks (again)");
+    run<3>("lane masks + clamp modifier (again)");
     return 0;
 }
