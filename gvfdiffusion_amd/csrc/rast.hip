@@ -1684,6 +1684,40 @@ extern "C" int gvf_debug_blend_consumed(unsigned long long* out12, int reset) {
 }
 #endif
 
+// The pixel's "done" flag of blend_kernel (outside the image, or saturated) and the predicates of its compositing step.
+// GVF_BLEND_LANE_MASKS = 1 (round 6, the product): the flag lives as the wave's 64-bit LANE MASK and the predicates are scalar operations on lane
+// masks (ballot / inverse ballot).  As a per-lane bool (= 0, the form up to round 6, kept as the A/B variant) the compiler holds the same masks in
+// scalar registers but pays one scalar instruction more per list entry (the complement of `done`) and rebuilds the flag in a vector register for
+// every __all() (v_cndmask + v_cmp per trip); scalar instructions come out of the same wave's issue stream as the vector ones (a s_waitcnt does
+// not: scripts/ubench/blend_step.hip MODE 4).  The loop alone: 41.4 -> 38.9 ticks per list entry per SIMD (MODE 2 there,
+// profiles/r06_ubench_blend_step.txt).  Same arithmetic, same decisions: images are bit-identical.  The fence between the two pairs of a trip
+// keeps the second pair's LDS reads behind the first pair's arithmetic: without it the scheduler requests all four entries' records at once --
+// 68 vector registers, seven waves per SIMD instead of eight.
+#ifndef GVF_BLEND_LANE_MASKS
+#define GVF_BLEND_LANE_MASKS 1
+#endif
+#if GVF_BLEND_LANE_MASKS
+#define BL_DONE_INIT(init) unsigned long long done_m = __builtin_amdgcn_ballot_w64(init)      /* all 64 lanes are active: workgroups are whole */
+#define BL_WAVE_DONE() (done_m == ~0ull)
+#define BL_WORKGROUP_DONE() __syncthreads_and(done_m == ~0ull)
+#define BL_STEP_PREDICATES(alpha, test_T)                                                                   \
+            const unsigned long long ok_m = __builtin_amdgcn_ballot_w64(!((alpha) < 1.0f / 255.0f)) & ~done_m;   \
+            const unsigned long long stop_m = ok_m & __builtin_amdgcn_ballot_w64((test_T) < 0.0001f);       \
+            done_m |= stop_m;                                                                               \
+            const bool acc = __builtin_amdgcn_inverse_ballot_w64(ok_m ^ stop_m);
+#define BL_PAIR_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define BL_DONE_INIT(init) bool done = (init)
+#define BL_WAVE_DONE() __all(done)
+#define BL_WORKGROUP_DONE() (__syncthreads_count(done) == BLEND_THREADS)
+#define BL_STEP_PREDICATES(alpha, test_T)                                                                   \
+            const bool ok = !done && !((alpha) < 1.0f / 255.0f);                                            \
+            const bool stop = ok && (test_T) < 0.0001f;                                                     \
+            done = done || stop;                                                                            \
+            const bool acc = ok != stop;           /* = ok && !stop (stop implies ok): a scalar xor of the two lane masks instead of a second compare */
+#define BL_PAIR_FENCE() do { } while (0)
+#endif
+
 // DEPTH: accumulate the depth channel (diff_gauss outputs; one fma per evaluated splat that the mip path does not pay)
 template <bool DEPTH>
 __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
@@ -1722,7 +1756,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
     const uint64_t lt_mask = (1ull << lane) - 1ull;
 
     const float pxr = pxf - (float)(tx * TILE), pyr = pyf - (float)(ty * TILE);      // tile-relative (exact: small integers + the sub-pixel offset)
-    bool done = !inside;
+    BL_DONE_INIT(!inside);
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dacc = 0.f;
 
     BT_DECL
@@ -1732,9 +1766,9 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
     for (int r = 0; r < rounds; ++r, todo -= BLEND_THREADS) {
         BT(6);
 #ifdef BLEND_CONSUMED
-        if (__syncthreads_count(done) == BLEND_THREADS) { rounds_done = r; break; }
+        if (BL_WORKGROUP_DONE()) { rounds_done = r; break; }
 #else
-        if (__syncthreads_count(done) == BLEND_THREADS) break;
+        if (BL_WORKGROUP_DONE()) break;
 #endif
         BT(0);
 #ifdef BLEND_TIMING
@@ -1776,7 +1810,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
         __syncthreads();
         BT(4);
         const int cnt = min(BLEND_THREADS, todo);
-        if (__all(done)) continue;                        // this quadrant is saturated (wave-uniform)
+        if (BL_WAVE_DONE()) continue;                     // this quadrant is saturated (wave-uniform)
         // compact the batch into this wave's list (ascending index = depth order)
         int n_w = 0;
 #pragma unroll
@@ -1803,12 +1837,9 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
             const float2 c = DEPTH ? make_float2(c4_.x, c4_.y) : make_float2(c4_.x, 0.f);              \
             const float nlog = splat_neg_exponent(a.x, a.y, a.z, a.w, b.x, pxr, pyr, b.y);   /* -log2(opacity * G) */ \
             const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(-nlog));                           \
-            const bool ok = !done && !(alpha < 1.0f / 255.0f);                                         \
             const float w_raw = alpha * T;                                                             \
             const float test_T = T - w_raw;        /* = T (1 - alpha) up to one rounding; one op less */ \
-            const bool stop = ok && test_T < 0.0001f;                                                  \
-            done = done || stop;                                                                       \
-            const bool acc = ok != stop;           /* = ok && !stop (stop implies ok): a scalar xor of the two lane masks instead of a second compare */ \
+            BL_STEP_PREDICATES(alpha, test_T)      /* ok = !done && !(alpha < 1/255); stop = ok && test_T < 1e-4; done |= stop; acc = ok && !stop */ \
             const float wgt = acc ? w_raw : 0.0f;                                                      \
             C0 = __builtin_fmaf(b.z, wgt, C0);                                                         \
             C1 = __builtin_fmaf(b.w, wgt, C1);                                                         \
@@ -1818,15 +1849,16 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
         }
         int jj = 0;
         for (; jj + 3 < n_w; jj += 4) {
-            if (__all(done)) break;
+            if (BL_WAVE_DONE()) break;
             const unsigned j0 = sList[wave][jj], j1 = sList[wave][jj + 1], j2 = sList[wave][jj + 2], j3 = sList[wave][jj + 3];
             GVF_BLEND_STEP(j0)
             GVF_BLEND_STEP(j1)
+            BL_PAIR_FENCE();
             GVF_BLEND_STEP(j2)
             GVF_BLEND_STEP(j3)
         }
         for (; jj < n_w; ++jj) {
-            if (__all(done)) break;
+            if (BL_WAVE_DONE()) break;
             const unsigned j0 = sList[wave][jj];
             GVF_BLEND_STEP(j0)
         }

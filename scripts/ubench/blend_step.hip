@@ -5,9 +5,15 @@
 //   MODE 1  the one shape not yet priced: the exponents of 4 splats x 64 pixels from six v_mfma_f32_4x4x1_16b_f32 on the monomials
 //           (x^2, xy, y^2, x, y, 1) -- lane = pixel, the accumulator's four registers = the pixel's four splats --, computed one group AHEAD of
 //           the compositing, which is then 11 vector instructions per entry
+//   MODE 2  today's arithmetic with the step's predicates kept as explicit 64-bit lane masks (ballot / inverse ballot): 6 scalar instructions fewer per
+//           trip of four entries -- what csrc/rast.hip runs since the end of round 6 (GVF_BLEND_LANE_MASKS)
+//   MODE 3  MODE 2 + the 0.99 clamp on v_exp_f32's output modifier (15 vector instructions; not bit-identical): no further gain
+//   MODE 4/5  MODE 2 with the trip's LDS reads first and ONE s_waitcnt (/ the next trip's list words ahead): slower -- a s_waitcnt is not an issue slot
+//   MODE 6  MODE 2 with one exit test per trip written as a select on the trip limit: the compiler turns it back into the two-exit form
 // Prints wave-cycles per list entry per wave and per SIMD (8 waves per SIMD resident).  Bar to build MODE 1 into the kernel: <= 26 per SIMD.
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form blend_step.hip -o blend_step.bin
-// (inner loops as compiled: 16.25 vector instructions per entry for MODE 0 = the product kernel's count, 12.0 + 1.5 MFMA for MODE 1)
+// (inner loops as compiled, per trip of four entries: MODE 0 65 vector + 31 scalar + 13 LDS instructions, MODE 2 65 + 25 + 13, MODE 3 61 + 25 + 13;
+//  MODE 1 12.0 vector + 1.5 MFMA per entry)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
@@ -106,6 +112,78 @@ __global__ __launch_bounds__(256) void k(float* out, long long* cyc, int reps) {
         done = __builtin_amdgcn_inverse_ballot_w64(dm);
         if (done) C0 += 1.0f;
 #undef STEP
+    } else if (MODE == 4 || MODE == 5) {
+        // MODE 4: MODE 2 with the trip's 13 LDS reads issued first and ONE s_waitcnt lgkmcnt(0) (the compiler's ~10 graded waits per trip are
+        //         instructions of the wave's stream too; the other 7 waves of the SIMD cover the exposed latency)
+        // MODE 5: MODE 4 + the list words of the NEXT trip requested before this trip's arithmetic
+        unsigned long long dm = 0ull;
+        const unsigned long long all = __builtin_amdgcn_ballot_w64(true);
+#define LOADS(J, A, B, C) const float4 A = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(sA) + (J));  \
+                          const float4 B = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(sB) + (J));  \
+                          const float C = reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(sC) + (J))->x;
+#define STEP(a, b, cx) {                                                                                                       \
+            const float nlog = neg_exponent(a.x, a.y, a.z, a.w, b.x, pxr, pyr, b.y);                                           \
+            const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(-nlog));                                                   \
+            const unsigned long long okm = __builtin_amdgcn_ballot_w64(!(alpha < 1.0f / 255.0f)) & ~dm;                        \
+            const float w_raw = alpha * T;                                                                                     \
+            const float test_T = T - w_raw;                                                                                    \
+            const unsigned long long stopm = okm & __builtin_amdgcn_ballot_w64(test_T < 0.0001f);                              \
+            dm |= stopm;                                                                                                       \
+            const bool acc = __builtin_amdgcn_inverse_ballot_w64(okm ^ stopm);                                                 \
+            const float wgt = acc ? w_raw : 0.0f;                                                                              \
+            C0 = __builtin_fmaf(b.z, wgt, C0); C1 = __builtin_fmaf(b.w, wgt, C1); C2 = __builtin_fmaf(cx, wgt, C2);            \
+            T = acc ? test_T : T; }
+        for (int r = 0; r < reps; ++r) {
+            uint4 jn = *reinterpret_cast<const uint4*>(&sList[wave][0]);
+            for (int jj = 0; jj < N; jj += 4) {
+                if (dm == all) break;
+                uint4 j;
+                if (MODE == 5) { j = jn; } else { j = *reinterpret_cast<const uint4*>(&sList[wave][jj]); }
+                LOADS(j.x, a0, b0, c0) LOADS(j.y, a1, b1, c1) LOADS(j.z, a2, b2, c2) LOADS(j.w, a3, b3, c3)
+                if (MODE == 5) jn = *reinterpret_cast<const uint4*>(&sList[wave][(jj + 4) & (N - 1)]);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0)
+                __builtin_amdgcn_sched_barrier(0);
+                STEP(a0, b0, c0) STEP(a1, b1, c1) STEP(a2, b2, c2) STEP(a3, b3, c3)
+            }
+            T = T * 0.5f + 0.5f;
+        }
+        done = __builtin_amdgcn_inverse_ballot_w64(dm);
+        if (done) C0 += 1.0f;
+#undef STEP
+#undef LOADS
+    } else if (MODE == 6) {
+        // MODE 6: MODE 2 with ONE exit test per trip: a saturated wave sets the trip limit to 0 (s_cmp_eq_u64 + s_cselect_b32) instead of leaving through a
+        //         second exit, which the compiler folds into the first through two s_cselect_b64, an s_or_b64 and an s_and_b64 with exec
+        //         (an asm goto for the second exit crashes hipcc 7.2's loop canonicalisation)
+        unsigned long long dm = 0ull;
+#define STEP(J) {                                                                                                              \
+            const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(sA) + (J));               \
+            const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(sB) + (J));               \
+            const float4 c = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(sC) + (J));               \
+            const float nlog = neg_exponent(a.x, a.y, a.z, a.w, b.x, pxr, pyr, b.y);                                           \
+            const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(-nlog));                                                   \
+            const unsigned long long okm = __builtin_amdgcn_ballot_w64(!(alpha < 1.0f / 255.0f)) & ~dm;                        \
+            const float w_raw = alpha * T;                                                                                     \
+            const float test_T = T - w_raw;                                                                                    \
+            const unsigned long long stopm = okm & __builtin_amdgcn_ballot_w64(test_T < 0.0001f);                              \
+            dm |= stopm;                                                                                                       \
+            const bool acc = __builtin_amdgcn_inverse_ballot_w64(okm ^ stopm);                                                 \
+            const float wgt = acc ? w_raw : 0.0f;                                                                              \
+            C0 = __builtin_fmaf(b.z, wgt, C0); C1 = __builtin_fmaf(b.w, wgt, C1); C2 = __builtin_fmaf(c.x, wgt, C2);           \
+            T = acc ? test_T : T; }
+        for (int r = 0; r < reps; ++r) {
+            int end = N;
+            for (int jj = 0; jj < end; jj += 4) {
+                const unsigned j0 = sList[wave][jj], j1 = sList[wave][jj + 1], j2 = sList[wave][jj + 2], j3 = sList[wave][jj + 3];
+                STEP(j0) STEP(j1) STEP(j2) STEP(j3)
+                end = dm == ~0ull ? 0 : end;
+            }
+            T = T * 0.5f + 0.5f;
+        }
+        done = __builtin_amdgcn_inverse_ballot_w64(dm);
+        if (done) C0 += 1.0f;
+#undef STEP
     } else {
         const float m[6] = {pxr * pxr, pxr * pyr, pyr * pyr, pxr, pyr, 1.0f};
         auto exps = [&](int jj) -> f4 {           // the four exponents of the group at jj for this lane's pixel
@@ -187,5 +265,13 @@ int main() {
     run<0>("today's step (third)");
     run<2>("lane masks (again)");
     run<3>("lane masks + clamp modifier (again)");
+    run<4>("lane masks, loads first, one s_waitcnt per trip");
+    run<5>("... + next trip's list words ahead");
+    run<2>("lane masks (third)");
+    run<4>("one s_waitcnt per trip (again)");
+    run<5>("... + list ahead (again)");
+    run<6>("lane masks + opaque saturation exit");
+    run<2>("lane masks (fourth)");
+    run<6>("lane masks + opaque saturation exit (again)");
     return 0;
 }
