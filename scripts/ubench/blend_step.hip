@@ -9,7 +9,9 @@
 //           trip of four entries -- what csrc/rast.hip runs since the end of round 6 (GVF_BLEND_LANE_MASKS)
 //   MODE 3  MODE 2 + the 0.99 clamp on v_exp_f32's output modifier (15 vector instructions; not bit-identical): no further gain
 //   MODE 4/5  MODE 2 with the trip's LDS reads first and ONE s_waitcnt (/ the next trip's list words ahead): slower -- a s_waitcnt is not an issue slot
-//   MODE 6  MODE 2 with one exit test per trip written as a select on the trip limit: the compiler turns it back into the two-exit form
+//   MODE 6  MODE 2 with the trip's two exits kept apart by a non-speculatable asm statement: the structuriser rebuilds the same 9-10 scalar instructions
+//   MODE 7  no done mask: a stopped pixel keeps its transmittance with the sign flipped
+//   MODE 8  MODE 2 with upstream's test_T = T * (1 - alpha): one vector instruction off the pixel's serial chain
 // Prints wave-cycles per list entry per wave and per SIMD (8 waves per SIMD resident).  Bar to build MODE 1 into the kernel: <= 26 per SIMD.
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form blend_step.hip -o blend_step.bin
 // (inner loops as compiled, per trip of four entries: MODE 0 65 vector + 31 scalar + 13 LDS instructions, MODE 2 65 + 25 + 13, MODE 3 61 + 25 + 13;
@@ -153,9 +155,9 @@ __global__ __launch_bounds__(256) void k(float* out, long long* cyc, int reps) {
 #undef STEP
 #undef LOADS
     } else if (MODE == 6) {
-        // MODE 6: MODE 2 with ONE exit test per trip: a saturated wave sets the trip limit to 0 (s_cmp_eq_u64 + s_cselect_b32) instead of leaving through a
-        //         second exit, which the compiler folds into the first through two s_cselect_b64, an s_or_b64 and an s_and_b64 with exec
-        //         (an asm goto for the second exit crashes hipcc 7.2's loop canonicalisation)
+        // MODE 6: MODE 2 with the saturation exit at the END of the trip, kept apart from the loop condition by a non-speculatable asm statement (the
+        //         compiler otherwise folds the two exits into one branch through two s_cselect_b64, an s_or_b64 and an s_and_b64 with exec; a select
+        //         on the trip limit is folded back into that form; an asm goto crashes hipcc 7.2's loop canonicalisation)
         unsigned long long dm = 0ull;
 #define STEP(J) {                                                                                                              \
             const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(sA) + (J));               \
@@ -173,11 +175,71 @@ __global__ __launch_bounds__(256) void k(float* out, long long* cyc, int reps) {
             C0 = __builtin_fmaf(b.z, wgt, C0); C1 = __builtin_fmaf(b.w, wgt, C1); C2 = __builtin_fmaf(c.x, wgt, C2);           \
             T = acc ? test_T : T; }
         for (int r = 0; r < reps; ++r) {
-            int end = N;
-            for (int jj = 0; jj < end; jj += 4) {
+            for (int jj = 0; jj < N; jj += 4) {
                 const unsigned j0 = sList[wave][jj], j1 = sList[wave][jj + 1], j2 = sList[wave][jj + 2], j3 = sList[wave][jj + 3];
                 STEP(j0) STEP(j1) STEP(j2) STEP(j3)
-                end = dm == ~0ull ? 0 : end;
+                if (dm == ~0ull) break;
+                asm volatile("" ::: "memory");          // not speculatable: the two exits stay two scalar compare-and-branch pairs
+            }
+            T = T * 0.5f + 0.5f;
+        }
+        done = __builtin_amdgcn_inverse_ballot_w64(dm);
+        if (done) C0 += 1.0f;
+#undef STEP
+    } else if (MODE == 7) {
+        // MODE 7: no `done` mask at all: a pixel that stops keeps its transmittance with the SIGN flipped (T < 0 = done; |T| = the final value).  A done
+        //         pixel's test_T = T (1 - alpha) is negative, i.e. "stops" again and never accumulates; per entry two scalar instructions (acc = c1 & ~c2,
+        //         stop = c1 & c2) instead of four, one v_cndmask (with neg / abs modifiers) more; the trip's exit test is ballot(T < 0)
+#define STEP(J) {                                                                                                              \
+            const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(sA) + (J));               \
+            const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(sB) + (J));               \
+            const float4 c = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(sC) + (J));               \
+            const float nlog = neg_exponent(a.x, a.y, a.z, a.w, b.x, pxr, pyr, b.y);                                           \
+            const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(-nlog));                                                   \
+            const unsigned long long c1m = __builtin_amdgcn_ballot_w64(!(alpha < 1.0f / 255.0f));                              \
+            const float w_raw = alpha * T;                                                                                     \
+            const float test_T = T - w_raw;                                                                                    \
+            const unsigned long long c2m = __builtin_amdgcn_ballot_w64(test_T < 0.0001f);                                      \
+            const bool acc = __builtin_amdgcn_inverse_ballot_w64(c1m & ~c2m);                                                  \
+            const float wgt = acc ? w_raw : 0.0f;                                                                              \
+            C0 = __builtin_fmaf(b.z, wgt, C0); C1 = __builtin_fmaf(b.w, wgt, C1); C2 = __builtin_fmaf(c.x, wgt, C2);           \
+            const float T1 = acc ? test_T : T;                                                                                 \
+            T = __builtin_amdgcn_inverse_ballot_w64(c1m & c2m) ? -__builtin_fabsf(T1) : T1; }
+        for (int r = 0; r < reps; ++r) {
+            for (int jj = 0; jj < N; jj += 4) {
+                if (__builtin_amdgcn_ballot_w64(T < 0.0f) == ~0ull) break;
+                const unsigned j0 = sList[wave][jj], j1 = sList[wave][jj + 1], j2 = sList[wave][jj + 2], j3 = sList[wave][jj + 3];
+                STEP(j0) STEP(j1) STEP(j2) STEP(j3)
+            }
+            T = T * 0.5f + 0.5f;
+        }
+        T = __builtin_fabsf(T);
+#undef STEP
+    } else if (MODE == 8) {
+        // MODE 8: MODE 2 with upstream's test_T = T * (1 - alpha): (1 - alpha) is off the pixel's serial chain, the chain T -> test_T -> compare -> masks -> T
+        //         is one vector instruction shorter (NOT the product's rounding: the product and its oracle use T - alpha T)
+        unsigned long long dm = 0ull;
+#define STEP(J) {                                                                                                              \
+            const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(sA) + (J));               \
+            const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(sB) + (J));               \
+            const float4 c = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(sC) + (J));               \
+            const float nlog = neg_exponent(a.x, a.y, a.z, a.w, b.x, pxr, pyr, b.y);                                           \
+            const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(-nlog));                                                   \
+            const float om = 1.0f - alpha;                                                                                     \
+            const unsigned long long okm = __builtin_amdgcn_ballot_w64(!(alpha < 1.0f / 255.0f)) & ~dm;                        \
+            const float test_T = T * om;                                                                                       \
+            const float w_raw = alpha * T;                                                                                     \
+            const unsigned long long stopm = okm & __builtin_amdgcn_ballot_w64(test_T < 0.0001f);                              \
+            dm |= stopm;                                                                                                       \
+            const bool acc = __builtin_amdgcn_inverse_ballot_w64(okm ^ stopm);                                                 \
+            const float wgt = acc ? w_raw : 0.0f;                                                                              \
+            C0 = __builtin_fmaf(b.z, wgt, C0); C1 = __builtin_fmaf(b.w, wgt, C1); C2 = __builtin_fmaf(c.x, wgt, C2);           \
+            T = acc ? test_T : T; }
+        for (int r = 0; r < reps; ++r) {
+            for (int jj = 0; jj < N; jj += 4) {
+                if (dm == ~0ull) break;
+                const unsigned j0 = sList[wave][jj], j1 = sList[wave][jj + 1], j2 = sList[wave][jj + 2], j3 = sList[wave][jj + 3];
+                STEP(j0) STEP(j1) STEP(j2) STEP(j3)
             }
             T = T * 0.5f + 0.5f;
         }
@@ -270,8 +332,13 @@ int main() {
     run<2>("lane masks (third)");
     run<4>("one s_waitcnt per trip (again)");
     run<5>("... + list ahead (again)");
-    run<6>("lane masks + opaque saturation exit");
+    run<6>("lane masks, exits kept apart by an asm statement");
+    run<7>("done = sign of T (2 scalar + 17 vector per entry)");
     run<2>("lane masks (fourth)");
-    run<6>("lane masks + opaque saturation exit (again)");
+    run<6>("exits kept apart (again)");
+    run<7>("done = sign of T (again)");
+    run<8>("lane masks, test_T = T * (1 - alpha)");
+    run<2>("lane masks (fifth)");
+    run<8>("test_T = T * (1 - alpha) (again)");
     return 0;
 }
