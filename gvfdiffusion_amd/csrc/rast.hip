@@ -1696,6 +1696,9 @@ extern "C" int gvf_debug_blend_consumed(unsigned long long* out12, int reset) {
 #ifndef GVF_BLEND_LANE_MASKS
 #define GVF_BLEND_LANE_MASKS 1
 #endif
+#ifndef GVF_BLEND_FIRST_ROUND_REDUCE       // 1: the workgroup-wide "every pixel saturated?" reduction runs before the first round too (the form up to round 6; A/B variant)
+#define GVF_BLEND_FIRST_ROUND_REDUCE 0
+#endif
 #if GVF_BLEND_LANE_MASKS
 #define BL_DONE_INIT(init) unsigned long long done_m = __builtin_amdgcn_ballot_w64(init)      /* all 64 lanes are active: workgroups are whole */
 #define BL_WAVE_DONE() (done_m == ~0ull)
@@ -1765,10 +1768,12 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_kernel(
 #endif
     for (int r = 0; r < rounds; ++r, todo -= BLEND_THREADS) {
         BT(6);
+        // (r > 0: before the first round no pixel inside the image is saturated and nothing in LDS has to be protected from a previous round;
+        //  the reduction's LDS round trip and barriers are ~1 % of a wave's life at 1.17 rounds per tile)
 #ifdef BLEND_CONSUMED
-        if (BL_WORKGROUP_DONE()) { rounds_done = r; break; }
+        if ((GVF_BLEND_FIRST_ROUND_REDUCE || r > 0) && BL_WORKGROUP_DONE()) { rounds_done = r; break; }
 #else
-        if (BL_WORKGROUP_DONE()) break;
+        if ((GVF_BLEND_FIRST_ROUND_REDUCE || r > 0) && BL_WORKGROUP_DONE()) break;
 #endif
         BT(0);
 #ifdef BLEND_TIMING
