@@ -11,6 +11,7 @@
 //   MODE 4/5  MODE 2 with the trip's LDS reads first and ONE s_waitcnt (/ the next trip's list words ahead): slower -- a s_waitcnt is not an issue slot
 //   MODE 6  MODE 2 with the trip's two exits kept apart by a non-speculatable asm statement: the structuriser rebuilds the same 9-10 scalar instructions
 //   MODE 7  no done mask: a stopped pixel keeps its transmittance with the sign flipped
+//   MODE 9  MODE 2 with eight entries per trip (half the loop control per entry)
 //   MODE 8  MODE 2 with upstream's test_T = T * (1 - alpha): one vector instruction off the pixel's serial chain
 // Prints wave-cycles per list entry per wave and per SIMD (8 waves per SIMD resident).  Bar to build MODE 1 into the kernel: <= 26 per SIMD.
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form blend_step.hip -o blend_step.bin
@@ -246,6 +247,41 @@ __global__ __launch_bounds__(256) void k(float* out, long long* cyc, int reps) {
         done = __builtin_amdgcn_inverse_ballot_w64(dm);
         if (done) C0 += 1.0f;
 #undef STEP
+    } else if (MODE == 9) {
+        // MODE 9: MODE 2 with EIGHT entries per trip (a fence between the pairs as in the product): the trip's ~10 scalar instructions of loop control per 8 entries
+        unsigned long long dm = 0ull;
+#define STEP(J) {                                                                                                              \
+            const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(sA) + (J));               \
+            const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(sB) + (J));               \
+            const float4 c = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(sC) + (J));               \
+            const float nlog = neg_exponent(a.x, a.y, a.z, a.w, b.x, pxr, pyr, b.y);                                           \
+            const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(-nlog));                                                   \
+            const unsigned long long okm = __builtin_amdgcn_ballot_w64(!(alpha < 1.0f / 255.0f)) & ~dm;                        \
+            const float w_raw = alpha * T;                                                                                     \
+            const float test_T = T - w_raw;                                                                                    \
+            const unsigned long long stopm = okm & __builtin_amdgcn_ballot_w64(test_T < 0.0001f);                              \
+            dm |= stopm;                                                                                                       \
+            const bool acc = __builtin_amdgcn_inverse_ballot_w64(okm ^ stopm);                                                 \
+            const float wgt = acc ? w_raw : 0.0f;                                                                              \
+            C0 = __builtin_fmaf(b.z, wgt, C0); C1 = __builtin_fmaf(b.w, wgt, C1); C2 = __builtin_fmaf(c.x, wgt, C2);           \
+            T = acc ? test_T : T; }
+        for (int r = 0; r < reps; ++r) {
+            for (int jj = 0; jj < N; jj += 8) {
+                if (dm == ~0ull) break;
+                const uint4 ja = *reinterpret_cast<const uint4*>(&sList[wave][jj]), jb = *reinterpret_cast<const uint4*>(&sList[wave][jj + 4]);
+                STEP(ja.x) STEP(ja.y)
+                __builtin_amdgcn_sched_barrier(0);
+                STEP(ja.z) STEP(ja.w)
+                __builtin_amdgcn_sched_barrier(0);
+                STEP(jb.x) STEP(jb.y)
+                __builtin_amdgcn_sched_barrier(0);
+                STEP(jb.z) STEP(jb.w)
+            }
+            T = T * 0.5f + 0.5f;
+        }
+        done = __builtin_amdgcn_inverse_ballot_w64(dm);
+        if (done) C0 += 1.0f;
+#undef STEP
     } else {
         const float m[6] = {pxr * pxr, pxr * pyr, pyr * pyr, pxr, pyr, 1.0f};
         auto exps = [&](int jj) -> f4 {           // the four exponents of the group at jj for this lane's pixel
@@ -340,5 +376,8 @@ int main() {
     run<8>("lane masks, test_T = T * (1 - alpha)");
     run<2>("lane masks (fifth)");
     run<8>("test_T = T * (1 - alpha) (again)");
+    run<9>("lane masks, eight entries per trip");
+    run<2>("lane masks (sixth)");
+    run<9>("eight entries per trip (again)");
     return 0;
 }
