@@ -17,7 +17,7 @@
 //                                        per touched tile
 //   seg_sums, seg_scan, frame_counts     exclusive scan of the counters = tile ranges + cursors, per-frame D, overflow guard
 //   bin<scatter> grid (ceil(P/1024), F)  (depth_bits << 32 | id) into the tile segments (order inside a segment arbitrary)
-//   classify + tile_sort                 per-tile bitonic sort: registers+shuffles for segments <= 2048, LDS <= 16384,
+//   classify + tile_sort                 per-tile sort: registers+shuffles / static LDS for segments <= 1536 (SORT_SMALL_N), LDS <= 16384,
 //                                        in-place global beyond; writes ordered ids (= upstream's stable (tile, depth) order)
 //   blend        grid (tiles, F)         16x16 px per workgroup, 4 waves = the four 8x8 quadrants
 // RADIX binning (kept for comparison): preprocess (+block sums) -> scan_sums -> duplicate ((frame*tiles + tile) << 32 |
@@ -807,7 +807,16 @@ __device__ __forceinline__ float float_unordered(uint32_t o) {
 // launches: block sums of 4096 counters, then every block adds up the sums in front of it (at most a few hundred
 // values) and rescans its own chunk.  Writes segment ranges + cursors, per-frame D, the grand total.
 constexpr int SCAN_CHUNK = 4096;
-constexpr int SORT_SMALL_N = 2048;     // size classes of the per-tile sort (R4, below)
+// Size classes of the per-tile sort (R4, below).  SORT_SMALL_N: segments of up to this many keys are sorted in static LDS by tile_sort_kernel<0>, one
+// workgroup of 256 threads each.  1536 since the end of round 6 (2048 before): 12 bytes of LDS per key = 18.4 KiB = EIGHT workgroups per CU instead
+// of six -- the launch lives on how many segments are in flight (its waves are parked 75 % of the time) --; the few segments of 1537-2048 keys join
+// the 512-thread LDS class.  Tile sort 0.137 -> 0.119 ms at the bench shape, the live render job -4 % (profiles/r06_tile_sort_classes.txt; sorting
+// the segments of up to 256-512 keys four to a workgroup, one WAVE each, was built and measured on top of it: -3 % of the launch at best, not kept).
+#ifndef GVF_SORT_SMALL_N
+#define GVF_SORT_SMALL_N 1536
+#endif
+constexpr int SORT_SMALL_N = GVF_SORT_SMALL_N;
+static_assert(SORT_SMALL_N == 1536 || SORT_SMALL_N == 2048, "register class of the per-tile sort: 6 or 8 keys per thread");
 constexpr int SORT_LARGE_N = 16384;
 constexpr int SORT_LARGE_BLOCKS = 256, SORT_HUGE_BLOCKS = 64;   // grid of the launch that walks the two rare classes
 #ifndef SORT_LIST_BIT
@@ -1169,7 +1178,7 @@ __device__ __forceinline__ void bitonic_sort_asc(Ptr keys, int n, int tid, int n
     }
 }
 
-// Small segments (<= 2048 keys, i.e. practically every tile): E = npad / 256 keys per thread live in REGISTERS
+// Small segments (<= SORT_SMALL_N keys, i.e. practically every tile): E = npad / 256 keys per thread live in REGISTERS
 // (key index e = tid * E + r).  Same all-ascending network as above: every step pairs e with e ^ m (m = k - 1 for the
 // mirrored first step of a merge, m = j for the half-cleaners), the lower index keeps the minimum.  Partners are in
 // the same thread (m < E), the same wave (one 64-bit lane exchange, no LDS, no barrier) or another wave (LDS round
@@ -1271,7 +1280,7 @@ __device__ __forceinline__ void tile_sort_regs(const uint64_t* __restrict__ k, c
 // the counting quadratic: the workgroup then returns false and its segment goes through the network (exact for any input).
 constexpr int BKT_MAX_RUN = 40;
 constexpr int BKT_AUX = 64;            // per wave: minimum, maximum, total, longest run (4 x up to 16 waves)
-constexpr int BKT_LARGE_NB = 4096;     // buckets of the 1024-thread class (2049 .. 16384 keys: 0.5 .. 4 keys per bucket)
+constexpr int BKT_LARGE_NB = 4096;     // buckets of the 512- / 1024-thread classes (SORT_SMALL_N + 1 .. 16384 keys: 0.4 .. 4 keys per bucket)
 
 #ifdef SORT_STATS
 __device__ unsigned long long g_sort_stats[16];
@@ -1422,8 +1431,8 @@ __global__ __launch_bounds__(MODE == 3 ? 512 : 1024, MODE == 3 ? 2 : 1) void til
             else if (n <= 768) done = tile_sort_buckets<3, 256, 3>(k, v, o, n, s_small, s_hist);
             else if (n <= 1024) done = tile_sort_buckets<4, 256, 4>(k, v, o, n, s_small, s_hist);
             else if (n <= 1280) done = tile_sort_buckets<5, 256, 5>(k, v, o, n, s_small, s_hist);
-            else if (n <= 1536) done = tile_sort_buckets<6, 256, 6>(k, v, o, n, s_small, s_hist);
-            else done = tile_sort_buckets<8, 256, 8>(k, v, o, n, s_small, s_hist);
+            else if (n <= 1536 || SORT_SMALL_N == 1536) done = tile_sort_buckets<6, 256, 6>(k, v, o, n, s_small, s_hist);
+            else done = tile_sort_buckets<SORT_SMALL_N / 256, 256, SORT_SMALL_N / 256>(k, v, o, n, s_small, s_hist);
             if (done) return;
             __syncthreads();
         }
@@ -1433,7 +1442,7 @@ __global__ __launch_bounds__(MODE == 3 ? 512 : 1024, MODE == 3 ? 2 : 1) void til
         else if (n <= 512) tile_sort_regs<2, 512>(k, v, o, n, s_small);
         else if (n <= 1024) tile_sort_regs<4, 1024>(k, v, o, n, s_small);
         else {
-            // 1024 < n <= 2048.  One 2048-key network would cost 66 rounds x 8 keys per thread even for 1025 keys (and
+            // 1024 < n <= SORT_SMALL_N.  One 2048-key network would cost 66 rounds x 8 keys per thread even for 1025 keys (and
             // dense tiles sit just above 1024: 61 % of all keys at the bench shape are in segments of 1025-1280).
             // Instead: sort the first 1024 keys and the remaining n - 1024 as two runs (55 rounds x 4 keys + a small
             // network), then merge by rank -- keys are unique (they end in the Gaussian id), so an element's final
@@ -1444,7 +1453,7 @@ __global__ __launch_bounds__(MODE == 3 ? 512 : 1024, MODE == 3 ? 2 : 1) void til
             if (nb <= 64) tile_sort_regs<1, 64, true>(k + 1024, vb, o, nb, s_small + 1024);
             else if (nb <= 128) tile_sort_regs<1, 128, true>(k + 1024, vb, o, nb, s_small + 1024);
             else if (nb <= 256) tile_sort_regs<1, 256, true>(k + 1024, vb, o, nb, s_small + 1024);
-            else if (nb <= 512) tile_sort_regs<2, 512, true>(k + 1024, vb, o, nb, s_small + 1024);
+            else if (nb <= 512 || SORT_SMALL_N == 1536) tile_sort_regs<2, 512, true>(k + 1024, vb, o, nb, s_small + 1024);
             else tile_sort_regs<4, 1024, true>(k + 1024, vb, o, nb, s_small + 1024);
             __syncthreads();
             for (int e = threadIdx.x; e < n; e += 256) {

@@ -305,7 +305,7 @@ _LAST_CARVE = {}     # (device index, stream handle) -> the workspace TENSOR + a
 
 
 def sort_class_counts(device=None):
-    """(segments with 2049 .. 16384 keys, segments with more) of the LAST rasterize_batched() call on the current stream: how many
+    """(segments with 1537 .. 16384 keys, segments with more) of the LAST rasterize_batched() call on the current stream: how many
     (frame, tile) segments went through the per-tile sort's LDS launches / its in-place HBM class (gvf_rast_sort_class_counts; a test
     diagnostic -- it waits for the stream)."""
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)

@@ -219,7 +219,7 @@ int gvf_rast_profile_read(float* ms_sum /*[GVF_RAST_NSTAGES]*/, int* calls);
 int64_t gvf_rast_shared_activation_calls(void);
 
 /* Diagnostic of the per-tile sort (R4): how many (frame, tile) segments of the LAST gvf_rast_forward*() call on this workspace fell into the
- * size classes above the one-workgroup register sort -- counts[0]: 2049 .. 16384 keys (the two LDS launches), counts[1]: more than 16384
+ * size classes above the one-workgroup register sort -- counts[0]: 1537 .. 16384 keys (the two LDS launches; 2049 .. up to round 6), counts[1]: more than 16384
  * (sorted in place in HBM).  Takes the arguments the forward call carved its workspace with; waits for `stream` and copies two words to the
  * host (tests use it to assert that a scene really entered those launches; not on any hot path). */
 int gvf_rast_sort_class_counts(const void* workspace, size_t workspace_bytes, int P, int F, int H, int W, int64_t max_rendered,
