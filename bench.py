@@ -907,13 +907,15 @@ def main():
                          "valu_issue": valu_issue,
                          # The bound that actually binds this launch: the compositing loop is 16 vector instructions per list
                          # entry of which one is a v_exp_f32; on the `valu_issue` scale (SQ_ACTIVE_INST_VALU x 2 cycles / busy cycles) that mix
-                         # tops out at ~0.69 (profiles/r05_blend_phase_stamps.txt); `achieved` = the counter figure of the committed SQ pass.
+                         # topped out at ~0.69 with the loop of rounds 5-6 (profiles/r05_blend_phase_stamps.txt) and at ~0.73 with the lane-mask form of
+                         # its predicates (the loop-only figure 41.4 -> 38.9 ticks per entry per SIMD, same 16 vector instructions:
+                         # profiles/r06_ubench_blend_step.txt); `achieved` = the counter figure of the committed SQ pass.
                          # The one restructuring not priced before round 6 -- exponents from six v_mfma_f32_4x4x1 per 4 splats, 11 vector
                          # instructions per entry -- is 8 % SLOWER in a loop-only micro-benchmark (profiles/r06_ubench_blend_step.txt), so the
                          # kernel stays and this is its roofline; the HBM figure above is what north_star asked to see.
                          "binding_bound": None if not valu_issue else {
-                             "bound": "valu", "unit": "fraction of VALU issue cycles", "achieved": valu_issue.get("valu_issue"), "peak": 0.69,
-                             "frac": round(valu_issue.get("valu_issue", 0.0) / 0.69, 4),
+                             "bound": "valu", "unit": "fraction of VALU issue cycles", "achieved": valu_issue.get("valu_issue"), "peak": 0.73,
+                             "frac": round(valu_issue.get("valu_issue", 0.0) / 0.73, 4),
                              "source": valu_issue.get("source")},
                          # BASELINE's north star prices "tile-sort + blend" together: the per-tile sort moves 8 B in + 4 B out per binned
                          # instance (PMC: 0.25 GB per launch = exactly that), priced like the blend on upstream's instance count
